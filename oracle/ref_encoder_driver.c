@@ -1,0 +1,166 @@
+/* oracle/ref_encoder_driver.c - TEST INFRASTRUCTURE, not product code.
+
+   Headless driver of the REAL reference encoder through its public API only
+   (include/daala/daalaenc.h:75-139), the same call sequence as
+   examples/encoder_example.c:974-1099 minus the Ogg container (libogg is not
+   part of the codec arithmetic and is not installed here).  Used for the
+   end-to-end CPU baseline (seconds per 1080p all-intra frame, packets) and for
+   counting the transform blocks the reference evaluates per frame.
+
+   Linked into oracle/_ref/libdaalaref.so together with the unmodified
+   reference sources; see oracle/Makefile. */
+#include <stdlib.h>
+#include <string.h>
+#include "daala/codec.h"
+#include "daala/daalaenc.h"
+#include "state.h"
+
+#define REF_EXPORT __attribute__((visibility("default")))
+
+/* Call counters wrapped around the reference's C function-pointer tables so
+   that "evaluated transform blocks" is measured, not assumed.  Installed by
+   ref_encode_yuv420 after daala_encode_create (the vtbl lives in od_state,
+   src/state.h:112-131; daala_enc_ctx starts with its od_state,
+   src/encint.h). */
+static long ref_fdct_calls[OD_NBSIZES];
+static long ref_idct_calls[OD_NBSIZES];
+static od_dct_func_2d ref_fdct_real[OD_NBSIZES];
+static od_dct_func_2d ref_idct_real[OD_NBSIZES];
+
+#define REF_COUNTED(dir, bs) \
+  static void ref_##dir##_counted_##bs(od_coeff *out, int out_stride, \
+   const od_coeff *in, int in_stride) { \
+    ref_##dir##_calls[bs]++; \
+    (*ref_##dir##_real[bs])(out, out_stride, in, in_stride); \
+  }
+REF_COUNTED(fdct, 0)
+REF_COUNTED(fdct, 1)
+REF_COUNTED(fdct, 2)
+REF_COUNTED(fdct, 3)
+REF_COUNTED(fdct, 4)
+REF_COUNTED(idct, 0)
+REF_COUNTED(idct, 1)
+REF_COUNTED(idct, 2)
+REF_COUNTED(idct, 3)
+REF_COUNTED(idct, 4)
+
+static const od_dct_func_2d REF_FDCT_COUNTED[OD_NBSIZES] = {
+  ref_fdct_counted_0, ref_fdct_counted_1, ref_fdct_counted_2,
+  ref_fdct_counted_3, ref_fdct_counted_4
+};
+static const od_dct_func_2d REF_IDCT_COUNTED[OD_NBSIZES] = {
+  ref_idct_counted_0, ref_idct_counted_1, ref_idct_counted_2,
+  ref_idct_counted_3, ref_idct_counted_4
+};
+
+REF_EXPORT void ref_get_dct_call_counts(long *fdct, long *idct) {
+  int i;
+  for (i = 0; i < OD_NBSIZES; i++) {
+    fdct[i] = ref_fdct_calls[i];
+    idct[i] = ref_idct_calls[i];
+  }
+}
+
+/* Encodes nframes planar 4:2:0 8-bit frames (Y, Cb, Cr contiguous per frame,
+   tightly packed) as all-intra (keyframe_rate = 1).  Packets are appended to
+   out[]; pkt_bytes[i] receives the size of data packet i.  Returns the number
+   of data packets, or a negative OD_E* code. */
+REF_EXPORT int ref_encode_yuv420(const unsigned char *frames, int w, int h,
+ int nframes, int quality, int complexity, int count_calls,
+ unsigned char *out, long out_cap, long *pkt_bytes) {
+  daala_info di;
+  daala_comment dc;
+  daala_enc_ctx *enc;
+  daala_packet dp;
+  daala_image img;
+  long out_pos;
+  long frame_bytes;
+  int npackets;
+  int f;
+  int i;
+  int ret;
+  daala_info_init(&di);
+  di.pic_width = w;
+  di.pic_height = h;
+  di.bitdepth_mode = OD_BITDEPTH_MODE_8;
+  di.timebase_numerator = 30;
+  di.timebase_denominator = 1;
+  di.frame_duration = 1;
+  di.pixel_aspect_numerator = 1;
+  di.pixel_aspect_denominator = 1;
+  di.full_precision_references = 0;
+  di.nplanes = 3;
+  di.plane_info[0].xdec = 0;
+  di.plane_info[0].ydec = 0;
+  di.plane_info[1].xdec = 1;
+  di.plane_info[1].ydec = 1;
+  di.plane_info[2].xdec = 1;
+  di.plane_info[2].ydec = 1;
+  di.keyframe_rate = 1;
+  enc = daala_encode_create(&di);
+  if (enc == NULL) return -1;
+  daala_comment_init(&dc);
+  daala_encode_ctl(enc, OD_SET_QUANT, &quality, sizeof(quality));
+  daala_encode_ctl(enc, OD_SET_COMPLEXITY, &complexity, sizeof(complexity));
+  if (count_calls) {
+    od_state *state;
+    state = (od_state *)enc;
+    for (i = 0; i < OD_NBSIZES; i++) {
+      ref_fdct_calls[i] = ref_idct_calls[i] = 0;
+      ref_fdct_real[i] = state->opt_vtbl.fdct_2d[i];
+      ref_idct_real[i] = state->opt_vtbl.idct_2d[i];
+      state->opt_vtbl.fdct_2d[i] = REF_FDCT_COUNTED[i];
+      state->opt_vtbl.idct_2d[i] = REF_IDCT_COUNTED[i];
+    }
+  }
+  for (;;) {
+    ret = daala_encode_flush_header(enc, &dc, &dp);
+    if (ret < 0) return ret;
+    if (ret == 0) break;
+  }
+  memset(&img, 0, sizeof(img));
+  img.nplanes = 3;
+  img.width = w;
+  img.height = h;
+  frame_bytes = (long)w*h + 2L*((w + 1) >> 1)*((h + 1) >> 1);
+  out_pos = 0;
+  npackets = 0;
+  for (f = 0; f <= nframes; f++) {
+    int last;
+    last = f == nframes;
+    while (daala_encode_packet_out(enc, last, &dp)) {
+      if (out_pos + dp.bytes > out_cap) return -2;
+      memcpy(out + out_pos, dp.packet, dp.bytes);
+      out_pos += dp.bytes;
+      pkt_bytes[npackets++] = dp.bytes;
+    }
+    if (!last) {
+      unsigned char *base;
+      base = (unsigned char *)frames + f*frame_bytes;
+      img.planes[0].data = base;
+      img.planes[0].xdec = 0;
+      img.planes[0].ydec = 0;
+      img.planes[0].xstride = 1;
+      img.planes[0].ystride = w;
+      img.planes[0].bitdepth = 8;
+      img.planes[1].data = base + (long)w*h;
+      img.planes[1].xdec = 1;
+      img.planes[1].ydec = 1;
+      img.planes[1].xstride = 1;
+      img.planes[1].ystride = (w + 1) >> 1;
+      img.planes[1].bitdepth = 8;
+      img.planes[2].data = img.planes[1].data
+       + (long)((w + 1) >> 1)*((h + 1) >> 1);
+      img.planes[2].xdec = 1;
+      img.planes[2].ydec = 1;
+      img.planes[2].xstride = 1;
+      img.planes[2].ystride = (w + 1) >> 1;
+      img.planes[2].bitdepth = 8;
+      ret = daala_encode_img_in(enc, &img, 0);
+      if (ret < 0) return ret;
+    }
+  }
+  daala_comment_clear(&dc);
+  daala_encode_free(enc);
+  return npackets;
+}
