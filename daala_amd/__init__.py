@@ -1,0 +1,14 @@
+"""daala_amd - MI355X-native block-transform hot path of the Daala encoder.
+
+The product is the C-ABI shared library daala_amd/lib/libdaalahip.so
+(include/daala_hip.h).  This package is only the thin host-side mirror used by
+tests, bench.py and the frame-sharded driver: it loads the library with ctypes
+and passes torch device pointers / streams to it.  PyTorch is plumbing here
+(device memory, streams, torch.distributed), not the compute path.
+
+There is NO CPU fallback: importing `daala_amd.api` raises if the HIP library
+has not been built, and every call raises if the library reports an error.
+"""
+from .api import (DaalaHipError, lib, lib_path, init, fdct2d_batch, idct2d_batch,  # noqa: F401
+                  fdct2d_plane, idct2d_plane, forward_pyramid, inverse_level,
+                  pvq_search_batch, host)

@@ -1,0 +1,192 @@
+"""ctypes binding of libdaalahip.so + torch-tensor convenience wrappers.
+
+Names and argument meaning mirror the C ABI (include/daala_hip.h), which in
+turn mirrors the reference's surfaces for this path (od_dct_func_2d,
+od_*filter*_split / _frame_sbs, pvq_search_rdo_double).
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+class DaalaHipError(RuntimeError):
+    pass
+
+
+def lib_path():
+    return os.path.join(_HERE, "lib", "libdaalahip.so")
+
+
+def lib():
+    """The loaded C-ABI library.  Fails loudly when it is missing."""
+    global _LIB
+    if _LIB is None:
+        path = lib_path()
+        if not os.path.exists(path):
+            raise DaalaHipError(
+                "%s not built: run `python -m daala_amd.build` "
+                "(there is no CPU fallback)" % path)
+        L = ctypes.CDLL(path)
+        L.odhip_version.restype = ctypes.c_char_p
+        L.od_pvq_search_rdo_double_hip.restype = ctypes.c_double
+        _LIB = L
+    return _LIB
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise DaalaHipError("%s failed with code %d" % (what, rc))
+
+
+def init(device=0):
+    _check(lib().odhip_init(int(device)), "odhip_init")
+
+
+def _stream():
+    import torch
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _need(t, dtype, what):
+    import torch
+    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == dtype
+            and t.is_contiguous()):
+        raise DaalaHipError("%s must be a contiguous CUDA tensor of %s" % (what, dtype))
+
+
+# ---- batched transforms ---------------------------------------------------
+def _dct_batch(fn, ln, x, exact32, out):
+    import torch
+    n = 4 << ln
+    _need(x, torch.int32, "x")
+    if x.shape[-2:] != (n, n):
+        raise DaalaHipError("x must be [..., %d, %d]" % (n, n))
+    nblocks = x.numel() // (n * n)
+    if out is None:
+        out = torch.empty_like(x)
+    _check(fn(int(ln), _p(out), _p(x), ctypes.c_long(nblocks), int(bool(exact32)),
+              _stream()), fn.__name__)
+    return out
+
+
+def fdct2d_batch(ln, x, exact32=False, out=None):
+    """od_bin_fdctNxN (N = 4 << ln) of every [N, N] tile of x (int32, CUDA)."""
+    return _dct_batch(lib().odhip_fdct2d_batch, ln, x, exact32, out)
+
+
+def idct2d_batch(ln, y, exact32=False, out=None):
+    return _dct_batch(lib().odhip_idct2d_batch, ln, y, exact32, out)
+
+
+def _dct_plane(fn, ln, x, exact32):
+    import torch
+    _need(x, torch.int32, "plane")
+    h, w = x.shape
+    out = torch.empty_like(x)
+    _check(fn(int(ln), _p(out), w, _p(x), w, w, h, int(bool(exact32)), _stream()),
+           fn.__name__)
+    return out
+
+
+def fdct2d_plane(ln, x, exact32=False):
+    return _dct_plane(lib().odhip_fdct2d_plane, ln, x, exact32)
+
+
+def idct2d_plane(ln, y, exact32=False):
+    return _dct_plane(lib().odhip_idct2d_plane, ln, y, exact32)
+
+
+# ---- fused lapped stage -----------------------------------------------------
+def forward_pyramid(px, dec, pic_w, pic_h, levels=None, want=None):
+    """px: uint8 [nplanes, h, w] CUDA.  Returns a list of int32 [nplanes, h, w]
+    tensors, index bs = 0..4-dec (None where `want` excludes a level)."""
+    import torch
+    _need(px, torch.uint8, "px")
+    nplanes, h, w = px.shape
+    top = 4 - dec
+    if levels is None:
+        levels = [torch.empty((nplanes, h, w), dtype=torch.int32, device=px.device)
+                  if (want is None or bs in want) else None
+                  for bs in range(top + 1)]
+    arr = (ctypes.c_void_p * 5)()
+    for bs in range(5):
+        t = levels[bs] if bs <= top else None
+        arr[bs] = ctypes.c_void_p(t.data_ptr() if t is not None else None)
+    _check(lib().odhip_forward_pyramid(arr, _p(px), w, ctypes.c_long(h * w), nplanes,
+                                       w, h, int(dec), int(pic_w), int(pic_h),
+                                       _stream()), "odhip_forward_pyramid")
+    return levels
+
+
+def inverse_level(coef, dec, leaf_bs, pic_w, pic_h, out=None):
+    """coef: int32 [nplanes, h, w] at uniform partition level leaf_bs ->
+    uint8 [nplanes, h, w] reconstructed pixels."""
+    import torch
+    _need(coef, torch.int32, "coef")
+    nplanes, h, w = coef.shape
+    if out is None:
+        out = torch.empty((nplanes, h, w), dtype=torch.uint8, device=coef.device)
+    _check(lib().odhip_inverse_level(_p(out), w, ctypes.c_long(h * w), _p(coef), nplanes,
+                                     w, h, int(dec), int(leaf_bs), int(pic_w), int(pic_h),
+                                     _stream()), "odhip_inverse_level")
+    return out
+
+
+# ---- PVQ ---------------------------------------------------------------------
+def pvq_search_batch(x, k, g2, pvq_norm_lambda, prev_k=None, y=None, cos=None):
+    """Batched pvq_search_rdo_double.  x int16 [nbands, n], k int32 [nbands],
+    g2 float64 [nbands]; returns (y int32 [nbands, n], cos float64 [nbands])."""
+    import torch
+    _need(x, torch.int16, "x")
+    _need(k, torch.int32, "k")
+    _need(g2, torch.float64, "g2")
+    nbands, n = x.shape
+    if y is None:
+        y = torch.zeros((nbands, n), dtype=torch.int32, device=x.device)
+    if cos is None:
+        cos = torch.empty(nbands, dtype=torch.float64, device=x.device)
+    pk = ctypes.c_void_p(None)
+    if prev_k is not None:
+        _need(prev_k, torch.int32, "prev_k")
+        pk = _p(prev_k)
+    _check(lib().odhip_pvq_search_batch(_p(x), int(n), _p(k), _p(y), _p(g2),
+                                        ctypes.c_double(pvq_norm_lambda), pk, _p(cos),
+                                        ctypes.c_long(nbands), _stream()),
+           "odhip_pvq_search_batch")
+    return y, cos
+
+
+# ---- per-call host-pointer surfaces (numpy) ---------------------------------
+class _Host:
+    """The reference-signature entry points, callable on numpy arrays."""
+
+    def dct2d(self, ln, x, inverse=False):
+        n = 4 << ln
+        x = np.ascontiguousarray(x, dtype=np.int32)
+        assert x.shape == (n, n)
+        out = np.zeros_like(x)
+        name = "od_bin_%sdct%dx%d_hip" % ("i" if inverse else "f", n, n)
+        getattr(lib(), name)(out.ctypes.data_as(ctypes.c_void_p), n,
+                             x.ctypes.data_as(ctypes.c_void_p), n)
+        return out
+
+    def pvq_search(self, x, k, g2, lam, prev_k=0, y=None):
+        x = np.ascontiguousarray(x, dtype=np.int16)
+        n = x.shape[0]
+        y = np.zeros(n, np.int32) if y is None else np.ascontiguousarray(y, np.int32)
+        c = lib().od_pvq_search_rdo_double_hip(
+            x.ctypes.data_as(ctypes.c_void_p), n, int(k),
+            y.ctypes.data_as(ctypes.c_void_p), ctypes.c_double(g2),
+            ctypes.c_double(lam), int(prev_k))
+        return y, c
+
+
+host = _Host()

@@ -1,0 +1,71 @@
+"""Build libdaalahip.so (hand-written HIP for gfx950) in-tree with hipcc.
+
+`python -m daala_amd.build` or `daala_amd.build.build()`.  hipcc cross-compiles
+without a GPU; the resulting daala_amd/lib/libdaalahip.so is git-ignored but
+travels to the GPU box with the gpurun snapshot.
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+LIB = os.path.join(LIBDIR, "libdaalahip.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+SOURCES = ["dct_kernels.hip", "lapped_kernels.hip", "pvq_kernels.hip",
+           "odhip_host.hip"]
+# -ffp-contract=off is MANDATORY for the fp64 PVQ search (bit-exactness with
+# gcc -O2 on x86-64, which emits no FMA); harmless for the integer kernels.
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
+         "-ffp-contract=off", "-fno-fast-math", "-Wall",
+         "-Wno-unused-function"]
+
+
+def _deps():
+    out = []
+    for root, _, files in os.walk(CSRC):
+        for f in files:
+            out.append(os.path.join(root, f))
+    out.append(os.path.join(os.path.dirname(HERE), "include", "daala_hip.h"))
+    return out
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    os.makedirs(LIBDIR, exist_ok=True)
+    deps = _deps()
+    objs = []
+    jobs = []
+    for src in SOURCES:
+        obj = os.path.join(LIBDIR, src.replace(".hip", ".o"))
+        objs.append(obj)
+        if force or _stale(obj, deps):
+            jobs.append([HIPCC] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj])
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed:\n%s\n%s" % (" ".join(cmd), r.stderr))
+        return r.stderr
+
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        for warn in ex.map(run, jobs):
+            if verbose and warn:
+                print(warn)
+    if jobs or force or _stale(LIB, objs):
+        run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

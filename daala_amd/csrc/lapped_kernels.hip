@@ -1,0 +1,471 @@
+/* lapped_kernels.hip - the fused "filter + DCT" stage for gfx950.
+
+   FORWARD (k_forward_pyramid): one workgroup per superblock (64x64 luma /
+   32x32 4:2:0 chroma).  The superblock's pixels are read once from HBM
+   (coalesced 4-pixel loads plus a 2-sample halo), converted to coefficients,
+   lapped across the superblock edges, and then kept in LDS while EVERY level
+   of the block-size pyramid is produced from it:
+
+       level bs = top..0:   2-D fDCT of every (4<<bs)-block  -> HBM level plane
+                            4-point split pre-filter of every block (in LDS)
+
+   so the algorithmic HBM traffic is 1 B read + 4 B written per pixel and level
+   (21 B / luma pixel for five levels) with no
+   re-reads.  Restates, level by level, the recursion of od_compute_dcts
+   (reference src/encode.c:1455-1512) over od_ref_plane_to_coeff
+   (src/state.c:1216-1277), od_apply_prefilter_frame_sbs (src/filter.c:
+   1529-1559), od_prefilter_split (:1459-1483) and fdct_2d[bs].
+
+   INVERSE: k_inverse_sb (iDCT + split post-filters, src/encode.c:1780-1789,
+   src/filter.c:1485-1527) and k_postfilter_px (superblock-edge post-filter
+   src/filter.c:1589-1618 + od_coeff_to_ref_plane src/state.c:1281-1345).
+
+   Pixels are bounded, so every lifting multiply uses the full-rate 24-bit
+   multiplier (OdMul24, see od_lift.cuh). */
+#include "../../include/daala_hip.h"
+#include "od_common.cuh"
+#include "od_tile.cuh"
+
+namespace {
+
+template <int TILE>
+struct Geo {
+  static constexpr int kNT = TILE*TILE/16;
+  static constexpr int kPitch = TILE + 4;
+  /* Tile with a 2-sample halo: rows/cols -2,-1 live at TILE, TILE+1 and rows/
+     cols TILE, TILE+1 at TILE+2, TILE+3 (the halo columns occupy the pitch
+     padding, the halo rows four extra rows), so the interior keeps its 16-byte
+     row alignment. */
+  static constexpr int kHaloWords = (TILE + 4)*kPitch;
+  __device__ static __forceinline__ int map(int i) {
+    return i < 0 ? TILE + 2 + i : (i >= TILE ? i + 2 : i);
+  }
+};
+
+struct PyramidArgs {
+  od_coeff *levels[ODHIP_NBSIZES];
+  const uint8_t *px;
+  int px_stride;
+  long px_plane_stride;
+  int w;
+  int h;
+  int pic_w;
+  int pic_h;
+};
+
+/* 4-point filter across 4 LDS words a, a+step, a+2*step, a+3*step. */
+template <bool INV>
+__device__ __forceinline__ void lds_filter4(int *p, int step) {
+  int t0 = p[0];
+  int t1 = p[step];
+  int t2 = p[2*step];
+  int t3 = p[3*step];
+  if constexpr (INV) od_post_filter4_dev(t0, t1, t2, t3);
+  else od_pre_filter4_dev(t0, t1, t2, t3);
+  p[0] = t0;
+  p[step] = t1;
+  p[2*step] = t2;
+  p[3*step] = t3;
+}
+
+/* Column-direction half of od_prefilter_split / od_postfilter_split for every
+   level-LN block of the tile: taps across the horizontal mid-line, gated by
+   `hfilter` (derived from the block's x index, src/encode.c:1487). */
+template <int TILE, int LN, bool INV>
+__device__ __forceinline__ void split_filter_cols(int *t, int tid, int x0, int pic_w) {
+  constexpr int N = 4 << LN;
+  constexpr int P = Geo<TILE>::kPitch;
+  constexpr int NT = Geo<TILE>::kNT;
+  for (int k = tid; k < TILE*(TILE/N); k += NT) {
+    const int x = k % TILE;
+    const int by = k / TILE;
+    const int gbx = (x0 + x)/N;
+    if ((gbx + 1)*N <= pic_w) lds_filter4<INV>(t + (by*N + N/2 - 2)*P + x, P);
+  }
+}
+
+/* Row-direction half: taps across the vertical mid-line, gated by `vfilter`
+   (from the block's y index, src/encode.c:1488). */
+template <int TILE, int LN, bool INV>
+__device__ __forceinline__ void split_filter_rows(int *t, int tid, int y0, int pic_h) {
+  constexpr int N = 4 << LN;
+  constexpr int P = Geo<TILE>::kPitch;
+  constexpr int NT = Geo<TILE>::kNT;
+  for (int k = tid; k < TILE*(TILE/N); k += NT) {
+    const int y = k % TILE;
+    const int bx = k / TILE;
+    const int gby = (y0 + y)/N;
+    if ((gby + 1)*N <= pic_h) lds_filter4<INV>(t + y*P + bx*N + N/2 - 2, 1);
+  }
+}
+
+template <int TILE>
+__device__ __forceinline__ void store_tile(od_coeff *plane, int w, int x0, int y0,
+ const int *z, int tid) {
+  constexpr int P = Geo<TILE>::kPitch;
+  constexpr int NT = Geo<TILE>::kNT;
+  for (int i = tid; i < TILE*TILE/4; i += NT) {
+    const int y = i/(TILE/4);
+    const int x = (i % (TILE/4))*4;
+    *reinterpret_cast<int4 *>(plane + (long)(y0 + y)*w + x0 + x) =
+     *reinterpret_cast<const int4 *>(z + y*P + x);
+  }
+}
+
+template <int TILE, int LN>
+__device__ __forceinline__ void pyramid_level(int *t, int *z, const PyramidArgs &a,
+ long plane_off, int x0, int y0, int tid) {
+  using T = OdMul24;
+  constexpr int NT = Geo<TILE>::kNT;
+  od_tile_cols<TILE, LN, false, T, NT>(z, t, tid, OdAllBlocks());
+  __syncthreads();
+  od_tile_rows<TILE, LN, false, T, NT>(z, z, tid, OdAllBlocks());
+  if constexpr (LN > 0) split_filter_cols<TILE, LN, false>(t, tid, x0, a.pic_w);
+  __syncthreads();
+  if (a.levels[LN]) store_tile<TILE>(a.levels[LN] + plane_off, a.w, x0, y0, z, tid);
+  if constexpr (LN > 0) {
+    split_filter_rows<TILE, LN, false>(t, tid, y0, a.pic_h);
+    __syncthreads();
+    pyramid_level<TILE, LN - 1>(t, z, a, plane_off, x0, y0, tid);
+  }
+}
+
+template <int TILE>
+__global__ __launch_bounds__(TILE*TILE/16) void k_forward_pyramid(PyramidArgs a) {
+  using G = Geo<TILE>;
+  constexpr int P = G::kPitch;
+  constexpr int NT = G::kNT;
+  constexpr int TOP = TILE == 64 ? 4 : 3;
+  __shared__ __attribute__((aligned(16))) int t[G::kHaloWords];
+  __shared__ __attribute__((aligned(16))) int z[TILE*P];
+  const int tid = threadIdx.x;
+  const int x0 = blockIdx.x*TILE;
+  const int y0 = blockIdx.y*TILE;
+  const int w = a.w;
+  const int h = a.h;
+  const uint8_t *px = a.px + blockIdx.z*a.px_plane_stride;
+  const long plane_off = (long)blockIdx.z*w*h;
+  /* od_ref_buf_to_coeff, src/state.c:1231-1237: (p - 128) << OD_COEFF_SHIFT. */
+  for (int i = tid; i < TILE*TILE/4; i += NT) {
+    const int y = i/(TILE/4);
+    const int x = (i % (TILE/4))*4;
+    const uchar4 v = *reinterpret_cast<const uchar4 *>(px + (long)(y0 + y)*a.px_stride + x0 + x);
+    *reinterpret_cast<int4 *>(t + y*P + x) =
+     make_int4((v.x - 128)*16, (v.y - 128)*16, (v.z - 128)*16, (v.w - 128)*16);
+  }
+  /* Halo ring: 2 samples of each neighbouring superblock (where it exists). */
+  for (int i = tid; i < 8*TILE + 16; i += NT) {
+    int r;
+    int c;
+    if (i < 4*(TILE + 4)) {
+      const int k = i/(TILE + 4);
+      r = k < 2 ? k - 2 : TILE + k - 2;
+      c = i % (TILE + 4) - 2;
+    }
+    else {
+      const int j = i - 4*(TILE + 4);
+      const int k = j & 3;
+      r = j >> 2;
+      c = k < 2 ? k - 2 : TILE + k - 2;
+    }
+    const int gx = x0 + c;
+    const int gy = y0 + r;
+    if (gx >= 0 && gx < w && gy >= 0 && gy < h) {
+      t[G::map(r)*P + G::map(c)] = (px[(long)gy*a.px_stride + gx] - 128)*16;
+    }
+  }
+  __syncthreads();
+  /* od_apply_prefilter_frame_sbs, src/filter.c:1540-1550: column taps across
+     every interior horizontal superblock edge, for every column (halo columns
+     included: the row taps below read them at the edge crossings). */
+  for (int i = tid; i < 2*(TILE + 4); i += NT) {
+    const int bottom = i/(TILE + 4);
+    const int c = i % (TILE + 4) - 2;
+    const int gx = x0 + c;
+    const bool edge = bottom ? y0 + TILE < h : y0 > 0;
+    if (edge && gx >= 0 && gx < w) {
+      const int r = bottom ? TILE - 2 : -2;
+      const int col = G::map(c);
+      int t0 = t[G::map(r)*P + col];
+      int t1 = t[G::map(r + 1)*P + col];
+      int t2 = t[G::map(r + 2)*P + col];
+      int t3 = t[G::map(r + 3)*P + col];
+      od_pre_filter4_dev(t0, t1, t2, t3);
+      t[G::map(r)*P + col] = t0;
+      t[G::map(r + 1)*P + col] = t1;
+      t[G::map(r + 2)*P + col] = t2;
+      t[G::map(r + 3)*P + col] = t3;
+    }
+  }
+  __syncthreads();
+  /* ... then row taps across every interior vertical edge, src/filter.c:
+     1551-1557. */
+  for (int i = tid; i < 2*TILE; i += NT) {
+    const int right = i/TILE;
+    const int r = i % TILE;
+    const bool edge = right ? x0 + TILE < w : x0 > 0;
+    if (edge) {
+      const int c = right ? TILE - 2 : -2;
+      int *row = t + r*P;
+      int t0 = row[G::map(c)];
+      int t1 = row[G::map(c + 1)];
+      int t2 = row[G::map(c + 2)];
+      int t3 = row[G::map(c + 3)];
+      od_pre_filter4_dev(t0, t1, t2, t3);
+      row[G::map(c)] = t0;
+      row[G::map(c + 1)] = t1;
+      row[G::map(c + 2)] = t2;
+      row[G::map(c + 3)] = t3;
+    }
+  }
+  __syncthreads();
+  pyramid_level<TILE, TOP>(t, z, a, plane_off, x0, y0, tid);
+}
+
+/* ---- inverse ------------------------------------------------------------ */
+
+struct InverseArgs {
+  const od_coeff *coef;  /* quantised coefficients, plane layout */
+  od_coeff *recon;       /* out: post-split-filter samples, plane layout */
+  int w;
+  int h;
+  int pic_w;
+  int pic_h;
+  int leaf_bs;
+};
+
+template <int TILE, int LN>
+__device__ __forceinline__ void inverse_split_levels(int *t, const InverseArgs &a,
+ int x0, int y0, int tid) {
+  constexpr int TOP = TILE == 64 ? 4 : 3;
+  if (LN > a.leaf_bs) {
+    /* od_postfilter_split, src/filter.c:1510-1525: rows first, then columns. */
+    split_filter_rows<TILE, LN, true>(t, tid, y0, a.pic_h);
+    __syncthreads();
+    split_filter_cols<TILE, LN, true>(t, tid, x0, a.pic_w);
+    __syncthreads();
+  }
+  if constexpr (LN < TOP) inverse_split_levels<TILE, LN + 1>(t, a, x0, y0, tid);
+}
+
+template <int TILE, int LN>
+__device__ __forceinline__ void inverse_leaf(int *t, int tid) {
+  using T = OdMul24;
+  constexpr int NT = Geo<TILE>::kNT;
+  od_tile_rows<TILE, LN, true, T, NT>(t, t, tid, OdAllBlocks());
+  __syncthreads();
+  od_tile_cols<TILE, LN, true, T, NT>(t, t, tid, OdAllBlocks());
+  __syncthreads();
+}
+
+template <int TILE>
+__global__ __launch_bounds__(TILE*TILE/16) void k_inverse_sb(InverseArgs a) {
+  using G = Geo<TILE>;
+  constexpr int P = G::kPitch;
+  constexpr int NT = G::kNT;
+  __shared__ __attribute__((aligned(16))) int t[TILE*P];
+  const int tid = threadIdx.x;
+  const int x0 = blockIdx.x*TILE;
+  const int y0 = blockIdx.y*TILE;
+  const long plane_off = (long)blockIdx.z*a.w*a.h;
+  for (int i = tid; i < TILE*TILE/4; i += NT) {
+    const int y = i/(TILE/4);
+    const int x = (i % (TILE/4))*4;
+    *reinterpret_cast<int4 *>(t + y*P + x) =
+     *reinterpret_cast<const int4 *>(a.coef + plane_off + (long)(y0 + y)*a.w + x0 + x);
+  }
+  __syncthreads();
+  switch (a.leaf_bs) {
+    case 0: inverse_leaf<TILE, 0>(t, tid); break;
+    case 1: inverse_leaf<TILE, 1>(t, tid); break;
+    case 2: inverse_leaf<TILE, 2>(t, tid); break;
+    case 3: inverse_leaf<TILE, 3>(t, tid); break;
+    default:
+      if constexpr (TILE == 64) inverse_leaf<TILE, 4>(t, tid);
+      break;
+  }
+  inverse_split_levels<TILE, 1>(t, a, x0, y0, tid);
+  store_tile<TILE>(a.recon + plane_off, a.w, x0, y0, t, tid);
+}
+
+struct PostPxArgs {
+  const od_coeff *recon;
+  uint8_t *px;
+  int px_stride;
+  long px_plane_stride;
+  int w;
+  int h;
+};
+
+/* od_apply_postfilter_frame_sbs (src/filter.c:1600-1617: row taps across the
+   vertical superblock edges first, then column taps across the horizontal
+   ones) fused with od_coeff_to_ref_buf (src/state.c:1296-1304). */
+template <int TILE>
+__global__ __launch_bounds__(TILE*TILE/16) void k_postfilter_px(PostPxArgs a) {
+  using G = Geo<TILE>;
+  constexpr int P = G::kPitch;
+  constexpr int NT = G::kNT;
+  __shared__ __attribute__((aligned(16))) int t[G::kHaloWords];
+  const int tid = threadIdx.x;
+  const int x0 = blockIdx.x*TILE;
+  const int y0 = blockIdx.y*TILE;
+  const int w = a.w;
+  const int h = a.h;
+  const od_coeff *src = a.recon + (long)blockIdx.z*w*h;
+  uint8_t *px = a.px + blockIdx.z*a.px_plane_stride;
+  for (int i = tid; i < TILE*TILE/4; i += NT) {
+    const int y = i/(TILE/4);
+    const int x = (i % (TILE/4))*4;
+    *reinterpret_cast<int4 *>(t + y*P + x) =
+     *reinterpret_cast<const int4 *>(src + (long)(y0 + y)*w + x0 + x);
+  }
+  for (int i = tid; i < 8*TILE + 16; i += NT) {
+    int r;
+    int c;
+    if (i < 4*(TILE + 4)) {
+      const int k = i/(TILE + 4);
+      r = k < 2 ? k - 2 : TILE + k - 2;
+      c = i % (TILE + 4) - 2;
+    }
+    else {
+      const int j = i - 4*(TILE + 4);
+      const int k = j & 3;
+      r = j >> 2;
+      c = k < 2 ? k - 2 : TILE + k - 2;
+    }
+    const int gx = x0 + c;
+    const int gy = y0 + r;
+    if (gx >= 0 && gx < w && gy >= 0 && gy < h) {
+      t[G::map(r)*P + G::map(c)] = src[(long)gy*w + gx];
+    }
+  }
+  __syncthreads();
+  /* Row taps across vertical edges, every row including the halo rows. */
+  for (int i = tid; i < 2*(TILE + 4); i += NT) {
+    const int right = i/(TILE + 4);
+    const int r = i % (TILE + 4) - 2;
+    const int gy = y0 + r;
+    const bool edge = right ? x0 + TILE < w : x0 > 0;
+    if (edge && gy >= 0 && gy < h) {
+      const int c = right ? TILE - 2 : -2;
+      int *row = t + G::map(r)*P;
+      int t0 = row[G::map(c)];
+      int t1 = row[G::map(c + 1)];
+      int t2 = row[G::map(c + 2)];
+      int t3 = row[G::map(c + 3)];
+      od_post_filter4_dev(t0, t1, t2, t3);
+      row[G::map(c)] = t0;
+      row[G::map(c + 1)] = t1;
+      row[G::map(c + 2)] = t2;
+      row[G::map(c + 3)] = t3;
+    }
+  }
+  __syncthreads();
+  /* Column taps across horizontal edges. */
+  for (int i = tid; i < 2*TILE; i += NT) {
+    const int bottom = i/TILE;
+    const int c = i % TILE;
+    const bool edge = bottom ? y0 + TILE < h : y0 > 0;
+    if (edge) {
+      const int r = bottom ? TILE - 2 : -2;
+      int t0 = t[G::map(r)*P + c];
+      int t1 = t[G::map(r + 1)*P + c];
+      int t2 = t[G::map(r + 2)*P + c];
+      int t3 = t[G::map(r + 3)*P + c];
+      od_post_filter4_dev(t0, t1, t2, t3);
+      t[G::map(r)*P + c] = t0;
+      t[G::map(r + 1)*P + c] = t1;
+      t[G::map(r + 2)*P + c] = t2;
+      t[G::map(r + 3)*P + c] = t3;
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < TILE*TILE/4; i += NT) {
+    const int y = i/(TILE/4);
+    const int x = (i % (TILE/4))*4;
+    const int4 v = *reinterpret_cast<const int4 *>(t + y*P + x);
+    uchar4 o;
+    o.x = (unsigned char)min(max(((v.x + 8) >> 4) + 128, 0), 255);
+    o.y = (unsigned char)min(max(((v.y + 8) >> 4) + 128, 0), 255);
+    o.z = (unsigned char)min(max(((v.z + 8) >> 4) + 128, 0), 255);
+    o.w = (unsigned char)min(max(((v.w + 8) >> 4) + 128, 0), 255);
+    *reinterpret_cast<uchar4 *>(px + (long)(y0 + y)*a.px_stride + x0 + x) = o;
+  }
+}
+
+/* Scratch plane for the two-kernel inverse; grows on demand, one per process
+   (the library is used with one stream per process in the sharded driver). */
+od_coeff *g_recon = nullptr;
+size_t g_recon_bytes = 0;
+
+}  // namespace
+
+extern "C" int odhip_forward_pyramid(od_coeff *const d_levels[ODHIP_NBSIZES],
+ const uint8_t *d_px, int px_stride, long px_plane_stride, int nplanes, int w,
+ int h, int dec, int pic_w, int pic_h, odhip_stream stream) {
+  if (!d_levels || !d_px || nplanes <= 0 || (dec != 0 && dec != 1)) return ODHIP_EINVAL;
+  const int tile = 64 >> dec;
+  if (w <= 0 || h <= 0 || w % tile || h % tile || (px_stride & 3)
+   || (px_plane_stride & 3)) {
+    return ODHIP_EINVAL;
+  }
+  PyramidArgs a;
+  for (int i = 0; i < ODHIP_NBSIZES; i++) a.levels[i] = i <= 4 - dec ? d_levels[i] : nullptr;
+  a.px = d_px;
+  a.px_stride = px_stride;
+  a.px_plane_stride = px_plane_stride;
+  a.w = w;
+  a.h = h;
+  a.pic_w = pic_w;
+  a.pic_h = pic_h;
+  const dim3 grid(w/tile, h/tile, nplanes);
+  hipStream_t s = (hipStream_t)stream;
+  if (dec) k_forward_pyramid<32><<<grid, Geo<32>::kNT, 0, s>>>(a);
+  else k_forward_pyramid<64><<<grid, Geo<64>::kNT, 0, s>>>(a);
+  return odhip_check_launch();
+}
+
+extern "C" int odhip_inverse_level(uint8_t *d_px, int px_stride, long px_plane_stride,
+ const od_coeff *d_coef, int nplanes, int w, int h, int dec, int leaf_bs,
+ int pic_w, int pic_h, odhip_stream stream) {
+  if (!d_px || !d_coef || nplanes <= 0 || (dec != 0 && dec != 1)) return ODHIP_EINVAL;
+  const int tile = 64 >> dec;
+  if (w <= 0 || h <= 0 || w % tile || h % tile || (px_stride & 3)
+   || (px_plane_stride & 3) || leaf_bs < 0 || leaf_bs > 4 - dec) {
+    return ODHIP_EINVAL;
+  }
+  const size_t need = (size_t)nplanes*w*h*sizeof(od_coeff);
+  if (need > g_recon_bytes) {
+    if (g_recon) ODHIP_TRY(hipFree(g_recon));
+    g_recon = nullptr;
+    g_recon_bytes = 0;
+    ODHIP_TRY(hipMalloc((void **)&g_recon, need));
+    g_recon_bytes = need;
+  }
+  InverseArgs ia;
+  ia.coef = d_coef;
+  ia.recon = g_recon;
+  ia.w = w;
+  ia.h = h;
+  ia.pic_w = pic_w;
+  ia.pic_h = pic_h;
+  ia.leaf_bs = leaf_bs;
+  PostPxArgs pa;
+  pa.recon = g_recon;
+  pa.px = d_px;
+  pa.px_stride = px_stride;
+  pa.px_plane_stride = px_plane_stride;
+  pa.w = w;
+  pa.h = h;
+  const dim3 grid(w/tile, h/tile, nplanes);
+  hipStream_t s = (hipStream_t)stream;
+  if (dec) {
+    k_inverse_sb<32><<<grid, Geo<32>::kNT, 0, s>>>(ia);
+    k_postfilter_px<32><<<grid, Geo<32>::kNT, 0, s>>>(pa);
+  }
+  else {
+    k_inverse_sb<64><<<grid, Geo<64>::kNT, 0, s>>>(ia);
+    k_postfilter_px<64><<<grid, Geo<64>::kNT, 0, s>>>(pa);
+  }
+  return odhip_check_launch();
+}

@@ -1,0 +1,279 @@
+/* odhip_host.hip - the per-call, host-pointer half of the C ABI.
+
+   These entry points have exactly the reference's signatures and calling
+   conventions (synchronous, caller-owned host memory, void return) so they can
+   be bound into the reference's function-pointer tables and call sites
+   unchanged; each one stages its operands into device scratch, runs the SAME
+   kernels as the batched API, and copies the result back.  They are the
+   drop-in / parity surface - one block per call cannot be fast.
+
+   There is no CPU fallback: if HIP fails the process aborts with a message,
+   as the reference's void surfaces leave no error channel. */
+#include <stdlib.h>
+#include <string.h>
+#include "../../include/daala_hip.h"
+#include "od_common.cuh"
+#include "od_lift.cuh"
+
+namespace {
+
+void die(const char *what, hipError_t e) {
+  fprintf(stderr, "libdaalahip: fatal: %s: %s (no CPU fallback)\n", what,
+   hipGetErrorString(e));
+  abort();
+}
+
+#define HIP_OR_DIE(expr) \
+  do { \
+    hipError_t e_ = (expr); \
+    if (e_ != hipSuccess) die(#expr, e_); \
+  } while (0)
+
+void ok_or_die(int rc, const char *what) {
+  if (rc != ODHIP_SUCCESS) {
+    fprintf(stderr, "libdaalahip: fatal: %s returned %d (no CPU fallback)\n", what, rc);
+    abort();
+  }
+}
+
+/* Per-thread scratch: the reference allows one encoder per host thread. */
+struct Scratch {
+  hipStream_t stream = nullptr;
+  char *buf[2] = {nullptr, nullptr};
+  size_t cap[2] = {0, 0};
+  void *get(int i, size_t bytes) {
+    if (!stream) HIP_OR_DIE(hipStreamCreate(&stream));
+    if (bytes > cap[i]) {
+      if (buf[i]) HIP_OR_DIE(hipFree(buf[i]));
+      size_t want = bytes < 65536 ? 65536 : bytes;
+      HIP_OR_DIE(hipMalloc((void **)&buf[i], want));
+      cap[i] = want;
+    }
+    return buf[i];
+  }
+};
+thread_local Scratch g_scratch;
+
+void dct_call(bool inverse, int ln, od_coeff *out, int out_stride,
+ const od_coeff *in, int in_stride) {
+  const int n = 4 << ln;
+  Scratch &s = g_scratch;
+  od_coeff *d_in = (od_coeff *)s.get(0, (size_t)n*n*sizeof(od_coeff));
+  od_coeff *d_out = (od_coeff *)s.get(1, (size_t)n*n*sizeof(od_coeff));
+  HIP_OR_DIE(hipMemcpy2DAsync(d_in, n*sizeof(od_coeff), in, in_stride*sizeof(od_coeff),
+   n*sizeof(od_coeff), n, hipMemcpyHostToDevice, s.stream));
+  ok_or_die(inverse ? odhip_idct2d_batch(ln, d_out, d_in, 1, 1, s.stream)
+                    : odhip_fdct2d_batch(ln, d_out, d_in, 1, 1, s.stream), "dct2d");
+  HIP_OR_DIE(hipMemcpy2DAsync(out, out_stride*sizeof(od_coeff), d_out, n*sizeof(od_coeff),
+   n*sizeof(od_coeff), n, hipMemcpyDeviceToHost, s.stream));
+  HIP_OR_DIE(hipStreamSynchronize(s.stream));
+}
+
+/* One 4-tap lapping filter per thread: tap k of task i of edge e lives at
+   first + e*edge_step + i*task_step + k*tap_step. */
+template <bool INV>
+__global__ void k_filter_edges(od_coeff *c, long first, long edge_step, int ntasks,
+ long task_step, long tap_step) {
+  const int i = blockIdx.x*blockDim.x + threadIdx.x;
+  if (i >= ntasks) return;
+  od_coeff *p = c + first + blockIdx.y*edge_step + i*task_step;
+  int t0 = p[0];
+  int t1 = p[tap_step];
+  int t2 = p[2*tap_step];
+  int t3 = p[3*tap_step];
+  if (INV) od_post_filter4_dev(t0, t1, t2, t3);
+  else od_pre_filter4_dev(t0, t1, t2, t3);
+  p[0] = t0;
+  p[tap_step] = t1;
+  p[2*tap_step] = t2;
+  p[3*tap_step] = t3;
+}
+
+template <bool INV>
+void filter_edges(od_coeff *d, long first, long edge_step, int nedges, int ntasks,
+ long task_step, long tap_step, hipStream_t s) {
+  if (nedges <= 0 || ntasks <= 0) return;
+  const dim3 grid((ntasks + 255)/256, nedges);
+  k_filter_edges<INV><<<grid, 256, 0, s>>>(d, first, edge_step, ntasks, task_step, tap_step);
+  ok_or_die(odhip_check_launch(), "k_filter_edges");
+}
+
+/* Round trip of a host sub-plane (rows x cols, host stride) through device
+   scratch around `body`, which sees a compact device plane of stride cols. */
+template <typename F>
+void with_device_plane(od_coeff *c, int stride, int rows, int cols, F body) {
+  Scratch &s = g_scratch;
+  od_coeff *d = (od_coeff *)s.get(0, (size_t)rows*cols*sizeof(od_coeff));
+  HIP_OR_DIE(hipMemcpy2DAsync(d, cols*sizeof(od_coeff), c, stride*sizeof(od_coeff),
+   cols*sizeof(od_coeff), rows, hipMemcpyHostToDevice, s.stream));
+  body(d, s.stream);
+  HIP_OR_DIE(hipMemcpy2DAsync(c, stride*sizeof(od_coeff), d, cols*sizeof(od_coeff),
+   cols*sizeof(od_coeff), rows, hipMemcpyDeviceToHost, s.stream));
+  HIP_OR_DIE(hipStreamSynchronize(s.stream));
+}
+
+void require_f0(int f) {
+  if (f != 0) {
+    fprintf(stderr, "libdaalahip: fatal: lapping filter size f=%d requested; the codec "
+     "only uses the 4-point filter (OD_FILT_SIZE == 0)\n", f);
+    abort();
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int odhip_init(int device) {
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
+    fprintf(stderr, "libdaalahip: no HIP device available (no CPU fallback)\n");
+    return ODHIP_EFAULT;
+  }
+  if (device < 0 || device >= count) return ODHIP_EINVAL;
+  ODHIP_TRY(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  ODHIP_TRY(hipGetDeviceProperties(&prop, device));
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+    fprintf(stderr, "libdaalahip: device %d is %s; this library is built for gfx950 only\n",
+     device, prop.gcnArchName);
+    return ODHIP_EFAULT;
+  }
+  return ODHIP_SUCCESS;
+}
+
+const char *odhip_version(void) {
+  return "libdaalahip 0.1 (gfx950; lapped DCT pyramid + PVQ search)";
+}
+
+#define ODHIP_DCT_PAIR(n, ln) \
+  void od_bin_fdct##n##x##n##_hip(od_coeff *y, int ystride, const od_coeff *x, int xstride) { \
+    dct_call(false, ln, y, ystride, x, xstride); \
+  } \
+  void od_bin_idct##n##x##n##_hip(od_coeff *x, int xstride, const od_coeff *y, int ystride) { \
+    dct_call(true, ln, x, xstride, y, ystride); \
+  }
+ODHIP_DCT_PAIR(4, 0)
+ODHIP_DCT_PAIR(8, 1)
+ODHIP_DCT_PAIR(16, 2)
+ODHIP_DCT_PAIR(32, 3)
+ODHIP_DCT_PAIR(64, 4)
+
+void odhip_install_dct_vtbl(odhip_dct_func_2d fdct_2d[ODHIP_NBSIZES],
+ odhip_dct_func_2d idct_2d[ODHIP_NBSIZES]) {
+  fdct_2d[0] = od_bin_fdct4x4_hip;
+  fdct_2d[1] = od_bin_fdct8x8_hip;
+  fdct_2d[2] = od_bin_fdct16x16_hip;
+  fdct_2d[3] = od_bin_fdct32x32_hip;
+  fdct_2d[4] = od_bin_fdct64x64_hip;
+  idct_2d[0] = od_bin_idct4x4_hip;
+  idct_2d[1] = od_bin_idct8x8_hip;
+  idct_2d[2] = od_bin_idct16x16_hip;
+  idct_2d[3] = od_bin_idct32x32_hip;
+  idct_2d[4] = od_bin_idct64x64_hip;
+}
+
+void od_pre_filter4_hip(od_coeff y[4], const od_coeff x[4]) {
+  od_coeff t[4];
+  memcpy(t, x, sizeof(t));
+  with_device_plane(t, 4, 1, 4, [](od_coeff *d, hipStream_t s) {
+    filter_edges<false>(d, 0, 0, 1, 1, 0, 1, s);
+  });
+  memcpy(y, t, sizeof(t));
+}
+
+void od_post_filter4_hip(od_coeff x[4], const od_coeff y[4]) {
+  od_coeff t[4];
+  memcpy(t, y, sizeof(t));
+  with_device_plane(t, 4, 1, 4, [](od_coeff *d, hipStream_t s) {
+    filter_edges<true>(d, 0, 0, 1, 1, 0, 1, s);
+  });
+  memcpy(x, t, sizeof(t));
+}
+
+/* od_prefilter_split, src/filter.c:1459-1483: columns (hfilter) then rows. */
+void od_prefilter_split_hip(od_coeff *c0, int stride, int bs, int f, int hfilter,
+ int vfilter) {
+  require_f0(f);
+  const int n = 4 << bs;
+  with_device_plane(c0, stride, n, n, [=](od_coeff *d, hipStream_t s) {
+    if (hfilter) filter_edges<false>(d, (long)(n/2 - 2)*n, 0, 1, n, 1, n, s);
+    if (vfilter) filter_edges<false>(d, n/2 - 2, 0, 1, n, n, 1, s);
+  });
+}
+
+/* od_postfilter_split, src/filter.c:1485-1527: rows (vfilter) then columns. */
+void od_postfilter_split_hip(od_coeff *c0, int stride, int bs, int f, int q,
+ unsigned char *skip, int skip_stride, int hfilter, int vfilter) {
+  (void)q;
+  (void)skip;
+  (void)skip_stride;
+  require_f0(f);
+  const int n = 4 << bs;
+  with_device_plane(c0, stride, n, n, [=](od_coeff *d, hipStream_t s) {
+    if (vfilter) filter_edges<true>(d, n/2 - 2, 0, 1, n, n, 1, s);
+    if (hfilter) filter_edges<true>(d, (long)(n/2 - 2)*n, 0, 1, n, 1, n, s);
+  });
+}
+
+/* od_apply_prefilter_frame_sbs, src/filter.c:1529-1559. */
+void od_apply_prefilter_frame_sbs_hip(od_coeff *c, int stride, int nhsb, int nvsb,
+ int xdec, int ydec) {
+  const int sbw = 64 >> xdec;
+  const int sbh = 64 >> ydec;
+  const int w = nhsb*sbw;
+  const int h = nvsb*sbh;
+  with_device_plane(c, stride, h, w, [=](od_coeff *d, hipStream_t s) {
+    filter_edges<false>(d, (long)(sbh - 2)*w, (long)sbh*w, nvsb - 1, w, 1, w, s);
+    filter_edges<false>(d, sbw - 2, sbw, nhsb - 1, h, w, 1, s);
+  });
+}
+
+/* od_apply_postfilter_frame_sbs, src/filter.c:1589-1618. */
+void od_apply_postfilter_frame_sbs_hip(od_coeff *c, int stride, int nhsb, int nvsb,
+ int xdec, int ydec, int q, unsigned char *skip, int skip_stride) {
+  (void)q;
+  (void)skip;
+  (void)skip_stride;
+  const int sbw = 64 >> xdec;
+  const int sbh = 64 >> ydec;
+  const int w = nhsb*sbw;
+  const int h = nvsb*sbh;
+  with_device_plane(c, stride, h, w, [=](od_coeff *d, hipStream_t s) {
+    filter_edges<true>(d, sbw - 2, sbw, nhsb - 1, h, w, 1, s);
+    filter_edges<true>(d, (long)(sbh - 2)*w, (long)sbh*w, nvsb - 1, w, 1, w, s);
+  });
+}
+
+double od_pvq_search_rdo_double_hip(const int16_t *xcoeff, int n, int k,
+ od_coeff *ypulse, double g2, double pvq_norm_lambda, int prev_k) {
+  if (n < 1 || n > 128) {
+    fprintf(stderr, "libdaalahip: fatal: pvq search n=%d out of range\n", n);
+    abort();
+  }
+  Scratch &s = g_scratch;
+  /* layout: x[n] int16 | pad | y[n] int32 | k | prev_k | g2 | cos */
+  const size_t off_y = 256;
+  const size_t off_k = off_y + 128*sizeof(od_coeff);
+  const size_t off_g2 = off_k + 16;
+  const size_t off_cos = off_g2 + 8;
+  char host[1024];
+  memset(host, 0, sizeof(host));
+  memcpy(host, xcoeff, n*sizeof(int16_t));
+  if (prev_k > 0) memcpy(host + off_y, ypulse, n*sizeof(od_coeff));
+  ((int32_t *)(host + off_k))[0] = k;
+  ((int32_t *)(host + off_k))[1] = prev_k;
+  *(double *)(host + off_g2) = g2;
+  char *d = (char *)s.get(0, sizeof(host));
+  HIP_OR_DIE(hipMemcpyAsync(d, host, sizeof(host), hipMemcpyHostToDevice, s.stream));
+  ok_or_die(odhip_pvq_search_batch((const int16_t *)d, n, (const int32_t *)(d + off_k),
+   (od_coeff *)(d + off_y), (const double *)(d + off_g2), pvq_norm_lambda,
+   (const int32_t *)(d + off_k + 4), (double *)(d + off_cos), 1, s.stream),
+   "odhip_pvq_search_batch");
+  HIP_OR_DIE(hipMemcpyAsync(host, d, sizeof(host), hipMemcpyDeviceToHost, s.stream));
+  HIP_OR_DIE(hipStreamSynchronize(s.stream));
+  memcpy(ypulse, host + off_y, n*sizeof(od_coeff));
+  return *(double *)(host + off_cos);
+}
+
+}  /* extern "C" */

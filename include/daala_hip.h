@@ -1,0 +1,172 @@
+/* daala_hip.h - C ABI of libdaalahip.so: the MI355X (gfx950) implementation of
+   Daala's block-transform encode hot path (lapped pre/post filter, 4..64 point
+   integer DCT/iDCT, PVQ band search), as a drop-in for the reference's own
+   surfaces for that path.
+
+   Plain C: pointers, sizes and ints only.  Two families of entry points:
+
+   (1) PER-CALL, HOST-POINTER functions with exactly the reference's
+       signatures and conventions (synchronous, caller-owned host buffers, void
+       return).  These are what the reference's function-pointer tables / call
+       sites bind.  One small block per call is
+       dominated by launch + PCIe latency; they exist for parity and for
+       drop-in completeness, not for throughput.
+
+   (2) BATCHED, DEVICE-POINTER functions (prefix odhip_) that the per-call
+       ones are built on and that a batched caller (bench.py, the frame-sharded
+       driver) uses directly: inputs already resident in HBM, asynchronous on a
+       caller-supplied HIP stream, int return (0 or a negative OD_E* value as
+       in the reference's include/daala/codec.h:89-103).
+
+   All coefficient data is od_coeff = int32_t (reference src/filter.h:29) at
+   scale 2^4 (OD_COEFF_SHIFT, src/internal.h:124).  Results are bit-exact with
+   the reference C path; the CPU checker lives in oracle/ (tests only). */
+#ifndef DAALA_HIP_H
+#define DAALA_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef int32_t od_coeff;
+
+#define ODHIP_SUCCESS (0)
+#define ODHIP_EFAULT (-1)   /* OD_EFAULT: HIP runtime failure / bad pointer */
+#define ODHIP_EINVAL (-10)  /* OD_EINVAL: bad argument */
+#define ODHIP_EIMPL (-23)   /* OD_EIMPL: not implemented */
+
+#define ODHIP_NBSIZES 5     /* OD_NBSIZES: 4,8,16,32,64 (src/internal.h:53-59) */
+
+/* A HIP stream as an opaque pointer (hipStream_t); NULL = the default stream. */
+typedef void *odhip_stream;
+
+/* ------------------------------------------------------------------------ */
+/* (1) Per-call surfaces                                                     */
+/* ------------------------------------------------------------------------ */
+
+/* od_dct_func_2d, reference src/dct.h:61-62:
+     void f(od_coeff *out, int out_stride, const od_coeff *in, int in_stride)
+   Strides in elements.  Replace OD_FDCT_2D_C / OD_IDCT_2D_C
+   (src/dct.c:54-68), i.e. od_bin_fdctNxN / od_bin_idctNxN (src/dct.c:151-163,
+   351-363, 792-806, 4890-4920), in od_state_opt_vtbl.fdct_2d[] / idct_2d[]
+   (src/state.h:128-129).  Called from src/encode.c:1304,1308,1397,1410,1449,
+   1477 and src/decode.c:521,596.  Arbitrary od_coeff input: exact 32-bit
+   products like the C. */
+typedef void (*odhip_dct_func_2d)(od_coeff *out, int out_stride,
+ const od_coeff *in, int in_stride);
+
+void od_bin_fdct4x4_hip(od_coeff *y, int ystride, const od_coeff *x, int xstride);
+void od_bin_idct4x4_hip(od_coeff *x, int xstride, const od_coeff *y, int ystride);
+void od_bin_fdct8x8_hip(od_coeff *y, int ystride, const od_coeff *x, int xstride);
+void od_bin_idct8x8_hip(od_coeff *x, int xstride, const od_coeff *y, int ystride);
+void od_bin_fdct16x16_hip(od_coeff *y, int ystride, const od_coeff *x, int xstride);
+void od_bin_idct16x16_hip(od_coeff *x, int xstride, const od_coeff *y, int ystride);
+void od_bin_fdct32x32_hip(od_coeff *y, int ystride, const od_coeff *x, int xstride);
+void od_bin_idct32x32_hip(od_coeff *x, int xstride, const od_coeff *y, int ystride);
+void od_bin_fdct64x64_hip(od_coeff *y, int ystride, const od_coeff *x, int xstride);
+void od_bin_idct64x64_hip(od_coeff *x, int xstride, const od_coeff *y, int ystride);
+
+/* Installer with the shape of od_state_opt_vtbl_init_x86
+   (src/x86/x86state.c:39-97): overwrites the five fdct_2d and five idct_2d
+   slots of a table pair.  The one line of reference glue is
+     odhip_install_dct_vtbl(state->opt_vtbl.fdct_2d, state->opt_vtbl.idct_2d);
+   after od_state_opt_vtbl_init_c (src/state.c:346-352). */
+void odhip_install_dct_vtbl(odhip_dct_func_2d fdct_2d[ODHIP_NBSIZES],
+ odhip_dct_func_2d idct_2d[ODHIP_NBSIZES]);
+
+/* od_filter_func, reference src/filter.h:43 (OD_PRE_FILTER[0] /
+   OD_POST_FILTER[0] = od_pre_filter4 / od_post_filter4, src/filter.c:147-222):
+   four samples, in place allowed. */
+void od_pre_filter4_hip(od_coeff y[4], const od_coeff x[4]);
+void od_post_filter4_hip(od_coeff x[4], const od_coeff y[4]);
+
+/* Block- and frame-level lapping drivers, same signatures as the reference
+   (src/filter.h:80-87; definitions src/filter.c:1459-1619), in place on a host
+   plane.  `f` must be 0 (OD_FILT_SIZE is identically 0, src/filter.h:77); q,
+   skip, skip_stride are unused exactly as in the reference's non-deblocking
+   build.  Link-time replacements for the calls at src/encode.c:1489,1760,1789,
+   2571,2675 and src/decode.c:807,823,962,994. */
+void od_prefilter_split_hip(od_coeff *c0, int stride, int bs, int f,
+ int hfilter, int vfilter);
+void od_postfilter_split_hip(od_coeff *c0, int stride, int bs, int f, int q,
+ unsigned char *skip, int skip_stride, int hfilter, int vfilter);
+void od_apply_prefilter_frame_sbs_hip(od_coeff *c, int stride, int nhsb,
+ int nvsb, int xdec, int ydec);
+void od_apply_postfilter_frame_sbs_hip(od_coeff *c, int stride, int nhsb,
+ int nvsb, int xdec, int ydec, int q, unsigned char *skip, int skip_stride);
+
+/* pvq_search_rdo_double, reference src/pvq_encoder.c:93-224 (file-static
+   there; BASELINE.json calls it od_pvq_search_rdo_double).  Same arguments and
+   return value: xcoeff[n] int16 (od_val16), ypulse[n] in/out (input only when
+   prev_k > 0), returns the cosine distance.  Called from pvq_theta,
+   src/pvq_encoder.c:542,589. */
+double od_pvq_search_rdo_double_hip(const int16_t *xcoeff, int n, int k,
+ od_coeff *ypulse, double g2, double pvq_norm_lambda, int prev_k);
+
+/* ------------------------------------------------------------------------ */
+/* (2) Batched device-pointer API                                            */
+/* ------------------------------------------------------------------------ */
+
+/* Library / device bring-up.  odhip_init selects the HIP device for the
+   calling thread and returns 0, or ODHIP_EFAULT when no gfx950 device is
+   usable (there is NO CPU fallback in this library). */
+int odhip_init(int device);
+const char *odhip_version(void);
+
+/* nblocks contiguous N x N tiles, N = 4 << ln; d_out may equal d_in.
+   exact32 != 0 forces exact 32-bit products (arbitrary input); 0 uses the
+   24-bit multiplier, valid while |intermediate| < 2^23 (always true for data
+   that came from pixels). */
+int odhip_fdct2d_batch(int ln, od_coeff *d_out, const od_coeff *d_in,
+ long nblocks, int exact32, odhip_stream stream);
+int odhip_idct2d_batch(int ln, od_coeff *d_out, const od_coeff *d_in,
+ long nblocks, int exact32, odhip_stream stream);
+
+/* Every N x N block of a w x h plane (w, h multiples of N), strides in
+   elements: the `d` plane layout of the reference encoder (block (bx,by)'s
+   coefficient (v,u) at [(by*N+v)*stride + bx*N+u]). */
+int odhip_fdct2d_plane(int ln, od_coeff *d_out, int out_stride,
+ const od_coeff *d_in, int in_stride, int w, int h, int exact32,
+ odhip_stream stream);
+int odhip_idct2d_plane(int ln, od_coeff *d_out, int out_stride,
+ const od_coeff *d_in, int in_stride, int w, int h, int exact32,
+ odhip_stream stream);
+
+/* Forward lapped-transform pyramid of a batch of planes: for each plane
+     od_ref_plane_to_coeff            (src/state.c:1216-1277)
+     od_apply_prefilter_frame_sbs     (src/filter.c:1529-1559)
+     for bs = top .. 0:  fdct_2d[bs] of every block, then od_prefilter_split
+                         of every block   (src/encode.c:1455-1512 forced to
+                                           split everywhere)
+   d_px:  nplanes planes of w x h 8-bit pixels, plane p at d_px + p*px_plane_stride,
+          row stride px_stride.
+   d_levels[bs] (bs = 0..4-dec): nplanes coefficient planes of w x h, plane p at
+          + p*(long)w*h, row stride w.  NULL skips the store of that level.
+   dec:   0 for luma (64x64 superblocks), 1 for 4:2:0 chroma (32x32).
+   pic_w, pic_h: UNPADDED LUMA picture size; gates the split filters exactly
+          like src/encode.c:1487-1488.  w, h: multiples of 64 >> dec. */
+int odhip_forward_pyramid(od_coeff *const d_levels[ODHIP_NBSIZES],
+ const uint8_t *d_px, int px_stride, long px_plane_stride, int nplanes, int w,
+ int h, int dec, int pic_w, int pic_h, odhip_stream stream);
+
+/* Inverse at a uniform partition level leaf_bs for a batch of planes:
+   idct_2d[leaf_bs] of every block, od_postfilter_split for levels
+   leaf_bs+1 .. top (src/encode.c:1780-1789), od_apply_postfilter_frame_sbs
+   (src/filter.c:1589-1618), od_coeff_to_ref_plane (src/state.c:1281-1345).
+   d_coef: nplanes planes w x h, row stride w.  d_px as above (output). */
+int odhip_inverse_level(uint8_t *d_px, int px_stride, long px_plane_stride,
+ const od_coeff *d_coef, int nplanes, int w, int h, int dec, int leaf_bs,
+ int pic_w, int pic_h, odhip_stream stream);
+
+/* Batched pvq_search_rdo_double: band b has d_x[b*n .. b*n+n) int16,
+   d_k[b], d_g2[b], optional d_prev_k[b] (NULL = 0; when > 0 d_y holds the
+   previous pulses), writes d_y[b*n ..) and d_cos[b].  n <= 128. */
+int odhip_pvq_search_batch(const int16_t *d_x, int n, const int32_t *d_k,
+ od_coeff *d_y, const double *d_g2, double pvq_norm_lambda,
+ const int32_t *d_prev_k, double *d_cos, long nbands, odhip_stream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
