@@ -190,3 +190,96 @@ class _Host:
 
 
 host = _Host()
+
+
+# ---- PVQ band stage -----------------------------------------------------------
+class _Cands(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_void_p) for n in
+                ("cg", "dist0", "gain", "k", "flags", "cos_dist", "dist", "y")]
+
+
+def pvq_band_layout(bs):
+    """(nb_bands, offsets[nb_bands + 1], len) for block size 4 << bs."""
+    nb = ctypes.c_int()
+    offs = (ctypes.c_int * 13)()
+    ln = ctypes.c_int()
+    _check(lib().odhip_pvq_band_layout(int(bs), ctypes.byref(nb), offs, ctypes.byref(ln)),
+           "odhip_pvq_band_layout")
+    return nb.value, [offs[i] for i in range(nb.value + 1)], ln.value
+
+
+def _cands_struct(c):
+    return _Cands(*[ctypes.c_void_p(c[n].data_ptr()) for n, _ in _Cands._fields_])
+
+
+def alloc_pvq_cands(nblocks, bs, device):
+    import torch
+    nb, _, ln = pvq_band_layout(bs)
+    i32 = dict(dtype=torch.int32, device=device)
+    f64 = dict(dtype=torch.float64, device=device)
+    return {
+        "cg": torch.empty((nblocks, nb), **i32),
+        "dist0": torch.empty((nblocks, nb), **f64),
+        "gain": torch.empty((nblocks, nb, 2), **i32),
+        "k": torch.empty((nblocks, nb, 2), **i32),
+        "flags": torch.empty((nblocks, nb, 2), **i32),
+        "cos_dist": torch.empty((nblocks, nb, 2), **f64),
+        "dist": torch.empty((nblocks, nb, 2), **f64),
+        "y": torch.zeros((2, nblocks, ln), **i32),
+    }
+
+
+def _band_arrays(q_band, beta_band, nb):
+    q = (ctypes.c_int32 * 12)(*[int(v) for v in q_band])
+    b = (ctypes.c_int32 * 12)(*[int(v) for v in beta_band])
+    assert len(q_band) == nb and len(beta_band) == nb
+    return q, b
+
+
+def pvq_noref_bands(coef, bs, qm, q_band, beta_band, pvq_norm_lambda, out=None):
+    """The adaptation-independent part of pvq_theta (no-reference path) for every
+    block of side 4 << bs of coef (int32 [nplanes, h, w]) and every band."""
+    import torch
+    _need(coef, torch.int32, "coef")
+    _need(qm, torch.int16, "qm")
+    nplanes, h, w = coef.shape
+    n = 4 << bs
+    nblocks = nplanes * (h // n) * (w // n)
+    nb, _, _ = pvq_band_layout(bs)
+    if out is None:
+        out = alloc_pvq_cands(nblocks, bs, coef.device)
+    q, b = _band_arrays(q_band, beta_band, nb)
+    st = _cands_struct(out)
+    _check(lib().odhip_pvq_noref_bands(_p(coef), nplanes, w, h, int(bs), _p(qm), q, b,
+                                       ctypes.c_double(pvq_norm_lambda), ctypes.byref(st),
+                                       _stream()), "odhip_pvq_noref_bands")
+    return out
+
+
+def pvq_select_synth_noref(coef, bs, qm_inv, q_band, beta_band, pvq_norm_lambda, cands,
+                           rate=None, dq=None, qg=None):
+    """Choice (`cost <= best_cost`, cost = dist + lambda*rate) + decoder-identical
+    dequantisation into a coefficient plane.  Returns (dq, qg)."""
+    import torch
+    _need(coef, torch.int32, "coef")
+    _need(qm_inv, torch.int16, "qm_inv")
+    nplanes, h, w = coef.shape
+    n = 4 << bs
+    nblocks = nplanes * (h // n) * (w // n)
+    nb, _, _ = pvq_band_layout(bs)
+    if dq is None:
+        dq = torch.empty_like(coef)
+    if qg is None:
+        qg = torch.empty((nblocks, nb), dtype=torch.int32, device=coef.device)
+    q, b = _band_arrays(q_band, beta_band, nb)
+    st = _cands_struct(cands)
+    pr = ctypes.c_void_p(None)
+    if rate is not None:
+        _need(rate, torch.float64, "rate")
+        pr = _p(rate)
+    _check(lib().odhip_pvq_select_synth_noref(_p(dq), _p(coef), nplanes, w, h, int(bs),
+                                              _p(qm_inv), q, b,
+                                              ctypes.c_double(pvq_norm_lambda),
+                                              ctypes.byref(st), pr, _p(qg), _stream()),
+           "odhip_pvq_select_synth_noref")
+    return dq, qg

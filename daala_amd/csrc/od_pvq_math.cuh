@@ -1,0 +1,167 @@
+/* od_pvq_math.cuh - device-side fixed-point PVQ helpers (gain, companding,
+   K selection, synthesis scale), bit-exact with the reference's integer
+   arithmetic in src/pvq.c and src/odintrin.h:164-199.
+
+   Integer widths, arithmetic shifts, truncating divisions and the int16
+   truncation on store are part of the specification and are spelled out. */
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define ODQ_CGAIN_SHIFT 8     /* OD_CGAIN_SHIFT, src/pvq.h:88 */
+#define ODQ_COMPAND_SHIFT 12  /* OD_COMPAND_SHIFT, src/pvq.h:104 */
+#define ODQ_BETA_SHIFT 12     /* OD_BETA_SHIFT, src/pvq.h:81 */
+#define ODQ_QM_SHIFT 11       /* OD_QM_SHIFT, src/pvq.h:60 */
+#define ODQ_QM_INV_SHIFT 12   /* OD_QM_INV_SHIFT, src/pvq.h:67 */
+#define ODQ_BETA_1_0 4096
+#define ODQ_BETA_1_5 6144
+
+__device__ __forceinline__ int odq_ilog(uint32_t v) { /* OD_ILOG */
+  return v ? 32 - __clz((int)v) : 0;
+}
+
+__device__ __forceinline__ int32_t odq_shl32(int64_t a, int s) { /* OD_SHL */
+  return (int32_t)((uint32_t)a << s);
+}
+
+__device__ __forceinline__ int32_t odq_shr_round(int64_t x, int s) { /* OD_SHR_ROUND */
+  return (int32_t)((x + ((1 << s) >> 1)) >> s);
+}
+
+__device__ __forceinline__ int32_t odq_vshr(int64_t x, int s) { /* OD_VSHR */
+  return s > 0 ? (int32_t)(x >> s) : odq_shl32(x, -s);
+}
+
+__device__ __forceinline__ int32_t odq_vshr_round(int64_t x, int s) { /* OD_VSHR_ROUND */
+  return s > 0 ? odq_shr_round(x, s) : odq_shl32(x, -s);
+}
+
+__device__ __forceinline__ int32_t odq_mult16_16_q15(int32_t a, int32_t b) {
+  return ((int16_t)a*(int32_t)(int16_t)b) >> 15;
+}
+
+__device__ __forceinline__ int32_t odq_mult16_16_qbeta(int32_t a, int32_t b) {
+  return ((int16_t)a*(int32_t)(int16_t)b) >> ODQ_BETA_SHIFT;
+}
+
+/* od_rsqrt_norm, src/pvq.c:968-997. */
+__device__ __forceinline__ int16_t odq_rsqrt_norm(int16_t t) {
+  const int16_t n = (int16_t)(t - 32768);
+  const int32_t r = 23565 + odq_mult16_16_q15(n, -13481 + odq_mult16_16_q15(n, 6711));
+  const int32_t r2 = r*r;
+  const int32_t y = (((r2 >> 15)*n + r2) >> 12) - 131077;
+  const int32_t ry = r*y;
+  return (int16_t)(r + ((((ry >> 16)*(3*y) >> 3) - ry) >> 18));
+}
+
+/* od_rsqrt, src/pvq.c:999-1015. */
+__device__ __forceinline__ int16_t odq_rsqrt(int32_t x, int *rsqrt_shift) {
+  const int k = (odq_ilog(x) - 1) >> 1;
+  const int s = 2*k - 14;
+  *rsqrt_shift = 14 + ((s + 16) >> 1);
+  return odq_rsqrt_norm((int16_t)odq_vshr(x, s));
+}
+
+/* od_sqrt_norm + od_sqrt, src/pvq.c:729-756. */
+__device__ __forceinline__ int16_t odq_sqrt(int32_t x, int *sqrt_shift) {
+  if (x == 0) {
+    *sqrt_shift = 0;
+    return 0;
+  }
+  const int k = (odq_ilog(x) - 1) >> 1;
+  const int s = 2*k - 14;
+  const int32_t t = odq_vshr(x, s);
+  *sqrt_shift = 15 - ((s + 16) >> 1);
+  const int32_t v = odq_shr_round(t*odq_rsqrt_norm((int16_t)t), 15);
+  return (int16_t)(v < 32767 ? v : 32767);
+}
+
+/* od_rcp, src/pvq.c:526-549. */
+__device__ __forceinline__ int16_t odq_rcp(int16_t x) {
+  const int i = odq_ilog(x) - 1;
+  const int16_t n = (int16_t)(odq_vshr_round(x, i - 15) - 32768);
+  int16_t r = (int16_t)(30840 + odq_mult16_16_q15(-15420, n));
+  r = (int16_t)(r - odq_mult16_16_q15(r, odq_mult16_16_q15(r, n) + r - 32768));
+  r = (int16_t)(r - (1 + odq_mult16_16_q15(r, odq_mult16_16_q15(r, n) + r - 32768)));
+  return (int16_t)odq_vshr_round(r, i - 14);
+}
+
+/* od_beta_rcp, src/pvq.c:626-637. */
+__device__ __forceinline__ int16_t odq_beta_rcp(int16_t beta) {
+  if (beta == ODQ_BETA_1_0) return ODQ_BETA_1_0;
+  if (beta == ODQ_BETA_1_5) return 2731;
+  return (int16_t)odq_shr_round(odq_rcp((int16_t)(beta << (15 - 1 - ODQ_BETA_SHIFT))),
+   14 + 1 - ODQ_BETA_SHIFT);
+}
+
+/* od_exp2, src/pvq.c:642-665. */
+__device__ __forceinline__ int32_t odq_exp2(int32_t x) {
+  const int integer = x >> 15;
+  if (integer > 14) return 0x7f000000;
+  if (integer < -15) return 0;
+  const int32_t f = x - odq_shl32(integer, 15);
+  const int32_t frac = odq_mult16_16_q15(f, 22709 + odq_mult16_16_q15(f, 7913
+   + odq_mult16_16_q15(f, 1704 + odq_mult16_16_q15(f, 443))));
+  return odq_vshr_round(32768 + frac, -integer) + 1;
+}
+
+/* od_log2, src/pvq.c:671-676. */
+__device__ __forceinline__ int16_t odq_log2(int16_t x) {
+  return (int16_t)(x + odq_mult16_16_q15(x, 14482 + odq_mult16_16_q15(x, -23234
+   + odq_mult16_16_q15(x, 13643 + odq_mult16_16_q15(x, -6403
+   + odq_mult16_16_q15(x, 1515))))));
+}
+
+/* od_pow, src/pvq.c:678-696. */
+__device__ __forceinline__ int32_t odq_pow(int32_t x, int16_t beta) {
+  if (x == 0) return 0;
+  const int log2_x = odq_ilog(x) - 1;
+  const int16_t t = (int16_t)(odq_vshr(x, log2_x - 15) - 32768);
+  int32_t logr = odq_log2(t) + (log2_x - ODQ_COMPAND_SHIFT)*32768;
+  logr = (int32_t)(beta*(int64_t)logr >> ODQ_BETA_SHIFT);
+  return odq_exp2(logr);
+}
+
+/* od_gain_compand, src/pvq.c:706-722. */
+__device__ __forceinline__ int32_t odq_gain_compand(int32_t g, int q0, int16_t beta) {
+  if (beta == ODQ_BETA_1_0) return (256*g + (q0 >> 1))/q0;
+  int32_t expr = odq_pow(g, odq_beta_rcp(beta));
+  expr <<= ODQ_CGAIN_SHIFT + ODQ_COMPAND_SHIFT - 15;
+  return (expr + (q0 >> 1))/q0;
+}
+
+/* od_gain_expand, src/pvq.c:766-811. */
+__device__ __forceinline__ int32_t odq_gain_expand(int32_t cg0, int q0, int beta) {
+  if (beta == ODQ_BETA_1_0) return odq_shr_round(cg0*q0, ODQ_CGAIN_SHIFT);
+  if (beta == ODQ_BETA_1_5) {
+    int sqrt_outshift;
+    const int32_t irt = odq_sqrt(cg0*q0, &sqrt_outshift);
+    const int64_t tmp = cg0*q0*(int64_t)irt;
+    return odq_vshr_round(tmp, ODQ_CGAIN_SHIFT + sqrt_outshift
+     + ((ODQ_CGAIN_SHIFT + ODQ_COMPAND_SHIFT) >> 1));
+  }
+  return odq_shr_round(odq_pow(odq_shr_round(cg0*q0, ODQ_CGAIN_SHIFT), (int16_t)beta),
+   15 - ODQ_COMPAND_SHIFT);
+}
+
+/* Tail of od_pvq_compute_gain, src/pvq.c:841-846, given acc = sum x^2. */
+__device__ __forceinline__ int32_t odq_gain_from_acc(int32_t acc, int q0, int beta,
+ int bshift, int32_t *g) {
+  int sqrt_shift;
+  const int32_t irt = odq_sqrt(acc, &sqrt_shift);
+  *g = odq_vshr_round(irt, sqrt_shift - bshift);
+  return odq_gain_compand(*g, q0, (int16_t)beta);
+}
+
+/* od_pvq_compute_k, noref branch, src/pvq.c:912-931. */
+__device__ __forceinline__ int odq_compute_k_noref(int32_t qcg, int n, int beta) {
+  if (qcg == 0) return 0;
+  if (n == 15 && qcg == 256 && beta > 5120) return 1;
+  /* od_sqrt_table[1][OD_ILOG(n + 1)], src/pvq.c:908-910. */
+  const int il = odq_ilog(n + 1);
+  const int rt = il == 4 ? 2401 : il == 5 ? 3072 : il == 6 ? 4284 : il == 8 ? 8287
+   : il == 10 ? 16432 : il == 12 ? 32767 : 0;
+  const int32_t v = odq_shr_round((qcg - (int64_t)51)
+   *odq_mult16_16_qbeta(odq_beta_rcp((int16_t)beta), rt), ODQ_CGAIN_SHIFT + 10);
+  return v > 1 ? v : 1;
+}

@@ -166,6 +166,57 @@ int odhip_pvq_search_batch(const int16_t *d_x, int n, const int32_t *d_k,
  od_coeff *d_y, const double *d_g2, double pvq_norm_lambda,
  const int32_t *d_prev_k, double *d_cos, long nbands, odhip_stream stream);
 
+/* ---- PVQ band stage (the data-parallel part of pvq_theta) -------------------
+
+   For every block of side N = 4 << bs of a batch of coefficient planes and
+   every PVQ band of that block size (OD_BAND_OFFSETS, src/partition.c:77-91),
+   the no-reference path of pvq_theta (src/pvq_encoder.c:333-641) up to, but
+   not including, the rate-dependent choice: QM scaling to x16 (:381,:398),
+   companded gain (:404), null-candidate distortion (:417), and for both gain
+   candidates (:578-609) the pulse count K, the pruning test (:588), the
+   K-pulse search and the distortion (:593-595).  The choice needs the rate of
+   each candidate from the ADAPTIVE entropy coder (od_pvq_rate, :247-287), which
+   is sequential host state in the reference and stays there; the host (or
+   odhip_pvq_select_synth_noref with a rate table) applies `cost <= best_cost`.
+
+   Block index: blk = (plane*(h/N) + by)*(w/N) + bx; B = number of blocks. */
+#define ODHIP_MAX_BANDS 12
+typedef struct {
+  int32_t *cg;        /* [B][nb]    companded gain of x, Q8 (od_pvq_compute_gain) */
+  double *dist0;      /* [B][nb]    distortion of the null (gain 0) candidate   */
+  int32_t *gain;      /* [B][nb][2] candidate gain index i; 0 = slot unused     */
+  int32_t *k;         /* [B][nb][2] pulses (od_pvq_compute_k)                   */
+  int32_t *flags;     /* [B][nb][2] 1 = searched, 0 = pruned / unused           */
+  double *cos_dist;   /* [B][nb][2] return value of pvq_search_rdo_double       */
+  double *dist;       /* [B][nb][2] distortion of the candidate                 */
+  od_coeff *y;        /* [2][B][len] pulse vectors in coding order (index 0 = DC
+                         slot, unused), len = min(N*N, 512)                     */
+} odhip_pvq_cands;
+
+/* nb_bands, offsets[nb_bands+1] and len for block size bs. */
+int odhip_pvq_band_layout(int bs, int *nb_bands, int *offsets, int *len);
+
+/* d_qm: QM in coding order for this (bs, decimation): od_state.qm +
+   od_qm_offset(bs, xdec) (src/pvq.c:306, src/encode.c:1355-1358), int16,
+   device.  q_band / beta_band: HOST arrays [nb_bands]: the per-band quantiser
+   max(1, q0*pvq_qm_q4[od_qm_get_index(bs, i+1)] >> 4) (src/pvq_encoder.c:874)
+   and OD_PVQ_BETA[masking][pli][bs][i] (src/pvq.c:243-268). */
+int odhip_pvq_noref_bands(const od_coeff *d_coef, int nplanes, int w, int h,
+ int bs, const int16_t *d_qm, const int32_t *q_band, const int32_t *beta_band,
+ double pvq_norm_lambda, const odhip_pvq_cands *out, odhip_stream stream);
+
+/* Choice + decoder-identical dequantisation of the chosen candidate into d_dq
+   (same plane layout as d_coef; DC passed through; uncoded positions zero):
+   od_gain_expand (src/pvq.c:766), od_pvq_synthesis_partial noref
+   (src/pvq.c:1037-1093), od_coding_order_to_raster (src/partition.c:176).
+   d_rate: [B][nb][2] bits per candidate from the host entropy model, or NULL
+   (distortion-only choice).  d_qg_out: optional [B][nb] chosen gain index. */
+int odhip_pvq_select_synth_noref(od_coeff *d_dq, const od_coeff *d_coef,
+ int nplanes, int w, int h, int bs, const int16_t *d_qm_inv,
+ const int32_t *q_band, const int32_t *beta_band, double pvq_norm_lambda,
+ const odhip_pvq_cands *in, const double *d_rate, int32_t *d_qg_out,
+ odhip_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

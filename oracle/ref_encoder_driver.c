@@ -164,3 +164,68 @@ REF_EXPORT int ref_encode_yuv420(const unsigned char *frames, int w, int h,
   daala_encode_free(enc);
   return npackets;
 }
+
+/* Quantiser set-up the reference derives per frame on the host (SURVEY.md
+   8(a) row a17): after encoding one frame at `quality`, copies out
+   state.quantizer, state.pvq_qm_q4[pli][OD_QM_SIZE] (od_interp_qm,
+   src/encode.c:2903-2940,:3052-3072) and state.qm / qm_inv (od_init_qm,
+   src/pvq.c:322-381).  Used by tools/make_golden.py to create the fixture the
+   GPU tests and bench.py feed to the kernels. */
+#include "encint.h"
+REF_EXPORT int ref_dump_quant_tables(int quality, int *quantizer,
+ unsigned char *pvq_qm_q4, int16_t *qm, int16_t *qm_inv) {
+  daala_info di;
+  daala_comment dc;
+  daala_enc_ctx *enc;
+  daala_packet dp;
+  daala_image img;
+  unsigned char *buf;
+  int complexity;
+  int pli;
+  int ret;
+  daala_info_init(&di);
+  di.pic_width = 64;
+  di.pic_height = 64;
+  di.bitdepth_mode = OD_BITDEPTH_MODE_8;
+  di.timebase_numerator = 30;
+  di.timebase_denominator = 1;
+  di.frame_duration = 1;
+  di.pixel_aspect_numerator = 1;
+  di.pixel_aspect_denominator = 1;
+  di.nplanes = 3;
+  di.plane_info[0].xdec = di.plane_info[0].ydec = 0;
+  di.plane_info[1].xdec = di.plane_info[1].ydec = 1;
+  di.plane_info[2].xdec = di.plane_info[2].ydec = 1;
+  di.keyframe_rate = 1;
+  enc = daala_encode_create(&di);
+  if (enc == NULL) return -1;
+  daala_comment_init(&dc);
+  complexity = 2;
+  daala_encode_ctl(enc, OD_SET_QUANT, &quality, sizeof(quality));
+  daala_encode_ctl(enc, OD_SET_COMPLEXITY, &complexity, sizeof(complexity));
+  while ((ret = daala_encode_flush_header(enc, &dc, &dp)) > 0);
+  buf = (unsigned char *)malloc(64*64*3/2);
+  memset(buf, 128, 64*64*3/2);
+  memset(&img, 0, sizeof(img));
+  img.nplanes = 3;
+  img.width = img.height = 64;
+  for (pli = 0; pli < 3; pli++) {
+    img.planes[pli].data = buf + (pli == 0 ? 0 : pli == 1 ? 4096 : 5120);
+    img.planes[pli].xdec = img.planes[pli].ydec = pli > 0;
+    img.planes[pli].xstride = 1;
+    img.planes[pli].ystride = pli ? 32 : 64;
+    img.planes[pli].bitdepth = 8;
+  }
+  daala_encode_img_in(enc, &img, 0);
+  while (daala_encode_packet_out(enc, 1, &dp));
+  *quantizer = enc->state.quantizer;
+  for (pli = 0; pli < 3; pli++) {
+    memcpy(pvq_qm_q4 + pli*OD_QM_SIZE, enc->state.pvq_qm_q4[pli], OD_QM_SIZE);
+  }
+  memcpy(qm, enc->state.qm, OD_QM_BUFFER_SIZE*sizeof(*qm));
+  memcpy(qm_inv, enc->state.qm_inv, OD_QM_BUFFER_SIZE*sizeof(*qm_inv));
+  free(buf);
+  daala_comment_clear(&dc);
+  daala_encode_free(enc);
+  return OD_QM_SIZE;
+}

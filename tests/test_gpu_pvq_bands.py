@@ -1,0 +1,141 @@
+"""GPU parity of the PVQ band stage (pvq_theta's no-reference path, candidates,
+choice and dequantisation) against the CPU oracle, band by band."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from _libs import P, oracle, synth_frame
+
+pytestmark = pytest.mark.gpu
+cd = ctypes.c_double
+MAXN = 128
+
+
+class Cand(ctypes.Structure):
+    _fields_ = [("with_ref", ctypes.c_int32), ("gain", ctypes.c_int32),
+                ("theta", ctypes.c_int32), ("ts", ctypes.c_int32), ("k", ctypes.c_int32),
+                ("qcg", ctypes.c_int32), ("qtheta", ctypes.c_int32),
+                ("searched", ctypes.c_int32), ("cos_dist", ctypes.c_double),
+                ("dist", ctypes.c_double), ("y", ctypes.c_int32 * MAXN)]
+
+
+class Trace(ctypes.Structure):
+    _fields_ = [("xshift", ctypes.c_int32), ("rshift", ctypes.c_int32),
+                ("g", ctypes.c_int32), ("gr", ctypes.c_int32), ("cg", ctypes.c_int32),
+                ("cgr", ctypes.c_int32), ("icgr", ctypes.c_int32),
+                ("gain_offset", ctypes.c_int32), ("m", ctypes.c_int32), ("s", ctypes.c_int32),
+                ("theta", ctypes.c_int32), ("corr", ctypes.c_double),
+                ("dist0", ctypes.c_double), ("skip_dist", ctypes.c_double),
+                ("x16", ctypes.c_int16 * MAXN), ("r16", ctypes.c_int16 * MAXN),
+                ("ncands", ctypes.c_int32), ("cands", Cand * 24)]
+
+
+@pytest.fixture(scope="module")
+def hip():
+    import torch
+    import daala_amd
+    assert torch.cuda.is_available()
+    daala_amd.init(0)
+    return daala_amd
+
+
+def _cuda(a):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def _oracle_pyramid(px, dec, pic):
+    h, w = px.shape
+    lv = [np.zeros((h, w), np.int32) for _ in range(5 - dec)]
+    arr = (ctypes.c_void_p * 5)(*[l.ctypes.data for l in lv])
+    c = np.zeros((h, w), np.int32)
+    oracle().odo_forward_pyramid_plane(arr, P(c), P(px), w, w, h, dec, pic[0], pic[1])
+    return lv
+
+
+@pytest.mark.parametrize("pli,dec", [(0, 0), (1, 1)])
+def test_band_stage_matches_oracle(hip, pli, dec):
+    W, H = 128, 128
+    planes = synth_frame(W, H, seed=5)
+    rng = np.random.RandomState(17)
+    # stronger texture so that gains > 1 and multi-pulse searches occur
+    planes[0] = np.clip(planes[0].astype(int) + rng.randint(-60, 61, size=(H, W)), 0, 255).astype(np.uint8)
+    px = planes[0] if dec == 0 else planes[1]
+    h, w = px.shape
+    levels = _oracle_pyramid(px, dec, (W, H))
+    qt = hip.QuantTables.load()
+    o = oracle()
+    lam = hip.OD_PVQ_LAMBDA
+    for bs in range(5 - dec):
+        n = 4 << bs
+        coef = levels[bs]
+        qm, qmi = qt.qm_slices(pli, bs)
+        qb = qt.q_band(pli, bs)
+        bb = qt.beta_band(pli, bs)
+        nb, offs, ln = hip.pvq_band_layout(bs)
+        tc = _cuda(coef[None])
+        cands = hip.pvq_noref_bands(tc, bs, _cuda(qm), qb, bb, lam)
+        dq, qg = hip.pvq_select_synth_noref(tc, bs, _cuda(qmi), qb, bb, lam, cands)
+        c = {k_: v.cpu().numpy() for k_, v in cands.items()}
+        dq = dq.cpu().numpy()[0]
+        qg = qg.cpu().numpy()
+        want_dq = np.zeros_like(coef)
+        nsearched = 0
+        for by in range(h // n):
+            for bx in range(w // n):
+                blk = by * (w // n) + bx
+                vec = np.zeros(n * n, np.int32)
+                o.odo_raster_to_coding_order(P(vec), n, ctypes.c_void_p(
+                    coef.ctypes.data + 4 * (by * n * w + bx * n)), w)
+                outvec = np.zeros(n * n, np.int32)
+                outvec[0] = vec[0]
+                for band in range(nb):
+                    a, b = offs[band], offs[band + 1]
+                    m = b - a
+                    x0 = np.ascontiguousarray(vec[a:b])
+                    r0 = np.zeros(m, np.int32)
+                    out = np.zeros(m, np.int32)
+                    y = np.zeros(m, np.int32)
+                    i1, i2, i3 = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+                    sd = cd(0)
+                    tr = Trace()
+                    qq = np.ascontiguousarray(qm[a:b])
+                    qi = np.ascontiguousarray(qmi[a:b])
+                    o.odo_pvq_theta(P(out), P(x0), P(r0), m, qb[band], P(y), ctypes.byref(i1),
+                                    ctypes.byref(i2), ctypes.byref(i3), bb[band],
+                                    ctypes.byref(sd), 1, 1, 0, P(qq), P(qi), cd(lam), 1,
+                                    ctypes.byref(tr))
+                    assert c["cg"][blk, band] == tr.cg
+                    assert c["dist0"][blk, band] == tr.dist0
+                    nr = [tr.cands[i] for i in range(tr.ncands) if not tr.cands[i].with_ref]
+                    assert len(nr) in (1, 2)
+                    best_cost, best_qg, best_y = tr.dist0, 0, None
+                    for slot in range(2):
+                        if slot >= len(nr):
+                            assert c["gain"][blk, band, slot] == 0 and c["flags"][blk, band, slot] == 0
+                            continue
+                        cnd = nr[slot]
+                        assert c["gain"][blk, band, slot] == cnd.gain
+                        assert c["k"][blk, band, slot] == cnd.k
+                        assert c["flags"][blk, band, slot] == cnd.searched
+                        if cnd.searched:
+                            nsearched += 1
+                            assert c["cos_dist"][blk, band, slot] == cnd.cos_dist
+                            assert c["dist"][blk, band, slot] == cnd.dist
+                            yy = np.array(cnd.y[:m], np.int32)
+                            assert np.array_equal(c["y"][slot, blk, a:b], yy)
+                            if cnd.dist <= best_cost:
+                                best_cost, best_qg, best_y = cnd.dist, cnd.gain, yy
+                    assert qg[blk, band] == best_qg
+                    if best_qg:
+                        gexp = o.odo_gain_expand(best_qg << 8, qb[band], bb[band])
+                        syn = np.zeros(m, np.int32)
+                        o.odo_pvq_synthesis_partial(P(syn), P(best_y), None, m, 1, gexp, 0, 0, 1,
+                                                    P(qi))
+                        outvec[a:b] = syn
+                blkout = np.zeros((n, n), np.int32)
+                o.odo_coding_order_to_raster(P(blkout), n, P(outvec), n)
+                want_dq[by * n:(by + 1) * n, bx * n:(bx + 1) * n] = blkout
+        assert nsearched > 0
+        assert np.array_equal(dq, want_dq), bs
