@@ -1,0 +1,310 @@
+#!/usr/bin/env python3
+"""bench.py - 1080p all-intra transform blocks/s (filter + DCT + PVQ) on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W [--frames F]
+
+One STEP = one pass of the block-transform hot path over a batch of F synthetic
+1920x1080 4:2:0 frames (coded size 1920x1088) already resident
+in HBM, per GPU:
+
+  1. odhip_forward_pyramid   pixels -> coefficients, superblock-edge lapping,
+                             and for EVERY block size 64..4 the split
+                             pre-filter + 2-D fDCT of every block (luma 5
+                             levels, chroma 4)
+  2. for every level: odhip_pvq_noref_bands        (QM scaling, gain, both gain
+                             candidates: K, pruning, K-pulse search, distortion)
+                      odhip_pvq_select_synth_noref (choice, od_gain_expand,
+                             od_pvq_synthesis_partial, scan -> raster)
+                      odhip_inverse_level          (iDCT, split post-filters,
+                             superblock-edge post-filter, coefficient -> pixel)
+
+i.e. every block the reference's block-size RDO would evaluate goes through
+prefilter + fDCT + PVQ + dequantisation + iDCT + postfilter exactly once:
+260 610 transform blocks per frame (173 910 luma + 2 x 43 350 chroma).  The
+metric counts those blocks.  Entropy coding / rate pricing stay on the host in
+the reference's own C (SURVEY.md hard part 1) and are not part of the step; the
+choice between PVQ candidates is therefore made on distortion alone.
+
+N > 1: frames are sharded over ranks (independent all-intra frames, no
+data-path collective) -> weak scaling, F frames per GPU.
+
+Prints ONE JSON line (rank 0).  `roofline` is for the kernel that dominates the
+step; `kernels` lists every kernel class of the step the same way.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+W, H, PIC_W, PIC_H = 1920, 1088, 1920, 1080
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def blocks_per_frame():
+    luma = sum((W // (4 << bs)) * (H // (4 << bs)) for bs in range(5))
+    chroma = sum(((W // 2) // (4 << bs)) * ((H // 2) // (4 << bs)) for bs in range(4))
+    return luma + 2 * chroma
+
+
+def synth_frames(nframes, seed, device):
+    """Synthetic content: low-pass texture + edges + noise (no media exists in
+    the reference tree or this image).  Generated on the GPU, kept in HBM."""
+    import torch
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    out = []
+    for (w, h) in ((W, H), (W // 2, H // 2), (W // 2, H // 2)):
+        yy, xx = torch.meshgrid(torch.arange(h, device=device), torch.arange(w, device=device),
+                                indexing="ij")
+        planes = []
+        for f in range(nframes):
+            base = 128 + 60 * torch.sin((xx + 7 * f) * (6.283 / 97.0)) * torch.cos(yy * (6.283 / 61.0))
+            checker = ((((xx + 3 * f) // 32) + (yy // 32)) % 2) * 40 - 20
+            noise = torch.randint(-12, 13, (h, w), generator=g, device=device)
+            planes.append((base + checker + noise).clamp(0, 255).to(torch.uint8))
+        out.append(torch.stack(planes))
+    luma = out[0]
+    chroma = torch.cat([out[1], out[2]])  # 2F planes: all Cb then all Cr
+    return luma.contiguous(), chroma.contiguous()
+
+
+class Pipeline:
+    """The GPU step.  All buffers are allocated once; a step only launches
+    kernels: 2 pyramid launches, 3 + 2 multi-job PVQ launches covering all nine
+    (plane set, level) jobs, and 2 inverse launches per job."""
+
+    def __init__(self, D, nframes, device):
+        import torch
+        self.D = D
+        self.torch = torch
+        self.F = nframes
+        self.qt = D.QuantTables.load()
+        self.lam = D.OD_PVQ_LAMBDA
+        self.luma, self.chroma = synth_frames(nframes, 1234 + int(os.environ.get("RANK", 0)), device)
+        self.sets = []
+        self.jobs = []
+        for name, px, dec, pli in (("luma", self.luma, 0, 0), ("chroma", self.chroma, 1, 1)):
+            levels = D.forward_pyramid(px, dec, PIC_W, PIC_H)
+            s = dict(name=name, px=px, dec=dec, pli=pli, levels=levels, jobs=[],
+                     recon=torch.empty_like(px))
+            for bs in range(5 - dec):
+                qm, qmi = self.qt.qm_slices(pli, bs)
+                job = D.PvqJob(levels[bs], bs, torch.from_numpy(qm).to(device),
+                               torch.from_numpy(qmi).to(device), self.qt.q_band(pli, bs),
+                               self.qt.beta_band(pli, bs), dq=torch.empty_like(levels[bs]))
+                s["jobs"].append(job)
+                self.jobs.append(job)
+            self.sets.append(s)
+        self.timers = {}
+
+    def _timed(self, key, fn, record):
+        if not record:
+            return fn()
+        t = self.torch
+        a = t.cuda.Event(enable_timing=True)
+        b = t.cuda.Event(enable_timing=True)
+        a.record()
+        r = fn()
+        b.record()
+        self.timers.setdefault(key, []).append((a, b))
+        return r
+
+    def step(self, record=False):
+        D = self.D
+        for s in self.sets:
+            self._timed("forward_pyramid_" + s["name"],
+                        lambda: D.forward_pyramid(s["px"], s["dec"], PIC_W, PIC_H,
+                                                  levels=s["levels"]), record)
+        self._timed("pvq_noref_bands", lambda: D.pvq_noref_bands_multi(self.jobs, self.lam),
+                    record)
+        self._timed("pvq_select_synth",
+                    lambda: D.pvq_select_synth_noref_multi(self.jobs, self.lam), record)
+        for s in self.sets:
+            for job in s["jobs"]:
+                self._timed("inverse_level_" + s["name"],
+                            lambda: D.inverse_level(job.dq, s["dec"], job.bs, PIC_W, PIC_H,
+                                                    out=s["recon"]), record)
+
+    def kernel_ms(self):
+        """Average milliseconds per launch group and groups per run, per class."""
+        out = {}
+        for key, evs in self.timers.items():
+            ms = [a.elapsed_time(b) for a, b in evs]
+            out[key] = (float(np.mean(ms)), len(ms))
+        return out
+
+
+def algorithmic_bytes(F):
+    """SURVEY.md 8(d) per-unit figures x units per launch."""
+    luma_px = F * W * H
+    chroma_px = 2 * F * (W // 2) * (H // 2)
+    # PVQ band stage, per band of n coefficients: 4n B coefficients in, two
+    # candidates x 4n B pulses + 64 B scalars out (2n + 4n +
+    # 32 B for the bare search); choice + synthesis: 4n B pulses in, 4n B
+    # dequantised coefficients out + 64 B scalars.  All nine (plane set, level)
+    # jobs of a step run in one multi-job launch group.
+    nbands = [1, 4, 7, 9, 9]
+    coded = [15, 63, 255, 511, 511]
+    bands_b = 0
+    synth_b = 0
+    for (w, h, planes, top) in ((W, H, F, 4), (W // 2, H // 2, 2 * F, 3)):
+        for bs in range(top + 1):
+            nblk = planes * (w // (4 << bs)) * (h // (4 << bs))
+            bands_b += nblk * (12 * coded[bs] + 64 * nbands[bs])
+            synth_b += nblk * (8 * coded[bs] + 64 * nbands[bs])
+    return {
+        "forward_pyramid_luma": luma_px * 21,      # 1 B read + 5 levels x 4 B written
+        "forward_pyramid_chroma": chroma_px * 17,  # 1 B read + 4 levels x 4 B written
+        "inverse_level_luma": luma_px * 5,         # 4 B read + 1 B written
+        "inverse_level_chroma": chroma_px * 5,
+        "pvq_noref_bands": bands_b,    # one multi-job launch group per step
+        "pvq_select_synth": synth_b,
+    }
+
+
+def cpu_baseline(qt):
+    """The same per-block work on ONE host core with the reference's own C
+    functions (oracle/_ref, kind 'reference') or, when that library is absent,
+    the oracle port.  Bounded sample: a 1920x1088 luma plane + two 960x544 chroma
+    planes = one frame (about 10-20 s)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from _libs import P, oracle, ref, synth_frame
+    r = ref()
+    kind = "reference" if r is not None else "port"
+    planes = synth_frame(W, H, seed=4321)
+    blocks = 0
+    t0 = time.perf_counter()
+    for pli, px, dec in ((0, planes[0], 0), (1, planes[1], 1), (2, planes[2], 1)):
+        p = 1 if pli else 0
+        h, w = px.shape
+        qm_off = (ctypes.c_int * 5)(*[int(qt.qm_offset[bs][p]) for bs in range(5)])
+        qb = (ctypes.c_int * 60)()
+        bb = (ctypes.c_int * 60)()
+        for bs in range(5):
+            for i, v in enumerate(qt.q_band(p, bs)):
+                qb[bs * 12 + i] = v
+            for i, v in enumerate(qt.beta_band(p, bs)):
+                bb[bs * 12 + i] = v
+        recon = np.zeros_like(px)
+        qm = np.ascontiguousarray(qt.qm)
+        qmi = np.ascontiguousarray(qt.qm_inv)
+        if r is not None:
+            r.ref_stage_plane.restype = ctypes.c_long
+            blocks += r.ref_stage_plane(P(px), w, w, h, dec, PIC_W, PIC_H, p, P(qm), P(qmi),
+                                        qm_off, qb, bb, ctypes.c_double(0.147), P(recon))
+        else:
+            o = oracle()
+            o.odo_stage_plane.restype = ctypes.c_long
+            blocks += o.odo_stage_plane(P(px), w, w, h, dec, PIC_W, PIC_H, p, P(qm), P(qmi),
+                                        qm_off, qb, bb, ctypes.c_double(0.147), 1, P(recon))
+    dt = time.perf_counter() - t0
+    return {"value": blocks / dt, "unit": "blocks/s", "cores": 1, "kind": kind,
+            "sample": "1 synthetic 1920x1088 4:2:0 frame (%d blocks) in %.2f s, same per-block "
+                      "work as the GPU step, single thread" % (blocks, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--frames", type=int, default=8, help="1080p frames per GPU per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import daala_amd as D
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback exists)")
+    torch.cuda.set_device(local_rank)
+    D.init(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    device = torch.device("cuda", local_rank)
+
+    pipe = Pipeline(D, args.frames, device)
+    for _ in range(args.warmup):
+        pipe.step()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        pipe.step(record=True)
+    torch.cuda.synchronize()
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        bpf = blocks_per_frame()
+        total_blocks = world * args.frames * args.steps * bpf
+        kms = pipe.kernel_ms()
+        ab = algorithmic_bytes(args.frames)
+        kernels = {}
+        for key, (ms, count) in kms.items():
+            ent = {"avg_ms_per_launch": round(ms, 4), "launches": count,
+                   "share_of_step": round(ms * count / args.steps / (dt / args.steps * 1e3), 4)}
+            if key in ab:
+                ent["algorithmic_bytes_per_launch"] = ab[key]
+                ent["achieved_GBs"] = round(ab[key] / (ms * 1e-3) / 1e9, 1)
+                ent["frac_of_hbm_peak"] = round(ent["achieved_GBs"] / HBM_PEAK_GBS, 4)
+            kernels[key] = ent
+        # roofline = the kernel class that takes the largest share of the step.
+        dom = max(kernels, key=lambda k_: kernels[k_]["share_of_step"])
+        roof = {"kernel": dom, "bound": "hbm",
+                "achieved": kernels[dom]["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": kernels[dom]["frac_of_hbm_peak"], "traffic": None,
+                "algorithmic_bytes_per_launch": ab[dom]}
+        line = {
+            "metric": "1080p all-intra transform blocks/s (filter+DCT+PVQ)",
+            "value": total_blocks / dt,
+            "unit": "blocks/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "int32 (lifting DCT/filters) + f64 (PVQ search)",
+            "data": "synthetic",
+            "config": {"workload": "configs[1]: 1920x1080 4:2:0 all-intra frames, full "
+                       "4/8/16/32/64 lapped-DCT pyramid + PVQ noref bands + inverse, "
+                       "every block of every level",
+                       "frames_per_gpu_per_step": args.frames,
+                       "blocks_per_frame": bpf, "quality": "-v 20 (quantizer 243)",
+                       "sharding": "frames over ranks, no data-path collective"},
+            "roofline": roof,
+            "kernels": kernels,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(pipe.qt)
+            line["speedup_vs_cpu_baseline"] = line["value"] / line["cpu_baseline"]["value"]
+        print(json.dumps(line))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

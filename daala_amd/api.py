@@ -193,9 +193,20 @@ host = _Host()
 
 
 # ---- PVQ band stage -----------------------------------------------------------
+_CAND_FIELDS = ("cg", "dist0", "gain", "k", "flags", "yy", "cos_dist", "dist", "y", "choice")
+
+
 class _Cands(ctypes.Structure):
-    _fields_ = [(n, ctypes.c_void_p) for n in
-                ("cg", "dist0", "gain", "k", "flags", "cos_dist", "dist", "y")]
+    _fields_ = [(n, ctypes.c_void_p) for n in _CAND_FIELDS]
+
+
+class _Job(ctypes.Structure):
+    _fields_ = [("d_coef", ctypes.c_void_p), ("nplanes", ctypes.c_int), ("w", ctypes.c_int),
+                ("h", ctypes.c_int), ("bs", ctypes.c_int), ("d_qm", ctypes.c_void_p),
+                ("d_qm_inv", ctypes.c_void_p), ("q_band", ctypes.POINTER(ctypes.c_int32)),
+                ("beta_band", ctypes.POINTER(ctypes.c_int32)), ("cands", _Cands),
+                ("d_dq", ctypes.c_void_p), ("d_rate", ctypes.c_void_p),
+                ("d_qg", ctypes.c_void_p)]
 
 
 def pvq_band_layout(bs):
@@ -206,10 +217,6 @@ def pvq_band_layout(bs):
     _check(lib().odhip_pvq_band_layout(int(bs), ctypes.byref(nb), offs, ctypes.byref(ln)),
            "odhip_pvq_band_layout")
     return nb.value, [offs[i] for i in range(nb.value + 1)], ln.value
-
-
-def _cands_struct(c):
-    return _Cands(*[ctypes.c_void_p(c[n].data_ptr()) for n, _ in _Cands._fields_])
 
 
 def alloc_pvq_cands(nblocks, bs, device):
@@ -223,63 +230,84 @@ def alloc_pvq_cands(nblocks, bs, device):
         "gain": torch.empty((nblocks, nb, 2), **i32),
         "k": torch.empty((nblocks, nb, 2), **i32),
         "flags": torch.empty((nblocks, nb, 2), **i32),
+        "yy": torch.empty((nblocks, nb, 2), **i32),
         "cos_dist": torch.empty((nblocks, nb, 2), **f64),
         "dist": torch.empty((nblocks, nb, 2), **f64),
         "y": torch.zeros((2, nblocks, ln), **i32),
+        "choice": torch.empty((nblocks, nb, 4), **i32),
     }
 
 
-def _band_arrays(q_band, beta_band, nb):
-    q = (ctypes.c_int32 * 12)(*[int(v) for v in q_band])
-    b = (ctypes.c_int32 * 12)(*[int(v) for v in beta_band])
-    assert len(q_band) == nb and len(beta_band) == nb
-    return q, b
+class PvqJob:
+    """One (plane set, block size) unit of the PVQ band stage; keeps every
+    tensor and host array it points to alive."""
+
+    def __init__(self, coef, bs, qm, qm_inv, q_band, beta_band, cands=None, dq=None,
+                 rate=None, qg=None):
+        import torch
+        _need(coef, torch.int32, "coef")
+        self.coef, self.bs, self.qm, self.qm_inv = coef, int(bs), qm, qm_inv
+        nplanes, h, w = coef.shape
+        n = 4 << bs
+        self.nblocks = nplanes * (h // n) * (w // n)
+        nb = pvq_band_layout(bs)[0]
+        assert len(q_band) == nb and len(beta_band) == nb
+        self.q_band = (ctypes.c_int32 * 12)(*[int(v) for v in q_band])
+        self.beta_band = (ctypes.c_int32 * 12)(*[int(v) for v in beta_band])
+        self.cands = cands if cands is not None else alloc_pvq_cands(self.nblocks, bs,
+                                                                     coef.device)
+        self.dq, self.rate, self.qg = dq, rate, qg
+        for t, dt, what in ((qm, torch.int16, "qm"), (qm_inv, torch.int16, "qm_inv"),
+                            (dq, torch.int32, "dq"), (rate, torch.float64, "rate"),
+                            (qg, torch.int32, "qg")):
+            if t is not None:
+                _need(t, dt, what)
+
+    def struct(self):
+        opt = lambda t: ctypes.c_void_p(t.data_ptr() if t is not None else None)  # noqa: E731
+        nplanes, h, w = self.coef.shape
+        c = _Cands(*[ctypes.c_void_p(self.cands[n].data_ptr()) for n in _CAND_FIELDS])
+        return _Job(_p(self.coef), nplanes, w, h, self.bs, opt(self.qm), opt(self.qm_inv),
+                    self.q_band, self.beta_band, c, opt(self.dq), opt(self.rate), opt(self.qg))
+
+
+def _jobs_array(jobs):
+    arr = (_Job * len(jobs))()
+    for i, j in enumerate(jobs):
+        arr[i] = j.struct()
+    return arr
+
+
+def pvq_noref_bands_multi(jobs, pvq_norm_lambda):
+    """The adaptation-independent part of pvq_theta (no-reference path) for every
+    block and band of every job, in one set of launches."""
+    _check(lib().odhip_pvq_noref_bands_multi(_jobs_array(jobs), len(jobs),
+                                             ctypes.c_double(pvq_norm_lambda), _stream()),
+           "odhip_pvq_noref_bands_multi")
+
+
+def pvq_select_synth_noref_multi(jobs, pvq_norm_lambda):
+    """Choice (`cost <= best_cost`, cost = dist + lambda*rate) + decoder-identical
+    dequantisation into each job's dq plane."""
+    _check(lib().odhip_pvq_select_synth_noref_multi(_jobs_array(jobs), len(jobs),
+                                                    ctypes.c_double(pvq_norm_lambda),
+                                                    _stream()),
+           "odhip_pvq_select_synth_noref_multi")
 
 
 def pvq_noref_bands(coef, bs, qm, q_band, beta_band, pvq_norm_lambda, out=None):
-    """The adaptation-independent part of pvq_theta (no-reference path) for every
-    block of side 4 << bs of coef (int32 [nplanes, h, w]) and every band."""
-    import torch
-    _need(coef, torch.int32, "coef")
-    _need(qm, torch.int16, "qm")
-    nplanes, h, w = coef.shape
-    n = 4 << bs
-    nblocks = nplanes * (h // n) * (w // n)
-    nb, _, _ = pvq_band_layout(bs)
-    if out is None:
-        out = alloc_pvq_cands(nblocks, bs, coef.device)
-    q, b = _band_arrays(q_band, beta_band, nb)
-    st = _cands_struct(out)
-    _check(lib().odhip_pvq_noref_bands(_p(coef), nplanes, w, h, int(bs), _p(qm), q, b,
-                                       ctypes.c_double(pvq_norm_lambda), ctypes.byref(st),
-                                       _stream()), "odhip_pvq_noref_bands")
-    return out
+    job = PvqJob(coef, bs, qm, None, q_band, beta_band, cands=out)
+    pvq_noref_bands_multi([job], pvq_norm_lambda)
+    return job.cands
 
 
 def pvq_select_synth_noref(coef, bs, qm_inv, q_band, beta_band, pvq_norm_lambda, cands,
                            rate=None, dq=None, qg=None):
-    """Choice (`cost <= best_cost`, cost = dist + lambda*rate) + decoder-identical
-    dequantisation into a coefficient plane.  Returns (dq, qg)."""
     import torch
-    _need(coef, torch.int32, "coef")
-    _need(qm_inv, torch.int16, "qm_inv")
-    nplanes, h, w = coef.shape
-    n = 4 << bs
-    nblocks = nplanes * (h // n) * (w // n)
-    nb, _, _ = pvq_band_layout(bs)
     if dq is None:
         dq = torch.empty_like(coef)
     if qg is None:
-        qg = torch.empty((nblocks, nb), dtype=torch.int32, device=coef.device)
-    q, b = _band_arrays(q_band, beta_band, nb)
-    st = _cands_struct(cands)
-    pr = ctypes.c_void_p(None)
-    if rate is not None:
-        _need(rate, torch.float64, "rate")
-        pr = _p(rate)
-    _check(lib().odhip_pvq_select_synth_noref(_p(dq), _p(coef), nplanes, w, h, int(bs),
-                                              _p(qm_inv), q, b,
-                                              ctypes.c_double(pvq_norm_lambda),
-                                              ctypes.byref(st), pr, _p(qg), _stream()),
-           "odhip_pvq_select_synth_noref")
+        qg = torch.empty(tuple(cands["cg"].shape), dtype=torch.int32, device=coef.device)
+    job = PvqJob(coef, bs, None, qm_inv, q_band, beta_band, cands=cands, dq=dq, rate=rate, qg=qg)
+    pvq_select_synth_noref_multi([job], pvq_norm_lambda)
     return dq, qg

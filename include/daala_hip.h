@@ -187,11 +187,43 @@ typedef struct {
   int32_t *gain;      /* [B][nb][2] candidate gain index i; 0 = slot unused     */
   int32_t *k;         /* [B][nb][2] pulses (od_pvq_compute_k)                   */
   int32_t *flags;     /* [B][nb][2] 1 = searched, 0 = pruned / unused           */
+  int32_t *yy;        /* [B][nb][2] sum of squared pulses of the candidate      */
   double *cos_dist;   /* [B][nb][2] return value of pvq_search_rdo_double       */
   double *dist;       /* [B][nb][2] distortion of the candidate                 */
   od_coeff *y;        /* [2][B][len] pulse vectors in coding order (index 0 = DC
                          slot, unused), len = min(N*N, 512)                     */
+  int32_t *choice;    /* [B][nb][4] written by odhip_pvq_select_synth_noref*:
+                         {chosen slot, chosen gain index qg (0 = null), synthesis
+                         scale, qshift}; 16-byte aligned                        */
 } odhip_pvq_cands;
+
+/* One (plane set, block size) unit of work for the multi-job entry points.
+   q_band / beta_band are HOST arrays [nb_bands]; everything prefixed d_ and the
+   arrays inside `cands` are device memory.  d_qm is needed by the band stage,
+   d_qm_inv and d_dq by select_synth; d_rate and d_qg are optional (NULL). */
+typedef struct {
+  const od_coeff *d_coef;
+  int nplanes;
+  int w;
+  int h;
+  int bs;
+  const int16_t *d_qm;
+  const int16_t *d_qm_inv;
+  const int32_t *q_band;
+  const int32_t *beta_band;
+  odhip_pvq_cands cands;
+  od_coeff *d_dq;
+  const double *d_rate;
+  int32_t *d_qg;
+} odhip_pvq_job;
+
+/* All jobs (at most 16) in one set of launches, so that small levels (510
+   64x64 blocks per frame) overlap with large ones instead of serialising their
+   tails.  Jobs of one call must use one stream. */
+int odhip_pvq_noref_bands_multi(const odhip_pvq_job *jobs, int njobs,
+ double pvq_norm_lambda, odhip_stream stream);
+int odhip_pvq_select_synth_noref_multi(const odhip_pvq_job *jobs, int njobs,
+ double pvq_norm_lambda, odhip_stream stream);
 
 /* nb_bands, offsets[nb_bands+1] and len for block size bs. */
 int odhip_pvq_band_layout(int bs, int *nb_bands, int *offsets, int *len);

@@ -1274,3 +1274,103 @@ double odo_now(void) {
   clock_gettime(CLOCK_MONOTONIC, &ts);
   return ts.tv_sec + 1e-9*ts.tv_nsec;
 }
+
+/* The whole hot-path stage on one plane with the oracle's functions: the CPU
+   "port" timed by bench.py when oracle/_ref is not available, and the
+   end-to-end checker of the GPU step.  Mirrors ref_stage_plane in ref_shim.c.
+   The choice between candidates uses `cost <= best_cost` with cost = dist when
+   rate_mode == 0 (what the GPU bench step does without a host entropy model)
+   or the closed-form rate of od_pvq_rate (speed > 0) when rate_mode == 1. */
+long odo_stage_plane(const uint8_t *px, int px_stride, int w, int h, int dec,
+ int pic_w, int pic_h, int pli, const int16_t *qm, const int16_t *qm_inv,
+ const int *qm_off, const int *q_band, const int *beta_band,
+ double pvq_norm_lambda, int rate_mode, uint8_t *recon_px) {
+  odo_coeff *levels[ODO_NBSIZES];
+  odo_coeff *c;
+  odo_coeff *dq;
+  long nblocks;
+  int top;
+  int bs;
+  top = ODO_NBSIZES - 1 - dec;
+  nblocks = 0;
+  c = (odo_coeff *)malloc(sizeof(*c)*w*h);
+  dq = (odo_coeff *)malloc(sizeof(*dq)*w*h);
+  for (bs = 0; bs <= top; bs++) levels[bs] = (odo_coeff *)malloc(sizeof(*c)*w*h);
+  odo_forward_pyramid_plane(levels, c, px, px_stride, w, h, dec, pic_w, pic_h);
+  for (bs = 0; bs <= top; bs++) {
+    int n;
+    int bx;
+    int by;
+    int nb;
+    const int *off;
+    n = 4 << bs;
+    nb = OD_NBANDS[bs];
+    off = OD_BAND_OFFS[bs];
+    memset(dq, 0, sizeof(*dq)*w*h);
+    for (by = 0; by < h/n; by++) {
+      for (bx = 0; bx < w/n; bx++) {
+        odo_coeff in[512];
+        odo_coeff out[512];
+        odo_coeff ref0[128];
+        odo_coeff y[128];
+        double skip_diff;
+        int i;
+        int bo;
+        bo = by*n*w + bx*n;
+        odo_raster_to_coding_order(in, n, levels[bs] + bo, w);
+        memset(ref0, 0, sizeof(ref0));
+        skip_diff = 0;
+        for (i = 0; i < nb; i++) {
+          int m;
+          int itheta;
+          int max_theta;
+          int k;
+          m = off[i + 1] - off[i];
+          if (rate_mode) {
+            odo_pvq_theta(out + off[i], in + off[i], ref0, m, q_band[bs*12 + i], y,
+             &itheta, &max_theta, &k, beta_band[bs*12 + i], &skip_diff, 1, 1, pli,
+             qm + qm_off[bs] + off[i], qm_inv + qm_off[bs] + off[i],
+             pvq_norm_lambda, 1, NULL);
+          }
+          else {
+            /* distortion-only choice from the candidate trace */
+            static odo_pvq_band_trace tr;
+            double best;
+            int qg;
+            int sel;
+            int j;
+            odo_pvq_theta(out + off[i], in + off[i], ref0, m, q_band[bs*12 + i], y,
+             &itheta, &max_theta, &k, beta_band[bs*12 + i], &skip_diff, 1, 1, 0,
+             qm + qm_off[bs] + off[i], qm_inv + qm_off[bs] + off[i],
+             pvq_norm_lambda, 1, &tr);
+            best = tr.dist0;
+            qg = 0;
+            sel = -1;
+            for (j = 0; j < tr.ncands; j++) {
+              if (tr.cands[j].with_ref || !tr.cands[j].searched) continue;
+              if (tr.cands[j].dist <= best) {
+                best = tr.cands[j].dist;
+                qg = tr.cands[j].gain;
+                sel = j;
+              }
+            }
+            if (qg == 0) memset(out + off[i], 0, m*sizeof(*out));
+            else {
+              odo_pvq_synthesis_partial(out + off[i], tr.cands[sel].y, NULL, m, 1,
+               odo_gain_expand(qg << 8, q_band[bs*12 + i], beta_band[bs*12 + i]),
+               0, 0, 1, qm_inv + qm_off[bs] + off[i]);
+            }
+          }
+        }
+        out[0] = in[0];
+        odo_coding_order_to_raster(dq + bo, w, out, n);
+        nblocks++;
+      }
+    }
+    odo_inverse_level_plane(recon_px, w, c, dq, w, h, dec, bs, pic_w, pic_h);
+  }
+  for (bs = 0; bs <= top; bs++) free(levels[bs]);
+  free(dq);
+  free(c);
+  return nblocks;
+}

@@ -111,6 +111,14 @@ int odo_pvq_theta(odo_coeff *out, const odo_coeff *x0, const odo_coeff *r0, int 
  int is_keyframe, int pli, const int16_t *qm, const int16_t *qm_inv, double pvq_norm_lambda,
  int speed, odo_pvq_band_trace *trace);
 
+/* The whole stage on one plane (forward pyramid, PVQ noref bands of every block
+   at every level, dequantisation, inverse at every level): the CPU "port" that
+   bench.py times when oracle/_ref is absent.  rate_mode 0 = distortion-only
+   choice (what the GPU bench step does), 1 = od_pvq_rate closed form. */
+long odo_stage_plane(const uint8_t *px, int px_stride, int w, int h, int dec, int pic_w, int pic_h,
+ int pli, const int16_t *qm, const int16_t *qm_inv, const int *qm_off, const int *q_band,
+ const int *beta_band, double pvq_norm_lambda, int rate_mode, uint8_t *recon_px);
+
 double odo_now(void);
 
 #ifdef __cplusplus

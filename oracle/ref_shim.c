@@ -360,3 +360,79 @@ REF_EXPORT double ref_now(void) {
   clock_gettime(CLOCK_MONOTONIC, &ts);
   return ts.tv_sec + 1e-9*ts.tv_nsec;
 }
+
+/* ---- the whole hot-path stage on one plane, with the reference's functions --
+   Same work per block as bench.py's GPU step, so the two can be timed side by
+   side (cpu_baseline.kind == "reference"):
+     forward pyramid (above), then for every level bs and every block:
+       od_raster_to_coding_order, pvq_theta per band on the no-reference keyframe
+       path (speed = 1: closed-form rate), od_coding_order_to_raster,
+     then iDCT + post-filters + pixels at that level (ref_inverse_level_plane).
+   q_band/beta_band: [5][12] per-band quantiser and beta; qm/qm_inv: coding-order
+   tables for this plane's decimation, one slice per bs at qm_off[bs].
+   Returns the number of transform blocks processed. */
+REF_EXPORT long ref_stage_plane(unsigned char *px, int px_stride, int w, int h,
+ int dec, int pic_w, int pic_h, int pli, const int16_t *qm, const int16_t *qm_inv,
+ const int *qm_off, const int *q_band, const int *beta_band,
+ double pvq_norm_lambda, unsigned char *recon_px) {
+  od_coeff *levels[OD_NBSIZES];
+  od_coeff *c;
+  od_coeff *dq;
+  od_adapt_ctx *adapt;
+  long nblocks;
+  int top;
+  int bs;
+  top = OD_NBSIZES - 1 - dec;
+  nblocks = 0;
+  c = (od_coeff *)malloc(sizeof(*c)*w*h);
+  dq = (od_coeff *)malloc(sizeof(*dq)*w*h);
+  adapt = (od_adapt_ctx *)calloc(1, sizeof(*adapt));
+  od_adapt_pvq_ctx_reset(&adapt->pvq, 1);
+  for (bs = 0; bs <= top; bs++) levels[bs] = (od_coeff *)malloc(sizeof(*c)*w*h);
+  ref_forward_pyramid_plane(levels, c, px, px_stride, w, h, dec, pic_w, pic_h);
+  for (bs = 0; bs <= top; bs++) {
+    int n;
+    int bx;
+    int by;
+    int nb;
+    const int *off;
+    n = 4 << bs;
+    nb = OD_BAND_OFFSETS[bs][0];
+    off = &OD_BAND_OFFSETS[bs][1];
+    for (by = 0; by < h/n; by++) {
+      for (bx = 0; bx < w/n; bx++) {
+        od_coeff in[OD_BSIZE_MAX*OD_BSIZE_MAX];
+        od_coeff out[OD_BSIZE_MAX*OD_BSIZE_MAX];
+        od_coeff ref0[OD_BSIZE_MAX*OD_BSIZE_MAX];
+        od_coeff y[OD_BSIZE_MAX*OD_BSIZE_MAX];
+        double skip_diff;
+        int i;
+        int bo;
+        bo = by*n*w + bx*n;
+        od_raster_to_coding_order(in, n, levels[bs] + bo, w);
+        memset(ref0, 0, sizeof(*ref0)*n*n);
+        skip_diff = 0;
+        for (i = 0; i < nb; i++) {
+          int itheta;
+          int max_theta;
+          int k;
+          pvq_theta(out + off[i], in + off[i], ref0 + off[i], off[i + 1] - off[i],
+           q_band[bs*12 + i], y + off[i], &itheta, &max_theta, &k,
+           (od_val16)beta_band[bs*12 + i], &skip_diff, 1, 1, pli, adapt,
+           qm + qm_off[bs] + off[i], qm_inv + qm_off[bs] + off[i],
+           pvq_norm_lambda, 1);
+        }
+        out[0] = in[0];
+        od_init_skipped_coeffs(dq, NULL, 1, bo, n, w);
+        od_coding_order_to_raster(dq + bo, w, out, n);
+        nblocks++;
+      }
+    }
+    ref_inverse_level_plane(recon_px, w, c, dq, w, h, dec, bs, pic_w, pic_h);
+  }
+  for (bs = 0; bs <= top; bs++) free(levels[bs]);
+  free(adapt);
+  free(dq);
+  free(c);
+  return nblocks;
+}

@@ -76,6 +76,8 @@ def test_band_stage_matches_oracle(hip, pli, dec):
         nb, offs, ln = hip.pvq_band_layout(bs)
         tc = _cuda(coef[None])
         cands = hip.pvq_noref_bands(tc, bs, _cuda(qm), qb, bb, lam)
+        import torch
+        torch.cuda.synchronize()
         dq, qg = hip.pvq_select_synth_noref(tc, bs, _cuda(qmi), qb, bb, lam, cands)
         c = {k_: v.cpu().numpy() for k_, v in cands.items()}
         dq = dq.cpu().numpy()[0]
