@@ -345,21 +345,33 @@ __global__ __launch_bounds__(256) void k_synth(Items it) {
   __shared__ unsigned char s_band[OD_SCAN_LEN];
   for (int i = threadIdx.x; i < 32*32; i += 256) s_inv[i] = gInvScan[i];
   for (int i = threadIdx.x; i < OD_SCAN_LEN; i += 256) s_band[i] = gBandOf[i];
+  /* One workgroup = one 1024-coefficient segment of one plane row: the
+     decomposition of the workgroup index is scalar (once per wave), the
+     per-lane one is shifts only. */
+  __shared__ int4 s_choice[256*ODHIP_MAX_BANDS/4];  /* <= 1024/N blocks x nb bands */
+  const int segs = (jb.w + 1023) >> 10;
+  const int wg = blockIdx.x - it.wg_start[item];
+  const int seg = wg % segs;
+  const int prow = wg / segs;                 /* plane * h + y */
+  const int y = prow % jb.h;
+  const int p = prow / jb.h;
+  const int sh = jb.bs + 2;
+  const int N = 1 << sh;
+  const int by = y >> sh;
+  const int ly = y & (N - 1);
+  const int x0 = seg << 10;
+  const int bx0 = x0 >> sh;
+  const int nbx = min(1024 >> sh, jb.bw - bx0);    /* blocks this segment touches */
+  const long blk0 = ((long)p*jb.bh + by)*jb.bw + bx0;
+  for (int i = threadIdx.x; i < nbx*jb.nb_bands; i += 256) {
+    s_choice[i] = reinterpret_cast<const int4 *>(jb.c.choice)[blk0*jb.nb_bands + i];
+  }
   __syncthreads();
-  const long t = (long)(blockIdx.x - it.wg_start[item])*256 + threadIdx.x;
-  const long total = (long)jb.nplanes*jb.w*jb.h/4;
-  if (t >= total) return;
-  const int w4 = jb.w/4;
-  const int p = (int)(t/((long)w4*jb.h));
-  const int rem = (int)(t - (long)p*w4*jb.h);
-  const int y = rem/w4;
-  const int x = (rem - y*w4)*4;
-  const int N = 4 << jb.bs;
-  const int by = y/N;
-  const int bx = x/N;
-  const int ly = y - by*N;
-  const int lx = x - bx*N;
-  const long blk = ((long)p*jb.bh + by)*jb.bw + bx;
+  const int x = x0 + threadIdx.x*4;
+  if (x >= jb.w) return;
+  const int bxl = (x >> sh) - bx0;
+  const int lx = x & (N - 1);
+  const long blk = blk0 + bxl;
   const long idx = (long)p*jb.w*jb.h + (long)y*jb.w + x;
   int out[4];
 #pragma unroll
@@ -370,7 +382,7 @@ __global__ __launch_bounds__(256) void k_synth(Items it) {
       if (j == 0) v = jb.coef[idx];
       else if (j > 0 && j < jb.len) {
         const int band = s_band[j];
-        const int4 ch = reinterpret_cast<const int4 *>(jb.c.choice)[blk*jb.nb_bands + band];
+        const int4 ch = s_choice[bxl*jb.nb_bands + band];
         if (ch.y != 0) {
           const int yv = jb.c.y[((long)ch.x*jb.nblocks + blk)*jb.len + j];
           const int32_t xq = (int32_t)((int16_t)yv*(int64_t)ch.z >> 16);
@@ -541,7 +553,7 @@ extern "C" int odhip_pvq_select_synth_noref_multi(const odhip_pvq_job *jobs, int
   k_choose<<<it.wg_start[it.nitems], 256, 0, s>>>(it);
   items_begin(it, pvq_norm_lambda);
   for (int j = 0; j < njobs; j++) {
-    items_add(it, j, 0, ((long)host[j].nplanes*host[j].w*host[j].h/4 + 255)/256);
+    items_add(it, j, 0, (long)host[j].nplanes*host[j].h*((host[j].w + 1023) >> 10));
   }
   k_synth<<<it.wg_start[it.nitems], 256, 0, s>>>(it);
   return odhip_check_launch();
