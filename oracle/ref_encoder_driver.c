@@ -53,6 +53,21 @@ static const od_dct_func_2d REF_IDCT_COUNTED[OD_NBSIZES] = {
   ref_idct_counted_3, ref_idct_counted_4
 };
 
+/* Optional external transform tables installed in place of the C ones: this is
+   how the drop-in test binds libdaalahip's od_bin_*_hip entry points into the
+   UNMODIFIED reference encoder - the same ten slots od_state_opt_vtbl_init_x86
+   overwrites (src/x86/x86state.c:66-91).  NULL = keep the reference's. */
+static od_dct_func_2d ref_ext_fdct[OD_NBSIZES];
+static od_dct_func_2d ref_ext_idct[OD_NBSIZES];
+
+REF_EXPORT void ref_set_external_dct_vtbl(void **fdct, void **idct) {
+  int i;
+  for (i = 0; i < OD_NBSIZES; i++) {
+    ref_ext_fdct[i] = fdct ? (od_dct_func_2d)fdct[i] : NULL;
+    ref_ext_idct[i] = idct ? (od_dct_func_2d)idct[i] : NULL;
+  }
+}
+
 REF_EXPORT void ref_get_dct_call_counts(long *fdct, long *idct) {
   int i;
   for (i = 0; i < OD_NBSIZES; i++) {
@@ -102,6 +117,14 @@ REF_EXPORT int ref_encode_yuv420(const unsigned char *frames, int w, int h,
   daala_comment_init(&dc);
   daala_encode_ctl(enc, OD_SET_QUANT, &quality, sizeof(quality));
   daala_encode_ctl(enc, OD_SET_COMPLEXITY, &complexity, sizeof(complexity));
+  {
+    od_state *st;
+    st = (od_state *)enc;
+    for (i = 0; i < OD_NBSIZES; i++) {
+      if (ref_ext_fdct[i]) st->opt_vtbl.fdct_2d[i] = ref_ext_fdct[i];
+      if (ref_ext_idct[i]) st->opt_vtbl.idct_2d[i] = ref_ext_idct[i];
+    }
+  }
   if (count_calls) {
     od_state *state;
     state = (od_state *)enc;

@@ -1,0 +1,52 @@
+"""GPU drop-in test: the UNMODIFIED reference encoder (oracle/_ref, built from
+the reference's own sources) with libdaalahip's od_bin_{f,i}dctNxN_hip bound into
+its od_state_opt_vtbl.fdct_2d/idct_2d slots produces byte-identical packets.
+
+Skipped when oracle/_ref is not present on the box (it is a prebuilt file that
+travels with the snapshot; /root/reference itself is never read here)."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from _libs import P, ref, synth_frame
+
+pytestmark = pytest.mark.gpu
+
+
+def _encode(r, frames, w, h, nframes, quality=20, complexity=7, count=0):
+    out = np.zeros(4 << 20, np.uint8)
+    sizes = (ctypes.c_long * 64)()
+    n = r.ref_encode_yuv420(P(frames), w, h, nframes, quality, complexity, count, P(out),
+                            ctypes.c_long(out.size), sizes)
+    assert n == nframes, n
+    total = sum(sizes[i] for i in range(n))
+    return bytes(out[:total]), [sizes[i] for i in range(n)]
+
+
+@pytest.mark.skipif(ref() is None, reason="oracle/_ref not present")
+def test_reference_encoder_with_hip_transforms_is_byte_identical():
+    import torch
+    import daala_amd
+    assert torch.cuda.is_available()
+    daala_amd.init(0)
+    L = daala_amd.lib()
+    r = ref()
+    w = h = 64
+    nframes = 2
+    frames = np.concatenate([np.concatenate([p.ravel() for p in synth_frame(w, h, seed=7, phase=5 * f)])
+                             for f in range(nframes)]).astype(np.uint8)
+    r.ref_set_external_dct_vtbl(None, None)
+    want, sizes_c = _encode(r, frames, w, h, nframes)
+    fd = (ctypes.c_void_p * 5)()
+    idt = (ctypes.c_void_p * 5)()
+    L.odhip_install_dct_vtbl(fd, idt)
+    assert all(fd[i] and idt[i] for i in range(5))
+    r.ref_set_external_dct_vtbl(fd, idt)
+    try:
+        got, sizes_h = _encode(r, frames, w, h, nframes, count=0)
+    finally:
+        r.ref_set_external_dct_vtbl(None, None)
+    assert sizes_h == sizes_c
+    assert got == want, "packets differ between the C and the HIP transform tables"
+    assert len(want) > 200
