@@ -30,7 +30,10 @@ namespace {
 
 template <int TILE>
 struct Geo {
-  static constexpr int kNT = TILE*TILE/16;
+#ifndef OD_PYR_NT64
+#define OD_PYR_NT64 256
+#endif
+  static constexpr int kNT = TILE == 64 ? OD_PYR_NT64 : TILE*TILE/16;
   static constexpr int kPitch = TILE + 4;
   /* Tile with a 2-sample halo: rows/cols -2,-1 live at TILE, TILE+1 and rows/
      cols TILE, TILE+1 at TILE+2, TILE+3 (the halo columns occupy the pitch
@@ -54,25 +57,25 @@ struct PyramidArgs {
 };
 
 /* 4-point filter across 4 LDS words a, a+step, a+2*step, a+3*step. */
-template <bool INV>
-__device__ __forceinline__ void lds_filter4(int *p, int step) {
+template <bool INV, typename E>
+__device__ __forceinline__ void lds_filter4(E *p, int step) {
   int t0 = p[0];
   int t1 = p[step];
   int t2 = p[2*step];
   int t3 = p[3*step];
   if constexpr (INV) od_post_filter4_dev(t0, t1, t2, t3);
   else od_pre_filter4_dev(t0, t1, t2, t3);
-  p[0] = t0;
-  p[step] = t1;
-  p[2*step] = t2;
-  p[3*step] = t3;
+  p[0] = (E)t0;
+  p[step] = (E)t1;
+  p[2*step] = (E)t2;
+  p[3*step] = (E)t3;
 }
 
 /* Column-direction half of od_prefilter_split / od_postfilter_split for every
    level-LN block of the tile: taps across the horizontal mid-line, gated by
    `hfilter` (derived from the block's x index, src/encode.c:1487). */
-template <int TILE, int LN, bool INV>
-__device__ __forceinline__ void split_filter_cols(int *t, int tid, int x0, int pic_w) {
+template <int TILE, int LN, bool INV, typename E>
+__device__ __forceinline__ void split_filter_cols(E *t, int tid, int x0, int pic_w) {
   constexpr int N = 4 << LN;
   constexpr int P = Geo<TILE>::kPitch;
   constexpr int NT = Geo<TILE>::kNT;
@@ -86,8 +89,8 @@ __device__ __forceinline__ void split_filter_cols(int *t, int tid, int x0, int p
 
 /* Row-direction half: taps across the vertical mid-line, gated by `vfilter`
    (from the block's y index, src/encode.c:1488). */
-template <int TILE, int LN, bool INV>
-__device__ __forceinline__ void split_filter_rows(int *t, int tid, int y0, int pic_h) {
+template <int TILE, int LN, bool INV, typename E>
+__device__ __forceinline__ void split_filter_rows(E *t, int tid, int y0, int pic_h) {
   constexpr int N = 4 << LN;
   constexpr int P = Geo<TILE>::kPitch;
   constexpr int NT = Geo<TILE>::kNT;
@@ -112,18 +115,148 @@ __device__ __forceinline__ void store_tile(od_coeff *plane, int w, int x0, int y
   }
 }
 
+/* 64- and 32-point levels of a luma superblock: only 64 / 128 columns exist for
+   256 threads, so each column (and then each row) is shared by TWO lanes
+   running the even and the odd half network (od_fdct_lift_half), the halves
+   assigned wave-uniformly.  The intermediate is kept TRANSPOSED and in
+   parity-split order (position p' = (p & 1)*N/2 + (p >> 1)) at an odd pitch of
+   65 words, which makes every access of both passes and of the copy-out a
+   conflict-free ds_read/write_b32:
+     pass 1  lane (x, h):       reads t[.., x] down the column, writes
+                                zt[x][by*N + v'], v' in half h
+     pass 2  lane (c, bx, h):   reads zt[bx*N + i][c], i = 0..N-1, then (after a
+                                barrier: its partner reads the same words) writes
+                                zt[bx*N + u'][c], u' in half h
+     store   raster (y, x)  <-  zt[bx*N + u'(x)][by*N + v'(y)]                  */
+template <int LN>
+__device__ __forceinline__ void pyramid_level_split64(short *t, int *z, const PyramidArgs &a,
+ long plane_off, int x0, int y0, int tid) {
+  using T = OdMul24;
+  constexpr int TILE = 64;
+  constexpr int N = 4 << LN;
+  constexpr int H = N/2;
+  constexpr int PT = Geo<TILE>::kPitch;
+  constexpr int PZ = 65;
+  constexpr int kTasks = TILE*(TILE/N);
+  static_assert(kTasks % 64 == 0, "wave-uniform halves");
+  const bool act = tid < 2*kTasks;
+  const int half = tid/kTasks;
+  const int tt = tid - half*kTasks;
+  const int c = tt % TILE;
+  const int bq = tt/TILE;
+  if (act) {
+    T in[N];
+    T out[H];
+#pragma unroll
+    for (int r = 0; r < N; r++) in[r] = T(t[(bq*N + r)*PT + c]);
+    if (half == 0) od_fdct_lift_half<LN, 0>(out, in);
+    else od_fdct_lift_half<LN, 1>(out, in);
+#pragma unroll
+    for (int k = 0; k < H; k++) z[c*PZ + bq*N + half*H + k] = out[k];
+  }
+  __syncthreads();
+  /* The tile is free now: lapping of the next level overlaps the row pass. */
+  split_filter_cols<TILE, LN, false>(t, tid, x0, a.pic_w);
+  {
+    T in[N];
+    T out[H];
+    if (act) {
+#pragma unroll
+      for (int i = 0; i < N; i++) in[i] = T(z[(bq*N + i)*PZ + c]);
+    }
+    __syncthreads();
+    if (act) {
+      if (half == 0) od_fdct_lift_half<LN, 0>(out, in);
+      else od_fdct_lift_half<LN, 1>(out, in);
+#pragma unroll
+      for (int k = 0; k < H; k++) z[(bq*N + half*H + k)*PZ + c] = out[k];
+    }
+  }
+  __syncthreads();
+  if (a.levels[LN]) {
+    od_coeff *plane = a.levels[LN] + plane_off;
+    for (int i = tid; i < TILE*TILE/4; i += Geo<TILE>::kNT) {
+      const int y = i/(TILE/4);
+      const int x = (i % (TILE/4))*4;
+      const int v = y & (N - 1);
+      const int col = (y - v) + (v & 1)*H + (v >> 1);
+      int o[4];
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const int u = (x + j) & (N - 1);
+        o[j] = z[((x + j - u) + (u & 1)*H + (u >> 1))*PZ + col];
+      }
+      *reinterpret_cast<int4 *>(plane + (long)(y0 + y)*a.w + x0 + x) =
+       make_int4(o[0], o[1], o[2], o[3]);
+    }
+  }
+  split_filter_rows<TILE, LN, false>(t, tid, y0, a.pic_h);
+  __syncthreads();
+}
+
+/* 4x4 level: one block per lane, both passes in registers, rows read from the
+   tile and written to HBM as 16-byte vectors (16 consecutive lanes = one
+   256-byte row segment). */
+template <int TILE>
+__device__ __forceinline__ void pyramid_level4(const short *t, const PyramidArgs &a,
+ long plane_off, int x0, int y0, int tid) {
+  using T = OdMul24;
+  constexpr int P = Geo<TILE>::kPitch;
+  constexpr int NB = TILE/4;
+  for (int blk = tid; blk < NB*NB; blk += Geo<TILE>::kNT) {
+  const int bx = blk % NB;
+  const int by = blk/NB;
+  T m[4][4];
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const short4 v = *reinterpret_cast<const short4 *>(t + (by*4 + r)*P + bx*4);
+    m[r][0] = T(v.x);
+    m[r][1] = T(v.y);
+    m[r][2] = T(v.z);
+    m[r][3] = T(v.w);
+  }
+  /* columns, then rows (od_bin_fdct4x4, src/dct.c:151-156) */
+#pragma unroll
+  for (int c = 0; c < 4; c++) {
+    T in[4] = {m[0][c], m[1][c], m[2][c], m[3][c]};
+    T out[4];
+    od_fdct4_lift(out, in);
+    m[0][c] = out[0];
+    m[1][c] = out[1];
+    m[2][c] = out[2];
+    m[3][c] = out[3];
+  }
+  if (!a.levels[0]) continue;
+  od_coeff *plane = a.levels[0] + plane_off;
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    T out[4];
+    od_fdct4_lift(out, m[r]);
+    *reinterpret_cast<int4 *>(plane + (long)(y0 + by*4 + r)*a.w + x0 + bx*4) =
+     make_int4(out[0], out[1], out[2], out[3]);
+  }
+  }
+}
+
 template <int TILE, int LN>
-__device__ __forceinline__ void pyramid_level(int *t, int *z, const PyramidArgs &a,
+__device__ __forceinline__ void pyramid_level(short *t, int *z, const PyramidArgs &a,
  long plane_off, int x0, int y0, int tid) {
   using T = OdMul24;
   constexpr int NT = Geo<TILE>::kNT;
-  od_tile_cols<TILE, LN, false, T, NT>(z, t, tid, OdAllBlocks());
-  __syncthreads();
-  od_tile_rows<TILE, LN, false, T, NT>(z, z, tid, OdAllBlocks());
-  if constexpr (LN > 0) split_filter_cols<TILE, LN, false>(t, tid, x0, a.pic_w);
-  __syncthreads();
-  if (a.levels[LN]) store_tile<TILE>(a.levels[LN] + plane_off, a.w, x0, y0, z, tid);
-  if constexpr (LN > 0) {
+  if constexpr (LN == 0) {
+    pyramid_level4<TILE>(t, a, plane_off, x0, y0, tid);
+  }
+  else if constexpr (TILE == 64 && LN >= 3 && Geo<TILE>::kNT == 256) {
+    pyramid_level_split64<LN>(t, z, a, plane_off, x0, y0, tid);
+    pyramid_level<TILE, LN - 1>(t, z, a, plane_off, x0, y0, tid);
+  }
+  else {
+    od_tile_cols<TILE, LN, false, T, NT>(z, t, tid, OdAllBlocks());
+    __syncthreads();
+    od_tile_rows<TILE, LN, false, T, NT>(z, z, tid, OdAllBlocks());
+    split_filter_cols<TILE, LN, false>(t, tid, x0, a.pic_w);
+    __syncthreads();
+    if (a.levels[LN]) store_tile<TILE>(a.levels[LN] + plane_off, a.w, x0, y0, z, tid);
     split_filter_rows<TILE, LN, false>(t, tid, y0, a.pic_h);
     __syncthreads();
     pyramid_level<TILE, LN - 1>(t, z, a, plane_off, x0, y0, tid);
@@ -131,12 +264,17 @@ __device__ __forceinline__ void pyramid_level(int *t, int *z, const PyramidArgs 
 }
 
 template <int TILE>
-__global__ __launch_bounds__(TILE*TILE/16) void k_forward_pyramid(PyramidArgs a) {
+__global__ __launch_bounds__(Geo<TILE>::kNT) void k_forward_pyramid(PyramidArgs a) {
   using G = Geo<TILE>;
   constexpr int P = G::kPitch;
   constexpr int NT = G::kNT;
   constexpr int TOP = TILE == 64 ? 4 : 3;
-  __shared__ __attribute__((aligned(16))) int t[G::kHaloWords];
+  /* Source tile as int16: (p - 128) << 4 lapped at most once per direction
+     stays below 2^13 * 1.78^2 < 2^15 (every sample lies in the support of
+     exactly one vertical and one horizontal 4-tap filter of the whole pyramid),
+     so the narrow type is exact and LDS per workgroup drops to 26.0 KiB: six
+     workgroups per CU instead of four. */
+  __shared__ __attribute__((aligned(16))) short t[G::kHaloWords];
   __shared__ __attribute__((aligned(16))) int z[TILE*P];
   const int tid = threadIdx.x;
   const int x0 = blockIdx.x*TILE;
@@ -150,8 +288,8 @@ __global__ __launch_bounds__(TILE*TILE/16) void k_forward_pyramid(PyramidArgs a)
     const int y = i/(TILE/4);
     const int x = (i % (TILE/4))*4;
     const uchar4 v = *reinterpret_cast<const uchar4 *>(px + (long)(y0 + y)*a.px_stride + x0 + x);
-    *reinterpret_cast<int4 *>(t + y*P + x) =
-     make_int4((v.x - 128)*16, (v.y - 128)*16, (v.z - 128)*16, (v.w - 128)*16);
+    *reinterpret_cast<short4 *>(t + y*P + x) =
+     make_short4((v.x - 128)*16, (v.y - 128)*16, (v.z - 128)*16, (v.w - 128)*16);
   }
   /* Halo ring: 2 samples of each neighbouring superblock (where it exists). */
   for (int i = tid; i < 8*TILE + 16; i += NT) {
@@ -171,7 +309,7 @@ __global__ __launch_bounds__(TILE*TILE/16) void k_forward_pyramid(PyramidArgs a)
     const int gx = x0 + c;
     const int gy = y0 + r;
     if (gx >= 0 && gx < w && gy >= 0 && gy < h) {
-      t[G::map(r)*P + G::map(c)] = (px[(long)gy*a.px_stride + gx] - 128)*16;
+      t[G::map(r)*P + G::map(c)] = (short)((px[(long)gy*a.px_stride + gx] - 128)*16);
     }
   }
   __syncthreads();
@@ -191,10 +329,10 @@ __global__ __launch_bounds__(TILE*TILE/16) void k_forward_pyramid(PyramidArgs a)
       int t2 = t[G::map(r + 2)*P + col];
       int t3 = t[G::map(r + 3)*P + col];
       od_pre_filter4_dev(t0, t1, t2, t3);
-      t[G::map(r)*P + col] = t0;
-      t[G::map(r + 1)*P + col] = t1;
-      t[G::map(r + 2)*P + col] = t2;
-      t[G::map(r + 3)*P + col] = t3;
+      t[G::map(r)*P + col] = (short)t0;
+      t[G::map(r + 1)*P + col] = (short)t1;
+      t[G::map(r + 2)*P + col] = (short)t2;
+      t[G::map(r + 3)*P + col] = (short)t3;
     }
   }
   __syncthreads();
@@ -206,16 +344,16 @@ __global__ __launch_bounds__(TILE*TILE/16) void k_forward_pyramid(PyramidArgs a)
     const bool edge = right ? x0 + TILE < w : x0 > 0;
     if (edge) {
       const int c = right ? TILE - 2 : -2;
-      int *row = t + r*P;
+      short *row = t + r*P;
       int t0 = row[G::map(c)];
       int t1 = row[G::map(c + 1)];
       int t2 = row[G::map(c + 2)];
       int t3 = row[G::map(c + 3)];
       od_pre_filter4_dev(t0, t1, t2, t3);
-      row[G::map(c)] = t0;
-      row[G::map(c + 1)] = t1;
-      row[G::map(c + 2)] = t2;
-      row[G::map(c + 3)] = t3;
+      row[G::map(c)] = (short)t0;
+      row[G::map(c + 1)] = (short)t1;
+      row[G::map(c + 2)] = (short)t2;
+      row[G::map(c + 3)] = (short)t3;
     }
   }
   __syncthreads();
@@ -259,7 +397,7 @@ __device__ __forceinline__ void inverse_leaf(int *t, int tid) {
 }
 
 template <int TILE>
-__global__ __launch_bounds__(TILE*TILE/16) void k_inverse_sb(InverseArgs a) {
+__global__ __launch_bounds__(Geo<TILE>::kNT) void k_inverse_sb(InverseArgs a) {
   using G = Geo<TILE>;
   constexpr int P = G::kPitch;
   constexpr int NT = G::kNT;
@@ -301,7 +439,7 @@ struct PostPxArgs {
    vertical superblock edges first, then column taps across the horizontal
    ones) fused with od_coeff_to_ref_buf (src/state.c:1296-1304). */
 template <int TILE>
-__global__ __launch_bounds__(TILE*TILE/16) void k_postfilter_px(PostPxArgs a) {
+__global__ __launch_bounds__(Geo<TILE>::kNT) void k_postfilter_px(PostPxArgs a) {
   using G = Geo<TILE>;
   constexpr int P = G::kPitch;
   constexpr int NT = G::kNT;

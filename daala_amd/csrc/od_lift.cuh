@@ -71,6 +71,27 @@ __device__ __forceinline__ void od_fdct_lift(T (&out)[4 << LN], const T (&in)[4 
   else od_fdct64_lift(out, in);
 }
 
+/* Half networks: out[k] = y[2k + PARITY].  An N-point forward transform splits
+   after its first butterfly stage into two independent N/2-point halves (even
+   outputs: asymmetric DCT of the sums, odd outputs: asymmetric DST of the
+   differences), so two lanes can share one column. */
+template <int LN, int PARITY, typename T>
+__device__ __forceinline__ void od_fdct_lift_half(T (&out)[2 << LN], const T (&in)[4 << LN]) {
+  static_assert(LN >= 2, "half networks exist for 16, 32 and 64 points");
+  if constexpr (LN == 2) {
+    if constexpr (PARITY == 0) od_fdct16_lift_even(out, in);
+    else od_fdct16_lift_odd(out, in);
+  }
+  else if constexpr (LN == 3) {
+    if constexpr (PARITY == 0) od_fdct32_lift_even(out, in);
+    else od_fdct32_lift_odd(out, in);
+  }
+  else {
+    if constexpr (PARITY == 0) od_fdct64_lift_even(out, in);
+    else od_fdct64_lift_odd(out, in);
+  }
+}
+
 template <int LN, typename T>
 __device__ __forceinline__ void od_idct_lift(T (&out)[4 << LN], const T (&in)[4 << LN]) {
   if constexpr (LN == 0) od_idct4_lift(out, in);

@@ -28,8 +28,8 @@ struct OdTile {
 /* Column pass over every block of the tile: dst column <- transform(src
    column).  src == dst is allowed (each lane rewrites only what it read).
    `active(bx, by)` masks blocks (partial tiles, partition leaves). */
-template <int TILE, int LN, bool INV, typename T, int NT, typename Pred>
-__device__ __forceinline__ void od_tile_cols(int *dst, const int *src, int tid, Pred active) {
+template <int TILE, int LN, bool INV, typename T, int NT, typename Pred, typename SrcE>
+__device__ __forceinline__ void od_tile_cols(int *dst, const SrcE *src, int tid, Pred active) {
   constexpr int N = 4 << LN;
   constexpr int P = OdTile<TILE>::kPitch;
   constexpr int kTasks = TILE*(TILE/N);

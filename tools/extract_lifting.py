@@ -391,6 +391,64 @@ def strip_parens(s):
     return s
 
 
+def regs_of(e, acc):
+    if e[0] == "reg":
+        acc.add(e[1])
+    elif e[0] not in ("const", "in", "stride", "out"):
+        for c in e[1:]:
+            if isinstance(c, tuple):
+                regs_of(c, acc)
+    return acc
+
+
+def slice_outputs(p, want):
+    """Backward slice: the statements needed to produce outputs `want`."""
+    live = set()
+    keep = [False] * len(p.stmts)
+    for idx in range(len(p.stmts) - 1, -1, -1):
+        _, lhs, op, e = p.stmts[idx]
+        if lhs[0] == "out":
+            if lhs[1] in want:
+                keep[idx] = True
+                regs_of(e, live)
+        elif lhs[1] in live:
+            keep[idx] = True
+            if op == "=":
+                live.discard(lhs[1])
+            regs_of(e, live)
+    return keep
+
+
+def emit_device_half(name, n, p, parity):
+    """The half network producing outputs of one parity (out[k] = y[2k + parity]).
+    After the first butterfly stage an n-point DCT separates into an n/2-point
+    asymmetric DCT on the sums (even outputs) and an n/2-point asymmetric DST on
+    the differences (odd outputs) that share nothing else: two lanes can each run
+    one half on the same input column."""
+    want = set(range(parity, n, 2))
+    keep = slice_outputs(p, want)
+    used = set()
+    for k, st in zip(keep, p.stmts):
+        if k:
+            if st[1][0] == "reg":
+                used.add(st[1][1])
+            regs_of(st[3], used)
+    lines = []
+    lines.append("template <typename T> __device__ __forceinline__ void "
+                 "%s(T (&out)[%d], const T (&in)[%d]) {" % (name, n // 2, n))
+    lines.append("  T " + ", ".join("r%d" % i for i in sorted(used)) + ";")
+    for k, (_, lhs, op, e) in zip(keep, p.stmts):
+        if not k:
+            continue
+        rhs = strip_parens(cxx(e))
+        if lhs[0] == "out":
+            lines.append("  out[%d] = %s;" % (lhs[1] // 2, rhs))
+        else:
+            lines.append("  r%d %s %s;" % (lhs[1], op, rhs))
+    lines.append("}")
+    return "\n".join(lines), sum(keep)
+
+
 def emit_device(name, n, p):
     lines = []
     lines.append("template <typename T> __device__ __forceinline__ void "
@@ -435,6 +493,11 @@ def main():
                 % (fname, len(ops), nregs, nmul, fname, tname, nregs,
                    tname, len(ops), tname, len(ops), rows))
             device.append(emit_device("od_%s%d_lift" % (kind, n), n, p))
+            if kind == "fdct" and n >= 16:
+                for parity, tag in ((0, "even"), (1, "odd")):
+                    code, cnt = emit_device_half("od_fdct%d_lift_%s" % (n, tag), n, p, parity)
+                    device.append(code)
+                    stats.append(("  fdct%d %s half" % (n, tag), cnt, 0, 0))
 
     hdr = (
         "/* GENERATED by tools/extract_lifting.py - do not edit.\n"
