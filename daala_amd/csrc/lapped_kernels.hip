@@ -28,6 +28,16 @@
 
 namespace {
 
+/* Workgroup barrier for LDS-only hand-offs.  __syncthreads() is a full
+   workgroup-scope release/acquire: it also drains vmcnt, i.e. every wave would
+   wait at each level boundary until its coefficient stores have reached memory.
+   All cross-wave communication in these kernels goes through LDS, so waiting
+   for the LDS queue (lgkmcnt) alone is sufficient and lets the 16-byte stores
+   of one level drain underneath the arithmetic of the next. */
+__device__ __forceinline__ void od_lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 template <int TILE>
 struct Geo {
 #ifndef OD_PYR_NT64
@@ -154,7 +164,7 @@ __device__ __forceinline__ void pyramid_level_split64(short *t, int *z, const Py
 #pragma unroll
     for (int k = 0; k < H; k++) z[c*PZ + bq*N + half*H + k] = out[k];
   }
-  __syncthreads();
+  od_lds_barrier();
   /* The tile is free now: lapping of the next level overlaps the row pass. */
   split_filter_cols<TILE, LN, false>(t, tid, x0, a.pic_w);
   {
@@ -164,7 +174,7 @@ __device__ __forceinline__ void pyramid_level_split64(short *t, int *z, const Py
 #pragma unroll
       for (int i = 0; i < N; i++) in[i] = T(z[(bq*N + i)*PZ + c]);
     }
-    __syncthreads();
+    od_lds_barrier();
     if (act) {
       if (half == 0) od_fdct_lift_half<LN, 0>(out, in);
       else od_fdct_lift_half<LN, 1>(out, in);
@@ -172,7 +182,7 @@ __device__ __forceinline__ void pyramid_level_split64(short *t, int *z, const Py
       for (int k = 0; k < H; k++) z[(bq*N + half*H + k)*PZ + c] = out[k];
     }
   }
-  __syncthreads();
+  od_lds_barrier();
   if (a.levels[LN]) {
     od_coeff *plane = a.levels[LN] + plane_off;
     for (int i = tid; i < TILE*TILE/4; i += Geo<TILE>::kNT) {
@@ -191,7 +201,7 @@ __device__ __forceinline__ void pyramid_level_split64(short *t, int *z, const Py
     }
   }
   split_filter_rows<TILE, LN, false>(t, tid, y0, a.pic_h);
-  __syncthreads();
+  od_lds_barrier();
 }
 
 /* 4x4 level: one block per lane, both passes in registers, rows read from the
@@ -252,13 +262,13 @@ __device__ __forceinline__ void pyramid_level(short *t, int *z, const PyramidArg
   }
   else {
     od_tile_cols<TILE, LN, false, T, NT>(z, t, tid, OdAllBlocks());
-    __syncthreads();
+    od_lds_barrier();
     od_tile_rows<TILE, LN, false, T, NT>(z, z, tid, OdAllBlocks());
     split_filter_cols<TILE, LN, false>(t, tid, x0, a.pic_w);
-    __syncthreads();
+    od_lds_barrier();
     if (a.levels[LN]) store_tile<TILE>(a.levels[LN] + plane_off, a.w, x0, y0, z, tid);
     split_filter_rows<TILE, LN, false>(t, tid, y0, a.pic_h);
-    __syncthreads();
+    od_lds_barrier();
     pyramid_level<TILE, LN - 1>(t, z, a, plane_off, x0, y0, tid);
   }
 }
@@ -312,7 +322,7 @@ __global__ __launch_bounds__(Geo<TILE>::kNT) void k_forward_pyramid(PyramidArgs 
       t[G::map(r)*P + G::map(c)] = (short)((px[(long)gy*a.px_stride + gx] - 128)*16);
     }
   }
-  __syncthreads();
+  od_lds_barrier();
   /* od_apply_prefilter_frame_sbs, src/filter.c:1540-1550: column taps across
      every interior horizontal superblock edge, for every column (halo columns
      included: the row taps below read them at the edge crossings). */
@@ -335,7 +345,7 @@ __global__ __launch_bounds__(Geo<TILE>::kNT) void k_forward_pyramid(PyramidArgs 
       t[G::map(r + 3)*P + col] = (short)t3;
     }
   }
-  __syncthreads();
+  od_lds_barrier();
   /* ... then row taps across every interior vertical edge, src/filter.c:
      1551-1557. */
   for (int i = tid; i < 2*TILE; i += NT) {
@@ -356,7 +366,7 @@ __global__ __launch_bounds__(Geo<TILE>::kNT) void k_forward_pyramid(PyramidArgs 
       row[G::map(c + 3)] = (short)t3;
     }
   }
-  __syncthreads();
+  od_lds_barrier();
   pyramid_level<TILE, TOP>(t, z, a, plane_off, x0, y0, tid);
 }
 

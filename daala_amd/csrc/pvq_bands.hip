@@ -119,6 +119,7 @@ struct CandOut {
 /* ---- short bands: one band per lane ------------------------------------------ */
 __global__ __launch_bounds__(kWave) void k_bands_narrow(Items it) {
   extern __shared__ __attribute__((aligned(16))) unsigned short lds[];
+  od_rsqrt_init(threadIdx.x);
   const int item = find_item(it, blockIdx.x);
   const DJob &jb = g_jobs[it.job[item]];
   const int band = it.band[item];
@@ -218,7 +219,7 @@ __global__ __launch_bounds__(kWave) void k_bands_wide(Items it) {
   const BlockPos bp = locate(jb, (long)(blockIdx.x - it.wg_start[item])*4 + row);
   __shared__ unsigned short s_scan[n];
   for (int j = lane; j < n; j += kWave) s_scan[j] = gScanXY[off + j];
-  __syncthreads();
+  od_rsqrt_init(lane);
   int v[E];
   int sum = 0;
 #pragma unroll

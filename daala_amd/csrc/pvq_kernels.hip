@@ -29,6 +29,7 @@ __global__ __launch_bounds__(kWave) void k_pvq_search(const int16_t *x_in, int n
   extern __shared__ __attribute__((aligned(16))) unsigned short lds[];
   short *xs = (short *)lds;              /* x  [n][64] */
   unsigned short *ys = lds + n*kWave;    /* |y| [n][64] */
+  od_rsqrt_init(threadIdx.x);
   const int lane = threadIdx.x;
   const long band = (long)blockIdx.x*kWave + lane;
   const bool live = band < nbands;

@@ -25,8 +25,18 @@ __device__ const double kRsqrtTable[16] = {
   0.333333, 0.316228, 0.301511, 0.288675,
   0.277350, 0.267261, 0.258199, 0.250000};
 
+/* The table is read with a different index in every lane: it is staged in LDS
+   (a global or constant load with 64 addresses would serialise or miss).
+   Every kernel that searches calls od_rsqrt_init() once. */
+__shared__ double od_rsq_lds[16];
+
+__device__ __forceinline__ void od_rsqrt_init(int tid) {
+  if (tid < 16) od_rsq_lds[tid] = kRsqrtTable[tid];
+  __syncthreads();
+}
+
 __device__ __forceinline__ double od_rsqrt_table(int i) {
-  if (i <= 16) return kRsqrtTable[i - 1];
+  if (i <= 16) return od_rsq_lds[i - 1];
   return __ddiv_rn(1., __dsqrt_rn((double)i));
 }
 

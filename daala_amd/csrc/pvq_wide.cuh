@@ -107,9 +107,13 @@ template <int E>
 __device__ __forceinline__ double od_pvq_search_row(const int (&ax)[E], int (&y)[E], int row,
  int l, int k, int prev_k, double g2, double pvq_norm_lambda, int force_scan, double *yy_out) {
   constexpr int n = 16*E;
+  double xd[E];  /* |x| as doubles: converted once, not once per pulse */
   double xx = 0;
 #pragma unroll
-  for (int e = 0; e < E; e++) xx += (double)ax[e]*(double)ax[e];
+  for (int e = 0; e < E; e++) {
+    xd[e] = (double)ax[e];
+    xx += xd[e]*xd[e];
+  }
   xx = row_sum(xx);
   const double norm_1 = __ddiv_rn(1., __dsqrt_rn(1e-30 + xx));
   const double lambda = __ddiv_rn(pvq_norm_lambda, 1e-30 + g2);
@@ -162,7 +166,7 @@ __device__ __forceinline__ double od_pvq_search_row(const int (&ax)[E], int (&y)
     double bb = 1;
 #pragma unroll
     for (int e = 0; e < E; e++) {
-      const double t = xy + (double)ax[e];
+      const double t = xy + xd[e];
       a[e] = t*t;
       b[e] = yy + (double)(2*y[e]) + 1;
       if (e == 0 || a[e]*bb > ba*b[e]) {
@@ -177,13 +181,15 @@ __device__ __forceinline__ double od_pvq_search_row(const int (&ax)[E], int (&y)
     const int wl = __ffs(wmask) - 1;
     const double wa = row_bcast(ba, row, wl);
     const double wb = row_bcast(bb, row, wl);
-    /* verification against the proposal */
+    /* verification against the proposal; wa_m = wa*(1 - 2^-30), so `loses`
+       keeps a margin of ~2^-30 (the extra rounding of wa_m is 2^-53) */
+    const double wa_m = wa*(1. - 9.3132257461547852e-10);
     bool bad = force_scan != 0;
     int first_dup = n;
 #pragma unroll
     for (int e = E - 1; e >= 0; e--) {
       const bool dup = a[e] == wa && b[e] == wb;
-      const bool loses = a[e]*wb < (wa*b[e])*(1. - 9.3132257461547852e-10);
+      const bool loses = a[e]*wb < wa_m*b[e];
       if (dup) first_dup = l*E + e;
       else if (!loses) bad = true;
     }
@@ -234,6 +240,9 @@ __device__ __forceinline__ double od_pvq_search_row(const int (&ax)[E], int (&y)
     }
   }
   /* ---- last pulses with the rate term ------------------------------------- */
+  double pen[E];  /* (lambda*j)*delta_rate: the same for every pulse */
+#pragma unroll
+  for (int e = 0; e < E; e++) pen[e] = (lambda*(l*E + e))*delta_rate;
   while (__any(i < k)) {
     const bool on = i < k;
     double tab[4];
@@ -244,12 +253,12 @@ __device__ __forceinline__ double od_pvq_search_row(const int (&ax)[E], int (&y)
 #pragma unroll
     for (int e = 0; e < E; e++) {
       const int j = l*E + e;
-      double tmp_xy = xy + (double)ax[e];
+      double tmp_xy = xy + xd[e];
       const int yj = y[e];
       double r;
       if (yj < 4) r = yj == 0 ? tab[0] : yj == 1 ? tab[1] : yj == 2 ? tab[2] : tab[3];
       else r = od_rsqrt_table((int)(yy + (double)(2*yj) + 1));
-      tmp_xy = ((2*tmp_xy)*norm_1)*r - (lambda*j)*delta_rate;
+      tmp_xy = ((2*tmp_xy)*norm_1)*r - pen[e];
       if (e == 0 || tmp_xy > bc) {
         bc = tmp_xy;
         bi = j;
