@@ -17,7 +17,7 @@
    1529-1559), od_prefilter_split (:1459-1483) and fdct_2d[bs].
 
    INVERSE: k_inverse_sb (iDCT + split post-filters, src/encode.c:1780-1789,
-   src/filter.c:1485-1527) and k_postfilter_px (superblock-edge post-filter
+   src/filter.c:1485-1527) and k_edge_rows/k_edge_cols (superblock-edge post-filter
    src/filter.c:1589-1618 + od_coeff_to_ref_plane src/state.c:1281-1345).
 
    Pixels are bounded, so every lifting multiply uses the full-rate 24-bit
@@ -374,13 +374,22 @@ __global__ __launch_bounds__(Geo<TILE>::kNT) void k_forward_pyramid(PyramidArgs 
 
 struct InverseArgs {
   const od_coeff *coef;  /* quantised coefficients, plane layout */
-  od_coeff *recon;       /* out: post-split-filter samples, plane layout */
+  uint8_t *px;           /* out: pixels (edge strips are finished by k_edge_*) */
+  od_coeff *vs;          /* out: [plane][nhsb-1][h][4] samples around vertical SB edges */
+  od_coeff *hs;          /* out: [plane][nvsb-1][4][w] samples around horizontal SB edges */
+  int px_stride;
+  long px_plane_stride;
   int w;
   int h;
   int pic_w;
   int pic_h;
   int leaf_bs;
 };
+
+/* od_coeff_to_ref_buf, src/state.c:1296-1304. */
+__device__ __forceinline__ unsigned char od_to_px(int c) {
+  return (unsigned char)min(max(((c + 8) >> 4) + 128, 0), 255);
+}
 
 template <int TILE, int LN>
 __device__ __forceinline__ void inverse_split_levels(int *t, const InverseArgs &a,
@@ -433,118 +442,125 @@ __global__ __launch_bounds__(Geo<TILE>::kNT) void k_inverse_sb(InverseArgs a) {
       break;
   }
   inverse_split_levels<TILE, 1>(t, a, x0, y0, tid);
-  store_tile<TILE>(a.recon + plane_off, a.w, x0, y0, t, tid);
-}
-
-struct PostPxArgs {
-  const od_coeff *recon;
-  uint8_t *px;
-  int px_stride;
-  long px_plane_stride;
-  int w;
-  int h;
-};
-
-/* od_apply_postfilter_frame_sbs (src/filter.c:1600-1617: row taps across the
-   vertical superblock edges first, then column taps across the horizontal
-   ones) fused with od_coeff_to_ref_buf (src/state.c:1296-1304). */
-template <int TILE>
-__global__ __launch_bounds__(Geo<TILE>::kNT) void k_postfilter_px(PostPxArgs a) {
-  using G = Geo<TILE>;
-  constexpr int P = G::kPitch;
-  constexpr int NT = G::kNT;
-  __shared__ __attribute__((aligned(16))) int t[G::kHaloWords];
-  const int tid = threadIdx.x;
-  const int x0 = blockIdx.x*TILE;
-  const int y0 = blockIdx.y*TILE;
+  /* Everything but the 2-sample strips along interior superblock edges is
+     final: convert and store it (the strips are stored too and overwritten by
+     k_edge_rows / k_edge_cols).  The strips go out as od_coeff so that the
+     edge post-filter, which couples neighbouring superblocks, can run on them:
+     4 B read + 1 B written per pixel plus ~12 % for the strips, instead of an
+     int32 round trip of the whole plane. */
   const int w = a.w;
   const int h = a.h;
-  const od_coeff *src = a.recon + (long)blockIdx.z*w*h;
   uint8_t *px = a.px + blockIdx.z*a.px_plane_stride;
-  for (int i = tid; i < TILE*TILE/4; i += NT) {
-    const int y = i/(TILE/4);
-    const int x = (i % (TILE/4))*4;
-    *reinterpret_cast<int4 *>(t + y*P + x) =
-     *reinterpret_cast<const int4 *>(src + (long)(y0 + y)*w + x0 + x);
-  }
-  for (int i = tid; i < 8*TILE + 16; i += NT) {
-    int r;
-    int c;
-    if (i < 4*(TILE + 4)) {
-      const int k = i/(TILE + 4);
-      r = k < 2 ? k - 2 : TILE + k - 2;
-      c = i % (TILE + 4) - 2;
-    }
-    else {
-      const int j = i - 4*(TILE + 4);
-      const int k = j & 3;
-      r = j >> 2;
-      c = k < 2 ? k - 2 : TILE + k - 2;
-    }
-    const int gx = x0 + c;
-    const int gy = y0 + r;
-    if (gx >= 0 && gx < w && gy >= 0 && gy < h) {
-      t[G::map(r)*P + G::map(c)] = src[(long)gy*w + gx];
-    }
-  }
-  __syncthreads();
-  /* Row taps across vertical edges, every row including the halo rows. */
-  for (int i = tid; i < 2*(TILE + 4); i += NT) {
-    const int right = i/(TILE + 4);
-    const int r = i % (TILE + 4) - 2;
-    const int gy = y0 + r;
-    const bool edge = right ? x0 + TILE < w : x0 > 0;
-    if (edge && gy >= 0 && gy < h) {
-      const int c = right ? TILE - 2 : -2;
-      int *row = t + G::map(r)*P;
-      int t0 = row[G::map(c)];
-      int t1 = row[G::map(c + 1)];
-      int t2 = row[G::map(c + 2)];
-      int t3 = row[G::map(c + 3)];
-      od_post_filter4_dev(t0, t1, t2, t3);
-      row[G::map(c)] = t0;
-      row[G::map(c + 1)] = t1;
-      row[G::map(c + 2)] = t2;
-      row[G::map(c + 3)] = t3;
-    }
-  }
-  __syncthreads();
-  /* Column taps across horizontal edges. */
-  for (int i = tid; i < 2*TILE; i += NT) {
-    const int bottom = i/TILE;
-    const int c = i % TILE;
-    const bool edge = bottom ? y0 + TILE < h : y0 > 0;
-    if (edge) {
-      const int r = bottom ? TILE - 2 : -2;
-      int t0 = t[G::map(r)*P + c];
-      int t1 = t[G::map(r + 1)*P + c];
-      int t2 = t[G::map(r + 2)*P + c];
-      int t3 = t[G::map(r + 3)*P + c];
-      od_post_filter4_dev(t0, t1, t2, t3);
-      t[G::map(r)*P + c] = t0;
-      t[G::map(r + 1)*P + c] = t1;
-      t[G::map(r + 2)*P + c] = t2;
-      t[G::map(r + 3)*P + c] = t3;
-    }
-  }
-  __syncthreads();
   for (int i = tid; i < TILE*TILE/4; i += NT) {
     const int y = i/(TILE/4);
     const int x = (i % (TILE/4))*4;
     const int4 v = *reinterpret_cast<const int4 *>(t + y*P + x);
     uchar4 o;
-    o.x = (unsigned char)min(max(((v.x + 8) >> 4) + 128, 0), 255);
-    o.y = (unsigned char)min(max(((v.y + 8) >> 4) + 128, 0), 255);
-    o.z = (unsigned char)min(max(((v.z + 8) >> 4) + 128, 0), 255);
-    o.w = (unsigned char)min(max(((v.w + 8) >> 4) + 128, 0), 255);
+    o.x = od_to_px(v.x);
+    o.y = od_to_px(v.y);
+    o.z = od_to_px(v.z);
+    o.w = od_to_px(v.w);
     *reinterpret_cast<uchar4 *>(px + (long)(y0 + y)*a.px_stride + x0 + x) = o;
+  }
+  const int nv = w/TILE - 1;
+  const int nh = h/TILE - 1;
+  const int sbx = blockIdx.x;
+  const int sby = blockIdx.y;
+  od_coeff *vs = a.vs + (long)blockIdx.z*nv*h*4;
+  od_coeff *hs = a.hs + (long)blockIdx.z*nh*4*w;
+  for (int i = tid; i < 2*TILE; i += NT) {
+    const int right = i/TILE;
+    const int r = i % TILE;
+    if (right ? sbx < nv : sbx > 0) {
+      const int e = right ? sbx : sbx - 1;
+      const int c = right ? TILE - 2 : 0;
+      int2 v;
+      v.x = t[r*P + c];
+      v.y = t[r*P + c + 1];
+      *reinterpret_cast<int2 *>(vs + ((long)e*h + y0 + r)*4 + (right ? 0 : 2)) = v;
+    }
+  }
+  for (int i = tid; i < 4*TILE; i += NT) {
+    const int k = i/TILE;          /* 0,1: top rows 0,1; 2,3: bottom rows TILE-2, TILE-1 */
+    const int c = i % TILE;
+    const bool bottom = k >= 2;
+    if (bottom ? sby < nh : sby > 0) {
+      const int e = bottom ? sby : sby - 1;
+      const int r = bottom ? TILE - 4 + k : k;
+      hs[((long)e*4 + (bottom ? k - 2 : k + 2))*w + x0 + c] = t[r*P + c];
+    }
   }
 }
 
-/* Scratch plane for the two-kernel inverse; grows on demand, one per process
-   (the library is used with one stream per process in the sharded driver). */
-od_coeff *g_recon = nullptr;
-size_t g_recon_bytes = 0;
+struct EdgeArgs {
+  od_coeff *vs;
+  od_coeff *hs;
+  uint8_t *px;
+  int px_stride;
+  long px_plane_stride;
+  int w;
+  int h;
+  int tile;
+};
+
+/* od_apply_postfilter_frame_sbs, first half (src/filter.c:1600-1606): row taps
+   across every interior vertical superblock edge, every row.  Rows that also lie
+   in a horizontal strip hand their result on to k_edge_cols through hs. */
+__global__ __launch_bounds__(256) void k_edge_rows(EdgeArgs a) {
+  const int y = blockIdx.x*256 + threadIdx.x;
+  if (y >= a.h) return;
+  const int e = blockIdx.y;
+  const int nv = a.w/a.tile - 1;
+  const int nh = a.h/a.tile - 1;
+  const int4 v = *reinterpret_cast<const int4 *>(a.vs + (((long)blockIdx.z*nv + e)*a.h + y)*4);
+  int t0 = v.x;
+  int t1 = v.y;
+  int t2 = v.z;
+  int t3 = v.w;
+  od_post_filter4_dev(t0, t1, t2, t3);
+  const int x = (e + 1)*a.tile - 2;
+  const int m = (y + 2) % a.tile;           /* < 4 inside a horizontal strip */
+  const int he = (y + 2)/a.tile - 1;
+  if (m < 4 && he >= 0 && he < nh) {
+    od_coeff *row = a.hs + (((long)blockIdx.z*nh + he)*4 + m)*a.w + x;
+    row[0] = t0;
+    row[1] = t1;
+    row[2] = t2;
+    row[3] = t3;
+  }
+  else {
+    uint8_t *p = a.px + blockIdx.z*a.px_plane_stride + (long)y*a.px_stride + x;
+    p[0] = od_to_px(t0);
+    p[1] = od_to_px(t1);
+    p[2] = od_to_px(t2);
+    p[3] = od_to_px(t3);
+  }
+}
+
+/* Second half (src/filter.c:1607-1617): column taps across every interior
+   horizontal edge, every column, then od_coeff_to_ref_buf. */
+__global__ __launch_bounds__(256) void k_edge_cols(EdgeArgs a) {
+  const int x = blockIdx.x*256 + threadIdx.x;
+  if (x >= a.w) return;
+  const int e = blockIdx.y;
+  const int nh = a.h/a.tile - 1;
+  const od_coeff *col = a.hs + ((long)blockIdx.z*nh + e)*4*a.w + x;
+  int t0 = col[0];
+  int t1 = col[a.w];
+  int t2 = col[2*a.w];
+  int t3 = col[3*a.w];
+  od_post_filter4_dev(t0, t1, t2, t3);
+  uint8_t *p = a.px + blockIdx.z*a.px_plane_stride + (long)((e + 1)*a.tile - 2)*a.px_stride + x;
+  p[0] = od_to_px(t0);
+  p[a.px_stride] = od_to_px(t1);
+  p[2*a.px_stride] = od_to_px(t2);
+  p[3*a.px_stride] = od_to_px(t3);
+}
+
+/* Scratch for the edge strips; grows on demand, one per process (the library is
+   used with one stream per process in the sharded driver). */
+od_coeff *g_strips = nullptr;
+size_t g_strips_bytes = 0;
 
 }  // namespace
 
@@ -582,38 +598,44 @@ extern "C" int odhip_inverse_level(uint8_t *d_px, int px_stride, long px_plane_s
    || (px_plane_stride & 3) || leaf_bs < 0 || leaf_bs > 4 - dec) {
     return ODHIP_EINVAL;
   }
-  const size_t need = (size_t)nplanes*w*h*sizeof(od_coeff);
-  if (need > g_recon_bytes) {
-    if (g_recon) ODHIP_TRY(hipFree(g_recon));
-    g_recon = nullptr;
-    g_recon_bytes = 0;
-    ODHIP_TRY(hipMalloc((void **)&g_recon, need));
-    g_recon_bytes = need;
+  const int nv = w/tile - 1;
+  const int nh = h/tile - 1;
+  const size_t vs_words = ((size_t)nplanes*nv*h*4 + 3) & ~(size_t)3;
+  const size_t hs_words = (size_t)nplanes*nh*4*w;
+  const size_t need = (vs_words + hs_words + 4)*sizeof(od_coeff);
+  if (need > g_strips_bytes) {
+    if (g_strips) ODHIP_TRY(hipFree(g_strips));
+    g_strips = nullptr;
+    g_strips_bytes = 0;
+    ODHIP_TRY(hipMalloc((void **)&g_strips, need));
+    g_strips_bytes = need;
   }
   InverseArgs ia;
   ia.coef = d_coef;
-  ia.recon = g_recon;
+  ia.px = d_px;
+  ia.vs = g_strips;
+  ia.hs = g_strips + vs_words;
+  ia.px_stride = px_stride;
+  ia.px_plane_stride = px_plane_stride;
   ia.w = w;
   ia.h = h;
   ia.pic_w = pic_w;
   ia.pic_h = pic_h;
   ia.leaf_bs = leaf_bs;
-  PostPxArgs pa;
-  pa.recon = g_recon;
-  pa.px = d_px;
-  pa.px_stride = px_stride;
-  pa.px_plane_stride = px_plane_stride;
-  pa.w = w;
-  pa.h = h;
+  EdgeArgs ea;
+  ea.vs = ia.vs;
+  ea.hs = ia.hs;
+  ea.px = d_px;
+  ea.px_stride = px_stride;
+  ea.px_plane_stride = px_plane_stride;
+  ea.w = w;
+  ea.h = h;
+  ea.tile = tile;
   const dim3 grid(w/tile, h/tile, nplanes);
   hipStream_t s = (hipStream_t)stream;
-  if (dec) {
-    k_inverse_sb<32><<<grid, Geo<32>::kNT, 0, s>>>(ia);
-    k_postfilter_px<32><<<grid, Geo<32>::kNT, 0, s>>>(pa);
-  }
-  else {
-    k_inverse_sb<64><<<grid, Geo<64>::kNT, 0, s>>>(ia);
-    k_postfilter_px<64><<<grid, Geo<64>::kNT, 0, s>>>(pa);
-  }
+  if (dec) k_inverse_sb<32><<<grid, Geo<32>::kNT, 0, s>>>(ia);
+  else k_inverse_sb<64><<<grid, Geo<64>::kNT, 0, s>>>(ia);
+  if (nv > 0) k_edge_rows<<<dim3((h + 255)/256, nv, nplanes), 256, 0, s>>>(ea);
+  if (nh > 0) k_edge_cols<<<dim3((w + 255)/256, nh, nplanes), 256, 0, s>>>(ea);
   return odhip_check_launch();
 }
