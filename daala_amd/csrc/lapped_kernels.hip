@@ -23,6 +23,7 @@
    Pixels are bounded, so every lifting multiply uses the full-rate 24-bit
    multiplier (OdMul24, see od_lift.cuh). */
 #include "../../include/daala_hip.h"
+#include <stdlib.h>
 #include "od_common.cuh"
 #include "od_tile.cuh"
 
@@ -273,26 +274,15 @@ __device__ __forceinline__ void pyramid_level(short *t, int *z, const PyramidArg
   }
 }
 
-template <int TILE>
-__global__ __launch_bounds__(Geo<TILE>::kNT) void k_forward_pyramid(PyramidArgs a) {
+/* The three steps that bring a superblock tile (with its 2-sample halo) into
+   LDS and lap it across the superblock edges; a barrier separates them. */
+template <int TILE, int NT>
+__device__ __forceinline__ void sb_load(short *t, const PyramidArgs &a, const uint8_t *px,
+ int x0, int y0, int tid) {
   using G = Geo<TILE>;
   constexpr int P = G::kPitch;
-  constexpr int NT = G::kNT;
-  constexpr int TOP = TILE == 64 ? 4 : 3;
-  /* Source tile as int16: (p - 128) << 4 lapped at most once per direction
-     stays below 2^13 * 1.78^2 < 2^15 (every sample lies in the support of
-     exactly one vertical and one horizontal 4-tap filter of the whole pyramid),
-     so the narrow type is exact and LDS per workgroup drops to 26.0 KiB: six
-     workgroups per CU instead of four. */
-  __shared__ __attribute__((aligned(16))) short t[G::kHaloWords];
-  __shared__ __attribute__((aligned(16))) int z[TILE*P];
-  const int tid = threadIdx.x;
-  const int x0 = blockIdx.x*TILE;
-  const int y0 = blockIdx.y*TILE;
   const int w = a.w;
   const int h = a.h;
-  const uint8_t *px = a.px + blockIdx.z*a.px_plane_stride;
-  const long plane_off = (long)blockIdx.z*w*h;
   /* od_ref_buf_to_coeff, src/state.c:1231-1237: (p - 128) << OD_COEFF_SHIFT. */
   for (int i = tid; i < TILE*TILE/4; i += NT) {
     const int y = i/(TILE/4);
@@ -322,7 +312,15 @@ __global__ __launch_bounds__(Geo<TILE>::kNT) void k_forward_pyramid(PyramidArgs 
       t[G::map(r)*P + G::map(c)] = (short)((px[(long)gy*a.px_stride + gx] - 128)*16);
     }
   }
-  od_lds_barrier();
+}
+
+template <int TILE, int NT>
+__device__ __forceinline__ void sb_edge_cols(short *t, const PyramidArgs &a, int x0, int y0,
+ int tid) {
+  using G = Geo<TILE>;
+  constexpr int P = G::kPitch;
+  const int w = a.w;
+  const int h = a.h;
   /* od_apply_prefilter_frame_sbs, src/filter.c:1540-1550: column taps across
      every interior horizontal superblock edge, for every column (halo columns
      included: the row taps below read them at the edge crossings). */
@@ -345,7 +343,13 @@ __global__ __launch_bounds__(Geo<TILE>::kNT) void k_forward_pyramid(PyramidArgs 
       t[G::map(r + 3)*P + col] = (short)t3;
     }
   }
-  od_lds_barrier();
+}
+
+template <int TILE, int NT>
+__device__ __forceinline__ void sb_edge_rows(short *t, const PyramidArgs &a, int x0, int tid) {
+  using G = Geo<TILE>;
+  constexpr int P = G::kPitch;
+  const int w = a.w;
   /* ... then row taps across every interior vertical edge, src/filter.c:
      1551-1557. */
   for (int i = tid; i < 2*TILE; i += NT) {
@@ -366,8 +370,154 @@ __global__ __launch_bounds__(Geo<TILE>::kNT) void k_forward_pyramid(PyramidArgs 
       row[G::map(c + 3)] = (short)t3;
     }
   }
+}
+
+template <int TILE>
+__global__ __launch_bounds__(Geo<TILE>::kNT) void k_forward_pyramid(PyramidArgs a) {
+  using G = Geo<TILE>;
+  constexpr int P = G::kPitch;
+  constexpr int NT = G::kNT;
+  constexpr int TOP = TILE == 64 ? 4 : 3;
+  /* Source tile as int16: (p - 128) << 4 lapped at most once per direction
+     stays below 2^13 * 1.78^2 < 2^15 (every sample lies in the support of
+     exactly one vertical and one horizontal 4-tap filter of the whole pyramid),
+     so the narrow type is exact and halves the tile's LDS footprint. */
+  __shared__ __attribute__((aligned(16))) short t[G::kHaloWords];
+  __shared__ __attribute__((aligned(16))) int z[TILE*P];
+  const int tid = threadIdx.x;
+  const int x0 = blockIdx.x*TILE;
+  const int y0 = blockIdx.y*TILE;
+  const uint8_t *px = a.px + blockIdx.z*a.px_plane_stride;
+  const long plane_off = (long)blockIdx.z*a.w*a.h;
+  sb_load<TILE, NT>(t, a, px, x0, y0, tid);
+  od_lds_barrier();
+  sb_edge_cols<TILE, NT>(t, a, x0, y0, tid);
+  od_lds_barrier();
+  sb_edge_rows<TILE, NT>(t, a, x0, tid);
   od_lds_barrier();
   pyramid_level<TILE, TOP>(t, z, a, plane_off, x0, y0, tid);
+}
+
+/* TWO horizontally adjacent luma superblocks per 256-thread workgroup.  With
+   one superblock only 128 (64-point level, split) of the 256 lanes have work
+   in the most expensive phases; with two, every phase of every level keeps all
+   four waves busy and one barrier covers twice the arithmetic:
+     64-point level: 2 tiles x 64 columns x 2 half networks = 256 lanes
+     32-point level: 2 tiles x 128 columns (full network)    = 256 lanes
+     16/8-point:     generic passes, tile after tile
+     4x4:            one block per lane, tile after tile                       */
+__global__ __launch_bounds__(256) void k_forward_pyramid64x2(PyramidArgs a) {
+  using T = OdMul24;
+  constexpr int TILE = 64;
+  using G = Geo<TILE>;
+  constexpr int P = G::kPitch;
+  constexpr int NT = 256;
+  constexpr int PZ = 65;
+  static_assert(G::kNT == NT, "kernel is written for 256-thread workgroups");
+  __shared__ __attribute__((aligned(16))) short t[2][G::kHaloWords];
+  __shared__ __attribute__((aligned(16))) int z[2][TILE*P];
+  const int tid = threadIdx.x;
+  const int xb = blockIdx.x*2*TILE;
+  const int y0 = blockIdx.y*TILE;
+  const uint8_t *px = a.px + blockIdx.z*a.px_plane_stride;
+  const long plane_off = (long)blockIdx.z*a.w*a.h;
+  for (int s = 0; s < 2; s++) sb_load<TILE, NT>(t[s], a, px, xb + s*TILE, y0, tid);
+  od_lds_barrier();
+  for (int s = 0; s < 2; s++) sb_edge_cols<TILE, NT>(t[s], a, xb + s*TILE, y0, tid);
+  od_lds_barrier();
+  for (int s = 0; s < 2; s++) sb_edge_rows<TILE, NT>(t[s], a, xb + s*TILE, tid);
+  od_lds_barrier();
+  const int s2 = tid >> 7;        /* tile owned in the 64- and 32-point phases */
+  const int lt = tid & 127;
+  /* ---- 64-point level (see pyramid_level_split64 for the layout) ---------- */
+  {
+    constexpr int N = 64;
+    constexpr int H = 32;
+    const int half = lt >> 6;
+    const int c = lt & 63;
+    short *ts = t[s2];
+    int *zs = z[s2];
+    {
+      T in[N];
+      T out[H];
+#pragma unroll
+      for (int r = 0; r < N; r++) in[r] = T(ts[r*P + c]);
+      if (half == 0) od_fdct_lift_half<4, 0>(out, in);
+      else od_fdct_lift_half<4, 1>(out, in);
+#pragma unroll
+      for (int k = 0; k < H; k++) zs[c*PZ + half*H + k] = out[k];
+    }
+    od_lds_barrier();
+    for (int s = 0; s < 2; s++) split_filter_cols<TILE, 4, false>(t[s], tid, xb + s*TILE, a.pic_w);
+    {
+      T in[N];
+      T out[H];
+#pragma unroll
+      for (int i = 0; i < N; i++) in[i] = T(zs[i*PZ + c]);
+      od_lds_barrier();
+      if (half == 0) od_fdct_lift_half<4, 0>(out, in);
+      else od_fdct_lift_half<4, 1>(out, in);
+#pragma unroll
+      for (int k = 0; k < H; k++) zs[(half*H + k)*PZ + c] = out[k];
+    }
+    od_lds_barrier();
+    if (a.levels[4]) {
+      od_coeff *plane = a.levels[4] + plane_off;
+      for (int i = tid; i < 2*TILE*TILE/4; i += NT) {
+        const int s = i/(TILE*TILE/4);
+        const int j = i - s*(TILE*TILE/4);
+        const int y = j/(TILE/4);
+        const int x = (j % (TILE/4))*4;
+        const int col = (y & 1)*H + (y >> 1);
+        int o[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) o[q] = z[s][(((x + q) & 1)*H + ((x + q) >> 1))*PZ + col];
+        *reinterpret_cast<int4 *>(plane + (long)(y0 + y)*a.w + xb + s*TILE + x) =
+         make_int4(o[0], o[1], o[2], o[3]);
+      }
+    }
+    for (int s = 0; s < 2; s++) split_filter_rows<TILE, 4, false>(t[s], tid, y0, a.pic_h);
+    od_lds_barrier();
+  }
+  /* ---- 32-point level: full network, 128 lanes per tile -------------------- */
+  od_tile_cols<TILE, 3, false, T, 128>(z[s2], t[s2], lt, OdAllBlocks());
+  od_lds_barrier();
+  od_tile_rows<TILE, 3, false, T, 128>(z[s2], z[s2], lt, OdAllBlocks());
+  for (int s = 0; s < 2; s++) split_filter_cols<TILE, 3, false>(t[s], tid, xb + s*TILE, a.pic_w);
+  od_lds_barrier();
+  for (int s = 0; s < 2; s++) {
+    if (a.levels[3]) store_tile<TILE>(a.levels[3] + plane_off, a.w, xb + s*TILE, y0, z[s], tid);
+    split_filter_rows<TILE, 3, false>(t[s], tid, y0, a.pic_h);
+  }
+  od_lds_barrier();
+  /* ---- 16-point level ------------------------------------------------------ */
+  for (int s = 0; s < 2; s++) od_tile_cols<TILE, 2, false, T, NT>(z[s], t[s], tid, OdAllBlocks());
+  od_lds_barrier();
+  for (int s = 0; s < 2; s++) {
+    od_tile_rows<TILE, 2, false, T, NT>(z[s], z[s], tid, OdAllBlocks());
+    split_filter_cols<TILE, 2, false>(t[s], tid, xb + s*TILE, a.pic_w);
+  }
+  od_lds_barrier();
+  for (int s = 0; s < 2; s++) {
+    if (a.levels[2]) store_tile<TILE>(a.levels[2] + plane_off, a.w, xb + s*TILE, y0, z[s], tid);
+    split_filter_rows<TILE, 2, false>(t[s], tid, y0, a.pic_h);
+  }
+  od_lds_barrier();
+  /* ---- 8-point level ------------------------------------------------------- */
+  for (int s = 0; s < 2; s++) od_tile_cols<TILE, 1, false, T, NT>(z[s], t[s], tid, OdAllBlocks());
+  od_lds_barrier();
+  for (int s = 0; s < 2; s++) {
+    od_tile_rows<TILE, 1, false, T, NT>(z[s], z[s], tid, OdAllBlocks());
+    split_filter_cols<TILE, 1, false>(t[s], tid, xb + s*TILE, a.pic_w);
+  }
+  od_lds_barrier();
+  for (int s = 0; s < 2; s++) {
+    if (a.levels[1]) store_tile<TILE>(a.levels[1] + plane_off, a.w, xb + s*TILE, y0, z[s], tid);
+    split_filter_rows<TILE, 1, false>(t[s], tid, y0, a.pic_h);
+  }
+  od_lds_barrier();
+  /* ---- 4x4 level ----------------------------------------------------------- */
+  for (int s = 0; s < 2; s++) pyramid_level4<TILE>(t[s], a, plane_off, xb + s*TILE, y0, tid);
 }
 
 /* ---- inverse ------------------------------------------------------------ */
@@ -585,6 +735,9 @@ extern "C" int odhip_forward_pyramid(od_coeff *const d_levels[ODHIP_NBSIZES],
   const dim3 grid(w/tile, h/tile, nplanes);
   hipStream_t s = (hipStream_t)stream;
   if (dec) k_forward_pyramid<32><<<grid, Geo<32>::kNT, 0, s>>>(a);
+  else if ((w/tile) % 2 == 0 && !getenv("ODHIP_PYRAMID_X1")) {
+    k_forward_pyramid64x2<<<dim3(w/(2*tile), h/tile, nplanes), 256, 0, s>>>(a);
+  }
   else k_forward_pyramid<64><<<grid, Geo<64>::kNT, 0, s>>>(a);
   return odhip_check_launch();
 }
