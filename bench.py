@@ -288,6 +288,15 @@ def main():
                 "achieved": kernels[dom]["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": kernels[dom]["frac_of_hbm_peak"], "traffic": None,
                 "algorithmic_bytes_per_launch": ab[dom]}
+        fd = kernels["forward_pyramid_luma"]
+        roof["note"] = ("largest share of the step; the PVQ band stage is fp64-VALU/latency bound "
+                        "(arithmetic intensity ~ the fp64 ridge), HBM is quoted because SURVEY 8(d) "
+                        "prices it against HBM; see roofline_filter_dct for the stage the north star "
+                        "prices at >= 60 % of HBM")
+        roof_fd = {"kernel": "k_forward_pyramid64x2 (forward_pyramid_luma)", "bound": "hbm",
+                   "achieved": fd["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                   "frac": fd["frac_of_hbm_peak"], "traffic": None,
+                   "algorithmic_bytes_per_launch": ab["forward_pyramid_luma"]}
         line = {
             "metric": "1080p all-intra transform blocks/s (filter+DCT+PVQ)",
             "value": total_blocks / dt,
@@ -308,6 +317,7 @@ def main():
                        "blocks_per_frame": bpf, "quality": "-v 20 (quantizer 243)",
                        "sharding": "frames over ranks, no data-path collective"},
             "roofline": roof,
+            "roofline_filter_dct": roof_fd,
             "kernels": kernels,
         }
         if world == 1 and not args.no_cpu_baseline:

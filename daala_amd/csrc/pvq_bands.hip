@@ -475,6 +475,37 @@ int stage_jobs(const odhip_pvq_job *jobs, int njobs, bool need_synth, DJob *host
   return ODHIP_SUCCESS;
 }
 
+/* Side streams for kernels that may overlap (created once per process). */
+hipStream_t g_side[2] = {nullptr, nullptr};
+hipEvent_t g_fork = nullptr;
+hipEvent_t g_join[2] = {nullptr, nullptr};
+
+int fork_streams(hipStream_t s, hipStream_t side[2]) {
+  if (getenv("ODHIP_PVQ_SERIAL")) return ODHIP_SUCCESS;
+  if (!g_fork) {
+    ODHIP_TRY(hipEventCreateWithFlags(&g_fork, hipEventDisableTiming));
+    for (int i = 0; i < 2; i++) {
+      ODHIP_TRY(hipStreamCreateWithFlags(&g_side[i], hipStreamNonBlocking));
+      ODHIP_TRY(hipEventCreateWithFlags(&g_join[i], hipEventDisableTiming));
+    }
+  }
+  ODHIP_TRY(hipEventRecord(g_fork, s));
+  for (int i = 0; i < 2; i++) {
+    ODHIP_TRY(hipStreamWaitEvent(g_side[i], g_fork, 0));
+    side[i] = g_side[i];
+  }
+  return ODHIP_SUCCESS;
+}
+
+int join_streams(hipStream_t s, hipStream_t side[2]) {
+  for (int i = 0; i < 2; i++) {
+    if (side[i] == s) continue;
+    ODHIP_TRY(hipEventRecord(g_join[i], side[i]));
+    ODHIP_TRY(hipStreamWaitEvent(s, g_join[i], 0));
+  }
+  return ODHIP_SUCCESS;
+}
+
 void items_begin(Items &it, double lambda) {
   memset(&it, 0, sizeof(it));
   it.lambda = lambda;
@@ -520,11 +551,17 @@ extern "C" int odhip_pvq_noref_bands_multi(const odhip_pvq_job *jobs, int njobs,
       }
     }
   }
+  /* The three band kernels are independent: the two long-band kernels run on
+     side streams forked from / joined to the caller's stream, so their tails
+     and their different bottlenecks (LDS vs DPP/VALU) overlap. */
+  hipStream_t side[2] = {s, s};
+  if (fork_streams(s, side) != ODHIP_SUCCESS) return ODHIP_EFAULT;
   if (it.nitems) {
     k_bands_narrow<<<it.wg_start[it.nitems], kWave, (size_t)nmax*kWave*4, s>>>(it);
   }
   /* long bands: 4 bands per workgroup */
   for (int width = 32; width <= 128; width *= 4) {
+    hipStream_t ws = side[width == 32 ? 0 : 1];
     items_begin(it, pvq_norm_lambda);
     for (int j = 0; j < njobs; j++) {
       for (int b = 0; b < host[j].nb_bands; b++) {
@@ -534,9 +571,10 @@ extern "C" int odhip_pvq_noref_bands_multi(const odhip_pvq_job *jobs, int njobs,
       }
     }
     if (!it.nitems) continue;
-    if (width == 32) k_bands_wide<2><<<it.wg_start[it.nitems], kWave, 0, s>>>(it);
-    else k_bands_wide<8><<<it.wg_start[it.nitems], kWave, 0, s>>>(it);
+    if (width == 32) k_bands_wide<2><<<it.wg_start[it.nitems], kWave, 0, ws>>>(it);
+    else k_bands_wide<8><<<it.wg_start[it.nitems], kWave, 0, ws>>>(it);
   }
+  if (join_streams(s, side) != ODHIP_SUCCESS) return ODHIP_EFAULT;
   return odhip_check_launch();
 }
 
