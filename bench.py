@@ -11,12 +11,13 @@ in HBM, per GPU:
                              and for EVERY block size 64..4 the split
                              pre-filter + 2-D fDCT of every block (luma 5
                              levels, chroma 4)
-  2. for every level: odhip_pvq_noref_bands        (QM scaling, gain, both gain
-                             candidates: K, pruning, K-pulse search, distortion)
-                      odhip_pvq_select_synth_noref (choice, od_gain_expand,
-                             od_pvq_synthesis_partial, scan -> raster)
-                      odhip_inverse_level          (iDCT, split post-filters,
-                             superblock-edge post-filter, coefficient -> pixel)
+  2. odhip_pvq_noref_bands_multi   every level: QM scaling, gain, both gain
+                             candidates (K, pruning, K-pulse search, distortion)
+     odhip_pvq_choose_multi        choice, od_gain_expand, synthesis scale
+  3. for every level: odhip_inverse_level_pvq  (dequantisation of the chosen
+                             pulses = od_pvq_synthesis_partial + scan -> raster
+                             on load, iDCT, split post-filters, superblock-edge
+                             post-filter, coefficient -> pixel)
 
 i.e. every block the reference's block-size RDO would evaluate goes through
 prefilter + fDCT + PVQ + dequantisation + iDCT + postfilter exactly once:
@@ -101,7 +102,7 @@ class Pipeline:
                 qm, qmi = self.qt.qm_slices(pli, bs)
                 job = D.PvqJob(levels[bs], bs, torch.from_numpy(qm).to(device),
                                torch.from_numpy(qmi).to(device), self.qt.q_band(pli, bs),
-                               self.qt.beta_band(pli, bs), dq=torch.empty_like(levels[bs]))
+                               self.qt.beta_band(pli, bs))
                 s["jobs"].append(job)
                 self.jobs.append(job)
             self.sets.append(s)
@@ -127,13 +128,12 @@ class Pipeline:
                                                   levels=s["levels"]), record)
         self._timed("pvq_noref_bands", lambda: D.pvq_noref_bands_multi(self.jobs, self.lam),
                     record)
-        self._timed("pvq_select_synth",
-                    lambda: D.pvq_select_synth_noref_multi(self.jobs, self.lam), record)
+        self._timed("pvq_choose", lambda: D.pvq_choose_multi(self.jobs, self.lam), record)
         for s in self.sets:
             for job in s["jobs"]:
-                self._timed("inverse_level_" + s["name"],
-                            lambda: D.inverse_level(job.dq, s["dec"], job.bs, PIC_W, PIC_H,
-                                                    out=s["recon"]), record)
+                self._timed("dequant_inverse_" + s["name"],
+                            lambda: D.inverse_level_pvq(job, s["dec"], PIC_W, PIC_H,
+                                                        out=s["recon"]), record)
 
     def kernel_ms(self):
         """Average milliseconds per launch group and groups per run, per class."""
@@ -165,10 +165,12 @@ def algorithmic_bytes(F):
     return {
         "forward_pyramid_luma": luma_px * 21,      # 1 B read + 5 levels x 4 B written
         "forward_pyramid_chroma": chroma_px * 17,  # 1 B read + 4 levels x 4 B written
-        "inverse_level_luma": luma_px * 5,         # 4 B read + 1 B written
-        "inverse_level_chroma": chroma_px * 5,
+        # dequantise-on-load inverse: per level 4 B per CODED coefficient read
+        # (all of them below 32x32, 512 per block above) + 1 B/px written; the
+        # figure below is the 4 B/px + 1 B/px upper bound of SURVEY 8(d).
+        "dequant_inverse_luma": luma_px * 5,
+        "dequant_inverse_chroma": chroma_px * 5,
         "pvq_noref_bands": bands_b,    # one multi-job launch group per step
-        "pvq_select_synth": synth_b,
     }
 
 

@@ -295,6 +295,27 @@ def pvq_select_synth_noref_multi(jobs, pvq_norm_lambda):
            "odhip_pvq_select_synth_noref_multi")
 
 
+def pvq_choose_multi(jobs, pvq_norm_lambda):
+    """The `cost <= best_cost` choice alone (fills cands['choice'])."""
+    _check(lib().odhip_pvq_choose_multi(_jobs_array(jobs), len(jobs),
+                                        ctypes.c_double(pvq_norm_lambda), _stream()),
+           "odhip_pvq_choose_multi")
+
+
+def inverse_level_pvq(job, dec, pic_w, pic_h, out=None):
+    """Inverse stage fed by the band stage: dequantise-on-load from the chosen
+    pulse vectors of `job` (no dequantised plane in HBM)."""
+    import torch
+    nplanes, h, w = job.coef.shape
+    if out is None:
+        out = torch.empty((nplanes, h, w), dtype=torch.uint8, device=job.coef.device)
+    st = job.struct()
+    _check(lib().odhip_inverse_level_pvq(_p(out), w, ctypes.c_long(h * w), ctypes.byref(st),
+                                         int(dec), int(pic_w), int(pic_h), _stream()),
+           "odhip_inverse_level_pvq")
+    return out
+
+
 def pvq_noref_bands(coef, bs, qm, q_band, beta_band, pvq_norm_lambda, out=None):
     job = PvqJob(coef, bs, qm, None, q_band, beta_band, cands=out)
     pvq_noref_bands_multi([job], pvq_norm_lambda)

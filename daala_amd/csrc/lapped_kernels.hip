@@ -24,8 +24,10 @@
    multiplier (OdMul24, see od_lift.cuh). */
 #include "../../include/daala_hip.h"
 #include <stdlib.h>
+#include <string.h>
 #include "od_common.cuh"
 #include "od_tile.cuh"
+#include "gen/od_scan_tables.h"
 
 namespace {
 
@@ -534,7 +536,19 @@ struct InverseArgs {
   int pic_w;
   int pic_h;
   int leaf_bs;
+  /* Optional PVQ source (odhip_inverse_level_pvq): when y != NULL the tile is
+     not read from a dequantised plane but synthesised on load from the chosen
+     pulse vectors; `coef` then only supplies the DCs. */
+  const od_coeff *y;        /* [2][nblocks][len] */
+  const int4 *choice;       /* [nblocks][nb_bands] {slot, qg, scale, qshift} */
+  const int16_t *qm_inv;    /* coding order */
+  long nblocks;
+  int len;
+  int nb_bands;
 };
+
+__device__ unsigned short gInvScanXY[OD_SCAN_LEN];  /* y << 8 | x of coding index j */
+__device__ unsigned char gInvBandOf[OD_SCAN_LEN];
 
 /* od_coeff_to_ref_buf, src/state.c:1296-1304. */
 __device__ __forceinline__ unsigned char od_to_px(int c) {
@@ -575,11 +589,65 @@ __global__ __launch_bounds__(Geo<TILE>::kNT) void k_inverse_sb(InverseArgs a) {
   const int x0 = blockIdx.x*TILE;
   const int y0 = blockIdx.y*TILE;
   const long plane_off = (long)blockIdx.z*a.w*a.h;
-  for (int i = tid; i < TILE*TILE/4; i += NT) {
-    const int y = i/(TILE/4);
-    const int x = (i % (TILE/4))*4;
-    *reinterpret_cast<int4 *>(t + y*P + x) =
-     *reinterpret_cast<const int4 *>(a.coef + plane_off + (long)(y0 + y)*a.w + x0 + x);
+  if (a.y) {
+    /* Dequantise on load: x = y*scale (Q16, no rounding), out = SHR_ROUND(x *
+       qm_inv, qshift) (od_pvq_synthesis_partial noref, src/pvq.c:1081-1092),
+       scattered to raster inside LDS (od_coding_order_to_raster,
+       src/partition.c:176-194).  The pulse vectors are read as contiguous
+       len-word rows; the dequantised plane never exists in HBM. */
+    __shared__ unsigned short s_scan[OD_SCAN_LEN];
+    __shared__ unsigned char s_band[OD_SCAN_LEN];
+    __shared__ int4 s_choice[256];
+    const int sh = a.leaf_bs + 2;
+    const int nbw = TILE >> sh;                 /* blocks per tile row */
+    const int nbsb = nbw*nbw;
+    const int bw = a.w >> sh;
+    const int bh = a.h >> sh;
+    for (int i = tid; i < a.len; i += NT) {
+      s_scan[i] = gInvScanXY[i];
+      s_band[i] = gInvBandOf[i];
+    }
+    for (int i = tid; i < nbsb*a.nb_bands; i += NT) {
+      const int b = i/a.nb_bands;
+      const int band = i - b*a.nb_bands;
+      const long blk = ((long)blockIdx.z*bh + (y0 >> sh) + b/nbw)*bw + (x0 >> sh) + b % nbw;
+      s_choice[i] = a.choice[blk*a.nb_bands + band];
+    }
+    if ((a.len >> sh) < (1 << sh)) {            /* 32x32 / 64x64: uncoded positions are zero */
+      for (int i = tid; i < TILE*P/4; i += NT) reinterpret_cast<int4 *>(t)[i] = make_int4(0, 0, 0, 0);
+    }
+    __syncthreads();
+    const int lsh = 31 - __clz(a.len);          /* len is a power of two */
+    for (int i = tid; i < nbsb << lsh; i += NT) {
+      const int b = i >> lsh;
+      const int j = i & (a.len - 1);
+      const int lby = b/nbw;
+      const int lbx = b - lby*nbw;
+      const long blk = ((long)blockIdx.z*bh + (y0 >> sh) + lby)*bw + (x0 >> sh) + lbx;
+      int v = 0;
+      if (j == 0) {
+        v = a.coef[plane_off + (long)(y0 + (lby << sh))*a.w + x0 + (lbx << sh)];
+      }
+      else {
+        const int4 ch = s_choice[b*a.nb_bands + s_band[j]];
+        if (ch.y != 0) {
+          const int yv = a.y[((long)ch.x*a.nblocks + blk)*a.len + j];
+          const int xq = (int)((short)yv*(long)ch.z >> 16);
+          const int r = xq*a.qm_inv[j];
+          v = (r + ((1 << ch.w) >> 1)) >> ch.w;
+        }
+      }
+      const int xy = s_scan[j];
+      t[((lby << sh) + (xy >> 8))*P + (lbx << sh) + (xy & 255)] = v;
+    }
+  }
+  else {
+    for (int i = tid; i < TILE*TILE/4; i += NT) {
+      const int y = i/(TILE/4);
+      const int x = (i % (TILE/4))*4;
+      *reinterpret_cast<int4 *>(t + y*P + x) =
+       *reinterpret_cast<const int4 *>(a.coef + plane_off + (long)(y0 + y)*a.w + x0 + x);
+    }
   }
   __syncthreads();
   switch (a.leaf_bs) {
@@ -742,15 +810,12 @@ extern "C" int odhip_forward_pyramid(od_coeff *const d_levels[ODHIP_NBSIZES],
   return odhip_check_launch();
 }
 
-extern "C" int odhip_inverse_level(uint8_t *d_px, int px_stride, long px_plane_stride,
- const od_coeff *d_coef, int nplanes, int w, int h, int dec, int leaf_bs,
- int pic_w, int pic_h, odhip_stream stream) {
-  if (!d_px || !d_coef || nplanes <= 0 || (dec != 0 && dec != 1)) return ODHIP_EINVAL;
+namespace {
+
+int inverse_launch(InverseArgs ia, int nplanes, int dec, hipStream_t s) {
   const int tile = 64 >> dec;
-  if (w <= 0 || h <= 0 || w % tile || h % tile || (px_stride & 3)
-   || (px_plane_stride & 3) || leaf_bs < 0 || leaf_bs > 4 - dec) {
-    return ODHIP_EINVAL;
-  }
+  const int w = ia.w;
+  const int h = ia.h;
   const int nv = w/tile - 1;
   const int nh = h/tile - 1;
   const size_t vs_words = ((size_t)nplanes*nv*h*4 + 3) & ~(size_t)3;
@@ -763,11 +828,58 @@ extern "C" int odhip_inverse_level(uint8_t *d_px, int px_stride, long px_plane_s
     ODHIP_TRY(hipMalloc((void **)&g_strips, need));
     g_strips_bytes = need;
   }
-  InverseArgs ia;
-  ia.coef = d_coef;
-  ia.px = d_px;
   ia.vs = g_strips;
   ia.hs = g_strips + vs_words;
+  EdgeArgs ea;
+  ea.vs = ia.vs;
+  ea.hs = ia.hs;
+  ea.px = ia.px;
+  ea.px_stride = ia.px_stride;
+  ea.px_plane_stride = ia.px_plane_stride;
+  ea.w = w;
+  ea.h = h;
+  ea.tile = tile;
+  const dim3 grid(w/tile, h/tile, nplanes);
+  if (dec) k_inverse_sb<32><<<grid, Geo<32>::kNT, 0, s>>>(ia);
+  else k_inverse_sb<64><<<grid, Geo<64>::kNT, 0, s>>>(ia);
+  if (nv > 0) k_edge_rows<<<dim3((h + 255)/256, nv, nplanes), 256, 0, s>>>(ea);
+  if (nh > 0) k_edge_cols<<<dim3((w + 255)/256, nh, nplanes), 256, 0, s>>>(ea);
+  return odhip_check_launch();
+}
+
+bool g_inv_tables = false;
+
+int upload_inv_tables(void) {
+  if (g_inv_tables) return ODHIP_SUCCESS;
+  unsigned short packed[OD_SCAN_LEN];
+  unsigned char band_of[OD_SCAN_LEN];
+  for (int j = 0; j < OD_SCAN_LEN; j++) {
+    packed[j] = (unsigned short)(OD_SCAN_XY[j][1] << 8 | OD_SCAN_XY[j][0]);
+    int b = 0;
+    while (b + 1 < OD_NBANDS[4] && j >= OD_BAND_OFFS[4][b + 1]) b++;
+    band_of[j] = (unsigned char)b;
+  }
+  ODHIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(gInvScanXY), packed, sizeof(packed)));
+  ODHIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(gInvBandOf), band_of, sizeof(band_of)));
+  g_inv_tables = true;
+  return ODHIP_SUCCESS;
+}
+
+}  // namespace
+
+extern "C" int odhip_inverse_level(uint8_t *d_px, int px_stride, long px_plane_stride,
+ const od_coeff *d_coef, int nplanes, int w, int h, int dec, int leaf_bs,
+ int pic_w, int pic_h, odhip_stream stream) {
+  if (!d_px || !d_coef || nplanes <= 0 || (dec != 0 && dec != 1)) return ODHIP_EINVAL;
+  const int tile = 64 >> dec;
+  if (w <= 0 || h <= 0 || w % tile || h % tile || (px_stride & 3)
+   || (px_plane_stride & 3) || leaf_bs < 0 || leaf_bs > 4 - dec) {
+    return ODHIP_EINVAL;
+  }
+  InverseArgs ia;
+  memset(&ia, 0, sizeof(ia));
+  ia.coef = d_coef;
+  ia.px = d_px;
   ia.px_stride = px_stride;
   ia.px_plane_stride = px_plane_stride;
   ia.w = w;
@@ -775,20 +887,42 @@ extern "C" int odhip_inverse_level(uint8_t *d_px, int px_stride, long px_plane_s
   ia.pic_w = pic_w;
   ia.pic_h = pic_h;
   ia.leaf_bs = leaf_bs;
-  EdgeArgs ea;
-  ea.vs = ia.vs;
-  ea.hs = ia.hs;
-  ea.px = d_px;
-  ea.px_stride = px_stride;
-  ea.px_plane_stride = px_plane_stride;
-  ea.w = w;
-  ea.h = h;
-  ea.tile = tile;
-  const dim3 grid(w/tile, h/tile, nplanes);
-  hipStream_t s = (hipStream_t)stream;
-  if (dec) k_inverse_sb<32><<<grid, Geo<32>::kNT, 0, s>>>(ia);
-  else k_inverse_sb<64><<<grid, Geo<64>::kNT, 0, s>>>(ia);
-  if (nv > 0) k_edge_rows<<<dim3((h + 255)/256, nv, nplanes), 256, 0, s>>>(ea);
-  if (nh > 0) k_edge_cols<<<dim3((w + 255)/256, nh, nplanes), 256, 0, s>>>(ea);
-  return odhip_check_launch();
+  return inverse_launch(ia, nplanes, dec, (hipStream_t)stream);
+}
+
+extern "C" int odhip_inverse_level_pvq(uint8_t *d_px, int px_stride, long px_plane_stride,
+ const odhip_pvq_job *job, int dec, int pic_w, int pic_h, odhip_stream stream) {
+  if (!d_px || !job || !job->d_coef || !job->cands.y || !job->cands.choice || !job->d_qm_inv
+   || job->nplanes <= 0 || (dec != 0 && dec != 1)) {
+    return ODHIP_EINVAL;
+  }
+  const int tile = 64 >> dec;
+  const int w = job->w;
+  const int h = job->h;
+  const int bs = job->bs;
+  if (w <= 0 || h <= 0 || w % tile || h % tile || (px_stride & 3) || (px_plane_stride & 3)
+   || bs < 0 || bs > 4 - dec) {
+    return ODHIP_EINVAL;
+  }
+  int rc = upload_inv_tables();
+  if (rc) return rc;
+  const int n = 4 << bs;
+  InverseArgs ia;
+  memset(&ia, 0, sizeof(ia));
+  ia.coef = job->d_coef;
+  ia.px = d_px;
+  ia.px_stride = px_stride;
+  ia.px_plane_stride = px_plane_stride;
+  ia.w = w;
+  ia.h = h;
+  ia.pic_w = pic_w;
+  ia.pic_h = pic_h;
+  ia.leaf_bs = bs;
+  ia.y = job->cands.y;
+  ia.choice = reinterpret_cast<const int4 *>(job->cands.choice);
+  ia.qm_inv = job->d_qm_inv;
+  ia.nblocks = (long)job->nplanes*(w/n)*(h/n);
+  ia.len = n*n < OD_SCAN_LEN ? n*n : OD_SCAN_LEN;
+  ia.nb_bands = OD_NBANDS[bs];
+  return inverse_launch(ia, job->nplanes, dec, (hipStream_t)stream);
 }

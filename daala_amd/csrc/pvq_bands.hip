@@ -420,7 +420,7 @@ int upload_tables(void) {
   return ODHIP_SUCCESS;
 }
 
-int fill_job(DJob &d, const odhip_pvq_job &j, bool need_synth) {
+int fill_job(DJob &d, const odhip_pvq_job &j, int mode) {
   if (!j.d_coef || !j.q_band || !j.beta_band || j.bs < 0 || j.bs >= ODHIP_NBSIZES
    || j.nplanes <= 0) {
     return ODHIP_EINVAL;
@@ -430,7 +430,8 @@ int fill_job(DJob &d, const odhip_pvq_job &j, bool need_synth) {
    || !c.y || !c.choice) {
     return ODHIP_EINVAL;
   }
-  if (need_synth ? (!j.d_qm_inv || !j.d_dq) : !j.d_qm) return ODHIP_EINVAL;
+  /* mode 0: band stage (needs qm); 1: choice + synthesis (qm_inv, dq); 2: choice only */
+  if (mode == 0 ? !j.d_qm : mode == 1 ? (!j.d_qm_inv || !j.d_dq) : false) return ODHIP_EINVAL;
   const int n = 4 << j.bs;
   if (j.w <= 0 || j.h <= 0 || j.w % n || j.h % n || (j.w & 3)) return ODHIP_EINVAL;
   memset(&d, 0, sizeof(d));
@@ -459,13 +460,13 @@ int fill_job(DJob &d, const odhip_pvq_job &j, bool need_synth) {
   return ODHIP_SUCCESS;
 }
 
-int stage_jobs(const odhip_pvq_job *jobs, int njobs, bool need_synth, DJob *host,
+int stage_jobs(const odhip_pvq_job *jobs, int njobs, int mode, DJob *host,
  hipStream_t s) {
   if (!jobs || njobs <= 0 || njobs > kMaxJobs) return ODHIP_EINVAL;
   int rc = upload_tables();
   if (rc) return rc;
   for (int i = 0; i < njobs; i++) {
-    rc = fill_job(host[i], jobs[i], need_synth);
+    rc = fill_job(host[i], jobs[i], mode);
     if (rc) return rc;
   }
   /* Pageable source: the runtime stages the bytes before returning, so `host`
@@ -536,7 +537,7 @@ extern "C" int odhip_pvq_noref_bands_multi(const odhip_pvq_job *jobs, int njobs,
  double pvq_norm_lambda, odhip_stream stream) {
   hipStream_t s = (hipStream_t)stream;
   DJob host[kMaxJobs];
-  int rc = stage_jobs(jobs, njobs, false, host, s);
+  int rc = stage_jobs(jobs, njobs, 0, host, s);
   if (rc) return rc;
   Items it;
   /* short bands: 64 bands per workgroup */
@@ -582,7 +583,7 @@ extern "C" int odhip_pvq_select_synth_noref_multi(const odhip_pvq_job *jobs, int
  double pvq_norm_lambda, odhip_stream stream) {
   hipStream_t s = (hipStream_t)stream;
   DJob host[kMaxJobs];
-  int rc = stage_jobs(jobs, njobs, true, host, s);
+  int rc = stage_jobs(jobs, njobs, 1, host, s);
   if (rc) return rc;
   Items it;
   items_begin(it, pvq_norm_lambda);
@@ -595,6 +596,21 @@ extern "C" int odhip_pvq_select_synth_noref_multi(const odhip_pvq_job *jobs, int
     items_add(it, j, 0, (long)host[j].nplanes*host[j].h*((host[j].w + 1023) >> 10));
   }
   k_synth<<<it.wg_start[it.nitems], 256, 0, s>>>(it);
+  return odhip_check_launch();
+}
+
+extern "C" int odhip_pvq_choose_multi(const odhip_pvq_job *jobs, int njobs,
+ double pvq_norm_lambda, odhip_stream stream) {
+  hipStream_t s = (hipStream_t)stream;
+  DJob host[kMaxJobs];
+  int rc = stage_jobs(jobs, njobs, 2, host, s);
+  if (rc) return rc;
+  Items it;
+  items_begin(it, pvq_norm_lambda);
+  for (int j = 0; j < njobs; j++) {
+    items_add(it, j, 0, (host[j].nblocks*host[j].nb_bands + 255)/256);
+  }
+  k_choose<<<it.wg_start[it.nitems], 256, 0, s>>>(it);
   return odhip_check_launch();
 }
 

@@ -225,6 +225,22 @@ int odhip_pvq_noref_bands_multi(const odhip_pvq_job *jobs, int njobs,
 int odhip_pvq_select_synth_noref_multi(const odhip_pvq_job *jobs, int njobs,
  double pvq_norm_lambda, odhip_stream stream);
 
+/* The choice alone (fills cands.choice and the optional d_qg of every job):
+   for callers that dequantise inside the inverse stage, below. */
+int odhip_pvq_choose_multi(const odhip_pvq_job *jobs, int njobs,
+ double pvq_norm_lambda, odhip_stream stream);
+
+/* odhip_inverse_level fed directly by the band stage: the chosen pulse vectors
+   of `job` (cands.y, cands.choice after odhip_pvq_choose_multi or
+   odhip_pvq_select_synth_noref*) are dequantised while the superblock tile is
+   loaded (od_pvq_synthesis_partial noref src/pvq.c:1081-1092,
+   od_coding_order_to_raster src/partition.c:176-194), DCs come from
+   job->d_coef; the dequantised plane is never written to HBM.  Partition level
+   = job->bs; needs job->d_qm_inv.  Same output as odhip_pvq_select_synth_noref
+   followed by odhip_inverse_level. */
+int odhip_inverse_level_pvq(uint8_t *d_px, int px_stride, long px_plane_stride,
+ const odhip_pvq_job *job, int dec, int pic_w, int pic_h, odhip_stream stream);
+
 /* nb_bands, offsets[nb_bands+1] and len for block size bs. */
 int odhip_pvq_band_layout(int bs, int *nb_bands, int *offsets, int *len);
 

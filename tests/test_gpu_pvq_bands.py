@@ -141,3 +141,40 @@ def test_band_stage_matches_oracle(hip, pli, dec):
                 want_dq[by * n:(by + 1) * n, bx * n:(bx + 1) * n] = blkout
         assert nsearched > 0
         assert np.array_equal(dq, want_dq), bs
+
+
+@pytest.mark.parametrize("dec", [0, 1])
+def test_inverse_from_pvq_equals_synth_then_inverse(hip, dec):
+    """odhip_inverse_level_pvq (dequantise on load, no dq plane) must give the
+    same pixels as select_synth + inverse_level, at every level, with and
+    without a host rate table."""
+    import torch
+    W, H = 256, 192
+    planes = synth_frame(W, H, seed=21)
+    rng = np.random.RandomState(4)
+    src = planes[0] if dec == 0 else planes[1]
+    src = np.clip(src.astype(int) + rng.randint(-70, 71, size=src.shape), 0, 255).astype(np.uint8)
+    px = _cuda(np.stack([src, src[::-1].copy()]))
+    pli = 0 if dec == 0 else 1
+    levels = hip.forward_pyramid(px, dec, W, H)
+    qt = hip.QuantTables.load()
+    for bs in range(5 - dec):
+        qm, qmi = qt.qm_slices(pli, bs)
+        for use_rate in (False, True):
+            job = hip.PvqJob(levels[bs], bs, _cuda(qm), _cuda(qmi), qt.q_band(pli, bs),
+                             qt.beta_band(pli, bs), dq=torch.empty_like(levels[bs]))
+            if use_rate:
+                job.rate = torch.from_numpy(rng.uniform(0, 60, size=tuple(job.cands["dist"].shape))).cuda()
+            hip.pvq_noref_bands_multi([job], hip.OD_PVQ_LAMBDA)
+            hip.pvq_select_synth_noref_multi([job], hip.OD_PVQ_LAMBDA)
+            want = hip.inverse_level(job.dq, dec, bs, W, H)
+            qg_a = job.cands["choice"][..., 1].clone()
+            hip.pvq_choose_multi([job], hip.OD_PVQ_LAMBDA)
+            assert torch.equal(job.cands["choice"][..., 1], qg_a)
+            got = hip.inverse_level_pvq(job, dec, W, H)
+            assert torch.equal(got, want), (dec, bs, use_rate)
+            if use_rate:
+                # the rate table must be able to change choices (cost = dist + lambda*rate)
+                job.rate = None
+                hip.pvq_choose_multi([job], hip.OD_PVQ_LAMBDA)
+                assert not torch.equal(job.cands["choice"][..., 1], qg_a) or bs == 4
