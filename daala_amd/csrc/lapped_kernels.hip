@@ -598,6 +598,7 @@ __global__ __launch_bounds__(Geo<TILE>::kNT) void k_inverse_sb(InverseArgs a) {
     __shared__ unsigned short s_scan[OD_SCAN_LEN];
     __shared__ unsigned char s_band[OD_SCAN_LEN];
     __shared__ int4 s_choice[256];
+    __shared__ short s_qmi[OD_SCAN_LEN];
     const int sh = a.leaf_bs + 2;
     const int nbw = TILE >> sh;                 /* blocks per tile row */
     const int nbsb = nbw*nbw;
@@ -606,6 +607,7 @@ __global__ __launch_bounds__(Geo<TILE>::kNT) void k_inverse_sb(InverseArgs a) {
     for (int i = tid; i < a.len; i += NT) {
       s_scan[i] = gInvScanXY[i];
       s_band[i] = gInvBandOf[i];
+      s_qmi[i] = a.qm_inv[i];
     }
     for (int i = tid; i < nbsb*a.nb_bands; i += NT) {
       const int b = i/a.nb_bands;
@@ -618,12 +620,15 @@ __global__ __launch_bounds__(Geo<TILE>::kNT) void k_inverse_sb(InverseArgs a) {
     }
     __syncthreads();
     const int lsh = 31 - __clz(a.len);          /* len is a power of two */
+    const int lnb = 31 - __clz(nbw);            /* so is the block count per tile row */
+    const long blk0 = ((long)blockIdx.z*bh + (y0 >> sh))*bw + (x0 >> sh);
+#pragma unroll 4
     for (int i = tid; i < nbsb << lsh; i += NT) {
       const int b = i >> lsh;
       const int j = i & (a.len - 1);
-      const int lby = b/nbw;
-      const int lbx = b - lby*nbw;
-      const long blk = ((long)blockIdx.z*bh + (y0 >> sh) + lby)*bw + (x0 >> sh) + lbx;
+      const int lby = b >> lnb;
+      const int lbx = b & (nbw - 1);
+      const unsigned blk = (unsigned)blk0 + lby*bw + lbx;   /* < 2^31/len, checked by the host */
       int v = 0;
       if (j == 0) {
         v = a.coef[plane_off + (long)(y0 + (lby << sh))*a.w + x0 + (lbx << sh)];
@@ -631,9 +636,10 @@ __global__ __launch_bounds__(Geo<TILE>::kNT) void k_inverse_sb(InverseArgs a) {
       else {
         const int4 ch = s_choice[b*a.nb_bands + s_band[j]];
         if (ch.y != 0) {
-          const int yv = a.y[((long)ch.x*a.nblocks + blk)*a.len + j];
-          const int xq = (int)((short)yv*(long)ch.z >> 16);
-          const int r = xq*a.qm_inv[j];
+          const int yv = a.y[(((unsigned)ch.x*(unsigned)a.nblocks + blk) << lsh) + j];
+          /* OD_MULT16_32_Q16: (int16)y * (int32)scale >> 16 == mulhi(y << 16, scale) */
+          const int xq = __mulhi((int)(short)yv << 16, ch.z);
+          const int r = xq*s_qmi[j];
           v = (r + ((1 << ch.w) >> 1)) >> ch.w;
         }
       }
@@ -923,6 +929,7 @@ extern "C" int odhip_inverse_level_pvq(uint8_t *d_px, int px_stride, long px_pla
   ia.qm_inv = job->d_qm_inv;
   ia.nblocks = (long)job->nplanes*(w/n)*(h/n);
   ia.len = n*n < OD_SCAN_LEN ? n*n : OD_SCAN_LEN;
+  if (2*ia.nblocks*ia.len >= 0x7fffffffL) return ODHIP_EINVAL;  /* 32-bit element indices */
   ia.nb_bands = OD_NBANDS[bs];
   return inverse_launch(ia, job->nplanes, dec, (hipStream_t)stream);
 }
