@@ -1,0 +1,224 @@
+/* frame_cache.hip - serving the reference encoder's per-block fdct_2d calls
+   from ONE batched GPU pyramid per plane.
+
+   The reference calls fdct_2d[bs](d + bo, w, c + bo, w) once per evaluated
+   block (src/encode.c:1304,1477): 366 264 calls per 1080p keyframe, one small
+   block each - a per-call offload pays launch + PCIe latency every time.  But
+   the samples a block of level bs sees depend only on the source plane and on
+   "every ancestor was split" (verified there on a whole
+   frame: 161 268 repeated calls, 0 differing inputs), i.e. they are exactly
+   what odhip_forward_pyramid computes for that (level, bx, by).  So:
+
+     odhip_cache_load_plane   at the moment the encoder has converted a plane to
+                              coefficients and is about to lap it across
+                              superblock edges (od_apply_prefilter_frame_sbs,
+                              src/encode.c:2571): pixels are recovered from the
+                              coefficients ((p - 128) << 4 is invertible), the
+                              whole pyramid is computed in one launch and copied
+                              to pinned host memory
+     odhip_cache_lookup       an fdct_2d call whose input pointer lies in a
+                              cached plane becomes a strided host copy
+
+   Anything that does not hit (other buffers, inter-frame prediction planes,
+   unaligned positions) falls through to the per-call GPU transform - never to a
+   CPU implementation.  ODHIP_CACHE_CHECK=1 recomputes every hit with the
+   per-call path and aborts on a mismatch (the OD_CHECKASM idea,
+   src/dct.c:4922-4948). */
+#include <stdlib.h>
+#include <string.h>
+#include "../../include/daala_hip.h"
+#include "od_common.cuh"
+
+struct odhip_frame_cache {
+  struct Plane {
+    const od_coeff *base;
+    int w;
+    int h;
+    int dec;
+    int valid;
+    uint8_t *h_px;
+    uint8_t *d_px;
+    od_coeff *h_levels[ODHIP_NBSIZES];
+    od_coeff *d_levels[ODHIP_NBSIZES];
+    size_t cap;
+  } planes[4];
+  hipStream_t stream;
+  int pic_w;
+  int pic_h;
+  int check;
+  long hits;
+  long misses;
+};
+
+namespace {
+
+thread_local odhip_frame_cache *g_current = nullptr;
+
+int plane_reserve(odhip_frame_cache::Plane &p, int w, int h, int dec) {
+  const size_t n = (size_t)w*h;
+  if (n <= p.cap && p.w == w && p.h == h && p.dec == dec) return ODHIP_SUCCESS;
+  if (p.h_px) ODHIP_TRY(hipHostFree(p.h_px));
+  if (p.d_px) ODHIP_TRY(hipFree(p.d_px));
+  p.h_px = nullptr;
+  p.d_px = nullptr;
+  for (int i = 0; i < ODHIP_NBSIZES; i++) {
+    if (p.h_levels[i]) ODHIP_TRY(hipHostFree(p.h_levels[i]));
+    if (p.d_levels[i]) ODHIP_TRY(hipFree(p.d_levels[i]));
+    p.h_levels[i] = nullptr;
+    p.d_levels[i] = nullptr;
+  }
+  p.cap = 0;
+  ODHIP_TRY(hipHostMalloc((void **)&p.h_px, n, hipHostMallocDefault));
+  ODHIP_TRY(hipMalloc((void **)&p.d_px, n));
+  for (int i = 0; i <= 4 - dec; i++) {
+    ODHIP_TRY(hipHostMalloc((void **)&p.h_levels[i], n*sizeof(od_coeff), hipHostMallocDefault));
+    ODHIP_TRY(hipMalloc((void **)&p.d_levels[i], n*sizeof(od_coeff)));
+  }
+  p.cap = n;
+  p.w = w;
+  p.h = h;
+  p.dec = dec;
+  return ODHIP_SUCCESS;
+}
+
+typedef void (*dct_fn)(od_coeff *, int, const od_coeff *, int);
+const dct_fn kPerCallFdct[ODHIP_NBSIZES] = {
+  od_bin_fdct4x4_hip, od_bin_fdct8x8_hip, od_bin_fdct16x16_hip, od_bin_fdct32x32_hip,
+  od_bin_fdct64x64_hip
+};
+
+template <int BS>
+void cached_fdct(od_coeff *out, int out_stride, const od_coeff *in, int in_stride) {
+  odhip_frame_cache *c = g_current;
+  if (c && odhip_cache_lookup(c, in, in_stride, BS, out, out_stride) == 1) return;
+  kPerCallFdct[BS](out, out_stride, in, in_stride);
+}
+
+}  // namespace
+
+extern "C" {
+
+odhip_frame_cache *odhip_cache_create(void) {
+  odhip_frame_cache *c = (odhip_frame_cache *)calloc(1, sizeof(*c));
+  if (!c) return nullptr;
+  if (hipStreamCreate(&c->stream) != hipSuccess) {
+    free(c);
+    return nullptr;
+  }
+  const char *e = getenv("ODHIP_CACHE_CHECK");
+  c->check = e && e[0] == '1';
+  return c;
+}
+
+void odhip_cache_destroy(odhip_frame_cache *c) {
+  if (!c) return;
+  if (g_current == c) g_current = nullptr;
+  for (int i = 0; i < 4; i++) {
+    odhip_frame_cache::Plane &p = c->planes[i];
+    if (p.h_px) (void)hipHostFree(p.h_px);
+    if (p.d_px) (void)hipFree(p.d_px);
+    for (int l = 0; l < ODHIP_NBSIZES; l++) {
+      if (p.h_levels[l]) (void)hipHostFree(p.h_levels[l]);
+      if (p.d_levels[l]) (void)hipFree(p.d_levels[l]);
+    }
+  }
+  (void)hipStreamDestroy(c->stream);
+  free(c);
+}
+
+void odhip_cache_set_picture(odhip_frame_cache *c, int pic_w, int pic_h) {
+  c->pic_w = pic_w;
+  c->pic_h = pic_h;
+}
+
+void odhip_cache_make_current(odhip_frame_cache *c) {
+  g_current = c;
+}
+
+void odhip_cache_stats(const odhip_frame_cache *c, long *hits, long *misses) {
+  if (hits) *hits = c->hits;
+  if (misses) *misses = c->misses;
+}
+
+int odhip_cache_load_plane(odhip_frame_cache *c, int pli, const od_coeff *coef, int stride,
+ int w, int h, int dec) {
+  if (!c || pli < 0 || pli >= 4 || !coef || stride != w || (dec != 0 && dec != 1)) {
+    return ODHIP_EINVAL;
+  }
+  const int tile = 64 >> dec;
+  if (w <= 0 || h <= 0 || w % tile || h % tile || c->pic_w <= 0 || c->pic_h <= 0) {
+    return ODHIP_EINVAL;
+  }
+  odhip_frame_cache::Plane &p = c->planes[pli];
+  p.valid = 0;
+  int rc = plane_reserve(p, w, h, dec);
+  if (rc) return rc;
+  /* od_ref_buf_to_coeff wrote (p - 128) << 4 (src/state.c:1233): recover p. */
+  const size_t n = (size_t)w*h;
+  for (size_t i = 0; i < n; i++) {
+    const int v = coef[i];
+    const int px = (v >> 4) + 128;
+    if ((v & 15) || px < 0 || px > 255) return ODHIP_EINVAL;  /* not a fresh 8-bit plane */
+    p.h_px[i] = (uint8_t)px;
+  }
+  ODHIP_TRY(hipMemcpyAsync(p.d_px, p.h_px, n, hipMemcpyHostToDevice, c->stream));
+  od_coeff *levels[ODHIP_NBSIZES];
+  for (int i = 0; i < ODHIP_NBSIZES; i++) levels[i] = p.d_levels[i];
+  rc = odhip_forward_pyramid(levels, p.d_px, w, (long)n, 1, w, h, dec, c->pic_w, c->pic_h,
+   c->stream);
+  if (rc) return rc;
+  for (int i = 0; i <= 4 - dec; i++) {
+    ODHIP_TRY(hipMemcpyAsync(p.h_levels[i], p.d_levels[i], n*sizeof(od_coeff),
+     hipMemcpyDeviceToHost, c->stream));
+  }
+  ODHIP_TRY(hipStreamSynchronize(c->stream));
+  p.base = coef;
+  p.valid = 1;
+  return ODHIP_SUCCESS;
+}
+
+int odhip_cache_lookup(odhip_frame_cache *c, const od_coeff *in, int in_stride, int bs,
+ od_coeff *out, int out_stride) {
+  if (!c || bs < 0 || bs >= ODHIP_NBSIZES) return 0;
+  const int n = 4 << bs;
+  for (int i = 0; i < 4; i++) {
+    odhip_frame_cache::Plane &p = c->planes[i];
+    if (!p.valid || in_stride != p.w || in < p.base || in >= p.base + (size_t)p.w*p.h) continue;
+    const size_t off = (size_t)(in - p.base);
+    const int y = (int)(off / p.w);
+    const int x = (int)(off % p.w);
+    if (bs > 4 - p.dec || x % n || y % n || x + n > p.w || y + n > p.h) break;
+    const od_coeff *src = p.h_levels[bs] + off;
+    if (c->check) {
+      od_coeff tmp[64*64];
+      kPerCallFdct[bs](tmp, n, in, in_stride);
+      for (int r = 0; r < n; r++) {
+        if (memcmp(tmp + r*n, src + (size_t)r*p.w, n*sizeof(od_coeff)) != 0) {
+          fprintf(stderr, "libdaalahip: frame cache mismatch: plane %d bs %d at (%d,%d)\n", i, bs,
+           x, y);
+          abort();
+        }
+      }
+    }
+    for (int r = 0; r < n; r++) {
+      memcpy(out + (size_t)r*out_stride, src + (size_t)r*p.w, n*sizeof(od_coeff));
+    }
+    c->hits++;
+    return 1;
+  }
+  c->misses++;
+  return 0;
+}
+
+void odhip_install_cached_dct_vtbl(odhip_dct_func_2d fdct_2d[ODHIP_NBSIZES],
+ odhip_dct_func_2d idct_2d[ODHIP_NBSIZES]) {
+  odhip_dct_func_2d tmp[ODHIP_NBSIZES];
+  odhip_install_dct_vtbl(tmp, idct_2d);
+  fdct_2d[0] = cached_fdct<0>;
+  fdct_2d[1] = cached_fdct<1>;
+  fdct_2d[2] = cached_fdct<2>;
+  fdct_2d[3] = cached_fdct<3>;
+  fdct_2d[4] = cached_fdct<4>;
+}
+
+}  /* extern "C" */

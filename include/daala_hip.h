@@ -265,6 +265,35 @@ int odhip_pvq_select_synth_noref(od_coeff *d_dq, const od_coeff *d_coef,
  const odhip_pvq_cands *in, const double *d_rate, int32_t *d_qg_out,
  odhip_stream stream);
 
+/* ---- frame cache: one batched pyramid serving every per-block fdct_2d call ---
+
+   The samples a block of level bs sees in the reference encoder depend only on
+   the source plane and on "every ancestor was split" (SURVEY.md section 7), so
+   one odhip_forward_pyramid per plane yields the output of every fdct_2d call
+   the encoder will make on that plane, in both RDO passes.
+
+   odhip_cache_load_plane is called when the encoder has just converted plane
+   `pli` to coefficients and is about to lap it across superblock edges
+   (od_apply_prefilter_frame_sbs, src/encode.c:2571): `coef` must still hold
+   (p - 128) << 4 (src/state.c:1233), stride == w.  odhip_cache_lookup serves an
+   fdct_2d(out, out_stride, in, in_stride) whose `in` lies inside a loaded plane
+   (returns 1) or reports a miss (returns 0).  odhip_install_cached_dct_vtbl
+   installs fdct_2d entries that try the calling thread's current cache first
+   and fall back to the per-call GPU transform (idct_2d entries are the per-call
+   ones).  ODHIP_CACHE_CHECK=1 verifies every hit against the per-call path. */
+typedef struct odhip_frame_cache odhip_frame_cache;
+odhip_frame_cache *odhip_cache_create(void);
+void odhip_cache_destroy(odhip_frame_cache *c);
+void odhip_cache_set_picture(odhip_frame_cache *c, int pic_w, int pic_h);
+void odhip_cache_make_current(odhip_frame_cache *c);
+int odhip_cache_load_plane(odhip_frame_cache *c, int pli, const od_coeff *coef,
+ int stride, int w, int h, int dec);
+int odhip_cache_lookup(odhip_frame_cache *c, const od_coeff *in, int in_stride,
+ int bs, od_coeff *out, int out_stride);
+void odhip_cache_stats(const odhip_frame_cache *c, long *hits, long *misses);
+void odhip_install_cached_dct_vtbl(odhip_dct_func_2d fdct_2d[ODHIP_NBSIZES],
+ odhip_dct_func_2d idct_2d[ODHIP_NBSIZES]);
+
 #ifdef __cplusplus
 }
 #endif

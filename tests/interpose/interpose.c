@@ -9,36 +9,137 @@
    1789,2571,2675; src/pvq_encoder.c:542,589) to these definitions - the link-time
    override INTEGRATION.md sections 2 and 3 describe.  Counters prove the calls really went
    through. */
+#define _GNU_SOURCE
+#include <dlfcn.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "../../include/daala_hip.h"
+
+/* ODHIP_INTERPOSE_PASSTHROUGH=1: forward to the reference's own definition
+   (the next one in symbol search order) instead of the *_hip entry point; used
+   with the frame cache to time "batched pyramid only" on large frames, where
+   one GPU round trip per 4-tap filter call would dominate. */
+static int passthrough(void) {
+  static int v = -1;
+  if (v < 0) {
+    const char *e = getenv("ODHIP_INTERPOSE_PASSTHROUGH");
+    v = e && e[0] == '1';
+  }
+  return v;
+}
+#include <stdio.h>
+/* dlopen handle of the reference library (dlsym(RTLD_NEXT) does not see
+   libraries outside a dlopen'ed object's own dependency scope). */
+static void *g_reference;
+void odhip_interpose_set_reference(void *handle) {
+  g_reference = handle;
+}
+static void *next_sym(const char *name) {
+  void *p = g_reference ? dlsym(g_reference, name) : NULL;
+  if (!p) {
+    fprintf(stderr, "interpose: no next definition of %s (%s)\n", name, dlerror());
+    abort();
+  }
+  return p;
+}
+#define NEXT(type, name) ((type)next_sym(name))
 
 long odhip_interposed_calls[5];
 
 void od_prefilter_split(od_coeff *c0, int stride, int bs, int f, int hfilter, int vfilter) {
   odhip_interposed_calls[0]++;
+  if (passthrough()) {
+    typedef void (*fn)(od_coeff *, int, int, int, int, int);
+    static fn next;
+    if (!next) next = NEXT(fn, "od_prefilter_split");
+    next(c0, stride, bs, f, hfilter, vfilter);
+    return;
+  }
   od_prefilter_split_hip(c0, stride, bs, f, hfilter, vfilter);
 }
 
 void od_postfilter_split(od_coeff *c0, int stride, int bs, int f, int q, unsigned char *skip,
  int skip_stride, int hfilter, int vfilter) {
   odhip_interposed_calls[1]++;
+  if (passthrough()) {
+    typedef void (*fn)(od_coeff *, int, int, int, int, unsigned char *, int, int, int);
+    static fn next;
+    if (!next) next = NEXT(fn, "od_postfilter_split");
+    next(c0, stride, bs, f, q, skip, skip_stride, hfilter, vfilter);
+    return;
+  }
   od_postfilter_split_hip(c0, stride, bs, f, q, skip, skip_stride, hfilter, vfilter);
 }
+
+static void interpose_load(const od_coeff *c, int stride, int nhsb, int nvsb, int xdec);
 
 void od_apply_prefilter_frame_sbs(od_coeff *c, int stride, int nhsb, int nvsb, int xdec,
  int ydec) {
   odhip_interposed_calls[2]++;
+  interpose_load(c, stride, nhsb, nvsb, xdec);
+  if (passthrough()) {
+    typedef void (*fn)(od_coeff *, int, int, int, int, int);
+    static fn next;
+    if (!next) next = NEXT(fn, "od_apply_prefilter_frame_sbs");
+    next(c, stride, nhsb, nvsb, xdec, ydec);
+    return;
+  }
   od_apply_prefilter_frame_sbs_hip(c, stride, nhsb, nvsb, xdec, ydec);
 }
 
 void od_apply_postfilter_frame_sbs(od_coeff *c, int stride, int nhsb, int nvsb, int xdec,
  int ydec, int q, unsigned char *skip, int skip_stride) {
   odhip_interposed_calls[3]++;
+  if (passthrough()) {
+    typedef void (*fn)(od_coeff *, int, int, int, int, int, int, unsigned char *, int);
+    static fn next;
+    if (!next) next = NEXT(fn, "od_apply_postfilter_frame_sbs");
+    next(c, stride, nhsb, nvsb, xdec, ydec, q, skip, skip_stride);
+    return;
+  }
   od_apply_postfilter_frame_sbs_hip(c, stride, nhsb, nvsb, xdec, ydec, q, skip, skip_stride);
 }
 
 double pvq_search_rdo_double(const int16_t *xcoeff, int n, int k, od_coeff *ypulse, double g2,
  double pvq_norm_lambda, int prev_k) {
   odhip_interposed_calls[4]++;
+  if (passthrough()) {
+    typedef double (*fn)(const int16_t *, int, int, od_coeff *, double, double, int);
+    static fn next;
+    if (!next) next = NEXT(fn, "pvq_search_rdo_double");
+    return next(xcoeff, n, k, ypulse, g2, pvq_norm_lambda, prev_k);
+  }
   return od_pvq_search_rdo_double_hip(xcoeff, n, k, ypulse, g2, pvq_norm_lambda, prev_k);
+}
+
+/* ---- mode 2: the frame cache ------------------------------------------------
+   When enabled (odhip_interpose_enable_cache), the interposed
+   od_apply_prefilter_frame_sbs - the moment the reference has just filled a
+   plane with (p - 128) << 4, src/encode.c:2568-2571 - first hands the plane to
+   odhip_cache_load_plane (one batched GPU pyramid), then laps it as before.
+   With odhip_install_cached_dct_vtbl bound into od_state.opt_vtbl, every later
+   fdct_2d call on that plane is served from the cache. */
+static odhip_frame_cache *g_cache;
+static const od_coeff *g_bases[4];
+static int g_nbases;
+
+void odhip_interpose_enable_cache(int pic_w, int pic_h) {
+  if (!g_cache) g_cache = odhip_cache_create();
+  odhip_cache_set_picture(g_cache, pic_w, pic_h);
+  odhip_cache_make_current(g_cache);
+}
+
+void odhip_interpose_cache_stats(long *hits, long *misses) {
+  odhip_cache_stats(g_cache, hits, misses);
+}
+
+static void interpose_load(const od_coeff *c, int stride, int nhsb, int nvsb, int xdec) {
+  int slot;
+  if (!g_cache) return;
+  for (slot = 0; slot < g_nbases; slot++) if (g_bases[slot] == c) break;
+  if (slot == g_nbases) {
+    if (g_nbases == 4) return;
+    g_bases[g_nbases++] = c;
+  }
+  odhip_cache_load_plane(g_cache, slot, c, stride, nhsb << 6 >> xdec, nvsb << 6 >> xdec, xdec);
 }

@@ -15,7 +15,7 @@ from _libs import P, synth_frame  # noqa: E402
 
 interpose = int(sys.argv[1])
 w = h = 64
-nframes = 2
+nframes = int(os.environ.get("NFRAMES", "2"))
 hip = ctypes.CDLL(os.path.join(ROOT, "daala_amd", "lib", "libdaalahip.so"), mode=ctypes.RTLD_GLOBAL)
 ipo = None
 if interpose:
@@ -23,16 +23,40 @@ if interpose:
     ipo = ctypes.CDLL(os.path.join(ROOT, "tests", "interpose", "libinterpose.so"),
                       mode=ctypes.RTLD_GLOBAL)
 r = ctypes.CDLL(os.path.join(ROOT, "oracle", "_ref", "libdaalaref.so"))
+if ipo is not None:
+    # pass-through mode (ODHIP_INTERPOSE_PASSTHROUGH=1) calls the reference's own definitions
+    ipo.odhip_interpose_set_reference(ctypes.c_void_p(r._handle))
+if interpose == 2:
+    # frame cache: batched pyramid per plane serves every fdct_2d call
+    w, h = int(sys.argv[2]), int(sys.argv[3])
+    ipo.odhip_interpose_enable_cache(w, h)
+    fd = (ctypes.c_void_p * 5)()
+    idt = (ctypes.c_void_p * 5)()
+    hip.odhip_install_cached_dct_vtbl(fd, idt)
+    # ODHIP_CACHE_FDCT_ONLY=1 leaves idct_2d on the reference's C tables (timing runs)
+    r.ref_set_external_dct_vtbl(fd, None if os.environ.get("ODHIP_CACHE_FDCT_ONLY") == "1" else idt)
+elif len(sys.argv) > 3:
+    w, h = int(sys.argv[2]), int(sys.argv[3])
 frames = np.concatenate([np.concatenate([p.ravel() for p in synth_frame(w, h, seed=7, phase=5 * f)])
                          for f in range(nframes)]).astype(np.uint8)
-out = np.zeros(1 << 20, np.uint8)
+out = np.zeros(8 << 20, np.uint8)
 sizes = (ctypes.c_long * 16)()
+import time
+t0 = time.perf_counter()
 n = r.ref_encode_yuv420(P(frames), w, h, nframes, 20, 7, 0, P(out), ctypes.c_long(out.size), sizes)
+seconds = time.perf_counter() - t0
 assert n == nframes, n
 total = sum(sizes[i] for i in range(n))
 calls = [0] * 5
 if ipo is not None:
     arr = (ctypes.c_long * 5).in_dll(ipo, "odhip_interposed_calls")
     calls = [arr[i] for i in range(5)]
-print(json.dumps({"packets": bytes(out[:total]).hex(), "sizes": [sizes[i] for i in range(n)],
-                  "calls": calls}))
+stats = [0, 0]
+if interpose == 2:
+    hits, misses = ctypes.c_long(), ctypes.c_long()
+    ipo.odhip_interpose_cache_stats(ctypes.byref(hits), ctypes.byref(misses))
+    stats = [hits.value, misses.value]
+import hashlib
+print(json.dumps({"packets": hashlib.sha256(bytes(out[:total])).hexdigest(),
+                  "sizes": [sizes[i] for i in range(n)], "calls": calls, "cache": stats,
+                  "encode_seconds": seconds}))

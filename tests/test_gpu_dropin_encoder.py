@@ -69,15 +69,29 @@ def test_reference_encoder_with_interposed_filters_and_pvq_search():
         subprocess.run(["gcc", "-O2", "-fPIC", "-shared", "-o", so,
                         os.path.join(here, "interpose", "interpose.c"),
                         "-L" + os.path.join(here, "..", "daala_amd", "lib"), "-ldaalahip",
-                        "-Wl,-rpath,$ORIGIN/../../daala_amd/lib"], check=True)
-    runs = []
-    for mode in (0, 1):
+                        "-Wl,-rpath,$ORIGIN/../../daala_amd/lib", "-ldl"], check=True)
+    def run(mode, *size, env=None):
+        e = dict(os.environ)
+        e.update(env or {})
         p = subprocess.run([sys.executable, os.path.join(here, "interpose", "run_interposed.py"),
-                            str(mode)], capture_output=True, text=True, timeout=600)
+                            str(mode)] + [str(v) for v in size], capture_output=True, text=True,
+                           timeout=900, env=e)
         assert p.returncode == 0, p.stderr[-2000:]
-        runs.append(json.loads(p.stdout.strip().splitlines()[-1]))
-    assert runs[0]["calls"] == [0] * 5
-    calls = runs[1]["calls"]
-    assert all(c > 0 for c in calls), calls
-    assert runs[1]["sizes"] == runs[0]["sizes"]
-    assert runs[1]["packets"] == runs[0]["packets"], "packets differ with the HIP surfaces bound"
+        return json.loads(p.stdout.strip().splitlines()[-1])
+
+    plain = run(0)
+    bound = run(1)
+    assert plain["calls"] == [0] * 5
+    assert all(c > 0 for c in bound["calls"]), bound["calls"]
+    assert bound["sizes"] == plain["sizes"]
+    assert bound["packets"] == plain["packets"], "packets differ with the HIP surfaces bound"
+    # Frame cache: a 180x116 picture (padded to 192x128 by the encoder, so the
+    # picture-edge gating of the split filters matters).  Every fdct_2d call of
+    # both RDO passes is served from ONE batched GPU pyramid per plane; with
+    # ODHIP_CACHE_CHECK=1 every hit is also verified against the per-call path.
+    plain2 = run(0, 180, 116, env={"NFRAMES": "1"})
+    cached = run(2, 180, 116, env={"NFRAMES": "1", "ODHIP_CACHE_CHECK": "1"})
+    assert cached["sizes"] == plain2["sizes"]
+    assert cached["packets"] == plain2["packets"], "packets differ with the frame cache"
+    hits, misses = cached["cache"]
+    assert hits > 1000 and misses == 0, cached["cache"]
