@@ -193,7 +193,13 @@ host = _Host()
 
 
 # ---- PVQ band stage -----------------------------------------------------------
-_CAND_FIELDS = ("cg", "dist0", "gain", "k", "flags", "yy", "cos_dist", "dist", "y", "choice")
+_CAND_FIELDS = ("band", "y", "choice", "cos_dist")
+
+# odhip_pvq_band (include/daala_hip.h): one 64-byte record per (block, band)
+BAND_RECORD = np.dtype([("cg", "<i4"), ("gain", "<i4", (2,)), ("k", "<i2", (2,)),
+                        ("flags", "u1", (2,)), ("reserved0", "u1", (6,)), ("dist0", "<f8"),
+                        ("yy", "<i4", (2,)), ("dist", "<f8", (2,)), ("reserved1", "u1", (8,))])
+assert BAND_RECORD.itemsize == 64
 
 
 class _Cands(ctypes.Structure):
@@ -219,23 +225,36 @@ def pvq_band_layout(bs):
     return nb.value, [offs[i] for i in range(nb.value + 1)], ln.value
 
 
-def alloc_pvq_cands(nblocks, bs, device):
+def alloc_pvq_cands(nblocks, bs, device, cos_dist=False):
+    """Device buffers of odhip_pvq_cands: 'band' is the [B][nb] array of 64-byte
+    odhip_pvq_band records (as bytes; unpack_cands decodes it), 'y' the int16
+    pulse vectors [2][B][len], 'choice' [B][nb][4]; 'cos_dist' [B][nb][2] only on
+    request (parity checks)."""
     import torch
     nb, _, ln = pvq_band_layout(bs)
-    i32 = dict(dtype=torch.int32, device=device)
-    f64 = dict(dtype=torch.float64, device=device)
-    return {
-        "cg": torch.empty((nblocks, nb), **i32),
-        "dist0": torch.empty((nblocks, nb), **f64),
-        "gain": torch.empty((nblocks, nb, 2), **i32),
-        "k": torch.empty((nblocks, nb, 2), **i32),
-        "flags": torch.empty((nblocks, nb, 2), **i32),
-        "yy": torch.empty((nblocks, nb, 2), **i32),
-        "cos_dist": torch.empty((nblocks, nb, 2), **f64),
-        "dist": torch.empty((nblocks, nb, 2), **f64),
-        "y": torch.zeros((2, nblocks, ln), **i32),
-        "choice": torch.empty((nblocks, nb, 4), **i32),
+    out = {
+        "band": torch.zeros((nblocks, nb, 64), dtype=torch.uint8, device=device),
+        "y": torch.zeros((2, nblocks, ln), dtype=torch.int16, device=device),
+        "choice": torch.empty((nblocks, nb, 4), dtype=torch.int32, device=device),
+        "cos_dist": None,
     }
+    if cos_dist:
+        out["cos_dist"] = torch.zeros((nblocks, nb, 2), dtype=torch.float64, device=device)
+    return out
+
+
+def unpack_cands(cands):
+    """Host copy of a cands dict as numpy arrays keyed by field name: the record
+    fields (cg, gain, k, flags, dist0, yy, dist: [B][nb] or [B][nb][2]) plus y,
+    choice and, when present, cos_dist."""
+    rec = cands["band"].cpu().numpy().view(BAND_RECORD)[..., 0]
+    out = {name: np.ascontiguousarray(rec[name]) for name in
+           ("cg", "gain", "k", "flags", "dist0", "yy", "dist")}
+    out["y"] = cands["y"].cpu().numpy()
+    out["choice"] = cands["choice"].cpu().numpy()
+    if cands.get("cos_dist") is not None:
+        out["cos_dist"] = cands["cos_dist"].cpu().numpy()
+    return out
 
 
 class PvqJob:
@@ -266,7 +285,8 @@ class PvqJob:
     def struct(self):
         opt = lambda t: ctypes.c_void_p(t.data_ptr() if t is not None else None)  # noqa: E731
         nplanes, h, w = self.coef.shape
-        c = _Cands(*[ctypes.c_void_p(self.cands[n].data_ptr()) for n in _CAND_FIELDS])
+        c = _Cands(*[ctypes.c_void_p(self.cands[n].data_ptr() if self.cands.get(n) is not None
+                                     else None) for n in _CAND_FIELDS])
         return _Job(_p(self.coef), nplanes, w, h, self.bs, opt(self.qm), opt(self.qm_inv),
                     self.q_band, self.beta_band, c, opt(self.dq), opt(self.rate), opt(self.qg))
 
@@ -316,7 +336,11 @@ def inverse_level_pvq(job, dec, pic_w, pic_h, out=None):
     return out
 
 
-def pvq_noref_bands(coef, bs, qm, q_band, beta_band, pvq_norm_lambda, out=None):
+def pvq_noref_bands(coef, bs, qm, q_band, beta_band, pvq_norm_lambda, out=None, cos_dist=False):
+    if out is None and cos_dist:
+        nplanes, h, w = coef.shape
+        n = 4 << bs
+        out = alloc_pvq_cands(nplanes * (h // n) * (w // n), bs, coef.device, cos_dist=True)
     job = PvqJob(coef, bs, qm, None, q_band, beta_band, cands=out)
     pvq_noref_bands_multi([job], pvq_norm_lambda)
     return job.cands
@@ -328,7 +352,7 @@ def pvq_select_synth_noref(coef, bs, qm_inv, q_band, beta_band, pvq_norm_lambda,
     if dq is None:
         dq = torch.empty_like(coef)
     if qg is None:
-        qg = torch.empty(tuple(cands["cg"].shape), dtype=torch.int32, device=coef.device)
+        qg = torch.empty(tuple(cands["band"].shape[:2]), dtype=torch.int32, device=coef.device)
     job = PvqJob(coef, bs, None, qm_inv, q_band, beta_band, cands=cands, dq=dq, rate=rate, qg=qg)
     pvq_select_synth_noref_multi([job], pvq_norm_lambda)
     return dq, qg

@@ -539,7 +539,7 @@ struct InverseArgs {
   /* Optional PVQ source (odhip_inverse_level_pvq): when y != NULL the tile is
      not read from a dequantised plane but synthesised on load from the chosen
      pulse vectors; `coef` then only supplies the DCs. */
-  const od_coeff *y;        /* [2][nblocks][len] */
+  const int16_t *y;         /* [2][nblocks][len] */
   const int4 *choice;       /* [nblocks][nb_bands] {slot, qg, scale, qshift} */
   const int16_t *qm_inv;    /* coding order */
   long nblocks;
@@ -638,7 +638,7 @@ __global__ __launch_bounds__(Geo<TILE>::kNT) void k_inverse_sb(InverseArgs a) {
         if (ch.y != 0) {
           const int yv = a.y[(((unsigned)ch.x*(unsigned)a.nblocks + blk) << lsh) + j];
           /* OD_MULT16_32_Q16: (int16)y * (int32)scale >> 16 == mulhi(y << 16, scale) */
-          const int xq = __mulhi((int)(short)yv << 16, ch.z);
+          const int xq = __mulhi(yv << 16, ch.z);
           const int r = xq*s_qmi[j];
           v = (r + ((1 << ch.w) >> 1)) >> ch.w;
         }

@@ -4,21 +4,35 @@
    a batch of coefficient planes, plus the choice/dequantisation that follows.
 
    MULTI-JOB launches.  One (plane set, block size) pair is a "job"; a frame
-   batch has nine (5 luma + 4 chroma levels).  Small jobs (510 64x64 blocks per
-   frame) cannot fill 256 CUs and a launch cannot end before its slowest
-   wavefront, so launching jobs back to back serialises their tails.  Instead
-   every kernel here takes a table of (job, band) work items with a prefix sum
-   of workgroup counts and covers ALL jobs in one launch:
+   batch has nine (5 luma + 4 chroma levels).  Every kernel takes a table of
+   (job, band) work items with a prefix sum of workgroup counts and covers ALL
+   jobs in one launch, so small levels overlap with large ones.
 
-     k_bands_narrow   bands of 8 / 15 coefficients, one band per lane
-     k_bands_wide<E>  bands of 32 / 128 coefficients, one band per 16-lane row
-     k_choose         per band: `cost <= best_cost` choice, od_gain_expand,
-                      synthesis scale (src/pvq.c:766, :1057-1078)
-     k_synth          per coefficient: y*scale, inverse QM, scan -> raster
-                      (src/pvq.c:1081-1092, src/partition.c:176-194), written as
-                      coalesced rows of the dequantised plane
+   SORTED SEARCH.  The cost of a band is its pulse count, which spans 1..350
+   within one level, and a wavefront runs as long as its slowest lane.  So:
 
-   Layouts: see odhip_pvq_cands in include/daala_hip.h. */
+     k_prep_lane / k_prep_wide     QM scaling to x16 (library scratch), gain, the
+                                   two candidates' K and pruning decision
+                                   (first half of the band record), and a SORT
+                                   KEY = binned (pulses of candidate 0, extra
+                                   pulses of candidate 1)
+     k_sort_chunk                  counting sort of the block indices of each
+                                   (job, band) item by key, within windows of
+                                   4096 blocks, heavy first
+     k_search<N>                   one band per lane over the sorted order: the
+                                   64 bands of a wavefront need (almost) the same
+                                   number of pulses (pvq_lane.cuh)
+     k_choose                      per band: `cost <= best_cost` choice,
+                                   od_gain_expand, synthesis scale
+                                   (src/pvq.c:766, :1057-1078)
+     k_synth                       per coefficient: y*scale, inverse QM,
+                                   scan -> raster (src/pvq.c:1081-1092,
+                                   src/partition.c:176-194)
+
+   Memory: every global access of the hot kernels is a whole 16-byte vector per
+   lane and every record half a whole 32-byte sector (odhip_pvq_band in
+   include/daala_hip.h): the earlier structure-of-arrays layout with 2..8-byte
+   scattered stores wrote 3x the bytes (rocprofv3 WRITE_SIZE). */
 #include "../../include/daala_hip.h"
 #include <stdlib.h>
 #include <string.h>
@@ -26,6 +40,7 @@
 #include "od_pvq_math.cuh"
 #include "gen/od_scan_tables.h"
 #include "pvq_search.cuh"
+#include "pvq_lane.cuh"
 
 namespace {
 
@@ -36,10 +51,17 @@ struct DJob {
   const od_coeff *coef;
   const int16_t *qm;
   const int16_t *qm_inv;
-  odhip_pvq_cands c;
+  odhip_pvq_band *rec;
+  int16_t *y;
+  int32_t *choice;
+  double *cos_dist;
   od_coeff *dq;
   const double *rate;
   int32_t *qg_out;
+  /* library scratch of the sorted band stage */
+  int16_t *x16;            /* [B][len]  QM-scaled band vectors, coding order      */
+  unsigned short *keys;    /* [nb][B]   sort key (pulse-count class)              */
+  unsigned *ids;           /* [nb][B]   block indices sorted by key               */
   long nblocks;
   int nplanes;
   int w;
@@ -56,7 +78,7 @@ struct DJob {
 
 struct Items {
   int nitems;
-  int force_scan;
+  int reserved;
   double lambda;
   int wg_start[kMaxItems + 1];
   unsigned char job[kMaxItems];
@@ -65,9 +87,9 @@ struct Items {
 
 __device__ DJob g_jobs[kMaxJobs];
 /* Scan tables.  kScanXY is indexed wave-uniformly by the one-band-per-lane
-   kernel (scalar loads); the kernels that index per lane copy their table into
-   LDS first - a constant-memory access with 64 different addresses
-   serialises. */
+   preparation kernel (scalar loads); the kernels that index per lane copy
+   their table into LDS first - a constant-memory access with 64 different
+   addresses serialises. */
 __constant__ unsigned char kScanXY[OD_SCAN_LEN][2];
 __device__ unsigned short gScanXY[OD_SCAN_LEN];  /* y << 8 | x */
 __device__ short gInvScan[32*32];                /* raster (y*32 + x) -> coding index, -1 */
@@ -105,121 +127,160 @@ __device__ __forceinline__ BlockPos locate(const DJob &j, long blk) {
   return r;
 }
 
-/* Per-candidate bookkeeping shared by both band kernels: src/pvq_encoder.c:
-   :575-595. */
-struct CandOut {
-  int gain;
-  int k;
-  int flag;
-  int yy;
-  double cos_dist;
-  double dist;
+constexpr int kKeyBins = 1024;
+constexpr int kSortChunk = 4096;
+
+__device__ __forceinline__ int od_pulse_bin(int p) {   /* 0..63, monotone */
+  if (p < 24) return p;
+  if (p < 32) return 24 + ((p - 24) >> 1);
+  if (p < 64) return 28 + ((p - 32) >> 2);
+  if (p < 128) return 36 + ((p - 64) >> 3);
+  if (p < 256) return 44 + ((p - 128) >> 4);
+  if (p < 512) return 52 + ((p - 256) >> 5);
+  const int t = (p - 512) >> 7;
+  return 60 + (t < 3 ? t : 3);
+}
+
+__device__ __forceinline__ int od_extra_bin(int p) {   /* 0..15, monotone */
+  if (p < 12) return p;
+  if (p < 16) return 12;
+  if (p < 24) return 13;
+  if (p < 48) return 14;
+  return 15;
+}
+
+/* First half of a band record as the two 16-byte vectors it is stored in. */
+struct RecHead {
+  int32_t cg;
+  int32_t gain[2];
+  int k[2];
+  int flags[2];
 };
 
-/* ---- short bands: one band per lane ------------------------------------------ */
-__global__ __launch_bounds__(kWave) void k_bands_narrow(Items it) {
-  extern __shared__ __attribute__((aligned(16))) unsigned short lds[];
-  od_rsqrt_init(threadIdx.x);
+__device__ __forceinline__ RecHead rec_head_load(const odhip_pvq_band *r) {
+  const int4 a = reinterpret_cast<const int4 *>(r)[0];
+  const int4 b = reinterpret_cast<const int4 *>(r)[1];
+  RecHead h;
+  h.cg = a.x;
+  h.gain[0] = a.y;
+  h.gain[1] = a.z;
+  h.k[0] = (int16_t)(a.w & 0xffff);
+  h.k[1] = a.w >> 16;
+  h.flags[0] = b.x & 0xff;
+  h.flags[1] = b.x >> 8 & 0xff;
+  return h;
+}
+
+/* Everything of a band that precedes the search, from cg on: the two gain
+   candidates (src/pvq_encoder.c:578-592), the first half of the record and the
+   sort key.  Heavy bands get SMALL keys so that they are dispatched first. */
+__device__ __forceinline__ void od_band_candidates(const DJob &jb, int band, int n, long blk,
+ int32_t cg, int beta) {
+  const double s2 = (1./256)*(1./256);  /* OD_CGAIN_SCALE_2 */
+  const double dist0 = ((1.4*cg)*cg)*s2;
+  const int gain_bound = cg >> ODQ_CGAIN_SHIFT;
+  const int first = gain_bound > 1 ? gain_bound : 1;
+  int kk[2] = {0, 0};
+  int fl[2] = {0, 0};
+  int gain[2] = {0, 0};
+  for (int c = 0; c < 2; c++) {
+    const int i = first + c;
+    if (i <= gain_bound + 1) {
+      const int32_t qcg = odq_shl32(i, ODQ_CGAIN_SHIFT);
+      gain[c] = i;
+      kk[c] = odq_compute_k_noref(qcg, n, beta);
+      const double dist = ((1.4*(qcg - cg))*(qcg - cg))*s2;
+      fl[c] = !(dist > dist0 && kk[c] != 0);
+      if (fl[c] && kk[c] > kMaxK) fl[c] = 2;   /* not representable: reported, not searched */
+      if (kk[c] > kMaxK) kk[c] = kMaxK;
+    }
+  }
+  int4 *out = reinterpret_cast<int4 *>(jb.rec + blk*jb.nb_bands + band);
+  out[0] = make_int4(cg, gain[0], gain[1], (kk[0] & 0xffff) | kk[1] << 16);
+  out[1] = make_int4(fl[0] | fl[1] << 8, 0, __double2loint(dist0), __double2hiint(dist0));
+  const bool s0 = fl[0] == 1;
+  const bool s1 = fl[1] == 1;
+  const int p0 = s0 ? kk[0] : 0;
+  int p1 = 0;
+  if (s1) p1 = s0 && kk[0] > 0 && kk[0] <= kk[1] ? kk[1] - kk[0] : kk[1];
+  jb.keys[(long)band*jb.nblocks + blk] =
+   (unsigned short)(kKeyBins - 1 - (od_pulse_bin(p0) << 4 | od_extra_bin(p1)));
+}
+
+/* ---- prep, bands of up to 32 coefficients: one band per lane ------------------
+   The band is gathered in coding order (od_raster_to_coding_order,
+   src/partition.c:144-170) with ALL its loads in flight at once (one exposed
+   memory latency per band, not one per four coefficients),
+   od_vector_log_mag (src/pvq.c:472-484) gives the scaling shift, and the QM
+   scaling (src/pvq_encoder.c:381,:398) is written as whole 16-byte groups of
+   x16 (the 15-coefficient band includes the unused DC slot of its block). */
+template <int N>
+__device__ __forceinline__ void od_prep_lane(const DJob &jb, int band, int off, const BlockPos &bp) {
+  constexpr int PAD = N == 15 ? 1 : 0;
+  constexpr int NV = (N + PAD)/8;
+  int v[N];
+#pragma unroll
+  for (int j = 0; j < N; j++) v[j] = bp.src[kScanXY[off + j][1]*jb.w + kScanXY[off + j][0]];
+  int sum = 0;
+#pragma unroll
+  for (int j = 0; j < N; j++) {
+    const int t = (int16_t)(v[j] >> 8);
+    sum += t*t;
+  }
+  int xshift = 8 + 1 + odq_ilog(N + sum)/2 - 15;
+  xshift = xshift > 0 ? xshift : 0;
+  int4 *xo = reinterpret_cast<int4 *>(jb.x16 + bp.blk*jb.len + off - PAD);
+  int acc = 0;
+#pragma unroll
+  for (int g = 0; g < NV; g++) {
+    int d[4];
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+      int x[2];
+#pragma unroll
+      for (int u = 0; u < 2; u++) {
+        const int j = g*8 + 2*t + u - PAD;
+        x[u] = 0;
+        if (j >= 0) x[u] = (int16_t)odq_shr_round(v[j]*jb.qm[off + j], ODQ_QM_SHIFT + xshift);
+        acc += x[u]*x[u];
+      }
+      d[t] = (x[0] & 0xffff) | x[1] << 16;
+    }
+    if (bp.live) xo[g] = make_int4(d[0], d[1], d[2], d[3]);
+  }
+  if (!bp.live) return;
+  int32_t g;
+  const int32_t cg = odq_gain_from_acc(acc, jb.q[band], jb.beta[band], xshift, &g);
+  od_band_candidates(jb, band, N, bp.blk, cg, jb.beta[band]);
+}
+
+__global__ __launch_bounds__(kWave) void k_prep_lane(Items it) {
   const int item = find_item(it, blockIdx.x);
   const DJob &jb = g_jobs[it.job[item]];
   const int band = it.band[item];
   const int off = jb.off[band];
   const int n = jb.off[band + 1] - off;
-  const int q = jb.q[band];
-  const int beta = jb.beta[band];
-  const int lane = threadIdx.x;
-  const BlockPos bp = locate(jb, (long)(blockIdx.x - it.wg_start[item])*kWave + lane);
-  int *x0s = (int *)lds;                 /* [n][64] int32 stash, then ...   */
-  short *xs = (short *)lds;              /* ... x16 [n][64] in its low half */
-  unsigned short *ys = lds + n*kWave;    /* |y| [n][64]                     */
-  /* od_vector_log_mag, src/pvq.c:472-484, while gathering the band in coding
-     order (od_raster_to_coding_order, src/partition.c:144-170). */
-  int sum = 0;
-  for (int j = 0; j < n; j++) {
-    const int v = bp.src[kScanXY[off + j][1]*jb.w + kScanXY[off + j][0]];
-    x0s[j*kWave + lane] = v;
-    const int t = (int16_t)(v >> 8);
-    sum += t*t;
-  }
-  int xshift = 8 + 1 + odq_ilog(n + sum)/2 - 15;
-  xshift = xshift > 0 ? xshift : 0;
-  int acc = 0;
-  for (int j = 0; j < n; j++) {
-    const int v = x0s[j*kWave + lane];
-    const int16_t x16 = (int16_t)odq_shr_round(v*jb.qm[off + j], ODQ_QM_SHIFT + xshift);
-    /* In-place narrowing: row j of the int16 view lies inside int32 row j/2,
-       which every lane of this (single-wave) workgroup has already read. */
-    xs[j*kWave + lane] = x16;
-    acc += x16*(int)x16;
-  }
-  int32_t g;
-  const int32_t cg = odq_gain_from_acc(acc, q, beta, xshift, &g);
-  const double s2 = (1./256)*(1./256);  /* OD_CGAIN_SCALE_2 */
-  const double dist0 = ((1.4*cg)*cg)*s2;
-  const long sb = bp.blk*jb.nb_bands + band;
-  if (bp.live) {
-    jb.c.cg[sb] = cg;
-    jb.c.dist0[sb] = dist0;
-  }
-  const int gain_bound = cg >> ODQ_CGAIN_SHIFT;
-  const int first = gain_bound > 1 ? gain_bound : 1;
-  int prev_k = 0;
-  for (int c = 0; c < 2; c++) {
-    const int i = first + c;
-    CandOut o = {0, 0, 0, 0, 0., 0.};
-    if (i <= gain_bound + 1) {
-      const int32_t qcg = odq_shl32(i, ODQ_CGAIN_SHIFT);
-      o.gain = i;
-      o.k = odq_compute_k_noref(qcg, n, beta);
-      o.dist = ((1.4*(qcg - cg))*(qcg - cg))*s2;
-      if (!(o.dist > dist0 && o.k != 0)) {
-        double yy;
-        o.flag = 1;
-        o.cos_dist = od_pvq_search_lane(xs, ys, lane, n, o.k, prev_k, (qcg*(double)cg)*s2,
-         it.lambda, &yy);
-        o.yy = (int)yy;
-        prev_k = o.k;
-        o.dist = ((1.4*(qcg - cg))*(qcg - cg) + (qcg*(double)cg)*(2 - 2*o.cos_dist))*s2;
-      }
-    }
-    if (bp.live) {
-      jb.c.gain[2*sb + c] = o.gain;
-      jb.c.k[2*sb + c] = o.k;
-      jb.c.flags[2*sb + c] = o.flag;
-      jb.c.yy[2*sb + c] = o.yy;
-      jb.c.cos_dist[2*sb + c] = o.cos_dist;
-      jb.c.dist[2*sb + c] = o.dist;
-      od_coeff *yo = jb.c.y + ((long)c*jb.nblocks + bp.blk)*jb.len + off;
-      if (o.flag) {
-        for (int j = 0; j < n; j++) {
-          const int yj = ys[j*kWave + lane];
-          yo[j] = xs[j*kWave + lane] < 0 ? -yj : yj;
-        }
-      }
-      else {
-        for (int j = 0; j < n; j++) yo[j] = 0;
-      }
-    }
-  }
+  const BlockPos bp = locate(jb, (long)(blockIdx.x - it.wg_start[item])*kWave + threadIdx.x);
+  if (n == 8) od_prep_lane<8>(jb, band, off, bp);
+  else if (n == 15) od_prep_lane<15>(jb, band, off, bp);
+  else od_prep_lane<32>(jb, band, off, bp);
 }
 
-/* ---- long bands: n = 16*E coefficients per 16-lane DPP row, 4 bands per wave */
-template <int E>
-__global__ __launch_bounds__(kWave) void k_bands_wide(Items it) {
+/* ---- prep, 128-coefficient bands: one band per 16-lane DPP row ---------------- */
+__global__ __launch_bounds__(kWave) void k_prep_wide(Items it) {
+  constexpr int E = 8;
   constexpr int n = 16*E;
   const int item = find_item(it, blockIdx.x);
   const DJob &jb = g_jobs[it.job[item]];
   const int band = it.band[item];
   const int off = jb.off[band];
-  const int q = jb.q[band];
-  const int beta = jb.beta[band];
   const int lane = threadIdx.x;
   const int row = lane >> 4;
   const int l = lane & 15;
   const BlockPos bp = locate(jb, (long)(blockIdx.x - it.wg_start[item])*4 + row);
   __shared__ unsigned short s_scan[n];
   for (int j = lane; j < n; j += kWave) s_scan[j] = gScanXY[off + j];
-  od_rsqrt_init(lane);
+  __syncthreads();
   int v[E];
   int sum = 0;
 #pragma unroll
@@ -232,61 +293,177 @@ __global__ __launch_bounds__(kWave) void k_bands_wide(Items it) {
   sum = row_sum(sum);
   int xshift = 8 + 1 + odq_ilog(n + sum)/2 - 15;
   xshift = xshift > 0 ? xshift : 0;
-  int x16[E];
-  int ax[E];
-  int y[E];
   int acc = 0;
+  int d[E/2];
 #pragma unroll
-  for (int e = 0; e < E; e++) {
-    x16[e] = (int16_t)odq_shr_round(v[e]*jb.qm[off + l*E + e], ODQ_QM_SHIFT + xshift);
-    ax[e] = abs(x16[e]);
-    y[e] = 0;
-    acc += x16[e]*x16[e];
+  for (int e = 0; e < E; e += 2) {
+    const int x0 = (int16_t)odq_shr_round(v[e]*jb.qm[off + l*E + e], ODQ_QM_SHIFT + xshift);
+    const int x1 = (int16_t)odq_shr_round(v[e + 1]*jb.qm[off + l*E + e + 1], ODQ_QM_SHIFT + xshift);
+    acc += x0*x0 + x1*x1;
+    d[e/2] = (x0 & 0xffff) | x1 << 16;
+  }
+  if (bp.live) {
+    *reinterpret_cast<int4 *>(jb.x16 + bp.blk*jb.len + off + l*E) = make_int4(d[0], d[1], d[2], d[3]);
   }
   acc = row_sum(acc);
+  if (!bp.live || l != 0) return;
   int32_t g;
-  const int32_t cg = odq_gain_from_acc(acc, q, beta, xshift, &g);
-  const double s2 = (1./256)*(1./256);
-  const double dist0 = ((1.4*cg)*cg)*s2;
-  const long sb = bp.blk*jb.nb_bands + band;
-  if (bp.live && l == 0) {
-    jb.c.cg[sb] = cg;
-    jb.c.dist0[sb] = dist0;
-  }
-  const int gain_bound = cg >> ODQ_CGAIN_SHIFT;
-  const int first = gain_bound > 1 ? gain_bound : 1;
-  int prev_k = 0;
-  for (int c = 0; c < 2; c++) {
-    const int i = first + c;
-    CandOut o = {0, 0, 0, 0, 0., 0.};
-    if (i <= gain_bound + 1) {
-      const int32_t qcg = odq_shl32(i, ODQ_CGAIN_SHIFT);
-      o.gain = i;
-      o.k = odq_compute_k_noref(qcg, n, beta);
-      o.dist = ((1.4*(qcg - cg))*(qcg - cg))*s2;
-      if (!(o.dist > dist0 && o.k != 0)) {
-        double yy;
-        o.flag = 1;
-        o.cos_dist = od_pvq_search_row<E>(ax, y, row, l, o.k, prev_k, (qcg*(double)cg)*s2,
-         it.lambda, it.force_scan, &yy);
-        o.yy = (int)yy;
-        prev_k = o.k;
-        o.dist = ((1.4*(qcg - cg))*(qcg - cg) + (qcg*(double)cg)*(2 - 2*o.cos_dist))*s2;
-      }
-    }
-    if (bp.live) {
-      if (l == 0) {
-        jb.c.gain[2*sb + c] = o.gain;
-        jb.c.k[2*sb + c] = o.k;
-        jb.c.flags[2*sb + c] = o.flag;
-        jb.c.yy[2*sb + c] = o.yy;
-        jb.c.cos_dist[2*sb + c] = o.cos_dist;
-        jb.c.dist[2*sb + c] = o.dist;
-      }
-      od_coeff *yo = jb.c.y + ((long)c*jb.nblocks + bp.blk)*jb.len + off + l*E;
+  const int32_t cg = odq_gain_from_acc(acc, jb.q[band], jb.beta[band], xshift, &g);
+  od_band_candidates(jb, band, n, bp.blk, cg, jb.beta[band]);
+}
+
+/* ---- counting sort of block indices by key, within windows of kSortChunk blocks -
+   A window of consecutive blocks is sorted on its own (LDS histogram, prefix,
+   scatter), heavy bands first.  The 64 lanes of a search wavefront then take
+   64 consecutive sorted positions of ONE window: their pulse counts are close
+   (1/64 of the window's sorted range) and their records, x16 and pulse vectors
+   lie within the window's few hundred KiB - a global sort made every lane's
+   32-byte access a random DRAM transaction (66% of wave cycles waiting). */
+__global__ __launch_bounds__(256) void k_sort_chunk(Items it) {
+  __shared__ unsigned h[kKeyBins];
+  __shared__ unsigned part[256];
+  const int item = find_item(it, blockIdx.x);
+  const DJob &jb = g_jobs[it.job[item]];
+  const long ibase = (long)it.band[item]*jb.nblocks;
+  const unsigned short *keys = jb.keys + ibase;
+  for (int b = threadIdx.x; b < kKeyBins; b += 256) h[b] = 0;
+  __syncthreads();
+  const long start = (long)(blockIdx.x - it.wg_start[item])*kSortChunk;
+  int key[kSortChunk/256];
+  unsigned rank[kSortChunk/256];
 #pragma unroll
-      for (int e = 0; e < E; e++) yo[e] = o.flag ? (x16[e] < 0 ? -y[e] : y[e]) : 0;
+  for (int t = 0; t < kSortChunk/256; t++) {
+    const long i = start + t*256 + threadIdx.x;
+    key[t] = -1;
+    if (i < jb.nblocks) {
+      key[t] = keys[i];
+      rank[t] = atomicAdd(&h[key[t]], 1u);
     }
+  }
+  __syncthreads();
+  /* exclusive prefix sum of the 1024 bins: 4 bins per thread + scan of partials */
+  unsigned c[kKeyBins/256];
+  unsigned sum = 0;
+#pragma unroll
+  for (int i = 0; i < kKeyBins/256; i++) {
+    c[i] = h[threadIdx.x*(kKeyBins/256) + i];
+    sum += c[i];
+  }
+  part[threadIdx.x] = sum;
+  __syncthreads();
+  for (int d = 1; d < 256; d <<= 1) {
+    const unsigned t = threadIdx.x >= d ? part[threadIdx.x - d] : 0;
+    __syncthreads();
+    part[threadIdx.x] += t;
+    __syncthreads();
+  }
+  unsigned run = part[threadIdx.x] - sum;
+#pragma unroll
+  for (int i = 0; i < kKeyBins/256; i++) {
+    h[threadIdx.x*(kKeyBins/256) + i] = run;
+    run += c[i];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int t = 0; t < kSortChunk/256; t++) {
+    if (key[t] >= 0) {
+      jb.ids[ibase + start + h[key[t]] + rank[t]] = (unsigned)(start + t*256 + threadIdx.x);
+    }
+  }
+}
+
+/* ---- search: one band per lane over the sorted order --------------------------
+   Every lane reads its band's x16 with 16-byte loads, unpacks |x| << 16 into
+   its LDS column, searches both candidates, and writes the signed pulses
+   (int16, signs from re-reading x16; src/pvq_encoder.c:220-222) with 16-byte
+   stores and the second half of the band record as one 32-byte sector.  No
+   cross-lane traffic. */
+template <int N>
+__global__ __launch_bounds__(kWave) void k_search(Items it) {
+  constexpr int PAD = N == 15 ? 1 : 0;      /* leading DC slot */
+  constexpr int NV = (N + PAD)/8;           /* 16-byte groups of int16 */
+  static_assert((N + PAD)%8 == 0, "band must be a whole number of 16-byte groups");
+  extern __shared__ __attribute__((aligned(16))) double lds_d[];
+  double *rsq = lds_d;                                   /* [kRsqN]  */
+  uint32_t *pk = (uint32_t *)(rsq + kRsqN);              /* [N][64]  */
+  const int lane = threadIdx.x;
+  for (int i = lane; i < kRsqN; i += kWave) rsq[i] = gRsqTable[i];
+  const int item = find_item(it, blockIdx.x);
+  const DJob &jb = g_jobs[it.job[item]];
+  const int band = it.band[item];
+  const int off = jb.off[band] - PAD;
+  const long nblocks = jb.nblocks;
+  const int len = jb.len;
+  const long spos = (long)(blockIdx.x - it.wg_start[item])*kWave + lane;
+  const bool live = spos < nblocks;
+  const long blk = live ? (long)jb.ids[(long)band*nblocks + spos] : 0;
+  odhip_pvq_band *const rec = jb.rec + blk*jb.nb_bands + band;
+  RecHead hd = {0, {0, 0}, {0, 0}, {0, 0}};
+  if (live) hd = rec_head_load(rec);
+  const int4 *xv = reinterpret_cast<const int4 *>(jb.x16 + blk*len + off);
+  {
+    int4 q[NV];
+#pragma unroll
+    for (int v = 0; v < NV; v++) q[v] = live ? xv[v] : make_int4(0, 0, 0, 0);
+#pragma unroll
+    for (int v = 0; v < NV; v++) {
+      const int d[4] = {q[v].x, q[v].y, q[v].z, q[v].w};
+#pragma unroll
+      for (int t = 0; t < 4; t++) {
+        const int j0 = v*8 + 2*t - PAD;
+        if (j0 >= 0) pk[j0*kWave + lane] = (uint32_t)abs((int)(short)d[t]) << 16;
+        pk[(j0 + 1)*kWave + lane] = (uint32_t)abs(d[t] >> 16) << 16;
+      }
+    }
+  }
+  __syncthreads();   /* the 1/sqrt table */
+  LaneSearch st;
+  od_lane_prepare<N>(st, pk, lane);
+  const int32_t cg = hd.cg;
+  const double s2 = (1./256)*(1./256);
+  int prev_k = 0;
+  int yy[2];
+  double dist[2];
+  for (int c = 0; c < 2; c++) {
+    const bool on = hd.flags[c] == 1;
+    const int k = hd.k[c];
+    const int32_t qcg = odq_shl32(hd.gain[c], ODQ_CGAIN_SHIFT);
+    const double g2 = (qcg*(double)cg)*s2;
+    const bool fresh = !(prev_k > 0 && prev_k <= k);
+    const double cos_dist = od_lane_search<N>(st, pk, rsq, lane, on, fresh, k, g2, it.lambda);
+    /* src/pvq_encoder.c:586,:593-595; a slot that is not in use has distortion 0 */
+    yy[c] = 0;
+    dist[c] = hd.gain[c] ? ((1.4*(qcg - cg))*(qcg - cg))*s2 : 0.;
+    if (on) {
+      prev_k = k;
+      yy[c] = (int)st.yy;
+      dist[c] = ((1.4*(qcg - cg))*(qcg - cg) + (qcg*(double)cg)*(2 - 2*cos_dist))*s2;
+    }
+    if (live) {
+      if (jb.cos_dist) jb.cos_dist[2*(blk*jb.nb_bands + band) + c] = on ? cos_dist : 0.;
+      int4 *yo = reinterpret_cast<int4 *>(jb.y + ((long)c*nblocks + blk)*len + off);
+#pragma unroll 2
+      for (int v = 0; v < NV; v++) {
+        const int4 q = xv[v];
+        const int d[4] = {q.x, q.y, q.z, q.w};
+        int o[4];
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+          const int j0 = v*8 + 2*t - PAD;
+          const int y0 = j0 >= 0 && on ? (int)(pk[j0*kWave + lane] >> 1 & 0x7fffu) : 0;
+          const int y1 = on ? (int)(pk[(j0 + 1)*kWave + lane] >> 1 & 0x7fffu) : 0;
+          const int s0 = (int)(short)d[t] >> 31;
+          const int s1 = d[t] >> 31;
+          o[t] = (((y0 ^ s0) - s0) & 0xffff) | ((y1 ^ s1) - s1) << 16;
+        }
+        yo[v] = make_int4(o[0], o[1], o[2], o[3]);
+      }
+    }
+  }
+  if (live) {
+    int4 *out = reinterpret_cast<int4 *>(rec) + 2;
+    out[0] = make_int4(yy[0], yy[1], __double2loint(dist[0]), __double2hiint(dist[0]));
+    out[1] = make_int4(__double2loint(dist[1]), __double2hiint(dist[1]), 0, 0);
   }
 }
 
@@ -302,16 +479,23 @@ __global__ __launch_bounds__(256) void k_choose(Items it) {
   const long sb = (long)(blockIdx.x - it.wg_start[item])*256 + threadIdx.x;
   if (sb >= jb.nblocks*jb.nb_bands) return;
   const int band = (int)(sb % jb.nb_bands);
-  double best_cost = jb.c.dist0[sb];
+  const int4 *r = reinterpret_cast<const int4 *>(jb.rec + sb);
+  const RecHead hd = rec_head_load(jb.rec + sb);
+  const int4 r1 = r[1];
+  const int4 r2 = r[2];
+  const int4 r3 = r[3];
+  const int yys[2] = {r2.x, r2.y};
+  const double dists[2] = {__hiloint2double(r2.w, r2.z), __hiloint2double(r3.y, r3.x)};
+  double best_cost = __hiloint2double(r1.w, r1.z);
   int qg = 0;
   int sel = 0;
   for (int c = 0; c < 2; c++) {
-    if (!jb.c.flags[2*sb + c]) continue;
-    double cost = jb.c.dist[2*sb + c];
+    if (hd.flags[c] != 1) continue;
+    double cost = dists[c];
     if (jb.rate) cost = cost + it.lambda*jb.rate[2*sb + c];
     if (cost <= best_cost) {
       best_cost = cost;
-      qg = jb.c.gain[2*sb + c];
+      qg = hd.gain[c];
       sel = c;
     }
   }
@@ -319,7 +503,7 @@ __global__ __launch_bounds__(256) void k_choose(Items it) {
   int qshift = ODQ_QM_INV_SHIFT;
   if (qg != 0) {
     const int32_t g = odq_gain_expand(odq_shl32(qg, ODQ_CGAIN_SHIFT), jb.q[band], jb.beta[band]);
-    const int yy = jb.c.yy[2*sb + sel];
+    const int yy = yys[sel];
     int gshift = odq_ilog(g) - 14;
     gshift = gshift > 0 ? gshift : 0;
     if (yy != 0) {
@@ -329,7 +513,7 @@ __global__ __launch_bounds__(256) void k_choose(Items it) {
     }
     qshift = ODQ_QM_INV_SHIFT - gshift;
   }
-  reinterpret_cast<int4 *>(jb.c.choice)[sb] = make_int4(sel, qg, scale, qshift);
+  reinterpret_cast<int4 *>(jb.choice)[sb] = make_int4(sel, qg, scale, qshift);
   if (jb.qg_out) jb.qg_out[sb] = qg;
 }
 
@@ -365,7 +549,7 @@ __global__ __launch_bounds__(256) void k_synth(Items it) {
   const int nbx = min(1024 >> sh, jb.bw - bx0);    /* blocks this segment touches */
   const long blk0 = ((long)p*jb.bh + by)*jb.bw + bx0;
   for (int i = threadIdx.x; i < nbx*jb.nb_bands; i += 256) {
-    s_choice[i] = reinterpret_cast<const int4 *>(jb.c.choice)[blk0*jb.nb_bands + i];
+    s_choice[i] = reinterpret_cast<const int4 *>(jb.choice)[blk0*jb.nb_bands + i];
   }
   __syncthreads();
   const int x = x0 + threadIdx.x*4;
@@ -385,7 +569,7 @@ __global__ __launch_bounds__(256) void k_synth(Items it) {
         const int band = s_band[j];
         const int4 ch = s_choice[bxl*jb.nb_bands + band];
         if (ch.y != 0) {
-          const int yv = jb.c.y[((long)ch.x*jb.nblocks + blk)*jb.len + j];
+          const int yv = jb.y[((long)ch.x*jb.nblocks + blk)*jb.len + j];
           const int32_t xq = (int32_t)((int16_t)yv*(int64_t)ch.z >> 16);
           v = odq_shr_round(xq*jb.qm_inv[j], ch.w);
         }
@@ -416,6 +600,8 @@ int upload_tables(void) {
   ODHIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(gScanXY), packed, sizeof(packed)));
   ODHIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(gInvScan), inv, sizeof(inv)));
   ODHIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(gBandOf), band_of, sizeof(band_of)));
+  k_rsq_fill<<<1, kRsqN, 0, 0>>>();
+  ODHIP_TRY(hipDeviceSynchronize());
   g_tables_uploaded = true;
   return ODHIP_SUCCESS;
 }
@@ -426,8 +612,8 @@ int fill_job(DJob &d, const odhip_pvq_job &j, int mode) {
     return ODHIP_EINVAL;
   }
   const odhip_pvq_cands &c = j.cands;
-  if (!c.cg || !c.dist0 || !c.gain || !c.k || !c.flags || !c.yy || !c.cos_dist || !c.dist
-   || !c.y || !c.choice) {
+  if (!c.band || !c.y || !c.choice) return ODHIP_EINVAL;
+  if (((uintptr_t)c.band & 63) || ((uintptr_t)c.y & 15) || ((uintptr_t)c.choice & 15)) {
     return ODHIP_EINVAL;
   }
   /* mode 0: band stage (needs qm); 1: choice + synthesis (qm_inv, dq); 2: choice only */
@@ -438,7 +624,10 @@ int fill_job(DJob &d, const odhip_pvq_job &j, int mode) {
   d.coef = j.d_coef;
   d.qm = j.d_qm;
   d.qm_inv = j.d_qm_inv;
-  d.c = c;
+  d.rec = c.band;
+  d.y = c.y;
+  d.choice = c.choice;
+  d.cos_dist = c.cos_dist;
   d.dq = j.d_dq;
   d.rate = j.d_rate;
   d.qg_out = j.d_qg;
@@ -460,8 +649,7 @@ int fill_job(DJob &d, const odhip_pvq_job &j, int mode) {
   return ODHIP_SUCCESS;
 }
 
-int stage_jobs(const odhip_pvq_job *jobs, int njobs, int mode, DJob *host,
- hipStream_t s) {
+int fill_jobs(const odhip_pvq_job *jobs, int njobs, int mode, DJob *host) {
   if (!jobs || njobs <= 0 || njobs > kMaxJobs) return ODHIP_EINVAL;
   int rc = upload_tables();
   if (rc) return rc;
@@ -469,10 +657,55 @@ int stage_jobs(const odhip_pvq_job *jobs, int njobs, int mode, DJob *host,
     rc = fill_job(host[i], jobs[i], mode);
     if (rc) return rc;
   }
+  return ODHIP_SUCCESS;
+}
+
+int upload_jobs(const DJob *host, int njobs, hipStream_t s) {
   /* Pageable source: the runtime stages the bytes before returning, so `host`
      may live on the caller's stack; stream order protects g_jobs itself. */
   ODHIP_TRY(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_jobs), host, sizeof(DJob)*njobs, 0,
    hipMemcpyHostToDevice, s));
+  return ODHIP_SUCCESS;
+}
+
+int stage_jobs(const odhip_pvq_job *jobs, int njobs, int mode, DJob *host,
+ hipStream_t s) {
+  const int rc = fill_jobs(jobs, njobs, mode, host);
+  if (rc) return rc;
+  return upload_jobs(host, njobs, s);
+}
+
+/* Library scratch of the sorted band stage, grown on demand and kept for the
+   life of the process.  One band-stage call may be in flight per process (calls
+   are ordered on the caller's stream). */
+struct Scratch {
+  int16_t *x16;
+  size_t x16_cap;     /* elements */
+  unsigned short *keys;
+  unsigned *ids;
+  size_t band_cap;    /* (band, block) pairs */
+} g_scr = {nullptr, 0, nullptr, nullptr, 0};
+
+int scratch_reserve(size_t x16_elems, size_t band_elems, hipStream_t s) {
+  if (x16_elems > g_scr.x16_cap) {
+    ODHIP_TRY(hipStreamSynchronize(s));
+    if (g_scr.x16) ODHIP_TRY(hipFree(g_scr.x16));
+    g_scr.x16 = nullptr;
+    g_scr.x16_cap = 0;
+    ODHIP_TRY(hipMalloc((void **)&g_scr.x16, x16_elems*sizeof(int16_t)));
+    g_scr.x16_cap = x16_elems;
+  }
+  if (band_elems > g_scr.band_cap) {
+    ODHIP_TRY(hipStreamSynchronize(s));
+    if (g_scr.keys) ODHIP_TRY(hipFree(g_scr.keys));
+    if (g_scr.ids) ODHIP_TRY(hipFree(g_scr.ids));
+    g_scr.keys = nullptr;
+    g_scr.ids = nullptr;
+    g_scr.band_cap = 0;
+    ODHIP_TRY(hipMalloc((void **)&g_scr.keys, band_elems*sizeof(unsigned short)));
+    ODHIP_TRY(hipMalloc((void **)&g_scr.ids, band_elems*sizeof(unsigned)));
+    g_scr.band_cap = band_elems;
+  }
   return ODHIP_SUCCESS;
 }
 
@@ -510,8 +743,6 @@ int join_streams(hipStream_t s, hipStream_t side[2]) {
 void items_begin(Items &it, double lambda) {
   memset(&it, 0, sizeof(it));
   it.lambda = lambda;
-  const char *e = getenv("ODHIP_PVQ_FORCE_SCAN");
-  it.force_scan = e && e[0] == '1';
 }
 
 void items_add(Items &it, int job, int band, long wgs) {
@@ -520,6 +751,22 @@ void items_add(Items &it, int job, int band, long wgs) {
   it.band[it.nitems] = (unsigned char)band;
   it.wg_start[it.nitems + 1] = it.wg_start[it.nitems] + (int)wgs;
   it.nitems++;
+}
+
+template <int N>
+void launch_search(const DJob *host, int njobs, double lambda, hipStream_t s) {
+  Items it;
+  items_begin(it, lambda);
+  for (int j = 0; j < njobs; j++) {
+    for (int b = 0; b < host[j].nb_bands; b++) {
+      if (host[j].off[b + 1] - host[j].off[b] == N) {
+        items_add(it, j, b, (host[j].nblocks + kWave - 1)/kWave);
+      }
+    }
+  }
+  if (!it.nitems) return;
+  constexpr size_t lds = kRsqN*sizeof(double) + (size_t)N*kPitch*4;
+  k_search<N><<<it.wg_start[it.nitems], kWave, lds, s>>>(it);
 }
 
 }  // namespace
@@ -536,45 +783,67 @@ extern "C" int odhip_pvq_band_layout(int bs, int *nb_bands, int *offsets, int *l
 extern "C" int odhip_pvq_noref_bands_multi(const odhip_pvq_job *jobs, int njobs,
  double pvq_norm_lambda, odhip_stream stream) {
   hipStream_t s = (hipStream_t)stream;
+  const double lambda = pvq_norm_lambda;
   DJob host[kMaxJobs];
-  int rc = stage_jobs(jobs, njobs, 0, host, s);
+  int rc = fill_jobs(jobs, njobs, 0, host);
   if (rc) return rc;
+  size_t x16_elems = 0;
+  size_t band_elems = 0;
+  for (int j = 0; j < njobs; j++) {
+    x16_elems += (size_t)host[j].nblocks*host[j].len;
+    band_elems += (size_t)host[j].nblocks*host[j].nb_bands;
+    for (int b = 0; b < host[j].nb_bands; b++) {
+      const int n = host[j].off[b + 1] - host[j].off[b];
+      if (n != 8 && n != 15 && n != 32 && n != 128) return ODHIP_EINVAL;
+    }
+  }
+  rc = scratch_reserve(x16_elems, band_elems, s);
+  if (rc) return rc;
+  x16_elems = 0;
+  band_elems = 0;
+  for (int j = 0; j < njobs; j++) {
+    host[j].x16 = g_scr.x16 + x16_elems;
+    host[j].keys = g_scr.keys + band_elems;
+    host[j].ids = g_scr.ids + band_elems;
+    x16_elems += (size_t)host[j].nblocks*host[j].len;
+    band_elems += (size_t)host[j].nblocks*host[j].nb_bands;
+  }
+  rc = upload_jobs(host, njobs, s);
+  if (rc) return rc;
+  hipStream_t side[2] = {s, s};
+  if (fork_streams(s, side) != ODHIP_SUCCESS) return ODHIP_EFAULT;
   Items it;
-  /* short bands: 64 bands per workgroup */
-  items_begin(it, pvq_norm_lambda);
-  int nmax = 0;
+  /* prep: bands up to 32 coefficients one per lane, 128 one per 16-lane row */
+  items_begin(it, lambda);
   for (int j = 0; j < njobs; j++) {
     for (int b = 0; b < host[j].nb_bands; b++) {
       const int n = host[j].off[b + 1] - host[j].off[b];
-      if (n < 32) {
-        items_add(it, j, b, (host[j].nblocks + kWave - 1)/kWave);
-        nmax = n > nmax ? n : nmax;
-      }
+      if (n <= 32) items_add(it, j, b, (host[j].nblocks + kWave - 1)/kWave);
     }
   }
-  /* The three band kernels are independent: the two long-band kernels run on
-     side streams forked from / joined to the caller's stream, so their tails
-     and their different bottlenecks (LDS vs DPP/VALU) overlap. */
-  hipStream_t side[2] = {s, s};
+  if (it.nitems) k_prep_lane<<<it.wg_start[it.nitems], kWave, 0, s>>>(it);
+  items_begin(it, lambda);
+  for (int j = 0; j < njobs; j++) {
+    for (int b = 0; b < host[j].nb_bands; b++) {
+      if (host[j].off[b + 1] - host[j].off[b] == 128) items_add(it, j, b, (host[j].nblocks + 3)/4);
+    }
+  }
+  if (it.nitems) k_prep_wide<<<it.wg_start[it.nitems], kWave, 0, side[0]>>>(it);
+  if (join_streams(s, side) != ODHIP_SUCCESS) return ODHIP_EFAULT;
+  /* counting sort of every item's blocks by pulse class, window by window */
+  items_begin(it, lambda);
+  for (int j = 0; j < njobs; j++) {
+    for (int b = 0; b < host[j].nb_bands; b++) {
+      items_add(it, j, b, (host[j].nblocks + kSortChunk - 1)/kSortChunk);
+    }
+  }
+  k_sort_chunk<<<it.wg_start[it.nitems], 256, 0, s>>>(it);
+  /* search: the band sizes are independent launches on forked streams */
   if (fork_streams(s, side) != ODHIP_SUCCESS) return ODHIP_EFAULT;
-  if (it.nitems) {
-    k_bands_narrow<<<it.wg_start[it.nitems], kWave, (size_t)nmax*kWave*4, s>>>(it);
-  }
-  /* long bands: 4 bands per workgroup */
-  for (int width = 32; width <= 128; width *= 4) {
-    hipStream_t ws = side[width == 32 ? 0 : 1];
-    items_begin(it, pvq_norm_lambda);
-    for (int j = 0; j < njobs; j++) {
-      for (int b = 0; b < host[j].nb_bands; b++) {
-        if (host[j].off[b + 1] - host[j].off[b] == width) {
-          items_add(it, j, b, (host[j].nblocks + 3)/4);
-        }
-      }
-    }
-    if (!it.nitems) continue;
-    if (width == 32) k_bands_wide<2><<<it.wg_start[it.nitems], kWave, 0, ws>>>(it);
-    else k_bands_wide<8><<<it.wg_start[it.nitems], kWave, 0, ws>>>(it);
-  }
+  launch_search<128>(host, njobs, lambda, s);
+  launch_search<32>(host, njobs, lambda, side[0]);
+  launch_search<15>(host, njobs, lambda, side[1]);
+  launch_search<8>(host, njobs, lambda, side[1]);
   if (join_streams(s, side) != ODHIP_SUCCESS) return ODHIP_EFAULT;
   return odhip_check_launch();
 }

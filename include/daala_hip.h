@@ -181,20 +181,34 @@ int odhip_pvq_search_batch(const int16_t *d_x, int n, const int32_t *d_k,
 
    Block index: blk = (plane*(h/N) + by)*(w/N) + bx; B = number of blocks. */
 #define ODHIP_MAX_BANDS 12
+#define ODHIP_PVQ_MAX_K 32767
+/* One record per (block, band), 64 bytes, 64-byte aligned: both halves are
+   whole 32-byte HBM sectors and are written by different kernels (the first by
+   the preparation pass, the second by the search). */
 typedef struct {
-  int32_t *cg;        /* [B][nb]    companded gain of x, Q8 (od_pvq_compute_gain) */
-  double *dist0;      /* [B][nb]    distortion of the null (gain 0) candidate   */
-  int32_t *gain;      /* [B][nb][2] candidate gain index i; 0 = slot unused     */
-  int32_t *k;         /* [B][nb][2] pulses (od_pvq_compute_k)                   */
-  int32_t *flags;     /* [B][nb][2] 1 = searched, 0 = pruned / unused           */
-  int32_t *yy;        /* [B][nb][2] sum of squared pulses of the candidate      */
-  double *cos_dist;   /* [B][nb][2] return value of pvq_search_rdo_double       */
-  double *dist;       /* [B][nb][2] distortion of the candidate                 */
-  od_coeff *y;        /* [2][B][len] pulse vectors in coding order (index 0 = DC
-                         slot, unused), len = min(N*N, 512)                     */
-  int32_t *choice;    /* [B][nb][4] written by odhip_pvq_select_synth_noref*:
-                         {chosen slot, chosen gain index qg (0 = null), synthesis
-                         scale, qshift}; 16-byte aligned                        */
+  int32_t cg;          /* companded gain of x, Q8 (od_pvq_compute_gain)            */
+  int32_t gain[2];     /* candidate gain index i; 0 = slot unused                  */
+  int16_t k[2];        /* pulses (od_pvq_compute_k), saturated at ODHIP_PVQ_MAX_K  */
+  uint8_t flags[2];    /* 1 = searched, 0 = pruned / unused, 2 = K above
+                          ODHIP_PVQ_MAX_K (not representable: never chosen)        */
+  uint8_t reserved0[6];
+  double dist0;        /* distortion of the null (gain 0) candidate                */
+  int32_t yy[2];       /* sum of squared pulses of the candidate                   */
+  double dist[2];      /* distortion of the candidate                              */
+  uint8_t reserved1[8];
+} odhip_pvq_band;
+
+typedef struct {
+  odhip_pvq_band *band; /* [B][nb]                                                  */
+  int16_t *y;           /* [2][B][len] signed pulse vectors in coding order (index
+                           0 = DC slot, unused, may be overwritten with 0),
+                           len = min(N*N, 512); 16-byte aligned                    */
+  int32_t *choice;      /* [B][nb][4] written by odhip_pvq_select_synth_noref* /
+                           odhip_pvq_choose_multi: {chosen slot, chosen gain index
+                           qg (0 = null), synthesis scale, qshift}; 16-byte aligned */
+  double *cos_dist;     /* optional [B][nb][2]: return value of
+                           pvq_search_rdo_double per candidate (parity checks);
+                           NULL = not stored                                       */
 } odhip_pvq_cands;
 
 /* One (plane set, block size) unit of work for the multi-job entry points.

@@ -75,11 +75,11 @@ def test_band_stage_matches_oracle(hip, pli, dec):
         bb = qt.beta_band(pli, bs)
         nb, offs, ln = hip.pvq_band_layout(bs)
         tc = _cuda(coef[None])
-        cands = hip.pvq_noref_bands(tc, bs, _cuda(qm), qb, bb, lam)
+        cands = hip.pvq_noref_bands(tc, bs, _cuda(qm), qb, bb, lam, cos_dist=True)
         import torch
         torch.cuda.synchronize()
         dq, qg = hip.pvq_select_synth_noref(tc, bs, _cuda(qmi), qb, bb, lam, cands)
-        c = {k_: v.cpu().numpy() for k_, v in cands.items()}
+        c = hip.unpack_cands(cands)
         dq = dq.cpu().numpy()[0]
         qg = qg.cpu().numpy()
         want_dq = np.zeros_like(coef)
@@ -164,7 +164,7 @@ def test_inverse_from_pvq_equals_synth_then_inverse(hip, dec):
             job = hip.PvqJob(levels[bs], bs, _cuda(qm), _cuda(qmi), qt.q_band(pli, bs),
                              qt.beta_band(pli, bs), dq=torch.empty_like(levels[bs]))
             if use_rate:
-                job.rate = torch.from_numpy(rng.uniform(0, 60, size=tuple(job.cands["dist"].shape))).cuda()
+                job.rate = torch.from_numpy(rng.uniform(0, 60, size=tuple(job.cands["band"].shape[:2]) + (2,))).cuda()
             hip.pvq_noref_bands_multi([job], hip.OD_PVQ_LAMBDA)
             hip.pvq_select_synth_noref_multi([job], hip.OD_PVQ_LAMBDA)
             want = hip.inverse_level(job.dq, dec, bs, W, H)

@@ -1,9 +1,9 @@
-timeout 300 python -m pytest tests/test_gpu_pvq_bands.py -m gpu -x -q 2>&1 | tail -4
-ODHIP_PVQ_FORCE_SCAN=1 timeout 300 python -m pytest tests/test_gpu_pvq_bands.py -m gpu -x -q 2>&1 | tail -3
-timeout 600 python bench.py --steps 5 --warmup 2 --no-cpu-baseline 2>&1 | tail -1 > gpurun_out/bench_last.json
+timeout 600 python -m pytest tests -m gpu -x -q 2>&1 | tail -5
+bash tools/prof_quick.sh 2>&1 | head -16
+timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline 2>&1 | tail -1 > gpurun_out/bench_last.json
 python - <<'PY'
 import json
 d=json.load(open('gpurun_out/bench_last.json'))
 print(d["value"], d["ms_per_step"])
-for k,v in d["kernels"].items(): print(k, v["avg_ms_per_launch"], v["launches"], v["share_of_step"], v.get("achieved_GBs"))
+for k,v in d["kernels"].items(): print("  ", k, v["avg_ms_per_launch"], v["launches"], v["share_of_step"], v.get("achieved_GBs"))
 PY
