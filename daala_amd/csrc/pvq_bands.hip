@@ -16,9 +16,8 @@
                                    (first half of the band record), and a SORT
                                    KEY = binned (pulses of candidate 0, extra
                                    pulses of candidate 1)
-     k_sort_chunk                  counting sort of the block indices of each
-                                   (job, band) item by key, within windows of
-                                   4096 blocks, heavy first
+     k_hist / k_prefix / k_scatter counting sort of the block indices of each
+                                   (job, band) item by key, heavy first
      k_search<N>                   one band per lane over the sorted order: the
                                    64 bands of a wavefront need (almost) the same
                                    number of pulses (pvq_lane.cuh)
@@ -312,16 +311,68 @@ __global__ __launch_bounds__(kWave) void k_prep_wide(Items it) {
   od_band_candidates(jb, band, n, bp.blk, cg, jb.beta[band]);
 }
 
-/* ---- counting sort of block indices by key, within windows of kSortChunk blocks -
-   A window of consecutive blocks is sorted on its own (LDS histogram, prefix,
-   scatter), heavy bands first.  The 64 lanes of a search wavefront then take
-   64 consecutive sorted positions of ONE window: their pulse counts are close
-   (1/64 of the window's sorted range) and their records, x16 and pulse vectors
-   lie within the window's few hundred KiB - a global sort made every lane's
-   32-byte access a random DRAM transaction (66% of wave cycles waiting). */
-__global__ __launch_bounds__(256) void k_sort_chunk(Items it) {
+/* ---- counting sort of each item's block indices by key (heavy first) ------------
+   The order inside a key bin stays close to block order (workgroups reserve
+   contiguous ranges per bin), so the 64 bands of a search wavefront are near
+   one another in memory as well as in pulse count.  Heavy-first matters: one
+   wavefront of 128-coefficient bands with K = 90 runs for ~250 us, as long as
+   the rest of its launch. */
+__device__ unsigned g_hist[kMaxItems*kKeyBins];      /* zero between calls */
+__device__ unsigned g_binstart[kMaxItems*kKeyBins];
+__device__ unsigned g_cursor[kMaxItems*kKeyBins];
+
+__device__ __forceinline__ int item_id(const Items &it, int item) {
+  return it.job[item]*ODHIP_MAX_BANDS + it.band[item];
+}
+
+__global__ __launch_bounds__(256) void k_hist(Items it) {
   __shared__ unsigned h[kKeyBins];
+  const int item = find_item(it, blockIdx.x);
+  const DJob &jb = g_jobs[it.job[item]];
+  const unsigned short *keys = jb.keys + (long)it.band[item]*jb.nblocks;
+  for (int b = threadIdx.x; b < kKeyBins; b += 256) h[b] = 0;
+  __syncthreads();
+  const long start = (long)(blockIdx.x - it.wg_start[item])*kSortChunk;
+  const long end = start + kSortChunk < jb.nblocks ? start + kSortChunk : jb.nblocks;
+  for (long i = start + threadIdx.x; i < end; i += 256) atomicAdd(&h[keys[i]], 1u);
+  __syncthreads();
+  unsigned *gh = g_hist + item_id(it, item)*kKeyBins;
+  for (int b = threadIdx.x; b < kKeyBins; b += 256) {
+    if (h[b]) atomicAdd(&gh[b], h[b]);
+  }
+}
+
+/* One workgroup per item: exclusive prefix sum of the histogram; clears the
+   histogram and the scatter cursors for the next use. */
+__global__ __launch_bounds__(256) void k_prefix(Items it) {
   __shared__ unsigned part[256];
+  const int id = item_id(it, blockIdx.x);
+  unsigned *gh = g_hist + id*kKeyBins;
+  unsigned c[kKeyBins/256];
+  unsigned sum = 0;
+  for (int i = 0; i < kKeyBins/256; i++) {
+    c[i] = gh[threadIdx.x*(kKeyBins/256) + i];
+    gh[threadIdx.x*(kKeyBins/256) + i] = 0;
+    sum += c[i];
+  }
+  part[threadIdx.x] = sum;
+  __syncthreads();
+  for (int d = 1; d < 256; d <<= 1) {
+    const unsigned t = threadIdx.x >= d ? part[threadIdx.x - d] : 0;
+    __syncthreads();
+    part[threadIdx.x] += t;
+    __syncthreads();
+  }
+  unsigned run = part[threadIdx.x] - sum;
+  for (int i = 0; i < kKeyBins/256; i++) {
+    g_binstart[id*kKeyBins + threadIdx.x*(kKeyBins/256) + i] = run;
+    g_cursor[id*kKeyBins + threadIdx.x*(kKeyBins/256) + i] = 0;
+    run += c[i];
+  }
+}
+
+__global__ __launch_bounds__(256) void k_scatter(Items it) {
+  __shared__ unsigned h[kKeyBins];
   const int item = find_item(it, blockIdx.x);
   const DJob &jb = g_jobs[it.job[item]];
   const long ibase = (long)it.band[item]*jb.nblocks;
@@ -341,73 +392,113 @@ __global__ __launch_bounds__(256) void k_sort_chunk(Items it) {
     }
   }
   __syncthreads();
-  /* exclusive prefix sum of the 1024 bins: 4 bins per thread + scan of partials */
-  unsigned c[kKeyBins/256];
-  unsigned sum = 0;
-#pragma unroll
-  for (int i = 0; i < kKeyBins/256; i++) {
-    c[i] = h[threadIdx.x*(kKeyBins/256) + i];
-    sum += c[i];
-  }
-  part[threadIdx.x] = sum;
-  __syncthreads();
-  for (int d = 1; d < 256; d <<= 1) {
-    const unsigned t = threadIdx.x >= d ? part[threadIdx.x - d] : 0;
-    __syncthreads();
-    part[threadIdx.x] += t;
-    __syncthreads();
-  }
-  unsigned run = part[threadIdx.x] - sum;
-#pragma unroll
-  for (int i = 0; i < kKeyBins/256; i++) {
-    h[threadIdx.x*(kKeyBins/256) + i] = run;
-    run += c[i];
+  const int id = item_id(it, item);
+  for (int b = threadIdx.x; b < kKeyBins; b += 256) {
+    if (h[b]) h[b] = g_binstart[id*kKeyBins + b] + atomicAdd(&g_cursor[id*kKeyBins + b], h[b]);
   }
   __syncthreads();
 #pragma unroll
   for (int t = 0; t < kSortChunk/256; t++) {
-    if (key[t] >= 0) {
-      jb.ids[ibase + start + h[key[t]] + rank[t]] = (unsigned)(start + t*256 + threadIdx.x);
-    }
+    if (key[t] >= 0) jb.ids[ibase + h[key[t]] + rank[t]] = (unsigned)(start + t*256 + threadIdx.x);
   }
 }
 
 /* ---- search: one band per lane over the sorted order --------------------------
    Every lane reads its band's x16 with 16-byte loads, unpacks |x| << 16 into
    its LDS column, searches both candidates, and writes the signed pulses
-   (int16, signs from re-reading x16; src/pvq_encoder.c:220-222) with 16-byte
-   stores and the second half of the band record as one 32-byte sector.  No
-   cross-lane traffic. */
+   (int16, src/pvq_encoder.c:220-222) with 16-byte stores and the second half
+   of the band record as one 32-byte sector.  No cross-lane traffic.
+
+   A wavefront can handle NB groups of 64 sorted positions, strided by the
+   item's wavefront count (group g = b*nwaves + w: one group from each of NB
+   weight classes), with the dependent loads of a group (sorted index -> record
+   head and x16) issued one / two groups ahead.  Measured on MI355X, NB = 1 is
+   the fastest for every band size (NB = 4 / 2: +30% on the short bands - the
+   extra live registers cost more occupancy than the prefetch buys), so that
+   is what the launches use; the exposed latency that motivated it turned out
+   to be eight serialised loads of the 1/sqrt table (fixed above). */
 template <int N>
+struct BandFetch {
+  static constexpr int PAD = N == 15 ? 1 : 0;      /* leading DC slot */
+  static constexpr int NV = (N + PAD)/8;           /* 16-byte groups of int16 */
+  int4 head[2];
+  int4 x[NV];
+};
+
+template <int N, int NB>
 __global__ __launch_bounds__(kWave) void k_search(Items it) {
-  constexpr int PAD = N == 15 ? 1 : 0;      /* leading DC slot */
-  constexpr int NV = (N + PAD)/8;           /* 16-byte groups of int16 */
+  constexpr int PAD = BandFetch<N>::PAD;
+  constexpr int NV = BandFetch<N>::NV;
   static_assert((N + PAD)%8 == 0, "band must be a whole number of 16-byte groups");
   extern __shared__ __attribute__((aligned(16))) double lds_d[];
   double *rsq = lds_d;                                   /* [kRsqN]  */
   uint32_t *pk = (uint32_t *)(rsq + kRsqN);              /* [N][64]  */
   const int lane = threadIdx.x;
-  for (int i = lane; i < kRsqN; i += kWave) rsq[i] = gRsqTable[i];
+  {
+    /* all eight loads in flight before the first LDS store (the compiler keeps
+       a load -> wait -> store order otherwise: eight exposed latencies) */
+    double r[kRsqN/kWave];
+#pragma unroll
+    for (int i = 0; i < kRsqN/kWave; i++) r[i] = gRsqTable[i*kWave + lane];
+#pragma unroll
+    for (int i = 0; i < kRsqN/kWave; i++) rsq[i*kWave + lane] = r[i];
+  }
   const int item = find_item(it, blockIdx.x);
   const DJob &jb = g_jobs[it.job[item]];
   const int band = it.band[item];
   const int off = jb.off[band] - PAD;
   const long nblocks = jb.nblocks;
   const int len = jb.len;
-  const long spos = (long)(blockIdx.x - it.wg_start[item])*kWave + lane;
-  const bool live = spos < nblocks;
-  const long blk = live ? (long)jb.ids[(long)band*nblocks + spos] : 0;
-  odhip_pvq_band *const rec = jb.rec + blk*jb.nb_bands + band;
-  RecHead hd = {0, {0, 0}, {0, 0}, {0, 0}};
-  if (live) hd = rec_head_load(rec);
-  const int4 *xv = reinterpret_cast<const int4 *>(jb.x16 + blk*len + off);
+  const int nb_bands = jb.nb_bands;
+  const unsigned *const ids = jb.ids + (long)band*nblocks;
+  odhip_pvq_band *const recs = jb.rec + band;
+  const int16_t *const x16 = jb.x16 + off;
+  int16_t *const yout = jb.y + off;
+  double *const cosd = jb.cos_dist;
+  const long stride = (long)(it.wg_start[item + 1] - it.wg_start[item])*kWave;
+  const long spos0 = (long)(blockIdx.x - it.wg_start[item])*kWave + lane;
+  /* prologue: indices of groups 0 and 1, data of group 0 */
+  unsigned blk_next = spos0 < nblocks ? ids[spos0] : 0;
+  unsigned blk_next2 = NB > 1 && spos0 + stride < nblocks ? ids[spos0 + stride] : 0;
+  BandFetch<N> nx;
   {
-    int4 q[NV];
+    const int4 *hp = reinterpret_cast<const int4 *>(recs + (long)blk_next*nb_bands);
+    const int4 *xp = reinterpret_cast<const int4 *>(x16 + (long)blk_next*len);
+    nx.head[0] = hp[0];
+    nx.head[1] = hp[1];
 #pragma unroll
-    for (int v = 0; v < NV; v++) q[v] = live ? xv[v] : make_int4(0, 0, 0, 0);
+    for (int v = 0; v < NV; v++) nx.x[v] = xp[v];
+  }
+  __syncthreads();   /* the 1/sqrt table */
+#pragma unroll 1
+  for (int b = 0; b < NB; b++) {
+    const long spos = spos0 + b*stride;
+    const bool live = spos < nblocks;
+    const long blk = blk_next;
+    const BandFetch<N> cur = nx;
+    if (b + 1 < NB) {
+      /* data of group b+1 (its index arrived during the previous iteration),
+         index of group b+2 */
+      blk_next = blk_next2;
+      const int4 *hp = reinterpret_cast<const int4 *>(recs + (long)blk_next*nb_bands);
+      const int4 *xp = reinterpret_cast<const int4 *>(x16 + (long)blk_next*len);
+      nx.head[0] = hp[0];
+      nx.head[1] = hp[1];
+#pragma unroll
+      for (int v = 0; v < NV; v++) nx.x[v] = xp[v];
+      blk_next2 = b + 2 < NB && spos + 2*stride < nblocks ? ids[spos + 2*stride] : 0;
+    }
+    RecHead hd;
+    hd.cg = cur.head[0].x;
+    hd.gain[0] = cur.head[0].y;
+    hd.gain[1] = cur.head[0].z;
+    hd.k[0] = (int16_t)(cur.head[0].w & 0xffff);
+    hd.k[1] = cur.head[0].w >> 16;
+    hd.flags[0] = live ? cur.head[1].x & 0xff : 0;
+    hd.flags[1] = live ? cur.head[1].x >> 8 & 0xff : 0;
 #pragma unroll
     for (int v = 0; v < NV; v++) {
-      const int d[4] = {q[v].x, q[v].y, q[v].z, q[v].w};
+      const int d[4] = {cur.x[v].x, cur.x[v].y, cur.x[v].z, cur.x[v].w};
 #pragma unroll
       for (int t = 0; t < 4; t++) {
         const int j0 = v*8 + 2*t - PAD;
@@ -415,55 +506,59 @@ __global__ __launch_bounds__(kWave) void k_search(Items it) {
         pk[(j0 + 1)*kWave + lane] = (uint32_t)abs(d[t] >> 16) << 16;
       }
     }
-  }
-  __syncthreads();   /* the 1/sqrt table */
-  LaneSearch st;
-  od_lane_prepare<N>(st, pk, lane);
-  const int32_t cg = hd.cg;
-  const double s2 = (1./256)*(1./256);
-  int prev_k = 0;
-  int yy[2];
-  double dist[2];
-  for (int c = 0; c < 2; c++) {
-    const bool on = hd.flags[c] == 1;
-    const int k = hd.k[c];
-    const int32_t qcg = odq_shl32(hd.gain[c], ODQ_CGAIN_SHIFT);
-    const double g2 = (qcg*(double)cg)*s2;
-    const bool fresh = !(prev_k > 0 && prev_k <= k);
-    const double cos_dist = od_lane_search<N>(st, pk, rsq, lane, on, fresh, k, g2, it.lambda);
-    /* src/pvq_encoder.c:586,:593-595; a slot that is not in use has distortion 0 */
-    yy[c] = 0;
-    dist[c] = hd.gain[c] ? ((1.4*(qcg - cg))*(qcg - cg))*s2 : 0.;
-    if (on) {
-      prev_k = k;
-      yy[c] = (int)st.yy;
-      dist[c] = ((1.4*(qcg - cg))*(qcg - cg) + (qcg*(double)cg)*(2 - 2*cos_dist))*s2;
-    }
-    if (live) {
-      if (jb.cos_dist) jb.cos_dist[2*(blk*jb.nb_bands + band) + c] = on ? cos_dist : 0.;
-      int4 *yo = reinterpret_cast<int4 *>(jb.y + ((long)c*nblocks + blk)*len + off);
-#pragma unroll 2
-      for (int v = 0; v < NV; v++) {
-        const int4 q = xv[v];
-        const int d[4] = {q.x, q.y, q.z, q.w};
-        int o[4];
+    LaneSearch st;
+    od_lane_prepare<N>(st, pk, lane);
+    const int32_t cg = hd.cg;
+    const double s2 = (1./256)*(1./256);
+    int prev_k = 0;
+    int yy[2];
+    double dist[2];
+#pragma unroll 1
+    for (int c = 0; c < 2; c++) {
+      const bool on = hd.flags[c] == 1;
+      const int k = hd.k[c];
+      const int32_t qcg = odq_shl32(hd.gain[c], ODQ_CGAIN_SHIFT);
+      const double g2 = (qcg*(double)cg)*s2;
+      const bool fresh = !(prev_k > 0 && prev_k <= k);
+      const double cos_dist = od_lane_search<N>(st, pk, rsq, lane, on, fresh, k, g2, it.lambda);
+      /* src/pvq_encoder.c:586,:593-595; a slot that is not in use has distortion 0 */
+      yy[c] = 0;
+      dist[c] = hd.gain[c] ? ((1.4*(qcg - cg))*(qcg - cg))*s2 : 0.;
+      if (on) {
+        prev_k = k;
+        yy[c] = (int)st.yy;
+        dist[c] = ((1.4*(qcg - cg))*(qcg - cg) + (qcg*(double)cg)*(2 - 2*cos_dist))*s2;
+      }
+      if (live) {
+        if (cosd) cosd[2*(blk*nb_bands + band) + c] = on ? cos_dist : 0.;
+        int4 *yo = reinterpret_cast<int4 *>(yout + ((long)c*nblocks + blk)*len);
+        const int4 *xp = reinterpret_cast<const int4 *>(x16 + blk*len);
 #pragma unroll
-        for (int t = 0; t < 4; t++) {
-          const int j0 = v*8 + 2*t - PAD;
-          const int y0 = j0 >= 0 && on ? (int)(pk[j0*kWave + lane] >> 1 & 0x7fffu) : 0;
-          const int y1 = on ? (int)(pk[(j0 + 1)*kWave + lane] >> 1 & 0x7fffu) : 0;
-          const int s0 = (int)(short)d[t] >> 31;
-          const int s1 = d[t] >> 31;
-          o[t] = (((y0 ^ s0) - s0) & 0xffff) | ((y1 ^ s1) - s1) << 16;
+        for (int v = 0; v < NV; v++) {
+          /* signs: from the registers for the short bands, re-read (L2) for the
+             128-coefficient band, whose 64 registers are better spent on the
+             pipelined search loops */
+          const int4 q = N > 32 ? xp[v] : cur.x[v];
+          const int d[4] = {q.x, q.y, q.z, q.w};
+          int o[4];
+#pragma unroll
+          for (int t = 0; t < 4; t++) {
+            const int j0 = v*8 + 2*t - PAD;
+            const int y0 = j0 >= 0 && on ? (int)(pk[j0*kWave + lane] >> 1 & 0x7fffu) : 0;
+            const int y1 = on ? (int)(pk[(j0 + 1)*kWave + lane] >> 1 & 0x7fffu) : 0;
+            const int s0 = (int)(short)d[t] >> 31;
+            const int s1 = d[t] >> 31;
+            o[t] = (((y0 ^ s0) - s0) & 0xffff) | ((y1 ^ s1) - s1) << 16;
+          }
+          yo[v] = make_int4(o[0], o[1], o[2], o[3]);
         }
-        yo[v] = make_int4(o[0], o[1], o[2], o[3]);
       }
     }
-  }
-  if (live) {
-    int4 *out = reinterpret_cast<int4 *>(rec) + 2;
-    out[0] = make_int4(yy[0], yy[1], __double2loint(dist[0]), __double2hiint(dist[0]));
-    out[1] = make_int4(__double2loint(dist[1]), __double2hiint(dist[1]), 0, 0);
+    if (live) {
+      int4 *out = reinterpret_cast<int4 *>(recs + blk*nb_bands) + 2;
+      out[0] = make_int4(yy[0], yy[1], __double2loint(dist[0]), __double2hiint(dist[0]));
+      out[1] = make_int4(__double2loint(dist[1]), __double2hiint(dist[1]), 0, 0);
+    }
   }
 }
 
@@ -503,7 +598,7 @@ __global__ __launch_bounds__(256) void k_choose(Items it) {
   int qshift = ODQ_QM_INV_SHIFT;
   if (qg != 0) {
     const int32_t g = odq_gain_expand(odq_shl32(qg, ODQ_CGAIN_SHIFT), jb.q[band], jb.beta[band]);
-    const int yy = yys[sel];
+    const int yy = sel ? yys[1] : yys[0];
     int gshift = odq_ilog(g) - 14;
     gshift = gshift > 0 ? gshift : 0;
     if (yy != 0) {
@@ -753,20 +848,20 @@ void items_add(Items &it, int job, int band, long wgs) {
   it.nitems++;
 }
 
-template <int N>
+template <int N, int NB>
 void launch_search(const DJob *host, int njobs, double lambda, hipStream_t s) {
   Items it;
   items_begin(it, lambda);
   for (int j = 0; j < njobs; j++) {
     for (int b = 0; b < host[j].nb_bands; b++) {
       if (host[j].off[b + 1] - host[j].off[b] == N) {
-        items_add(it, j, b, (host[j].nblocks + kWave - 1)/kWave);
+        items_add(it, j, b, (host[j].nblocks + kWave*NB - 1)/(kWave*NB));
       }
     }
   }
   if (!it.nitems) return;
   constexpr size_t lds = kRsqN*sizeof(double) + (size_t)N*kPitch*4;
-  k_search<N><<<it.wg_start[it.nitems], kWave, lds, s>>>(it);
+  k_search<N, NB><<<it.wg_start[it.nitems], kWave, lds, s>>>(it);
 }
 
 }  // namespace
@@ -830,20 +925,25 @@ extern "C" int odhip_pvq_noref_bands_multi(const odhip_pvq_job *jobs, int njobs,
   }
   if (it.nitems) k_prep_wide<<<it.wg_start[it.nitems], kWave, 0, side[0]>>>(it);
   if (join_streams(s, side) != ODHIP_SUCCESS) return ODHIP_EFAULT;
-  /* counting sort of every item's blocks by pulse class, window by window */
+  /* counting sort of every item's blocks by pulse class */
+  Items all;
+  items_begin(all, lambda);
   items_begin(it, lambda);
   for (int j = 0; j < njobs; j++) {
     for (int b = 0; b < host[j].nb_bands; b++) {
       items_add(it, j, b, (host[j].nblocks + kSortChunk - 1)/kSortChunk);
+      items_add(all, j, b, 1);
     }
   }
-  k_sort_chunk<<<it.wg_start[it.nitems], 256, 0, s>>>(it);
+  k_hist<<<it.wg_start[it.nitems], 256, 0, s>>>(it);
+  k_prefix<<<all.nitems, 256, 0, s>>>(all);
+  k_scatter<<<it.wg_start[it.nitems], 256, 0, s>>>(it);
   /* search: the band sizes are independent launches on forked streams */
   if (fork_streams(s, side) != ODHIP_SUCCESS) return ODHIP_EFAULT;
-  launch_search<128>(host, njobs, lambda, s);
-  launch_search<32>(host, njobs, lambda, side[0]);
-  launch_search<15>(host, njobs, lambda, side[1]);
-  launch_search<8>(host, njobs, lambda, side[1]);
+  launch_search<128, 1>(host, njobs, lambda, s);
+  launch_search<32, 1>(host, njobs, lambda, side[0]);
+  launch_search<15, 1>(host, njobs, lambda, side[1]);
+  launch_search<8, 1>(host, njobs, lambda, side[1]);
   if (join_streams(s, side) != ODHIP_SUCCESS) return ODHIP_EFAULT;
   return odhip_check_launch();
 }

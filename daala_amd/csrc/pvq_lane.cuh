@@ -124,6 +124,25 @@ __device__ __forceinline__ void od_lane_load_group(uint32_t (&w)[kGrp], const ui
 template <int N, bool ACCEL>
 __device__ __forceinline__ int od_lane_rdo_scan(const uint32_t *pk, const double *rsq, int lane,
  unsigned xy, unsigned base, double norm2, double lambda, double delta_rate, double accel_rate) {
+  if (N <= 16) {
+    /* short bands: fully unrolled, every load is requested up front anyway */
+    double best = 0;
+    int pos = 0;
+#pragma unroll
+    for (int j = 0; j < N; j++) {
+      const uint32_t w = pk[j*kPitch + lane];
+      const double tt = (double)(xy + (w >> 16));
+      const double r = rsq[base + (w & 0xffffu)];
+      const double val = (tt*norm2)*r - (lambda*j)*(ACCEL ? delta_rate + j*accel_rate : delta_rate);
+      if (j == 0) best = val;
+      else {
+        const unsigned long long m = od_cmp_gt(val, best);
+        best = od_sel(m, val, best);
+        pos = od_sel(m, j, pos);
+      }
+    }
+    return pos;
+  }
   constexpr int NG = (N + kGrp - 1)/kGrp;
   uint32_t w0[kGrp];
   uint32_t w1[kGrp];
@@ -175,6 +194,29 @@ __device__ __forceinline__ int od_lane_rdo_scan(const uint32_t *pk, const double
 template <int N>
 __device__ __forceinline__ int od_lane_greedy_scan(const uint32_t *pk, int lane, unsigned xy,
  unsigned yyp1) {
+  if (N <= 16) {
+    double ba = 0;
+    double bb = 1;
+    int pos = 0;
+#pragma unroll
+    for (int j = 0; j < N; j++) {
+      const uint32_t w = pk[j*kPitch + lane];
+      const double tt = (double)(xy + (w >> 16));
+      const double a = tt*tt;
+      const double b = (double)(yyp1 + (w & 0xffffu));
+      if (j == 0) {
+        ba = a;
+        bb = b;
+      }
+      else {
+        const unsigned long long m = od_cmp_gt(a*bb, ba*b);
+        ba = od_sel(m, a, ba);
+        bb = od_sel(m, b, bb);
+        pos = od_sel(m, j, pos);
+      }
+    }
+    return pos;
+  }
   constexpr int NG = (N + kGrp - 1)/kGrp;
   uint32_t w0[kGrp];
   uint32_t w1[kGrp];
