@@ -595,10 +595,10 @@ __global__ __launch_bounds__(Geo<TILE>::kNT) void k_inverse_sb(InverseArgs a) {
        scattered to raster inside LDS (od_coding_order_to_raster,
        src/partition.c:176-194).  The pulse vectors are read as contiguous
        len-word rows; the dequantised plane never exists in HBM. */
-    __shared__ unsigned short s_scan[OD_SCAN_LEN];
+    __shared__ __attribute__((aligned(16))) unsigned short s_scan[OD_SCAN_LEN];
     __shared__ unsigned char s_band[OD_SCAN_LEN];
     __shared__ int4 s_choice[256];
-    __shared__ short s_qmi[OD_SCAN_LEN];
+    __shared__ __attribute__((aligned(16))) short s_qmi[OD_SCAN_LEN];
     const int sh = a.leaf_bs + 2;
     const int nbw = TILE >> sh;                 /* blocks per tile row */
     const int nbsb = nbw*nbw;
@@ -619,32 +619,60 @@ __global__ __launch_bounds__(Geo<TILE>::kNT) void k_inverse_sb(InverseArgs a) {
       for (int i = tid; i < TILE*P/4; i += NT) reinterpret_cast<int4 *>(t)[i] = make_int4(0, 0, 0, 0);
     }
     __syncthreads();
+    /* One CHUNK of 16 consecutive coding indices of one block per thread
+       (len/16 chunks per block, at most one chunk per thread): two 16-byte
+       loads of pulses, two of inverse-QM entries and two of scan positions per
+       chunk, one exposed memory latency per workgroup.  A chunk touches at
+       most two bands (coding indices 16..31 hold two bands of 8): one choice
+       per half. */
     const int lsh = 31 - __clz(a.len);          /* len is a power of two */
+    const int csh = lsh - 4;                    /* chunks per block = len/16 */
     const int lnb = 31 - __clz(nbw);            /* so is the block count per tile row */
     const long blk0 = ((long)blockIdx.z*bh + (y0 >> sh))*bw + (x0 >> sh);
-#pragma unroll 4
-    for (int i = tid; i < nbsb << lsh; i += NT) {
-      const int b = i >> lsh;
-      const int j = i & (a.len - 1);
+    for (int c = tid; c < nbsb << csh; c += NT) {
+      const int b = c >> csh;
+      const int j0 = (c & ((1 << csh) - 1)) << 4;
       const int lby = b >> lnb;
       const int lbx = b & (nbw - 1);
       const unsigned blk = (unsigned)blk0 + lby*bw + lbx;   /* < 2^31/len, checked by the host */
-      int v = 0;
-      if (j == 0) {
-        v = a.coef[plane_off + (long)(y0 + (lby << sh))*a.w + x0 + (lbx << sh)];
-      }
-      else {
-        const int4 ch = s_choice[b*a.nb_bands + s_band[j]];
-        if (ch.y != 0) {
-          const int yv = a.y[(((unsigned)ch.x*(unsigned)a.nblocks + blk) << lsh) + j];
-          /* OD_MULT16_32_Q16: (int16)y * (int32)scale >> 16 == mulhi(y << 16, scale) */
-          const int xq = __mulhi(yv << 16, ch.z);
-          const int r = xq*s_qmi[j];
-          v = (r + ((1 << ch.w) >> 1)) >> ch.w;
+      const int4 chs[2] = {s_choice[b*a.nb_bands + s_band[j0 ? j0 : 1]],
+       s_choice[b*a.nb_bands + s_band[j0 + 8]]};
+      int4 yq[2];
+#pragma unroll
+      for (int hf = 0; hf < 2; hf++) {
+        yq[hf] = make_int4(0, 0, 0, 0);
+        if (chs[hf].y != 0) {
+          yq[hf] = *reinterpret_cast<const int4 *>(a.y
+           + (((unsigned)chs[hf].x*(unsigned)a.nblocks + blk) << lsh) + j0 + 8*hf);
         }
       }
-      const int xy = s_scan[j];
-      t[((lby << sh) + (xy >> 8))*P + (lbx << sh) + (xy & 255)] = v;
+      int dc = 0;
+      if (j0 == 0) dc = a.coef[plane_off + (long)(y0 + (lby << sh))*a.w + x0 + (lbx << sh)];
+      const int base = (lby << sh)*P + (lbx << sh);
+#pragma unroll
+      for (int hf = 0; hf < 2; hf++) {
+        const int4 qm4 = *reinterpret_cast<const int4 *>(s_qmi + j0 + 8*hf);
+        const int4 sc4 = *reinterpret_cast<const int4 *>(s_scan + j0 + 8*hf);
+        const int yd[4] = {yq[hf].x, yq[hf].y, yq[hf].z, yq[hf].w};
+        const int qd[4] = {qm4.x, qm4.y, qm4.z, qm4.w};
+        const int sd[4] = {sc4.x, sc4.y, sc4.z, sc4.w};
+        const int4 ch = chs[hf];
+        const int rnd = (1 << ch.w) >> 1;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+#pragma unroll
+          for (int u = 0; u < 2; u++) {
+            /* OD_MULT16_32_Q16: (int16)y * (int32)scale >> 16 == mulhi(y << 16, scale) */
+            const int yhi = u ? (yd[e] & (int)0xffff0000) : yd[e] << 16;
+            const int qmi = u ? qd[e] >> 16 : (int)(short)qd[e];
+            const int xy = u ? (unsigned)sd[e] >> 16 : sd[e] & 0xffff;
+            int v = (__mulhi(yhi, ch.z)*qmi + rnd) >> ch.w;
+            if (ch.y == 0) v = 0;
+            if (hf == 0 && e == 0 && u == 0 && j0 == 0) v = dc;
+            t[base + (xy >> 8)*P + (xy & 255)] = v;
+          }
+        }
+      }
     }
   }
   else {
@@ -907,7 +935,7 @@ extern "C" int odhip_inverse_level_pvq(uint8_t *d_px, int px_stride, long px_pla
   const int h = job->h;
   const int bs = job->bs;
   if (w <= 0 || h <= 0 || w % tile || h % tile || (px_stride & 3) || (px_plane_stride & 3)
-   || bs < 0 || bs > 4 - dec) {
+   || bs < 0 || bs > 4 - dec || ((uintptr_t)job->cands.y & 15) || ((uintptr_t)job->cands.choice & 15)) {
     return ODHIP_EINVAL;
   }
   int rc = upload_inv_tables();

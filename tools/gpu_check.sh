@@ -1,3 +1,4 @@
+timeout 600 python -m pytest tests -m gpu -x -q 2>&1 | tail -3
 bash tools/prof_quick.sh 2>&1 | head -12
 timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline 2>&1 | tail -1 > gpurun_out/bench_last.json
 python - <<'PY'
