@@ -35,6 +35,7 @@
 #include "../../include/daala_hip.h"
 #include <stdlib.h>
 #include <string.h>
+#include <type_traits>
 #include "od_common.cuh"
 #include "od_pvq_math.cuh"
 #include "gen/od_scan_tables.h"
@@ -170,11 +171,40 @@ __device__ __forceinline__ RecHead rec_head_load(const odhip_pvq_band *r) {
   return h;
 }
 
+/* Everything the preparation kernels need of a job, read ONCE at the top of the
+   kernel: g_jobs is global memory that the kernels' own stores might alias as
+   far as the compiler knows, so a field read after a store is reloaded with an
+   exposed memory latency (five serialised reloads per band before this). */
+struct PrepCtx {
+  const int16_t *qm;       /* + off */
+  int16_t *x16;            /* + off - pad */
+  odhip_pvq_band *rec;     /* + band */
+  unsigned short *keys;    /* + band*nblocks */
+  int w;
+  int len;
+  int nb_bands;
+  int q;
+  int beta;
+};
+
+__device__ __forceinline__ PrepCtx prep_ctx(const DJob &jb, int band, int off, int pad) {
+  PrepCtx c;
+  c.qm = jb.qm + off;
+  c.x16 = jb.x16 + off - pad;
+  c.rec = jb.rec + band;
+  c.keys = jb.keys + (long)band*jb.nblocks;
+  c.w = jb.w;
+  c.len = jb.len;
+  c.nb_bands = jb.nb_bands;
+  c.q = jb.q[band];
+  c.beta = jb.beta[band];
+  return c;
+}
+
 /* Everything of a band that precedes the search, from cg on: the two gain
    candidates (src/pvq_encoder.c:578-592), the first half of the record and the
    sort key.  Heavy bands get SMALL keys so that they are dispatched first. */
-__device__ __forceinline__ void od_band_candidates(const DJob &jb, int band, int n, long blk,
- int32_t cg, int beta) {
+__device__ __forceinline__ void od_band_candidates(const PrepCtx &cx, int n, long blk, int32_t cg) {
   const double s2 = (1./256)*(1./256);  /* OD_CGAIN_SCALE_2 */
   const double dist0 = ((1.4*cg)*cg)*s2;
   const int gain_bound = cg >> ODQ_CGAIN_SHIFT;
@@ -182,19 +212,20 @@ __device__ __forceinline__ void od_band_candidates(const DJob &jb, int band, int
   int kk[2] = {0, 0};
   int fl[2] = {0, 0};
   int gain[2] = {0, 0};
+#pragma unroll
   for (int c = 0; c < 2; c++) {
     const int i = first + c;
     if (i <= gain_bound + 1) {
       const int32_t qcg = odq_shl32(i, ODQ_CGAIN_SHIFT);
       gain[c] = i;
-      kk[c] = odq_compute_k_noref(qcg, n, beta);
+      kk[c] = odq_compute_k_noref(qcg, n, cx.beta);
       const double dist = ((1.4*(qcg - cg))*(qcg - cg))*s2;
       fl[c] = !(dist > dist0 && kk[c] != 0);
       if (fl[c] && kk[c] > kMaxK) fl[c] = 2;   /* not representable: reported, not searched */
       if (kk[c] > kMaxK) kk[c] = kMaxK;
     }
   }
-  int4 *out = reinterpret_cast<int4 *>(jb.rec + blk*jb.nb_bands + band);
+  int4 *out = reinterpret_cast<int4 *>(cx.rec + blk*cx.nb_bands);
   out[0] = make_int4(cg, gain[0], gain[1], (kk[0] & 0xffff) | kk[1] << 16);
   out[1] = make_int4(fl[0] | fl[1] << 8, 0, __double2loint(dist0), __double2hiint(dist0));
   const bool s0 = fl[0] == 1;
@@ -202,8 +233,7 @@ __device__ __forceinline__ void od_band_candidates(const DJob &jb, int band, int
   const int p0 = s0 ? kk[0] : 0;
   int p1 = 0;
   if (s1) p1 = s0 && kk[0] > 0 && kk[0] <= kk[1] ? kk[1] - kk[0] : kk[1];
-  jb.keys[(long)band*jb.nblocks + blk] =
-   (unsigned short)(kKeyBins - 1 - (od_pulse_bin(p0) << 4 | od_extra_bin(p1)));
+  cx.keys[blk] = (unsigned short)(kKeyBins - 1 - (od_pulse_bin(p0) << 4 | od_extra_bin(p1)));
 }
 
 /* ---- prep, bands of up to 32 coefficients: one band per lane ------------------
@@ -217,9 +247,13 @@ template <int N>
 __device__ __forceinline__ void od_prep_lane(const DJob &jb, int band, int off, const BlockPos &bp) {
   constexpr int PAD = N == 15 ? 1 : 0;
   constexpr int NV = (N + PAD)/8;
+  const PrepCtx cx = prep_ctx(jb, band, off, PAD);
+  int qm[N];
+#pragma unroll
+  for (int j = 0; j < N; j++) qm[j] = cx.qm[j];
   int v[N];
 #pragma unroll
-  for (int j = 0; j < N; j++) v[j] = bp.src[kScanXY[off + j][1]*jb.w + kScanXY[off + j][0]];
+  for (int j = 0; j < N; j++) v[j] = bp.src[kScanXY[off + j][1]*cx.w + kScanXY[off + j][0]];
   int sum = 0;
 #pragma unroll
   for (int j = 0; j < N; j++) {
@@ -228,7 +262,7 @@ __device__ __forceinline__ void od_prep_lane(const DJob &jb, int band, int off, 
   }
   int xshift = 8 + 1 + odq_ilog(N + sum)/2 - 15;
   xshift = xshift > 0 ? xshift : 0;
-  int4 *xo = reinterpret_cast<int4 *>(jb.x16 + bp.blk*jb.len + off - PAD);
+  int4 *xo = reinterpret_cast<int4 *>(cx.x16 + bp.blk*cx.len);
   int acc = 0;
 #pragma unroll
   for (int g = 0; g < NV; g++) {
@@ -240,7 +274,7 @@ __device__ __forceinline__ void od_prep_lane(const DJob &jb, int band, int off, 
       for (int u = 0; u < 2; u++) {
         const int j = g*8 + 2*t + u - PAD;
         x[u] = 0;
-        if (j >= 0) x[u] = (int16_t)odq_shr_round(v[j]*jb.qm[off + j], ODQ_QM_SHIFT + xshift);
+        if (j >= 0) x[u] = (int16_t)odq_shr_round(v[j]*qm[j], ODQ_QM_SHIFT + xshift);
         acc += x[u]*x[u];
       }
       d[t] = (x[0] & 0xffff) | x[1] << 16;
@@ -249,8 +283,8 @@ __device__ __forceinline__ void od_prep_lane(const DJob &jb, int band, int off, 
   }
   if (!bp.live) return;
   int32_t g;
-  const int32_t cg = odq_gain_from_acc(acc, jb.q[band], jb.beta[band], xshift, &g);
-  od_band_candidates(jb, band, N, bp.blk, cg, jb.beta[band]);
+  const int32_t cg = odq_gain_from_acc(acc, cx.q, cx.beta, xshift, &g);
+  od_band_candidates(cx, N, bp.blk, cg);
 }
 
 __global__ __launch_bounds__(kWave) void k_prep_lane(Items it) {
@@ -265,6 +299,92 @@ __global__ __launch_bounds__(kWave) void k_prep_lane(Items it) {
   else od_prep_lane<32>(jb, band, off, bp);
 }
 
+/* ---- prep, the CxC low-frequency corner of every block: one block per lane -----
+   Coding positions 0..15 of a 4x4 block and 0..63 of every larger block lie in
+   its top-left 4x4 / 8x8 corner (od_raster_to_coding_order,
+   src/partition.c:144-170) and hold band 0 (15 coefficients) resp. bands 0..3
+   (15, 8, 8, 32).  A lane loads its block's corner as whole 16-byte row
+   segments - adjacent lanes read adjacent blocks, so a wavefront's loads are
+   (nearly) contiguous, where one-band-per-lane gathers fetched every 32-byte
+   sector once per coefficient - permutes it to coding order in registers (the
+   scan is a compile-time constant), and prepares all of the corner's bands. */
+/* Compile-time loop: f(std::integral_constant<int, J>) for J in [J0, J1).  The
+   corner kernel indexes its register arrays with scan-table entries; the
+   indices must be constant expressions for the arrays to stay in registers
+   (a plain unrolled loop left them in scratch memory: 784 bytes per lane). */
+template <int J0, int J1, class F>
+__device__ __forceinline__ void od_static_for(F &&f) {
+  if constexpr (J0 < J1) {
+    f(std::integral_constant<int, J0>{});
+    od_static_for<J0 + 1, J1>(f);
+  }
+}
+
+template <int C>
+__global__ __launch_bounds__(kWave) void k_prep_corner(Items it) {
+  constexpr int NC = C*C;
+  constexpr int NBANDS = C == 4 ? 1 : 4;
+  const int item = find_item(it, blockIdx.x);
+  const DJob &jb = g_jobs[it.job[item]];
+  const BlockPos bp = locate(jb, (long)(blockIdx.x - it.wg_start[item])*kWave + threadIdx.x);
+  PrepCtx cx[NBANDS];
+#pragma unroll
+  for (int b = 0; b < NBANDS; b++) cx[b] = prep_ctx(jb, b, 0, 0);
+  const int16_t *const qmp = cx[0].qm;
+  const int w = cx[0].w;
+  int r[NC];        /* raster, row-major CxC */
+#pragma unroll
+  for (int y = 0; y < C; y++) {
+#pragma unroll
+    for (int x = 0; x < C; x += 4) {
+      const int4 q = *reinterpret_cast<const int4 *>(bp.src + y*w + x);
+      r[y*C + x] = q.x;
+      r[y*C + x + 1] = q.y;
+      r[y*C + x + 2] = q.z;
+      r[y*C + x + 3] = q.w;
+    }
+  }
+  int x16[NC];
+  x16[0] = 0;
+  od_static_for<0, NBANDS>([&](auto bc) {
+    constexpr int b = decltype(bc)::value;
+    constexpr int kOff[5] = {1, 16, 24, 32, 64};
+    constexpr int off = kOff[b];
+    constexpr int n = kOff[b + 1] - off;
+    /* od_vector_log_mag, src/pvq.c:472-484 */
+    int sum = 0;
+    od_static_for<off, off + n>([&](auto jc) {
+      constexpr int j = decltype(jc)::value;
+      const int t = (int16_t)(r[OD_SCAN_XY[j][1]*C + OD_SCAN_XY[j][0]] >> 8);
+      sum += t*t;
+    });
+    int xshift = 8 + 1 + odq_ilog(n + sum)/2 - 15;
+    xshift = xshift > 0 ? xshift : 0;
+    int acc = 0;
+    od_static_for<off, off + n>([&](auto jc) {
+      constexpr int j = decltype(jc)::value;
+      x16[j] = (int16_t)odq_shr_round(r[OD_SCAN_XY[j][1]*C + OD_SCAN_XY[j][0]]*qmp[j],
+       ODQ_QM_SHIFT + xshift);
+      acc += x16[j]*x16[j];
+    });
+    if (bp.live) {
+      int32_t g;
+      const int32_t cg = odq_gain_from_acc(acc, cx[b].q, cx[b].beta, xshift, &g);
+      od_band_candidates(cx[b], n, bp.blk, cg);
+    }
+  });
+  if (bp.live) {
+    int4 *xo = reinterpret_cast<int4 *>(cx[0].x16 + bp.blk*cx[0].len);
+    od_static_for<0, NC/8>([&](auto gc) {
+      constexpr int g = decltype(gc)::value;
+      xo[g] = make_int4((x16[g*8] & 0xffff) | x16[g*8 + 1] << 16,
+       (x16[g*8 + 2] & 0xffff) | x16[g*8 + 3] << 16,
+       (x16[g*8 + 4] & 0xffff) | x16[g*8 + 5] << 16,
+       (x16[g*8 + 6] & 0xffff) | x16[g*8 + 7] << 16);
+    });
+  }
+}
+
 /* ---- prep, 128-coefficient bands: one band per 16-lane DPP row ---------------- */
 __global__ __launch_bounds__(kWave) void k_prep_wide(Items it) {
   constexpr int E = 8;
@@ -277,15 +397,20 @@ __global__ __launch_bounds__(kWave) void k_prep_wide(Items it) {
   const int row = lane >> 4;
   const int l = lane & 15;
   const BlockPos bp = locate(jb, (long)(blockIdx.x - it.wg_start[item])*4 + row);
+  const PrepCtx cx = prep_ctx(jb, band, off, 0);
   __shared__ unsigned short s_scan[n];
   for (int j = lane; j < n; j += kWave) s_scan[j] = gScanXY[off + j];
+  const int4 qm4 = *reinterpret_cast<const int4 *>(cx.qm + l*E);
   __syncthreads();
   int v[E];
   int sum = 0;
 #pragma unroll
   for (int e = 0; e < E; e++) {
     const int xy = s_scan[l*E + e];
-    v[e] = bp.src[(xy >> 8)*jb.w + (xy & 255)];
+    v[e] = bp.src[(xy >> 8)*cx.w + (xy & 255)];
+  }
+#pragma unroll
+  for (int e = 0; e < E; e++) {
     const int t = (int16_t)(v[e] >> 8);
     sum += t*t;
   }
@@ -294,21 +419,22 @@ __global__ __launch_bounds__(kWave) void k_prep_wide(Items it) {
   xshift = xshift > 0 ? xshift : 0;
   int acc = 0;
   int d[E/2];
+  const int qd[4] = {qm4.x, qm4.y, qm4.z, qm4.w};
 #pragma unroll
   for (int e = 0; e < E; e += 2) {
-    const int x0 = (int16_t)odq_shr_round(v[e]*jb.qm[off + l*E + e], ODQ_QM_SHIFT + xshift);
-    const int x1 = (int16_t)odq_shr_round(v[e + 1]*jb.qm[off + l*E + e + 1], ODQ_QM_SHIFT + xshift);
+    const int x0 = (int16_t)odq_shr_round(v[e]*(int)(short)qd[e/2], ODQ_QM_SHIFT + xshift);
+    const int x1 = (int16_t)odq_shr_round(v[e + 1]*(qd[e/2] >> 16), ODQ_QM_SHIFT + xshift);
     acc += x0*x0 + x1*x1;
     d[e/2] = (x0 & 0xffff) | x1 << 16;
   }
   if (bp.live) {
-    *reinterpret_cast<int4 *>(jb.x16 + bp.blk*jb.len + off + l*E) = make_int4(d[0], d[1], d[2], d[3]);
+    *reinterpret_cast<int4 *>(cx.x16 + bp.blk*cx.len + l*E) = make_int4(d[0], d[1], d[2], d[3]);
   }
   acc = row_sum(acc);
   if (!bp.live || l != 0) return;
   int32_t g;
-  const int32_t cg = odq_gain_from_acc(acc, jb.q[band], jb.beta[band], xshift, &g);
-  od_band_candidates(jb, band, n, bp.blk, cg, jb.beta[band]);
+  const int32_t cg = odq_gain_from_acc(acc, cx.q, cx.beta, xshift, &g);
+  od_band_candidates(cx, n, bp.blk, cg);
 }
 
 /* ---- counting sort of each item's block indices by key (heavy first) ------------
@@ -574,6 +700,11 @@ __global__ __launch_bounds__(256) void k_choose(Items it) {
   const long sb = (long)(blockIdx.x - it.wg_start[item])*256 + threadIdx.x;
   if (sb >= jb.nblocks*jb.nb_bands) return;
   const int band = (int)(sb % jb.nb_bands);
+  const int qb = jb.q[band];
+  const int betab = jb.beta[band];
+  const double *const rate = jb.rate;
+  int4 *const choice = reinterpret_cast<int4 *>(jb.choice);
+  int32_t *const qg_out = jb.qg_out;
   const int4 *r = reinterpret_cast<const int4 *>(jb.rec + sb);
   const RecHead hd = rec_head_load(jb.rec + sb);
   const int4 r1 = r[1];
@@ -587,7 +718,7 @@ __global__ __launch_bounds__(256) void k_choose(Items it) {
   for (int c = 0; c < 2; c++) {
     if (hd.flags[c] != 1) continue;
     double cost = dists[c];
-    if (jb.rate) cost = cost + it.lambda*jb.rate[2*sb + c];
+    if (rate) cost = cost + it.lambda*rate[2*sb + c];
     if (cost <= best_cost) {
       best_cost = cost;
       qg = hd.gain[c];
@@ -597,7 +728,7 @@ __global__ __launch_bounds__(256) void k_choose(Items it) {
   int32_t scale = 0;
   int qshift = ODQ_QM_INV_SHIFT;
   if (qg != 0) {
-    const int32_t g = odq_gain_expand(odq_shl32(qg, ODQ_CGAIN_SHIFT), jb.q[band], jb.beta[band]);
+    const int32_t g = odq_gain_expand(odq_shl32(qg, ODQ_CGAIN_SHIFT), qb, betab);
     const int yy = sel ? yys[1] : yys[0];
     int gshift = odq_ilog(g) - 14;
     gshift = gshift > 0 ? gshift : 0;
@@ -608,8 +739,8 @@ __global__ __launch_bounds__(256) void k_choose(Items it) {
     }
     qshift = ODQ_QM_INV_SHIFT - gshift;
   }
-  reinterpret_cast<int4 *>(jb.choice)[sb] = make_int4(sel, qg, scale, qshift);
-  if (jb.qg_out) jb.qg_out[sb] = qg;
+  choice[sb] = make_int4(sel, qg, scale, qshift);
+  if (qg_out) qg_out[sb] = qg;
 }
 
 /* ---- synthesis: four horizontally adjacent coefficients per lane -------------
@@ -713,6 +844,8 @@ int fill_job(DJob &d, const odhip_pvq_job &j, int mode) {
   }
   /* mode 0: band stage (needs qm); 1: choice + synthesis (qm_inv, dq); 2: choice only */
   if (mode == 0 ? !j.d_qm : mode == 1 ? (!j.d_qm_inv || !j.d_dq) : false) return ODHIP_EINVAL;
+  /* 16-byte loads of QM rows and of coefficient row segments */
+  if (mode == 0 && (((uintptr_t)j.d_qm & 15) || ((uintptr_t)j.d_coef & 15))) return ODHIP_EINVAL;
   const int n = 4 << j.bs;
   if (j.w <= 0 || j.h <= 0 || j.w % n || j.h % n || (j.w & 3)) return ODHIP_EINVAL;
   memset(&d, 0, sizeof(d));
@@ -908,15 +1041,27 @@ extern "C" int odhip_pvq_noref_bands_multi(const odhip_pvq_job *jobs, int njobs,
   hipStream_t side[2] = {s, s};
   if (fork_streams(s, side) != ODHIP_SUCCESS) return ODHIP_EFAULT;
   Items it;
-  /* prep: bands up to 32 coefficients one per lane, 128 one per 16-lane row */
+  /* prep: the low-frequency corner of every block one block per lane (bands
+     0..3), the remaining 32-coefficient bands one band per lane, the
+     128-coefficient bands one per 16-lane row */
   items_begin(it, lambda);
   for (int j = 0; j < njobs; j++) {
-    for (int b = 0; b < host[j].nb_bands; b++) {
+    if (host[j].bs == 0) items_add(it, j, 0, (host[j].nblocks + kWave - 1)/kWave);
+  }
+  if (it.nitems) k_prep_corner<4><<<it.wg_start[it.nitems], kWave, 0, s>>>(it);
+  items_begin(it, lambda);
+  for (int j = 0; j < njobs; j++) {
+    if (host[j].bs > 0) items_add(it, j, 0, (host[j].nblocks + kWave - 1)/kWave);
+  }
+  if (it.nitems) k_prep_corner<8><<<it.wg_start[it.nitems], kWave, 0, s>>>(it);
+  items_begin(it, lambda);
+  for (int j = 0; j < njobs; j++) {
+    for (int b = 4; b < host[j].nb_bands; b++) {
       const int n = host[j].off[b + 1] - host[j].off[b];
       if (n <= 32) items_add(it, j, b, (host[j].nblocks + kWave - 1)/kWave);
     }
   }
-  if (it.nitems) k_prep_lane<<<it.wg_start[it.nitems], kWave, 0, s>>>(it);
+  if (it.nitems) k_prep_lane<<<it.wg_start[it.nitems], kWave, 0, side[1]>>>(it);
   items_begin(it, lambda);
   for (int j = 0; j < njobs; j++) {
     for (int b = 0; b < host[j].nb_bands; b++) {

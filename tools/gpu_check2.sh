@@ -1,8 +1,5 @@
-timeout 300 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "pyramid or inverse" 2>&1 | tail -4
-timeout 600 python bench.py --steps 5 --warmup 2 --no-cpu-baseline 2>&1 | tail -1 > gpurun_out/bench_last.json
-python - <<'PY'
-import json
-d=json.load(open('gpurun_out/bench_last.json'))
-print(d["value"], d["ms_per_step"])
-for k,v in d["kernels"].items(): print(k, v["avg_ms_per_launch"], v["launches"], v["share_of_step"], v.get("achieved_GBs"))
-PY
+for d in 0 1 2 4 7; do
+  export ODHIP_PREP_DEBUG=$d
+  echo "== debug $d"
+  bash tools/prof_quick.sh 2>&1 | grep -E "k_prep_lane|k_prep_wide"
+done
