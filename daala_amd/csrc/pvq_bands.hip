@@ -543,22 +543,26 @@ __global__ __launch_bounds__(256) void k_scatter(Items it) {
    extra live registers cost more occupancy than the prefetch buys), so that
    is what the launches use; the exposed latency that motivated it turned out
    to be eight serialised loads of the 1/sqrt table (fixed above). */
-template <int N>
+template <int NL, int PAD>
 struct BandFetch {
-  static constexpr int PAD = N == 15 ? 1 : 0;      /* leading DC slot */
-  static constexpr int NV = (N + PAD)/8;           /* 16-byte groups of int16 */
+  static constexpr int NV = (NL + PAD)/8;          /* 16-byte groups of int16 */
   int4 head[2];
   int4 x[NV];
 };
 
-template <int N, int NB>
-__global__ __launch_bounds__(kWave) void k_search(Items it) {
-  constexpr int PAD = BandFetch<N>::PAD;
-  constexpr int NV = BandFetch<N>::NV;
-  static_assert((N + PAD)%8 == 0, "band must be a whole number of 16-byte groups");
+/* N = band size, S = lanes per band (pvq_lane.cuh: S = 2 for the 128-coefficient
+   band), NB = groups per wavefront. */
+template <int N, int S, int NB>
+__global__ __launch_bounds__(kWave, (S == 2 ? 2 : 1)) void k_search(Items it) {
+  constexpr int NL = N/S;                   /* coefficients per lane */
+  constexpr int PAD = N == 15 ? 1 : 0;      /* leading DC slot */
+  constexpr int NV = BandFetch<NL, PAD>::NV;
+  constexpr int SLOTS = kWave/S;            /* bands per wavefront */
+  static_assert(N % S == 0 && (NL + PAD)%8 == 0, "a lane holds whole 16-byte groups");
+  static_assert(S == 1 || PAD == 0, "pair mode has no padded band");
   extern __shared__ __attribute__((aligned(16))) double lds_d[];
   double *rsq = lds_d;                                   /* [kRsqN]  */
-  uint32_t *pk = (uint32_t *)(rsq + kRsqN);              /* [N][64]  */
+  uint32_t *pk = (uint32_t *)(rsq + kRsqN);              /* [NL][64] */
   const int lane = threadIdx.x;
   {
     /* all eight loads in flight before the first LDS store (the compiler keeps
@@ -572,7 +576,8 @@ __global__ __launch_bounds__(kWave) void k_search(Items it) {
   const int item = find_item(it, blockIdx.x);
   const DJob &jb = g_jobs[it.job[item]];
   const int band = it.band[item];
-  const int off = jb.off[band] - PAD;
+  const int half = S == 2 ? lane & 1 : 0;
+  const int off = jb.off[band] - PAD + half*NL;
   const long nblocks = jb.nblocks;
   const int len = jb.len;
   const int nb_bands = jb.nb_bands;
@@ -581,12 +586,12 @@ __global__ __launch_bounds__(kWave) void k_search(Items it) {
   const int16_t *const x16 = jb.x16 + off;
   int16_t *const yout = jb.y + off;
   double *const cosd = jb.cos_dist;
-  const long stride = (long)(it.wg_start[item + 1] - it.wg_start[item])*kWave;
-  const long spos0 = (long)(blockIdx.x - it.wg_start[item])*kWave + lane;
+  const long stride = (long)(it.wg_start[item + 1] - it.wg_start[item])*SLOTS;
+  const long spos0 = (long)(blockIdx.x - it.wg_start[item])*SLOTS + lane/S;
   /* prologue: indices of groups 0 and 1, data of group 0 */
   unsigned blk_next = spos0 < nblocks ? ids[spos0] : 0;
   unsigned blk_next2 = NB > 1 && spos0 + stride < nblocks ? ids[spos0 + stride] : 0;
-  BandFetch<N> nx;
+  BandFetch<NL, PAD> nx;
   {
     const int4 *hp = reinterpret_cast<const int4 *>(recs + (long)blk_next*nb_bands);
     const int4 *xp = reinterpret_cast<const int4 *>(x16 + (long)blk_next*len);
@@ -601,7 +606,7 @@ __global__ __launch_bounds__(kWave) void k_search(Items it) {
     const long spos = spos0 + b*stride;
     const bool live = spos < nblocks;
     const long blk = blk_next;
-    const BandFetch<N> cur = nx;
+    const BandFetch<NL, PAD> cur = nx;
     if (b + 1 < NB) {
       /* data of group b+1 (its index arrived during the previous iteration),
          index of group b+2 */
@@ -633,36 +638,49 @@ __global__ __launch_bounds__(kWave) void k_search(Items it) {
       }
     }
     LaneSearch st;
-    od_lane_prepare<N>(st, pk, lane);
+    od_lane_prepare<NL, S>(st, pk, lane);
     const int32_t cg = hd.cg;
     const double s2 = (1./256)*(1./256);
     int prev_k = 0;
-    int yy[2];
-    double dist[2];
+    int yy0 = 0;
+    int yy1 = 0;
+    double dist0 = 0;
+    double dist1 = 0;
 #pragma unroll 1
     for (int c = 0; c < 2; c++) {
-      const bool on = hd.flags[c] == 1;
-      const int k = hd.k[c];
-      const int32_t qcg = odq_shl32(hd.gain[c], ODQ_CGAIN_SHIFT);
+      /* selects, not hd.x[c]: a dynamically indexed local array lives in scratch */
+      const bool on = (c ? hd.flags[1] : hd.flags[0]) == 1;
+      const int k = c ? hd.k[1] : hd.k[0];
+      const int gain = c ? hd.gain[1] : hd.gain[0];
+      const int32_t qcg = odq_shl32(gain, ODQ_CGAIN_SHIFT);
       const double g2 = (qcg*(double)cg)*s2;
       const bool fresh = !(prev_k > 0 && prev_k <= k);
-      const double cos_dist = od_lane_search<N>(st, pk, rsq, lane, on, fresh, k, g2, it.lambda);
+      const double cos_dist = od_lane_search<NL, S>(st, pk, rsq, lane, half, on, fresh, k, g2,
+       it.lambda);
       /* src/pvq_encoder.c:586,:593-595; a slot that is not in use has distortion 0 */
-      yy[c] = 0;
-      dist[c] = hd.gain[c] ? ((1.4*(qcg - cg))*(qcg - cg))*s2 : 0.;
+      int yyc = 0;
+      double distc = gain ? ((1.4*(qcg - cg))*(qcg - cg))*s2 : 0.;
       if (on) {
         prev_k = k;
-        yy[c] = (int)st.yy;
-        dist[c] = ((1.4*(qcg - cg))*(qcg - cg) + (qcg*(double)cg)*(2 - 2*cos_dist))*s2;
+        yyc = (int)st.yy;
+        distc = ((1.4*(qcg - cg))*(qcg - cg) + (qcg*(double)cg)*(2 - 2*cos_dist))*s2;
+      }
+      if (c) {
+        yy1 = yyc;
+        dist1 = distc;
+      }
+      else {
+        yy0 = yyc;
+        dist0 = distc;
       }
       if (live) {
-        if (cosd) cosd[2*(blk*nb_bands + band) + c] = on ? cos_dist : 0.;
+        if (cosd && half == 0) cosd[2*(blk*nb_bands + band) + c] = on ? cos_dist : 0.;
         int4 *yo = reinterpret_cast<int4 *>(yout + ((long)c*nblocks + blk)*len);
         const int4 *xp = reinterpret_cast<const int4 *>(x16 + blk*len);
 #pragma unroll
         for (int v = 0; v < NV; v++) {
           /* signs: from the registers for the short bands, re-read (L2) for the
-             128-coefficient band, whose 64 registers are better spent on the
+             128-coefficient band, whose registers are better spent on the
              pipelined search loops */
           const int4 q = N > 32 ? xp[v] : cur.x[v];
           const int d[4] = {q.x, q.y, q.z, q.w};
@@ -680,10 +698,10 @@ __global__ __launch_bounds__(kWave) void k_search(Items it) {
         }
       }
     }
-    if (live) {
+    if (live && half == 0) {
       int4 *out = reinterpret_cast<int4 *>(recs + blk*nb_bands) + 2;
-      out[0] = make_int4(yy[0], yy[1], __double2loint(dist[0]), __double2hiint(dist[0]));
-      out[1] = make_int4(__double2loint(dist[1]), __double2hiint(dist[1]), 0, 0);
+      out[0] = make_int4(yy0, yy1, __double2loint(dist0), __double2hiint(dist0));
+      out[1] = make_int4(__double2loint(dist1), __double2hiint(dist1), 0, 0);
     }
   }
 }
@@ -981,20 +999,21 @@ void items_add(Items &it, int job, int band, long wgs) {
   it.nitems++;
 }
 
-template <int N, int NB>
+template <int N, int S, int NB>
 void launch_search(const DJob *host, int njobs, double lambda, hipStream_t s) {
+  constexpr int per_wave = kWave/S*NB;
   Items it;
   items_begin(it, lambda);
   for (int j = 0; j < njobs; j++) {
     for (int b = 0; b < host[j].nb_bands; b++) {
       if (host[j].off[b + 1] - host[j].off[b] == N) {
-        items_add(it, j, b, (host[j].nblocks + kWave*NB - 1)/(kWave*NB));
+        items_add(it, j, b, (host[j].nblocks + per_wave - 1)/per_wave);
       }
     }
   }
   if (!it.nitems) return;
-  constexpr size_t lds = kRsqN*sizeof(double) + (size_t)N*kPitch*4;
-  k_search<N, NB><<<it.wg_start[it.nitems], kWave, lds, s>>>(it);
+  constexpr size_t lds = kRsqN*sizeof(double) + (size_t)(N/S)*kPitch*4;
+  k_search<N, S, NB><<<it.wg_start[it.nitems], kWave, lds, s>>>(it);
 }
 
 }  // namespace
@@ -1085,10 +1104,10 @@ extern "C" int odhip_pvq_noref_bands_multi(const odhip_pvq_job *jobs, int njobs,
   k_scatter<<<it.wg_start[it.nitems], 256, 0, s>>>(it);
   /* search: the band sizes are independent launches on forked streams */
   if (fork_streams(s, side) != ODHIP_SUCCESS) return ODHIP_EFAULT;
-  launch_search<128, 1>(host, njobs, lambda, s);
-  launch_search<32, 1>(host, njobs, lambda, side[0]);
-  launch_search<15, 1>(host, njobs, lambda, side[1]);
-  launch_search<8, 1>(host, njobs, lambda, side[1]);
+  launch_search<128, 2, 1>(host, njobs, lambda, s);
+  launch_search<32, 1, 1>(host, njobs, lambda, side[0]);
+  launch_search<15, 1, 1>(host, njobs, lambda, side[1]);
+  launch_search<8, 1, 1>(host, njobs, lambda, side[1]);
   if (join_streams(s, side) != ODHIP_SUCCESS) return ODHIP_EFAULT;
   return odhip_check_launch();
 }

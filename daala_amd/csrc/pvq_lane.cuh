@@ -56,6 +56,13 @@ __device__ __forceinline__ int od_sel(unsigned long long m, int t, int f) {
   return d;
 }
 
+/* The candidate index as a running VGPR: `pos = od_sel(m, j, pos)` with j a
+   literal would need one VGPR per distinct j for the asm operand (the compiler
+   hoists all of them: 127 registers for n = 128). */
+__device__ __forceinline__ void od_inc(int &j) {
+  asm("v_add_u32 %0, 1, %0" : "+v"(j));
+}
+
 __device__ __forceinline__ double od_sel(unsigned long long m, double t, double f) {
   const int lo = od_sel(m, __double2loint(t), __double2loint(f));
   const int hi = od_sel(m, __double2hiint(t), __double2hiint(f));
@@ -66,6 +73,7 @@ struct LaneSearch {
   double xx;
   double norm2;   /* 2*norm_1 */
   double l1_inv;
+  unsigned xmax;  /* largest |x| of the band (pair mode: exactness bound) */
   unsigned xy;    /* sum |x|*y   (< 2^30 for K <= kMaxK) */
   unsigned yy;    /* sum y*y     (< 2^30) */
   int i;          /* pulses placed */
@@ -78,20 +86,56 @@ constexpr int kMaxK = 32767;
 
 /* Per-band constants: xx, 2/sqrt(1e-30 + xx), 1/max(L1, 1e-100)
    (src/pvq_encoder.c:118-125,:139-141). */
-template <int N>
+/* PAIR MODE (S = 2): a band of 2*N coefficients is shared by two adjacent
+   lanes, the even lane holding coding positions 0..N-1 and the odd lane
+   N..2N-1 (`jbase` = first position of the lane).  It halves the LDS of a
+   wavefront (n = 128: 16 KiB instead of 32, so two wavefronts fit a SIMD and
+   other kernels fit beside them) and the latency of a pulse.  Sums are
+   combined with one DPP swap; the two halves of an argmax are combined as
+   described at od_lane_search. */
+__device__ __forceinline__ int od_pair_swap(int v) {
+  return row_mov<OD_DPP_XOR1>(v);
+}
+
+__device__ __forceinline__ unsigned od_pair_swap(unsigned v) {
+  return (unsigned)row_mov<OD_DPP_XOR1>((int)v);
+}
+
+__device__ __forceinline__ double od_pair_swap(double v) {
+  return row_mov<OD_DPP_XOR1>(v);
+}
+
+__device__ __forceinline__ unsigned long long od_pair_swap(unsigned long long v) {
+  const unsigned lo = od_pair_swap((unsigned)v);
+  const unsigned hi = od_pair_swap((unsigned)(v >> 32));
+  return (unsigned long long)hi << 32 | lo;
+}
+
+/* Per-band constants: xx, 2/sqrt(1e-30 + xx), 1/max(L1, 1e-100)
+   (src/pvq_encoder.c:118-125,:139-141). */
+template <int N, int S>
 __device__ __forceinline__ void od_lane_prepare(LaneSearch &s, const uint32_t *pk, int lane) {
   unsigned long long xx = 0;
   unsigned l1 = 0;
+  unsigned xmax = 0;
 #pragma unroll 8
   for (int j = 0; j < N; j++) {
     const unsigned ax = pk[j*kPitch + lane] >> 16;
     xx += (unsigned long long)ax*ax;
     l1 += ax;
+    xmax = ax > xmax ? ax : xmax;
+  }
+  if (S == 2) {
+    xx += od_pair_swap(xx);
+    l1 += od_pair_swap(l1);
+    const unsigned o = od_pair_swap(xmax);
+    xmax = o > xmax ? o : xmax;
   }
   s.xx = (double)xx;
   s.norm2 = 2*__ddiv_rn(1., __dsqrt_rn(1e-30 + s.xx));
   const double l1d = (double)l1;
   s.l1_inv = __ddiv_rn(1., l1d > 1e-100 ? l1d : 1e-100);
+  s.xmax = xmax;
   s.xy = 0;
   s.yy = 0;
   s.i = 0;
@@ -123,24 +167,32 @@ __device__ __forceinline__ void od_lane_load_group(uint32_t (&w)[kGrp], const ui
    delta + j*0 == delta exactly). */
 template <int N, bool ACCEL>
 __device__ __forceinline__ int od_lane_rdo_scan(const uint32_t *pk, const double *rsq, int lane,
- unsigned xy, unsigned base, double norm2, double lambda, double delta_rate, double accel_rate) {
+ unsigned xy, unsigned base, double norm2, double lambda, double delta_rate, double accel_rate,
+ int jbase, double &best_out) {
   if (N <= 16) {
     /* short bands: fully unrolled, every load is requested up front anyway */
     double best = 0;
-    int pos = 0;
-#pragma unroll
+    int pos = jbase;
+    int jv = jbase;
+#pragma unroll 4
     for (int j = 0; j < N; j++) {
       const uint32_t w = pk[j*kPitch + lane];
       const double tt = (double)(xy + (w >> 16));
       const double r = rsq[base + (w & 0xffffu)];
-      const double val = (tt*norm2)*r - (lambda*j)*(ACCEL ? delta_rate + j*accel_rate : delta_rate);
+      if (j > 0) od_inc(jv);
+      /* the position as a double from the running index register: exact, and
+         (being opaque to the compiler) it keeps the per-candidate penalties
+         from being hoisted out of the pulse loop into 2 registers each */
+      const double jd = (double)jv;
+      const double val = (tt*norm2)*r - (lambda*jd)*(ACCEL ? delta_rate + jd*accel_rate : delta_rate);
       if (j == 0) best = val;
       else {
         const unsigned long long m = od_cmp_gt(val, best);
         best = od_sel(m, val, best);
-        pos = od_sel(m, j, pos);
+        pos = od_sel(m, jv, pos);
       }
     }
+    best_out = best;
     return pos;
   }
   constexpr int NG = (N + kGrp - 1)/kGrp;
@@ -154,7 +206,8 @@ __device__ __forceinline__ int od_lane_rdo_scan(const uint32_t *pk, const double
 #pragma unroll
   for (int t = 0; t < kGrp; t++) r0[t] = rsq[base + (w0[t] & 0xffffu)];
   double best = 0;
-  int pos = 0;
+  int pos = jbase;
+  int jv = jbase;
 #pragma unroll
   for (int g = 0; g < NG; g++) {
     if (g + 2 < NG) od_lane_load_group<N>(w2, pk, lane, g + 2);
@@ -168,12 +221,15 @@ __device__ __forceinline__ int od_lane_rdo_scan(const uint32_t *pk, const double
       const int j = g*kGrp + t;
       if (j < N) {
         const double tt = (double)(xy + (w0[t] >> 16));
-        const double val = (tt*norm2)*r0[t] - (lambda*j)*(ACCEL ? delta_rate + j*accel_rate : delta_rate);
+        if (j > 0) od_inc(jv);
+        const double jd = (double)jv;
+        const double val = (tt*norm2)*r0[t]
+         - (lambda*jd)*(ACCEL ? delta_rate + jd*accel_rate : delta_rate);
         if (j == 0) best = val;
         else {
           const unsigned long long m = od_cmp_gt(val, best);
           best = od_sel(m, val, best);
-          pos = od_sel(m, j, pos);
+          pos = od_sel(m, jv, pos);
         }
       }
     }
@@ -185,6 +241,7 @@ __device__ __forceinline__ int od_lane_rdo_scan(const uint32_t *pk, const double
       r0[t] = r1[t];
     }
   }
+  best_out = best;
   return pos;
 }
 
@@ -193,12 +250,13 @@ __device__ __forceinline__ int od_lane_rdo_scan(const uint32_t *pk, const double
    reference's cross-multiplied comparison. */
 template <int N>
 __device__ __forceinline__ int od_lane_greedy_scan(const uint32_t *pk, int lane, unsigned xy,
- unsigned yyp1) {
+ unsigned yyp1, int jbase, double &ba_out, double &bb_out) {
   if (N <= 16) {
     double ba = 0;
     double bb = 1;
-    int pos = 0;
-#pragma unroll
+    int pos = jbase;
+    int jv = jbase;
+#pragma unroll 4
     for (int j = 0; j < N; j++) {
       const uint32_t w = pk[j*kPitch + lane];
       const double tt = (double)(xy + (w >> 16));
@@ -209,12 +267,15 @@ __device__ __forceinline__ int od_lane_greedy_scan(const uint32_t *pk, int lane,
         bb = b;
       }
       else {
+        od_inc(jv);
         const unsigned long long m = od_cmp_gt(a*bb, ba*b);
         ba = od_sel(m, a, ba);
         bb = od_sel(m, b, bb);
-        pos = od_sel(m, j, pos);
+        pos = od_sel(m, jv, pos);
       }
     }
+    ba_out = ba;
+    bb_out = bb;
     return pos;
   }
   constexpr int NG = (N + kGrp - 1)/kGrp;
@@ -223,7 +284,8 @@ __device__ __forceinline__ int od_lane_greedy_scan(const uint32_t *pk, int lane,
   od_lane_load_group<N>(w0, pk, lane, 0);
   double ba = 0;
   double bb = 1;
-  int pos = 0;
+  int pos = jbase;
+  int jv = jbase;
 #pragma unroll
   for (int g = 0; g < NG; g++) {
     if (g + 1 < NG) od_lane_load_group<N>(w1, pk, lane, g + 1);
@@ -240,10 +302,11 @@ __device__ __forceinline__ int od_lane_greedy_scan(const uint32_t *pk, int lane,
           bb = b;
         }
         else {
+          od_inc(jv);
           const unsigned long long m = od_cmp_gt(a*bb, ba*b);
           ba = od_sel(m, a, ba);
           bb = od_sel(m, b, bb);
-          pos = od_sel(m, j, pos);
+          pos = od_sel(m, jv, pos);
         }
       }
     }
@@ -251,6 +314,8 @@ __device__ __forceinline__ int od_lane_greedy_scan(const uint32_t *pk, int lane,
 #pragma unroll
     for (int t = 0; t < kGrp; t++) w0[t] = w1[t];
   }
+  ba_out = ba;
+  bb_out = bb;
   return pos;
 }
 
@@ -261,10 +326,27 @@ __device__ __forceinline__ int od_lane_greedy_scan(const uint32_t *pk, int lane,
    coefficient j: |x| << 16 | 2*y.  xy, yy and the per-candidate t = xy + x_j,
    b = yy + 2*y_j + 1 are formed in 32-bit integers and converted: they are
    below 2^31, so the doubles are the reference's.  Returns the cosine
-   distance. */
-template <int N>
+   distance.
+
+   N = coefficients per lane, S = lanes per band (band size n = N*S), `half` =
+   lane % S.  In pair mode each lane scans its half and the halves are
+   combined:
+     - rate pass: the costs are doubles compared with `>`, (max cost, lowest
+       position) is a total order, so max-of-halves with the lower half winning
+       ties IS the sequential scan;
+     - greedy pass: the reference's `a_j*b_best > a_best*b_j` compares ROUNDED
+       products and need not be transitive.  When (xy + max|x|)^2 *
+       (yy + 2k + 1) < 2^53 every product of the pulse is an exact integer, the
+       comparison is the exact order of the rationals a/b, and "upper half's
+       best beats lower half's best, else lower" is what the sequential scan
+       ends on.  Otherwise (never seen with 8-bit video; the bound is checked
+       every pulse) the upper lane rescans its half starting from the lower
+       lane's best, which is the sequential scan literally. */
+template <int N, int S>
 __device__ __forceinline__ double od_lane_search(LaneSearch &s, uint32_t *pk, const double *rsq,
- int lane, bool on, bool fresh, int k, double g2, double pvq_norm_lambda) {
+ int lane, int half, bool on, bool fresh, int k, double g2, double pvq_norm_lambda) {
+  constexpr int NBAND = N*S;
+  const int jbase = S == 2 ? half*N : 0;
   fresh = fresh && on;
   if (__any(fresh)) {
     /* src/pvq_encoder.c:139-153; k <= 2 starts from zero, which is the same
@@ -284,6 +366,11 @@ __device__ __forceinline__ double od_lane_search(LaneSearch &s, uint32_t *pk, co
       yy += (unsigned)yj*(unsigned)yj;
       i += yj;
     }
+    if (S == 2) {
+      xy += od_pair_swap(xy);
+      yy += od_pair_swap(yy);
+      i += od_pair_swap(i);
+    }
     if (fresh) {
       s.xy = xy;
       s.yy = yy;
@@ -295,48 +382,97 @@ __device__ __forceinline__ double od_lane_search(LaneSearch &s, uint32_t *pk, co
   /* Greedy pulses, src/pvq_encoder.c:165-187. */
   while (__any(on && s.i < n_greedy)) {
     const bool step = on && s.i < n_greedy;
-    const int pos = od_lane_greedy_scan<N>(pk, lane, s.xy, s.yy + 1);
+    double ba;
+    double bb;
+    int pos = od_lane_greedy_scan<N>(pk, lane, s.xy, s.yy + 1, jbase, ba, bb);
+    if (S == 2) {
+      /* lower (A) and upper (B) half's best, the same in both lanes */
+      const double oa = od_pair_swap(ba);
+      const double ob = od_pair_swap(bb);
+      const int op = od_pair_swap(pos);
+      const double aa = half ? oa : ba;
+      const double ab = half ? ob : bb;
+      const int ap = half ? op : pos;
+      double xa = half ? ba : oa;
+      double xb = half ? bb : ob;
+      int xp = half ? pos : op;
+      const double tmax = (double)(s.xy + s.xmax);
+      const bool exact = (tmax*tmax)*(double)(s.yy + 2*(unsigned)k + 1) < 4503599627370496.;   /* 2^52: a factor 2 of margin for the bound's own rounding */
+      if (__any(step && !exact)) {
+        /* sequential: the upper lane rescans from the lower half's best */
+        double ra = aa;
+        double rb = ab;
+        int rp = ap;
+#pragma unroll 1
+        for (int j = 0; j < N; j++) {
+          const uint32_t w = pk[j*kPitch + lane];
+          const double tt = (double)(s.xy + (w >> 16));
+          const double a = tt*tt;
+          const double b = (double)(s.yy + 1 + (w & 0xffffu));
+          if (a*rb > ra*b) {
+            ra = a;
+            rb = b;
+            rp = jbase + j;
+          }
+        }
+        /* valid in the upper lane; hand it to the lower one */
+        const int up = od_pair_swap(rp);
+        pos = half ? rp : up;
+      }
+      else pos = xa*ab > aa*xb ? xp : ap;
+    }
+    int owner = 1;
+    int local = pos;
+    if (S == 2) {
+      owner = (pos >= N) == (half != 0);
+      local = pos - jbase;
+    }
+    uint32_t w = 0;
+    if (step && owner) w = pk[local*kPitch + lane];
+    if (S == 2) w |= od_pair_swap(w);
     if (step) {
-      const uint32_t w = pk[pos*kPitch + lane];
       s.xy += w >> 16;
       s.yy += (w & 0xffffu) + 1;
-      pk[pos*kPitch + lane] = w + 2;
+      if (owner) pk[local*kPitch + lane] = w + 2;
       s.i++;
     }
   }
   /* Last pulses with the rate term, src/pvq_encoder.c:192-219. */
   const double lambda = __ddiv_rn(pvq_norm_lambda, 1e-30 + g2);
-  double delta_rate = 3./N;
+  double delta_rate = 3./NBAND;
   double accel_rate = 0.;
   if (k == 1) {
-    if (N == 15) {
-      accel_rate = -8./N;
-      delta_rate = 4.5/N - accel_rate;
+    if (NBAND == 15) {
+      accel_rate = -8./NBAND;
+      delta_rate = 4.5/NBAND - accel_rate;
     }
-    else if (N == 8) {
-      accel_rate = 5.7/N;
-      delta_rate = 9.3/N - accel_rate;
+    else if (NBAND == 8) {
+      accel_rate = 5.7/NBAND;
+      delta_rate = 9.3/NBAND - accel_rate;
     }
   }
   while (__any(on && s.i < k)) {
     const bool step = on && s.i < k;
     int pos = 0;
+    double best = 0;
     /* Largest table index any candidate of this pulse can use: yy + 2*y + 1
        with y <= i < k. */
     if (!__any(step && s.yy + 2*(unsigned)k + 1 > (unsigned)kRsqN)) {
       const unsigned base = step ? s.yy : 0;   /* table slot of index yy + 1 */
       const unsigned xy = step ? s.xy : 0;
-      if ((N == 8 || N == 15) && __any(step && k == 1)) {
+      if ((NBAND == 8 || NBAND == 15) && __any(step && k == 1)) {
         pos = od_lane_rdo_scan<N, true>(pk, rsq, lane, xy, base, s.norm2, lambda, delta_rate,
-         accel_rate);
+         accel_rate, jbase, best);
       }
       else {
         pos = od_lane_rdo_scan<N, false>(pk, rsq, lane, xy, base, s.norm2, lambda, delta_rate,
-         accel_rate);
+         accel_rate, jbase, best);
       }
     }
     else {
-      double best = 0;
+      /* rare (an index beyond the table): not unrolled, it must not set the
+         register budget of the kernel */
+#pragma unroll 1
       for (int j = 0; j < N; j++) {
         const uint32_t w = pk[j*kPitch + lane];
         const double t = (double)(s.xy + (w >> 16));
@@ -344,18 +480,36 @@ __device__ __forceinline__ double od_lane_search(LaneSearch &s, uint32_t *pk, co
         double r;
         if (step && idx <= (unsigned)kRsqN) r = rsq[idx - 1];
         else r = __ddiv_rn(1., __dsqrt_rn((double)idx));
-        const double val = (t*s.norm2)*r - (lambda*j)*(delta_rate + j*accel_rate);
+        const int jg = jbase + j;
+        const double val = (t*s.norm2)*r - (lambda*jg)*(delta_rate + jg*accel_rate);
         if (j == 0 || val > best) {
           best = val;
-          pos = j;
+          pos = jg;
         }
       }
     }
+    if (S == 2) {
+      const double ob = od_pair_swap(best);
+      const int op = od_pair_swap(pos);
+      const double va = half ? ob : best;   /* lower half */
+      const double vb = half ? best : ob;   /* upper half */
+      const int pa = half ? op : pos;
+      const int pb = half ? pos : op;
+      pos = vb > va ? pb : pa;
+    }
+    int owner = 1;
+    int local = pos;
+    if (S == 2) {
+      owner = (pos >= N) == (half != 0);
+      local = pos - jbase;
+    }
+    uint32_t w = 0;
+    if (step && owner) w = pk[local*kPitch + lane];
+    if (S == 2) w |= od_pair_swap(w);
     if (step) {
-      const uint32_t w = pk[pos*kPitch + lane];
       s.xy += w >> 16;
       s.yy += (w & 0xffffu) + 1;
-      pk[pos*kPitch + lane] = w + 2;
+      if (owner) pk[local*kPitch + lane] = w + 2;
       s.i++;
     }
   }
