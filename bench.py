@@ -149,10 +149,11 @@ def algorithmic_bytes(F):
     luma_px = F * W * H
     chroma_px = 2 * F * (W // 2) * (H // 2)
     # PVQ band stage, per band of n coefficients: 4n B coefficients in, two
-    # candidates x 4n B pulses + 64 B scalars out (2n + 4n +
-    # 32 B for the bare search); choice + synthesis: 4n B pulses in, 4n B
-    # dequantised coefficients out + 64 B scalars.  All nine (plane set, level)
-    # jobs of a step run in one multi-job launch group.
+    # candidates x 2n B signed pulses (int16) + one 64 B band record out
+    # (2n + 4n + 32 B for the bare search).  The x16 scratch
+    # (2n B written by the preparation pass, read by the search) and the sort
+    # keys / indices are implementation traffic, not counted.  All nine (plane
+    # set, level) jobs of a step run in one multi-job launch group.
     nbands = [1, 4, 7, 9, 9]
     coded = [15, 63, 255, 511, 511]
     bands_b = 0
@@ -160,7 +161,7 @@ def algorithmic_bytes(F):
     for (w, h, planes, top) in ((W, H, F, 4), (W // 2, H // 2, 2 * F, 3)):
         for bs in range(top + 1):
             nblk = planes * (w // (4 << bs)) * (h // (4 << bs))
-            bands_b += nblk * (12 * coded[bs] + 64 * nbands[bs])
+            bands_b += nblk * (8 * coded[bs] + 64 * nbands[bs])
             synth_b += nblk * (8 * coded[bs] + 64 * nbands[bs])
     return {
         "forward_pyramid_luma": luma_px * 21,      # 1 B read + 5 levels x 4 B written
@@ -258,6 +259,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    D.pvq_profile(True)   # HIP events around the dominant kernel, on its own stream
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -265,6 +267,8 @@ def main():
     torch.cuda.synchronize()
     barrier()
     dt = time.perf_counter() - t0
+    search_ms = D.pvq_profile_read()
+    D.pvq_profile(False)
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -284,16 +288,31 @@ def main():
                 ent["achieved_GBs"] = round(ab[key] / (ms * 1e-3) / 1e9, 1)
                 ent["frac_of_hbm_peak"] = round(ent["achieved_GBs"] / HBM_PEAK_GBS, 4)
             kernels[key] = ent
-        # roofline = the kernel class that takes the largest share of the step.
-        dom = max(kernels, key=lambda k_: kernels[k_]["share_of_step"])
-        roof = {"kernel": dom, "bound": "hbm",
-                "achieved": kernels[dom]["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": kernels[dom]["frac_of_hbm_peak"], "traffic": None,
-                "algorithmic_bytes_per_launch": ab[dom]}
+        # roofline = the single kernel with the largest share of the step: the
+        # search of the 128-coefficient PVQ bands.  Its duration is measured by
+        # the library with HIP events on the stream the kernel is launched on
+        # (odhip_pvq_profile); the rocprofv3 summary under profiles/ shows the same
+        # kernel.  Algorithmic bytes per band: 2n B x16 in + 32 B record head in,
+        # 2 x 2n B pulses + 32 B record tail out = 6n + 64 = 832 B.
+        n128 = 0
+        for (w, h, planes, top) in ((W, H, args.frames, 4), (W // 2, H // 2, 2 * args.frames, 3)):
+            for bs in range(top + 1):
+                n128 += planes * (w // (4 << bs)) * (h // (4 << bs)) * [0, 0, 1, 3, 3][bs]
+        s_ms = float(np.mean(search_ms)) if search_ms else float("nan")
+        s_bytes = n128 * (6 * 128 + 64)
+        roof = {"kernel": "k_search<128,2,1> (PVQ search of the 128-coefficient bands)",
+                "bound": "hbm", "achieved": round(s_bytes / (s_ms * 1e-3) / 1e9, 1),
+                "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(s_bytes / (s_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+                "avg_ms_per_launch": round(s_ms, 4), "launches": len(search_ms),
+                "share_of_step": round(s_ms / (dt / args.steps * 1e3), 4),
+                "algorithmic_bytes_per_launch": s_bytes, "bands_per_launch": n128}
         fd = kernels["forward_pyramid_luma"]
-        roof["note"] = ("largest share of the step; the PVQ band stage is fp64-VALU/latency bound "
-                        "(arithmetic intensity ~ the fp64 ridge), HBM is quoted because SURVEY 8(d) "
-                        "prices it against HBM; see roofline_filter_dct for the stage the north star "
+        roof["note"] = ("largest single kernel of the step; it overlaps with the other band-size "
+                        "searches on forked streams, so its share is of wall time, not exclusive. "
+                        "The K-pulse search is fp64 VALU-issue bound (13 VALU instructions per "
+                        "candidate per pulse, DESIGN.md), HBM is quoted because SURVEY 8(d) prices "
+                        "it against HBM; see roofline_filter_dct for the stage the north star "
                         "prices at >= 60 % of HBM")
         roof_fd = {"kernel": "k_forward_pyramid64x2 (forward_pyramid_luma)", "bound": "hbm",
                    "achieved": fd["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",

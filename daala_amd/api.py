@@ -215,6 +215,20 @@ class _Job(ctypes.Structure):
                 ("d_qg", ctypes.c_void_p)]
 
 
+def pvq_profile(enable):
+    """Bracket the band stage's dominant kernel with HIP events (see daala_hip.h)."""
+    _check(lib().odhip_pvq_profile(int(bool(enable))), "odhip_pvq_profile")
+
+
+def pvq_profile_read(max_n=256):
+    """Milliseconds of every bracketed launch since the last read."""
+    buf = (ctypes.c_float * max_n)()
+    n = lib().odhip_pvq_profile_read(buf, max_n)
+    if n < 0:
+        raise DaalaHipError("odhip_pvq_profile_read failed with code %d" % n)
+    return [buf[i] for i in range(n)]
+
+
 def pvq_band_layout(bs):
     """(nb_bands, offsets[nb_bands + 1], len) for block size 4 << bs."""
     nb = ctypes.c_int()

@@ -656,7 +656,7 @@ __global__ __launch_bounds__(kWave, (S == 2 ? 2 : 1)) void k_search(Items it) {
       const double g2 = (qcg*(double)cg)*s2;
       const bool fresh = !(prev_k > 0 && prev_k <= k);
       const double cos_dist = od_lane_search<NL, S>(st, pk, rsq, lane, half, on, fresh, k, g2,
-       it.lambda);
+       it.lambda, it.reserved != 0);
       /* src/pvq_encoder.c:586,:593-595; a slot that is not in use has distortion 0 */
       int yyc = 0;
       double distc = gain ? ((1.4*(qcg - cg))*(qcg - cg))*s2 : 0.;
@@ -989,6 +989,8 @@ int join_streams(hipStream_t s, hipStream_t side[2]) {
 void items_begin(Items &it, double lambda) {
   memset(&it, 0, sizeof(it));
   it.lambda = lambda;
+  const char *e = getenv("ODHIP_PVQ_FORCE_SEQ");
+  it.reserved = e && e[0] == '1';   /* pair-mode search: always take the sequential combine */
 }
 
 void items_add(Items &it, int job, int band, long wgs) {
@@ -998,6 +1000,14 @@ void items_add(Items &it, int job, int band, long wgs) {
   it.wg_start[it.nitems + 1] = it.wg_start[it.nitems] + (int)wgs;
   it.nitems++;
 }
+
+/* Profiling aid (odhip_pvq_profile): HIP events around the dominant kernel of
+   the band stage, on the stream it is launched on. */
+constexpr int kProfSlots = 256;
+bool g_prof_on = false;
+int g_prof_n = 0;
+hipEvent_t g_prof_ev[kProfSlots][2];
+bool g_prof_made = false;
 
 template <int N, int S, int NB>
 void launch_search(const DJob *host, int njobs, double lambda, hipStream_t s) {
@@ -1013,10 +1023,36 @@ void launch_search(const DJob *host, int njobs, double lambda, hipStream_t s) {
   }
   if (!it.nitems) return;
   constexpr size_t lds = kRsqN*sizeof(double) + (size_t)(N/S)*kPitch*4;
+  const bool prof = N == 128 && g_prof_on && g_prof_n < kProfSlots;
+  if (prof) (void)hipEventRecord(g_prof_ev[g_prof_n][0], s);
   k_search<N, S, NB><<<it.wg_start[it.nitems], kWave, lds, s>>>(it);
+  if (prof) (void)hipEventRecord(g_prof_ev[g_prof_n++][1], s);
 }
 
 }  // namespace
+
+extern "C" int odhip_pvq_profile(int enable) {
+  if (enable && !g_prof_made) {
+    for (int i = 0; i < kProfSlots; i++) {
+      ODHIP_TRY(hipEventCreate(&g_prof_ev[i][0]));
+      ODHIP_TRY(hipEventCreate(&g_prof_ev[i][1]));
+    }
+    g_prof_made = true;
+  }
+  g_prof_on = enable != 0;
+  g_prof_n = 0;
+  return ODHIP_SUCCESS;
+}
+
+extern "C" int odhip_pvq_profile_read(float *ms, int max_n) {
+  int n = 0;
+  for (; n < g_prof_n && n < max_n; n++) {
+    ODHIP_TRY(hipEventSynchronize(g_prof_ev[n][1]));
+    ODHIP_TRY(hipEventElapsedTime(&ms[n], g_prof_ev[n][0], g_prof_ev[n][1]));
+  }
+  g_prof_n = 0;
+  return n;
+}
 
 extern "C" int odhip_pvq_band_layout(int bs, int *nb_bands, int *offsets, int *len) {
   if (bs < 0 || bs >= ODHIP_NBSIZES) return ODHIP_EINVAL;

@@ -341,10 +341,12 @@ __device__ __forceinline__ int od_lane_greedy_scan(const uint32_t *pk, int lane,
        best beats lower half's best, else lower" is what the sequential scan
        ends on.  Otherwise (never seen with 8-bit video; the bound is checked
        every pulse) the upper lane rescans its half starting from the lower
-       lane's best, which is the sequential scan literally. */
+       lane's best, which is the sequential scan literally
+       (ODHIP_PVQ_FORCE_SEQ=1 forces that path: tests run both). */
 template <int N, int S>
 __device__ __forceinline__ double od_lane_search(LaneSearch &s, uint32_t *pk, const double *rsq,
- int lane, int half, bool on, bool fresh, int k, double g2, double pvq_norm_lambda) {
+ int lane, int half, bool on, bool fresh, int k, double g2, double pvq_norm_lambda,
+ bool force_seq) {
   constexpr int NBAND = N*S;
   const int jbase = S == 2 ? half*N : 0;
   fresh = fresh && on;
@@ -397,7 +399,8 @@ __device__ __forceinline__ double od_lane_search(LaneSearch &s, uint32_t *pk, co
       double xb = half ? bb : ob;
       int xp = half ? pos : op;
       const double tmax = (double)(s.xy + s.xmax);
-      const bool exact = (tmax*tmax)*(double)(s.yy + 2*(unsigned)k + 1) < 4503599627370496.;   /* 2^52: a factor 2 of margin for the bound's own rounding */
+      const bool exact = !force_seq
+       && (tmax*tmax)*(double)(s.yy + 2*(unsigned)k + 1) < 4503599627370496.;   /* 2^52: a factor 2 of margin for the bound's own rounding */
       if (__any(step && !exact)) {
         /* sequential: the upper lane rescans from the lower half's best */
         double ra = aa;

@@ -1,9 +1,8 @@
-/* pvq_search.cuh - the two mappings of pvq_search_rdo_double (reference
-   src/pvq_encoder.c:93-224) onto a wavefront, shared by the raw batched search
-   (pvq_kernels.hip) and the PVQ band stage (pvq_bands.hip):
-
-     od_pvq_search_lane  one band per lane, |x| and y in LDS  (short bands)
-     od_pvq_search_row   one band per 16-lane DPP row         (n = 32, 128)
+/* pvq_search.cuh - pvq_search_rdo_double (reference src/pvq_encoder.c:93-224)
+   with one band per lane, |x| and y in LDS, for an arbitrary band size n: the
+   raw batched search (pvq_kernels.hip: odhip_pvq_search_batch and the per-call
+   od_pvq_search_rdo_double_hip).  The PVQ band stage (pvq_bands.hip) uses the
+   engineered form of the same mapping in pvq_lane.cuh.
 
    Every floating-point operation is a single IEEE-754 binary64 operation in
    the reference's order; translation units including this header MUST be
@@ -40,7 +39,7 @@ __device__ __forceinline__ double od_rsqrt_table(int i) {
   return __ddiv_rn(1., __dsqrt_rn((double)i));
 }
 
-#include "pvq_wide.cuh"
+#include "od_dpp.cuh"
 
 /* One band per lane: the K-pulse search proper.  xs holds the band's SIGNED
    x (int16) and ys the pulse magnitudes, both laid out [j][64 lanes].  On

@@ -255,6 +255,15 @@ int odhip_pvq_choose_multi(const odhip_pvq_job *jobs, int njobs,
 int odhip_inverse_level_pvq(uint8_t *d_px, int px_stride, long px_plane_stride,
  const odhip_pvq_job *job, int dec, int pic_w, int pic_h, odhip_stream stream);
 
+/* Profiling aid (bench.py): while enabled, odhip_pvq_noref_bands_multi brackets
+   its dominant kernel - the search of the 128-coefficient bands,
+   k_search<128,2,1> - with HIP events on the stream the kernel is launched on
+   (up to 256 calls are kept).  odhip_pvq_profile_read waits for the recorded
+   events, writes one duration in milliseconds per call to ms[] and returns how
+   many (or a negative ODHIP_E* code), then starts over. */
+int odhip_pvq_profile(int enable);
+int odhip_pvq_profile_read(float *ms, int max_n);
+
 /* nb_bands, offsets[nb_bands+1] and len for block size bs. */
 int odhip_pvq_band_layout(int bs, int *nb_bands, int *offsets, int *len);
 

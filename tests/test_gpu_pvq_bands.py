@@ -178,3 +178,32 @@ def test_inverse_from_pvq_equals_synth_then_inverse(hip, dec):
                 job.rate = None
                 hip.pvq_choose_multi([job], hip.OD_PVQ_LAMBDA)
                 assert not torch.equal(job.cands["choice"][..., 1], qg_a) or bs == 4
+
+
+def test_pair_search_sequential_combine_equals_exact_combine(hip, monkeypatch):
+    """The 128-coefficient band is searched by two lanes per band; the halves of
+    the greedy argmax are combined by an exact-arithmetic argument, with a
+    literal sequential rescan when its bound does not hold.
+    ODHIP_PVQ_FORCE_SEQ=1 forces the rescan: both must give the same records
+    and pulses (the default path is checked against the oracle above)."""
+    import torch
+    W, H = 256, 192
+    planes = synth_frame(W, H, seed=33)
+    rng = np.random.RandomState(9)
+    src = np.clip(planes[0].astype(int) + rng.randint(-90, 91, size=planes[0].shape), 0, 255)
+    px = _cuda(src.astype(np.uint8)[None])
+    levels = hip.forward_pyramid(px, 0, W, H)
+    qt = hip.QuantTables.load()
+    for bs in (2, 3, 4):
+        qm, _ = qt.qm_slices(0, bs)
+        outs = []
+        for force in ("0", "1"):
+            monkeypatch.setenv("ODHIP_PVQ_FORCE_SEQ", force)
+            job = hip.PvqJob(levels[bs], bs, _cuda(qm), None, qt.q_band(0, bs), qt.beta_band(0, bs))
+            hip.pvq_noref_bands_multi([job], hip.OD_PVQ_LAMBDA)
+            torch.cuda.synchronize()
+            outs.append((job.cands["band"].clone(), job.cands["y"].clone()))
+        assert torch.equal(outs[0][0], outs[1][0]), bs
+        assert torch.equal(outs[0][1], outs[1][1]), bs
+        k = hip.unpack_cands({"band": outs[0][0], "y": outs[0][1], "choice": outs[0][1]})["k"]
+        assert k.max() > 8   # multi-pulse searches did run
