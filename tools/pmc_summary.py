@@ -20,8 +20,35 @@ def short(name):
     return re.sub(r"\(.*$", "", name)
 
 
+def trace_table(root, sub, title):
+    dur = collections.defaultdict(list)
+    grid = {}
+    try:
+        f = open(root + "/" + sub + "/t_kernel_trace.csv")
+    except FileNotFoundError:
+        return
+    with f:
+        for r in csv.DictReader(f):
+            n = short(r["Kernel_Name"])
+            if not n.startswith("k_"):
+                continue
+            key = (n, r["Grid_Size_X"], r["Grid_Size_Y"], r["Grid_Size_Z"]) if "Grid_Size_X" in r else (n, r.get("Grid_Size", ""), "", "")
+            dur[key].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+            grid[key] = (r.get("Workgroup_Size_X", r.get("Workgroup_Size", "")), r.get("LDS_Block_Size", ""), r.get("VGPR_Count", ""))
+    print(title)
+    print("%-28s %-18s %5s %6s %5s %6s %10s %10s" % ("kernel", "grid", "wg", "lds", "vgpr", "calls", "avg_us", "min_us"))
+    tot = sum(sum(v) for v in dur.values())
+    for k, v in sorted(dur.items(), key=lambda kv: -sum(kv[1])):
+        g = grid[k]
+        print("%-28s %-18s %5s %6s %5s %6d %10.1f %10.1f  %5.1f%%" % (
+            k[0], ",".join(x for x in k[1:] if x), g[0], g[1], g[2], len(v), sum(v) / len(v) / 1e3,
+            min(v) / 1e3, 100.0 * sum(v) / tot))
+    print()
+
+
 def main():
     root = sys.argv[1]
+    trace_table(root, "trace_serial", "# kernel trace, ODHIP_PVQ_SERIAL=1 (one stream: exclusive durations), our kernels only")
     dur = collections.defaultdict(list)
     grid = {}
     with open(root + "/trace/t_kernel_trace.csv") as f:
@@ -33,7 +60,7 @@ def main():
             dur[key].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
             grid[key] = (r.get("Workgroup_Size_X", r.get("Workgroup_Size", "")), r.get("LDS_Block_Size", ""), r.get("VGPR_Count", ""))
     ctr = collections.defaultdict(lambda: collections.defaultdict(list))
-    for sub in ("pmc_fetch", "pmc_write", "pmc_sq"):
+    for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_wait"):
         try:
             with open(root + "/" + sub + "/t_counter_collection.csv") as f:
                 for r in csv.DictReader(f):
@@ -43,7 +70,8 @@ def main():
                     ctr[(n, r["Grid_Size"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
         except FileNotFoundError:
             pass
-    print("# kernel trace (rocprofv3 --kernel-trace --stats), our kernels only")
+    print("# kernel trace (rocprofv3 --kernel-trace --stats) of the default bench command: the band-stage")
+    print("# kernels overlap on forked streams, durations include the time they share the GPU")
     print("%-28s %-18s %5s %6s %5s %6s %10s %10s" % ("kernel", "grid", "wg", "lds", "vgpr", "calls", "avg_us", "min_us"))
     tot = sum(sum(v) for v in dur.values())
     for k, v in sorted(dur.items(), key=lambda kv: -sum(kv[1])):
@@ -52,9 +80,10 @@ def main():
             k[0], ",".join(x for x in k[1:] if x), g[0], g[1], g[2], len(v), sum(v) / len(v) / 1e3,
             min(v) / 1e3, 100.0 * sum(v) / tot))
     print()
-    print("# PMC counters, average per launch (separate passes: FETCH_SIZE | WRITE_SIZE | SQ_*)")
+    print("# PMC counters, average per launch, ODHIP_PVQ_SERIAL=1 (separate passes: FETCH_SIZE | WRITE_SIZE | SQ_* | SQ_WAIT_*)")
     names = ["FETCH_SIZE", "WRITE_SIZE", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "SQ_INSTS_VALU",
-             "SQ_INSTS_LDS", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_INST_LDS", "SQ_ACTIVE_INST_VALU"]
+             "SQ_INSTS_LDS", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_INST_LDS", "SQ_ACTIVE_INST_VALU",
+             "SQ_WAIT_ANY", "SQ_WAVES"]
     print("%-28s %-10s " % ("kernel", "grid") + " ".join("%14s" % n[-14:] for n in names)
           + " %12s %9s" % ("HBM_est_MB", "bankconf%"))
     for k, c in sorted(ctr.items()):
