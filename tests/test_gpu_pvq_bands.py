@@ -207,3 +207,29 @@ def test_pair_search_sequential_combine_equals_exact_combine(hip, monkeypatch):
         assert torch.equal(outs[0][1], outs[1][1]), bs
         k = hip.unpack_cands({"band": outs[0][0], "y": outs[0][1], "choice": outs[0][1]})["k"]
         assert k.max() > 8   # multi-pulse searches did run
+
+
+def test_pulse_count_above_layout_limit_is_reported_not_searched(hip):
+    """A band whose K exceeds ODHIP_PVQ_MAX_K (32767; only reachable with absurd
+    quantisers) must come back as flags == 2 with k saturated, must not be
+    searched (no hang: K pulses x n candidates would run for minutes) and must
+    never be chosen."""
+    import torch
+    rng = np.random.RandomState(3)
+    coef = (rng.randint(-(1 << 19), 1 << 19, size=(1, 64, 64))).astype(np.int32)
+    qt = hip.QuantTables.load()
+    qm, qmi = qt.qm_slices(0, 0)
+    tc = _cuda(coef)
+    job = hip.PvqJob(tc, 0, _cuda(qm), _cuda(qmi), [1], [4096], dq=torch.empty_like(tc))
+    hip.pvq_noref_bands_multi([job], hip.OD_PVQ_LAMBDA)
+    hip.pvq_choose_multi([job], hip.OD_PVQ_LAMBDA)
+    torch.cuda.synchronize()
+    c = hip.unpack_cands(job.cands)
+    over = c["flags"] == 2
+    assert over.any()
+    assert (c["k"][over] == 32767).all()
+    qg = c["choice"][..., 1]
+    for slot in range(2):
+        bad = over[..., slot] & (qg == c["gain"][..., slot]) & (qg != 0)
+        assert not bad.any()
+    assert (c["yy"][over] == 0).all()
