@@ -215,6 +215,65 @@ class _Job(ctypes.Structure):
                 ("d_qg", ctypes.c_void_p)]
 
 
+# ---- with-reference (theta / Householder) building blocks -------------------------
+REFPREP_RECORD = np.dtype([("xshift", "<i4"), ("rshift", "<i4"), ("g", "<i4"), ("gr", "<i4"),
+                           ("cg", "<i4"), ("cgr", "<i4"), ("icgr", "<i4"), ("gain_offset", "<i4"),
+                           ("m", "<i4"), ("s", "<i4"), ("r_null", "<i4"), ("reserved", "<i4"),
+                           ("corr", "<f8"), ("reserved2", "<f8")])
+REFCAND_RECORD = np.dtype([("gain", "<i4"), ("theta", "<i4"), ("ts", "<i4"), ("k", "<i4"),
+                           ("qcg", "<i4"), ("qtheta", "<i4")])
+MAX_REFCANDS = 24
+assert REFPREP_RECORD.itemsize == 64 and REFCAND_RECORD.itemsize == 24
+
+
+def pvq_ref_prepare(x0, r0, qm, q0, beta, cfl_enabled):
+    """x0, r0: int32 [nbands, n] CUDA; qm int16 [n].  Returns (x16, r16, xr, prep)
+    with prep a uint8 [nbands, 64] tensor of odhip_pvq_refprep records."""
+    import torch
+    _need(x0, torch.int32, "x0")
+    _need(r0, torch.int32, "r0")
+    _need(qm, torch.int16, "qm")
+    nbands, n = x0.shape
+    dev = x0.device
+    x16 = torch.empty((nbands, n), dtype=torch.int16, device=dev)
+    r16 = torch.empty((nbands, n), dtype=torch.int16, device=dev)
+    xr = torch.empty((nbands, n - 1), dtype=torch.int16, device=dev)
+    prep = torch.empty((nbands, 64), dtype=torch.uint8, device=dev)
+    _check(lib().odhip_pvq_ref_prepare(_p(x0), _p(r0), int(n), ctypes.c_long(nbands), _p(qm),
+                                       int(q0), int(beta), int(bool(cfl_enabled)), _p(x16), _p(r16),
+                                       _p(xr), _p(prep), _stream()), "odhip_pvq_ref_prepare")
+    return x16, r16, xr, prep
+
+
+def pvq_ref_candidates(prep, theta, n, beta):
+    """theta: int32 [nbands] = floor(.5 + OD_THETA_SCALE*acos(corr)) from the host.
+    Returns (items uint8 [nbands, 24, 24] of odhip_pvq_refcand, nitems int32 [nbands])."""
+    import torch
+    _need(theta, torch.int32, "theta")
+    nbands = prep.shape[0]
+    items = torch.zeros((nbands, MAX_REFCANDS, 24), dtype=torch.uint8, device=prep.device)
+    nitems = torch.empty(nbands, dtype=torch.int32, device=prep.device)
+    _check(lib().odhip_pvq_ref_candidates(_p(prep), _p(theta), int(n), ctypes.c_long(nbands),
+                                          int(beta), _p(items), _p(nitems), _stream()),
+           "odhip_pvq_ref_candidates")
+    return items, nitems
+
+
+def pvq_synthesis(y, r16, params, qm_inv):
+    """od_pvq_synthesis_partial per band.  y int32 [nbands, n], r16 int16 [nbands, n],
+    params int32 [nbands, 5] = (noref, g, theta, m, s), qm_inv int16 [n]."""
+    import torch
+    _need(y, torch.int32, "y")
+    _need(r16, torch.int16, "r16")
+    _need(params, torch.int32, "params")
+    _need(qm_inv, torch.int16, "qm_inv")
+    nbands, n = y.shape
+    out = torch.empty_like(y)
+    _check(lib().odhip_pvq_synthesis(_p(out), _p(y), _p(r16), int(n), ctypes.c_long(nbands),
+                                     _p(params), _p(qm_inv), _stream()), "odhip_pvq_synthesis")
+    return out
+
+
 def pvq_profile(enable):
     """Bracket the band stage's dominant kernel with HIP events (see daala_hip.h)."""
     _check(lib().odhip_pvq_profile(int(bool(enable))), "odhip_pvq_profile")

@@ -165,3 +165,68 @@ __device__ __forceinline__ int odq_compute_k_noref(int32_t qcg, int n, int beta)
    *odq_mult16_16_qbeta(odq_beta_rcp((int16_t)beta), rt), ODQ_CGAIN_SHIFT + 10);
   return v > 1 ? v : 1;
 }
+
+/* ---- with-reference (theta / Householder) arithmetic --------------------------- */
+
+__device__ __forceinline__ int32_t odq_mult16_16(int32_t a, int32_t b) { /* OD_MULT16_16 */
+  return (int32_t)(int16_t)a*(int32_t)(int16_t)b;
+}
+
+__device__ __forceinline__ int32_t odq_mult16_16_q16(int32_t a, int32_t b) {
+  return ((int16_t)a*(int32_t)(int16_t)b) >> 16;
+}
+
+__device__ __forceinline__ int64_t odq_mult16_32_q16(int32_t a, int32_t b) {
+  return (int16_t)a*(int64_t)b >> 16;
+}
+
+/* od_pvq_cos_pi_2, src/pvq.c:417-423. */
+__device__ __forceinline__ int16_t odq_cos_pi_2(int16_t x) {
+  const int16_t x2 = (int16_t)odq_mult16_16_q15(x, x);
+  const int32_t v = (1073758164 - x*x + x2*(-7654 + odq_mult16_16_q16(x2, 16573
+   + odq_mult16_16_q16(-2529, x2)))) >> 15;
+  return (int16_t)(v < 32767 ? v : 32767);
+}
+
+/* od_pvq_cos, src/pvq.c:428-457 (angle in units of pi/2 / 2^15). */
+__device__ __forceinline__ int odq_pvq_cos(int32_t x) {
+  x &= 0x1ffff;
+  if (x > (1 << 16)) x = (1 << 17) - x;
+  if (x & 0x7fff) {
+    if (x < (1 << 15)) return odq_cos_pi_2((int16_t)x);
+    return (int16_t)-odq_cos_pi_2((int16_t)(65536 - x));
+  }
+  if (x & 0xffff) return 0;
+  if (x & 0x1ffff) return -32767;
+  return 32767;
+}
+
+/* od_pvq_sin, src/pvq.c:461-467. */
+__device__ __forceinline__ int odq_pvq_sin(int32_t x) {
+  return odq_pvq_cos(32768 - x);
+}
+
+/* od_pvq_compute_max_theta, src/pvq.c:855-865. */
+__device__ __forceinline__ int odq_pvq_compute_max_theta(int32_t qcg, int beta) {
+  int ts = odq_shr_round(qcg*odq_mult16_16_qbeta(402, odq_beta_rcp((int16_t)beta)),
+   2*ODQ_CGAIN_SHIFT);
+  if (qcg < 358) ts = 1;
+  return ts;
+}
+
+/* od_pvq_compute_theta, src/pvq.c:874-884 (C truncating division). */
+__device__ __forceinline__ int32_t odq_pvq_compute_theta(int t, int max_theta) {
+  if (max_theta == 0) return 0;
+  return (32768*(t < max_theta - 1 ? t : max_theta - 1) + (max_theta >> 1))/max_theta;
+}
+
+/* od_pvq_compute_k with a reference, nodesync (all-integer) branch,
+   src/pvq.c:941-953; od_sqrt_table[0][OD_ILOG(n + 1)]. */
+__device__ __forceinline__ int odq_compute_k_ref(int itheta, int n) {
+  if (itheta == 0) return 0;
+  const int il = odq_ilog(n + 1);
+  const int rt = il == 4 ? 2290 : il == 5 ? 2985 : il == 6 ? 4222 : il == 8 ? 8256
+   : il == 10 ? 16416 : il == 12 ? 32767 : 0;
+  const int32_t v = odq_vshr_round((odq_shl32(itheta, 15) - 6554)*(int64_t)rt, 10 + 15);
+  return v > 1 ? v : 1;
+}

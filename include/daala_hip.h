@@ -288,6 +288,60 @@ int odhip_pvq_select_synth_noref(od_coeff *d_dq, const od_coeff *d_coef,
  const odhip_pvq_cands *in, const double *d_rate, int32_t *d_qg_out,
  odhip_stream stream);
 
+/* ---- with-reference (theta / Householder) path: data-parallel pieces -----------
+
+   pvq_theta with a reference vector r (inter frames, chroma-from-luma;
+   src/pvq_encoder.c:381-565) around its one libm call, acos(corr) (:478), which
+   is not reproducible bit for bit on the device and stays on the host, as does
+   od_pvq_rate (adaptive entropy coder).  All vectors are plain band vectors
+   [band][n] in coding order, device memory; n <= 128 (OD_MAX_PVQ_SIZE).
+
+   odhip_pvq_ref_prepare    :381-438 and the Householder reflection
+                            (od_compute_householder / od_apply_householder,
+                            src/pvq.c:498-623): x16, r16 (r16[m] updated as the
+                            reference does when the reflection is computed, i.e.
+                            when r != 0 and corr > 0), the reflected x without
+                            element m in d_xr [band][n-1], and one record per
+                            band.  q0 = per-band quantiser, beta = OD_PVQ_BETA
+                            entry (Q12), cfl_enabled as at :410.
+   odhip_pvq_ref_candidates :466-504 given d_theta[band] =
+                            floor(.5 + OD_THETA_SCALE*acos(corr)) from the host:
+                            the (gain, theta) candidates with their K
+                            (od_pvq_compute_max_theta, od_pvq_compute_theta,
+                            od_pvq_compute_k nodesync branch, src/pvq.c:855-953)
+                            in the reference's stable (k, gain) order; up to
+                            ODHIP_PVQ_MAX_REFCANDS per band.
+   odhip_pvq_synthesis      od_pvq_synthesis_partial (src/pvq.c:1037-1115) of a
+                            chosen candidate; d_params[band] = {noref, g
+                            (od_gain_expand result), theta (Q15 angle), m, s};
+                            d_y holds n pulses (n-1 used when noref == 0).
+
+   The K-pulse searches of the candidates are odhip_pvq_search_batch on d_xr. */
+typedef struct {
+  int32_t xshift, rshift;
+  int32_t g, gr;          /* raw gains (od_pvq_compute_gain *g)                 */
+  int32_t cg, cgr;        /* companded gains, Q8 (cgr = 256 when cfl_enabled)   */
+  int32_t icgr, gain_offset;
+  int32_t m, s;           /* Householder pivot and sign (0, 1 when not computed) */
+  int32_t r_null;         /* 1 = the reference vector is all zero                */
+  int32_t reserved;
+  double corr;            /* clamped correlation, :436-438                       */
+  double reserved2;
+} odhip_pvq_refprep;      /* 64 bytes */
+
+#define ODHIP_PVQ_MAX_REFCANDS 24
+typedef struct {
+  int32_t gain, theta, ts, k, qcg, qtheta;
+} odhip_pvq_refcand;
+
+int odhip_pvq_ref_prepare(const od_coeff *d_x0, const od_coeff *d_r0, int n, long nbands,
+ const int16_t *d_qm, int q0, int beta, int cfl_enabled, int16_t *d_x16, int16_t *d_r16,
+ int16_t *d_xr, odhip_pvq_refprep *d_out, odhip_stream stream);
+int odhip_pvq_ref_candidates(const odhip_pvq_refprep *d_prep, const int32_t *d_theta, int n,
+ long nbands, int beta, odhip_pvq_refcand *d_items, int32_t *d_nitems, odhip_stream stream);
+int odhip_pvq_synthesis(od_coeff *d_out, const od_coeff *d_y, const int16_t *d_r16, int n,
+ long nbands, const int32_t *d_params, const int16_t *d_qm_inv, odhip_stream stream);
+
 /* ---- frame cache: one batched pyramid serving every per-block fdct_2d call ---
 
    The samples a block of level bs sees in the reference encoder depend only on
