@@ -81,8 +81,9 @@ def synth_frames(nframes, seed, device):
 
 class Pipeline:
     """The GPU step.  All buffers are allocated once; a step only launches
-    kernels: 2 pyramid launches, 3 + 2 multi-job PVQ launches covering all nine
-    (plane set, level) jobs, and 2 inverse launches per job."""
+    kernels: 2 pyramid launches, the multi-job PVQ band stage and choice covering
+    all nine (plane set, level) jobs, and one inverse launch group per plane set
+    (all its levels)."""
 
     def __init__(self, D, nframes, device):
         import torch
@@ -97,7 +98,7 @@ class Pipeline:
         for name, px, dec, pli in (("luma", self.luma, 0, 0), ("chroma", self.chroma, 1, 1)):
             levels = D.forward_pyramid(px, dec, PIC_W, PIC_H)
             s = dict(name=name, px=px, dec=dec, pli=pli, levels=levels, jobs=[],
-                     recon=torch.empty_like(px))
+                     recon=[torch.empty_like(px) for _ in range(5 - dec)])
             for bs in range(5 - dec):
                 qm, qmi = self.qt.qm_slices(pli, bs)
                 job = D.PvqJob(levels[bs], bs, torch.from_numpy(qm).to(device),
@@ -130,10 +131,11 @@ class Pipeline:
                     record)
         self._timed("pvq_choose", lambda: D.pvq_choose_multi(self.jobs, self.lam), record)
         for s in self.sets:
-            for job in s["jobs"]:
-                self._timed("dequant_inverse_" + s["name"],
-                            lambda: D.inverse_level_pvq(job, s["dec"], PIC_W, PIC_H,
-                                                        out=s["recon"]), record)
+            # every level of the plane set in one set of launches, one
+            # reconstruction per level (what a block-size decision compares)
+            self._timed("dequant_inverse_" + s["name"],
+                        lambda: D.inverse_levels_pvq(s["jobs"], s["dec"], PIC_W, PIC_H,
+                                                     outs=s["recon"]), record)
 
     def kernel_ms(self):
         """Average milliseconds per launch group and groups per run, per class."""
@@ -169,8 +171,8 @@ def algorithmic_bytes(F):
         # dequantise-on-load inverse: per level 4 B per CODED coefficient read
         # (all of them below 32x32, 512 per block above) + 1 B/px written; the
         # figure below is the 4 B/px + 1 B/px upper bound of SURVEY 8(d).
-        "dequant_inverse_luma": luma_px * 5,
-        "dequant_inverse_chroma": chroma_px * 5,
+        "dequant_inverse_luma": luma_px * 5 * 5,      # five levels per launch group
+        "dequant_inverse_chroma": chroma_px * 5 * 4,  # four levels
         "pvq_noref_bands": bands_b,    # one multi-job launch group per step
     }
 

@@ -14,6 +14,6 @@ from .api import (DaalaHipError, lib, lib_path, init, fdct2d_batch, idct2d_batch
                   pvq_search_batch, pvq_band_layout, alloc_pvq_cands, unpack_cands, BAND_RECORD,
                   pvq_noref_bands,
                   pvq_select_synth_noref, PvqJob, pvq_noref_bands_multi,
-                  pvq_select_synth_noref_multi, pvq_choose_multi, inverse_level_pvq, pvq_profile, pvq_profile_read, pvq_ref_prepare,
+                  pvq_select_synth_noref_multi, pvq_choose_multi, inverse_level_pvq, inverse_levels_pvq, pvq_profile, pvq_profile_read, pvq_ref_prepare,
                   pvq_ref_candidates, pvq_synthesis, REFPREP_RECORD, REFCAND_RECORD, host)
 from .quant import QuantTables, OD_PVQ_LAMBDA  # noqa: F401

@@ -409,6 +409,21 @@ def inverse_level_pvq(job, dec, pic_w, pic_h, out=None):
     return out
 
 
+def inverse_levels_pvq(jobs, dec, pic_w, pic_h, outs=None):
+    """inverse_level_pvq for several levels of one plane set in one set of launches;
+    returns the list of reconstructed uint8 [nplanes, h, w] tensors."""
+    import torch
+    nplanes, h, w = jobs[0].coef.shape
+    if outs is None:
+        outs = [torch.empty((nplanes, h, w), dtype=torch.uint8, device=jobs[0].coef.device)
+                for _ in jobs]
+    ptrs = (ctypes.c_void_p * len(jobs))(*[o.data_ptr() for o in outs])
+    _check(lib().odhip_inverse_levels_pvq(ptrs, w, ctypes.c_long(h * w), _jobs_array(jobs),
+                                          len(jobs), int(dec), int(pic_w), int(pic_h), _stream()),
+           "odhip_inverse_levels_pvq")
+    return outs
+
+
 def pvq_noref_bands(coef, bs, qm, q_band, beta_band, pvq_norm_lambda, out=None, cos_dist=False):
     if out is None and cos_dist:
         nplanes, h, w = coef.shape

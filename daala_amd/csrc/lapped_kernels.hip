@@ -547,6 +547,16 @@ struct InverseArgs {
   int nb_bands;
 };
 
+/* Several partition levels of one plane set in ONE launch (blockIdx.z = level *
+   nplanes + plane): five back-to-back launches of 4080 workgroups each leave a
+   partially filled last round per launch, and the two edge kernels per level
+   (a few microseconds of work) cost a launch each. */
+constexpr int kMaxInvLevels = 5;
+struct InverseArgsMulti {
+  InverseArgs a[kMaxInvLevels];
+  int nplanes;
+};
+
 __device__ unsigned short gInvScanXY[OD_SCAN_LEN];  /* y << 8 | x of coding index j */
 __device__ unsigned char gInvBandOf[OD_SCAN_LEN];
 
@@ -580,7 +590,7 @@ __device__ __forceinline__ void inverse_leaf(int *t, int tid) {
 }
 
 template <int TILE>
-__global__ __launch_bounds__(Geo<TILE>::kNT) void k_inverse_sb(InverseArgs a) {
+__global__ __launch_bounds__(Geo<TILE>::kNT) void k_inverse_sb(InverseArgsMulti mm) {
   using G = Geo<TILE>;
   constexpr int P = G::kPitch;
   constexpr int NT = G::kNT;
@@ -588,7 +598,9 @@ __global__ __launch_bounds__(Geo<TILE>::kNT) void k_inverse_sb(InverseArgs a) {
   const int tid = threadIdx.x;
   const int x0 = blockIdx.x*TILE;
   const int y0 = blockIdx.y*TILE;
-  const long plane_off = (long)blockIdx.z*a.w*a.h;
+  const int plane = blockIdx.z % mm.nplanes;
+  const InverseArgs &a = mm.a[blockIdx.z / mm.nplanes];
+  const long plane_off = (long)plane*a.w*a.h;
   if (a.y) {
     /* Dequantise on load: x = y*scale (Q16, no rounding), out = SHR_ROUND(x *
        qm_inv, qshift) (od_pvq_synthesis_partial noref, src/pvq.c:1081-1092),
@@ -612,7 +624,7 @@ __global__ __launch_bounds__(Geo<TILE>::kNT) void k_inverse_sb(InverseArgs a) {
     for (int i = tid; i < nbsb*a.nb_bands; i += NT) {
       const int b = i/a.nb_bands;
       const int band = i - b*a.nb_bands;
-      const long blk = ((long)blockIdx.z*bh + (y0 >> sh) + b/nbw)*bw + (x0 >> sh) + b % nbw;
+      const long blk = ((long)plane*bh + (y0 >> sh) + b/nbw)*bw + (x0 >> sh) + b % nbw;
       s_choice[i] = a.choice[blk*a.nb_bands + band];
     }
     if ((a.len >> sh) < (1 << sh)) {            /* 32x32 / 64x64: uncoded positions are zero */
@@ -628,7 +640,7 @@ __global__ __launch_bounds__(Geo<TILE>::kNT) void k_inverse_sb(InverseArgs a) {
     const int lsh = 31 - __clz(a.len);          /* len is a power of two */
     const int csh = lsh - 4;                    /* chunks per block = len/16 */
     const int lnb = 31 - __clz(nbw);            /* so is the block count per tile row */
-    const long blk0 = ((long)blockIdx.z*bh + (y0 >> sh))*bw + (x0 >> sh);
+    const long blk0 = ((long)plane*bh + (y0 >> sh))*bw + (x0 >> sh);
     for (int c = tid; c < nbsb << csh; c += NT) {
       const int b = c >> csh;
       const int j0 = (c & ((1 << csh) - 1)) << 4;
@@ -702,7 +714,7 @@ __global__ __launch_bounds__(Geo<TILE>::kNT) void k_inverse_sb(InverseArgs a) {
      int32 round trip of the whole plane. */
   const int w = a.w;
   const int h = a.h;
-  uint8_t *px = a.px + blockIdx.z*a.px_plane_stride;
+  uint8_t *px = a.px + plane*a.px_plane_stride;
   for (int i = tid; i < TILE*TILE/4; i += NT) {
     const int y = i/(TILE/4);
     const int x = (i % (TILE/4))*4;
@@ -718,8 +730,8 @@ __global__ __launch_bounds__(Geo<TILE>::kNT) void k_inverse_sb(InverseArgs a) {
   const int nh = h/TILE - 1;
   const int sbx = blockIdx.x;
   const int sby = blockIdx.y;
-  od_coeff *vs = a.vs + (long)blockIdx.z*nv*h*4;
-  od_coeff *hs = a.hs + (long)blockIdx.z*nh*4*w;
+  od_coeff *vs = a.vs + (long)plane*nv*h*4;
+  od_coeff *hs = a.hs + (long)plane*nh*4*w;
   for (int i = tid; i < 2*TILE; i += NT) {
     const int right = i/TILE;
     const int r = i % TILE;
@@ -755,16 +767,23 @@ struct EdgeArgs {
   int tile;
 };
 
+struct EdgeArgsMulti {
+  EdgeArgs a[kMaxInvLevels];
+  int nplanes;
+};
+
 /* od_apply_postfilter_frame_sbs, first half (src/filter.c:1600-1606): row taps
    across every interior vertical superblock edge, every row.  Rows that also lie
    in a horizontal strip hand their result on to k_edge_cols through hs. */
-__global__ __launch_bounds__(256) void k_edge_rows(EdgeArgs a) {
+__global__ __launch_bounds__(256) void k_edge_rows(EdgeArgsMulti mm) {
+  const EdgeArgs &a = mm.a[blockIdx.z / mm.nplanes];
+  const int plane = blockIdx.z % mm.nplanes;
   const int y = blockIdx.x*256 + threadIdx.x;
   if (y >= a.h) return;
   const int e = blockIdx.y;
   const int nv = a.w/a.tile - 1;
   const int nh = a.h/a.tile - 1;
-  const int4 v = *reinterpret_cast<const int4 *>(a.vs + (((long)blockIdx.z*nv + e)*a.h + y)*4);
+  const int4 v = *reinterpret_cast<const int4 *>(a.vs + (((long)plane*nv + e)*a.h + y)*4);
   int t0 = v.x;
   int t1 = v.y;
   int t2 = v.z;
@@ -774,14 +793,14 @@ __global__ __launch_bounds__(256) void k_edge_rows(EdgeArgs a) {
   const int m = (y + 2) % a.tile;           /* < 4 inside a horizontal strip */
   const int he = (y + 2)/a.tile - 1;
   if (m < 4 && he >= 0 && he < nh) {
-    od_coeff *row = a.hs + (((long)blockIdx.z*nh + he)*4 + m)*a.w + x;
+    od_coeff *row = a.hs + (((long)plane*nh + he)*4 + m)*a.w + x;
     row[0] = t0;
     row[1] = t1;
     row[2] = t2;
     row[3] = t3;
   }
   else {
-    uint8_t *p = a.px + blockIdx.z*a.px_plane_stride + (long)y*a.px_stride + x;
+    uint8_t *p = a.px + plane*a.px_plane_stride + (long)y*a.px_stride + x;
     p[0] = od_to_px(t0);
     p[1] = od_to_px(t1);
     p[2] = od_to_px(t2);
@@ -791,18 +810,20 @@ __global__ __launch_bounds__(256) void k_edge_rows(EdgeArgs a) {
 
 /* Second half (src/filter.c:1607-1617): column taps across every interior
    horizontal edge, every column, then od_coeff_to_ref_buf. */
-__global__ __launch_bounds__(256) void k_edge_cols(EdgeArgs a) {
+__global__ __launch_bounds__(256) void k_edge_cols(EdgeArgsMulti mm) {
+  const EdgeArgs &a = mm.a[blockIdx.z / mm.nplanes];
+  const int plane = blockIdx.z % mm.nplanes;
   const int x = blockIdx.x*256 + threadIdx.x;
   if (x >= a.w) return;
   const int e = blockIdx.y;
   const int nh = a.h/a.tile - 1;
-  const od_coeff *col = a.hs + ((long)blockIdx.z*nh + e)*4*a.w + x;
+  const od_coeff *col = a.hs + ((long)plane*nh + e)*4*a.w + x;
   int t0 = col[0];
   int t1 = col[a.w];
   int t2 = col[2*a.w];
   int t3 = col[3*a.w];
   od_post_filter4_dev(t0, t1, t2, t3);
-  uint8_t *p = a.px + blockIdx.z*a.px_plane_stride + (long)((e + 1)*a.tile - 2)*a.px_stride + x;
+  uint8_t *p = a.px + plane*a.px_plane_stride + (long)((e + 1)*a.tile - 2)*a.px_stride + x;
   p[0] = od_to_px(t0);
   p[a.px_stride] = od_to_px(t1);
   p[2*a.px_stride] = od_to_px(t2);
@@ -846,39 +867,55 @@ extern "C" int odhip_forward_pyramid(od_coeff *const d_levels[ODHIP_NBSIZES],
 
 namespace {
 
-int inverse_launch(InverseArgs ia, int nplanes, int dec, hipStream_t s) {
+/* All levels share w, h, nplanes and dec (one plane set). */
+int inverse_launch(const InverseArgs *levels, int nlevels, int nplanes, int dec, hipStream_t s) {
+  if (nlevels <= 0 || nlevels > kMaxInvLevels) return ODHIP_EINVAL;
   const int tile = 64 >> dec;
-  const int w = ia.w;
-  const int h = ia.h;
+  const int w = levels[0].w;
+  const int h = levels[0].h;
   const int nv = w/tile - 1;
   const int nh = h/tile - 1;
   const size_t vs_words = ((size_t)nplanes*nv*h*4 + 3) & ~(size_t)3;
-  const size_t hs_words = (size_t)nplanes*nh*4*w;
-  const size_t need = (vs_words + hs_words + 4)*sizeof(od_coeff);
+  const size_t hs_words = ((size_t)nplanes*nh*4*w + 3) & ~(size_t)3;
+  const size_t need = ((vs_words + hs_words)*nlevels + 4)*sizeof(od_coeff);
   if (need > g_strips_bytes) {
+    ODHIP_TRY(hipStreamSynchronize(s));
     if (g_strips) ODHIP_TRY(hipFree(g_strips));
     g_strips = nullptr;
     g_strips_bytes = 0;
     ODHIP_TRY(hipMalloc((void **)&g_strips, need));
     g_strips_bytes = need;
   }
-  ia.vs = g_strips;
-  ia.hs = g_strips + vs_words;
-  EdgeArgs ea;
-  ea.vs = ia.vs;
-  ea.hs = ia.hs;
-  ea.px = ia.px;
-  ea.px_stride = ia.px_stride;
-  ea.px_plane_stride = ia.px_plane_stride;
-  ea.w = w;
-  ea.h = h;
-  ea.tile = tile;
-  const dim3 grid(w/tile, h/tile, nplanes);
-  if (dec) k_inverse_sb<32><<<grid, Geo<32>::kNT, 0, s>>>(ia);
-  else k_inverse_sb<64><<<grid, Geo<64>::kNT, 0, s>>>(ia);
-  if (nv > 0) k_edge_rows<<<dim3((h + 255)/256, nv, nplanes), 256, 0, s>>>(ea);
-  if (nh > 0) k_edge_cols<<<dim3((w + 255)/256, nh, nplanes), 256, 0, s>>>(ea);
+  InverseArgsMulti im;
+  EdgeArgsMulti em;
+  memset(&im, 0, sizeof(im));
+  memset(&em, 0, sizeof(em));
+  im.nplanes = nplanes;
+  em.nplanes = nplanes;
+  for (int l = 0; l < nlevels; l++) {
+    if (levels[l].w != w || levels[l].h != h) return ODHIP_EINVAL;
+    im.a[l] = levels[l];
+    im.a[l].vs = g_strips + (vs_words + hs_words)*l;
+    im.a[l].hs = im.a[l].vs + vs_words;
+    em.a[l].vs = im.a[l].vs;
+    em.a[l].hs = im.a[l].hs;
+    em.a[l].px = levels[l].px;
+    em.a[l].px_stride = levels[l].px_stride;
+    em.a[l].px_plane_stride = levels[l].px_plane_stride;
+    em.a[l].w = w;
+    em.a[l].h = h;
+    em.a[l].tile = tile;
+  }
+  const dim3 grid(w/tile, h/tile, nplanes*nlevels);
+  if (dec) k_inverse_sb<32><<<grid, Geo<32>::kNT, 0, s>>>(im);
+  else k_inverse_sb<64><<<grid, Geo<64>::kNT, 0, s>>>(im);
+  if (nv > 0) k_edge_rows<<<dim3((h + 255)/256, nv, nplanes*nlevels), 256, 0, s>>>(em);
+  if (nh > 0) k_edge_cols<<<dim3((w + 255)/256, nh, nplanes*nlevels), 256, 0, s>>>(em);
   return odhip_check_launch();
+}
+
+int inverse_launch(InverseArgs ia, int nplanes, int dec, hipStream_t s) {
+  return inverse_launch(&ia, 1, nplanes, dec, s);
 }
 
 bool g_inv_tables = false;
@@ -924,8 +961,10 @@ extern "C" int odhip_inverse_level(uint8_t *d_px, int px_stride, long px_plane_s
   return inverse_launch(ia, nplanes, dec, (hipStream_t)stream);
 }
 
-extern "C" int odhip_inverse_level_pvq(uint8_t *d_px, int px_stride, long px_plane_stride,
- const odhip_pvq_job *job, int dec, int pic_w, int pic_h, odhip_stream stream) {
+namespace {
+
+int pvq_inverse_args(InverseArgs &ia, uint8_t *d_px, int px_stride, long px_plane_stride,
+ const odhip_pvq_job *job, int dec, int pic_w, int pic_h) {
   if (!d_px || !job || !job->d_coef || !job->cands.y || !job->cands.choice || !job->d_qm_inv
    || job->nplanes <= 0 || (dec != 0 && dec != 1)) {
     return ODHIP_EINVAL;
@@ -938,10 +977,7 @@ extern "C" int odhip_inverse_level_pvq(uint8_t *d_px, int px_stride, long px_pla
    || bs < 0 || bs > 4 - dec || ((uintptr_t)job->cands.y & 15) || ((uintptr_t)job->cands.choice & 15)) {
     return ODHIP_EINVAL;
   }
-  int rc = upload_inv_tables();
-  if (rc) return rc;
   const int n = 4 << bs;
-  InverseArgs ia;
   memset(&ia, 0, sizeof(ia));
   ia.coef = job->d_coef;
   ia.px = d_px;
@@ -959,5 +995,34 @@ extern "C" int odhip_inverse_level_pvq(uint8_t *d_px, int px_stride, long px_pla
   ia.len = n*n < OD_SCAN_LEN ? n*n : OD_SCAN_LEN;
   if (2*ia.nblocks*ia.len >= 0x7fffffffL) return ODHIP_EINVAL;  /* 32-bit element indices */
   ia.nb_bands = OD_NBANDS[bs];
+  return ODHIP_SUCCESS;
+}
+
+}  // namespace
+
+extern "C" int odhip_inverse_level_pvq(uint8_t *d_px, int px_stride, long px_plane_stride,
+ const odhip_pvq_job *job, int dec, int pic_w, int pic_h, odhip_stream stream) {
+  InverseArgs ia;
+  int rc = pvq_inverse_args(ia, d_px, px_stride, px_plane_stride, job, dec, pic_w, pic_h);
+  if (rc) return rc;
+  rc = upload_inv_tables();
+  if (rc) return rc;
   return inverse_launch(ia, job->nplanes, dec, (hipStream_t)stream);
+}
+
+extern "C" int odhip_inverse_levels_pvq(uint8_t *const *d_px, int px_stride, long px_plane_stride,
+ const odhip_pvq_job *jobs, int njobs, int dec, int pic_w, int pic_h, odhip_stream stream) {
+  if (!d_px || !jobs || njobs <= 0 || njobs > kMaxInvLevels) return ODHIP_EINVAL;
+  InverseArgs ia[kMaxInvLevels];
+  for (int i = 0; i < njobs; i++) {
+    const int rc = pvq_inverse_args(ia[i], d_px[i], px_stride, px_plane_stride, &jobs[i], dec, pic_w,
+     pic_h);
+    if (rc) return rc;
+    if (jobs[i].nplanes != jobs[0].nplanes || jobs[i].w != jobs[0].w || jobs[i].h != jobs[0].h) {
+      return ODHIP_EINVAL;
+    }
+  }
+  const int rc = upload_inv_tables();
+  if (rc) return rc;
+  return inverse_launch(ia, njobs, jobs[0].nplanes, dec, (hipStream_t)stream);
 }

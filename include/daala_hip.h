@@ -264,6 +264,12 @@ int odhip_inverse_level_pvq(uint8_t *d_px, int px_stride, long px_plane_stride,
 int odhip_pvq_profile(int enable);
 int odhip_pvq_profile_read(float *ms, int max_n);
 
+/* odhip_inverse_level_pvq for several partition levels of ONE plane set (same
+   nplanes, w, h, dec; at most 5 jobs) in a single set of launches: level i of
+   jobs[] is reconstructed into d_px[i] (distinct buffers, same strides). */
+int odhip_inverse_levels_pvq(uint8_t *const *d_px, int px_stride, long px_plane_stride,
+ const odhip_pvq_job *jobs, int njobs, int dec, int pic_w, int pic_h, odhip_stream stream);
+
 /* nb_bands, offsets[nb_bands+1] and len for block size bs. */
 int odhip_pvq_band_layout(int bs, int *nb_bands, int *offsets, int *len);
 

@@ -180,6 +180,34 @@ def test_inverse_from_pvq_equals_synth_then_inverse(hip, dec):
                 assert not torch.equal(job.cands["choice"][..., 1], qg_a) or bs == 4
 
 
+@pytest.mark.parametrize("dec", [0, 1])
+def test_inverse_levels_in_one_launch_equal_level_by_level(hip, dec):
+    import torch
+    W, H = 256, 192
+    planes = synth_frame(W, H, seed=27)
+    rng = np.random.RandomState(5)
+    src = planes[0] if dec == 0 else planes[1]
+    src = np.clip(src.astype(int) + rng.randint(-70, 71, size=src.shape), 0, 255).astype(np.uint8)
+    px = _cuda(np.stack([src, src[::-1].copy(), src[:, ::-1].copy()]))
+    pli = 0 if dec == 0 else 1
+    levels = hip.forward_pyramid(px, dec, W, H)
+    qt = hip.QuantTables.load()
+    jobs = []
+    for bs in range(5 - dec):
+        qm, qmi = qt.qm_slices(pli, bs)
+        jobs.append(hip.PvqJob(levels[bs], bs, _cuda(qm), _cuda(qmi), qt.q_band(pli, bs),
+                               qt.beta_band(pli, bs)))
+    hip.pvq_noref_bands_multi(jobs, hip.OD_PVQ_LAMBDA)
+    hip.pvq_choose_multi(jobs, hip.OD_PVQ_LAMBDA)
+    want = [hip.inverse_level_pvq(j, dec, W, H) for j in jobs]
+    got = hip.inverse_levels_pvq(jobs, dec, W, H)
+    for bs, (g, w_) in enumerate(zip(got, want)):
+        assert torch.equal(g, w_), (dec, bs)
+    # a subset of levels, in a different order
+    got2 = hip.inverse_levels_pvq([jobs[2], jobs[0]], dec, W, H)
+    assert torch.equal(got2[0], want[2]) and torch.equal(got2[1], want[0])
+
+
 def test_pair_search_sequential_combine_equals_exact_combine(hip, monkeypatch):
     """The 128-coefficient band is searched by two lanes per band; the halves of
     the greedy argmax are combined by an exact-arithmetic argument, with a
