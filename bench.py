@@ -309,6 +309,17 @@ def main():
                 "avg_ms_per_launch": round(s_ms, 4), "launches": len(search_ms),
                 "share_of_step": round(s_ms / (dt / args.steps * 1e3), 4),
                 "algorithmic_bytes_per_launch": s_bytes, "bands_per_launch": n128}
+        # HBM traffic of that kernel from the committed PMC run of this command
+        # (tools/profile_round.sh; bench.py cannot collect counters itself)
+        try:
+            with open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")) as f:
+                tr = json.load(f)["kernels"]
+            key = [k_ for k_ in tr if k_.startswith("k_search<128")]
+            if key and args.frames == 8:
+                roof["traffic"] = tr[key[0]]["hbm_bytes_per_launch"]
+                roof["traffic_source"] = "profiles/r1_pmc_traffic.json (rocprofv3 --pmc, same command)"
+        except (OSError, ValueError, KeyError):
+            pass
         fd = kernels["forward_pyramid_luma"]
         roof["note"] = ("largest single kernel of the step; it overlaps with the other band-size "
                         "searches on forked streams, so its share is of wall time, not exclusive. "

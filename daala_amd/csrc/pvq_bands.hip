@@ -1135,6 +1135,13 @@ extern "C" int odhip_pvq_noref_bands_multi(const odhip_pvq_job *jobs, int njobs,
       items_add(all, j, b, 1);
     }
   }
+  {
+    /* the histograms are consumed and cleared by k_prefix; clear them here as
+       well so that a call that failed half way cannot poison the next sort */
+    void *hist = nullptr;
+    ODHIP_TRY(hipGetSymbolAddress(&hist, HIP_SYMBOL(g_hist)));
+    ODHIP_TRY(hipMemsetAsync(hist, 0, sizeof(unsigned)*kMaxItems*kKeyBins, s));
+  }
   k_hist<<<it.wg_start[it.nitems], 256, 0, s>>>(it);
   k_prefix<<<all.nitems, 256, 0, s>>>(all);
   k_scatter<<<it.wg_start[it.nitems], 256, 0, s>>>(it);

@@ -1,5 +1,5 @@
-for d in 0 1 2 4 7; do
-  export ODHIP_PREP_DEBUG=$d
-  echo "== debug $d"
-  bash tools/prof_quick.sh 2>&1 | grep -E "k_prep_lane|k_prep_wide"
+for l in 0 5000 10000 20000 40000; do
+  export ODHIP_LDS4=$l ODHIP_LDS8=$l
+  echo "== dummy LDS $l"
+  bash tools/prof_quick.sh 2>&1 | grep -E "k_prep_corner"
 done

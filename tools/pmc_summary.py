@@ -86,11 +86,21 @@ def main():
              "SQ_WAIT_ANY", "SQ_WAVES"]
     print("%-28s %-10s " % ("kernel", "grid") + " ".join("%14s" % n[-14:] for n in names)
           + " %12s %9s" % ("HBM_est_MB", "bankconf%"))
+    traffic = {}
     for k, c in sorted(ctr.items()):
         vals = [sum(c[n]) / len(c[n]) if c.get(n) else float("nan") for n in names]
         hbm = (2 * vals[0] + vals[1]) * 1024 / 1e6
+        if hbm == hbm:
+            traffic["%s grid %s" % k] = {"fetch_size_KiB": vals[0], "write_size_KiB": vals[1],
+                                         "hbm_bytes_per_launch": int(hbm * 1e6)}
         bc = 100.0 * vals[2] / vals[3] if vals[3] == vals[3] and vals[3] else float("nan")
         print("%-28s %-10s " % (k[0], k[1]) + " ".join("%14.0f" % v for v in vals) + " %12.1f %9.2f" % (hbm, bc))
+    if len(sys.argv) > 2:
+        import json
+        with open(sys.argv[2], "w") as f:
+            json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), "
+                                 "HBM bytes = (2*FETCH_SIZE + WRITE_SIZE) KiB, MI355X_MICROARCH.md gfx950 correction",
+                       "kernels": traffic}, f, indent=1)
 
 
 if __name__ == "__main__":
