@@ -53,3 +53,33 @@ def test_argument_validation_without_gpu(built):
     assert L.odhip_pvq_band_layout(2, ctypes.byref(nb), offs, ctypes.byref(ln)) == 0
     assert nb.value == 7 and ln.value == 256
     assert [offs[i] for i in range(8)] == [1, 16, 24, 32, 64, 96, 128, 256]
+
+
+def test_band_stage_and_reference_path_validation_without_gpu(built):
+    """The multi-job and with-reference entry points reject bad arguments before
+    any HIP call (no GPU in this container)."""
+    import ctypes
+    import daala_amd
+    from daala_amd import api
+    L = daala_amd.lib()
+    EINVAL = -10
+    assert L.odhip_pvq_noref_bands_multi(None, 1, ctypes.c_double(0.1), None) == EINVAL
+    assert L.odhip_pvq_choose_multi(None, 0, ctypes.c_double(0.1), None) == EINVAL
+    jobs = (api._Job * 17)()
+    assert L.odhip_pvq_noref_bands_multi(jobs, 17, ctypes.c_double(0.1), None) == EINVAL  # > 16 jobs
+    assert L.odhip_inverse_levels_pvq(None, 64, ctypes.c_long(4096), jobs, 1, 0, 64, 64, None) == EINVAL
+    ptrs = (ctypes.c_void_p * 6)()
+    assert L.odhip_inverse_levels_pvq(ptrs, 64, ctypes.c_long(4096), jobs, 6, 0, 64, 64, None) == EINVAL
+    # with-reference blocks: empty batches succeed, bad sizes / null pointers are refused
+    z = ctypes.c_long(0)
+    one = ctypes.c_long(1)
+    assert L.odhip_pvq_ref_prepare(None, None, 16, z, None, 1, 4096, 0, None, None, None, None, None) == 0
+    assert L.odhip_pvq_ref_prepare(None, None, 16, one, None, 1, 4096, 0, None, None, None, None,
+                                   None) == EINVAL
+    assert L.odhip_pvq_ref_candidates(None, None, 16, one, 4096, None, None, None) == EINVAL
+    assert L.odhip_pvq_synthesis(None, None, None, 16, one, None, None, None) == EINVAL
+    assert L.odhip_pvq_synthesis(None, None, None, 16, z, None, None, None) == 0
+    # record layouts the Python mirror relies on
+    assert api.BAND_RECORD.itemsize == 64 and api.BAND_RECORD.fields["dist0"][1] == 24
+    assert api.BAND_RECORD.fields["yy"][1] == 32 and api.BAND_RECORD.fields["dist"][1] == 40
+    assert api.REFPREP_RECORD.fields["corr"][1] == 48
