@@ -104,6 +104,21 @@ def idct2d_plane(ln, y, exact32=False):
     return _dct_plane(lib().odhip_idct2d_plane, ln, y, exact32)
 
 
+def filter_batch(f, x, inverse=False, out=None):
+    """(4 << f)-tap lapping filter (od_pre_filterN / od_post_filterN) of every row
+    of x: int32 [count, 4 << f] CUDA."""
+    import torch
+    _need(x, torch.int32, "x")
+    count, n = x.shape
+    if n != 4 << f:
+        raise DaalaHipError("x must be [count, %d]" % (4 << f))
+    if out is None:
+        out = torch.empty_like(x)
+    _check(lib().odhip_filter_batch(int(f), int(bool(inverse)), _p(out), _p(x),
+                                    ctypes.c_long(count), _stream()), "odhip_filter_batch")
+    return out
+
+
 # ---- fused lapped stage -----------------------------------------------------
 def forward_pyramid(px, dec, pic_w, pic_h, levels=None, want=None):
     """px: uint8 [nplanes, h, w] CUDA.  Returns a list of int32 [nplanes, h, w]

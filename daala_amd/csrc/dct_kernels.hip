@@ -11,6 +11,7 @@
 #include "../../include/daala_hip.h"
 #include "od_common.cuh"
 #include "od_tile.cuh"
+#include "od_filters.cuh"
 
 namespace {
 
@@ -160,6 +161,54 @@ int launch_plane(int ln, od_coeff *out, int out_stride, const od_coeff *in,
 }
 
 }  // namespace
+
+namespace {
+
+/* One n-tap lapping filter per lane on contiguous vectors [count][n]. */
+template <int N, bool INV>
+__global__ __launch_bounds__(256) void k_filter_batch(od_coeff *out, const od_coeff *in, long count) {
+  const long i = (long)blockIdx.x*256 + threadIdx.x;
+  if (i >= count) return;
+  int t[N];
+  const int4 *src = reinterpret_cast<const int4 *>(in + i*N);
+#pragma unroll
+  for (int v = 0; v < N/4; v++) {
+    const int4 q = src[v];
+    t[4*v] = q.x;
+    t[4*v + 1] = q.y;
+    t[4*v + 2] = q.z;
+    t[4*v + 3] = q.w;
+  }
+  if (INV) od_post_filter_dev<N>(t);
+  else od_pre_filter_dev<N>(t);
+  int4 *dst = reinterpret_cast<int4 *>(out + i*N);
+#pragma unroll
+  for (int v = 0; v < N/4; v++) dst[v] = make_int4(t[4*v], t[4*v + 1], t[4*v + 2], t[4*v + 3]);
+}
+
+template <int N>
+int launch_filter(int inverse, od_coeff *d_out, const od_coeff *d_in, long count, hipStream_t s) {
+  const unsigned grid = (unsigned)((count + 255)/256);
+  if (inverse) k_filter_batch<N, true><<<grid, 256, 0, s>>>(d_out, d_in, count);
+  else k_filter_batch<N, false><<<grid, 256, 0, s>>>(d_out, d_in, count);
+  return odhip_check_launch();
+}
+
+}  // namespace
+
+extern "C" int odhip_filter_batch(int f, int inverse, od_coeff *d_out, const od_coeff *d_in, long count,
+ odhip_stream stream) {
+  if (f < 0 || f > 3) return ODHIP_EINVAL;
+  if (count <= 0) return count < 0 ? ODHIP_EINVAL : ODHIP_SUCCESS;
+  if (!d_out || !d_in || ((uintptr_t)d_out & 15) || ((uintptr_t)d_in & 15)) return ODHIP_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  switch (f) {
+    case 0: return launch_filter<4>(inverse, d_out, d_in, count, s);
+    case 1: return launch_filter<8>(inverse, d_out, d_in, count, s);
+    case 2: return launch_filter<16>(inverse, d_out, d_in, count, s);
+    default: return launch_filter<32>(inverse, d_out, d_in, count, s);
+  }
+}
 
 extern "C" int odhip_fdct2d_batch(int ln, od_coeff *d_out, const od_coeff *d_in,
  long nblocks, int exact32, odhip_stream stream) {

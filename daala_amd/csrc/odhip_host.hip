@@ -191,6 +191,41 @@ void od_post_filter4_hip(od_coeff x[4], const od_coeff y[4]) {
   memcpy(x, t, sizeof(t));
 }
 
+namespace {
+
+void filter_call(int f, int inverse, od_coeff *out, const od_coeff *in) {
+  const int n = 4 << f;
+  Scratch &s = g_scratch;
+  od_coeff *d_in = (od_coeff *)s.get(0, n*sizeof(od_coeff));
+  od_coeff *d_out = (od_coeff *)s.get(1, n*sizeof(od_coeff));
+  HIP_OR_DIE(hipMemcpyAsync(d_in, in, n*sizeof(od_coeff), hipMemcpyHostToDevice, s.stream));
+  ok_or_die(odhip_filter_batch(f, inverse, d_out, d_in, 1, s.stream), "filter_batch");
+  HIP_OR_DIE(hipMemcpyAsync(out, d_out, n*sizeof(od_coeff), hipMemcpyDeviceToHost, s.stream));
+  HIP_OR_DIE(hipStreamSynchronize(s.stream));
+}
+
+}  // namespace
+
+/* od_pre_filter8/16/32, od_post_filter8/16/32 (src/filter.c:279-1321): unused by
+   the codec (OD_FILT_SIZE == 0) but part of OD_PRE_FILTER[] / OD_POST_FILTER[]. */
+void od_pre_filter8_hip(od_coeff y[8], const od_coeff x[8]) { filter_call(1, 0, y, x); }
+void od_post_filter8_hip(od_coeff x[8], const od_coeff y[8]) { filter_call(1, 1, x, y); }
+void od_pre_filter16_hip(od_coeff y[16], const od_coeff x[16]) { filter_call(2, 0, y, x); }
+void od_post_filter16_hip(od_coeff x[16], const od_coeff y[16]) { filter_call(2, 1, x, y); }
+void od_pre_filter32_hip(od_coeff y[32], const od_coeff x[32]) { filter_call(3, 0, y, x); }
+void od_post_filter32_hip(od_coeff x[32], const od_coeff y[32]) { filter_call(3, 1, x, y); }
+
+void odhip_install_filter_tables(odhip_filter_func pre[4], odhip_filter_func post[4]) {
+  pre[0] = od_pre_filter4_hip;
+  pre[1] = od_pre_filter8_hip;
+  pre[2] = od_pre_filter16_hip;
+  pre[3] = od_pre_filter32_hip;
+  post[0] = od_post_filter4_hip;
+  post[1] = od_post_filter8_hip;
+  post[2] = od_post_filter16_hip;
+  post[3] = od_post_filter32_hip;
+}
+
 /* od_prefilter_split, src/filter.c:1459-1483: columns (hfilter) then rows. */
 void od_prefilter_split_hip(od_coeff *c0, int stride, int bs, int f, int hfilter,
  int vfilter) {

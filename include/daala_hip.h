@@ -80,6 +80,25 @@ void odhip_install_dct_vtbl(odhip_dct_func_2d fdct_2d[ODHIP_NBSIZES],
    four samples, in place allowed. */
 void od_pre_filter4_hip(od_coeff y[4], const od_coeff x[4]);
 void od_post_filter4_hip(od_coeff x[4], const od_coeff y[4]);
+/* The larger lapping filters of the same tables, od_pre_filter8/16/32 and
+   od_post_filter8/16/32 (src/filter.c:279-1321, the TYPE3 parameter sets its
+   `#elif 1` chains select).  The codec does not use them (OD_FILT_SIZE == 0,
+   src/filter.h:77); the reference's own tests do (dcttest dynamic_range,
+   src/dct.c:8606; the filter test).  odhip_install_filter_tables fills
+   OD_PRE_FILTER[0..3] / OD_POST_FILTER[0..3]-shaped arrays (src/filter.c:115-127)
+   with the host-pointer functions; odhip_filter_batch runs `count` independent
+   (4 << f)-tap filters on contiguous device vectors [count][4 << f] (16-byte
+   aligned; in place allowed), f = 0..3, inverse = 0 pre / 1 post. */
+typedef void (*odhip_filter_func)(od_coeff out[], const od_coeff in[]);   /* od_filter_func, src/filter.h:43 */
+void od_pre_filter8_hip(od_coeff y[8], const od_coeff x[8]);
+void od_post_filter8_hip(od_coeff x[8], const od_coeff y[8]);
+void od_pre_filter16_hip(od_coeff y[16], const od_coeff x[16]);
+void od_post_filter16_hip(od_coeff x[16], const od_coeff y[16]);
+void od_pre_filter32_hip(od_coeff y[32], const od_coeff x[32]);
+void od_post_filter32_hip(od_coeff x[32], const od_coeff y[32]);
+void odhip_install_filter_tables(odhip_filter_func pre[4], odhip_filter_func post[4]);
+int odhip_filter_batch(int f, int inverse, od_coeff *d_out, const od_coeff *d_in, long count,
+ odhip_stream stream);
 
 /* Block- and frame-level lapping drivers, same signatures as the reference
    (src/filter.h:80-87; definitions src/filter.c:1459-1619), in place on a host

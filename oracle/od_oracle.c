@@ -166,6 +166,75 @@ void odo_post_filter4(odo_coeff x[4], const odo_coeff y[4]) {
   x[3] = s0 - d30;
 }
 
+/* od_pre_filter8/16/32, src/filter.c:279-364, :519-676, :852-1144 (the TYPE3
+   variants the `#elif 1` chains select), stated once for n = 2h taps: +1/-1
+   butterflies, Q6 scaling of the high half with the "+1 if positive" that makes
+   it invertible (skipped for a factor of 64), the rotation ladder from the top
+   pair down, butterflies back.  n = 4 gives od_pre_filter4. */
+#include "od_filter_params.h"
+
+static const int *odo_filter_params(int n) {
+  return n == 4 ? OD_FPARAMS4 : n == 8 ? OD_FPARAMS8 : n == 16 ? OD_FPARAMS16
+   : n == 32 ? OD_FPARAMS32 : NULL;
+}
+
+int odo_pre_filter(int n, odo_coeff *y, const odo_coeff *x) {
+  const int *p;
+  int32_t t[32];
+  int h;
+  int i;
+  int k;
+  p = odo_filter_params(n);
+  if (!p) return -1;
+  h = n >> 1;
+  for (i = 0; i < h; i++) t[n - 1 - i] = x[i] - x[n - 1 - i];
+  for (i = 0; i < h; i++) t[i] = x[i] - (t[n - 1 - i] >> 1);
+  for (i = 0; i < h; i++) {
+    if (p[i] != 64) {
+      t[h + i] = t[h + i]*p[i] >> 6;
+      t[h + i] += t[h + i] > 0;
+    }
+  }
+  for (k = h - 2; k >= 0; k--) {
+    t[h + k + 1] += (t[h + k]*p[h + k] + 32) >> 6;
+    t[h + k] += (t[h + k + 1]*p[2*h - 1 + k] + 32) >> 6;
+  }
+  for (i = 0; i < h; i++) {
+    t[i] += t[n - 1 - i] >> 1;
+    y[i] = t[i];
+  }
+  for (i = 0; i < h; i++) y[n - 1 - i] = t[i] - t[n - 1 - i];
+  return 0;
+}
+
+/* od_post_filter8/16/32, src/filter.c:366-421, :678-783, :1146-1321: the exact
+   inverse; the scalings are undone with C truncating divisions. */
+int odo_post_filter(int n, odo_coeff *x, const odo_coeff *y) {
+  const int *p;
+  int32_t t[32];
+  int h;
+  int i;
+  int k;
+  p = odo_filter_params(n);
+  if (!p) return -1;
+  h = n >> 1;
+  for (i = 0; i < h; i++) t[n - 1 - i] = y[i] - y[n - 1 - i];
+  for (i = 0; i < h; i++) t[i] = y[i] - (t[n - 1 - i] >> 1);
+  for (k = 0; k <= h - 2; k++) {
+    t[h + k] -= (t[h + k + 1]*p[2*h - 1 + k] + 32) >> 6;
+    t[h + k + 1] -= (t[h + k]*p[h + k] + 32) >> 6;
+  }
+  for (i = 0; i < h; i++) {
+    if (p[i] != 64) t[h + i] = t[h + i]*64/p[i];
+  }
+  for (i = 0; i < h; i++) {
+    t[i] += t[n - 1 - i] >> 1;
+    x[i] = t[i];
+  }
+  for (i = 0; i < h; i++) x[n - 1 - i] = t[i] - t[n - 1 - i];
+  return 0;
+}
+
 static void odo_filter4_col(odo_coeff *c, int stride, int inverse) {
   odo_coeff t[4];
   int k;

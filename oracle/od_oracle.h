@@ -35,6 +35,9 @@ void odo_idct_2d_batch(int ln, odo_coeff *x, const odo_coeff *y, long nblocks);
 /* ---- 4-point lapping filter and its drivers: src/filter.c ----------------- */
 void odo_pre_filter4(odo_coeff y[4], const odo_coeff x[4]);
 void odo_post_filter4(odo_coeff x[4], const odo_coeff y[4]);
+/* n = 4, 8, 16, 32 (src/filter.c:147-1321); return -1 for any other n.  In place allowed. */
+int odo_pre_filter(int n, odo_coeff *y, const odo_coeff *x);
+int odo_post_filter(int n, odo_coeff *x, const odo_coeff *y);
 void odo_prefilter_split(odo_coeff *c0, int stride, int bs, int hfilter, int vfilter);
 void odo_postfilter_split(odo_coeff *c0, int stride, int bs, int hfilter, int vfilter);
 void odo_apply_prefilter_frame_sbs(odo_coeff *c0, int stride, int nhsb, int nvsb, int xdec, int ydec);

@@ -169,6 +169,44 @@ def test_pvq_search_matches_oracle(hip, n):
     assert np.array_equal(cg2.cpu().numpy().view(np.int64), co2.view(np.int64))
 
 
+@pytest.mark.parametrize("f", [0, 1, 2, 3])
+def test_filter_batch_matches_oracle(hip, f):
+    """od_pre_filterN / od_post_filterN, N = 4 << f, batched and per call."""
+    import ctypes as ct
+    n = 4 << f
+    rng = np.random.RandomState(60 + f)
+    x = np.concatenate([rng.randint(-a, a + 1, size=(2500, n)) for a in (3, 255, 4096, 1 << 19)])
+    x = x.astype(np.int32)
+    o = oracle()
+    for inverse in (False, True):
+        want = np.zeros_like(x)
+        fn = o.odo_post_filter if inverse else o.odo_pre_filter
+        for i in range(len(x)):
+            fn(n, P(want[i]), P(x[i]))
+        got = hip.filter_batch(f, _cuda(x), inverse=inverse)
+        assert np.array_equal(got.cpu().numpy(), want), (f, inverse)
+    # in place, and pre -> post is the identity at full size
+    t = _cuda(x)
+    hip.filter_batch(f, t, out=t)
+    hip.filter_batch(f, t, inverse=True, out=t)
+    assert np.array_equal(t.cpu().numpy(), x)
+    assert hip.filter_batch(f, _cuda(x[:0])).shape == (0, n)
+    # per-call host-pointer surface and the table installer (od_filter_func shape)
+    L = hip.lib()
+    FT = ct.CFUNCTYPE(None, ct.c_void_p, ct.c_void_p)
+    pre = (ct.c_void_p * 4)()
+    post = (ct.c_void_p * 4)()
+    L.odhip_install_filter_tables(pre, post)
+    a = np.zeros(n, np.int32)
+    b = np.zeros(n, np.int32)
+    FT(pre[f])(a.ctypes.data, x[7].ctypes.data)
+    o.odo_pre_filter(n, P(b), P(x[7]))
+    assert np.array_equal(a, b)
+    FT(post[f])(a.ctypes.data, x[7].ctypes.data)
+    o.odo_post_filter(n, P(b), P(x[7]))
+    assert np.array_equal(a, b)
+
+
 def test_per_call_surfaces(hip):
     """The reference-signature host-pointer entry points (drop-in surface)."""
     rng = np.random.RandomState(42)

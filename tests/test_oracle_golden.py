@@ -70,6 +70,52 @@ def test_filter4_golden_and_known_answers():
     assert ys.max(0).tolist() == [1003, 1198, 1198, 1003]
 
 
+def test_filters_8_16_32_golden_and_reference():
+    """od_pre_filter8/16/32, od_post_filter8/16/32 (unused by the codec, exercised by
+    the reference's own tests): the oracle's generic network against vectors from
+    the compiled reference, perfect reconstruction, and - when oracle/_ref is
+    present - the reference itself on fresh inputs."""
+    g = load("filters.npz")
+    o = oracle()
+    for n in (8, 16, 32):
+        x = g["x%d" % n]
+        for i in range(len(x)):
+            a = np.zeros(n, np.int32)
+            assert o.odo_pre_filter(n, P(a), P(x[i])) == 0
+            assert np.array_equal(a, g["pre%d" % n][i])
+            b = np.zeros(n, np.int32)
+            assert o.odo_post_filter(n, P(b), P(x[i])) == 0
+            assert np.array_equal(b, g["post%d" % n][i])
+            c = np.zeros(n, np.int32)
+            o.odo_post_filter(n, P(c), P(a))
+            assert np.array_equal(c, x[i]), "pre -> post is the identity"
+    t = np.zeros(4, np.int32)
+    assert o.odo_pre_filter(12, P(t), P(t)) == -1
+    # the generic network at n = 4 is od_pre_filter4 / od_post_filter4
+    g4 = load("filter4.npz")
+    for i in range(len(g4["x"])):
+        a = np.zeros(4, np.int32)
+        o.odo_pre_filter(4, P(a), P(g4["x"][i]))
+        assert np.array_equal(a, g4["pre"][i])
+        o.odo_post_filter(4, P(a), P(g4["x"][i]))
+        assert np.array_equal(a, g4["post"][i])
+    r = ref()
+    if r is not None:
+        rng = np.random.RandomState(5)
+        for f in (1, 2, 3):
+            n = 4 << f
+            for _ in range(300):
+                x = rng.randint(-(1 << 20), 1 << 20, size=n).astype(np.int32)
+                a = np.zeros(n, np.int32)
+                b = np.zeros(n, np.int32)
+                o.odo_pre_filter(n, P(a), P(x))
+                r.ref_pre_filter(f, P(b), P(x))
+                assert np.array_equal(a, b)
+                o.odo_post_filter(n, P(a), P(x))
+                r.ref_post_filter(f, P(b), P(x))
+                assert np.array_equal(a, b)
+
+
 def _pyramid(lib, prefix, px, dec, pic):
     h, w = px.shape
     top = 4 - dec
