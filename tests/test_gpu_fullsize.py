@@ -104,3 +104,92 @@ def test_ragged_and_minimum_sizes(hip):
     g2 = torch.ones(65, dtype=torch.float64, device="cuda")
     y, _ = hip.pvq_search_batch(x, k, g2, 0.147)
     assert bool((y.abs().sum(1) == 7).all())
+
+
+def test_1080p_band_stage_properties_and_oracle_subset(hip):
+    """The PVQ band stage on whole 1080p frames (all nine (plane set, level) jobs of
+    the bench step in one multi-job call): size-independent properties of every
+    band, run-to-run identity (the counting sort uses atomics, the results must not
+    depend on the order), and oracle parity on a random subset of bands."""
+    import os
+    import sys
+    import torch
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from test_gpu_pvq_bands import Trace
+    y_, cb, cr = bench.synth_frame_np(0, 99)
+    qt = hip.QuantTables.load()
+    lam = hip.OD_PVQ_LAMBDA
+    sets = []
+    jobs = []
+    for px, dec, pli in ((y_[None], 0, 0), (np.stack([cb, cr]), 1, 1)):
+        tpx = torch.from_numpy(np.ascontiguousarray(px)).cuda()
+        levels = hip.forward_pyramid(tpx, dec, 1920, 1080)
+        for bs in range(5 - dec):
+            qm, qmi = qt.qm_slices(pli, bs)
+            job = hip.PvqJob(levels[bs], bs, torch.from_numpy(qm).cuda(), torch.from_numpy(qmi).cuda(),
+                             qt.q_band(pli, bs), qt.beta_band(pli, bs))
+            jobs.append(job)
+            sets.append((pli, dec, bs, qm, qmi))
+    hip.pvq_noref_bands_multi(jobs, lam)
+    torch.cuda.synchronize()
+    first = [(j.cands["band"].clone(), j.cands["y"].clone()) for j in jobs]
+    hip.pvq_noref_bands_multi(jobs, lam)
+    torch.cuda.synchronize()
+    o = oracle()
+    rng = np.random.RandomState(1)
+    cd = ctypes.c_double
+    nsearched = 0
+    for job, (band0, y0), (pli, dec, bs, qm, qmi) in zip(jobs, first, sets):
+        assert torch.equal(job.cands["band"], band0) and torch.equal(job.cands["y"], y0), (pli, bs)
+        c = hip.unpack_cands(job.cands)
+        nb, offs, ln = hip.pvq_band_layout(bs)
+        y = c["y"].astype(np.int64)
+        for band in range(nb):
+            a, b = offs[band], offs[band + 1]
+            for slot in range(2):
+                fl = c["flags"][:, band, slot]
+                ys = y[slot][:, a:b]
+                k = c["k"][:, band, slot].astype(np.int64)
+                on = fl == 1
+                assert (np.abs(ys).sum(1)[on] == k[on]).all(), (pli, bs, band, slot)
+                assert ((ys * ys).sum(1)[on] == c["yy"][:, band, slot][on]).all()
+                assert (ys[~on] == 0).all() and (c["yy"][:, band, slot][~on] == 0).all()
+                assert (c["dist"][:, band, slot][on] >= 0).all()
+                nsearched += int(on.sum())
+            assert (c["dist0"][:, band] >= 0).all() and (c["cg"][:, band] >= 0).all()
+        # oracle parity on 40 random (block, band) pairs of this job
+        n = 4 << bs
+        coef = job.coef.cpu().numpy()
+        nplanes, h, w = coef.shape
+        qb, bb = qt.q_band(pli, bs), qt.beta_band(pli, bs)
+        for _ in range(40):
+            blk = int(rng.randint(job.nblocks))
+            band = int(rng.randint(nb))
+            p, rem = divmod(blk, (h // n) * (w // n))
+            by, bx = divmod(rem, w // n)
+            vec = np.zeros(n * n, np.int32)
+            tile = np.ascontiguousarray(coef[p, by * n:(by + 1) * n, bx * n:(bx + 1) * n])
+            o.odo_raster_to_coding_order(P(vec), n, P(tile), n)
+            a, b = offs[band], offs[band + 1]
+            m = b - a
+            x0 = np.ascontiguousarray(vec[a:b])
+            r0 = np.zeros(m, np.int32)
+            out = np.zeros(m, np.int32)
+            yv = np.zeros(m, np.int32)
+            i1, i2, i3 = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+            sd = cd(0)
+            tr = Trace()
+            o.odo_pvq_theta(P(out), P(x0), P(r0), m, qb[band], P(yv), ctypes.byref(i1), ctypes.byref(i2),
+                            ctypes.byref(i3), bb[band], ctypes.byref(sd), 1, 1, 0,
+                            P(np.ascontiguousarray(qm[a:b])), P(np.ascontiguousarray(qmi[a:b])), cd(lam), 1,
+                            ctypes.byref(tr))
+            assert c["cg"][blk, band] == tr.cg and c["dist0"][blk, band] == tr.dist0
+            nr = [tr.cands[i] for i in range(tr.ncands) if not tr.cands[i].with_ref]
+            for slot, cnd in enumerate(nr):
+                assert c["gain"][blk, band, slot] == cnd.gain and c["k"][blk, band, slot] == cnd.k
+                assert c["flags"][blk, band, slot] == cnd.searched
+                if cnd.searched:
+                    assert c["dist"][blk, band, slot] == cnd.dist
+                    assert np.array_equal(c["y"][slot, blk, a:b], np.array(cnd.y[:m], np.int32))
+    assert nsearched > 500000
