@@ -318,6 +318,14 @@ def main():
             if key and args.frames == 8:
                 roof["traffic"] = tr[key[0]]["hbm_bytes_per_launch"]
                 roof["traffic_source"] = "profiles/r1_pmc_traffic.json (rocprofv3 --pmc, same command)"
+                vi = tr[key[0]].get("valu_wave_instructions")
+                ex = tr[key[0]].get("exclusive_avg_us")
+                if vi and ex:
+                    # secondary number SURVEY 8(d) asks for: achieved VALU issue.  1024 SIMDs,
+                    # one wave-instruction per 4 cycles at the 2.4 GHz peak clock.
+                    roof["valu"] = {"wave_instructions_per_launch": vi, "exclusive_ms": round(ex / 1e3, 4),
+                                    "issue_frac_of_peak": round(vi * 4 / (1024 * 2.4e9 * ex * 1e-6), 3),
+                                    "source": "same PMC run (SQ_INSTS_VALU) and its serialised kernel trace"}
         except (OSError, ValueError, KeyError):
             pass
         fd = kernels["forward_pyramid_luma"]

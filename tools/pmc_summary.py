@@ -46,8 +46,21 @@ def trace_table(root, sub, title):
     print()
 
 
+def exclusive_durations(root):
+    """kernel name -> average duration (us) in the serialised trace."""
+    acc = collections.defaultdict(list)
+    try:
+        with open(root + "/trace_serial/t_kernel_trace.csv") as f:
+            for r in csv.DictReader(f):
+                acc[short(r["Kernel_Name"])].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    except FileNotFoundError:
+        pass
+    return {k: sum(v) / len(v) / 1e3 for k, v in acc.items()}
+
+
 def main():
     root = sys.argv[1]
+    excl = exclusive_durations(root)
     trace_table(root, "trace_serial", "# kernel trace, ODHIP_PVQ_SERIAL=1 (one stream: exclusive durations), our kernels only")
     dur = collections.defaultdict(list)
     grid = {}
@@ -92,7 +105,9 @@ def main():
         hbm = (2 * vals[0] + vals[1]) * 1024 / 1e6
         if hbm == hbm:
             traffic["%s grid %s" % k] = {"fetch_size_KiB": vals[0], "write_size_KiB": vals[1],
-                                         "hbm_bytes_per_launch": int(hbm * 1e6)}
+                                         "hbm_bytes_per_launch": int(hbm * 1e6),
+                                         "valu_wave_instructions": vals[4],
+                                         "exclusive_avg_us": excl.get(k[0])}
         bc = 100.0 * vals[2] / vals[3] if vals[3] == vals[3] and vals[3] else float("nan")
         print("%-28s %-10s " % (k[0], k[1]) + " ".join("%14.0f" % v for v in vals) + " %12.1f %9.2f" % (hbm, bc))
     if len(sys.argv) > 2:
