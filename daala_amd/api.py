@@ -119,6 +119,30 @@ def filter_batch(f, x, inverse=False, out=None):
     return out
 
 
+def dering_planes(x, xdec, dirs, pli, bskip, thresholds, overlap=1, coeff_shift=4):
+    """od_dering on every superblock of every plane for every candidate threshold.
+    x int16 [nplanes, h, w]; dirs int32 [nplanes, h/(8>>xdec)... see daala_hip.h] =
+    [nplanes, nvsb*8, nhsb*8]; bskip uint8 [nplanes, rows, skip_stride];
+    thresholds int32 [nplanes, ncand, nvsb*nhsb].  Returns y int16
+    [nplanes, ncand, h, w]."""
+    import torch
+    _need(x, torch.int16, "x")
+    _need(dirs, torch.int32, "dirs")
+    _need(bskip, torch.uint8, "bskip")
+    _need(thresholds, torch.int32, "thresholds")
+    nplanes, h, w = x.shape
+    n = 64 >> xdec
+    nhsb, nvsb = w // n, h // n
+    ncand = thresholds.shape[1]
+    y = torch.empty((nplanes, ncand, h, w), dtype=torch.int16, device=x.device)
+    _check(lib().odhip_dering_planes(_p(y), _p(x), w, nhsb, nvsb, int(xdec), nplanes, _p(dirs),
+                                     int(pli), _p(bskip), bskip.shape[2],
+                                     ctypes.c_long(bskip.shape[1] * bskip.shape[2]), _p(thresholds),
+                                     ncand, int(overlap), int(coeff_shift), _stream()),
+           "odhip_dering_planes")
+    return y
+
+
 # ---- fused lapped stage -----------------------------------------------------
 def forward_pyramid(px, dec, pic_w, pic_h, levels=None, want=None):
     """px: uint8 [nplanes, h, w] CUDA.  Returns a list of int32 [nplanes, h, w]

@@ -367,6 +367,31 @@ int odhip_pvq_ref_candidates(const odhip_pvq_refprep *d_prep, const int32_t *d_t
 int odhip_pvq_synthesis(od_coeff *d_out, const od_coeff *d_y, const int16_t *d_r16, int n,
  long nbands, const int32_t *d_params, const int16_t *d_qm_inv, odhip_stream stream);
 
+/* ---- deringing filter (src/dering.c) ----------------------
+
+   od_dering_hip has od_dering's arguments (src/dering.h:64-69, definition
+   src/dering.c:252-257: ..., nhb, nvb, ...) minus the function table it
+   dispatches through (od_dering_opt_vtbl): host pointers, synchronous, full
+   superblocks (nhb == nvb == 8).  A reference build binds it with
+     #define od_dering(vtbl, ...) od_dering_hip(__VA_ARGS__)
+   at its call sites (src/encode.c:2787,2826; src/decode.c).
+
+   odhip_dering_planes filters EVERY superblock of nplanes planes for ncand
+   candidate thresholds in one launch (what the encoder's per-superblock level
+   search, src/encode.c:2785-2810, evaluates): d_x int16 [plane][h][stride]
+   (h = nvsb*64 >> xdec), d_y int16 [plane][cand][h][stride], d_dirs int32
+   [plane][nvsb*8][nhsb*8] (written when pli == 0, read otherwise), d_bskip the
+   skip map of each plane (rows of skip_stride bytes, planes
+   bskip_plane_stride bytes apart), d_thresholds int32 [plane][cand][nvsb*nhsb]
+   (0 leaves a superblock unchanged). */
+void od_dering_hip(int16_t *y, int ystride, const int16_t *x, int xstride, int nhb, int nvb,
+ int sbx, int sby, int nhsb, int nvsb, int xdec, int dir[8][8], int pli, unsigned char *bskip,
+ int skip_stride, int threshold, int overlap, int coeff_shift);
+int odhip_dering_planes(int16_t *d_y, const int16_t *d_x, int stride, int nhsb, int nvsb, int xdec,
+ int nplanes, int32_t *d_dirs, int pli, const uint8_t *d_bskip, int skip_stride,
+ long bskip_plane_stride, const int32_t *d_thresholds, int ncand, int overlap, int coeff_shift,
+ odhip_stream stream);
+
 /* ---- frame cache: one batched pyramid serving every per-block fdct_2d call ---
 
    The samples a block of level bs sees in the reference encoder depend only on

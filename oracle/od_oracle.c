@@ -1338,6 +1338,257 @@ int odo_pvq_theta(odo_coeff *out, const odo_coeff *x0, const odo_coeff *r0,
   return noref ? qg - 1 : odo_neg_interleave(qg + 1, icgr + 1);
 }
 
+/* ======================================================================== */
+/* Deringing filter, src/dering.c                    */
+/* ======================================================================== */
+
+#define ODO_FILT_BORDER 3                       /* OD_FILT_BORDER, src/dering.h:45 */
+#define ODO_FILT_BSTRIDE (64 + 2*ODO_FILT_BORDER)  /* OD_FILT_BSTRIDE, :46 */
+#define ODO_DERING_VERY_LARGE 30000             /* src/dering.c:127 */
+
+/* OD_DIRECTION_OFFSETS_TABLE, src/dering.c:39-48, as (dy, dx) steps k = 1..3
+   along direction d: 0 = 45 degrees up-right, 2 = horizontal, 6 = vertical. */
+static const signed char ODO_DIR_STEP[8][3][2] = {
+  {{-1, 1}, {-2, 2}, {-3, 3}},
+  {{0, 1}, {-1, 2}, {-1, 3}},
+  {{0, 1}, {0, 2}, {0, 3}},
+  {{0, 1}, {1, 2}, {1, 3}},
+  {{1, 1}, {2, 2}, {3, 3}},
+  {{1, 0}, {2, 1}, {3, 1}},
+  {{1, 0}, {2, 0}, {3, 0}},
+  {{1, 0}, {2, -1}, {3, -1}}
+};
+
+/* od_dir_find8, src/dering.c:61-124: the direction whose lines best predict
+   the 8x8 block (largest sum of squared line sums, each weighted by 840/n for
+   a line of n pixels); *var = (best - orthogonal) >> 10. */
+int odo_dir_find8(const int16_t *img, int stride, int32_t *var, int coeff_shift) {
+  static const int DIV[9] = {0, 840, 420, 280, 210, 168, 140, 120, 105};
+  int32_t cost[8];
+  int partial[8][15];
+  int32_t best_cost;
+  int best_dir;
+  int i;
+  int j;
+  memset(cost, 0, sizeof(cost));
+  memset(partial, 0, sizeof(partial));
+  for (i = 0; i < 8; i++) {
+    for (j = 0; j < 8; j++) {
+      int x;
+      x = img[i*stride + j] >> coeff_shift;
+      partial[0][i + j] += x;
+      partial[1][i + j/2] += x;
+      partial[2][i] += x;
+      partial[3][3 + i - j/2] += x;
+      partial[4][7 + i - j] += x;
+      partial[5][3 - i/2 + j] += x;
+      partial[6][j] += x;
+      partial[7][i/2 + j] += x;
+    }
+  }
+  for (i = 0; i < 8; i++) {
+    cost[2] += partial[2][i]*partial[2][i];
+    cost[6] += partial[6][i]*partial[6][i];
+  }
+  cost[2] *= DIV[8];
+  cost[6] *= DIV[8];
+  for (i = 0; i < 7; i++) {
+    cost[0] += (partial[0][i]*partial[0][i] + partial[0][14 - i]*partial[0][14 - i])*DIV[i + 1];
+    cost[4] += (partial[4][i]*partial[4][i] + partial[4][14 - i]*partial[4][14 - i])*DIV[i + 1];
+  }
+  cost[0] += partial[0][7]*partial[0][7]*DIV[8];
+  cost[4] += partial[4][7]*partial[4][7]*DIV[8];
+  for (i = 1; i < 8; i += 2) {
+    for (j = 0; j < 5; j++) cost[i] += partial[i][3 + j]*partial[i][3 + j];
+    cost[i] *= DIV[8];
+    for (j = 0; j < 3; j++) {
+      cost[i] += (partial[i][j]*partial[i][j] + partial[i][10 - j]*partial[i][10 - j])*DIV[2*j + 2];
+    }
+  }
+  best_cost = 0;
+  best_dir = 0;
+  for (i = 0; i < 8; i++) {
+    if (cost[i] > best_cost) {
+      best_cost = cost[i];
+      best_dir = i;
+    }
+  }
+  *var = (best_cost - cost[(best_dir + 4) & 7]) >> 10;
+  return best_dir;
+}
+
+/* od_filter_dering_direction_c, src/dering.c:132-159: taps {3,2,1} on both
+   sides along the direction, a neighbour counts only if it differs from the
+   centre by less than the threshold.  int16 arithmetic as in the reference. */
+static void odo_dering_direction(int16_t *y, int ystride, const int16_t *in, int ln, int threshold,
+ int dir) {
+  static const int TAPS[3] = {3, 2, 1};
+  int i;
+  int j;
+  int k;
+  for (i = 0; i < 1 << ln; i++) {
+    for (j = 0; j < 1 << ln; j++) {
+      int16_t sum;
+      int16_t xx;
+      xx = in[i*ODO_FILT_BSTRIDE + j];
+      sum = 0;
+      for (k = 0; k < 3; k++) {
+        int o;
+        int16_t p0;
+        int16_t p1;
+        o = ODO_DIR_STEP[dir][k][0]*ODO_FILT_BSTRIDE + ODO_DIR_STEP[dir][k][1];
+        p0 = (int16_t)(in[i*ODO_FILT_BSTRIDE + j + o] - xx);
+        p1 = (int16_t)(in[i*ODO_FILT_BSTRIDE + j - o] - xx);
+        if (abs(p0) < threshold) sum = (int16_t)(sum + TAPS[k]*p0);
+        if (abs(p1) < threshold) sum = (int16_t)(sum + TAPS[k]*p1);
+      }
+      y[i*ystride + j] = (int16_t)(xx + ((sum + 8) >> 4));
+    }
+  }
+}
+
+/* od_filter_dering_orthogonal_c, src/dering.c:172-208. */
+static void odo_dering_orthogonal(int16_t *y, int ystride, const int16_t *in, const int16_t *x,
+ int xstride, int ln, int threshold, int dir) {
+  int i;
+  int j;
+  int offset;
+  offset = dir > 0 && dir < 4 ? ODO_FILT_BSTRIDE : 1;
+  for (i = 0; i < 1 << ln; i++) {
+    for (j = 0; j < 1 << ln; j++) {
+      int16_t athresh;
+      int16_t yy;
+      int16_t sum;
+      int16_t p;
+      int t;
+      t = threshold/3 + abs(in[i*ODO_FILT_BSTRIDE + j] - x[i*xstride + j]);
+      athresh = (int16_t)(threshold < t ? threshold : t);
+      yy = in[i*ODO_FILT_BSTRIDE + j];
+      sum = 0;
+      p = (int16_t)(in[i*ODO_FILT_BSTRIDE + j + offset] - yy);
+      if (abs(p) < athresh) sum = (int16_t)(sum + p);
+      p = (int16_t)(in[i*ODO_FILT_BSTRIDE + j - offset] - yy);
+      if (abs(p) < athresh) sum = (int16_t)(sum + p);
+      p = (int16_t)(in[i*ODO_FILT_BSTRIDE + j + 2*offset] - yy);
+      if (abs(p) < athresh) sum = (int16_t)(sum + p);
+      p = (int16_t)(in[i*ODO_FILT_BSTRIDE + j - 2*offset] - yy);
+      if (abs(p) < athresh) sum = (int16_t)(sum + p);
+      y[i*ystride + j] = (int16_t)(yy + ((3*sum + 8) >> 4));
+    }
+  }
+}
+
+/* OD_THRESH_TABLE_Q8, src/dering.c:225-229 (x^0.16, index = ilog2). */
+static const int16_t ODO_THRESH_TABLE_Q8[18] = {
+  128, 134, 150, 168, 188, 210, 234, 262, 292, 327, 365, 408, 455, 509, 569, 635, 710, 768};
+
+/* od_dering, src/dering.c:252-349 (DAALA_ODINTRIN build): one superblock of
+   nhb x nvb blocks of side 8 >> xdec.  y: [nvb << bsize][ystride]; x points at
+   the superblock inside its plane; dir is written for pli == 0 and read
+   otherwise. */
+void odo_dering(int16_t *y, int ystride, const int16_t *x, int xstride, int nhb, int nvb, int sbx,
+ int sby, int nhsb, int nvsb, int xdec, int dir[8][8], int pli, const unsigned char *bskip,
+ int skip_stride, int threshold, int overlap, int coeff_shift) {
+  int16_t inbuf[ODO_FILT_BSTRIDE*ODO_FILT_BSTRIDE];
+  int16_t *in;
+  int32_t var[8][8];
+  int thresh[8][8];
+  int bsize;
+  int i;
+  int j;
+  int bx;
+  int by;
+  bsize = 3 - xdec;
+  in = inbuf + ODO_FILT_BORDER*ODO_FILT_BSTRIDE + ODO_FILT_BORDER;
+  for (i = 0; i < ODO_FILT_BSTRIDE*ODO_FILT_BSTRIDE; i++) inbuf[i] = ODO_DERING_VERY_LARGE;
+  for (i = -ODO_FILT_BORDER*(sby != 0); i < (nvb << bsize) + ODO_FILT_BORDER*(sby != nvsb - 1); i++) {
+    for (j = -ODO_FILT_BORDER*(sbx != 0); j < (nhb << bsize) + ODO_FILT_BORDER*(sbx != nhsb - 1); j++) {
+      in[i*ODO_FILT_BSTRIDE + j] = x[i*xstride + j];
+    }
+  }
+  if (pli == 0) {
+    for (by = 0; by < nvb; by++) {
+      for (bx = 0; bx < nhb; bx++) {
+        int v1;
+        dir[by][bx] = odo_dir_find8(&x[8*by*xstride + 8*bx], xstride, &var[by][bx], coeff_shift);
+        /* od_compute_thresh, src/dering.c:237-250 */
+        v1 = var[by][bx] >> 6;
+        if (v1 > 32767) v1 = 32767;
+        thresh[by][bx] = (threshold*ODO_THRESH_TABLE_Q8[odo_ilog(v1)] + 128) >> 8;
+      }
+    }
+  }
+  else {
+    for (by = 0; by < nvb; by++) for (bx = 0; bx < nhb; bx++) thresh[by][bx] = threshold;
+  }
+  for (by = 0; by < nvb; by++) {
+    for (bx = 0; bx < nhb; bx++) {
+      int skip;
+      int xstart;
+      int ystart;
+      int xend;
+      int yend;
+      xstart = ystart = 0;
+      xend = yend = 2 >> xdec;
+      if (overlap) {
+        xstart -= sbx != 0;
+        ystart -= sby != 0;
+        xend += sbx != nhsb - 1;
+        yend += sby != nvsb - 1;
+      }
+      skip = 1;
+      for (i = ystart; i < yend; i++) {
+        for (j = xstart; j < xend; j++) {
+          skip = skip && bskip[((by << 1 >> xdec) + i)*skip_stride + (bx << 1 >> xdec) + j];
+        }
+      }
+      if (skip) thresh[by][bx] = 0;
+    }
+  }
+  for (by = 0; by < nvb; by++) {
+    for (bx = 0; bx < nhb; bx++) {
+      odo_dering_direction(&y[(by*ystride << bsize) + (bx << bsize)], ystride,
+       &in[(by*ODO_FILT_BSTRIDE << bsize) + (bx << bsize)], bsize, thresh[by][bx], dir[by][bx]);
+    }
+  }
+  for (i = 0; i < nvb << bsize; i++) {
+    for (j = 0; j < nhb << bsize; j++) in[i*ODO_FILT_BSTRIDE + j] = y[i*ystride + j];
+  }
+  for (by = 0; by < nvb; by++) {
+    for (bx = 0; bx < nhb; bx++) {
+      odo_dering_orthogonal(&y[(by*ystride << bsize) + (bx << bsize)], ystride,
+       &in[(by*ODO_FILT_BSTRIDE << bsize) + (bx << bsize)],
+       &x[(by*xstride << bsize) + (bx << bsize)], xstride, bsize, thresh[by][bx], dir[by][bx]);
+    }
+  }
+}
+
+/* Every superblock of a plane (the loop of src/encode.c:2709-2843 without the
+   level decision): plane of (nhsb*64 >> xdec) x (nvsb*64 >> xdec) samples,
+   thresholds[nvsb*nhsb] per superblock, dirs[nvsb*8][nhsb*8] written for
+   pli == 0 and read otherwise; y is a whole plane with the same stride. */
+void odo_dering_plane(int16_t *y, const int16_t *x, int stride, int nhsb, int nvsb, int xdec,
+ int32_t *dirs, int pli, const unsigned char *bskip, int skip_stride, const int32_t *thresholds,
+ int overlap, int coeff_shift) {
+  int sbx;
+  int sby;
+  int ln;
+  ln = 6 - xdec;
+  for (sby = 0; sby < nvsb; sby++) {
+    for (sbx = 0; sbx < nhsb; sbx++) {
+      int dir[8][8];
+      int bx;
+      int by;
+      for (by = 0; by < 8; by++) for (bx = 0; bx < 8; bx++) dir[by][bx] = dirs[(sby*8 + by)*nhsb*8 + sbx*8 + bx];
+      odo_dering(y + ((long)(sby << ln)*stride + (sbx << ln)), stride,
+       x + ((long)(sby << ln)*stride + (sbx << ln)), stride, 8, 8, sbx, sby, nhsb, nvsb, xdec, dir, pli,
+       bskip + (sby << (4 - xdec))*skip_stride + (sbx << (4 - xdec)), skip_stride,
+       thresholds[sby*nhsb + sbx], overlap, coeff_shift);
+      for (by = 0; by < 8; by++) for (bx = 0; bx < 8; bx++) dirs[(sby*8 + by)*nhsb*8 + sbx*8 + bx] = dir[by][bx];
+    }
+  }
+}
+
 double odo_now(void) {
   struct timespec ts;
   clock_gettime(CLOCK_MONOTONIC, &ts);

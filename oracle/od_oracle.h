@@ -118,6 +118,15 @@ int odo_pvq_theta(odo_coeff *out, const odo_coeff *x0, const odo_coeff *r0, int 
    at every level, dequantisation, inverse at every level): the CPU "port" that
    bench.py times when oracle/_ref is absent.  rate_mode 0 = distortion-only
    choice (what the GPU bench step does), 1 = od_pvq_rate closed form. */
+/* ---- deringing filter, src/dering.c ------------------- */
+int odo_dir_find8(const int16_t *img, int stride, int32_t *var, int coeff_shift);
+void odo_dering(int16_t *y, int ystride, const int16_t *x, int xstride, int nhb, int nvb, int sbx,
+ int sby, int nhsb, int nvsb, int xdec, int dir[8][8], int pli, const unsigned char *bskip,
+ int skip_stride, int threshold, int overlap, int coeff_shift);
+void odo_dering_plane(int16_t *y, const int16_t *x, int stride, int nhsb, int nvsb, int xdec,
+ int32_t *dirs, int pli, const unsigned char *bskip, int skip_stride, const int32_t *thresholds,
+ int overlap, int coeff_shift);
+
 long odo_stage_plane(const uint8_t *px, int px_stride, int w, int h, int dec, int pic_w, int pic_h,
  int pli, const int16_t *qm, const int16_t *qm_inv, const int *qm_off, const int *q_band,
  const int *beta_band, double pvq_norm_lambda, int rate_mode, uint8_t *recon_px);

@@ -74,6 +74,15 @@ REF_EXPORT void ref_idct_2d_batch(int ln, od_coeff *x, const od_coeff *y,
   }
 }
 
+/* ---- deringing (src/dering.c) --------------------------------------------- */
+#include "dering.h"
+REF_EXPORT void ref_dering(int16_t *y, int ystride, const int16_t *x, int xstride, int nhb, int nvb,
+ int sbx, int sby, int nhsb, int nvsb, int xdec, int dir[OD_DERING_NBLOCKS][OD_DERING_NBLOCKS],
+ int pli, unsigned char *bskip, int skip_stride, int threshold, int overlap, int coeff_shift) {
+  od_dering(&OD_DERING_VTBL_C, y, ystride, x, xstride, nhb, nvb, sbx, sby, nhsb, nvsb, xdec, dir, pli,
+   bskip, skip_stride, threshold, overlap, coeff_shift);
+}
+
 /* ---- lapping filters (src/filter.c) ------------------------------------- */
 REF_EXPORT void ref_pre_filter(int f, od_coeff *y, const od_coeff *x) {
   (*OD_PRE_FILTER[f])(y, x);

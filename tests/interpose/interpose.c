@@ -44,7 +44,7 @@ static void *next_sym(const char *name) {
 }
 #define NEXT(type, name) ((type)next_sym(name))
 
-long odhip_interposed_calls[5];
+long odhip_interposed_calls[6];
 
 void od_prefilter_split(od_coeff *c0, int stride, int bs, int f, int hfilter, int vfilter) {
   odhip_interposed_calls[0]++;
@@ -142,4 +142,23 @@ static void interpose_load(const od_coeff *c, int stride, int nhsb, int nvsb, in
     g_bases[g_nbases++] = c;
   }
   odhip_cache_load_plane(g_cache, slot, c, stride, nhsb << 6 >> xdec, nvsb << 6 >> xdec, xdec);
+}
+
+/* od_dering, src/dering.c:252 (call sites src/encode.c:2787,2826): the function
+   table argument is dropped, the HIP kernel implements what it would dispatch to. */
+void od_dering(const void *vtbl, int16_t *y, int ystride, const int16_t *x, int xstride, int nhb, int nvb,
+ int sbx, int sby, int nhsb, int nvsb, int xdec, int dir[8][8], int pli, unsigned char *bskip,
+ int skip_stride, int threshold, int overlap, int coeff_shift) {
+  odhip_interposed_calls[5]++;
+  if (passthrough()) {
+    typedef void (*fn)(const void *, int16_t *, int, const int16_t *, int, int, int, int, int, int, int, int,
+     int (*)[8], int, unsigned char *, int, int, int, int);
+    static fn next;
+    if (!next) next = NEXT(fn, "od_dering");
+    next(vtbl, y, ystride, x, xstride, nhb, nvb, sbx, sby, nhsb, nvsb, xdec, dir, pli, bskip, skip_stride,
+     threshold, overlap, coeff_shift);
+    return;
+  }
+  od_dering_hip(y, ystride, x, xstride, nhb, nvb, sbx, sby, nhsb, nvsb, xdec, dir, pli, bskip, skip_stride,
+   threshold, overlap, coeff_shift);
 }

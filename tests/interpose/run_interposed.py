@@ -47,10 +47,10 @@ n = r.ref_encode_yuv420(P(frames), w, h, nframes, 20, 7, 0, P(out), ctypes.c_lon
 seconds = time.perf_counter() - t0
 assert n == nframes, n
 total = sum(sizes[i] for i in range(n))
-calls = [0] * 5
+calls = [0] * 6
 if ipo is not None:
-    arr = (ctypes.c_long * 5).in_dll(ipo, "odhip_interposed_calls")
-    calls = [arr[i] for i in range(5)]
+    arr = (ctypes.c_long * 6).in_dll(ipo, "odhip_interposed_calls")
+    calls = [arr[i] for i in range(6)]
 stats = [0, 0]
 if interpose == 2:
     hits, misses = ctypes.c_long(), ctypes.c_long()

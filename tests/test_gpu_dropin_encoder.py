@@ -81,7 +81,7 @@ def test_reference_encoder_with_interposed_filters_and_pvq_search():
 
     plain = run(0)
     bound = run(1)
-    assert plain["calls"] == [0] * 5
+    assert plain["calls"] == [0] * 6
     assert all(c > 0 for c in bound["calls"]), bound["calls"]
     assert bound["sizes"] == plain["sizes"]
     assert bound["packets"] == plain["packets"], "packets differ with the HIP surfaces bound"
