@@ -141,6 +141,7 @@ __global__ __launch_bounds__(256) void k_dering(DeringArgs a) {
   __shared__ int s_var[64];
   __shared__ int s_thr[64];
   __shared__ unsigned char s_skip[64];
+  __shared__ __attribute__((aligned(16))) int s_off[64][4];   /* LDS offsets of the three directional taps; [3] = orthogonal step */
   const int tid = threadIdx.x;
   const int plane = blockIdx.z;
   const int sbx = a.window ? a.sbx : blockIdx.x;
@@ -181,6 +182,11 @@ __global__ __launch_bounds__(256) void k_dering(DeringArgs a) {
     else dir = dirs[dpos];
     s_dir[tid] = dir;
     s_var[tid] = var;
+    /* a __constant__ table indexed by a per-lane direction would be read with
+       up to eight different addresses per wavefront: resolve it once per block */
+#pragma unroll
+    for (int k = 0; k < 3; k++) s_off[tid][k] = kDirStep[dir][k][0]*P + kDirStep[dir][k][1];
+    s_off[tid][3] = dir > 0 && dir < 4 ? P : 1;
     /* src/dering.c:306-325 */
     int xstart = 0;
     int ystart = 0;
@@ -227,12 +233,13 @@ __global__ __launch_bounds__(256) void k_dering(DeringArgs a) {
       const int j = px%N;
       const int blk = (i >> BS)*8 + (j >> BS);
       const int th = s_thr[blk];
-      const int dir = s_dir[blk];
+      const int4 offs = *reinterpret_cast<const int4 *>(s_off[blk]);
+      const int off3[3] = {offs.x, offs.y, offs.z};
       const short xx = Ai[i*P + j];
       short sum = 0;
 #pragma unroll
       for (int k = 0; k < 3; k++) {
-        const int o = kDirStep[dir][k][0]*P + kDirStep[dir][k][1];
+        const int o = off3[k];
         const short p0 = (short)(Ai[i*P + j + o] - xx);
         const short p1 = (short)(Ai[i*P + j - o] - xx);
         if (abs((int)p0) < th) sum = (short)(sum + (3 - k)*p0);
@@ -256,8 +263,7 @@ __global__ __launch_bounds__(256) void k_dering(DeringArgs a) {
       const int j = px%N;
       const int blk = (i >> BS)*8 + (j >> BS);
       const int th = s_thr[blk];
-      const int dir = s_dir[blk];
-      const int offset = dir > 0 && dir < 4 ? P : 1;
+      const int offset = s_off[blk][3];
       const short yy = Bi[i*P + j];
       const int tt = th/3 + abs((int)yy - (int)Ai[i*P + j]);
       const short athresh = (short)(th < tt ? th : tt);
