@@ -68,6 +68,20 @@ REF_EXPORT void ref_set_external_dct_vtbl(void **fdct, void **idct) {
   }
 }
 
+/* Writes external 2-D transform tables into an od_state's opt_vtbl (the slots
+   od_state_opt_vtbl_init_x86 overwrites, src/x86/x86state.c:66-91).  Used by
+   tests/interpose's od_state_opt_vtbl_init, which does not see the reference's
+   headers. */
+REF_EXPORT void ref_state_set_dct_vtbl(void *state, void **fdct, void **idct) {
+  od_state *st;
+  int i;
+  st = (od_state *)state;
+  for (i = 0; i < OD_NBSIZES; i++) {
+    if (fdct && fdct[i]) st->opt_vtbl.fdct_2d[i] = (od_dct_func_2d)fdct[i];
+    if (idct && idct[i]) st->opt_vtbl.idct_2d[i] = (od_dct_func_2d)idct[i];
+  }
+}
+
 REF_EXPORT void ref_get_dct_call_counts(long *fdct, long *idct) {
   int i;
   for (i = 0; i < OD_NBSIZES; i++) {

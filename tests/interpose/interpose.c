@@ -35,7 +35,10 @@ void odhip_interpose_set_reference(void *handle) {
   g_reference = handle;
 }
 static void *next_sym(const char *name) {
-  void *p = g_reference ? dlsym(g_reference, name) : NULL;
+  /* dlopen'ed reference (python harness): its handle; a binary linked against
+     the reference with this library in LD_PRELOAD (encoder_example): the next
+     definition in load order. */
+  void *p = g_reference ? dlsym(g_reference, name) : dlsym(RTLD_NEXT, name);
   if (!p) {
     fprintf(stderr, "interpose: no next definition of %s (%s)\n", name, dlerror());
     abort();
@@ -45,6 +48,52 @@ static void *next_sym(const char *name) {
 #define NEXT(type, name) ((type)next_sym(name))
 
 long odhip_interposed_calls[6];
+
+/* ODHIP_INTERPOSE_REPORT=1: print the call counters on stderr at exit (for
+   processes the test cannot ask, i.e. the reference's encoder_example). */
+__attribute__((destructor)) static void interpose_report(void) {
+  const char *e = getenv("ODHIP_INTERPOSE_REPORT");
+  if (e && e[0] == '1') {
+    fprintf(stderr, "odhip_interposed_calls %ld %ld %ld %ld %ld %ld\n", odhip_interposed_calls[0],
+     odhip_interposed_calls[1], odhip_interposed_calls[2], odhip_interposed_calls[3],
+     odhip_interposed_calls[4], odhip_interposed_calls[5]);
+  }
+}
+
+/* od_state_opt_vtbl_init (src/state.c:346-352): the reference's backend
+   dispatch.  With ODHIP_INTERPOSE_VTBL=1 this is the load-time form of the one
+   line of glue in INTEGRATION.md section 1: the reference's own initialisation
+   runs first, then libdaalahip's ten 2-D transforms are written into
+   opt_vtbl.fdct_2d / idct_2d - the shape of od_state_opt_vtbl_init_x86
+   (src/x86/x86state.c:39-97).  The slot offsets inside od_state are known to
+   ref_state_set_dct_vtbl (oracle/ref_encoder_driver.c, compiled with the
+   reference's headers), not to this file. */
+void od_state_opt_vtbl_init(void *state) {
+  typedef void (*init_fn)(void *);
+  typedef void (*set_fn)(void *, void **, void **);
+  static init_fn next;
+  const char *e;
+  if (!next) next = NEXT(init_fn, "od_state_opt_vtbl_init");
+  next(state);
+  e = getenv("ODHIP_INTERPOSE_VTBL");
+  if (e && e[0] == '1') {
+    odhip_dct_func_2d fd[5];
+    odhip_dct_func_2d id[5];
+    set_fn set;
+    if (odhip_init(0) != 0) {
+      fprintf(stderr, "interpose: odhip_init failed\n");
+      abort();
+    }
+    odhip_install_dct_vtbl(fd, id);
+    set = g_reference ? (set_fn)dlsym(g_reference, "ref_state_set_dct_vtbl")
+     : (set_fn)dlsym(RTLD_DEFAULT, "ref_state_set_dct_vtbl");
+    if (!set) {
+      fprintf(stderr, "interpose: ref_state_set_dct_vtbl not found\n");
+      abort();
+    }
+    set(state, (void **)fd, (void **)id);
+  }
+}
 
 void od_prefilter_split(od_coeff *c0, int stride, int bs, int f, int hfilter, int vfilter) {
   odhip_interposed_calls[0]++;
