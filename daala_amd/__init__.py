@@ -15,5 +15,9 @@ from .api import (DaalaHipError, lib, lib_path, init, fdct2d_batch, idct2d_batch
                   pvq_noref_bands,
                   pvq_select_synth_noref, PvqJob, pvq_noref_bands_multi,
                   pvq_select_synth_noref_multi, pvq_choose_multi, inverse_level_pvq, inverse_levels_pvq, pvq_profile, pvq_profile_read, pvq_ref_prepare,
-                  pvq_ref_candidates, pvq_synthesis, REFPREP_RECORD, REFCAND_RECORD, host)
+                  pvq_ref_candidates, pvq_synthesis, REFPREP_RECORD, REFCAND_RECORD, host,
+                  PvqRefJob, pvq_ref_bands_multi, pvq_ref_select_synth_multi,
+                  pvq_ref_set_theta_margin, pvq_ref_theta_probe, REF_SLOTS, REFBAND_RECORD,
+                  REFITEM_RECORD, REFBAND_R_NULL, REFBAND_THETA, REFBAND_NOREF, REFBAND_FLIP,
+                  REFBAND_UNCERTAIN, REFITEM_SEARCHED, REFITEM_WITH_REF)
 from .quant import QuantTables, OD_PVQ_LAMBDA  # noqa: F401

@@ -483,3 +483,125 @@ def pvq_select_synth_noref(coef, bs, qm_inv, q_band, beta_band, pvq_norm_lambda,
     job = PvqJob(coef, bs, None, qm_inv, q_band, beta_band, cands=cands, dq=dq, rate=rate, qg=qg)
     pvq_select_synth_noref_multi([job], pvq_norm_lambda)
     return dq, qg
+
+
+# ---- with-reference band stage on whole planes (odhip_pvq_ref_bands_multi) ---------
+REF_SLOTS = 16
+REFBAND_RECORD = np.dtype([("xshift", "<i4"), ("rshift", "<i4"), ("g", "<i4"), ("gr", "<i4"),
+                           ("cg", "<i4"), ("cgr", "<i4"), ("icgr", "<i4"), ("gain_offset", "<i4"),
+                           ("m", "<i2"), ("s", "i1"), ("flags", "u1"), ("theta", "<i4"),
+                           ("nitems", "<i4"), ("ntheta", "<i4"), ("corr", "<f8"), ("dist0", "<f8")])
+assert REFBAND_RECORD.itemsize == 64
+REFITEM_RECORD = np.dtype([("gain", "<i4"), ("theta", "<i4"), ("ts", "<i4"), ("k", "<i4"),
+                           ("qcg", "<i4"), ("qtheta", "<i4"), ("flags", "<i4"), ("yslot", "<i4"),
+                           ("cos_dist", "<f8"), ("dist", "<f8")])
+assert REFITEM_RECORD.itemsize == 48
+REFBAND_R_NULL, REFBAND_THETA, REFBAND_NOREF, REFBAND_FLIP, REFBAND_UNCERTAIN = 1, 2, 4, 8, 16
+REFITEM_SEARCHED, REFITEM_WITH_REF = 1, 2
+
+
+class _RefJob(ctypes.Structure):
+    _fields_ = [("d_coef", ctypes.c_void_p), ("d_ref", ctypes.c_void_p), ("nplanes", ctypes.c_int),
+                ("w", ctypes.c_int), ("h", ctypes.c_int), ("bs", ctypes.c_int),
+                ("is_keyframe", ctypes.c_int), ("pli", ctypes.c_int), ("d_qm", ctypes.c_void_p),
+                ("d_qm_inv", ctypes.c_void_p), ("q_band", ctypes.POINTER(ctypes.c_int32)),
+                ("beta_band", ctypes.POINTER(ctypes.c_int32)), ("band", ctypes.c_void_p),
+                ("items", ctypes.c_void_p), ("y", ctypes.c_void_p), ("r16", ctypes.c_void_p),
+                ("x16", ctypes.c_void_p), ("xr", ctypes.c_void_p), ("d_rate", ctypes.c_void_p),
+                ("choice", ctypes.c_void_p), ("d_dq", ctypes.c_void_p)]
+
+
+class PvqRefJob:
+    """One (plane set, reference plane set, block size) unit of the with-reference
+    band stage (odhip_pvq_refjob); owns its output and work buffers."""
+
+    def __init__(self, coef, ref, bs, qm, qm_inv, q_band, beta_band, is_keyframe, pli, rate=None):
+        import torch
+        _need(coef, torch.int32, "coef")
+        _need(ref, torch.int32, "ref")
+        assert coef.shape == ref.shape
+        self.coef, self.ref, self.bs, self.qm, self.qm_inv = coef, ref, int(bs), qm, qm_inv
+        self.is_keyframe, self.pli, self.rate = int(is_keyframe), int(pli), rate
+        nplanes, h, w = coef.shape
+        n = 4 << bs
+        self.nblocks = B = nplanes * (h // n) * (w // n)
+        self.nb, self.offsets, self.len = pvq_band_layout(bs)
+        assert len(q_band) == self.nb and len(beta_band) == self.nb
+        self.q_band = (ctypes.c_int32 * 12)(*[int(v) for v in q_band])
+        self.beta_band = (ctypes.c_int32 * 12)(*[int(v) for v in beta_band])
+        dev = coef.device
+        self.band = torch.zeros((B, self.nb, 64), dtype=torch.uint8, device=dev)
+        self.items = torch.zeros((B, self.nb, REF_SLOTS, 48), dtype=torch.uint8, device=dev)
+        self.y = torch.zeros((REF_SLOTS, B, self.len), dtype=torch.int16, device=dev)
+        self.r16 = torch.zeros((B, self.len), dtype=torch.int16, device=dev)
+        self.x16 = torch.zeros((B, self.len), dtype=torch.int16, device=dev)
+        self.xr = torch.zeros((B, self.len), dtype=torch.int16, device=dev)
+        self.choice = torch.zeros((B, self.nb, 8), dtype=torch.int32, device=dev)
+        self.dq = torch.zeros_like(coef)
+        for t, dt, what in ((qm, torch.int16, "qm"), (qm_inv, torch.int16, "qm_inv"),
+                            (rate, torch.float64, "rate")):
+            if t is not None:
+                _need(t, dt, what)
+
+    def struct(self):
+        opt = lambda t: ctypes.c_void_p(t.data_ptr() if t is not None else None)  # noqa: E731
+        nplanes, h, w = self.coef.shape
+        return _RefJob(_p(self.coef), _p(self.ref), nplanes, w, h, self.bs, self.is_keyframe,
+                       self.pli, opt(self.qm), opt(self.qm_inv), self.q_band, self.beta_band,
+                       _p(self.band), _p(self.items), _p(self.y), _p(self.r16), _p(self.x16),
+                       _p(self.xr), opt(self.rate), _p(self.choice), _p(self.dq))
+
+    def unpack(self):
+        """Host copies: record fields [B][nb], item fields [B][nb][REF_SLOTS], y, choice."""
+        rec = self.band.cpu().numpy().view(REFBAND_RECORD)[..., 0]
+        items = self.items.cpu().numpy().view(REFITEM_RECORD)[..., 0]
+        return {"rec": rec, "items": items, "y": self.y.cpu().numpy(),
+                "choice": self.choice.cpu().numpy(), "r16": self.r16.cpu().numpy(),
+                "x16": self.x16.cpu().numpy(), "xr": self.xr.cpu().numpy()}
+
+
+def _refjobs_array(jobs):
+    arr = (_RefJob * len(jobs))()
+    for i, j in enumerate(jobs):
+        arr[i] = j.struct()
+    return arr
+
+
+def pvq_ref_bands_multi(jobs, pvq_norm_lambda, resolve=True):
+    """pvq_theta with a reference up to the rate-dependent choice, for every block
+    and band of every job; resolve=True also settles the bands whose theta is
+    inside the device-acos margin with the host libm (returns how many were
+    re-run)."""
+    arr = _refjobs_array(jobs)
+    _check(lib().odhip_pvq_ref_bands_multi(arr, len(jobs), ctypes.c_double(pvq_norm_lambda),
+                                           _stream()), "odhip_pvq_ref_bands_multi")
+    if not resolve:
+        return 0
+    n = lib().odhip_pvq_ref_resolve(arr, len(jobs), ctypes.c_double(pvq_norm_lambda), _stream())
+    if n < 0:
+        raise DaalaHipError("odhip_pvq_ref_resolve failed with code %d" % n)
+    return n
+
+
+def pvq_ref_select_synth_multi(jobs, pvq_norm_lambda):
+    """The reference's choice among the candidates (cost = dist + lambda*rate, rate
+    table optional), skip rules and decoder-identical synthesis into job.dq."""
+    _check(lib().odhip_pvq_ref_select_synth_multi(_refjobs_array(jobs), len(jobs),
+                                                  ctypes.c_double(pvq_norm_lambda), _stream()),
+           "odhip_pvq_ref_select_synth_multi")
+
+
+def pvq_ref_set_theta_margin(margin, perturb=False):
+    f = lib().odhip_pvq_ref_set_theta_margin
+    f.restype = None
+    f(ctypes.c_double(margin), int(bool(perturb)))
+
+
+def pvq_ref_theta_probe(corr):
+    """.5 + OD_THETA_SCALE*acos(corr) as the device evaluates it."""
+    import torch
+    _need(corr, torch.float64, "corr")
+    out = torch.empty_like(corr)
+    _check(lib().odhip_pvq_ref_theta_probe(_p(corr), _p(out), ctypes.c_long(corr.numel()),
+                                           _stream()), "odhip_pvq_ref_theta_probe")
+    return out

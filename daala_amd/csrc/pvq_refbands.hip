@@ -1,0 +1,894 @@
+/* pvq_refbands.hip - pvq_theta WITH a reference (reference
+   src/pvq_encoder.c:333-641: keyframe chroma predicted from luma, inter frames)
+   for every block and band of a batch of coefficient planes, up to the
+   rate-dependent choice, and the choice + synthesis that follows it.
+
+     k_refb_prep        one band per lane: chroma-from-luma sign flip of the block
+                        (od_pvq_encode, :846-872), gather of x and r in coding
+                        order (od_raster_to_coding_order, src/partition.c:144),
+                        QM scaling, gains, correlation, initial distortion
+                        (:381-455), od_compute_householder / od_apply_householder
+                        (src/pvq.c:498-623), theta = floor(.5 + OD_THETA_SCALE *
+                        acos(corr)) (:478) with the DEVICE acos and the
+                        uncertainty test described in include/daala_hip.h
+     k_refb_cands       the (gain, theta) candidates in the reference's stable
+                        (k, gain) order (:466-504) followed by the no-reference
+                        candidates (:571-581)
+     k_refb_search      one band per lane: the candidate loop (:506-565) - pruning,
+                        K-pulse searches on the reflected vector chained through
+                        prev_k, distortions - then the no-reference loop
+                        (:578-595)
+     k_refb_select      `cost < best_cost` / `cost <= best_cost` (:553, :600),
+                        skip rules (:611-622), od_gain_expand and
+                        od_pvq_synthesis_partial (:623-633, src/pvq.c:1037-1115),
+                        od_coding_order_to_raster
+
+   The libm call of the path: the reference's theta comes from glibc's acos.
+   Everything downstream depends only on the INTEGER theta, so the device value
+   is the reference's whenever OD_THETA_SCALE*acos(corr) + .5 is not within the
+   margin (1e-9, 30x the worst disagreement of two <= 2-ulp implementations at
+   this magnitude) of an integer; the bands inside the margin are listed and
+   odhip_pvq_ref_resolve recomputes their theta on the host with the very libm
+   the reference calls, re-running a band when it differs.
+
+   First version of this stage: one band per lane throughout, no sorting by
+   pulse count, gathers per lane (DESIGN.md lists what the no-reference stage
+   did about each of these).  All double arithmetic is one IEEE operation per
+   reference operation (-ffp-contract=off). */
+#include "../../include/daala_hip.h"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include "od_common.cuh"
+#include "od_pvq_math.cuh"
+#include "gen/od_scan_tables.h"
+#include "pvq_search.cuh"
+
+namespace {
+
+constexpr int kMaxJobs = 16;
+constexpr int kMaxItems = kMaxJobs*ODHIP_MAX_BANDS;
+constexpr int kSlots = ODHIP_PVQ_REF_SLOTS;
+constexpr int kUncCap = 1 << 16;
+constexpr double kDefaultMargin = 1e-9;
+
+struct RJob {
+  const od_coeff *coef;
+  const od_coeff *ref;
+  const int16_t *qm;
+  const int16_t *qm_inv;
+  odhip_pvq_refband *rec;
+  odhip_pvq_refitem *items;
+  int16_t *y;
+  int16_t *r16;
+  int16_t *x16;
+  int16_t *xr;
+  const double *rate;
+  int32_t *choice;
+  od_coeff *dq;
+  long nblocks;
+  int nplanes;
+  int w;
+  int h;
+  int bs;
+  int nb_bands;
+  int len;
+  int bw;
+  int bh;
+  int is_keyframe;
+  int pli;
+  int q[ODHIP_MAX_BANDS];
+  int beta[ODHIP_MAX_BANDS];
+  int off[ODHIP_MAX_BANDS + 1];
+};
+
+struct RItems {
+  int nitems;
+  int perturb;
+  double lambda;
+  double margin;
+  int wg_start[kMaxItems + 1];
+  unsigned char job[kMaxItems];
+  unsigned char band[kMaxItems];
+};
+
+/* One band whose theta lies inside the margin (written by k_refb_prep) or has
+   to be re-run with the host's theta (read by the *_list kernels). */
+struct Unc {
+  int job;
+  int band;
+  unsigned blk;
+  int theta;
+  double corr;
+};
+
+__device__ RJob g_rjobs[kMaxJobs];
+__constant__ unsigned char kRScanXY[OD_SCAN_LEN][2];
+__device__ unsigned g_unc_count;
+__device__ Unc g_unc[kUncCap];
+
+__device__ __forceinline__ int find_item(const RItems &it, int wg) {
+  int lo = 0;
+  int hi = it.nitems - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (it.wg_start[mid] <= wg) lo = mid;
+    else hi = mid - 1;
+  }
+  return lo;
+}
+
+/* Offset of block blk inside its plane set. */
+__device__ __forceinline__ long block_base(const RJob &j, long blk) {
+  const int N = 4 << j.bs;
+  const long per = (long)j.bw*j.bh;
+  const int p = (int)(blk/per);
+  const int rem = (int)(blk - p*per);
+  const int by = rem/j.bw;
+  const int bx = rem - by*j.bw;
+  return (long)p*j.w*j.h + (long)by*N*j.w + bx*N;
+}
+
+__device__ __forceinline__ long coef_pos(const RJob &j, int c) {
+  return (long)kRScanXY[c][1]*j.w + kRScanXY[c][0];
+}
+
+constexpr double kPi = 3.14159265358979323846;       /* M_PI */
+constexpr double kThetaScale = 32768*2./kPi;         /* OD_THETA_SCALE, src/pvq.h:78 */
+
+/* .5 + OD_THETA_SCALE*acos(corr): the argument of the floor at
+   src/pvq_encoder.c:478 (OD_ROUND32, src/odintrin.h:169). */
+__device__ __forceinline__ double theta_arg(double corr) {
+  return .5 + kThetaScale*acos(corr);
+}
+
+__global__ __launch_bounds__(kWave) void k_theta_probe(const double *corr, double *t, long n) {
+  const long i = (long)blockIdx.x*kWave + threadIdx.x;
+  if (i < n) t[i] = theta_arg(corr[i]);
+}
+
+/* ---- preparation ---------------------------------------------------------------- */
+__global__ __launch_bounds__(kWave) void k_refb_prep(RItems it) {
+  const int item = find_item(it, blockIdx.x);
+  const int job = it.job[item];
+  const RJob &jb = g_rjobs[job];
+  const int band = it.band[item];
+  const long blk = (long)(blockIdx.x - it.wg_start[item])*kWave + threadIdx.x;
+  if (blk >= jb.nblocks) return;
+  const int off = jb.off[band];
+  const int n = jb.off[band + 1] - off;
+  const long base = block_base(jb, blk);
+  const od_coeff *x0 = jb.coef + base;
+  const od_coeff *r0 = jb.ref + base;
+  const int16_t *qm = jb.qm + off;
+  const int cfl_enabled = jb.is_keyframe && jb.pli != 0;
+  /* chroma-from-luma sign, src/pvq_encoder.c:846-872: OD_QM_SHIFT +
+     OD_CFL_FLIP_SHIFT = 11 + 4, doubled */
+  int flip = 0;
+  if (cfl_enabled) {
+    uint32_t xy = 0;
+    for (int c = jb.off[0]; c < jb.off[1]; c++) {
+      const long p = coef_pos(jb, c);
+      const int32_t q = jb.qm[c];
+      const int32_t rq = (int32_t)((uint32_t)r0[p]*(uint32_t)q);
+      const int32_t inq = (int32_t)((uint32_t)x0[p]*(uint32_t)q);
+      xy += (uint32_t)((rq*(int64_t)inq) >> 30);
+    }
+    flip = (int32_t)xy < 0;
+  }
+  /* od_vector_log_mag, src/pvq.c:472-484; src/pvq_encoder.c:381-385 */
+  int sx = 0;
+  int sr = 0;
+  for (int i = 0; i < n; i++) {
+    const long p = coef_pos(jb, off + i);
+    const int tx = (int16_t)(x0[p] >> 8);
+    const int rv = flip ? -r0[p] : r0[p];
+    const int tr = (int16_t)(rv >> 8);
+    sx += tx*tx;
+    sr += tr*tr;
+  }
+  int xshift = 8 + 1 + odq_ilog(n + sx)/2 - 15;
+  xshift = xshift > 0 ? xshift : 0;
+  int rshift = 8 + 1 + odq_ilog(n + sr)/2 - 14;
+  rshift = rshift > 0 ? rshift : 0;
+  int16_t *x16 = jb.x16 + blk*jb.len + off;
+  int16_t *r16 = jb.r16 + blk*jb.len + off;
+  int16_t *xr = jb.xr + blk*jb.len + off;
+  double corr = 0;
+  int r_null = 1;
+  int accx = 0;
+  int accr = 0;
+  for (int i = 0; i < n; i++) {
+    const long p = coef_pos(jb, off + i);
+    const int32_t xv0 = x0[p];
+    const int32_t rv0 = flip ? -r0[p] : r0[p];
+    const int16_t xv = (int16_t)odq_shr_round((int32_t)((uint32_t)xv0*(uint32_t)(int32_t)qm[i]),
+     ODQ_QM_SHIFT + xshift);
+    const int16_t rv = (int16_t)odq_shr_round((int32_t)((uint32_t)rv0*(uint32_t)(int32_t)qm[i]),
+     ODQ_QM_SHIFT + rshift);
+    x16[i] = xv;
+    r16[i] = rv;
+    corr += odq_mult16_16(xv, rv);
+    if (rv0) r_null = 0;
+    accx += xv*(int)xv;
+    accr += rv*(int)rv;
+  }
+  const int q0 = jb.q[band];
+  const int beta = jb.beta[band];
+  int32_t g;
+  int32_t gr;
+  const int32_t cg = odq_gain_from_acc(accx, q0, beta, xshift, &g);
+  int32_t cgr = odq_gain_from_acc(accr, q0, beta, rshift, &gr);
+  if (cfl_enabled) cgr = 256;
+  const int icgr = odq_shr_round(cgr, ODQ_CGAIN_SHIFT);
+  const int32_t gain_offset = cgr - odq_shl32(icgr, ODQ_CGAIN_SHIFT);
+  /* src/pvq_encoder.c:436-438 */
+  corr = __ddiv_rn(corr, 1e-100 + __ddiv_rn(g*(double)gr, (double)odq_shl32(1, xshift + rshift)));
+  corr = corr < 1. ? corr : 1.;
+  corr = corr > -1. ? corr : -1.;
+  /* initial candidate, :417-455 */
+  const double s2 = (1./256)*(1./256);
+  double dist0 = ((1.4*cg)*cg)*s2;
+  if (!jb.is_keyframe && icgr == 0) {
+    const int32_t scgr = gain_offset > 0 ? gain_offset : 0;
+    dist0 = (1.4*(cg - scgr))*(cg - scgr) + (scgr*(double)cg)*(2 - 2*corr);
+    dist0 *= s2;
+  }
+  int m = 0;
+  int s = 1;
+  int flags = (r_null ? ODHIP_REFBAND_R_NULL : 0) | (flip ? ODHIP_REFBAND_FLIP : 0);
+  int32_t theta = 0;
+  if (!r_null && corr > 0) {
+    flags |= ODHIP_REFBAND_THETA;
+    const double u = theta_arg(corr);
+    theta = (int32_t)floor(u);
+    if (fabs(u - rint(u)) < it.margin) {
+      flags |= ODHIP_REFBAND_UNCERTAIN;
+      if (it.perturb) theta += 1;
+      const unsigned slot = atomicAdd(&g_unc_count, 1u);
+      if (slot < (unsigned)kUncCap) {
+        Unc e;
+        e.job = job;
+        e.band = band;
+        e.blk = (unsigned)blk;
+        e.theta = theta;
+        e.corr = corr;
+        g_unc[slot] = e;
+      }
+    }
+    /* od_compute_householder, src/pvq.c:498-521: first largest |r_i| wins */
+    int maxr = 0;
+    for (int i = 0; i < n; i++) {
+      const int a = abs((int)r16[i]);
+      if (a > maxr) {
+        maxr = (int16_t)a;
+        m = i;
+      }
+    }
+    s = r16[m] > 0 ? 1 : -1;
+    r16[m] = (int16_t)(r16[m] + odq_shr_round(gr*s, rshift));
+    /* od_apply_householder, src/pvq.c:560-623 */
+    int32_t l2r = 0;
+    int32_t proj = 0;
+    for (int i = 0; i < n; i++) {
+      l2r += odq_mult16_16(r16[i], r16[i]);
+      proj += odq_mult16_16(r16[i], x16[i]);
+    }
+    const int l2r_shift = (odq_ilog(l2r) - 1) - 14;
+    const int16_t l2r_norm = (int16_t)odq_vshr_round(l2r, l2r_shift);
+    const int16_t rcp = odq_rcp(l2r_norm);
+    const int proj_shift = (odq_ilog(abs(proj)) - 1) - 14;
+    const int16_t proj_norm = (int16_t)odq_vshr_round(proj, proj_shift);
+    const int16_t proj_1 = (int16_t)odq_mult16_16_q15(proj_norm, rcp);
+    int outshift = 14 - proj_shift - 1 + l2r_shift;
+    if (outshift > 30) outshift = 30;
+    /* the reflected vector without element m (src/pvq_encoder.c:481) */
+    for (int i = 0; i < n; i++) {
+      int32_t tmp = odq_mult16_16(r16[i], proj_1);
+      tmp = outshift >= 0 ? odq_shr_round(tmp, outshift) : odq_shl32(tmp, -outshift);
+      const int16_t v = (int16_t)(x16[i] - tmp);
+      if (i < m) xr[i] = v;
+      else if (i > m) xr[i - 1] = v;
+    }
+  }
+  odhip_pvq_refband o;
+  o.xshift = xshift;
+  o.rshift = rshift;
+  o.g = g;
+  o.gr = gr;
+  o.cg = cg;
+  o.cgr = cgr;
+  o.icgr = icgr;
+  o.gain_offset = gain_offset;
+  o.m = (int16_t)m;
+  o.s = (int8_t)s;
+  o.flags = (uint8_t)flags;
+  o.theta = theta;
+  o.nitems = 0;
+  o.ntheta = 0;
+  o.corr = corr;
+  o.dist0 = dist0;
+  jb.rec[blk*jb.nb_bands + band] = o;
+}
+
+/* ---- candidate lists -------------------------------------------------------------- */
+__device__ __forceinline__ void refb_candidates(const RJob &jb, int band, long blk,
+ int theta_override) {
+  odhip_pvq_refband *rp = jb.rec + blk*jb.nb_bands + band;
+  odhip_pvq_refband r = *rp;
+  if (theta_override >= 0) r.theta = theta_override;
+  const int n = jb.off[band + 1] - jb.off[band];
+  const int beta = jb.beta[band];
+  odhip_pvq_refitem *items = jb.items + (blk*jb.nb_bands + band)*kSlots;
+  int nitems = 0;
+  if (r.flags & ODHIP_REFBAND_THETA) {
+    const int gain_bound = (r.cg - r.gain_offset) >> ODQ_CGAIN_SHIFT;
+    const double scale_1 = __ddiv_rn(1., kThetaScale);   /* OD_THETA_SCALE_1 */
+    for (int i = gain_bound - 1 > 1 ? gain_bound - 1 : 1; i <= gain_bound + 1; i++) {
+      const int32_t qcg = odq_shl32(i, ODQ_CGAIN_SHIFT) + r.gain_offset;
+      const int ts = odq_pvq_compute_max_theta(qcg, beta);
+      /* same left-to-right products as src/pvq_encoder.c:482-484 */
+      const double t = __ddiv_rn(((r.theta*scale_1)*2), kPi)*ts;
+      int lower = (int)floor(.5 + t) - 2;
+      if (lower < 0) lower = 0;
+      int upper = (int)ceil(t);
+      if (upper > ts - 1) upper = ts - 1;
+      for (int j = lower; j <= upper && nitems < kSlots - 2; j++) {
+        odhip_pvq_refitem c;
+        c.gain = i;
+        c.theta = j;
+        c.ts = ts;
+        c.k = odq_compute_k_ref(j, n);
+        c.qcg = qcg;
+        c.qtheta = odq_pvq_compute_theta(j, ts);
+        c.flags = ODHIP_REFITEM_WITH_REF;
+        c.yslot = -1;
+        c.cos_dist = 0;
+        c.dist = 0;
+        /* stable insertion by (k, gain): items_compare, src/pvq_encoder.c:301-305
+           (glibc's qsort is a stable merge sort at this size) */
+        int pos = nitems;
+        while (pos > 0) {
+          const odhip_pvq_refitem q = items[pos - 1];
+          const int cmp = q.k == c.k ? q.gain - c.gain : q.k - c.k;
+          if (cmp <= 0) break;
+          items[pos] = q;
+          pos--;
+        }
+        items[pos] = c;
+        nitems++;
+      }
+    }
+  }
+  const int ntheta = nitems;
+  int flags = r.flags & ~ODHIP_REFBAND_NOREF;
+  /* src/pvq_encoder.c:571-581 */
+  if ((jb.is_keyframe && jb.pli == 0) || r.corr < .5 || r.cg < odq_shl32(2, ODQ_CGAIN_SHIFT)) {
+    flags |= ODHIP_REFBAND_NOREF;
+    const int gain_bound = r.cg >> ODQ_CGAIN_SHIFT;
+    for (int i = gain_bound > 1 ? gain_bound : 1; i <= gain_bound + 1; i++) {
+      odhip_pvq_refitem c;
+      c.gain = i;
+      c.theta = -1;
+      c.ts = 0;
+      c.qcg = odq_shl32(i, ODQ_CGAIN_SHIFT);
+      c.k = odq_compute_k_noref(c.qcg, n, beta);
+      c.qtheta = 0;
+      c.flags = 0;
+      c.yslot = -1;
+      c.cos_dist = 0;
+      c.dist = 0;
+      items[nitems++] = c;
+    }
+  }
+  rp->theta = r.theta;
+  rp->flags = (uint8_t)flags;
+  rp->nitems = nitems;
+  rp->ntheta = ntheta;
+}
+
+__global__ __launch_bounds__(kWave) void k_refb_cands(RItems it) {
+  const int item = find_item(it, blockIdx.x);
+  const RJob &jb = g_rjobs[it.job[item]];
+  const long blk = (long)(blockIdx.x - it.wg_start[item])*kWave + threadIdx.x;
+  if (blk >= jb.nblocks) return;
+  refb_candidates(jb, it.band[item], blk, -1);
+}
+
+__global__ __launch_bounds__(kWave) void k_refb_cands_list(const Unc *list, int count) {
+  const int i = blockIdx.x*kWave + threadIdx.x;
+  if (i >= count) return;
+  const Unc e = list[i];
+  refb_candidates(g_rjobs[e.job], e.band, e.blk, e.theta);
+}
+
+/* ---- the candidate loops ---------------------------------------------------------- */
+__device__ __forceinline__ void store_pulses(int16_t *dst, const short *xs, const unsigned short *ys,
+ int lane, int n) {
+  for (int j = 0; j < n; j++) {
+    const int yj = ys[j*kWave + lane];
+    dst[j] = (int16_t)(xs[j*kWave + lane] < 0 ? -yj : yj);
+  }
+}
+
+__device__ __forceinline__ void refb_search(const RJob &jb, int band, long blk, int lane, short *xs,
+ unsigned short *ys, double lambda) {
+  const odhip_pvq_refband r = jb.rec[blk*jb.nb_bands + band];
+  const int off = jb.off[band];
+  const int n = jb.off[band + 1] - off;
+  odhip_pvq_refitem *items = jb.items + (blk*jb.nb_bands + band)*kSlots;
+  const double s2 = (1./256)*(1./256);   /* OD_CGAIN_SCALE_2 */
+  const double t1 = 1./32768;            /* OD_TRIG_SCALE_1 */
+  const int32_t cg = r.cg;
+  const double dist0 = r.dist0;
+  if (r.ntheta > 0) {
+    const int16_t *xr = jb.xr + blk*jb.len + off;
+    for (int j = 0; j < n - 1; j++) xs[j*kWave + lane] = xr[j];
+    int prev_k = 0;
+    int cur_slot = -1;
+    double cos_dist = 0;
+    const int32_t theta = r.theta;
+    for (int idx = 0; idx < r.ntheta; idx++) {
+      odhip_pvq_refitem *ip = items + idx;
+      const int32_t qcg = ip->qcg;
+      const int32_t qtheta = ip->qtheta;
+      const int k = ip->k;
+      /* src/pvq_encoder.c:526-531 */
+      double dist_theta = 2 - (2.*odq_pvq_cos(theta - qtheta))*t1;
+      double dist = (1.4*(qcg - cg))*(qcg - cg) + (qcg*(double)cg)*dist_theta;
+      dist *= s2;
+      if (dist > dist0 + 1.0*lambda && k != 0) {
+        ip->flags = ODHIP_REFITEM_WITH_REF;
+        ip->yslot = -1;
+        continue;
+      }
+      const double sin_prod = ((odq_pvq_sin(theta)*t1)*odq_pvq_sin(qtheta))*t1;
+      if (k == 0) {
+        cos_dist = 0;
+        cur_slot = -1;
+      }
+      else if (k != prev_k) {
+        double yy;
+        cos_dist = od_pvq_search_lane(xs, ys, lane, n - 1, k, prev_k,
+         ((qcg*(double)cg)*sin_prod)*s2, lambda, &yy);
+        cur_slot = idx;
+        store_pulses(jb.y + ((long)idx*jb.nblocks + blk)*jb.len + off, xs, ys, lane, n - 1);
+      }
+      prev_k = k;
+      /* :548-552 */
+      dist_theta = 2 - (2.*odq_pvq_cos(theta - qtheta))*t1 + sin_prod*(2 - 2*cos_dist);
+      dist = (1.4*(qcg - cg))*(qcg - cg) + (qcg*(double)cg)*dist_theta;
+      dist *= s2;
+      ip->flags = ODHIP_REFITEM_WITH_REF | ODHIP_REFITEM_SEARCHED;
+      ip->yslot = cur_slot;
+      ip->cos_dist = cos_dist;
+      ip->dist = dist;
+    }
+  }
+  if (r.nitems > r.ntheta) {
+    const int16_t *x16 = jb.x16 + blk*jb.len + off;
+    for (int j = 0; j < n; j++) xs[j*kWave + lane] = x16[j];
+    int prev_k = 0;
+    for (int idx = r.ntheta; idx < r.nitems; idx++) {
+      odhip_pvq_refitem *ip = items + idx;
+      const int32_t qcg = ip->qcg;
+      const int k = ip->k;
+      /* :585-595 */
+      double dist = (1.4*(qcg - cg))*(qcg - cg);
+      dist *= s2;
+      if (dist > dist0 && k != 0) {
+        ip->flags = 0;
+        ip->yslot = -1;
+        continue;
+      }
+      double yy;
+      const double cos_dist = od_pvq_search_lane(xs, ys, lane, n, k, prev_k, (qcg*(double)cg)*s2,
+       lambda, &yy);
+      prev_k = k;
+      store_pulses(jb.y + ((long)idx*jb.nblocks + blk)*jb.len + off, xs, ys, lane, n);
+      dist = (1.4*(qcg - cg))*(qcg - cg) + (qcg*(double)cg)*(2 - 2*cos_dist);
+      dist *= s2;
+      ip->flags = ODHIP_REFITEM_SEARCHED;
+      ip->yslot = idx;
+      ip->cos_dist = cos_dist;
+      ip->dist = dist;
+    }
+  }
+}
+
+__global__ __launch_bounds__(kWave) void k_refb_search(RItems it) {
+  extern __shared__ __attribute__((aligned(16))) unsigned short lds[];
+  od_rsqrt_init(threadIdx.x);
+  const int item = find_item(it, blockIdx.x);
+  const RJob &jb = g_rjobs[it.job[item]];
+  const int band = it.band[item];
+  const int n = jb.off[band + 1] - jb.off[band];
+  short *xs = (short *)lds;
+  unsigned short *ys = lds + n*kWave;
+  const long blk = (long)(blockIdx.x - it.wg_start[item])*kWave + threadIdx.x;
+  if (blk >= jb.nblocks) return;
+  refb_search(jb, band, blk, threadIdx.x, xs, ys, it.lambda);
+}
+
+/* One listed band per wavefront (lane 0): the list is a handful of bands. */
+__global__ __launch_bounds__(kWave) void k_refb_search_list(const Unc *list, int count, double lambda) {
+  extern __shared__ __attribute__((aligned(16))) unsigned short lds[];
+  od_rsqrt_init(threadIdx.x);
+  if (threadIdx.x != 0 || (int)blockIdx.x >= count) return;
+  const Unc e = list[blockIdx.x];
+  short *xs = (short *)lds;
+  unsigned short *ys = lds + 128*kWave;
+  refb_search(g_rjobs[e.job], e.band, e.blk, 0, xs, ys, lambda);
+}
+
+/* ---- choice + synthesis ----------------------------------------------------------- */
+__device__ __forceinline__ int neg_interleave(int x, int ref) { /* src/pvq_encoder.c:235-239 */
+  if (x < ref) return -2*(x - ref) - 1;
+  if (x < 2*ref) return 2*(x - ref);
+  return x - 1;
+}
+
+__global__ __launch_bounds__(kWave) void k_refb_select(RItems it) {
+  const int item = find_item(it, blockIdx.x);
+  const RJob &jb = g_rjobs[it.job[item]];
+  const int band = it.band[item];
+  const long blk = (long)(blockIdx.x - it.wg_start[item])*kWave + threadIdx.x;
+  if (blk >= jb.nblocks) return;
+  const long bi = blk*jb.nb_bands + band;
+  const odhip_pvq_refband r = jb.rec[bi];
+  const odhip_pvq_refitem *items = jb.items + bi*kSlots;
+  const double *rate = jb.rate ? jb.rate + bi*(kSlots + 1) : nullptr;
+  const double lambda = it.lambda;
+  const int off = jb.off[band];
+  const int n = jb.off[band + 1] - off;
+  const int cfl_enabled = jb.is_keyframe && jb.pli != 0;
+  /* :417-455 */
+  double best_cost = r.dist0 + lambda*(rate ? rate[0] : 0.);
+  int qg = 0;
+  int noref = jb.is_keyframe ? 1 : 0;
+  int itheta = jb.is_keyframe ? -1 : 0;
+  int max_theta = 0;
+  int best_k = 0;
+  int32_t best_qtheta = 0;
+  int chosen = -1;
+  for (int idx = 0; idx < r.ntheta; idx++) {
+    const odhip_pvq_refitem c = items[idx];
+    if (!(c.flags & ODHIP_REFITEM_SEARCHED)) continue;
+    const double cost = c.dist + lambda*(rate ? rate[1 + idx] : 0.);
+    if (cost < best_cost) {
+      best_cost = cost;
+      qg = c.gain;
+      best_k = c.k;
+      best_qtheta = c.qtheta;
+      itheta = c.theta;
+      max_theta = c.ts;
+      noref = 0;
+      chosen = idx;
+    }
+  }
+  for (int idx = r.ntheta; idx < r.nitems; idx++) {
+    const odhip_pvq_refitem c = items[idx];
+    if (!(c.flags & ODHIP_REFITEM_SEARCHED)) continue;
+    const double cost = c.dist + lambda*(rate ? rate[1 + idx] : 0.);
+    if (cost <= best_cost) {
+      best_cost = cost;
+      qg = c.gain;
+      noref = 1;
+      best_k = c.k;
+      itheta = -1;
+      max_theta = 0;
+      chosen = idx;
+    }
+  }
+  /* :611-622 */
+  int skip = 0;
+  if (noref) {
+    if (qg == 0) skip = 1;
+  }
+  else {
+    if (!jb.is_keyframe && qg == 0) skip = r.icgr ? 1 : 2;
+    if (qg == r.icgr && itheta == 0 && !cfl_enabled) skip = 2;
+  }
+  int32_t *ch = jb.choice + bi*8;
+  ch[0] = chosen;
+  ch[1] = qg;
+  ch[2] = noref;
+  ch[3] = itheta;
+  ch[4] = max_theta;
+  ch[5] = best_k;
+  ch[6] = skip;
+  ch[7] = jb.is_keyframe ? (noref ? qg : neg_interleave(qg, r.icgr))
+   : (noref ? qg - 1 : neg_interleave(qg + 1, r.icgr + 1));
+  /* synthesis, :623-633 */
+  const long base = block_base(jb, blk);
+  od_coeff *out = jb.dq + base;
+  if (band == 0) out[0] = jb.coef[base];
+  if (skip) {
+    const int flip = (r.flags & ODHIP_REFBAND_FLIP) != 0;
+    for (int i = 0; i < n; i++) {
+      const long p = coef_pos(jb, off + i);
+      const od_coeff rv = jb.ref[base + p];
+      out[p] = skip == 2 ? (flip ? -rv : rv) : 0;
+    }
+    return;
+  }
+  const int yslot = chosen >= 0 ? items[chosen].yslot : -1;
+  const int16_t *yp = yslot >= 0 ? jb.y + ((long)yslot*jb.nblocks + blk)*jb.len + off : nullptr;
+  const int16_t *qm_inv = jb.qm_inv + off;
+  const int32_t g = odq_gain_expand(odq_shl32(qg, ODQ_CGAIN_SHIFT) + (noref ? 0 : r.gain_offset),
+   jb.q[band], jb.beta[band]);
+  /* od_pvq_synthesis_partial, src/pvq.c:1037-1115 */
+  const int nn = n - (!noref);
+  int yy = 0;
+  for (int i = 0; i < nn; i++) {
+    const int v = yp ? yp[i] : 0;
+    yy += v*v;
+  }
+  int gshift = odq_ilog(g) - 14;
+  gshift = gshift > 0 ? gshift : 0;
+  int32_t scale = 0;
+  if (yy != 0) {
+    int rsqrt_shift;
+    const int16_t rsqrt = odq_rsqrt(yy, &rsqrt_shift);
+    scale = odq_vshr_round(rsqrt*(int64_t)g, rsqrt_shift + gshift - 16);
+  }
+  const int qshift = ODQ_QM_INV_SHIFT - gshift;
+  if (noref) {
+    for (int i = 0; i < n; i++) {
+      const int32_t x = (int32_t)odq_mult16_32_q16(yp ? yp[i] : 0, scale);
+      out[coef_pos(jb, off + i)] = odq_shr_round(x*qm_inv[i], qshift);
+    }
+    return;
+  }
+  const int16_t *r16 = jb.r16 + blk*jb.len + off;
+  const int m = r.m;
+  const int s = r.s;
+  const int32_t theta = best_qtheta;
+  /* src/pvq.c:1094-1114: the two double products by 2^-15 are exact */
+  scale = (int32_t)floor(.5 + (scale*(1./32768))*odq_pvq_sin(theta));
+  const int16_t xm = (int16_t)floor(.5 + ((-s*odq_shr_round(g, gshift))*(1./32768))*odq_pvq_cos(theta));
+  int32_t l2r = 0;
+  int32_t proj = 0;
+  for (int i = 0; i < n; i++) {
+    const int16_t xi = i == m ? xm
+     : (int16_t)odq_mult16_32_q16(yp ? yp[i < m ? i : i - 1] : 0, scale);
+    l2r += odq_mult16_16(r16[i], r16[i]);
+    proj += odq_mult16_16(r16[i], xi);
+  }
+  const int l2r_shift = (odq_ilog(l2r) - 1) - 14;
+  const int16_t l2r_norm = (int16_t)odq_vshr_round(l2r, l2r_shift);
+  const int16_t rcp = odq_rcp(l2r_norm);
+  const int proj_shift = (odq_ilog(abs(proj)) - 1) - 14;
+  const int16_t proj_norm = (int16_t)odq_vshr_round(proj, proj_shift);
+  const int16_t proj_1 = (int16_t)odq_mult16_16_q15(proj_norm, rcp);
+  int outshift = 14 - proj_shift - 1 + l2r_shift;
+  if (outshift > 30) outshift = 30;
+  for (int i = 0; i < n; i++) {
+    const int16_t xi = i == m ? xm
+     : (int16_t)odq_mult16_32_q16(yp ? yp[i < m ? i : i - 1] : 0, scale);
+    int32_t tmp = odq_mult16_16(r16[i], proj_1);
+    tmp = outshift >= 0 ? odq_shr_round(tmp, outshift) : odq_shl32(tmp, -outshift);
+    const int16_t v = (int16_t)(xi - tmp);
+    out[coef_pos(jb, off + i)] = odq_shr_round(v*qm_inv[i], qshift);
+  }
+}
+
+/* ---- host side --------------------------------------------------------------------- */
+bool g_tables_uploaded = false;
+double g_margin = kDefaultMargin;
+int g_perturb = 0;
+
+int upload_tables(void) {
+  if (g_tables_uploaded) return ODHIP_SUCCESS;
+  ODHIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(kRScanXY), OD_SCAN_XY, sizeof(OD_SCAN_XY)));
+  g_tables_uploaded = true;
+  return ODHIP_SUCCESS;
+}
+
+/* mode 0: band stage; 1: choice + synthesis */
+int fill_job(RJob &d, const odhip_pvq_refjob &j, int mode) {
+  if (!j.d_coef || !j.d_ref || !j.q_band || !j.beta_band || j.bs < 0 || j.bs >= ODHIP_NBSIZES
+   || j.nplanes <= 0 || !j.band || !j.items || !j.y || !j.r16) {
+    return ODHIP_EINVAL;
+  }
+  if (((uintptr_t)j.band & 63) || ((uintptr_t)j.items & 15)) return ODHIP_EINVAL;
+  if (mode == 0 ? (!j.d_qm || !j.x16 || !j.xr) : (!j.d_qm_inv || !j.choice || !j.d_dq)) {
+    return ODHIP_EINVAL;
+  }
+  const int n = 4 << j.bs;
+  if (j.w <= 0 || j.h <= 0 || j.w % n || j.h % n) return ODHIP_EINVAL;
+  memset(&d, 0, sizeof(d));
+  d.coef = j.d_coef;
+  d.ref = j.d_ref;
+  d.qm = j.d_qm;
+  d.qm_inv = j.d_qm_inv;
+  d.rec = j.band;
+  d.items = j.items;
+  d.y = j.y;
+  d.r16 = j.r16;
+  d.x16 = j.x16;
+  d.xr = j.xr;
+  d.rate = j.d_rate;
+  d.choice = j.choice;
+  d.dq = j.d_dq;
+  d.nplanes = j.nplanes;
+  d.w = j.w;
+  d.h = j.h;
+  d.bs = j.bs;
+  d.bw = j.w/n;
+  d.bh = j.h/n;
+  d.nblocks = (long)j.nplanes*d.bw*d.bh;
+  if (d.nblocks > 0xffffffffL) return ODHIP_EINVAL;
+  d.nb_bands = OD_NBANDS[j.bs];
+  d.len = n*n < OD_SCAN_LEN ? n*n : OD_SCAN_LEN;
+  d.is_keyframe = j.is_keyframe != 0;
+  d.pli = j.pli;
+  for (int i = 0; i <= d.nb_bands; i++) d.off[i] = OD_BAND_OFFS[j.bs][i];
+  for (int i = 0; i < d.nb_bands; i++) {
+    if (j.q_band[i] < 1) return ODHIP_EINVAL;
+    d.q[i] = j.q_band[i];
+    d.beta[i] = j.beta_band[i];
+  }
+  return ODHIP_SUCCESS;
+}
+
+int stage_jobs(const odhip_pvq_refjob *jobs, int njobs, int mode, RJob *host, hipStream_t s) {
+  if (!jobs || njobs <= 0 || njobs > kMaxJobs) return ODHIP_EINVAL;
+  int rc = upload_tables();
+  if (rc) return rc;
+  for (int i = 0; i < njobs; i++) {
+    rc = fill_job(host[i], jobs[i], mode);
+    if (rc) return rc;
+  }
+  ODHIP_TRY(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_rjobs), host, sizeof(RJob)*njobs, 0,
+   hipMemcpyHostToDevice, s));
+  return ODHIP_SUCCESS;
+}
+
+void items_begin(RItems &it, double lambda) {
+  memset(&it, 0, sizeof(it));
+  it.lambda = lambda;
+  it.margin = g_margin;
+  it.perturb = g_perturb;
+}
+
+void items_add(RItems &it, int job, int band, long wgs) {
+  if (wgs <= 0) return;
+  it.job[it.nitems] = (unsigned char)job;
+  it.band[it.nitems] = (unsigned char)band;
+  it.wg_start[it.nitems + 1] = it.wg_start[it.nitems] + (int)wgs;
+  it.nitems++;
+}
+
+/* All (job, band) items; n_only > 0 keeps the bands of that size. */
+void items_all(RItems &it, const RJob *host, int njobs, double lambda, int n_only) {
+  items_begin(it, lambda);
+  for (int j = 0; j < njobs; j++) {
+    for (int b = 0; b < host[j].nb_bands; b++) {
+      if (n_only > 0 && host[j].off[b + 1] - host[j].off[b] != n_only) continue;
+      items_add(it, j, b, (host[j].nblocks + kWave - 1)/kWave);
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" void odhip_pvq_ref_set_theta_margin(double margin, int perturb) {
+  g_margin = margin > 0 ? margin : kDefaultMargin;
+  g_perturb = perturb != 0;
+}
+
+extern "C" int odhip_pvq_ref_theta_probe(const double *d_corr, double *d_t, long n,
+ odhip_stream stream) {
+  if (!d_corr || !d_t || n < 0) return ODHIP_EINVAL;
+  if (n == 0) return ODHIP_SUCCESS;
+  k_theta_probe<<<(unsigned)((n + kWave - 1)/kWave), kWave, 0, (hipStream_t)stream>>>(d_corr, d_t, n);
+  return odhip_check_launch();
+}
+
+extern "C" int odhip_pvq_ref_bands_multi(const odhip_pvq_refjob *jobs, int njobs,
+ double pvq_norm_lambda, odhip_stream stream) {
+  hipStream_t s = (hipStream_t)stream;
+  RJob host[kMaxJobs];
+  int rc = stage_jobs(jobs, njobs, 0, host, s);
+  if (rc) return rc;
+  void *cnt = nullptr;
+  ODHIP_TRY(hipGetSymbolAddress(&cnt, HIP_SYMBOL(g_unc_count)));
+  ODHIP_TRY(hipMemsetAsync(cnt, 0, sizeof(unsigned), s));
+  RItems it;
+  items_all(it, host, njobs, pvq_norm_lambda, 0);
+  if (!it.nitems) return ODHIP_SUCCESS;
+  k_refb_prep<<<it.wg_start[it.nitems], kWave, 0, s>>>(it);
+  k_refb_cands<<<it.wg_start[it.nitems], kWave, 0, s>>>(it);
+  static const int sizes[4] = {128, 32, 15, 8};
+  for (int i = 0; i < 4; i++) {
+    items_all(it, host, njobs, pvq_norm_lambda, sizes[i]);
+    if (!it.nitems) continue;
+    const size_t lds = (size_t)2*sizes[i]*kWave*sizeof(unsigned short);
+    k_refb_search<<<it.wg_start[it.nitems], kWave, lds, s>>>(it);
+  }
+  return odhip_check_launch();
+}
+
+extern "C" int odhip_pvq_ref_resolve(const odhip_pvq_refjob *jobs, int njobs,
+ double pvq_norm_lambda, odhip_stream stream) {
+  hipStream_t s = (hipStream_t)stream;
+  ODHIP_TRY(hipStreamSynchronize(s));
+  unsigned count = 0;
+  ODHIP_TRY(hipMemcpyFromSymbol(&count, HIP_SYMBOL(g_unc_count), sizeof(count)));
+  if (count == 0) return 0;
+  if (count > (unsigned)kUncCap) {
+    fprintf(stderr, "libdaalahip: %u bands inside the theta margin exceed the list (%d)\n", count,
+     kUncCap);
+    return ODHIP_EFAULT;
+  }
+  Unc *list = (Unc *)malloc(sizeof(Unc)*count);
+  if (!list) return ODHIP_EFAULT;
+  if (hipMemcpyFromSymbol(list, HIP_SYMBOL(g_unc), sizeof(Unc)*count) != hipSuccess) {
+    free(list);
+    return ODHIP_EFAULT;
+  }
+  /* the reference's own expression with the host libm, src/pvq_encoder.c:478 */
+  unsigned nfix = 0;
+  for (unsigned i = 0; i < count; i++) {
+    const int32_t theta = (int32_t)floor(.5 + (32768*2./M_PI)*acos(list[i].corr));
+    if (theta != list[i].theta) {
+      list[nfix] = list[i];
+      list[nfix].theta = theta;
+      nfix++;
+    }
+  }
+  if (nfix == 0) {
+    free(list);
+    return 0;
+  }
+  RJob host[kMaxJobs];
+  int rc = stage_jobs(jobs, njobs, 0, host, s);
+  if (rc) {
+    free(list);
+    return rc;
+  }
+  for (unsigned i = 0; i < nfix; i++) {
+    if (list[i].job >= njobs) {
+      free(list);
+      return ODHIP_EINVAL;
+    }
+  }
+  Unc *d_list = nullptr;
+  if (hipMalloc((void **)&d_list, sizeof(Unc)*nfix) != hipSuccess
+   || hipMemcpyAsync(d_list, list, sizeof(Unc)*nfix, hipMemcpyHostToDevice, s) != hipSuccess) {
+    free(list);
+    if (d_list) (void)hipFree(d_list);
+    return ODHIP_EFAULT;
+  }
+  k_refb_cands_list<<<(nfix + kWave - 1)/kWave, kWave, 0, s>>>(d_list, (int)nfix);
+  k_refb_search_list<<<nfix, kWave, (size_t)2*128*kWave*sizeof(unsigned short), s>>>(d_list,
+   (int)nfix, pvq_norm_lambda);
+  rc = odhip_check_launch();
+  hipError_t e = hipStreamSynchronize(s);
+  free(list);
+  (void)hipFree(d_list);
+  if (rc) return rc;
+  if (e != hipSuccess) return ODHIP_EFAULT;
+  return (int)nfix;
+}
+
+extern "C" int odhip_pvq_ref_select_synth_multi(const odhip_pvq_refjob *jobs, int njobs,
+ double pvq_norm_lambda, odhip_stream stream) {
+  hipStream_t s = (hipStream_t)stream;
+  RJob host[kMaxJobs];
+  int rc = stage_jobs(jobs, njobs, 1, host, s);
+  if (rc) return rc;
+  for (int j = 0; j < njobs; j++) {
+    /* 32x32 and 64x64 blocks code their lowest 512 coefficients only */
+    if (host[j].bs >= 3) {
+      ODHIP_TRY(hipMemsetAsync(host[j].dq, 0, sizeof(od_coeff)*(size_t)host[j].nplanes*host[j].w
+       *host[j].h, s));
+    }
+  }
+  RItems it;
+  items_all(it, host, njobs, pvq_norm_lambda, 0);
+  if (!it.nitems) return ODHIP_SUCCESS;
+  k_refb_select<<<it.wg_start[it.nitems], kWave, 0, s>>>(it);
+  return odhip_check_launch();
+}

@@ -367,6 +367,134 @@ int odhip_pvq_ref_candidates(const odhip_pvq_refprep *d_prep, const int32_t *d_t
 int odhip_pvq_synthesis(od_coeff *d_out, const od_coeff *d_y, const int16_t *d_r16, int n,
  long nbands, const int32_t *d_params, const int16_t *d_qm_inv, odhip_stream stream);
 
+/* ---- with-reference band stage on whole planes ---------------------------------
+
+   pvq_theta (src/pvq_encoder.c:333-641) for every block of side N = 4 << bs of a
+   batch of coefficient planes and every PVQ band, WITH a reference plane of the
+   same layout (keyframe chroma: the chroma-from-luma prediction; inter frames:
+   the transformed motion-compensated prediction), up to but not including the
+   rate-dependent choice:
+
+     - the chroma-from-luma sign flip of od_pvq_encode (:846-872) per block when
+       is_keyframe && pli != 0 (the reference plane itself is not modified: the
+       flip is recorded and applied on the fly);
+     - QM scaling of x and r, gains, correlation, null-candidate distortion
+       (:381-455), od_compute_householder / od_apply_householder
+       (src/pvq.c:498-623);
+     - theta = floor(.5 + OD_THETA_SCALE*acos(corr)) (:478) with the device's
+       acos.  The reference's value comes from the host libm, which is not
+       reproducible bit for bit on the device; the integer theta is, except when
+       OD_THETA_SCALE*acos(corr) + .5 lies within 1e-9 of an integer (the two
+       libraries agree to < 1e-10 there, tests/test_gpu_pvq_refbands.py).  Such bands
+       are listed and odhip_pvq_ref_resolve settles them with the host's libm;
+     - the (gain, theta) candidates in the reference's order (:466-504), the
+       pruning test (:531), the K-pulse searches on the reflected vector with the
+       prev_k chain (:536-545) and the distortion of every candidate (:548-552);
+     - the no-reference candidates (:571-609) when the reference's condition
+       (:571-573) holds.
+
+   od_pvq_rate (adaptive entropy coder) stays on the host:
+   odhip_pvq_ref_select_synth_multi takes its rate table, applies `cost <
+   best_cost` to the theta candidates and `cost <= best_cost` to the
+   no-reference ones in the reference's order, then the skip rules (:611-622)
+   and the decoder-identical synthesis (:623-633).
+
+   Block index blk = (plane*(h/N) + by)*(w/N) + bx, B = number of blocks, nb =
+   bands of the block size, len = min(N*N, 512).  Band i of block blk: record
+   band[blk*nb + i], candidates items[(blk*nb + i)*ODHIP_PVQ_REF_SLOTS ..] (theta
+   candidates first, in search order, then the no-reference ones), pulse vector
+   of slot s at y[(s*B + blk)*len + off[i] ..] (signed int16, coding order; n-1
+   values for a theta candidate, n for a no-reference one). */
+#define ODHIP_PVQ_REF_SLOTS 16
+#define ODHIP_REFBAND_R_NULL 1      /* the reference band is all zero                   */
+#define ODHIP_REFBAND_THETA 2       /* the theta search ran (:452)                      */
+#define ODHIP_REFBAND_NOREF 4       /* the no-reference candidates ran (:571)           */
+#define ODHIP_REFBAND_FLIP 8        /* chroma-from-luma: reference of the block negated */
+#define ODHIP_REFBAND_UNCERTAIN 16  /* theta within the margin: see odhip_pvq_ref_resolve */
+typedef struct {
+  int32_t xshift, rshift;
+  int32_t g, gr;          /* raw gains                                          */
+  int32_t cg, cgr;        /* companded gains, Q8 (cgr = 256 with CfL)           */
+  int32_t icgr, gain_offset;
+  int16_t m;              /* Householder pivot (0 when not computed)            */
+  int8_t s;               /* Householder sign (1 when not computed)             */
+  uint8_t flags;          /* ODHIP_REFBAND_*                                    */
+  int32_t theta;          /* Q15 angle index, 0 when the theta search did not run */
+  int32_t nitems;         /* candidates in items[]                              */
+  int32_t ntheta;         /* how many of them are theta candidates (the first)  */
+  double corr;            /* clamped correlation (:436-438)                     */
+  double dist0;           /* distortion of the initial candidate (:455)         */
+} odhip_pvq_refband;      /* 64 bytes */
+
+#define ODHIP_REFITEM_SEARCHED 1    /* not pruned (:531, :588)                          */
+#define ODHIP_REFITEM_WITH_REF 2    /* theta candidate                                  */
+typedef struct {
+  int32_t gain;           /* i                                                  */
+  int32_t theta;          /* j, -1 for a no-reference candidate                 */
+  int32_t ts;             /* max_theta                                          */
+  int32_t k;
+  int32_t qcg;
+  int32_t qtheta;
+  int32_t flags;          /* ODHIP_REFITEM_*                                    */
+  int32_t yslot;          /* slot holding this candidate's pulses (a candidate
+                             with the K of its predecessor shares its slot,
+                             :539-544); -1 = all zero                           */
+  double cos_dist;        /* return value of pvq_search_rdo_double              */
+  double dist;
+} odhip_pvq_refitem;      /* 48 bytes */
+
+/* choice[(blk*nb + i)*8 ..]: {item (-1 = the initial candidate), qg, noref,
+   itheta, max_theta, k, skip (0, OD_PVQ_SKIP_ZERO 1, OD_PVQ_SKIP_COPY 2), the
+   return value of pvq_theta (:636-637)}. */
+typedef struct {
+  const od_coeff *d_coef;    /* nplanes planes w x h of level bs               */
+  const od_coeff *d_ref;     /* reference planes, same layout                  */
+  int nplanes;
+  int w;
+  int h;
+  int bs;
+  int is_keyframe;
+  int pli;
+  const int16_t *d_qm;       /* as odhip_pvq_job                               */
+  const int16_t *d_qm_inv;   /* select_synth only                              */
+  const int32_t *q_band;     /* HOST [nb]                                      */
+  const int32_t *beta_band;  /* HOST [nb]                                      */
+  odhip_pvq_refband *band;   /* out [B][nb], 64-byte aligned                   */
+  odhip_pvq_refitem *items;  /* out [B][nb][ODHIP_PVQ_REF_SLOTS], 16-byte aligned */
+  int16_t *y;                /* out [ODHIP_PVQ_REF_SLOTS][B][len]              */
+  int16_t *r16;              /* out [B][len]: QM-scaled reference after
+                                od_compute_householder (input of the synthesis) */
+  int16_t *x16;              /* work [B][len]                                  */
+  int16_t *xr;               /* work [B][len]: reflected x without element m   */
+  const double *d_rate;      /* select_synth: optional [B][nb][ODHIP_PVQ_REF_SLOTS + 1]
+                                bits; entry 0 = the initial candidate (:420 /
+                                :452), entry 1 + i = items[i]; NULL = choose on
+                                distortion alone                               */
+  int32_t *choice;           /* select_synth out [B][nb][8]                    */
+  od_coeff *d_dq;            /* select_synth out: dequantised planes, layout of
+                                d_coef; DC passed through; uncoded positions 0 */
+} odhip_pvq_refjob;
+
+/* At most 16 jobs per call, all on one stream; one call in flight per process. */
+int odhip_pvq_ref_bands_multi(const odhip_pvq_refjob *jobs, int njobs,
+ double pvq_norm_lambda, odhip_stream stream);
+/* Settles the bands odhip_pvq_ref_bands_multi flagged ODHIP_REFBAND_UNCERTAIN:
+   waits for the stream, evaluates floor(.5 + OD_THETA_SCALE*acos(corr)) with the
+   HOST libm (the function the reference itself calls) for the listed bands and
+   re-runs those whose theta differs.  Pass the same jobs.  Returns the number
+   of bands re-run (normally 0; about 2 in 10^9 bands are listed at all), or a
+   negative ODHIP_E* code.  Results are exact only after this call. */
+int odhip_pvq_ref_resolve(const odhip_pvq_refjob *jobs, int njobs,
+ double pvq_norm_lambda, odhip_stream stream);
+int odhip_pvq_ref_select_synth_multi(const odhip_pvq_refjob *jobs, int njobs,
+ double pvq_norm_lambda, odhip_stream stream);
+/* Test hooks: the uncertainty margin (default 1e-9; <= 0 restores it) and, when
+   perturb != 0, a deliberately wrong device theta (+1) for the listed bands, so
+   that tests exercise the host-libm path on real data. */
+void odhip_pvq_ref_set_theta_margin(double margin, int perturb);
+/* S*acos(corr) + .5 as the device evaluates it (parity check of the margin). */
+int odhip_pvq_ref_theta_probe(const double *d_corr, double *d_t, long n, odhip_stream stream);
+
 /* ---- deringing filter (src/dering.c) ----------------------
 
    od_dering_hip has od_dering's arguments (src/dering.h:64-69, definition

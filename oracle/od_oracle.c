@@ -984,6 +984,34 @@ void odo_pvq_search_batch(const int16_t *x, int n, const int *k, odo_coeff *y,
 /* One band: pvq_theta                                                       */
 /* ======================================================================== */
 
+/* The chroma-from-luma sign decision of od_pvq_encode, src/pvq_encoder.c:846-872
+   (keyframe chroma blocks only): the QM-weighted dot product of the first band
+   of the block with its luma-derived reference; when negative, the reference of
+   the whole block is negated.  ref/in: one block in coding order, qm: the
+   block's QM in coding order.  OD_CFL_FLIP_SHIFT = OD_LIMIT_BSIZE_MAX = 4
+   (src/pvq_encoder.c:42, src/internal.h:101).  Returns flip. */
+int odo_cfl_flip(odo_coeff *ref, const odo_coeff *in, const int16_t *qm, int bs) {
+  int32_t xy;
+  int i;
+  const int *off;
+  int nb;
+  off = OD_BAND_OFFS[bs];
+  nb = OD_NBANDS[bs];
+  xy = 0;
+  for (i = off[0]; i < off[1]; i++) {
+    int32_t rq;
+    int32_t inq;
+    rq = (int32_t)((uint32_t)ref[i]*(uint32_t)(int32_t)qm[i]);
+    inq = (int32_t)((uint32_t)in[i]*(uint32_t)(int32_t)qm[i]);
+    xy = (int32_t)((uint32_t)xy + (uint32_t)((rq*(int64_t)inq) >> ((Q_QM_SHIFT + 4) << 1)));
+  }
+  if (xy < 0) {
+    for (i = off[0]; i < off[nb]; i++) ref[i] = -ref[i];
+    return 1;
+  }
+  return 0;
+}
+
 /* od_pvq_rate, src/pvq_encoder.c:247-287, speed > 0 branch only (closed form;
    the speed == 0 branch prices with the live adaptive entropy coder and stays
    in the reference's host code). */
@@ -1009,6 +1037,13 @@ static double odo_pvq_rate_fast(int qg, int icgr, int theta, int ts,
     if (qg == icgr) rate -= .5;
   }
   return rate;
+}
+
+/* The same, callable from the tests that play the host's part of the split
+   band stage (price every candidate, let the GPU choose). */
+double odo_pvq_rate_speed1(int qg, int icgr, int theta, int ts, const odo_coeff *y0, int k,
+ int n, int is_keyframe, int pli) {
+  return odo_pvq_rate_fast(qg, icgr, theta, ts, y0, k, n, is_keyframe, pli);
 }
 
 static int odo_neg_interleave(int x, int ref) { /* src/pvq_encoder.c:235-239 */

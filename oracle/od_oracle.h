@@ -109,6 +109,9 @@ typedef struct {
   odo_pvq_cand cands[ODO_MAX_CANDS];
 } odo_pvq_band_trace;
 
+double odo_pvq_rate_speed1(int qg, int icgr, int theta, int ts, const odo_coeff *y0, int k,
+ int n, int is_keyframe, int pli);
+int odo_cfl_flip(odo_coeff *ref, const odo_coeff *in, const int16_t *qm, int bs);
 int odo_pvq_theta(odo_coeff *out, const odo_coeff *x0, const odo_coeff *r0, int n, int q0,
  odo_coeff *y, int *itheta, int *max_theta, int *vk, int beta, double *skip_diff, int nodesync,
  int is_keyframe, int pli, const int16_t *qm, const int16_t *qm_inv, double pvq_norm_lambda,

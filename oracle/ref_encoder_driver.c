@@ -266,3 +266,44 @@ REF_EXPORT int ref_dump_quant_tables(int quality, int *quantizer,
   daala_encode_free(enc);
   return OD_QM_SIZE;
 }
+
+/* One block through the REAL od_pvq_encode (src/pvq_encoder.c:789-979) on a
+   fresh encoder context: range coder and adaptation state reset as at the
+   start of a frame (src/encode.c:3029,3080).  `ref` is mutated exactly as the
+   reference mutates it (the chroma-from-luma sign flip, :846-872), which is
+   what tests/test_oracle_golden.py pins odo_cfl_flip against; `out` receives the
+   dequantised block, *flip_out whether ref was negated.  Returns the skip flag.
+   ref/in/out: one block in coding order; qm/qm_inv: that block size's tables. */
+#include "pvq_encoder.h"
+REF_EXPORT int ref_pvq_encode_block(od_coeff *ref, const od_coeff *in, od_coeff *out,
+ int q0, int pli, int bs, const int *beta_band, int is_keyframe, const int16_t *qm,
+ const int16_t *qm_inv, int speed) {
+  daala_info di;
+  daala_enc_ctx *enc;
+  od_val16 beta[16];
+  int i;
+  int ret;
+  daala_info_init(&di);
+  di.pic_width = 64;
+  di.pic_height = 64;
+  di.bitdepth_mode = OD_BITDEPTH_MODE_8;
+  di.timebase_numerator = 30;
+  di.timebase_denominator = 1;
+  di.frame_duration = 1;
+  di.pixel_aspect_numerator = 1;
+  di.pixel_aspect_denominator = 1;
+  di.nplanes = 3;
+  di.plane_info[1].xdec = di.plane_info[1].ydec = 1;
+  di.plane_info[2].xdec = di.plane_info[2].ydec = 1;
+  di.keyframe_rate = 1;
+  enc = daala_encode_create(&di);
+  if (enc == NULL) return -1;
+  od_ec_enc_reset(&enc->ec);
+  od_adapt_ctx_reset(&enc->state.adapt, is_keyframe);
+  for (i = 0; i < OD_QM_SIZE; i++) enc->state.pvq_qm_q4[pli][i] = 16;
+  for (i = 0; i < 16; i++) beta[i] = (od_val16)beta_band[i < 12 ? i : 11];
+  ret = od_pvq_encode(enc, ref, in, out, q0, pli, bs, beta, 1, is_keyframe, 0, 0, 0,
+   qm, qm_inv, speed);
+  daala_encode_free(enc);
+  return ret;
+}
