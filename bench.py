@@ -85,9 +85,10 @@ class Pipeline:
     all nine (plane set, level) jobs, and one inverse launch group per plane set
     (all its levels)."""
 
-    def __init__(self, D, nframes, device):
+    def __init__(self, D, nframes, device, chroma_cfl=False):
         import torch
         self.D = D
+        self.chroma_cfl = chroma_cfl
         self.torch = torch
         self.F = nframes
         self.qt = D.QuantTables.load()
@@ -108,6 +109,38 @@ class Pipeline:
                 self.jobs.append(job)
             self.sets.append(s)
         self.timers = {}
+        self.refjobs = []
+        if chroma_cfl:
+            self._setup_chroma_cfl(device)
+
+    def _setup_chroma_cfl(self, device):
+        """--chroma-cfl: keyframe chroma goes through pvq_theta's WITH-reference
+        path, as in the reference encoder (chroma-from-luma, src/encode.c:1683).
+        The reference planes are built once, before timing, from the luma
+        reconstruction of this pipeline: the low-frequency n x n corner of the
+        co-located 2n x 2n luma block's dequantised coefficients (the shape of
+        od_resample_luma_coeffs' output when the luma block is not split
+        further), and stay resident in HBM like the pictures."""
+        D, torch = self.D, self.torch
+        luma, chroma = self.sets
+        D.pvq_noref_bands_multi(luma["jobs"], self.lam)
+        for job in luma["jobs"]:
+            job.dq = torch.zeros_like(job.coef)
+        D.pvq_select_synth_noref_multi(luma["jobs"], self.lam)
+        torch.cuda.synchronize()
+        for bs in range(4):
+            n = 4 << bs
+            dq = luma["jobs"][bs + 1].dq                       # [F, H, W], blocks of 2n
+            F, h, w = dq.shape
+            corner = dq.view(F, h // (2 * n), 2 * n, w // (2 * n), 2 * n)[:, :, :n, :, :n]
+            ref = corner.reshape(F, h // 2, w // 2).contiguous()
+            ref = torch.cat([ref, ref], dim=0).contiguous()     # Cb planes, then Cr planes
+            cj = chroma["jobs"][bs]
+            self.refjobs.append(D.PvqRefJob(cj.coef, ref, bs, cj.qm, cj.qm_inv,
+                                            self.qt.q_band(1, bs), self.qt.beta_band(1, bs), 1, 1))
+        for job in luma["jobs"]:
+            job.dq = None
+        self.noref_jobs = luma["jobs"]
 
     def _timed(self, key, fn, record):
         if not record:
@@ -127,6 +160,24 @@ class Pipeline:
             self._timed("forward_pyramid_" + s["name"],
                         lambda: D.forward_pyramid(s["px"], s["dec"], PIC_W, PIC_H,
                                                   levels=s["levels"]), record)
+        if self.chroma_cfl:
+            luma, chroma = self.sets
+            self._timed("pvq_noref_bands", lambda: D.pvq_noref_bands_multi(self.noref_jobs, self.lam),
+                        record)
+            self._timed("pvq_choose", lambda: D.pvq_choose_multi(self.noref_jobs, self.lam), record)
+            self._timed("pvq_ref_bands", lambda: D.pvq_ref_bands_multi(self.refjobs, self.lam),
+                        record)
+            self._timed("pvq_ref_select_synth",
+                        lambda: D.pvq_ref_select_synth_multi(self.refjobs, self.lam), record)
+            self._timed("dequant_inverse_luma",
+                        lambda: D.inverse_levels_pvq(luma["jobs"], 0, PIC_W, PIC_H,
+                                                     outs=luma["recon"]), record)
+
+            def chroma_inverse():
+                for bs, rj in enumerate(self.refjobs):
+                    D.inverse_level(rj.dq, 1, bs, PIC_W, PIC_H, out=chroma["recon"][bs])
+            self._timed("inverse_chroma", chroma_inverse, record)
+            return
         self._timed("pvq_noref_bands", lambda: D.pvq_noref_bands_multi(self.jobs, self.lam),
                     record)
         self._timed("pvq_choose", lambda: D.pvq_choose_multi(self.jobs, self.lam), record)
@@ -234,6 +285,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--frames", type=int, default=8, help="1080p frames per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--chroma-cfl", action="store_true",
+                    help="chroma through pvq_theta's with-reference (chroma-from-luma) path")
     args = ap.parse_args()
 
     import torch
@@ -252,7 +305,7 @@ def main():
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     device = torch.device("cuda", local_rank)
 
-    pipe = Pipeline(D, args.frames, device)
+    pipe = Pipeline(D, args.frames, device, chroma_cfl=args.chroma_cfl)
     for _ in range(args.warmup):
         pipe.step()
 
@@ -354,7 +407,9 @@ def main():
             "data": "synthetic",
             "config": {"workload": "configs[1]: 1920x1080 4:2:0 all-intra frames, full "
                        "4/8/16/32/64 lapped-DCT pyramid + PVQ noref bands + inverse, "
-                       "every block of every level",
+                       "every block of every level" + (
+                           "; chroma through the with-reference (chroma-from-luma) PVQ path"
+                           if args.chroma_cfl else ""),
                        "frames_per_gpu_per_step": args.frames,
                        "blocks_per_frame": bpf, "quality": "-v 20 (quantizer 243)",
                        "sharding": "frames over ranks, no data-path collective"},

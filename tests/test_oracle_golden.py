@@ -276,3 +276,45 @@ def test_oracle_vs_reference_scan_and_helpers():
         assert o.odo_pvq_cos(th) == r.ref_pvq_cos(th)
         xi = x.astype(np.int32) << 3
         assert o.odo_vector_log_mag(P(xi), n) == r.ref_vector_log_mag(P(xi), n)
+
+
+def test_cfl_flip_golden():
+    """odo_cfl_flip against the fixture made from the reference's od_pvq_encode
+    (tools/make_golden_cfl.py): the decision and the negated range."""
+    g = load("cfl_flip.npz")
+    o = oracle()
+    import daala_amd.quant as Q
+    qt = Q.QuantTables.load()
+    for bs in range(4):
+        qm, _ = qt.qm_slices(1, bs)
+        x, r, flips = g["x%d" % bs], g["r%d" % bs], g["flip%d" % bs]
+        assert 0 < flips.sum() < len(flips)
+        for i in range(len(x)):
+            r1 = r[i].copy()
+            f = o.odo_cfl_flip(P(r1), P(x[i]), P(qm), bs)
+            assert f == flips[i], (bs, i)
+            n = min(r1.size, 512)
+            assert np.array_equal(r1[1:n], -r[i][1:n] if f else r[i][1:n])
+            assert r1[0] == r[i][0] and np.array_equal(r1[n:], r[i][n:])
+
+
+@pytest.mark.skipif(ref() is None, reason="oracle/_ref not present")
+def test_cfl_flip_vs_reference_random():
+    """Live: the reference's od_pvq_encode mutates `ref` exactly as odo_cfl_flip."""
+    o, r = oracle(), ref()
+    import daala_amd.quant as Q
+    qt = Q.QuantTables.load()
+    rng = np.random.RandomState(99)
+    for bs in range(4):
+        n = 4 << bs
+        qm, qmi = qt.qm_slices(1, bs)
+        beta = np.array(list(qt.beta_band(1, bs)) + [4096] * 12, np.int32)[:12]
+        for _ in range(40):
+            amp = rng.choice([30, 300, 3000, 30000])
+            x = (rng.laplace(size=n * n) * amp).astype(np.int32)
+            rr = (rng.choice([1, -1]) * x * rng.choice([0.01, 0.2, 1.0])
+                  + rng.laplace(size=n * n) * amp * rng.choice([0.3, 1, 5])).astype(np.int32)
+            r1, r2, out = rr.copy(), rr.copy(), np.zeros(n * n, np.int32)
+            r.ref_pvq_encode_block(P(r1), P(x), P(out), 37, 1, bs, P(beta), 1, P(qm), P(qmi), 1)
+            o.odo_cfl_flip(P(r2), P(x), P(qm), bs)
+            assert np.array_equal(r1, r2)
