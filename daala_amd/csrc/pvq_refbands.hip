@@ -43,6 +43,7 @@
 #include "od_pvq_math.cuh"
 #include "gen/od_scan_tables.h"
 #include "pvq_search.cuh"
+#include "pvq_row.cuh"
 
 namespace {
 
@@ -244,7 +245,7 @@ __global__ __launch_bounds__(kWave) void k_refb_prep(RItems it) {
     theta = (int32_t)floor(u);
     if (fabs(u - rint(u)) < it.margin) {
       flags |= ODHIP_REFBAND_UNCERTAIN;
-      if (it.perturb) theta += 1;
+      if (it.perturb & 1) theta += 1;
       const unsigned slot = atomicAdd(&g_unc_count, 1u);
       if (slot < (unsigned)kUncCap) {
         Unc e;
@@ -508,6 +509,151 @@ __global__ __launch_bounds__(kWave) void k_refb_search(RItems it) {
   const long blk = (long)(blockIdx.x - it.wg_start[item])*kWave + threadIdx.x;
   if (blk >= jb.nblocks) return;
   refb_search(jb, band, blk, threadIdx.x, xs, ys, it.lambda);
+}
+
+/* The same candidate loops with one band per 16-lane row (pvq_row.cuh): bands of
+   16*E coefficients (E = 2: 32, E = 8: 128), all state in registers.  The
+   decisions of a row are uniform over its lanes (every lane evaluates them on
+   the same record and items); lane 0 of the row writes the item fields, every
+   lane its E pulses as one vector store. */
+template <int E>
+__device__ __forceinline__ void store_row_pulses(int16_t *dst, const int (&sg)[E], const int (&y)[E]) {
+  uint32_t w[E/2];
+#pragma unroll
+  for (int e = 0; e < E; e += 2) {
+    const int lo = sg[e] ? -y[e] : y[e];
+    const int hi = sg[e + 1] ? -y[e + 1] : y[e + 1];
+    w[e/2] = (uint32_t)(lo & 0xffff) | (uint32_t)hi << 16;
+  }
+  if constexpr (E == 8) *reinterpret_cast<uint4 *>(dst) = make_uint4(w[0], w[1], w[2], w[3]);
+  else {
+#pragma unroll
+    for (int e = 0; e < E/2; e++) reinterpret_cast<uint32_t *>(dst)[e] = w[e];
+  }
+}
+
+template <int E>
+__device__ __forceinline__ void load_row_vector(const int16_t *src, int (&ax)[E], int (&sg)[E]) {
+#pragma unroll
+  for (int e = 0; e < E; e++) {
+    const int v = src[e];
+    ax[e] = abs(v);
+    sg[e] = v < 0;
+  }
+}
+
+template <int E>
+__global__ __launch_bounds__(kWave) void k_refb_search_row(RItems it) {
+  constexpr int n = 16*E;
+  od_rsqrt_init(threadIdx.x);
+  const int item = find_item(it, blockIdx.x);
+  const RJob &jb = g_rjobs[it.job[item]];
+  const int band = it.band[item];
+  const int off = jb.off[band];
+  const int lane = threadIdx.x;
+  const int row = lane >> 4;
+  const int l = lane & 15;
+  const long nblocks = jb.nblocks;
+  const int len = jb.len;
+  const int nb_bands = jb.nb_bands;
+  int16_t *const yout = jb.y;
+  const long blk0 = (long)(blockIdx.x - it.wg_start[item])*4 + row;
+  const bool live = blk0 < nblocks;
+  const long blk = live ? blk0 : nblocks - 1;
+  const bool writer = live && l == 0;
+  const odhip_pvq_refband r = jb.rec[blk*nb_bands + band];
+  odhip_pvq_refitem *items = jb.items + (blk*nb_bands + band)*kSlots;
+  const double lambda = it.lambda;
+  const int force = it.perturb >> 1;
+  const double s2 = (1./256)*(1./256);   /* OD_CGAIN_SCALE_2 */
+  const double t1 = 1./32768;            /* OD_TRIG_SCALE_1 */
+  const int32_t cg = r.cg;
+  const double dist0 = r.dist0;
+  int ax[E];
+  int sg[E];
+  int y[E];
+  if (r.ntheta > 0) {
+    load_row_vector<E>(jb.xr + blk*len + off + l*E, ax, sg);
+    if (l == 15) {        /* the pad: xr holds n - 1 values */
+      ax[E - 1] = 0;
+      sg[E - 1] = 0;
+    }
+#pragma unroll
+    for (int e = 0; e < E; e++) y[e] = 0;
+    int prev_k = 0;
+    int cur_slot = -1;
+    double cos_dist = 0;
+    const int32_t theta = r.theta;
+    for (int idx = 0; idx < r.ntheta; idx++) {
+      odhip_pvq_refitem *ip = items + idx;
+      const int32_t qcg = ip->qcg;
+      const int32_t qtheta = ip->qtheta;
+      const int k = ip->k;
+      double dist_theta = 2 - (2.*odq_pvq_cos(theta - qtheta))*t1;
+      double dist = (1.4*(qcg - cg))*(qcg - cg) + (qcg*(double)cg)*dist_theta;
+      dist *= s2;
+      if (dist > dist0 + 1.0*lambda && k != 0) {
+        if (writer) {
+          ip->flags = ODHIP_REFITEM_WITH_REF;
+          ip->yslot = -1;
+        }
+        continue;
+      }
+      const double sin_prod = ((odq_pvq_sin(theta)*t1)*odq_pvq_sin(qtheta))*t1;
+      if (k == 0) {
+        cos_dist = 0;
+        cur_slot = -1;
+      }
+      else if (k != prev_k) {
+        double yy;
+        cos_dist = od_pvq_search_row<E>(ax, y, row, l, n - 1, k, prev_k,
+         ((qcg*(double)cg)*sin_prod)*s2, lambda, force, &yy);
+        cur_slot = idx;
+        if (live) store_row_pulses<E>(yout + ((long)idx*nblocks + blk)*len + off + l*E, sg, y);
+      }
+      prev_k = k;
+      dist_theta = 2 - (2.*odq_pvq_cos(theta - qtheta))*t1 + sin_prod*(2 - 2*cos_dist);
+      dist = (1.4*(qcg - cg))*(qcg - cg) + (qcg*(double)cg)*dist_theta;
+      dist *= s2;
+      if (writer) {
+        ip->flags = ODHIP_REFITEM_WITH_REF | ODHIP_REFITEM_SEARCHED;
+        ip->yslot = cur_slot;
+        ip->cos_dist = cos_dist;
+        ip->dist = dist;
+      }
+    }
+  }
+  if (r.nitems > r.ntheta) {
+    load_row_vector<E>(jb.x16 + blk*len + off + l*E, ax, sg);
+    int prev_k = 0;
+    for (int idx = r.ntheta; idx < r.nitems; idx++) {
+      odhip_pvq_refitem *ip = items + idx;
+      const int32_t qcg = ip->qcg;
+      const int k = ip->k;
+      double dist = (1.4*(qcg - cg))*(qcg - cg);
+      dist *= s2;
+      if (dist > dist0 && k != 0) {
+        if (writer) {
+          ip->flags = 0;
+          ip->yslot = -1;
+        }
+        continue;
+      }
+      double yy;
+      const double cos_dist = od_pvq_search_row<E>(ax, y, row, l, n, k, prev_k, (qcg*(double)cg)*s2,
+       lambda, force, &yy);
+      prev_k = k;
+      if (live) store_row_pulses<E>(yout + ((long)idx*nblocks + blk)*len + off + l*E, sg, y);
+      dist = (1.4*(qcg - cg))*(qcg - cg) + (qcg*(double)cg)*(2 - 2*cos_dist);
+      dist *= s2;
+      if (writer) {
+        ip->flags = ODHIP_REFITEM_SEARCHED;
+        ip->yslot = idx;
+        ip->cos_dist = cos_dist;
+        ip->dist = dist;
+      }
+    }
+  }
 }
 
 /* One listed band per wavefront (lane 0): the list is a handful of bands. */
@@ -800,8 +946,26 @@ extern "C" int odhip_pvq_ref_bands_multi(const odhip_pvq_refjob *jobs, int njobs
   if (!it.nitems) return ODHIP_SUCCESS;
   k_refb_prep<<<it.wg_start[it.nitems], kWave, 0, s>>>(it);
   k_refb_cands<<<it.wg_start[it.nitems], kWave, 0, s>>>(it);
+  /* 128- and 32-coefficient bands: one band per 16-lane row; 15 and 8: per lane */
+  const bool lane_only = getenv("ODHIP_PVQ_REF_LANE") != nullptr;
   static const int sizes[4] = {128, 32, 15, 8};
   for (int i = 0; i < 4; i++) {
+    if (sizes[i] >= 32 && !lane_only) {
+      items_begin(it, pvq_norm_lambda);
+      const char *e = getenv("ODHIP_PVQ_FORCE_SEQ");
+      if (e && e[0] == '1') it.perturb |= 2;   /* every greedy pulse by the literal scan */
+      for (int j = 0; j < njobs; j++) {
+        for (int b = 0; b < host[j].nb_bands; b++) {
+          if (host[j].off[b + 1] - host[j].off[b] == sizes[i]) {
+            items_add(it, j, b, (host[j].nblocks + 3)/4);
+          }
+        }
+      }
+      if (!it.nitems) continue;
+      if (sizes[i] == 128) k_refb_search_row<8><<<it.wg_start[it.nitems], kWave, 0, s>>>(it);
+      else k_refb_search_row<2><<<it.wg_start[it.nitems], kWave, 0, s>>>(it);
+      continue;
+    }
     items_all(it, host, njobs, pvq_norm_lambda, sizes[i]);
     if (!it.nitems) continue;
     const size_t lds = (size_t)2*sizes[i]*kWave*sizeof(unsigned short);

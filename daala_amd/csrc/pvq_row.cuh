@@ -1,0 +1,290 @@
+/* pvq_row.cuh - pvq_search_rdo_double (reference src/pvq_encoder.c:93-224) with
+   one band per 16-lane DPP ROW, four bands per wavefront: the low-latency form
+   for the long bands of the with-reference stage (pvq_refbands.hip), where a
+   frame batch holds too few 128-coefficient bands to fill the chip one band per
+   lane and each band runs a chain of up to 14 searches.
+
+   A band of up to 16*E coefficients (E = 2: n = 31/32, E = 8: n = 127/128) is
+   held in VGPRs in BLOCKED index order (lane l of the row owns j = l*E ..
+   l*E+E-1), so lane order is index order.  The cross-lane steps are DPP row
+   operations (VALU, no LDS), two wave ballots and a few ds_bpermute broadcasts.
+   n_true = 16*E - 1 (the reflected vector of a with-reference search) is
+   handled by a PAD in the last position: |x| = 0, y = 0, and its candidate is
+   given a key that can never win (see the two places marked PAD), so every sum,
+   the projection and every argmax are those of the n_true-dimensional search;
+   n_true enters the rate term (3./n).
+
+   Sums (xx, xy, yy, L1) are sums of integers below 2^53: exact in any order.
+
+   The greedy argmax (:172-183) compares ROUNDED cross products, `a_j*b_best >
+   a_best*b_j` with a = (xy + x_j)^2, b = yy + 2*y_j + 1, scanning j upward from
+   0; that relation need not be transitive, so a reduction is not equivalent a
+   priori.  It is made exact:
+     1. each lane folds its own E candidates left to right with the reference
+        comparator; a cheap float key a/b picks the row's proposal W;
+     2. every lane checks every one of its candidates against W with the
+        reference's two products: it must be an exact duplicate of W (same a and
+        b) or lose to W by a relative margin of 2^-30 (>> the 2^-52 rounding of
+        the products).  Then the sequential scan provably ends on the
+        lowest-indexed duplicate: before it the running best is a clear loser,
+        which it beats; after it nothing beats it;
+     3. otherwise (a near tie that is not exact, or a float key that picked a
+        non-maximal proposal) the row replays that pulse with the literal
+        left-to-right scan.
+   The last 1 + k/4 pulses (:192-219) maximise one double per candidate with
+   `>`: (max value, lowest index) is a total order, so the reduction is exact.
+
+   Requires pvq_search.cuh (od_rsqrt_table, od_dpp.cuh) before it and
+   -ffp-contract=off.  Not valid for n_true in {8, 15} (the k == 1 special
+   cases of :154-163 are not implemented here; those bands are searched one
+   per lane). */
+#pragma once
+
+namespace {
+
+__device__ __forceinline__ double row_sum(double v) {
+  v += row_mov<OD_DPP_XOR1>(v);
+  v += row_mov<OD_DPP_XOR2>(v);
+  v += row_mov<OD_DPP_HALF_MIRROR>(v);
+  v += row_mov<OD_DPP_MIRROR>(v);
+  return v;
+}
+
+__device__ __forceinline__ int row_min(int v) {
+  v = min(v, row_mov<OD_DPP_XOR1>(v));
+  v = min(v, row_mov<OD_DPP_XOR2>(v));
+  v = min(v, row_mov<OD_DPP_HALF_MIRROR>(v));
+  v = min(v, row_mov<OD_DPP_MIRROR>(v));
+  return v;
+}
+
+__device__ __forceinline__ int row_max(int v) {
+  v = max(v, row_mov<OD_DPP_XOR1>(v));
+  v = max(v, row_mov<OD_DPP_XOR2>(v));
+  v = max(v, row_mov<OD_DPP_HALF_MIRROR>(v));
+  v = max(v, row_mov<OD_DPP_MIRROR>(v));
+  return v;
+}
+
+__device__ __forceinline__ float row_max(float v) {
+  v = fmaxf(v, __int_as_float(row_mov<OD_DPP_XOR1>(__float_as_int(v))));
+  v = fmaxf(v, __int_as_float(row_mov<OD_DPP_XOR2>(__float_as_int(v))));
+  v = fmaxf(v, __int_as_float(row_mov<OD_DPP_HALF_MIRROR>(__float_as_int(v))));
+  v = fmaxf(v, __int_as_float(row_mov<OD_DPP_MIRROR>(__float_as_int(v))));
+  return v;
+}
+
+/* 16-bit slice of a wave ballot belonging to this lane's row. */
+__device__ __forceinline__ unsigned row_ballot(bool p, int row) {
+  const unsigned long long m = __ballot(p);
+  return (unsigned)(m >> (16*row)) & 0xffffu;
+}
+
+/* Value of `v` in lane `src` (0..15) of this lane's row. */
+__device__ __forceinline__ int row_bcast(int v, int row, int src) {
+  return __shfl(v, 16*row + src, 64);
+}
+
+__device__ __forceinline__ double row_bcast(double v, int row, int src) {
+  return __shfl(v, 16*row + src, 64);
+}
+
+/* ax[e] = |x16|, y[e] = pulse magnitudes (input when prev_k > 0); row = lane/16,
+   l = lane%16.  Every lane of a row must call with the same arguments; rows of
+   a wavefront may differ (or not call at all).  With n_true == 16*E - 1 the
+   caller sets ax[E-1] = y[E-1] = 0 in lane 15.  Every lane of the row returns
+   the same cosine distance. */
+template <int E>
+__device__ __forceinline__ double od_pvq_search_row(const int (&ax)[E], int (&y)[E], int row,
+ int l, int n_true, int k, int prev_k, double g2, double pvq_norm_lambda, int force_scan,
+ double *yy_out) {
+  constexpr int n = 16*E;
+  const bool pad_lane = n_true != n && l == 15;
+  double xx = 0;
+#pragma unroll
+  for (int e = 0; e < E; e++) xx += (double)ax[e]*(double)ax[e];
+  xx = row_sum(xx);
+  const double norm_1 = __ddiv_rn(1., __dsqrt_rn(1e-30 + xx));
+  const double lambda = __ddiv_rn(pvq_norm_lambda, 1e-30 + g2);
+  double xy = 0;
+  double yy = 0;
+  int i = 0;
+  if (prev_k > 0 && prev_k <= k) {
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+      xy += (double)ax[e]*y[e];
+      yy += (double)(y[e]*y[e]);
+      i += y[e];
+    }
+  }
+  else if (k > 2) {
+    double l1 = 0;
+#pragma unroll
+    for (int e = 0; e < E; e++) l1 += (double)ax[e];
+    l1 = row_sum(l1);
+    const double l1_inv = __ddiv_rn(1., l1 > 1e-100 ? l1 : 1e-100);
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+      const double tmp = (k*(double)ax[e])*l1_inv;
+      const int v = (int)floor(tmp);
+      y[e] = v > 0 ? v : 0;
+      xy += (double)ax[e]*y[e];
+      yy += (double)(y[e]*y[e]);
+      i += y[e];
+    }
+  }
+  else {
+#pragma unroll
+    for (int e = 0; e < E; e++) y[e] = 0;
+  }
+  xy = row_sum(xy);
+  yy = row_sum(yy);
+  i = row_sum(i);
+  const int rdo_pulses = 1 + k/4;
+  const int n_greedy = k - rdo_pulses;
+  const double delta_rate = __ddiv_rn(3., (double)n_true);
+  /* Rows of one wavefront run different pulse counts; the ballots inside the
+     loops are wave-wide, so iterate to the maximum of the calling rows with
+     per-row predication. */
+  /* ---- greedy pulses ---------------------------------------------------- */
+  while (__any(i < n_greedy)) {
+    const bool on = i < n_greedy;
+    double a[E];
+    double b[E];
+    double ba = 0;
+    double bb = 1;
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+      const double t = xy + (double)ax[e];
+      a[e] = t*t;
+      b[e] = yy + (double)(2*y[e]) + 1;
+      if (e == E - 1 && pad_lane) a[e] = -1;   /* PAD: loses every comparison */
+      if (e == 0 || a[e]*bb > ba*b[e]) {
+        ba = a[e];
+        bb = b[e];
+      }
+    }
+    /* proposal: best float key of the row, lowest lane on equal keys */
+    const float key = (float)ba*__frcp_rn((float)bb);
+    const float kmax = row_max(key);
+    const unsigned wmask = row_ballot(key == kmax, row);
+    const int wl = wmask ? __ffs(wmask) - 1 : 0;
+    const double wa = row_bcast(ba, row, wl);
+    const double wb = row_bcast(bb, row, wl);
+    /* verification against the proposal */
+    bool bad = force_scan != 0 || wmask == 0;
+    int first_dup = n;
+#pragma unroll
+    for (int e = E - 1; e >= 0; e--) {
+      const bool dup = a[e] == wa && b[e] == wb;
+      const bool loses = a[e]*wb < (wa*b[e])*(1. - 9.3132257461547852e-10);
+      if (dup) first_dup = l*E + e;
+      else if (!loses) bad = true;
+    }
+    int pos;
+    if (row_ballot(bad && on, row) != 0) {
+      /* literal scan, src/pvq_encoder.c:172-183 */
+      double sa = 0;
+      double sb = 1;
+      pos = 0;
+      for (int j = 0; j < n; j++) {
+        const int e = j % E;
+        double ca = a[0];
+        double cb = b[0];
+#pragma unroll
+        for (int t = 1; t < E; t++) {
+          if (e == t) {
+            ca = a[t];
+            cb = b[t];
+          }
+        }
+        ca = row_bcast(ca, row, j/E);
+        cb = row_bcast(cb, row, j/E);
+        if (j == 0 || ca*sb > sa*cb) {
+          sa = ca;
+          sb = cb;
+          pos = j;
+        }
+      }
+    }
+    else pos = row_min(first_dup);
+    /* xy += x[pos]; yy += 2*y[pos] + 1; y[pos]++ */
+    int px = 0;
+    int py = 0;
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+      if (on && l*E + e == pos) {
+        px = ax[e];
+        py = y[e];
+        y[e]++;
+      }
+    }
+    px = row_bcast(px, row, pos/E);
+    py = row_bcast(py, row, pos/E);
+    if (on) {
+      xy = xy + (double)px;
+      yy = yy + (double)(2*py) + 1;
+      i++;
+    }
+  }
+  /* ---- last pulses with the rate term ------------------------------------- */
+  while (__any(i < k)) {
+    const bool on = i < k;
+    double tab[4];
+#pragma unroll
+    for (int t = 0; t < 4; t++) tab[t] = od_rsqrt_table((int)(yy + 2*t + 1));
+    double bc = 0;
+    int bi = 0;
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+      const int j = l*E + e;
+      double tmp_xy = xy + (double)ax[e];
+      const int yj = y[e];
+      double r;
+      if (yj < 4) r = yj == 0 ? tab[0] : yj == 1 ? tab[1] : yj == 2 ? tab[2] : tab[3];
+      else r = od_rsqrt_table((int)(yy + (double)(2*yj) + 1));
+      tmp_xy = ((2*tmp_xy)*norm_1)*r - (lambda*j)*delta_rate;
+      if (e == E - 1 && pad_lane) tmp_xy = -1.7976931348623157e308;   /* PAD */
+      if (e == 0 || tmp_xy > bc) {
+        bc = tmp_xy;
+        bi = j;
+      }
+    }
+    /* (max cost, lowest index): butterfly over the row, both fields moved by DPP */
+#define OD_RDO_STEP(CTRL) \
+    { \
+      const double oc = row_mov<CTRL>(bc); \
+      const int oi = row_mov<CTRL>(bi); \
+      const bool take = oc > bc || (oc == bc && oi < bi); \
+      bc = take ? oc : bc; \
+      bi = take ? oi : bi; \
+    }
+    OD_RDO_STEP(OD_DPP_XOR1)
+    OD_RDO_STEP(OD_DPP_XOR2)
+    OD_RDO_STEP(OD_DPP_HALF_MIRROR)
+    OD_RDO_STEP(OD_DPP_MIRROR)
+#undef OD_RDO_STEP
+    const int pos = bi;
+    int px = 0;
+    int py = 0;
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+      if (on && l*E + e == pos) {
+        px = ax[e];
+        py = y[e];
+        y[e]++;
+      }
+    }
+    px = row_bcast(px, row, pos/E);
+    py = row_bcast(py, row, pos/E);
+    if (on) {
+      xy = xy + (double)px;
+      yy = yy + (double)(2*py) + 1;
+      i++;
+    }
+  }
+  *yy_out = yy;
+  return __ddiv_rn(xy, 1e-100 + __dsqrt_rn(xx*yy));
+}
+
+}  // namespace

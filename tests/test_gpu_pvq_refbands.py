@@ -44,9 +44,15 @@ def _job(hip, rng, bs, is_keyframe, pli, h=64, w=128, nplanes=2):
 MODES = [(1, 1), (0, 0), (0, 1), (1, 0)]   # (is_keyframe, pli): CfL, inter luma/chroma, key luma
 
 
-@pytest.mark.parametrize("is_keyframe,pli", MODES)
-def test_ref_band_stage_matches_oracle(hip, is_keyframe, pli):
+@pytest.mark.parametrize("is_keyframe,pli,env", [m + (None,) for m in MODES]
+                         + [(1, 1, "ODHIP_PVQ_FORCE_SEQ"), (0, 0, "ODHIP_PVQ_REF_LANE")])
+def test_ref_band_stage_matches_oracle(hip, is_keyframe, pli, env, monkeypatch):
+    """env: ODHIP_PVQ_FORCE_SEQ=1 makes the row-parallel search take the literal
+    left-to-right scan for every greedy pulse; ODHIP_PVQ_REF_LANE=1 searches the
+    32- and 128-coefficient bands one band per lane instead of one per row."""
     import torch
+    if env:
+        monkeypatch.setenv(env, "1")
     lam = hip.OD_PVQ_LAMBDA
     rng = np.random.RandomState(41 + 2 * is_keyframe + pli)
     top = 3 if pli else 4
