@@ -148,100 +148,75 @@ __global__ __launch_bounds__(kWave) void k_theta_probe(const double *corr, doubl
   if (i < n) t[i] = theta_arg(corr[i]);
 }
 
-/* ---- preparation ---------------------------------------------------------------- */
-__global__ __launch_bounds__(kWave) void k_refb_prep(RItems it) {
-  const int item = find_item(it, blockIdx.x);
-  const int job = it.job[item];
-  const RJob &jb = g_rjobs[job];
-  const int band = it.band[item];
-  const long blk = (long)(blockIdx.x - it.wg_start[item])*kWave + threadIdx.x;
-  if (blk >= jb.nblocks) return;
-  const int off = jb.off[band];
-  const int n = jb.off[band + 1] - off;
-  const long base = block_base(jb, blk);
-  const od_coeff *x0 = jb.coef + base;
-  const od_coeff *r0 = jb.ref + base;
-  const int16_t *qm = jb.qm + off;
-  const int cfl_enabled = jb.is_keyframe && jb.pli != 0;
-  /* chroma-from-luma sign, src/pvq_encoder.c:846-872: OD_QM_SHIFT +
-     OD_CFL_FLIP_SHIFT = 11 + 4, doubled */
-  int flip = 0;
-  if (cfl_enabled) {
-    uint32_t xy = 0;
-    for (int c = jb.off[0]; c < jb.off[1]; c++) {
-      const long p = coef_pos(jb, c);
-      const int32_t q = jb.qm[c];
-      const int32_t rq = (int32_t)((uint32_t)r0[p]*(uint32_t)q);
-      const int32_t inq = (int32_t)((uint32_t)x0[p]*(uint32_t)q);
-      xy += (uint32_t)((rq*(int64_t)inq) >> 30);
-    }
-    flip = (int32_t)xy < 0;
-  }
-  /* od_vector_log_mag, src/pvq.c:472-484; src/pvq_encoder.c:381-385 */
-  int sx = 0;
-  int sr = 0;
-  for (int i = 0; i < n; i++) {
-    const long p = coef_pos(jb, off + i);
-    const int tx = (int16_t)(x0[p] >> 8);
-    const int rv = flip ? -r0[p] : r0[p];
-    const int tr = (int16_t)(rv >> 8);
-    sx += tx*tx;
-    sr += tr*tr;
-  }
-  int xshift = 8 + 1 + odq_ilog(n + sx)/2 - 15;
-  xshift = xshift > 0 ? xshift : 0;
-  int rshift = 8 + 1 + odq_ilog(n + sr)/2 - 14;
-  rshift = rshift > 0 ? rshift : 0;
-  int16_t *x16 = jb.x16 + blk*jb.len + off;
-  int16_t *r16 = jb.r16 + blk*jb.len + off;
-  int16_t *xr = jb.xr + blk*jb.len + off;
-  double corr = 0;
-  int r_null = 1;
-  int accx = 0;
-  int accr = 0;
-  for (int i = 0; i < n; i++) {
-    const long p = coef_pos(jb, off + i);
-    const int32_t xv0 = x0[p];
-    const int32_t rv0 = flip ? -r0[p] : r0[p];
-    const int16_t xv = (int16_t)odq_shr_round((int32_t)((uint32_t)xv0*(uint32_t)(int32_t)qm[i]),
-     ODQ_QM_SHIFT + xshift);
-    const int16_t rv = (int16_t)odq_shr_round((int32_t)((uint32_t)rv0*(uint32_t)(int32_t)qm[i]),
-     ODQ_QM_SHIFT + rshift);
-    x16[i] = xv;
-    r16[i] = rv;
-    corr += odq_mult16_16(xv, rv);
-    if (rv0) r_null = 0;
-    accx += xv*(int)xv;
-    accr += rv*(int)rv;
-  }
-  const int q0 = jb.q[band];
-  const int beta = jb.beta[band];
-  int32_t g;
-  int32_t gr;
-  const int32_t cg = odq_gain_from_acc(accx, q0, beta, xshift, &g);
-  int32_t cgr = odq_gain_from_acc(accr, q0, beta, rshift, &gr);
-  if (cfl_enabled) cgr = 256;
-  const int icgr = odq_shr_round(cgr, ODQ_CGAIN_SHIFT);
-  const int32_t gain_offset = cgr - odq_shl32(icgr, ODQ_CGAIN_SHIFT);
-  /* src/pvq_encoder.c:436-438 */
-  corr = __ddiv_rn(corr, 1e-100 + __ddiv_rn(g*(double)gr, (double)odq_shl32(1, xshift + rshift)));
+/* ---- preparation -------------------------------------------------------------------
+   Two mappings: the 15- and 8-coefficient bands one band per lane with the band
+   in registers (k_refb_prep_lane), the 32- and 128-coefficient bands one band per
+   16-lane row (k_refb_prep_row; a frame batch has too few of them to fill the
+   chip one per lane, and a lane walking 128 coefficients three times is a chain
+   of exposed latencies).  Band 0 of every block goes first and decides the
+   chroma-from-luma flip of its block; the other bands read it from band 0's
+   record.  Sums of integers are accumulated in any order (exact); the
+   Householder pivot is the first largest |r| (src/pvq.c:505-512; |r16| < 2^15
+   by construction of rshift, so the int16 running maximum of the reference
+   cannot wrap). */
+__device__ unsigned short gRScanPk[OD_SCAN_LEN];   /* y << 8 | x */
+
+struct PrepScalars {
+  int32_t g, gr, cg, cgr, gain_offset;
+  int icgr;
+  double corr, dist0;
+  bool ran;
+};
+
+/* :404-455 from the band sums. */
+__device__ __forceinline__ PrepScalars prep_scalars(int accx, int accr, double corr_sum, int xshift,
+ int rshift, int q0, int beta, int cfl_enabled, int is_keyframe, int r_null) {
+  PrepScalars o;
+  o.cg = odq_gain_from_acc(accx, q0, beta, xshift, &o.g);
+  o.cgr = odq_gain_from_acc(accr, q0, beta, rshift, &o.gr);
+  if (cfl_enabled) o.cgr = 256;
+  o.icgr = odq_shr_round(o.cgr, ODQ_CGAIN_SHIFT);
+  o.gain_offset = o.cgr - odq_shl32(o.icgr, ODQ_CGAIN_SHIFT);
+  double corr = __ddiv_rn(corr_sum,
+   1e-100 + __ddiv_rn(o.g*(double)o.gr, (double)odq_shl32(1, xshift + rshift)));
   corr = corr < 1. ? corr : 1.;
   corr = corr > -1. ? corr : -1.;
-  /* initial candidate, :417-455 */
+  o.corr = corr;
   const double s2 = (1./256)*(1./256);
-  double dist0 = ((1.4*cg)*cg)*s2;
-  if (!jb.is_keyframe && icgr == 0) {
-    const int32_t scgr = gain_offset > 0 ? gain_offset : 0;
-    dist0 = (1.4*(cg - scgr))*(cg - scgr) + (scgr*(double)cg)*(2 - 2*corr);
+  double dist0 = ((1.4*o.cg)*o.cg)*s2;
+  if (!is_keyframe && o.icgr == 0) {
+    const int32_t scgr = o.gain_offset > 0 ? o.gain_offset : 0;
+    dist0 = (1.4*(o.cg - scgr))*(o.cg - scgr) + (scgr*(double)o.cg)*(2 - 2*corr);
     dist0 *= s2;
   }
-  int m = 0;
-  int s = 1;
+  o.dist0 = dist0;
+  o.ran = !r_null && corr > 0;
+  return o;
+}
+
+/* Householder projection constants from l2r = <r, r> and proj = <r, x>,
+   src/pvq.c:573-590. */
+__device__ __forceinline__ void householder_consts(int32_t l2r, int32_t proj, int16_t *proj_1,
+ int *outshift) {
+  const int l2r_shift = (odq_ilog(l2r) - 1) - 14;
+  const int16_t l2r_norm = (int16_t)odq_vshr_round(l2r, l2r_shift);
+  const int16_t rcp = odq_rcp(l2r_norm);
+  const int proj_shift = (odq_ilog(abs(proj)) - 1) - 14;
+  const int16_t proj_norm = (int16_t)odq_vshr_round(proj, proj_shift);
+  *proj_1 = (int16_t)odq_mult16_16_q15(proj_norm, rcp);
+  int os = 14 - proj_shift - 1 + l2r_shift;
+  *outshift = os > 30 ? 30 : os;
+}
+
+/* Record of the band, theta with the device acos and the uncertainty list
+   (one lane per band). */
+__device__ __forceinline__ void prep_write(const RItems &it, odhip_pvq_refband *rec, int job, int band,
+ long blk, int xshift, int rshift, const PrepScalars &p, int r_null, int flip, int m, int s) {
   int flags = (r_null ? ODHIP_REFBAND_R_NULL : 0) | (flip ? ODHIP_REFBAND_FLIP : 0);
   int32_t theta = 0;
-  if (!r_null && corr > 0) {
+  if (p.ran) {
     flags |= ODHIP_REFBAND_THETA;
-    const double u = theta_arg(corr);
+    const double u = theta_arg(p.corr);
     theta = (int32_t)floor(u);
     if (fabs(u - rint(u)) < it.margin) {
       flags |= ODHIP_REFBAND_UNCERTAIN;
@@ -253,64 +228,349 @@ __global__ __launch_bounds__(kWave) void k_refb_prep(RItems it) {
         e.band = band;
         e.blk = (unsigned)blk;
         e.theta = theta;
-        e.corr = corr;
+        e.corr = p.corr;
         g_unc[slot] = e;
       }
-    }
-    /* od_compute_householder, src/pvq.c:498-521: first largest |r_i| wins */
-    int maxr = 0;
-    for (int i = 0; i < n; i++) {
-      const int a = abs((int)r16[i]);
-      if (a > maxr) {
-        maxr = (int16_t)a;
-        m = i;
-      }
-    }
-    s = r16[m] > 0 ? 1 : -1;
-    r16[m] = (int16_t)(r16[m] + odq_shr_round(gr*s, rshift));
-    /* od_apply_householder, src/pvq.c:560-623 */
-    int32_t l2r = 0;
-    int32_t proj = 0;
-    for (int i = 0; i < n; i++) {
-      l2r += odq_mult16_16(r16[i], r16[i]);
-      proj += odq_mult16_16(r16[i], x16[i]);
-    }
-    const int l2r_shift = (odq_ilog(l2r) - 1) - 14;
-    const int16_t l2r_norm = (int16_t)odq_vshr_round(l2r, l2r_shift);
-    const int16_t rcp = odq_rcp(l2r_norm);
-    const int proj_shift = (odq_ilog(abs(proj)) - 1) - 14;
-    const int16_t proj_norm = (int16_t)odq_vshr_round(proj, proj_shift);
-    const int16_t proj_1 = (int16_t)odq_mult16_16_q15(proj_norm, rcp);
-    int outshift = 14 - proj_shift - 1 + l2r_shift;
-    if (outshift > 30) outshift = 30;
-    /* the reflected vector without element m (src/pvq_encoder.c:481) */
-    for (int i = 0; i < n; i++) {
-      int32_t tmp = odq_mult16_16(r16[i], proj_1);
-      tmp = outshift >= 0 ? odq_shr_round(tmp, outshift) : odq_shl32(tmp, -outshift);
-      const int16_t v = (int16_t)(x16[i] - tmp);
-      if (i < m) xr[i] = v;
-      else if (i > m) xr[i - 1] = v;
     }
   }
   odhip_pvq_refband o;
   o.xshift = xshift;
   o.rshift = rshift;
-  o.g = g;
-  o.gr = gr;
-  o.cg = cg;
-  o.cgr = cgr;
-  o.icgr = icgr;
-  o.gain_offset = gain_offset;
+  o.g = p.g;
+  o.gr = p.gr;
+  o.cg = p.cg;
+  o.cgr = p.cgr;
+  o.icgr = p.icgr;
+  o.gain_offset = p.gain_offset;
   o.m = (int16_t)m;
   o.s = (int8_t)s;
   o.flags = (uint8_t)flags;
   o.theta = theta;
   o.nitems = 0;
   o.ntheta = 0;
-  o.corr = corr;
-  o.dist0 = dist0;
-  jb.rec[blk*jb.nb_bands + band] = o;
+  o.corr = p.corr;
+  o.dist0 = p.dist0;
+  *rec = o;
 }
+
+__device__ __forceinline__ uint32_t pack16(int lo, int hi) {
+  return (uint32_t)(lo & 0xffff) | (uint32_t)hi << 16;
+}
+
+/* N = 15 (band 0: the flip is decided here) or N = 8. */
+template <int N>
+__global__ __launch_bounds__(kWave) void k_refb_prep_lane(RItems it) {
+  const int item = find_item(it, blockIdx.x);
+  const int job = it.job[item];
+  const RJob &jb = g_rjobs[job];
+  const int band = it.band[item];
+  const long blk = (long)(blockIdx.x - it.wg_start[item])*kWave + threadIdx.x;
+  if (blk >= jb.nblocks) return;
+  const int off = jb.off[band];
+  const int w = jb.w;
+  const int len = jb.len;
+  const int nb_bands = jb.nb_bands;
+  const int q0 = jb.q[band];
+  const int beta = jb.beta[band];
+  const int is_keyframe = jb.is_keyframe;
+  const int cfl_enabled = is_keyframe && jb.pli != 0;
+  const long base = block_base(jb, blk);
+  const od_coeff *x0 = jb.coef + base;
+  const od_coeff *r0 = jb.ref + base;
+  const int16_t *qmp = jb.qm + off;
+  odhip_pvq_refband *rec = jb.rec + blk*nb_bands;
+  int16_t *x16o = jb.x16 + blk*len;
+  int16_t *r16o = jb.r16 + blk*len;
+  int16_t *xro = jb.xr + blk*len;
+  int xv[N];
+  int rv[N];
+  int qm[N];
+#pragma unroll
+  for (int i = 0; i < N; i++) {
+    const long p = (long)kRScanXY[off + i][1]*w + kRScanXY[off + i][0];
+    xv[i] = x0[p];
+    rv[i] = r0[p];
+    qm[i] = qmp[i];
+  }
+  int flip = 0;
+  if (cfl_enabled) {
+    if (N == 15 && band == 0) {
+      /* src/pvq_encoder.c:846-872: OD_QM_SHIFT + OD_CFL_FLIP_SHIFT = 11 + 4, doubled */
+      uint32_t xy = 0;
+#pragma unroll
+      for (int i = 0; i < N; i++) {
+        const int32_t rq = (int32_t)((uint32_t)rv[i]*(uint32_t)qm[i]);
+        const int32_t inq = (int32_t)((uint32_t)xv[i]*(uint32_t)qm[i]);
+        xy += (uint32_t)((rq*(int64_t)inq) >> 30);
+      }
+      flip = (int32_t)xy < 0;
+    }
+    else flip = (rec[0].flags & ODHIP_REFBAND_FLIP) != 0;
+  }
+  /* od_vector_log_mag, src/pvq.c:472-484; src/pvq_encoder.c:381-385 */
+  int sx = 0;
+  int sr = 0;
+  int r_null = 1;
+#pragma unroll
+  for (int i = 0; i < N; i++) {
+    if (flip) rv[i] = -rv[i];
+    const int tx = (int16_t)(xv[i] >> 8);
+    const int tr = (int16_t)(rv[i] >> 8);
+    sx += tx*tx;
+    sr += tr*tr;
+    if (rv[i]) r_null = 0;
+  }
+  int xshift = 8 + 1 + odq_ilog(N + sx)/2 - 15;
+  xshift = xshift > 0 ? xshift : 0;
+  int rshift = 8 + 1 + odq_ilog(N + sr)/2 - 14;
+  rshift = rshift > 0 ? rshift : 0;
+  int x16[N];
+  int r16[N];
+  double corr = 0;
+  int accx = 0;
+  int accr = 0;
+#pragma unroll
+  for (int i = 0; i < N; i++) {
+    x16[i] = (int16_t)odq_shr_round((int32_t)((uint32_t)xv[i]*(uint32_t)qm[i]), ODQ_QM_SHIFT + xshift);
+    r16[i] = (int16_t)odq_shr_round((int32_t)((uint32_t)rv[i]*(uint32_t)qm[i]), ODQ_QM_SHIFT + rshift);
+    corr += odq_mult16_16(x16[i], r16[i]);
+    accx += x16[i]*x16[i];
+    accr += r16[i]*r16[i];
+  }
+  const PrepScalars p = prep_scalars(accx, accr, corr, xshift, rshift, q0, beta, cfl_enabled,
+   is_keyframe, r_null);
+  int m = 0;
+  int s = 1;
+  int xr[N];
+#pragma unroll
+  for (int i = 0; i < N; i++) xr[i] = 0;
+  if (p.ran) {
+    /* od_compute_householder, src/pvq.c:498-521 */
+    int maxr = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+      const int a = abs(r16[i]);
+      if (a > maxr) {
+        maxr = a;
+        m = i;
+      }
+    }
+    int rm = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) if (i == m) rm = r16[i];
+    s = rm > 0 ? 1 : -1;
+    const int upd = (int16_t)(rm + odq_shr_round(p.gr*s, rshift));
+    int32_t l2r = 0;
+    int32_t proj = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+      if (i == m) r16[i] = upd;
+      l2r += odq_mult16_16(r16[i], r16[i]);
+      proj += odq_mult16_16(r16[i], x16[i]);
+    }
+    int16_t proj_1;
+    int outshift;
+    householder_consts(l2r, proj, &proj_1, &outshift);
+    int v[N];
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+      int32_t tmp = odq_mult16_16(r16[i], proj_1);
+      tmp = outshift >= 0 ? odq_shr_round(tmp, outshift) : odq_shl32(tmp, -outshift);
+      v[i] = (int16_t)(x16[i] - tmp);
+    }
+    /* the reflected vector without element m (src/pvq_encoder.c:481) */
+#pragma unroll
+    for (int i = 0; i < N - 1; i++) xr[i] = i < m ? v[i] : v[i + 1];
+  }
+  /* whole 16-byte vectors: the 15-coefficient band shares its first vector with
+     the (unused) DC slot of the block */
+  if (N == 15) {
+    uint4 *xo = reinterpret_cast<uint4 *>(x16o);
+    uint4 *ro = reinterpret_cast<uint4 *>(r16o);
+    uint4 *xro4 = reinterpret_cast<uint4 *>(xro);
+    xo[0] = make_uint4(pack16(0, x16[0]), pack16(x16[1], x16[2]), pack16(x16[3], x16[4]),
+     pack16(x16[5], x16[6]));
+    xo[1] = make_uint4(pack16(x16[7], x16[8]), pack16(x16[9], x16[10]), pack16(x16[11], x16[12]),
+     pack16(x16[13], x16[N - 1]));
+    ro[0] = make_uint4(pack16(0, r16[0]), pack16(r16[1], r16[2]), pack16(r16[3], r16[4]),
+     pack16(r16[5], r16[6]));
+    ro[1] = make_uint4(pack16(r16[7], r16[8]), pack16(r16[9], r16[10]), pack16(r16[11], r16[12]),
+     pack16(r16[13], r16[N - 1]));
+    xro4[0] = make_uint4(pack16(0, xr[0]), pack16(xr[1], xr[2]), pack16(xr[3], xr[4]),
+     pack16(xr[5], xr[6]));
+    xro4[1] = make_uint4(pack16(xr[7], xr[8]), pack16(xr[9], xr[10]), pack16(xr[11], xr[12]),
+     pack16(xr[13], 0));
+  }
+  else {
+    *reinterpret_cast<uint4 *>(x16o + off) = make_uint4(pack16(x16[0], x16[1]), pack16(x16[2], x16[3]),
+     pack16(x16[4], x16[5]), pack16(x16[6], x16[7]));
+    *reinterpret_cast<uint4 *>(r16o + off) = make_uint4(pack16(r16[0], r16[1]), pack16(r16[2], r16[3]),
+     pack16(r16[4], r16[5]), pack16(r16[6], r16[7]));
+    *reinterpret_cast<uint4 *>(xro + off) = make_uint4(pack16(xr[0], xr[1]), pack16(xr[2], xr[3]),
+     pack16(xr[4], xr[5]), pack16(xr[6], 0));
+  }
+  prep_write(it, rec + band, job, band, blk, xshift, rshift, p, r_null, flip, m, s);
+}
+
+/* n = 16*E coefficients per 16-lane row, four bands per wavefront; lane l of the
+   row owns coding positions l*E .. l*E+E-1 of the band. */
+template <int E>
+__global__ __launch_bounds__(kWave) void k_refb_prep_row(RItems it) {
+  constexpr int n = 16*E;
+  __shared__ unsigned short s_scan[n];
+  const int item = find_item(it, blockIdx.x);
+  const int job = it.job[item];
+  const RJob &jb = g_rjobs[job];
+  const int band = it.band[item];
+  const int off = jb.off[band];
+  const int lane = threadIdx.x;
+  for (int j = lane; j < n; j += kWave) s_scan[j] = gRScanPk[off + j];
+  __syncthreads();
+  const int row = lane >> 4;
+  const int l = lane & 15;
+  const long nblocks = jb.nblocks;
+  const long blk0 = (long)(blockIdx.x - it.wg_start[item])*4 + row;
+  const bool live = blk0 < nblocks;
+  const long blk = live ? blk0 : nblocks - 1;
+  const int w = jb.w;
+  const int len = jb.len;
+  const int nb_bands = jb.nb_bands;
+  const int q0 = jb.q[band];
+  const int beta = jb.beta[band];
+  const int is_keyframe = jb.is_keyframe;
+  const int cfl_enabled = is_keyframe && jb.pli != 0;
+  const long base = block_base(jb, blk);
+  const od_coeff *x0 = jb.coef + base;
+  const od_coeff *r0 = jb.ref + base;
+  const int16_t *qmp = jb.qm + off + l*E;
+  odhip_pvq_refband *rec = jb.rec + blk*nb_bands;
+  int16_t *x16o = jb.x16 + blk*len + off;
+  int16_t *r16o = jb.r16 + blk*len + off;
+  int16_t *xro = jb.xr + blk*len + off;
+  const int flip = cfl_enabled ? (rec[0].flags & ODHIP_REFBAND_FLIP) != 0 : 0;
+  int xv[E];
+  int rv[E];
+  int qm[E];
+  int sx = 0;
+  int sr = 0;
+  int nz = 0;
+#pragma unroll
+  for (int e = 0; e < E; e++) {
+    const int pk = s_scan[l*E + e];
+    const long p = (long)(pk >> 8)*w + (pk & 255);
+    xv[e] = x0[p];
+    const int r = r0[p];
+    rv[e] = flip ? -r : r;
+    qm[e] = qmp[e];
+  }
+#pragma unroll
+  for (int e = 0; e < E; e++) {
+    const int tx = (int16_t)(xv[e] >> 8);
+    const int tr = (int16_t)(rv[e] >> 8);
+    sx += tx*tx;
+    sr += tr*tr;
+    nz |= rv[e] != 0;
+  }
+  sx = row_sum(sx);
+  sr = row_sum(sr);
+  const int r_null = row_max(nz) == 0;
+  int xshift = 8 + 1 + odq_ilog(n + sx)/2 - 15;
+  xshift = xshift > 0 ? xshift : 0;
+  int rshift = 8 + 1 + odq_ilog(n + sr)/2 - 14;
+  rshift = rshift > 0 ? rshift : 0;
+  int x16[E];
+  int r16[E];
+  double corr = 0;
+  int accx = 0;
+  int accr = 0;
+#pragma unroll
+  for (int e = 0; e < E; e++) {
+    x16[e] = (int16_t)odq_shr_round((int32_t)((uint32_t)xv[e]*(uint32_t)qm[e]), ODQ_QM_SHIFT + xshift);
+    r16[e] = (int16_t)odq_shr_round((int32_t)((uint32_t)rv[e]*(uint32_t)qm[e]), ODQ_QM_SHIFT + rshift);
+    corr += odq_mult16_16(x16[e], r16[e]);
+    accx += x16[e]*x16[e];
+    accr += r16[e]*r16[e];
+  }
+  corr = row_sum(corr);
+  accx = row_sum(accx);
+  accr = row_sum(accr);
+  const PrepScalars p = prep_scalars(accx, accr, corr, xshift, rshift, q0, beta, cfl_enabled,
+   is_keyframe, r_null);
+  int m = 0;
+  int s = 1;
+  if (p.ran) {
+    /* od_compute_householder: (largest |r|, lowest index) over the row */
+    int ba = -1;
+    int bi = 0;
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+      const int a = abs(r16[e]);
+      if (a > ba) {
+        ba = a;
+        bi = l*E + e;
+      }
+    }
+#define OD_ARGMAX_STEP(CTRL) \
+    { \
+      const int oa = row_mov<CTRL>(ba); \
+      const int oi = row_mov<CTRL>(bi); \
+      const bool take = oa > ba || (oa == ba && oi < bi); \
+      ba = take ? oa : ba; \
+      bi = take ? oi : bi; \
+    }
+    OD_ARGMAX_STEP(OD_DPP_XOR1)
+    OD_ARGMAX_STEP(OD_DPP_XOR2)
+    OD_ARGMAX_STEP(OD_DPP_HALF_MIRROR)
+    OD_ARGMAX_STEP(OD_DPP_MIRROR)
+#undef OD_ARGMAX_STEP
+    m = bi;
+    int rm = 0;
+#pragma unroll
+    for (int e = 0; e < E; e++) if (l*E + e == m) rm = r16[e];
+    rm = row_sum(rm);
+    s = rm > 0 ? 1 : -1;
+    const int upd = (int16_t)(rm + odq_shr_round(p.gr*s, rshift));
+    int32_t l2r = 0;
+    int32_t proj = 0;
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+      if (l*E + e == m) r16[e] = upd;
+      l2r += odq_mult16_16(r16[e], r16[e]);
+      proj += odq_mult16_16(r16[e], x16[e]);
+    }
+    l2r = row_sum(l2r);
+    proj = row_sum(proj);
+    int16_t proj_1;
+    int outshift;
+    householder_consts(l2r, proj, &proj_1, &outshift);
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+      const int i = l*E + e;
+      int32_t tmp = odq_mult16_16(r16[e], proj_1);
+      tmp = outshift >= 0 ? odq_shr_round(tmp, outshift) : odq_shl32(tmp, -outshift);
+      const int16_t v = (int16_t)(x16[e] - tmp);
+      /* the reflected vector without element m (src/pvq_encoder.c:481) */
+      if (live && i != m) xro[i - (i > m)] = v;
+    }
+  }
+  if (live) {
+    if constexpr (E == 8) {
+      *reinterpret_cast<uint4 *>(x16o + l*E) = make_uint4(pack16(x16[0], x16[1]),
+       pack16(x16[2], x16[3]), pack16(x16[4], x16[5]), pack16(x16[6], x16[7]));
+      *reinterpret_cast<uint4 *>(r16o + l*E) = make_uint4(pack16(r16[0], r16[1]),
+       pack16(r16[2], r16[3]), pack16(r16[4], r16[5]), pack16(r16[6], r16[7]));
+    }
+    else {
+#pragma unroll
+      for (int e = 0; e < E; e += 2) {
+        *reinterpret_cast<uint32_t *>(x16o + l*E + e) = pack16(x16[e], x16[e + 1]);
+        *reinterpret_cast<uint32_t *>(r16o + l*E + e) = pack16(r16[e], r16[e + 1]);
+      }
+    }
+    if (l == 0) prep_write(it, rec + band, job, band, blk, xshift, rshift, p, r_null, flip, m, s);
+  }
+}
+
 
 /* ---- candidate lists -------------------------------------------------------------- */
 __device__ __forceinline__ void refb_candidates(const RJob &jb, int band, long blk,
@@ -827,6 +1087,9 @@ int g_perturb = 0;
 int upload_tables(void) {
   if (g_tables_uploaded) return ODHIP_SUCCESS;
   ODHIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(kRScanXY), OD_SCAN_XY, sizeof(OD_SCAN_XY)));
+  unsigned short packed[OD_SCAN_LEN];
+  for (int j = 0; j < OD_SCAN_LEN; j++) packed[j] = (unsigned short)(OD_SCAN_XY[j][1] << 8 | OD_SCAN_XY[j][0]);
+  ODHIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(gRScanPk), packed, sizeof(packed)));
   g_tables_uploaded = true;
   return ODHIP_SUCCESS;
 }
@@ -944,7 +1207,33 @@ extern "C" int odhip_pvq_ref_bands_multi(const odhip_pvq_refjob *jobs, int njobs
   RItems it;
   items_all(it, host, njobs, pvq_norm_lambda, 0);
   if (!it.nitems) return ODHIP_SUCCESS;
-  k_refb_prep<<<it.wg_start[it.nitems], kWave, 0, s>>>(it);
+  /* band 0 of every block first (it decides the chroma-from-luma flip of the
+     block), then the 8-coefficient bands per lane and the 32- / 128-coefficient
+     bands per row */
+  {
+    RItems pi;
+    items_begin(pi, pvq_norm_lambda);
+    for (int j = 0; j < njobs; j++) items_add(pi, j, 0, (host[j].nblocks + kWave - 1)/kWave);
+    k_refb_prep_lane<15><<<pi.wg_start[pi.nitems], kWave, 0, s>>>(pi);
+    items_begin(pi, pvq_norm_lambda);
+    for (int j = 0; j < njobs; j++) {
+      for (int b = 1; b < host[j].nb_bands; b++) {
+        if (host[j].off[b + 1] - host[j].off[b] == 8) items_add(pi, j, b, (host[j].nblocks + kWave - 1)/kWave);
+      }
+    }
+    if (pi.nitems) k_refb_prep_lane<8><<<pi.wg_start[pi.nitems], kWave, 0, s>>>(pi);
+    for (int sz = 32; sz <= 128; sz *= 4) {
+      items_begin(pi, pvq_norm_lambda);
+      for (int j = 0; j < njobs; j++) {
+        for (int b = 1; b < host[j].nb_bands; b++) {
+          if (host[j].off[b + 1] - host[j].off[b] == sz) items_add(pi, j, b, (host[j].nblocks + 3)/4);
+        }
+      }
+      if (!pi.nitems) continue;
+      if (sz == 32) k_refb_prep_row<2><<<pi.wg_start[pi.nitems], kWave, 0, s>>>(pi);
+      else k_refb_prep_row<8><<<pi.wg_start[pi.nitems], kWave, 0, s>>>(pi);
+    }
+  }
   k_refb_cands<<<it.wg_start[it.nitems], kWave, 0, s>>>(it);
   /* 128- and 32-coefficient bands: one band per 16-lane row; 15 and 8: per lane */
   const bool lane_only = getenv("ODHIP_PVQ_REF_LANE") != nullptr;
