@@ -536,7 +536,7 @@ class PvqRefJob:
         self.r16 = torch.zeros((B, self.len), dtype=torch.int16, device=dev)
         self.x16 = torch.zeros((B, self.len), dtype=torch.int16, device=dev)
         self.xr = torch.zeros((B, self.len), dtype=torch.int16, device=dev)
-        self.choice = torch.zeros((B, self.nb, 8), dtype=torch.int32, device=dev)
+        self.choice = torch.zeros((B, self.nb, 16), dtype=torch.int32, device=dev)
         self.dq = torch.zeros_like(coef)
         for t, dt, what in ((qm, torch.int16, "qm"), (qm_inv, torch.int16, "qm_inv"),
                             (rate, torch.float64, "rate")):

@@ -3,7 +3,7 @@
    for every block and band of a batch of coefficient planes, up to the
    rate-dependent choice, and the choice + synthesis that follows it.
 
-     k_refb_prep        one band per lane: chroma-from-luma sign flip of the block
+     k_refb_prep_*      per band: chroma-from-luma sign flip of the block
                         (od_pvq_encode, :846-872), gather of x and r in coding
                         order (od_raster_to_coding_order, src/partition.c:144),
                         QM scaling, gains, correlation, initial distortion
@@ -18,10 +18,11 @@
                         K-pulse searches on the reflected vector chained through
                         prev_k, distortions - then the no-reference loop
                         (:578-595)
-     k_refb_select      `cost < best_cost` / `cost <= best_cost` (:553, :600),
-                        skip rules (:611-622), od_gain_expand and
-                        od_pvq_synthesis_partial (:623-633, src/pvq.c:1037-1115),
-                        od_coding_order_to_raster
+     k_refb_choose      `cost < best_cost` / `cost <= best_cost` (:553, :600),
+                        skip rules (:611-622), od_gain_expand and the band-wide
+                        part of od_pvq_synthesis_partial (:623-633,
+                        src/pvq.c:1037-1115)
+     k_refb_synth       its per-coefficient part and od_coding_order_to_raster
 
    The libm call of the path: the reference's theta comes from glibc's acos.
    Everything downstream depends only on the INTEGER theta, so the device value
@@ -31,10 +32,10 @@
    odhip_pvq_ref_resolve recomputes their theta on the host with the very libm
    the reference calls, re-running a band when it differs.
 
-   First version of this stage: one band per lane throughout, no sorting by
-   pulse count, gathers per lane (DESIGN.md lists what the no-reference stage
-   did about each of these).  All double arithmetic is one IEEE operation per
-   reference operation (-ffp-contract=off). */
+   Mappings: 15- and 8-coefficient bands one band per lane, 32- and
+   128-coefficient bands one band per 16-lane DPP row (pvq_row.cuh).  The per-lane
+   searches are not yet sorted by pulse count.  All double arithmetic
+   is one IEEE operation per reference operation (-ffp-contract=off). */
 #include "../../include/daala_hip.h"
 #include <math.h>
 #include <stdlib.h>
@@ -927,14 +928,33 @@ __global__ __launch_bounds__(kWave) void k_refb_search_list(const Unc *list, int
   refb_search(g_rjobs[e.job], e.band, e.blk, 0, xs, ys, lambda);
 }
 
-/* ---- choice + synthesis ----------------------------------------------------------- */
+/* ---- choice + synthesis -----------------------------------------------------------
+   k_refb_choose<N>  one band per lane: the reference's selection among the
+                     candidates, the skip rules, and everything of
+                     od_pvq_synthesis_partial that is a property of the whole
+                     band (sum of squared pulses -> scale, the Householder
+                     projection of the synthesised vector), with the band's
+                     pulses and reference held as packed 16-byte vectors
+   k_refb_synth      one coefficient per thread in coding order: the
+                     per-coefficient part (scale, reflection, inverse QM) and
+                     od_coding_order_to_raster
+
+   choice[(blk*nb + band)*16 ..]: [0..7] as documented in include/daala_hip.h;
+   [8] mode (0 zero, 1 copy the reference, 4 copy the negated reference, 2
+   no-reference synthesis, 3 with reference), [9] pulse slot, [10] scale, [11]
+   qshift, [12] xm, [13] m, [14] proj_1, [15] outshift. */
 __device__ __forceinline__ int neg_interleave(int x, int ref) { /* src/pvq_encoder.c:235-239 */
   if (x < ref) return -2*(x - ref) - 1;
   if (x < 2*ref) return 2*(x - ref);
   return x - 1;
 }
 
-__global__ __launch_bounds__(kWave) void k_refb_select(RItems it) {
+__device__ unsigned char gRBandOf[OD_SCAN_LEN];
+
+template <int N>
+__global__ __launch_bounds__(kWave) void k_refb_choose(RItems it) {
+  constexpr int SH = N == 15 ? 1 : 0;     /* the 15-coefficient band is read from the DC slot on */
+  constexpr int NW = (N + SH)/2;
   const int item = find_item(it, blockIdx.x);
   const RJob &jb = g_rjobs[it.job[item]];
   const int band = it.band[item];
@@ -946,7 +966,6 @@ __global__ __launch_bounds__(kWave) void k_refb_select(RItems it) {
   const double *rate = jb.rate ? jb.rate + bi*(kSlots + 1) : nullptr;
   const double lambda = it.lambda;
   const int off = jb.off[band];
-  const int n = jb.off[band + 1] - off;
   const int cfl_enabled = jb.is_keyframe && jb.pli != 0;
   /* :417-455 */
   double best_cost = r.dist0 + lambda*(rate ? rate[0] : 0.);
@@ -957,33 +976,29 @@ __global__ __launch_bounds__(kWave) void k_refb_select(RItems it) {
   int best_k = 0;
   int32_t best_qtheta = 0;
   int chosen = -1;
-  for (int idx = 0; idx < r.ntheta; idx++) {
-    const odhip_pvq_refitem c = items[idx];
-    if (!(c.flags & ODHIP_REFITEM_SEARCHED)) continue;
-    const double cost = c.dist + lambda*(rate ? rate[1 + idx] : 0.);
-    if (cost < best_cost) {
+  int yslot = -1;
+  for (int idx = 0; idx < r.nitems; idx++) {
+    const int4 head = *reinterpret_cast<const int4 *>(&items[idx].gain);   /* gain, theta, ts, k */
+    const int4 tail = *reinterpret_cast<const int4 *>(&items[idx].qcg);    /* qcg, qtheta, flags, yslot */
+    if (!(tail.z & ODHIP_REFITEM_SEARCHED)) continue;
+    const double cost = items[idx].dist + lambda*(rate ? rate[1 + idx] : 0.);
+    if (idx < r.ntheta ? cost < best_cost : cost <= best_cost) {
       best_cost = cost;
-      qg = c.gain;
-      best_k = c.k;
-      best_qtheta = c.qtheta;
-      itheta = c.theta;
-      max_theta = c.ts;
-      noref = 0;
+      qg = head.x;
+      best_k = head.w;
       chosen = idx;
-    }
-  }
-  for (int idx = r.ntheta; idx < r.nitems; idx++) {
-    const odhip_pvq_refitem c = items[idx];
-    if (!(c.flags & ODHIP_REFITEM_SEARCHED)) continue;
-    const double cost = c.dist + lambda*(rate ? rate[1 + idx] : 0.);
-    if (cost <= best_cost) {
-      best_cost = cost;
-      qg = c.gain;
-      noref = 1;
-      best_k = c.k;
-      itheta = -1;
-      max_theta = 0;
-      chosen = idx;
+      yslot = tail.w;
+      if (idx < r.ntheta) {
+        best_qtheta = tail.y;
+        itheta = head.y;
+        max_theta = head.z;
+        noref = 0;
+      }
+      else {
+        noref = 1;
+        itheta = -1;
+        max_theta = 0;
+      }
     }
   }
   /* :611-622 */
@@ -995,39 +1010,45 @@ __global__ __launch_bounds__(kWave) void k_refb_select(RItems it) {
     if (!jb.is_keyframe && qg == 0) skip = r.icgr ? 1 : 2;
     if (qg == r.icgr && itheta == 0 && !cfl_enabled) skip = 2;
   }
-  int32_t *ch = jb.choice + bi*8;
-  ch[0] = chosen;
-  ch[1] = qg;
-  ch[2] = noref;
-  ch[3] = itheta;
-  ch[4] = max_theta;
-  ch[5] = best_k;
-  ch[6] = skip;
-  ch[7] = jb.is_keyframe ? (noref ? qg : neg_interleave(qg, r.icgr))
-   : (noref ? qg - 1 : neg_interleave(qg + 1, r.icgr + 1));
-  /* synthesis, :623-633 */
-  const long base = block_base(jb, blk);
-  od_coeff *out = jb.dq + base;
-  if (band == 0) out[0] = jb.coef[base];
+  int4 *ch = reinterpret_cast<int4 *>(jb.choice + bi*16);
+  ch[0] = make_int4(chosen, qg, noref, itheta);
+  ch[1] = make_int4(max_theta, best_k, skip, jb.is_keyframe ? (noref ? qg : neg_interleave(qg, r.icgr))
+   : (noref ? qg - 1 : neg_interleave(qg + 1, r.icgr + 1)));
   if (skip) {
     const int flip = (r.flags & ODHIP_REFBAND_FLIP) != 0;
-    for (int i = 0; i < n; i++) {
-      const long p = coef_pos(jb, off + i);
-      const od_coeff rv = jb.ref[base + p];
-      out[p] = skip == 2 ? (flip ? -rv : rv) : 0;
-    }
+    ch[2] = make_int4(skip == 2 ? (flip ? 4 : 1) : 0, -1, 0, 0);
+    ch[3] = make_int4(0, 0, 0, 0);
     return;
   }
-  const int yslot = chosen >= 0 ? items[chosen].yslot : -1;
-  const int16_t *yp = yslot >= 0 ? jb.y + ((long)yslot*jb.nblocks + blk)*jb.len + off : nullptr;
-  const int16_t *qm_inv = jb.qm_inv + off;
+  /* od_gain_expand + od_pvq_synthesis_partial (band-wide part), :623-633,
+     src/pvq.c:1037-1115 */
   const int32_t g = odq_gain_expand(odq_shl32(qg, ODQ_CGAIN_SHIFT) + (noref ? 0 : r.gain_offset),
    jb.q[band], jb.beta[band]);
-  /* od_pvq_synthesis_partial, src/pvq.c:1037-1115 */
-  const int nn = n - (!noref);
+  uint32_t yw[NW];
+  if (yslot >= 0) {
+    const uint4 *yp = reinterpret_cast<const uint4 *>(jb.y + ((long)yslot*jb.nblocks + blk)*jb.len
+     + off - SH);
+    if constexpr (NW >= 4) {
+#pragma unroll
+      for (int v = 0; v < NW/4; v++) {
+        const uint4 q = yp[v];
+        yw[4*v] = q.x;
+        yw[4*v + 1] = q.y;
+        yw[4*v + 2] = q.z;
+        yw[4*v + 3] = q.w;
+      }
+    }
+  }
+  else {
+#pragma unroll
+    for (int v = 0; v < NW; v++) yw[v] = 0;
+  }
+  auto yget = [&](int i) -> int { return (int16_t)(yw[(i + SH) >> 1] >> (16*((i + SH) & 1))); };
+  const int nn = N - (!noref);
   int yy = 0;
-  for (int i = 0; i < nn; i++) {
-    const int v = yp ? yp[i] : 0;
+#pragma unroll
+  for (int i = 0; i < N; i++) {
+    const int v = i < nn ? yget(i) : 0;
     yy += v*v;
   }
   int gshift = odq_ilog(g) - 14;
@@ -1040,44 +1061,95 @@ __global__ __launch_bounds__(kWave) void k_refb_select(RItems it) {
   }
   const int qshift = ODQ_QM_INV_SHIFT - gshift;
   if (noref) {
-    for (int i = 0; i < n; i++) {
-      const int32_t x = (int32_t)odq_mult16_32_q16(yp ? yp[i] : 0, scale);
-      out[coef_pos(jb, off + i)] = odq_shr_round(x*qm_inv[i], qshift);
-    }
+    ch[2] = make_int4(2, yslot, scale, qshift);
+    ch[3] = make_int4(0, 0, 0, 0);
     return;
   }
-  const int16_t *r16 = jb.r16 + blk*jb.len + off;
   const int m = r.m;
   const int s = r.s;
-  const int32_t theta = best_qtheta;
   /* src/pvq.c:1094-1114: the two double products by 2^-15 are exact */
-  scale = (int32_t)floor(.5 + (scale*(1./32768))*odq_pvq_sin(theta));
-  const int16_t xm = (int16_t)floor(.5 + ((-s*odq_shr_round(g, gshift))*(1./32768))*odq_pvq_cos(theta));
+  scale = (int32_t)floor(.5 + (scale*(1./32768))*odq_pvq_sin(best_qtheta));
+  const int16_t xm = (int16_t)floor(.5 + ((-s*odq_shr_round(g, gshift))*(1./32768))*odq_pvq_cos(best_qtheta));
+  uint32_t rw[NW];
+  {
+    const uint4 *rp = reinterpret_cast<const uint4 *>(jb.r16 + blk*jb.len + off - SH);
+#pragma unroll
+    for (int v = 0; v < NW/4; v++) {
+      const uint4 q = rp[v];
+      rw[4*v] = q.x;
+      rw[4*v + 1] = q.y;
+      rw[4*v + 2] = q.z;
+      rw[4*v + 3] = q.w;
+    }
+  }
   int32_t l2r = 0;
   int32_t proj = 0;
-  for (int i = 0; i < n; i++) {
-    const int16_t xi = i == m ? xm
-     : (int16_t)odq_mult16_32_q16(yp ? yp[i < m ? i : i - 1] : 0, scale);
-    l2r += odq_mult16_16(r16[i], r16[i]);
-    proj += odq_mult16_16(r16[i], xi);
+#pragma unroll
+  for (int i = 0; i < N; i++) {
+    const int ri = (int16_t)(rw[(i + SH) >> 1] >> (16*((i + SH) & 1)));
+    const int ysrc = i == 0 ? yget(0) : (i < m ? yget(i < N - 1 ? i : N - 2) : yget(i - 1));
+    const int16_t xi = i == m ? xm : (int16_t)odq_mult16_32_q16(ysrc, scale);
+    l2r += odq_mult16_16(ri, ri);
+    proj += odq_mult16_16(ri, xi);
   }
-  const int l2r_shift = (odq_ilog(l2r) - 1) - 14;
-  const int16_t l2r_norm = (int16_t)odq_vshr_round(l2r, l2r_shift);
-  const int16_t rcp = odq_rcp(l2r_norm);
-  const int proj_shift = (odq_ilog(abs(proj)) - 1) - 14;
-  const int16_t proj_norm = (int16_t)odq_vshr_round(proj, proj_shift);
-  const int16_t proj_1 = (int16_t)odq_mult16_16_q15(proj_norm, rcp);
-  int outshift = 14 - proj_shift - 1 + l2r_shift;
-  if (outshift > 30) outshift = 30;
-  for (int i = 0; i < n; i++) {
-    const int16_t xi = i == m ? xm
-     : (int16_t)odq_mult16_32_q16(yp ? yp[i < m ? i : i - 1] : 0, scale);
-    int32_t tmp = odq_mult16_16(r16[i], proj_1);
-    tmp = outshift >= 0 ? odq_shr_round(tmp, outshift) : odq_shl32(tmp, -outshift);
-    const int16_t v = (int16_t)(xi - tmp);
-    out[coef_pos(jb, off + i)] = odq_shr_round(v*qm_inv[i], qshift);
-  }
+  int16_t proj_1;
+  int outshift;
+  householder_consts(l2r, proj, &proj_1, &outshift);
+  ch[2] = make_int4(3, yslot, scale, qshift);
+  ch[3] = make_int4(xm, m, proj_1, outshift);
 }
+
+__global__ __launch_bounds__(256) void k_refb_synth(RItems it) {
+  const int item = find_item(it, blockIdx.x);
+  const RJob &jb = g_rjobs[it.job[item]];
+  const int len = jb.len;
+  const long t = (long)(blockIdx.x - it.wg_start[item])*256 + threadIdx.x;
+  const long blk = t/len;
+  if (blk >= jb.nblocks) return;
+  const int c = (int)(t - blk*len);
+  const long base = block_base(jb, blk);
+  od_coeff *out = jb.dq + base;
+  if (c == 0) {
+    out[0] = jb.coef[base];
+    return;
+  }
+  const int band = gRBandOf[c];
+  const int off = jb.off[band];
+  const int i = c - off;
+  const int pk = gRScanPk[c];
+  const long p = (long)(pk >> 8)*jb.w + (pk & 255);
+  const int4 *ch = reinterpret_cast<const int4 *>(jb.choice + (blk*jb.nb_bands + band)*16);
+  const int4 a = ch[2];
+  const int mode = a.x;
+  if (mode == 0) {
+    out[p] = 0;
+    return;
+  }
+  if (mode == 1 || mode == 4) {
+    const od_coeff rv = jb.ref[base + p];
+    out[p] = mode == 4 ? -rv : rv;
+    return;
+  }
+  const int yslot = a.y;
+  const int32_t scale = a.z;
+  const int qshift = a.w;
+  const int qmi = jb.qm_inv[c];
+  const int16_t *yp = jb.y + ((long)yslot*jb.nblocks + blk)*len + off;
+  if (mode == 2) {
+    const int32_t x = (int32_t)odq_mult16_32_q16(yslot >= 0 ? yp[i] : 0, scale);
+    out[p] = odq_shr_round(x*qmi, qshift);
+    return;
+  }
+  const int4 b = ch[3];
+  const int m = b.y;
+  const int16_t xi = i == m ? (int16_t)b.x
+   : (int16_t)odq_mult16_32_q16(yslot >= 0 ? yp[i < m ? i : i - 1] : 0, scale);
+  int32_t tmp = odq_mult16_16(jb.r16[blk*len + c], b.z);
+  tmp = b.w >= 0 ? odq_shr_round(tmp, b.w) : odq_shl32(tmp, -b.w);
+  const int16_t v = (int16_t)(xi - tmp);
+  out[p] = odq_shr_round(v*qmi, qshift);
+}
+
 
 /* ---- host side --------------------------------------------------------------------- */
 bool g_tables_uploaded = false;
@@ -1090,6 +1162,13 @@ int upload_tables(void) {
   unsigned short packed[OD_SCAN_LEN];
   for (int j = 0; j < OD_SCAN_LEN; j++) packed[j] = (unsigned short)(OD_SCAN_XY[j][1] << 8 | OD_SCAN_XY[j][0]);
   ODHIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(gRScanPk), packed, sizeof(packed)));
+  unsigned char band_of[OD_SCAN_LEN];
+  for (int j = 0; j < OD_SCAN_LEN; j++) {
+    int b = 0;
+    while (b + 1 < OD_NBANDS[4] && j >= OD_BAND_OFFS[4][b + 1]) b++;
+    band_of[j] = (unsigned char)b;
+  }
+  ODHIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(gRBandOf), band_of, sizeof(band_of)));
   g_tables_uploaded = true;
   return ODHIP_SUCCESS;
 }
@@ -1100,7 +1179,11 @@ int fill_job(RJob &d, const odhip_pvq_refjob &j, int mode) {
    || j.nplanes <= 0 || !j.band || !j.items || !j.y || !j.r16) {
     return ODHIP_EINVAL;
   }
-  if (((uintptr_t)j.band & 63) || ((uintptr_t)j.items & 15)) return ODHIP_EINVAL;
+  if (((uintptr_t)j.band & 63) || ((uintptr_t)j.items & 15) || ((uintptr_t)j.y & 15)
+   || ((uintptr_t)j.r16 & 15) || ((uintptr_t)j.x16 & 15) || ((uintptr_t)j.xr & 15)
+   || ((uintptr_t)j.choice & 15)) {
+    return ODHIP_EINVAL;
+  }
   if (mode == 0 ? (!j.d_qm || !j.x16 || !j.xr) : (!j.d_qm_inv || !j.choice || !j.d_dq)) {
     return ODHIP_EINVAL;
   }
@@ -1340,8 +1423,18 @@ extern "C" int odhip_pvq_ref_select_synth_multi(const odhip_pvq_refjob *jobs, in
     }
   }
   RItems it;
-  items_all(it, host, njobs, pvq_norm_lambda, 0);
-  if (!it.nitems) return ODHIP_SUCCESS;
-  k_refb_select<<<it.wg_start[it.nitems], kWave, 0, s>>>(it);
+  static const int sizes[4] = {128, 32, 15, 8};
+  for (int i = 0; i < 4; i++) {
+    items_all(it, host, njobs, pvq_norm_lambda, sizes[i]);
+    if (!it.nitems) continue;
+    const unsigned grid = it.wg_start[it.nitems];
+    if (sizes[i] == 128) k_refb_choose<128><<<grid, kWave, 0, s>>>(it);
+    else if (sizes[i] == 32) k_refb_choose<32><<<grid, kWave, 0, s>>>(it);
+    else if (sizes[i] == 15) k_refb_choose<15><<<grid, kWave, 0, s>>>(it);
+    else k_refb_choose<8><<<grid, kWave, 0, s>>>(it);
+  }
+  items_begin(it, pvq_norm_lambda);
+  for (int j = 0; j < njobs; j++) items_add(it, j, 0, (host[j].nblocks*host[j].len + 255)/256);
+  k_refb_synth<<<it.wg_start[it.nitems], 256, 0, s>>>(it);
   return odhip_check_launch();
 }

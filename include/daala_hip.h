@@ -443,9 +443,10 @@ typedef struct {
   double dist;
 } odhip_pvq_refitem;      /* 48 bytes */
 
-/* choice[(blk*nb + i)*8 ..]: {item (-1 = the initial candidate), qg, noref,
+/* choice[(blk*nb + i)*16 ..]: {item (-1 = the initial candidate), qg, noref,
    itheta, max_theta, k, skip (0, OD_PVQ_SKIP_ZERO 1, OD_PVQ_SKIP_COPY 2), the
-   return value of pvq_theta (:636-637)}. */
+   return value of pvq_theta (:636-637)}, then 8 words of synthesis parameters
+   private to the library. */
 typedef struct {
   const od_coeff *d_coef;    /* nplanes planes w x h of level bs               */
   const od_coeff *d_ref;     /* reference planes, same layout                  */
@@ -461,7 +462,8 @@ typedef struct {
   const int32_t *beta_band;  /* HOST [nb]                                      */
   odhip_pvq_refband *band;   /* out [B][nb], 64-byte aligned                   */
   odhip_pvq_refitem *items;  /* out [B][nb][ODHIP_PVQ_REF_SLOTS], 16-byte aligned */
-  int16_t *y;                /* out [ODHIP_PVQ_REF_SLOTS][B][len]              */
+  int16_t *y;                /* out [ODHIP_PVQ_REF_SLOTS][B][len]; y, r16, x16,
+                                xr 16-byte aligned                             */
   int16_t *r16;              /* out [B][len]: QM-scaled reference after
                                 od_compute_householder (input of the synthesis) */
   int16_t *x16;              /* work [B][len]                                  */
@@ -470,7 +472,7 @@ typedef struct {
                                 bits; entry 0 = the initial candidate (:420 /
                                 :452), entry 1 + i = items[i]; NULL = choose on
                                 distortion alone                               */
-  int32_t *choice;           /* select_synth out [B][nb][8]                    */
+  int32_t *choice;           /* select_synth out [B][nb][16], 16-byte aligned  */
   od_coeff *d_dq;            /* select_synth out: dequantised planes, layout of
                                 d_coef; DC passed through; uncoded positions 0 */
 } odhip_pvq_refjob;
