@@ -531,7 +531,7 @@ class PvqRefJob:
         self.beta_band = (ctypes.c_int32 * 12)(*[int(v) for v in beta_band])
         dev = coef.device
         self.band = torch.zeros((B, self.nb, 64), dtype=torch.uint8, device=dev)
-        self.items = torch.zeros((B, self.nb, REF_SLOTS, 48), dtype=torch.uint8, device=dev)
+        self.items = torch.zeros((3, self.nb, REF_SLOTS, B, 16), dtype=torch.uint8, device=dev)
         self.y = torch.zeros((REF_SLOTS, B, self.len), dtype=torch.int16, device=dev)
         self.r16 = torch.zeros((B, self.len), dtype=torch.int16, device=dev)
         self.x16 = torch.zeros((B, self.len), dtype=torch.int16, device=dev)
@@ -554,7 +554,19 @@ class PvqRefJob:
     def unpack(self):
         """Host copies: record fields [B][nb], item fields [B][nb][REF_SLOTS], y, choice."""
         rec = self.band.cpu().numpy().view(REFBAND_RECORD)[..., 0]
-        items = self.items.cpu().numpy().view(REFITEM_RECORD)[..., 0]
+        # three planes of 16-byte vectors [part][nb][slot][B] -> records [B][nb][slot]
+        raw = self.items.cpu().numpy()
+        items = np.zeros(raw.shape[1:4], REFITEM_RECORD)
+        head = raw[0].view("<i4")
+        tail = raw[1].view("<i4")
+        res = raw[2].view("<f8")
+        for i, f in enumerate(("gain", "theta", "ts", "k")):
+            items[f] = head[..., i]
+        for i, f in enumerate(("qcg", "qtheta", "flags", "yslot")):
+            items[f] = tail[..., i]
+        items["cos_dist"] = res[..., 0]
+        items["dist"] = res[..., 1]
+        items = np.ascontiguousarray(items.transpose(2, 0, 1))
         return {"rec": rec, "items": items, "y": self.y.cpu().numpy(),
                 "choice": self.choice.cpu().numpy(), "r16": self.r16.cpu().numpy(),
                 "x16": self.x16.cpu().numpy(), "xr": self.xr.cpu().numpy()}

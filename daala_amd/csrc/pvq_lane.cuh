@@ -23,6 +23,7 @@
    Translation units including this header are compiled with -ffp-contract=off;
    sqrt and division are the correctly rounded forms. */
 #pragma once
+#include "od_sel.cuh"
 
 namespace {
 
@@ -37,36 +38,6 @@ __global__ void k_rsq_fill(void) {
   if (i < kRsqN) {
     gRsqTable[i] = i < 16 ? kRsqrtTable[i] : __ddiv_rn(1., __dsqrt_rn((double)(i + 1)));
   }
-}
-
-/* Selects through an SGPR-pair mask (VOP3 encodings).  Measured on gfx950
-   (tools/ubench/fp64_rate.hip): back-to-back VOP2 `v_cndmask_b32 ..., vcc` -
-   what the compiler emits for `c ? a : b` on doubles, two per select - issue at
-   ~16-19 cycles each instead of ~4.4; the e64 forms do not.  The search loops
-   are five selects per candidate, so they are spelled out. */
-__device__ __forceinline__ unsigned long long od_cmp_gt(double a, double b) {
-  unsigned long long m;
-  asm("v_cmp_gt_f64_e64 %0, %1, %2" : "=s"(m) : "v"(a), "v"(b));
-  return m;
-}
-
-__device__ __forceinline__ int od_sel(unsigned long long m, int t, int f) {
-  int d;
-  asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(d) : "v"(f), "v"(t), "s"(m));
-  return d;
-}
-
-/* The candidate index as a running VGPR: `pos = od_sel(m, j, pos)` with j a
-   literal would need one VGPR per distinct j for the asm operand (the compiler
-   hoists all of them: 127 registers for n = 128). */
-__device__ __forceinline__ void od_inc(int &j) {
-  asm("v_add_u32 %0, 1, %0" : "+v"(j));
-}
-
-__device__ __forceinline__ double od_sel(unsigned long long m, double t, double f) {
-  const int lo = od_sel(m, __double2loint(t), __double2loint(f));
-  const int hi = od_sel(m, __double2hiint(t), __double2hiint(f));
-  return __hiloint2double(hi, lo);
 }
 
 struct LaneSearch {

@@ -43,8 +43,10 @@
 #include "od_common.cuh"
 #include "od_pvq_math.cuh"
 #include "gen/od_scan_tables.h"
+#define OD_RSQ_TABLE_N 512
 #include "pvq_search.cuh"
 #include "pvq_row.cuh"
+#include "pvq_regs.cuh"
 
 namespace {
 
@@ -60,7 +62,7 @@ struct RJob {
   const int16_t *qm;
   const int16_t *qm_inv;
   odhip_pvq_refband *rec;
-  odhip_pvq_refitem *items;
+  void *items;
   int16_t *y;
   int16_t *r16;
   int16_t *x16;
@@ -573,6 +575,32 @@ __global__ __launch_bounds__(kWave) void k_refb_prep_row(RItems it) {
 }
 
 
+/* ---- candidate records -------------------------------------------------------------
+   odhip_pvq_refitem in memory: three planes of 16-byte vectors, each
+   [nb][ODHIP_PVQ_REF_SLOTS][B] (block index fastest, so the lanes of a
+   wavefront - adjacent blocks - touch one contiguous kilobyte per access):
+     head  {gain, theta, ts, k}          written by the candidate kernel
+     tail  {qcg, qtheta, flags, yslot}   written by the search
+     res   {cos_dist, dist}              written by the search
+   The first layout - 48-byte records per (block, band, slot), fields read and
+   written one by one - made every access of a wavefront 64 separate sectors. */
+struct ItemPtr {
+  int4 *head;
+  int4 *tail;
+  int4 *res;
+  long stride;   /* vectors between consecutive slots */
+};
+
+__device__ __forceinline__ ItemPtr item_ptr(const RJob &jb, int band, long blk) {
+  ItemPtr p;
+  const long plane = (long)jb.nb_bands*kSlots*jb.nblocks;
+  p.head = reinterpret_cast<int4 *>(jb.items) + (long)band*kSlots*jb.nblocks + blk;
+  p.tail = p.head + plane;
+  p.res = p.tail + plane;
+  p.stride = jb.nblocks;
+  return p;
+}
+
 /* ---- candidate lists -------------------------------------------------------------- */
 __device__ __forceinline__ void refb_candidates(const RJob &jb, int band, long blk,
  int theta_override) {
@@ -581,7 +609,7 @@ __device__ __forceinline__ void refb_candidates(const RJob &jb, int band, long b
   if (theta_override >= 0) r.theta = theta_override;
   const int n = jb.off[band + 1] - jb.off[band];
   const int beta = jb.beta[band];
-  odhip_pvq_refitem *items = jb.items + (blk*jb.nb_bands + band)*kSlots;
+  const ItemPtr ip = item_ptr(jb, band, blk);
   int nitems = 0;
   if (r.flags & ODHIP_REFBAND_THETA) {
     const int gain_bound = (r.cg - r.gain_offset) >> ODQ_CGAIN_SHIFT;
@@ -596,28 +624,18 @@ __device__ __forceinline__ void refb_candidates(const RJob &jb, int band, long b
       int upper = (int)ceil(t);
       if (upper > ts - 1) upper = ts - 1;
       for (int j = lower; j <= upper && nitems < kSlots - 2; j++) {
-        odhip_pvq_refitem c;
-        c.gain = i;
-        c.theta = j;
-        c.ts = ts;
-        c.k = odq_compute_k_ref(j, n);
-        c.qcg = qcg;
-        c.qtheta = odq_pvq_compute_theta(j, ts);
-        c.flags = ODHIP_REFITEM_WITH_REF;
-        c.yslot = -1;
-        c.cos_dist = 0;
-        c.dist = 0;
+        const int4 c = make_int4(i, j, ts, odq_compute_k_ref(j, n));
         /* stable insertion by (k, gain): items_compare, src/pvq_encoder.c:301-305
            (glibc's qsort is a stable merge sort at this size) */
         int pos = nitems;
         while (pos > 0) {
-          const odhip_pvq_refitem q = items[pos - 1];
-          const int cmp = q.k == c.k ? q.gain - c.gain : q.k - c.k;
+          const int4 q = ip.head[(pos - 1)*ip.stride];
+          const int cmp = q.w == c.w ? q.x - c.x : q.w - c.w;
           if (cmp <= 0) break;
-          items[pos] = q;
+          ip.head[pos*ip.stride] = q;
           pos--;
         }
-        items[pos] = c;
+        ip.head[pos*ip.stride] = c;
         nitems++;
       }
     }
@@ -629,24 +647,18 @@ __device__ __forceinline__ void refb_candidates(const RJob &jb, int band, long b
     flags |= ODHIP_REFBAND_NOREF;
     const int gain_bound = r.cg >> ODQ_CGAIN_SHIFT;
     for (int i = gain_bound > 1 ? gain_bound : 1; i <= gain_bound + 1; i++) {
-      odhip_pvq_refitem c;
-      c.gain = i;
-      c.theta = -1;
-      c.ts = 0;
-      c.qcg = odq_shl32(i, ODQ_CGAIN_SHIFT);
-      c.k = odq_compute_k_noref(c.qcg, n, beta);
-      c.qtheta = 0;
-      c.flags = 0;
-      c.yslot = -1;
-      c.cos_dist = 0;
-      c.dist = 0;
-      items[nitems++] = c;
+      ip.head[nitems*ip.stride] = make_int4(i, -1, 0,
+       odq_compute_k_noref(odq_shl32(i, ODQ_CGAIN_SHIFT), n, beta));
+      nitems++;
     }
   }
-  rp->theta = r.theta;
-  rp->flags = (uint8_t)flags;
-  rp->nitems = nitems;
-  rp->ntheta = ntheta;
+  /* third vector of the record: {m, s, flags | theta | nitems | ntheta} */
+  int4 v;
+  v.x = (int)((uint32_t)(uint16_t)r.m | (uint32_t)(uint8_t)r.s << 16 | (uint32_t)flags << 24);
+  v.y = r.theta;
+  v.z = nitems;
+  v.w = ntheta;
+  reinterpret_cast<int4 *>(rp)[2] = v;
 }
 
 __global__ __launch_bounds__(kWave) void k_refb_cands(RItems it) {
@@ -664,44 +676,46 @@ __global__ __launch_bounds__(kWave) void k_refb_cands_list(const Unc *list, int 
   refb_candidates(g_rjobs[e.job], e.band, e.blk, e.theta);
 }
 
-/* ---- the candidate loops ---------------------------------------------------------- */
-__device__ __forceinline__ void store_pulses(int16_t *dst, const short *xs, const unsigned short *ys,
- int lane, int n) {
-  for (int j = 0; j < n; j++) {
-    const int yj = ys[j*kWave + lane];
-    dst[j] = (int16_t)(xs[j*kWave + lane] < 0 ? -yj : yj);
-  }
-}
-
-__device__ __forceinline__ void refb_search(const RJob &jb, int band, long blk, int lane, short *xs,
- unsigned short *ys, double lambda) {
+/* ---- the candidate loops -----------------------------------------------------------
+   src/pvq_encoder.c:506-565 (theta candidates) and :578-595 (no-reference
+   candidates) for one band, over a vector holder V that owns the band's |x|,
+   signs and pulses in whatever form its mapping uses:
+     V::load(src, pad)      the band vector (pad: the last position is not part
+                            of it - the n - 1 reflected coefficients)
+     V::search(n, k, prev_k, g2, lambda)   pvq_search_rdo_double on it
+     V::store(dst)          the signed pulses, coding order
+   `writer`: this lane records the band's results (one lane per band). */
+template <class V>
+__device__ __forceinline__ void refb_loops(const RJob &jb, int band, long blk, bool writer,
+ bool may_store, double lambda, V &v) {
   const odhip_pvq_refband r = jb.rec[blk*jb.nb_bands + band];
   const int off = jb.off[band];
   const int n = jb.off[band + 1] - off;
-  odhip_pvq_refitem *items = jb.items + (blk*jb.nb_bands + band)*kSlots;
+  const long nblocks = jb.nblocks;
+  const int len = jb.len;
+  int16_t *const yout = jb.y;
+  const ItemPtr ip = item_ptr(jb, band, blk);
   const double s2 = (1./256)*(1./256);   /* OD_CGAIN_SCALE_2 */
   const double t1 = 1./32768;            /* OD_TRIG_SCALE_1 */
   const int32_t cg = r.cg;
   const double dist0 = r.dist0;
   if (r.ntheta > 0) {
-    const int16_t *xr = jb.xr + blk*jb.len + off;
-    for (int j = 0; j < n - 1; j++) xs[j*kWave + lane] = xr[j];
+    v.load(jb.xr + blk*len + off, true);
     int prev_k = 0;
     int cur_slot = -1;
     double cos_dist = 0;
     const int32_t theta = r.theta;
     for (int idx = 0; idx < r.ntheta; idx++) {
-      odhip_pvq_refitem *ip = items + idx;
-      const int32_t qcg = ip->qcg;
-      const int32_t qtheta = ip->qtheta;
-      const int k = ip->k;
-      /* src/pvq_encoder.c:526-531 */
+      const int4 h = ip.head[idx*ip.stride];      /* gain, theta, ts, k */
+      const int32_t qcg = odq_shl32(h.x, ODQ_CGAIN_SHIFT) + r.gain_offset;
+      const int32_t qtheta = odq_pvq_compute_theta(h.y, h.z);
+      const int k = h.w;
+      /* :526-531 */
       double dist_theta = 2 - (2.*odq_pvq_cos(theta - qtheta))*t1;
       double dist = (1.4*(qcg - cg))*(qcg - cg) + (qcg*(double)cg)*dist_theta;
       dist *= s2;
       if (dist > dist0 + 1.0*lambda && k != 0) {
-        ip->flags = ODHIP_REFITEM_WITH_REF;
-        ip->yslot = -1;
+        if (writer) ip.tail[idx*ip.stride] = make_int4(qcg, qtheta, ODHIP_REFITEM_WITH_REF, -1);
         continue;
       }
       const double sin_prod = ((odq_pvq_sin(theta)*t1)*odq_pvq_sin(qtheta))*t1;
@@ -710,53 +724,75 @@ __device__ __forceinline__ void refb_search(const RJob &jb, int band, long blk, 
         cur_slot = -1;
       }
       else if (k != prev_k) {
-        double yy;
-        cos_dist = od_pvq_search_lane(xs, ys, lane, n - 1, k, prev_k,
-         ((qcg*(double)cg)*sin_prod)*s2, lambda, &yy);
+        cos_dist = v.search(n - 1, k, prev_k, ((qcg*(double)cg)*sin_prod)*s2, lambda);
         cur_slot = idx;
-        store_pulses(jb.y + ((long)idx*jb.nblocks + blk)*jb.len + off, xs, ys, lane, n - 1);
+        if (may_store) v.store(yout + ((long)idx*nblocks + blk)*len + off);
       }
       prev_k = k;
       /* :548-552 */
       dist_theta = 2 - (2.*odq_pvq_cos(theta - qtheta))*t1 + sin_prod*(2 - 2*cos_dist);
       dist = (1.4*(qcg - cg))*(qcg - cg) + (qcg*(double)cg)*dist_theta;
       dist *= s2;
-      ip->flags = ODHIP_REFITEM_WITH_REF | ODHIP_REFITEM_SEARCHED;
-      ip->yslot = cur_slot;
-      ip->cos_dist = cos_dist;
-      ip->dist = dist;
+      if (writer) {
+        ip.tail[idx*ip.stride] = make_int4(qcg, qtheta,
+         ODHIP_REFITEM_WITH_REF | ODHIP_REFITEM_SEARCHED, cur_slot);
+        ip.res[idx*ip.stride] = make_int4(__double2loint(cos_dist), __double2hiint(cos_dist),
+         __double2loint(dist), __double2hiint(dist));
+      }
     }
   }
   if (r.nitems > r.ntheta) {
-    const int16_t *x16 = jb.x16 + blk*jb.len + off;
-    for (int j = 0; j < n; j++) xs[j*kWave + lane] = x16[j];
+    v.load(jb.x16 + blk*len + off, false);
     int prev_k = 0;
     for (int idx = r.ntheta; idx < r.nitems; idx++) {
-      odhip_pvq_refitem *ip = items + idx;
-      const int32_t qcg = ip->qcg;
-      const int k = ip->k;
+      const int4 h = ip.head[idx*ip.stride];
+      const int32_t qcg = odq_shl32(h.x, ODQ_CGAIN_SHIFT);
+      const int k = h.w;
       /* :585-595 */
       double dist = (1.4*(qcg - cg))*(qcg - cg);
       dist *= s2;
       if (dist > dist0 && k != 0) {
-        ip->flags = 0;
-        ip->yslot = -1;
+        if (writer) ip.tail[idx*ip.stride] = make_int4(qcg, 0, 0, -1);
         continue;
       }
-      double yy;
-      const double cos_dist = od_pvq_search_lane(xs, ys, lane, n, k, prev_k, (qcg*(double)cg)*s2,
-       lambda, &yy);
+      const double cos_dist = v.search(n, k, prev_k, (qcg*(double)cg)*s2, lambda);
       prev_k = k;
-      store_pulses(jb.y + ((long)idx*jb.nblocks + blk)*jb.len + off, xs, ys, lane, n);
+      if (may_store) v.store(yout + ((long)idx*nblocks + blk)*len + off);
       dist = (1.4*(qcg - cg))*(qcg - cg) + (qcg*(double)cg)*(2 - 2*cos_dist);
       dist *= s2;
-      ip->flags = ODHIP_REFITEM_SEARCHED;
-      ip->yslot = idx;
-      ip->cos_dist = cos_dist;
-      ip->dist = dist;
+      if (writer) {
+        ip.tail[idx*ip.stride] = make_int4(qcg, 0, ODHIP_REFITEM_SEARCHED, idx);
+        ip.res[idx*ip.stride] = make_int4(__double2loint(cos_dist), __double2hiint(cos_dist),
+         __double2loint(dist), __double2hiint(dist));
+      }
     }
   }
 }
+
+/* One band per lane, |x| and pulses in LDS columns, any n (pvq_search.cuh): the
+   resolve path and, with ODHIP_PVQ_REF_LANE=1, every band size. */
+struct LdsVector {
+  short *xs;
+  unsigned short *ys;
+  int lane;
+  int n;
+  __device__ __forceinline__ void load(const int16_t *src, bool pad) {
+    const int cnt = n - (pad ? 1 : 0);
+    for (int j = 0; j < cnt; j++) xs[j*kWave + lane] = src[j];
+  }
+  __device__ __forceinline__ double search(int n_true, int k, int prev_k, double g2, double lambda) {
+    double yy;
+    cur = n_true;
+    return od_pvq_search_lane(xs, ys, lane, n_true, k, prev_k, g2, lambda, &yy);
+  }
+  __device__ __forceinline__ void store(int16_t *dst) {
+    for (int j = 0; j < cur; j++) {
+      const int yj = ys[j*kWave + lane];
+      dst[j] = (int16_t)(xs[j*kWave + lane] < 0 ? -yj : yj);
+    }
+  }
+  int cur;
+};
 
 __global__ __launch_bounds__(kWave) void k_refb_search(RItems it) {
   extern __shared__ __attribute__((aligned(16))) unsigned short lds[];
@@ -765,156 +801,10 @@ __global__ __launch_bounds__(kWave) void k_refb_search(RItems it) {
   const RJob &jb = g_rjobs[it.job[item]];
   const int band = it.band[item];
   const int n = jb.off[band + 1] - jb.off[band];
-  short *xs = (short *)lds;
-  unsigned short *ys = lds + n*kWave;
   const long blk = (long)(blockIdx.x - it.wg_start[item])*kWave + threadIdx.x;
   if (blk >= jb.nblocks) return;
-  refb_search(jb, band, blk, threadIdx.x, xs, ys, it.lambda);
-}
-
-/* The same candidate loops with one band per 16-lane row (pvq_row.cuh): bands of
-   16*E coefficients (E = 2: 32, E = 8: 128), all state in registers.  The
-   decisions of a row are uniform over its lanes (every lane evaluates them on
-   the same record and items); lane 0 of the row writes the item fields, every
-   lane its E pulses as one vector store. */
-template <int E>
-__device__ __forceinline__ void store_row_pulses(int16_t *dst, const int (&sg)[E], const int (&y)[E]) {
-  uint32_t w[E/2];
-#pragma unroll
-  for (int e = 0; e < E; e += 2) {
-    const int lo = sg[e] ? -y[e] : y[e];
-    const int hi = sg[e + 1] ? -y[e + 1] : y[e + 1];
-    w[e/2] = (uint32_t)(lo & 0xffff) | (uint32_t)hi << 16;
-  }
-  if constexpr (E == 8) *reinterpret_cast<uint4 *>(dst) = make_uint4(w[0], w[1], w[2], w[3]);
-  else {
-#pragma unroll
-    for (int e = 0; e < E/2; e++) reinterpret_cast<uint32_t *>(dst)[e] = w[e];
-  }
-}
-
-template <int E>
-__device__ __forceinline__ void load_row_vector(const int16_t *src, int (&ax)[E], int (&sg)[E]) {
-#pragma unroll
-  for (int e = 0; e < E; e++) {
-    const int v = src[e];
-    ax[e] = abs(v);
-    sg[e] = v < 0;
-  }
-}
-
-template <int E>
-__global__ __launch_bounds__(kWave) void k_refb_search_row(RItems it) {
-  constexpr int n = 16*E;
-  od_rsqrt_init(threadIdx.x);
-  const int item = find_item(it, blockIdx.x);
-  const RJob &jb = g_rjobs[it.job[item]];
-  const int band = it.band[item];
-  const int off = jb.off[band];
-  const int lane = threadIdx.x;
-  const int row = lane >> 4;
-  const int l = lane & 15;
-  const long nblocks = jb.nblocks;
-  const int len = jb.len;
-  const int nb_bands = jb.nb_bands;
-  int16_t *const yout = jb.y;
-  const long blk0 = (long)(blockIdx.x - it.wg_start[item])*4 + row;
-  const bool live = blk0 < nblocks;
-  const long blk = live ? blk0 : nblocks - 1;
-  const bool writer = live && l == 0;
-  const odhip_pvq_refband r = jb.rec[blk*nb_bands + band];
-  odhip_pvq_refitem *items = jb.items + (blk*nb_bands + band)*kSlots;
-  const double lambda = it.lambda;
-  const int force = it.perturb >> 1;
-  const double s2 = (1./256)*(1./256);   /* OD_CGAIN_SCALE_2 */
-  const double t1 = 1./32768;            /* OD_TRIG_SCALE_1 */
-  const int32_t cg = r.cg;
-  const double dist0 = r.dist0;
-  int ax[E];
-  int sg[E];
-  int y[E];
-  if (r.ntheta > 0) {
-    load_row_vector<E>(jb.xr + blk*len + off + l*E, ax, sg);
-    if (l == 15) {        /* the pad: xr holds n - 1 values */
-      ax[E - 1] = 0;
-      sg[E - 1] = 0;
-    }
-#pragma unroll
-    for (int e = 0; e < E; e++) y[e] = 0;
-    int prev_k = 0;
-    int cur_slot = -1;
-    double cos_dist = 0;
-    const int32_t theta = r.theta;
-    for (int idx = 0; idx < r.ntheta; idx++) {
-      odhip_pvq_refitem *ip = items + idx;
-      const int32_t qcg = ip->qcg;
-      const int32_t qtheta = ip->qtheta;
-      const int k = ip->k;
-      double dist_theta = 2 - (2.*odq_pvq_cos(theta - qtheta))*t1;
-      double dist = (1.4*(qcg - cg))*(qcg - cg) + (qcg*(double)cg)*dist_theta;
-      dist *= s2;
-      if (dist > dist0 + 1.0*lambda && k != 0) {
-        if (writer) {
-          ip->flags = ODHIP_REFITEM_WITH_REF;
-          ip->yslot = -1;
-        }
-        continue;
-      }
-      const double sin_prod = ((odq_pvq_sin(theta)*t1)*odq_pvq_sin(qtheta))*t1;
-      if (k == 0) {
-        cos_dist = 0;
-        cur_slot = -1;
-      }
-      else if (k != prev_k) {
-        double yy;
-        cos_dist = od_pvq_search_row<E>(ax, y, row, l, n - 1, k, prev_k,
-         ((qcg*(double)cg)*sin_prod)*s2, lambda, force, &yy);
-        cur_slot = idx;
-        if (live) store_row_pulses<E>(yout + ((long)idx*nblocks + blk)*len + off + l*E, sg, y);
-      }
-      prev_k = k;
-      dist_theta = 2 - (2.*odq_pvq_cos(theta - qtheta))*t1 + sin_prod*(2 - 2*cos_dist);
-      dist = (1.4*(qcg - cg))*(qcg - cg) + (qcg*(double)cg)*dist_theta;
-      dist *= s2;
-      if (writer) {
-        ip->flags = ODHIP_REFITEM_WITH_REF | ODHIP_REFITEM_SEARCHED;
-        ip->yslot = cur_slot;
-        ip->cos_dist = cos_dist;
-        ip->dist = dist;
-      }
-    }
-  }
-  if (r.nitems > r.ntheta) {
-    load_row_vector<E>(jb.x16 + blk*len + off + l*E, ax, sg);
-    int prev_k = 0;
-    for (int idx = r.ntheta; idx < r.nitems; idx++) {
-      odhip_pvq_refitem *ip = items + idx;
-      const int32_t qcg = ip->qcg;
-      const int k = ip->k;
-      double dist = (1.4*(qcg - cg))*(qcg - cg);
-      dist *= s2;
-      if (dist > dist0 && k != 0) {
-        if (writer) {
-          ip->flags = 0;
-          ip->yslot = -1;
-        }
-        continue;
-      }
-      double yy;
-      const double cos_dist = od_pvq_search_row<E>(ax, y, row, l, n, k, prev_k, (qcg*(double)cg)*s2,
-       lambda, force, &yy);
-      prev_k = k;
-      if (live) store_row_pulses<E>(yout + ((long)idx*nblocks + blk)*len + off + l*E, sg, y);
-      dist = (1.4*(qcg - cg))*(qcg - cg) + (qcg*(double)cg)*(2 - 2*cos_dist);
-      dist *= s2;
-      if (writer) {
-        ip->flags = ODHIP_REFITEM_SEARCHED;
-        ip->yslot = idx;
-        ip->cos_dist = cos_dist;
-        ip->dist = dist;
-      }
-    }
-  }
+  LdsVector v = {(short *)lds, lds + n*kWave, (int)threadIdx.x, n, 0};
+  refb_loops(jb, band, blk, true, true, it.lambda, v);
 }
 
 /* One listed band per wavefront (lane 0): the list is a handful of bands. */
@@ -923,10 +813,145 @@ __global__ __launch_bounds__(kWave) void k_refb_search_list(const Unc *list, int
   od_rsqrt_init(threadIdx.x);
   if (threadIdx.x != 0 || (int)blockIdx.x >= count) return;
   const Unc e = list[blockIdx.x];
-  short *xs = (short *)lds;
-  unsigned short *ys = lds + 128*kWave;
-  refb_search(g_rjobs[e.job], e.band, e.blk, 0, xs, ys, lambda);
+  const RJob &jb = g_rjobs[e.job];
+  LdsVector v = {(short *)lds, lds + 128*kWave, 0, jb.off[e.band + 1] - jb.off[e.band], 0};
+  refb_loops(jb, e.band, e.blk, true, true, lambda, v);
 }
+
+__device__ __forceinline__ uint32_t pack_pulses(int s0, int y0, int s1, int y1) {
+  return pack16(s0 ? -y0 : y0, s1 ? -y1 : y1);
+}
+
+/* One band per 16-lane row (pvq_row.cuh): bands of 16*E coefficients (E = 2: 32,
+   E = 8: 128), all state in registers; lane l of the row owns positions l*E ..
+   l*E+E-1.  The decisions of a row are uniform over its lanes (every lane
+   evaluates them on the same record and items). */
+template <int E>
+struct RowVector {
+  int ax[E];
+  int sg[E];
+  int y[E];
+  int row;
+  int l;
+  int force;
+  double xx;
+  double norm_1;
+  __device__ __forceinline__ void load(const int16_t *src, bool pad) {
+    const int16_t *p = src + l*E;
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+      const int v = p[e];
+      ax[e] = abs(v);
+      sg[e] = v < 0;
+      y[e] = 0;
+    }
+    if (pad && l == 15) {
+      ax[E - 1] = 0;
+      sg[E - 1] = 0;
+    }
+    od_row_norm<E>(ax, &xx, &norm_1);
+  }
+  __device__ __forceinline__ double search(int n_true, int k, int prev_k, double g2, double lambda) {
+    double yy;
+    return od_pvq_search_row<E>(ax, y, row, l, n_true, k, prev_k, g2, lambda, force, xx, norm_1, &yy);
+  }
+  __device__ __forceinline__ void store(int16_t *dst) {
+    int16_t *p = dst + l*E;
+    if constexpr (E == 8) {
+      *reinterpret_cast<uint4 *>(p) = make_uint4(pack_pulses(sg[0], y[0], sg[1], y[1]),
+       pack_pulses(sg[2], y[2], sg[3], y[3]), pack_pulses(sg[4], y[4], sg[5], y[5]),
+       pack_pulses(sg[6], y[6], sg[7], y[7]));
+    }
+    else {
+#pragma unroll
+      for (int e = 0; e < E; e += 2) {
+        *reinterpret_cast<uint32_t *>(p + e) = pack_pulses(sg[e], y[e], sg[e + 1], y[e + 1]);
+      }
+    }
+  }
+};
+
+template <int E>
+__global__ __launch_bounds__(kWave) void k_refb_search_row(RItems it) {
+  od_rsqrt_init(threadIdx.x);
+  const int item = find_item(it, blockIdx.x);
+  const RJob &jb = g_rjobs[it.job[item]];
+  const int lane = threadIdx.x;
+  RowVector<E> v;
+  v.row = lane >> 4;
+  v.l = lane & 15;
+  v.force = it.perturb >> 1;
+  const long nblocks = jb.nblocks;
+  const long blk0 = (long)(blockIdx.x - it.wg_start[item])*4 + v.row;
+  const bool live = blk0 < nblocks;
+  /* rows beyond the end redo the last block without storing anything */
+  refb_loops(jb, it.band[item], live ? blk0 : nblocks - 1, live && v.l == 0, live, it.lambda, v);
+}
+
+/* The short bands (N = 15, 8): one band per lane, the band in registers
+   (pvq_regs.cuh).  Vectors are read and written as whole 16-byte pieces; the
+   15-coefficient band shares its first piece with the unused DC slot. */
+template <int N>
+struct RegVector {
+  static constexpr int SH = N == 15 ? 1 : 0;
+  int ax[N];
+  int sg[N];
+  int y[N];
+  double xx;
+  double norm_1;
+  __device__ __forceinline__ void load(const int16_t *src, bool pad) {
+    const uint4 *p = reinterpret_cast<const uint4 *>(src - SH);
+    uint32_t w[(N + SH)/2];
+#pragma unroll
+    for (int q = 0; q < (N + SH)/8; q++) {
+      const uint4 t = p[q];
+      w[4*q] = t.x;
+      w[4*q + 1] = t.y;
+      w[4*q + 2] = t.z;
+      w[4*q + 3] = t.w;
+    }
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+      const int t = (int16_t)(w[(i + SH) >> 1] >> (16*((i + SH) & 1)));
+      ax[i] = abs(t);
+      sg[i] = t < 0;
+      y[i] = 0;
+    }
+    if (pad) {
+      ax[N - 1] = 0;
+      sg[N - 1] = 0;
+    }
+    od_regs_norm<N>(ax, &xx, &norm_1);
+  }
+  __device__ __forceinline__ double search(int n_true, int k, int prev_k, double g2, double lambda) {
+    double yy;
+    return od_pvq_search_regs<N>(ax, y, n_true, k, prev_k, g2, lambda, xx, norm_1, &yy);
+  }
+  __device__ __forceinline__ void store(int16_t *dst) {
+    uint4 *p = reinterpret_cast<uint4 *>(dst - SH);
+    int t[N + SH];
+    if (SH) t[0] = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) t[i + SH] = sg[i] ? -y[i] : y[i];
+#pragma unroll
+    for (int q = 0; q < (N + SH)/8; q++) {
+      p[q] = make_uint4(pack16(t[8*q], t[8*q + 1]), pack16(t[8*q + 2], t[8*q + 3]),
+       pack16(t[8*q + 4], t[8*q + 5]), pack16(t[8*q + 6], t[8*q + 7]));
+    }
+  }
+};
+
+template <int N>
+__global__ __launch_bounds__(kWave) void k_refb_search_regs(RItems it) {
+  od_rsqrt_init(threadIdx.x);
+  const int item = find_item(it, blockIdx.x);
+  const RJob &jb = g_rjobs[it.job[item]];
+  const long blk = (long)(blockIdx.x - it.wg_start[item])*kWave + threadIdx.x;
+  if (blk >= jb.nblocks) return;
+  RegVector<N> v;
+  refb_loops(jb, it.band[item], blk, true, true, it.lambda, v);
+}
+
 
 /* ---- choice + synthesis -----------------------------------------------------------
    k_refb_choose<N>  one band per lane: the reference's selection among the
@@ -962,7 +987,7 @@ __global__ __launch_bounds__(kWave) void k_refb_choose(RItems it) {
   if (blk >= jb.nblocks) return;
   const long bi = blk*jb.nb_bands + band;
   const odhip_pvq_refband r = jb.rec[bi];
-  const odhip_pvq_refitem *items = jb.items + bi*kSlots;
+  const ItemPtr ip = item_ptr(jb, band, blk);
   const double *rate = jb.rate ? jb.rate + bi*(kSlots + 1) : nullptr;
   const double lambda = it.lambda;
   const int off = jb.off[band];
@@ -978,10 +1003,11 @@ __global__ __launch_bounds__(kWave) void k_refb_choose(RItems it) {
   int chosen = -1;
   int yslot = -1;
   for (int idx = 0; idx < r.nitems; idx++) {
-    const int4 head = *reinterpret_cast<const int4 *>(&items[idx].gain);   /* gain, theta, ts, k */
-    const int4 tail = *reinterpret_cast<const int4 *>(&items[idx].qcg);    /* qcg, qtheta, flags, yslot */
+    const int4 tail = ip.tail[idx*ip.stride];    /* qcg, qtheta, flags, yslot */
     if (!(tail.z & ODHIP_REFITEM_SEARCHED)) continue;
-    const double cost = items[idx].dist + lambda*(rate ? rate[1 + idx] : 0.);
+    const int4 head = ip.head[idx*ip.stride];    /* gain, theta, ts, k */
+    const int4 res = ip.res[idx*ip.stride];      /* cos_dist, dist */
+    const double cost = __hiloint2double(res.w, res.z) + lambda*(rate ? rate[1 + idx] : 0.);
     if (idx < r.ntheta ? cost < best_cost : cost <= best_cost) {
       best_cost = cost;
       qg = head.x;
@@ -1169,6 +1195,8 @@ int upload_tables(void) {
     band_of[j] = (unsigned char)b;
   }
   ODHIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(gRBandOf), band_of, sizeof(band_of)));
+  od_rsqrt_fill_launch();
+  ODHIP_TRY(hipDeviceSynchronize());
   g_tables_uploaded = true;
   return ODHIP_SUCCESS;
 }
@@ -1340,6 +1368,11 @@ extern "C" int odhip_pvq_ref_bands_multi(const odhip_pvq_refjob *jobs, int njobs
     }
     items_all(it, host, njobs, pvq_norm_lambda, sizes[i]);
     if (!it.nitems) continue;
+    if (sizes[i] < 32 && !lane_only) {
+      if (sizes[i] == 15) k_refb_search_regs<15><<<it.wg_start[it.nitems], kWave, 0, s>>>(it);
+      else k_refb_search_regs<8><<<it.wg_start[it.nitems], kWave, 0, s>>>(it);
+      continue;
+    }
     const size_t lds = (size_t)2*sizes[i]*kWave*sizeof(unsigned short);
     k_refb_search<<<it.wg_start[it.nitems], kWave, lds, s>>>(it);
   }

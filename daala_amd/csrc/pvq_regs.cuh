@@ -1,0 +1,158 @@
+/* pvq_regs.cuh - pvq_search_rdo_double (reference src/pvq_encoder.c:93-224), one
+   band per lane with the band in REGISTERS: the form for the short bands
+   (N = 8, 15) of the with-reference stage, where a lane runs a chain of up to 14
+   searches on the same vector.  Every loop over the band is fully unrolled
+   (static register indices); each lane scans its candidates j = 0..n-1 in order
+   with the reference's comparator, so the result is the reference's by
+   construction.
+
+   n == N or N - 1: the n - 1 reflected coefficients of a with-reference search
+   occupy a vector of N with a PAD in the last position (|x| = 0, y = 0) whose
+   candidate key can never win; n enters the rate term and selects the k == 1
+   special cases (:154-163) as in the reference.
+
+   Requires pvq_search.cuh (od_rsqrt_table) before it and -ffp-contract=off. */
+#pragma once
+#include "od_sel.cuh"
+
+namespace {
+
+/* xx = sum x^2 and 1/sqrt(1e-30 + xx) (:107-109, :147): properties of the
+   vector, computed once per chain of searches. */
+template <int N>
+__device__ __forceinline__ void od_regs_norm(const int (&ax)[N], double *xx_out, double *norm_1_out) {
+  double xx = 0;
+#pragma unroll
+  for (int j = 0; j < N; j++) xx += (double)ax[j]*(double)ax[j];
+  *xx_out = xx;
+  *norm_1_out = __ddiv_rn(1., __dsqrt_rn(1e-30 + xx));
+}
+
+template <int N>
+__device__ __forceinline__ double od_pvq_search_regs(const int (&ax)[N], int (&y)[N], int n, int k,
+ int prev_k, double g2, double pvq_norm_lambda, double xx, double norm_1, double *yy_out) {
+  const bool padded = n != N;
+  double x[N];
+#pragma unroll
+  for (int j = 0; j < N; j++) x[j] = (double)ax[j];
+  const double lambda = __ddiv_rn(pvq_norm_lambda, 1e-30 + g2);
+  double xy = 0;
+  double yy = 0;
+  int i = 0;
+  if (prev_k > 0 && prev_k <= k) {
+#pragma unroll
+    for (int j = 0; j < N; j++) {
+      xy += x[j]*y[j];
+      yy += (double)(y[j]*y[j]);
+      i += y[j];
+    }
+  }
+  else if (k > 2) {
+    double l1_norm = 0;
+#pragma unroll
+    for (int j = 0; j < N; j++) l1_norm += x[j];
+    const double l1_inv = __ddiv_rn(1., l1_norm > 1e-100 ? l1_norm : 1e-100);
+#pragma unroll
+    for (int j = 0; j < N; j++) {
+      const double tmp = (k*x[j])*l1_inv;
+      int yj = (int)floor(tmp);
+      yj = yj > 0 ? yj : 0;
+      y[j] = yj;
+      xy += x[j]*yj;
+      yy += (double)(yj*yj);
+      i += yj;
+    }
+  }
+  else {
+#pragma unroll
+    for (int j = 0; j < N; j++) y[j] = 0;
+  }
+  const int rdo_pulses = 1 + k/4;
+  double delta_rate = __ddiv_rn(3., (double)n);
+  double accel_rate = 0.;
+  if (k == 1) {
+    if (n == 15) {
+      accel_rate = __ddiv_rn(-8., (double)n);
+      delta_rate = __ddiv_rn(4.5, (double)n) - accel_rate;
+    }
+    else if (n == 8) {
+      accel_rate = __ddiv_rn(5.7, (double)n);
+      delta_rate = __ddiv_rn(9.3, (double)n) - accel_rate;
+    }
+  }
+  /* Greedy pulses, :165-187. */
+  for (; i < k - rdo_pulses; i++) {
+    int pos = 0;
+    double best_xy = -10;
+    double best_yy = 1;
+#pragma unroll
+    for (int j = 0; j < N; j++) {
+      double tmp_xy = xy + x[j];
+      const double tmp_yy = yy + (double)(2*y[j]) + 1;
+      tmp_xy = tmp_xy*tmp_xy;
+      if (j == N - 1 && padded) tmp_xy = -1;   /* PAD: loses every comparison */
+      if (j == 0) {
+        best_xy = tmp_xy;
+        best_yy = tmp_yy;
+      }
+      else {
+        const unsigned long long take = od_cmp_gt(tmp_xy*best_yy, best_xy*tmp_yy);
+        best_xy = od_sel(take, tmp_xy, best_xy);
+        best_yy = od_sel(take, tmp_yy, best_yy);
+        pos = od_sel(take, j, pos);
+      }
+    }
+    int xp = 0;
+    int yp = 0;
+#pragma unroll
+    for (int j = 0; j < N; j++) {
+      if (j == pos) {
+        xp = ax[j];
+        yp = y[j];
+        y[j] = yp + 1;
+      }
+    }
+    xy = xy + (double)xp;
+    yy = yy + (double)(2*yp) + 1;
+  }
+  /* Last pulses with the rate term, :192-219. */
+  for (; i < k; i++) {
+    double tab[4];
+#pragma unroll
+    for (int t = 0; t < 4; t++) tab[t] = od_rsqrt_table((int)(yy + 2*t + 1));
+    int pos = 0;
+    double best_cost = -1e5;
+#pragma unroll
+    for (int j = 0; j < N; j++) {
+      double tmp_xy = xy + x[j];
+      const int yj = y[j];
+      double tmp_yy;
+      if (yj < 4) tmp_yy = yj == 0 ? tab[0] : yj == 1 ? tab[1] : yj == 2 ? tab[2] : tab[3];
+      else tmp_yy = od_rsqrt_table((int)(yy + (double)(2*yj) + 1));
+      tmp_xy = ((2*tmp_xy)*norm_1)*tmp_yy - (lambda*j)*(delta_rate + j*accel_rate);
+      if (j == N - 1 && padded) tmp_xy = -1.7976931348623157e308;   /* PAD */
+      if (j == 0) best_cost = tmp_xy;
+      else {
+        const unsigned long long take = od_cmp_gt(tmp_xy, best_cost);
+        best_cost = od_sel(take, tmp_xy, best_cost);
+        pos = od_sel(take, j, pos);
+      }
+    }
+    int xp = 0;
+    int yp = 0;
+#pragma unroll
+    for (int j = 0; j < N; j++) {
+      if (j == pos) {
+        xp = ax[j];
+        yp = y[j];
+        y[j] = yp + 1;
+      }
+    }
+    xy = xy + (double)xp;
+    yy = yy + (double)(2*yp) + 1;
+  }
+  *yy_out = yy;
+  return __ddiv_rn(xy, 1e-100 + __dsqrt_rn(xx*yy));
+}
+
+}  // namespace

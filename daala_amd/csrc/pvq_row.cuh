@@ -94,17 +94,24 @@ __device__ __forceinline__ double row_bcast(double v, int row, int src) {
    a wavefront may differ (or not call at all).  With n_true == 16*E - 1 the
    caller sets ax[E-1] = y[E-1] = 0 in lane 15.  Every lane of the row returns
    the same cosine distance. */
+/* xx = sum x^2 of the band (every lane of the row) and 1/sqrt(1e-30 + xx)
+   (:107-109, :147): properties of the vector, computed once per chain. */
 template <int E>
-__device__ __forceinline__ double od_pvq_search_row(const int (&ax)[E], int (&y)[E], int row,
- int l, int n_true, int k, int prev_k, double g2, double pvq_norm_lambda, int force_scan,
- double *yy_out) {
-  constexpr int n = 16*E;
-  const bool pad_lane = n_true != n && l == 15;
+__device__ __forceinline__ void od_row_norm(const int (&ax)[E], double *xx_out, double *norm_1_out) {
   double xx = 0;
 #pragma unroll
   for (int e = 0; e < E; e++) xx += (double)ax[e]*(double)ax[e];
   xx = row_sum(xx);
-  const double norm_1 = __ddiv_rn(1., __dsqrt_rn(1e-30 + xx));
+  *xx_out = xx;
+  *norm_1_out = __ddiv_rn(1., __dsqrt_rn(1e-30 + xx));
+}
+
+template <int E>
+__device__ __forceinline__ double od_pvq_search_row(const int (&ax)[E], int (&y)[E], int row,
+ int l, int n_true, int k, int prev_k, double g2, double pvq_norm_lambda, int force_scan,
+ double xx, double norm_1, double *yy_out) {
+  constexpr int n = 16*E;
+  const bool pad_lane = n_true != n && l == 15;
   const double lambda = __ddiv_rn(pvq_norm_lambda, 1e-30 + g2);
   double xy = 0;
   double yy = 0;

@@ -26,16 +26,45 @@ __device__ const double kRsqrtTable[16] = {
 
 /* The table is read with a different index in every lane: it is staged in LDS
    (a global or constant load with 64 addresses would serialise or miss).
-   Every kernel that searches calls od_rsqrt_init() once. */
-__shared__ double od_rsq_lds[16];
+   Every kernel that searches calls od_rsqrt_init() once.  OD_RSQ_TABLE_N
+   (default 16) may be raised by the including translation unit: entries beyond
+   16 are 1/sqrt(i) with the correctly rounded sqrt and division - the values
+   od_rsqrt_table computes on the fly - read from a table filled once per
+   process (od_rsqrt_fill_launch).  The last pulses of a search evaluate four
+   entries per pulse plus one per candidate holding four or more pulses; without
+   the table each is an fp64 sqrt and an fp64 division. */
+#ifndef OD_RSQ_TABLE_N
+# define OD_RSQ_TABLE_N 16
+#endif
+__shared__ double od_rsq_lds[OD_RSQ_TABLE_N];
 
+#if OD_RSQ_TABLE_N > 16
+__device__ double gRsqBig[OD_RSQ_TABLE_N];
+
+__global__ void k_rsq_big_fill(void) {
+  const int i = blockIdx.x*blockDim.x + threadIdx.x;
+  if (i < OD_RSQ_TABLE_N) {
+    gRsqBig[i] = i < 16 ? kRsqrtTable[i] : __ddiv_rn(1., __dsqrt_rn((double)(i + 1)));
+  }
+}
+
+static inline void od_rsqrt_fill_launch(void) {
+  k_rsq_big_fill<<<(OD_RSQ_TABLE_N + 255)/256, 256, 0, 0>>>();
+}
+
+__device__ __forceinline__ void od_rsqrt_init(int tid) {
+  for (int i = tid; i < OD_RSQ_TABLE_N; i += kWave) od_rsq_lds[i] = gRsqBig[i];
+  __syncthreads();
+}
+#else
 __device__ __forceinline__ void od_rsqrt_init(int tid) {
   if (tid < 16) od_rsq_lds[tid] = kRsqrtTable[tid];
   __syncthreads();
 }
+#endif
 
 __device__ __forceinline__ double od_rsqrt_table(int i) {
-  if (i <= 16) return od_rsq_lds[i - 1];
+  if (i <= OD_RSQ_TABLE_N) return od_rsq_lds[i - 1];
   return __ddiv_rn(1., __dsqrt_rn((double)i));
 }
 

@@ -401,10 +401,17 @@ int odhip_pvq_synthesis(od_coeff *d_out, const od_coeff *d_y, const int16_t *d_r
 
    Block index blk = (plane*(h/N) + by)*(w/N) + bx, B = number of blocks, nb =
    bands of the block size, len = min(N*N, 512).  Band i of block blk: record
-   band[blk*nb + i], candidates items[(blk*nb + i)*ODHIP_PVQ_REF_SLOTS ..] (theta
-   candidates first, in search order, then the no-reference ones), pulse vector
-   of slot s at y[(s*B + blk)*len + off[i] ..] (signed int16, coding order; n-1
-   values for a theta candidate, n for a no-reference one). */
+   band[blk*nb + i]; its candidates occupy slots 0 .. nitems-1 (theta candidates
+   first, in search order, then the no-reference ones); pulse vector of slot s at
+   y[(s*B + blk)*len + off[i] ..] (signed int16, coding order; n-1 values for a
+   theta candidate, n for a no-reference one).
+
+   `items` holds the candidates of all bands as THREE planes of 16-byte vectors,
+   each [nb][ODHIP_PVQ_REF_SLOTS][B] (block index fastest: adjacent lanes =
+   adjacent blocks = adjacent vectors): vector (i*ODHIP_PVQ_REF_SLOTS + s)*B + blk
+   of plane 0 is {gain, theta, ts, k}, of plane 1 (at + nb*SLOTS*B vectors)
+   {qcg, qtheta, flags, yslot}, of plane 2 {cos_dist, dist}; odhip_pvq_refitem
+   below names the fields (it is the gathered form, 48 bytes). */
 #define ODHIP_PVQ_REF_SLOTS 16
 #define ODHIP_REFBAND_R_NULL 1      /* the reference band is all zero                   */
 #define ODHIP_REFBAND_THETA 2       /* the theta search ran (:452)                      */
@@ -461,7 +468,8 @@ typedef struct {
   const int32_t *q_band;     /* HOST [nb]                                      */
   const int32_t *beta_band;  /* HOST [nb]                                      */
   odhip_pvq_refband *band;   /* out [B][nb], 64-byte aligned                   */
-  odhip_pvq_refitem *items;  /* out [B][nb][ODHIP_PVQ_REF_SLOTS], 16-byte aligned */
+  void *items;               /* out: 3 planes [nb][ODHIP_PVQ_REF_SLOTS][B] of 16-byte
+                                vectors (see above), 16-byte aligned           */
   int16_t *y;                /* out [ODHIP_PVQ_REF_SLOTS][B][len]; y, r16, x16,
                                 xr 16-byte aligned                             */
   int16_t *r16;              /* out [B][len]: QM-scaled reference after
