@@ -141,6 +141,7 @@ class Pipeline:
         for job in luma["jobs"]:
             job.dq = None
         self.noref_jobs = luma["jobs"]
+        self.side = torch.cuda.Stream(device=device)
 
     def _timed(self, key, fn, record):
         if not record:
@@ -156,28 +157,12 @@ class Pipeline:
 
     def step(self, record=False):
         D = self.D
+        if self.chroma_cfl:
+            return self._step_cfl(record)
         for s in self.sets:
             self._timed("forward_pyramid_" + s["name"],
                         lambda: D.forward_pyramid(s["px"], s["dec"], PIC_W, PIC_H,
                                                   levels=s["levels"]), record)
-        if self.chroma_cfl:
-            luma, chroma = self.sets
-            self._timed("pvq_noref_bands", lambda: D.pvq_noref_bands_multi(self.noref_jobs, self.lam),
-                        record)
-            self._timed("pvq_choose", lambda: D.pvq_choose_multi(self.noref_jobs, self.lam), record)
-            self._timed("pvq_ref_bands", lambda: D.pvq_ref_bands_multi(self.refjobs, self.lam),
-                        record)
-            self._timed("pvq_ref_select_synth",
-                        lambda: D.pvq_ref_select_synth_multi(self.refjobs, self.lam), record)
-            self._timed("dequant_inverse_luma",
-                        lambda: D.inverse_levels_pvq(luma["jobs"], 0, PIC_W, PIC_H,
-                                                     outs=luma["recon"]), record)
-
-            def chroma_inverse():
-                for bs, rj in enumerate(self.refjobs):
-                    D.inverse_level(rj.dq, 1, bs, PIC_W, PIC_H, out=chroma["recon"][bs])
-            self._timed("inverse_chroma", chroma_inverse, record)
-            return
         self._timed("pvq_noref_bands", lambda: D.pvq_noref_bands_multi(self.jobs, self.lam),
                     record)
         self._timed("pvq_choose", lambda: D.pvq_choose_multi(self.jobs, self.lam), record)
@@ -187,6 +172,38 @@ class Pipeline:
             self._timed("dequant_inverse_" + s["name"],
                         lambda: D.inverse_levels_pvq(s["jobs"], s["dec"], PIC_W, PIC_H,
                                                      outs=s["recon"]), record)
+
+    def _step_cfl(self, record):
+        """Luma (no-reference path) on the current stream, chroma (with-reference
+        path, reference planes resident) on a side stream; joined at the end."""
+        D, torch = self.D, self.torch
+        luma, chroma = self.sets
+        main = torch.cuda.current_stream()
+        self.side.wait_stream(main)
+        self._timed("forward_pyramid_luma",
+                    lambda: D.forward_pyramid(luma["px"], 0, PIC_W, PIC_H, levels=luma["levels"]),
+                    record)
+        self._timed("pvq_noref_bands", lambda: D.pvq_noref_bands_multi(self.noref_jobs, self.lam),
+                    record)
+        self._timed("pvq_choose", lambda: D.pvq_choose_multi(self.noref_jobs, self.lam), record)
+        self._timed("dequant_inverse_luma",
+                    lambda: D.inverse_levels_pvq(luma["jobs"], 0, PIC_W, PIC_H, outs=luma["recon"]),
+                    record)
+        with torch.cuda.stream(self.side):
+            self._timed("forward_pyramid_chroma",
+                        lambda: D.forward_pyramid(chroma["px"], 1, PIC_W, PIC_H,
+                                                  levels=chroma["levels"]), record)
+            # includes odhip_pvq_ref_resolve (waits for this stream only)
+            self._timed("pvq_ref_bands", lambda: D.pvq_ref_bands_multi(self.refjobs, self.lam),
+                        record)
+            self._timed("pvq_ref_select_synth",
+                        lambda: D.pvq_ref_select_synth_multi(self.refjobs, self.lam), record)
+
+            def chroma_inverse():
+                for bs, rj in enumerate(self.refjobs):
+                    D.inverse_level(rj.dq, 1, bs, PIC_W, PIC_H, out=chroma["recon"][bs])
+            self._timed("inverse_chroma", chroma_inverse, record)
+        main.wait_stream(self.side)
 
     def kernel_ms(self):
         """Average milliseconds per launch group and groups per run, per class."""

@@ -380,10 +380,11 @@ REF_EXPORT double ref_now(void) {
    q_band/beta_band: [5][12] per-band quantiser and beta; qm/qm_inv: coding-order
    tables for this plane's decimation, one slice per bs at qm_off[bs].
    Returns the number of transform blocks processed. */
-REF_EXPORT long ref_stage_plane(unsigned char *px, int px_stride, int w, int h,
+static long stage_plane_core(unsigned char *px, int px_stride, int w, int h,
  int dec, int pic_w, int pic_h, int pli, const int16_t *qm, const int16_t *qm_inv,
  const int *qm_off, const int *q_band, const int *beta_band,
- double pvq_norm_lambda, unsigned char *recon_px) {
+ double pvq_norm_lambda, unsigned char *recon_px, od_coeff **dq_out,
+ od_coeff *const *ref_levels) {
   od_coeff *levels[OD_NBSIZES];
   od_coeff *c;
   od_coeff *dq;
@@ -419,7 +420,27 @@ REF_EXPORT long ref_stage_plane(unsigned char *px, int px_stride, int w, int h,
         int bo;
         bo = by*n*w + bx*n;
         od_raster_to_coding_order(in, n, levels[bs] + bo, w);
-        memset(ref0, 0, sizeof(*ref0)*n*n);
+        if (ref_levels != NULL) {
+          /* keyframe chroma: the chroma-from-luma prediction and its sign, as
+             od_pvq_encode applies it before the band loop
+             (src/pvq_encoder.c:846-872; that block is not callable on its own,
+             so its dot product and negation are spelled out here) */
+          int32_t xy;
+          const int16_t *bqm;
+          od_raster_to_coding_order(ref0, n, ref_levels[bs] + bo, w);
+          bqm = qm + qm_off[bs];
+          xy = 0;
+          for (i = off[0]; i < off[1]; i++) {
+            int32_t rq;
+            int32_t inq;
+            rq = (int32_t)((uint32_t)ref0[i]*(uint32_t)(int32_t)bqm[i]);
+            inq = (int32_t)((uint32_t)in[i]*(uint32_t)(int32_t)bqm[i]);
+            xy = (int32_t)((uint32_t)xy + (uint32_t)((rq*(int64_t)inq)
+             >> ((OD_QM_SHIFT + OD_CFL_FLIP_SHIFT) << 1)));
+          }
+          if (xy < 0) for (i = off[0]; i < off[nb]; i++) ref0[i] = -ref0[i];
+        }
+        else memset(ref0, 0, sizeof(*ref0)*n*n);
         skip_diff = 0;
         for (i = 0; i < nb; i++) {
           int itheta;
@@ -437,6 +458,7 @@ REF_EXPORT long ref_stage_plane(unsigned char *px, int px_stride, int w, int h,
         nblocks++;
       }
     }
+    if (dq_out != NULL && dq_out[bs] != NULL) memcpy(dq_out[bs], dq, sizeof(*dq)*w*h);
     ref_inverse_level_plane(recon_px, w, c, dq, w, h, dec, bs, pic_w, pic_h);
   }
   for (bs = 0; bs <= top; bs++) free(levels[bs]);
@@ -444,4 +466,29 @@ REF_EXPORT long ref_stage_plane(unsigned char *px, int px_stride, int w, int h,
   free(dq);
   free(c);
   return nblocks;
+}
+
+REF_EXPORT long ref_stage_plane(unsigned char *px, int px_stride, int w, int h,
+ int dec, int pic_w, int pic_h, int pli, const int16_t *qm, const int16_t *qm_inv,
+ const int *qm_off, const int *q_band, const int *beta_band,
+ double pvq_norm_lambda, unsigned char *recon_px) {
+  return stage_plane_core(px, px_stride, w, h, dec, pic_w, pic_h, pli, qm, qm_inv,
+   qm_off, q_band, beta_band, pvq_norm_lambda, recon_px, NULL, NULL);
+}
+
+/* The same stage with, optionally, the dequantised coefficient plane of every
+   level handed back (dq_out[bs], w x h each, may be NULL) and, optionally, a
+   reference plane per level (ref_levels[bs], same layout as the coefficient
+   planes): every block is then coded by pvq_theta WITH that reference, after
+   the chroma-from-luma sign flip - the path keyframe chroma takes in the
+   reference encoder (src/encode.c:1680-1687).  bench.py times luma with dq_out
+   and chroma with ref_levels built from it (the non-TF branch of
+   od_resample_luma_coeffs, src/intra.c:97-108). */
+REF_EXPORT long ref_stage_plane_cfl(unsigned char *px, int px_stride, int w, int h,
+ int dec, int pic_w, int pic_h, int pli, const int16_t *qm, const int16_t *qm_inv,
+ const int *qm_off, const int *q_band, const int *beta_band,
+ double pvq_norm_lambda, unsigned char *recon_px, od_coeff **dq_out,
+ od_coeff *const *ref_levels) {
+  return stage_plane_core(px, px_stride, w, h, dec, pic_w, pic_h, pli, qm, qm_inv,
+   qm_off, q_band, beta_band, pvq_norm_lambda, recon_px, dq_out, ref_levels);
 }

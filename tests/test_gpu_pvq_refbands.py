@@ -141,3 +141,91 @@ def test_ref_jobs_argument_validation(hip):
     L = hip.lib()
     assert L.odhip_pvq_ref_bands_multi(None, 1, ctypes.c_double(0.1), None) != 0
     assert L.odhip_pvq_ref_select_synth_multi(None, 0, ctypes.c_double(0.1), None) != 0
+
+
+def test_chroma_from_luma_planes_match_the_compiled_reference(hip):
+    """End to end against the REAL reference (oracle/_ref): luma planes through
+    the reference's stage give the dequantised luma coefficients; their
+    upper-left quarters are the chroma-from-luma predictions (the non-TF branch of
+    od_resample_luma_coeffs, src/intra.c:97-108); the chroma plane then goes
+    through pvq_theta with those references on the CPU (ref_stage_plane_cfl) and
+    through forward pyramid -> with-reference band stage -> choice with the
+    host's rates -> synthesis -> inverse on the GPU.  Dequantised coefficient
+    planes of all four levels and the reconstructed pixels must be identical."""
+    import ctypes
+    import torch
+    from _libs import P, ref, synth_frame
+    r = ref()
+    if r is None:
+        pytest.skip("oracle/_ref not present")
+    lam = hip.OD_PVQ_LAMBDA
+    W, H = 128, 128
+    planes = synth_frame(W, H, seed=21)
+    rng = np.random.RandomState(5)
+    planes = [np.clip(p.astype(int) + rng.randint(-40, 41, size=p.shape), 0, 255).astype(np.uint8)
+              for p in planes]
+    qt = hip.QuantTables.load()
+    r.ref_stage_plane_cfl.restype = ctypes.c_long
+    qm_all = np.ascontiguousarray(qt.qm)
+    qmi_all = np.ascontiguousarray(qt.qm_inv)
+
+    def tables(p):
+        qm_off = (ctypes.c_int * 5)(*[int(qt.qm_offset[bs][p]) for bs in range(5)])
+        qb = (ctypes.c_int * 60)()
+        bb = (ctypes.c_int * 60)()
+        for bs in range(5):
+            for i, v in enumerate(qt.q_band(p, bs)):
+                qb[bs * 12 + i] = v
+            for i, v in enumerate(qt.beta_band(p, bs)):
+                bb[bs * 12 + i] = v
+        return qm_off, qb, bb
+
+    # luma on the CPU: dequantised planes of the five levels
+    luma = planes[0]
+    ldq = [np.zeros((H, W), np.int32) for _ in range(5)]
+    arr = (ctypes.c_void_p * 5)(*[a.ctypes.data for a in ldq])
+    qm_off, qb, bb = tables(0)
+    recon = np.zeros_like(luma)
+    r.ref_stage_plane_cfl(P(luma), W, W, H, 0, W, H, 0, P(qm_all), P(qmi_all), qm_off, qb, bb,
+                          ctypes.c_double(lam), P(recon), arr, None)
+    # chroma-from-luma predictions: upper-left quarter of every luma block one size up
+    cw, chh = W // 2, H // 2
+    refs = []
+    for bs in range(4):
+        n = 4 << bs
+        corner = ldq[bs + 1].reshape(H // (2 * n), 2 * n, W // (2 * n), 2 * n)[:, :n, :, :n]
+        refs.append(np.ascontiguousarray(corner.reshape(chh, cw)))
+    chroma = planes[1]
+    cdq = [np.zeros((chh, cw), np.int32) for _ in range(4)]
+    arr_dq = (ctypes.c_void_p * 5)(*([a.ctypes.data for a in cdq] + [None]))
+    arr_ref = (ctypes.c_void_p * 5)(*([a.ctypes.data for a in refs] + [None]))
+    qm_off, qb, bb = tables(1)
+    crecon = np.zeros_like(chroma)
+    nblk = r.ref_stage_plane_cfl(P(chroma), cw, cw, chh, 1, W, H, 1, P(qm_all), P(qmi_all), qm_off,
+                                 qb, bb, ctypes.c_double(lam), P(crecon), arr_dq, arr_ref)
+    assert nblk == sum((cw // (4 << bs)) * (chh // (4 << bs)) for bs in range(4))
+    # the same on the GPU
+    levels = hip.forward_pyramid(_cuda(chroma[None]), 1, W, H)
+    jobs, meta = [], []
+    for bs in range(4):
+        qm, qmi = qt.qm_slices(1, bs)
+        job = hip.PvqRefJob(levels[bs], _cuda(refs[bs][None]), bs, _cuda(qm), _cuda(qmi),
+                            qt.q_band(1, bs), qt.beta_band(1, bs), 1, 1)
+        jobs.append(job)
+        meta.append((qm, qmi))
+    hip.pvq_ref_bands_multi(jobs, lam)
+    torch.cuda.synchronize()
+    flips = 0
+    for bs, (job, (qm, qmi)) in enumerate(zip(jobs, meta)):
+        traces, _ = oracle_traces(levels[bs].cpu().numpy(), refs[bs][None], bs, qm, qmi,
+                                  qt.q_band(1, bs), qt.beta_band(1, bs), 1, 1, lam)
+        job.rate = _cuda(host_rates(job, traces, 1, 1))
+        flips += sum(t["flip"] for (blk, b), t in traces.items() if b == 0)
+    assert flips > 0
+    hip.pvq_ref_select_synth_multi(jobs, lam)
+    torch.cuda.synchronize()
+    for bs, job in enumerate(jobs):
+        assert np.array_equal(job.dq[0].cpu().numpy(), cdq[bs]), "dequantised chroma plane, level %d" % bs
+        assert np.abs(cdq[bs]).sum() > 0
+    got = hip.inverse_level(jobs[3].dq, 1, 3, W, H)[0].cpu().numpy()
+    assert np.array_equal(got, crecon), "reconstructed chroma pixels (32x32 level)"
