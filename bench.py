@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py - 1080p all-intra transform blocks/s (filter + DCT + PVQ) on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W [--frames F]
+    python bench.py --gpus N --steps K --warmup W [--frames F] [--chroma-noref]
 
 One STEP = one pass of the block-transform hot path over a batch of F synthetic
 1920x1080 4:2:0 frames (coded size 1920x1088) already resident
@@ -11,12 +11,18 @@ in HBM, per GPU:
                              and for EVERY block size 64..4 the split
                              pre-filter + 2-D fDCT of every block (luma 5
                              levels, chroma 4)
-  2. odhip_pvq_noref_bands_multi   every level: QM scaling, gain, both gain
+  2. luma: odhip_pvq_noref_bands_multi   every level: QM scaling, gain, both gain
                              candidates (K, pruning, K-pulse search, distortion)
-     odhip_pvq_choose_multi        choice, od_gain_expand, synthesis scale
-  3. for every level: odhip_inverse_level_pvq  (dequantisation of the chosen
-                             pulses = od_pvq_synthesis_partial + scan -> raster
-                             on load, iDCT, split post-filters, superblock-edge
+           odhip_pvq_choose_multi        choice, od_gain_expand, synthesis scale
+     chroma: odhip_pvq_ref_bands_multi (+ odhip_pvq_ref_resolve) - pvq_theta WITH
+                             the chroma-from-luma reference, as the reference
+                             encoder codes keyframe chroma: sign flip,
+                             Householder reflection, theta, up to 12 (gain,
+                             theta) candidates + 2 no-reference candidates per
+                             band with chained K-pulse searches
+             odhip_pvq_ref_select_synth_multi   choice, skip rules, synthesis
+  3. for every level: inverse (luma: dequantisation of the chosen pulses on
+                             load; iDCT, split post-filters, superblock-edge
                              post-filter, coefficient -> pixel)
 
 i.e. every block the reference's block-size RDO would evaluate goes through
@@ -25,6 +31,12 @@ prefilter + fDCT + PVQ + dequantisation + iDCT + postfilter exactly once:
 metric counts those blocks.  Entropy coding / rate pricing stay on the host in
 the reference's own C (SURVEY.md hard part 1) and are not part of the step; the
 choice between PVQ candidates is therefore made on distortion alone.
+
+The chroma-from-luma reference planes are built once, before timing, from this
+pipeline's own luma reconstruction (upper-left quarter of the co-located luma
+block's dequantised coefficients: od_resample_luma_coeffs, src/intra.c:97-108)
+and are resident in HBM like the pictures.  --chroma-noref runs chroma through
+the no-reference path instead (the workload of the first round-1 bench lines).
 
 N > 1: frames are sharded over ranks (independent all-intra frames, no
 data-path collective) -> weak scaling, F frames per GPU.
@@ -205,6 +217,29 @@ class Pipeline:
             self._timed("inverse_chroma", chroma_inverse, record)
         main.wait_stream(self.side)
 
+    def ref128_bytes(self):
+        """Algorithmic bytes and band count of one k_refb_search_row<8> launch,
+        counted from the records and candidate vectors the last step left."""
+        t = self.torch
+        total = 0
+        bands = 0
+        for job in self.refjobs:
+            for b in range(job.nb):
+                if job.offsets[b + 1] - job.offsets[b] != 128:
+                    continue
+                rec = job.band[:, b, :].contiguous().view(t.int32)       # [B][16]
+                nitems = rec[:, 10].to(t.int64)
+                ntheta = rec[:, 11].to(t.int64)
+                tail = job.items[1, b].contiguous().view(t.int32)        # [slot][B][4]
+                slot = t.arange(tail.shape[0], device=tail.device).view(-1, 1)
+                valid = slot < nitems.view(1, -1)
+                searched = valid & ((tail[:, :, 2] & 1) != 0)
+                stored = searched & (tail[:, :, 3] == slot)
+                total += int((64 + 254 * (ntheta > 0) + 256 * (nitems > ntheta) + 32 * nitems).sum())
+                total += int(16 * searched.sum() + 256 * stored.sum())
+                bands += rec.shape[0]
+        return total, bands
+
     def kernel_ms(self):
         """Average milliseconds per launch group and groups per run, per class."""
         out = {}
@@ -245,15 +280,17 @@ def algorithmic_bytes(F):
     }
 
 
-def cpu_baseline(qt, min_seconds=12.0, max_frames=32):
+def cpu_baseline(qt, chroma_cfl, min_seconds=12.0, max_frames=32):
     """The same per-block work on ONE host core with the reference's own C
     functions (oracle/_ref, kind 'reference') or, when that library is absent,
-    the oracle port.  Bounded sample: whole frames of the bench generator until
-    at least `min_seconds` of CPU work (about 10-30 s)."""
+    the oracle port (no-reference chroma only).  Bounded sample: whole frames of
+    the bench generator until at least `min_seconds` of CPU work (about 10-30 s)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from _libs import P, oracle, ref
     r = ref()
     kind = "reference" if r is not None else "port"
+    if r is None and chroma_cfl:
+        raise SystemExit("the chroma-from-luma CPU baseline needs oracle/_ref (prebuilt by build())")
     tables = []
     for p in (0, 1):
         qm_off = (ctypes.c_int * 5)(*[int(qt.qm_offset[bs][p]) for bs in range(5)])
@@ -267,32 +304,56 @@ def cpu_baseline(qt, min_seconds=12.0, max_frames=32):
         tables.append((qm_off, qb, bb))
     qm = np.ascontiguousarray(qt.qm)
     qmi = np.ascontiguousarray(qt.qm_inv)
+    lam = ctypes.c_double(0.147)
     blocks = 0
     nframes = 0
     busy = 0.0
+    if r is not None:
+        r.ref_stage_plane.restype = ctypes.c_long
+        r.ref_stage_plane_cfl.restype = ctypes.c_long
     while busy < min_seconds and nframes < max_frames:
         planes = synth_frame_np(1000 + nframes, 1234)  # generation is not timed
-        t0 = time.perf_counter()
+        ldq = [np.zeros((H, W), np.int32) for _ in range(5)] if chroma_cfl else None
+        refs = None
         for pli, px, dec in ((0, planes[0], 0), (1, planes[1], 1), (2, planes[2], 1)):
             p = 1 if pli else 0
             h, w = px.shape
             qm_off, qb, bb = tables[p]
             recon = np.zeros_like(px)
-            if r is not None:
-                r.ref_stage_plane.restype = ctypes.c_long
-                blocks += r.ref_stage_plane(P(px), w, w, h, dec, PIC_W, PIC_H, p, P(qm), P(qmi),
-                                            qm_off, qb, bb, ctypes.c_double(0.147), P(recon))
-            else:
+            t0 = time.perf_counter()
+            if r is None:
                 o = oracle()
                 o.odo_stage_plane.restype = ctypes.c_long
                 blocks += o.odo_stage_plane(P(px), w, w, h, dec, PIC_W, PIC_H, p, P(qm), P(qmi),
-                                            qm_off, qb, bb, ctypes.c_double(0.147), 1, P(recon))
-        busy += time.perf_counter() - t0
+                                            qm_off, qb, bb, lam, 1, P(recon))
+            elif not chroma_cfl:
+                blocks += r.ref_stage_plane(P(px), w, w, h, dec, PIC_W, PIC_H, p, P(qm), P(qmi),
+                                            qm_off, qb, bb, lam, P(recon))
+            elif pli == 0:
+                arr = (ctypes.c_void_p * 5)(*[a.ctypes.data for a in ldq])
+                blocks += r.ref_stage_plane_cfl(P(px), w, w, h, 0, PIC_W, PIC_H, 0, P(qm), P(qmi),
+                                                qm_off, qb, bb, lam, P(recon), arr, None)
+            else:
+                arr = (ctypes.c_void_p * 5)(*([a.ctypes.data for a in refs] + [None]))
+                blocks += r.ref_stage_plane_cfl(P(px), w, w, h, 1, PIC_W, PIC_H, 1, P(qm), P(qmi),
+                                                qm_off, qb, bb, lam, P(recon), None, arr)
+            busy += time.perf_counter() - t0
+            if chroma_cfl and pli == 0:
+                # chroma-from-luma predictions (a strided copy in the reference,
+                # od_resample_luma_coeffs; not timed on either side)
+                refs = []
+                for bs in range(4):
+                    n = 4 << bs
+                    c = ldq[bs + 1].reshape(H // (2 * n), 2 * n, W // (2 * n), 2 * n)[:, :n, :, :n]
+                    refs.append(np.ascontiguousarray(c.reshape(H // 2, W // 2)))
         nframes += 1
+    what = ("forward pyramid + pvq_theta (luma: no-reference bands; chroma: WITH the "
+            "chroma-from-luma reference) + inverse" if chroma_cfl else
+            "forward pyramid + pvq_theta noref bands + inverse")
     return {"value": blocks / busy, "unit": "blocks/s", "cores": 1, "kind": kind,
             "sample": "%d synthetic 1920x1088 4:2:0 frames of the bench generator (%d blocks) in "
-                      "%.1f s: forward pyramid + pvq_theta noref bands + inverse of every block "
-                      "at every level, reference C functions, single thread" % (nframes, blocks, busy)}
+                      "%.1f s: %s of every block at every level, reference C functions, single "
+                      "thread" % (nframes, blocks, busy, what)}
 
 
 def main():
@@ -302,8 +363,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--frames", type=int, default=8, help="1080p frames per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--chroma-cfl", action="store_true",
-                    help="chroma through pvq_theta's with-reference (chroma-from-luma) path")
+    ap.add_argument("--chroma-noref", action="store_true",
+                    help="chroma through pvq_theta's no-reference path (default: with the "
+                         "chroma-from-luma reference, as the reference encoder codes keyframes)")
+    ap.add_argument("--chroma-cfl", action="store_true", help="(default; kept for old command lines)")
     args = ap.parse_args()
 
     import torch
@@ -322,7 +385,8 @@ def main():
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     device = torch.device("cuda", local_rank)
 
-    pipe = Pipeline(D, args.frames, device, chroma_cfl=args.chroma_cfl)
+    cfl = not args.chroma_noref
+    pipe = Pipeline(D, args.frames, device, chroma_cfl=cfl)
     for _ in range(args.warmup):
         pipe.step()
 
@@ -331,7 +395,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    D.pvq_profile(True)   # HIP events around the dominant kernel, on its own stream
+    # HIP events around the dominant kernel, on the stream it is launched on
+    D.pvq_profile(True)
+    D.pvq_ref_profile(True)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -341,6 +407,8 @@ def main():
     dt = time.perf_counter() - t0
     search_ms = D.pvq_profile_read()
     D.pvq_profile(False)
+    ref_search_ms = D.pvq_ref_profile_read()
+    D.pvq_ref_profile(False)
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -368,6 +436,8 @@ def main():
         # 2 x 2n B pulses + 32 B record tail out = 6n + 64 = 832 B.
         n128 = 0
         for (w, h, planes, top) in ((W, H, args.frames, 4), (W // 2, H // 2, 2 * args.frames, 3)):
+            if cfl and top == 3:
+                continue     # chroma goes through the with-reference stage
             for bs in range(top + 1):
                 n128 += planes * (w // (4 << bs)) * (h // (4 << bs)) * [0, 0, 1, 3, 3][bs]
         s_ms = float(np.mean(search_ms)) if search_ms else float("nan")
@@ -398,6 +468,45 @@ def main():
                                     "source": "same PMC run (SQ_INSTS_VALU) and its serialised kernel trace"}
         except (OSError, ValueError, KeyError):
             pass
+        roof_noref = roof
+        if cfl and ref_search_ms:
+            # The with-reference stage's search of the 128-coefficient bands (one band
+            # per 16-lane row), timed the same way (odhip_pvq_ref_profile).  Algorithmic
+            # bytes per launch are counted from what the launch produced: per band the
+            # 64 B record, the 254 B reflected vector (+ 256 B x16 when the no-reference
+            # candidates run), per candidate 16 B in + 16 B out (+ 16 B result when
+            # searched), and 256 B of pulses per search that stored its vector.
+            r_ms = float(np.mean(ref_search_ms))
+            r_bytes, r_bands = pipe.ref128_bytes()
+            roof_ref = {"kernel": "k_refb_search_row<8> (with-reference candidate chains of the "
+                                  "128-coefficient chroma bands, one band per 16-lane row)",
+                        "bound": "hbm", "achieved": round(r_bytes / (r_ms * 1e-3) / 1e9, 1),
+                        "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(r_bytes / (r_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                        "traffic": None, "avg_ms_per_launch": round(r_ms, 4),
+                        "launches": len(ref_search_ms),
+                        "share_of_step": round(r_ms / (dt / args.steps * 1e3), 4),
+                        "algorithmic_bytes_per_launch": r_bytes, "bands_per_launch": r_bands}
+            try:
+                with open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")) as f:
+                    tr = json.load(f)["kernels"]
+                key = [k_ for k_ in tr if k_.startswith("k_refb_search_row<8")]
+                if key and args.frames == 8:
+                    roof_ref["traffic"] = tr[key[0]]["hbm_bytes_per_launch"]
+                    roof_ref["traffic_source"] = ("profiles/r1_pmc_traffic.json (rocprofv3 --pmc, "
+                                                  "same command)")
+                    vi = tr[key[0]].get("valu_wave_instructions")
+                    ex = tr[key[0]].get("exclusive_avg_us")
+                    if vi and ex:
+                        roof_ref["valu"] = {"wave_instructions_per_launch": vi,
+                                            "exclusive_ms": round(ex / 1e3, 4),
+                                            "issue_frac_of_peak": round(vi * 4 / (1024 * 2.4e9 * ex * 1e-6), 3),
+                                            "source": "same PMC run (SQ_INSTS_VALU) and its serialised "
+                                                      "kernel trace"}
+            except (OSError, ValueError, KeyError):
+                pass
+            if r_ms >= s_ms:
+                roof = roof_ref
         fd = kernels["forward_pyramid_luma"]
         roof["note"] = ("largest single kernel of the step; it overlaps with the other band-size "
                         "searches on forked streams, so its share is of wall time, not exclusive. "
@@ -426,16 +535,17 @@ def main():
                        "4/8/16/32/64 lapped-DCT pyramid + PVQ noref bands + inverse, "
                        "every block of every level" + (
                            "; chroma through the with-reference (chroma-from-luma) PVQ path"
-                           if args.chroma_cfl else ""),
+                           if cfl else "; chroma through the no-reference PVQ path"),
                        "frames_per_gpu_per_step": args.frames,
                        "blocks_per_frame": bpf, "quality": "-v 20 (quantizer 243)",
                        "sharding": "frames over ranks, no data-path collective"},
             "roofline": roof,
             "roofline_filter_dct": roof_fd,
+            "roofline_noref_search": roof_noref if roof is not roof_noref else None,
             "kernels": kernels,
         }
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(pipe.qt)
+            line["cpu_baseline"] = cpu_baseline(pipe.qt, cfl)
             line["speedup_vs_cpu_baseline"] = line["value"] / line["cpu_baseline"]["value"]
         print(json.dumps(line))
     if dist is not None:

@@ -617,3 +617,16 @@ def pvq_ref_theta_probe(corr):
     _check(lib().odhip_pvq_ref_theta_probe(_p(corr), _p(out), ctypes.c_long(corr.numel()),
                                            _stream()), "odhip_pvq_ref_theta_probe")
     return out
+
+
+def pvq_ref_profile(enable):
+    _check(lib().odhip_pvq_ref_profile(int(bool(enable))), "odhip_pvq_ref_profile")
+
+
+def pvq_ref_profile_read(max_n=256):
+    """Milliseconds of each k_refb_search_row<8> launch recorded since the last read."""
+    buf = (ctypes.c_float * max_n)()
+    n = lib().odhip_pvq_ref_profile_read(buf, max_n)
+    if n < 0:
+        raise DaalaHipError("odhip_pvq_ref_profile_read failed with code %d" % n)
+    return [buf[i] for i in range(n)]

@@ -1323,7 +1323,39 @@ int rjoin(hipStream_t s, hipStream_t side[2]) {
   return ODHIP_SUCCESS;
 }
 
+/* Profiling aid (odhip_pvq_ref_profile): HIP events around the dominant kernel of
+   the stage - the row-parallel search of the 128-coefficient bands - on the
+   stream it is launched on. */
+constexpr int kProfSlots = 256;
+bool g_prof_on = false;
+bool g_prof_made = false;
+int g_prof_n = 0;
+hipEvent_t g_prof_ev[kProfSlots][2];
+
 }  // namespace
+
+extern "C" int odhip_pvq_ref_profile(int enable) {
+  if (enable && !g_prof_made) {
+    for (int i = 0; i < kProfSlots; i++) {
+      ODHIP_TRY(hipEventCreate(&g_prof_ev[i][0]));
+      ODHIP_TRY(hipEventCreate(&g_prof_ev[i][1]));
+    }
+    g_prof_made = true;
+  }
+  g_prof_on = enable != 0;
+  g_prof_n = 0;
+  return ODHIP_SUCCESS;
+}
+
+extern "C" int odhip_pvq_ref_profile_read(float *ms, int max_n) {
+  int n = 0;
+  for (; n < g_prof_n && n < max_n; n++) {
+    ODHIP_TRY(hipEventSynchronize(g_prof_ev[n][1]));
+    ODHIP_TRY(hipEventElapsedTime(&ms[n], g_prof_ev[n][0], g_prof_ev[n][1]));
+  }
+  g_prof_n = 0;
+  return n;
+}
 
 extern "C" void odhip_pvq_ref_set_theta_margin(double margin, int perturb) {
   g_margin = margin > 0 ? margin : kDefaultMargin;
@@ -1399,7 +1431,12 @@ extern "C" int odhip_pvq_ref_bands_multi(const odhip_pvq_refjob *jobs, int njobs
         }
       }
       if (!it.nitems) continue;
-      if (sizes[i] == 128) k_refb_search_row<8><<<it.wg_start[it.nitems], kWave, 0, s>>>(it);
+      if (sizes[i] == 128) {
+        const bool prof = g_prof_on && g_prof_n < kProfSlots;
+        if (prof) (void)hipEventRecord(g_prof_ev[g_prof_n][0], s);
+        k_refb_search_row<8><<<it.wg_start[it.nitems], kWave, 0, s>>>(it);
+        if (prof) (void)hipEventRecord(g_prof_ev[g_prof_n++][1], s);
+      }
       else k_refb_search_row<2><<<it.wg_start[it.nitems], kWave, 0, s>>>(it);
       continue;
     }

@@ -498,6 +498,12 @@ int odhip_pvq_ref_resolve(const odhip_pvq_refjob *jobs, int njobs,
  double pvq_norm_lambda, odhip_stream stream);
 int odhip_pvq_ref_select_synth_multi(const odhip_pvq_refjob *jobs, int njobs,
  double pvq_norm_lambda, odhip_stream stream);
+/* Profiling aid (bench.py), as odhip_pvq_profile: while enabled,
+   odhip_pvq_ref_bands_multi brackets the dominant kernel of this stage - the
+   row-parallel search of the 128-coefficient bands, k_refb_search_row<8> - with
+   HIP events on the stream the kernel is launched on. */
+int odhip_pvq_ref_profile(int enable);
+int odhip_pvq_ref_profile_read(float *ms, int max_n);
 /* Test hooks: the uncertainty margin (default 1e-9; <= 0 restores it) and, when
    perturb != 0, a deliberately wrong device theta (+1) for the listed bands, so
    that tests exercise the host-libm path on real data. */
