@@ -70,6 +70,9 @@ struct RJob {
   const double *rate;
   int32_t *choice;
   od_coeff *dq;
+  /* library scratch of the sorted searches */
+  unsigned short *keys;   /* [nb][B] work class of the band (heavy = small)       */
+  unsigned *ids;          /* [nb][B] block indices sorted by key                  */
   long nblocks;
   int nplanes;
   int w;
@@ -601,6 +604,99 @@ __device__ __forceinline__ ItemPtr item_ptr(const RJob &jb, int band, long blk) 
   return p;
 }
 
+/* ---- sorting the bands of an item by work -----------------------------------------
+   The cost of a band is the number of pulses its chains place, which spans
+   0..hundreds within one level, and a wavefront (64 bands, or 4 rows) runs as
+   long as its slowest member.  The candidate kernel classifies every band
+   (kSortBins classes, heavy first); a counting sort per (job, band) item - LDS
+   histogram per chunk of blocks, one global atomic per non-empty class per
+   chunk - yields the block order the searches walk. */
+constexpr int kSortBins = 256;
+constexpr int kSortChunk = 2048;
+
+__device__ __forceinline__ int od_work_bin(int pulses) {   /* 0..kSortBins-1, monotone */
+  if (pulses < 96) return pulses;
+  const int b = 96 + ((pulses - 96) >> 3);
+  return b < kSortBins ? b : kSortBins - 1;
+}
+
+__device__ unsigned g_rhist[kMaxItems*kSortBins];     /* zero between calls */
+__device__ unsigned g_rcursor[kMaxItems*kSortBins];
+
+__device__ __forceinline__ int item_slot(const RItems &it, int item) {
+  return it.job[item]*ODHIP_MAX_BANDS + it.band[item];
+}
+
+__global__ __launch_bounds__(256) void k_refb_hist(RItems it) {
+  __shared__ unsigned h[kSortBins];
+  const int item = find_item(it, blockIdx.x);
+  const RJob &jb = g_rjobs[it.job[item]];
+  const long nblocks = jb.nblocks;
+  const unsigned short *keys = jb.keys + (long)it.band[item]*nblocks;
+  h[threadIdx.x] = 0;
+  __syncthreads();
+  const long first = (long)(blockIdx.x - it.wg_start[item])*kSortChunk;
+  for (int i = threadIdx.x; i < kSortChunk; i += 256) {
+    const long blk = first + i;
+    if (blk < nblocks) atomicAdd(&h[keys[blk]], 1u);
+  }
+  __syncthreads();
+  const unsigned c = h[threadIdx.x];
+  if (c) atomicAdd(&g_rhist[item_slot(it, item)*kSortBins + threadIdx.x], c);
+}
+
+/* One workgroup per item: exclusive prefix over the classes -> start cursors;
+   clears the histogram for the next call. */
+__global__ __launch_bounds__(256) void k_refb_prefix(RItems it) {
+  __shared__ unsigned h[kSortBins];
+  const int slot = item_slot(it, blockIdx.x);
+  h[threadIdx.x] = g_rhist[slot*kSortBins + threadIdx.x];
+  g_rhist[slot*kSortBins + threadIdx.x] = 0;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned acc = 0;
+    for (int b = 0; b < kSortBins; b++) {
+      const unsigned c = h[b];
+      h[b] = acc;
+      acc += c;
+    }
+  }
+  __syncthreads();
+  g_rcursor[slot*kSortBins + threadIdx.x] = h[threadIdx.x];
+}
+
+__global__ __launch_bounds__(256) void k_refb_scatter(RItems it) {
+  __shared__ unsigned h[kSortBins];
+  __shared__ unsigned base[kSortBins];
+  const int item = find_item(it, blockIdx.x);
+  const RJob &jb = g_rjobs[it.job[item]];
+  const long nblocks = jb.nblocks;
+  const unsigned short *keys = jb.keys + (long)it.band[item]*nblocks;
+  unsigned *ids = jb.ids + (long)it.band[item]*nblocks;
+  h[threadIdx.x] = 0;
+  __syncthreads();
+  const long first = (long)(blockIdx.x - it.wg_start[item])*kSortChunk;
+  unsigned rank[kSortChunk/256];
+  int key[kSortChunk/256];
+#pragma unroll
+  for (int t = 0; t < kSortChunk/256; t++) {
+    const long blk = first + t*256 + threadIdx.x;
+    key[t] = -1;
+    if (blk < nblocks) {
+      key[t] = keys[blk];
+      rank[t] = atomicAdd(&h[key[t]], 1u);
+    }
+  }
+  __syncthreads();
+  const unsigned c = h[threadIdx.x];
+  base[threadIdx.x] = c ? atomicAdd(&g_rcursor[item_slot(it, item)*kSortBins + threadIdx.x], c) : 0;
+  __syncthreads();
+#pragma unroll
+  for (int t = 0; t < kSortChunk/256; t++) {
+    if (key[t] >= 0) ids[base[key[t]] + rank[t]] = (unsigned)(first + t*256 + threadIdx.x);
+  }
+}
+
 /* ---- candidate lists -------------------------------------------------------------- */
 __device__ __forceinline__ void refb_candidates(const RJob &jb, int band, long blk,
  int theta_override) {
@@ -611,6 +707,8 @@ __device__ __forceinline__ void refb_candidates(const RJob &jb, int band, long b
   const int beta = jb.beta[band];
   const ItemPtr ip = item_ptr(jb, band, blk);
   int nitems = 0;
+  int kmax_theta = 0;
+  int kmax_noref = 0;
   if (r.flags & ODHIP_REFBAND_THETA) {
     const int gain_bound = (r.cg - r.gain_offset) >> ODQ_CGAIN_SHIFT;
     const double scale_1 = __ddiv_rn(1., kThetaScale);   /* OD_THETA_SCALE_1 */
@@ -625,6 +723,7 @@ __device__ __forceinline__ void refb_candidates(const RJob &jb, int band, long b
       if (upper > ts - 1) upper = ts - 1;
       for (int j = lower; j <= upper && nitems < kSlots - 2; j++) {
         const int4 c = make_int4(i, j, ts, odq_compute_k_ref(j, n));
+        kmax_theta = c.w > kmax_theta ? c.w : kmax_theta;
         /* stable insertion by (k, gain): items_compare, src/pvq_encoder.c:301-305
            (glibc's qsort is a stable merge sort at this size) */
         int pos = nitems;
@@ -647,8 +746,9 @@ __device__ __forceinline__ void refb_candidates(const RJob &jb, int band, long b
     flags |= ODHIP_REFBAND_NOREF;
     const int gain_bound = r.cg >> ODQ_CGAIN_SHIFT;
     for (int i = gain_bound > 1 ? gain_bound : 1; i <= gain_bound + 1; i++) {
-      ip.head[nitems*ip.stride] = make_int4(i, -1, 0,
-       odq_compute_k_noref(odq_shl32(i, ODQ_CGAIN_SHIFT), n, beta));
+      const int kk = odq_compute_k_noref(odq_shl32(i, ODQ_CGAIN_SHIFT), n, beta);
+      ip.head[nitems*ip.stride] = make_int4(i, -1, 0, kk);
+      kmax_noref = kk > kmax_noref ? kk : kmax_noref;
       nitems++;
     }
   }
@@ -659,6 +759,8 @@ __device__ __forceinline__ void refb_candidates(const RJob &jb, int band, long b
   v.z = nitems;
   v.w = ntheta;
   reinterpret_cast<int4 *>(rp)[2] = v;
+  /* work class for the sorted searches: the chains place about kmax pulses */
+  jb.keys[(long)band*jb.nblocks + blk] = (unsigned short)(kSortBins - 1 - od_work_bin(kmax_theta + kmax_noref));
 }
 
 __global__ __launch_bounds__(kWave) void k_refb_cands(RItems it) {
@@ -687,7 +789,7 @@ __global__ __launch_bounds__(kWave) void k_refb_cands_list(const Unc *list, int 
    `writer`: this lane records the band's results (one lane per band). */
 template <class V>
 __device__ __forceinline__ void refb_loops(const RJob &jb, int band, long blk, bool writer,
- bool may_store, double lambda, V &v) {
+ bool may_store, double lambda, V &v, int dbg = 0) {
   const odhip_pvq_refband r = jb.rec[blk*jb.nb_bands + band];
   const int off = jb.off[band];
   const int n = jb.off[band + 1] - off;
@@ -724,7 +826,7 @@ __device__ __forceinline__ void refb_loops(const RJob &jb, int band, long blk, b
         cur_slot = -1;
       }
       else if (k != prev_k) {
-        cos_dist = v.search(n - 1, k, prev_k, ((qcg*(double)cg)*sin_prod)*s2, lambda);
+        cos_dist = dbg ? 0.5 : v.search(n - 1, k, prev_k, ((qcg*(double)cg)*sin_prod)*s2, lambda);
         cur_slot = idx;
         if (may_store) v.store(yout + ((long)idx*nblocks + blk)*len + off);
       }
@@ -755,7 +857,7 @@ __device__ __forceinline__ void refb_loops(const RJob &jb, int band, long blk, b
         if (writer) ip.tail[idx*ip.stride] = make_int4(qcg, 0, 0, -1);
         continue;
       }
-      const double cos_dist = v.search(n, k, prev_k, (qcg*(double)cg)*s2, lambda);
+      const double cos_dist = dbg ? 0.5 : v.search(n, k, prev_k, (qcg*(double)cg)*s2, lambda);
       prev_k = k;
       if (may_store) v.store(yout + ((long)idx*nblocks + blk)*len + off);
       dist = (1.4*(qcg - cg))*(qcg - cg) + (qcg*(double)cg)*(2 - 2*cos_dist);
@@ -801,8 +903,9 @@ __global__ __launch_bounds__(kWave) void k_refb_search(RItems it) {
   const RJob &jb = g_rjobs[it.job[item]];
   const int band = it.band[item];
   const int n = jb.off[band + 1] - jb.off[band];
-  const long blk = (long)(blockIdx.x - it.wg_start[item])*kWave + threadIdx.x;
-  if (blk >= jb.nblocks) return;
+  const long pos = (long)(blockIdx.x - it.wg_start[item])*kWave + threadIdx.x;
+  if (pos >= jb.nblocks) return;
+  const long blk = jb.ids[(long)band*jb.nblocks + pos];
   LdsVector v = {(short *)lds, lds + n*kWave, (int)threadIdx.x, n, 0};
   refb_loops(jb, band, blk, true, true, it.lambda, v);
 }
@@ -882,10 +985,11 @@ __global__ __launch_bounds__(kWave) void k_refb_search_row(RItems it) {
   v.l = lane & 15;
   v.force = it.perturb >> 1;
   const long nblocks = jb.nblocks;
-  const long blk0 = (long)(blockIdx.x - it.wg_start[item])*4 + v.row;
-  const bool live = blk0 < nblocks;
-  /* rows beyond the end redo the last block without storing anything */
-  refb_loops(jb, it.band[item], live ? blk0 : nblocks - 1, live && v.l == 0, live, it.lambda, v);
+  const long pos = (long)(blockIdx.x - it.wg_start[item])*4 + v.row;
+  const bool live = pos < nblocks;
+  /* rows beyond the end redo the last band without storing anything */
+  const long blk = jb.ids[(long)it.band[item]*nblocks + (live ? pos : nblocks - 1)];
+  refb_loops(jb, it.band[item], blk, live && v.l == 0, live, it.lambda, v, it.perturb & 4);
 }
 
 /* The short bands (N = 15, 8): one band per lane, the band in registers
@@ -946,10 +1050,11 @@ __global__ __launch_bounds__(kWave) void k_refb_search_regs(RItems it) {
   od_rsqrt_init(threadIdx.x);
   const int item = find_item(it, blockIdx.x);
   const RJob &jb = g_rjobs[it.job[item]];
-  const long blk = (long)(blockIdx.x - it.wg_start[item])*kWave + threadIdx.x;
-  if (blk >= jb.nblocks) return;
+  const long pos = (long)(blockIdx.x - it.wg_start[item])*kWave + threadIdx.x;
+  if (pos >= jb.nblocks) return;
+  const long blk = jb.ids[(long)it.band[item]*jb.nblocks + pos];
   RegVector<N> v;
-  refb_loops(jb, it.band[item], blk, true, true, it.lambda, v);
+  refb_loops(jb, it.band[item], blk, true, true, it.lambda, v, it.perturb & 4);
 }
 
 
@@ -1252,13 +1357,43 @@ int fill_job(RJob &d, const odhip_pvq_refjob &j, int mode) {
   return ODHIP_SUCCESS;
 }
 
+/* Library scratch of the sorted searches (keys, sorted block indices), grown on
+   demand and kept for the life of the process.  One band-stage call may be in
+   flight per process. */
+struct RScratch {
+  unsigned short *keys;
+  unsigned *ids;
+  size_t cap;    /* (band, block) pairs */
+} g_rscr = {nullptr, nullptr, 0};
+
 int stage_jobs(const odhip_pvq_refjob *jobs, int njobs, int mode, RJob *host, hipStream_t s) {
   if (!jobs || njobs <= 0 || njobs > kMaxJobs) return ODHIP_EINVAL;
   int rc = upload_tables();
   if (rc) return rc;
+  size_t pairs = 0;
   for (int i = 0; i < njobs; i++) {
     rc = fill_job(host[i], jobs[i], mode);
     if (rc) return rc;
+    pairs += (size_t)host[i].nblocks*host[i].nb_bands;
+  }
+  if (mode == 0) {
+    if (pairs > g_rscr.cap) {
+      ODHIP_TRY(hipStreamSynchronize(s));
+      if (g_rscr.keys) ODHIP_TRY(hipFree(g_rscr.keys));
+      if (g_rscr.ids) ODHIP_TRY(hipFree(g_rscr.ids));
+      g_rscr.keys = nullptr;
+      g_rscr.ids = nullptr;
+      g_rscr.cap = 0;
+      ODHIP_TRY(hipMalloc((void **)&g_rscr.keys, pairs*sizeof(unsigned short)));
+      ODHIP_TRY(hipMalloc((void **)&g_rscr.ids, pairs*sizeof(unsigned)));
+      g_rscr.cap = pairs;
+    }
+    pairs = 0;
+    for (int i = 0; i < njobs; i++) {
+      host[i].keys = g_rscr.keys + pairs;
+      host[i].ids = g_rscr.ids + pairs;
+      pairs += (size_t)host[i].nblocks*host[i].nb_bands;
+    }
   }
   ODHIP_TRY(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_rjobs), host, sizeof(RJob)*njobs, 0,
    hipMemcpyHostToDevice, s));
@@ -1270,6 +1405,7 @@ void items_begin(RItems &it, double lambda) {
   it.lambda = lambda;
   it.margin = g_margin;
   it.perturb = g_perturb;
+  if (getenv("ODHIP_REF_DEBUG_NOSEARCH")) it.perturb |= 4;   /* timing experiments only */
 }
 
 void items_add(RItems &it, int job, int band, long wgs) {
@@ -1379,6 +1515,13 @@ extern "C" int odhip_pvq_ref_bands_multi(const odhip_pvq_refjob *jobs, int njobs
   void *cnt = nullptr;
   ODHIP_TRY(hipGetSymbolAddress(&cnt, HIP_SYMBOL(g_unc_count)));
   ODHIP_TRY(hipMemsetAsync(cnt, 0, sizeof(unsigned), s));
+  {
+    /* consumed and cleared by k_refb_prefix; cleared here as well so that a call
+       that failed half way cannot poison the next sort */
+    void *hist = nullptr;
+    ODHIP_TRY(hipGetSymbolAddress(&hist, HIP_SYMBOL(g_rhist)));
+    ODHIP_TRY(hipMemsetAsync(hist, 0, sizeof(unsigned)*kMaxItems*kSortBins, s));
+  }
   RItems it;
   items_all(it, host, njobs, pvq_norm_lambda, 0);
   if (!it.nitems) return ODHIP_SUCCESS;
@@ -1410,6 +1553,22 @@ extern "C" int odhip_pvq_ref_bands_multi(const odhip_pvq_refjob *jobs, int njobs
     }
   }
   k_refb_cands<<<it.wg_start[it.nitems], kWave, 0, s>>>(it);
+  /* counting sort of every item's blocks by work class */
+  {
+    RItems chunks;
+    RItems all;
+    items_begin(chunks, pvq_norm_lambda);
+    items_begin(all, pvq_norm_lambda);
+    for (int j = 0; j < njobs; j++) {
+      for (int b = 0; b < host[j].nb_bands; b++) {
+        items_add(chunks, j, b, (host[j].nblocks + kSortChunk - 1)/kSortChunk);
+        items_add(all, j, b, 1);
+      }
+    }
+    k_refb_hist<<<chunks.wg_start[chunks.nitems], 256, 0, s>>>(chunks);
+    k_refb_prefix<<<all.nitems, 256, 0, s>>>(all);
+    k_refb_scatter<<<chunks.wg_start[chunks.nitems], 256, 0, s>>>(chunks);
+  }
   /* 128- and 32-coefficient bands: one band per 16-lane row; 15 and 8: per lane */
   const bool lane_only = getenv("ODHIP_PVQ_REF_LANE") != nullptr;
   static const int sizes[4] = {128, 32, 15, 8};
