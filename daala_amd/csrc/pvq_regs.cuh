@@ -116,20 +116,22 @@ __device__ __forceinline__ double od_pvq_search_regs(const int (&ax)[N], int (&y
     yy = yy + (double)(2*yp) + 1;
   }
   /* Last pulses with the rate term, :192-219. */
-  for (; i < k; i++) {
-    double tab[4];
+  /* rate penalty of each candidate, (lambda*j)*(delta_rate + j*accel_rate):
+     constant over the pulses of a search */
+  double pen[N];
 #pragma unroll
-    for (int t = 0; t < 4; t++) tab[t] = od_rsqrt_table((int)(yy + 2*t + 1));
+  for (int j = 0; j < N; j++) pen[j] = (lambda*j)*(delta_rate + j*accel_rate);
+  for (; i < k; i++) {
+    /* od_rsqrt_table(yy + 2*y_j + 1) for every candidate straight from the LDS
+       table (the reference's four-entry cache :199-200 holds the same values) */
+    const int yyi = (int)yy;
     int pos = 0;
     double best_cost = -1e5;
 #pragma unroll
     for (int j = 0; j < N; j++) {
       double tmp_xy = xy + x[j];
-      const int yj = y[j];
-      double tmp_yy;
-      if (yj < 4) tmp_yy = yj == 0 ? tab[0] : yj == 1 ? tab[1] : yj == 2 ? tab[2] : tab[3];
-      else tmp_yy = od_rsqrt_table((int)(yy + (double)(2*yj) + 1));
-      tmp_xy = ((2*tmp_xy)*norm_1)*tmp_yy - (lambda*j)*(delta_rate + j*accel_rate);
+      const double tmp_yy = od_rsqrt_table(yyi + 2*y[j] + 1);
+      tmp_xy = ((2*tmp_xy)*norm_1)*tmp_yy - pen[j];
       if (j == N - 1 && padded) tmp_xy = -1.7976931348623157e308;   /* PAD */
       if (j == 0) best_cost = tmp_xy;
       else {

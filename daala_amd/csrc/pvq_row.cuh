@@ -235,22 +235,24 @@ __device__ __forceinline__ double od_pvq_search_row(const int (&ax)[E], int (&y)
     }
   }
   /* ---- last pulses with the rate term ------------------------------------- */
+  /* rate penalty of each of the lane's candidates, (lambda*j)*delta_rate: constant
+     over the pulses of a search */
+  double pen[E];
+#pragma unroll
+  for (int e = 0; e < E; e++) pen[e] = (lambda*(l*E + e))*delta_rate;
   while (__any(i < k)) {
     const bool on = i < k;
-    double tab[4];
-#pragma unroll
-    for (int t = 0; t < 4; t++) tab[t] = od_rsqrt_table((int)(yy + 2*t + 1));
+    /* od_rsqrt_table(yy + 2*y_j + 1) for every candidate straight from the LDS
+       table (the reference's four-entry cache :199-200 holds the same values) */
+    const int yyi = (int)yy;
     double bc = 0;
     int bi = 0;
 #pragma unroll
     for (int e = 0; e < E; e++) {
       const int j = l*E + e;
       double tmp_xy = xy + (double)ax[e];
-      const int yj = y[e];
-      double r;
-      if (yj < 4) r = yj == 0 ? tab[0] : yj == 1 ? tab[1] : yj == 2 ? tab[2] : tab[3];
-      else r = od_rsqrt_table((int)(yy + (double)(2*yj) + 1));
-      tmp_xy = ((2*tmp_xy)*norm_1)*r - (lambda*j)*delta_rate;
+      const double r = od_rsqrt_table(yyi + 2*y[e] + 1);
+      tmp_xy = ((2*tmp_xy)*norm_1)*r - pen[e];
       if (e == E - 1 && pad_lane) tmp_xy = -1.7976931348623157e308;   /* PAD */
       if (e == 0 || tmp_xy > bc) {
         bc = tmp_xy;
