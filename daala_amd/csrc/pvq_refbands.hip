@@ -807,8 +807,11 @@ __device__ __forceinline__ void refb_loops(const RJob &jb, int band, long blk, b
     int cur_slot = -1;
     double cos_dist = 0;
     const int32_t theta = r.theta;
+    int4 hnext = ip.head[0];
     for (int idx = 0; idx < r.ntheta; idx++) {
-      const int4 h = ip.head[idx*ip.stride];      /* gain, theta, ts, k */
+      const int4 h = hnext;                       /* gain, theta, ts, k */
+      /* the next candidate's head is requested before this one is worked on */
+      hnext = ip.head[(idx + 1 < r.nitems ? idx + 1 : idx)*ip.stride];
       const int32_t qcg = odq_shl32(h.x, ODQ_CGAIN_SHIFT) + r.gain_offset;
       const int32_t qtheta = odq_pvq_compute_theta(h.y, h.z);
       const int k = h.w;
