@@ -455,7 +455,8 @@ def main():
             with open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")) as f:
                 tr = json.load(f)["kernels"]
             key = [k_ for k_ in tr if k_.startswith("k_search<128")]
-            if key and args.frames == 8:
+            # the committed PMC run is of the default command (8 frames, chroma with reference)
+            if key and args.frames == 8 and cfl:
                 roof["traffic"] = tr[key[0]]["hbm_bytes_per_launch"]
                 roof["traffic_source"] = "profiles/r1_pmc_traffic.json (rocprofv3 --pmc, same command)"
                 vi = tr[key[0]].get("valu_wave_instructions")
