@@ -479,7 +479,7 @@ def main():
             # searched), and 256 B of pulses per search that stored its vector.
             r_ms = float(np.mean(ref_search_ms))
             r_bytes, r_bands = pipe.ref128_bytes()
-            roof_ref = {"kernel": "k_refb_search_row<8> (with-reference candidate chains of the "
+            roof_ref = {"kernel": "k_refb_search_row<8,16> (with-reference candidate chains of the "
                                   "128-coefficient chroma bands, one band per 16-lane row)",
                         "bound": "hbm", "achieved": round(r_bytes / (r_ms * 1e-3) / 1e9, 1),
                         "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -491,7 +491,7 @@ def main():
             try:
                 with open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")) as f:
                     tr = json.load(f)["kernels"]
-                key = [k_ for k_ in tr if k_.startswith("k_refb_search_row<8")]
+                key = [k_ for k_ in tr if k_.startswith("k_refb_search_row<8, 16>")]
                 if key and args.frames == 8:
                     roof_ref["traffic"] = tr[key[0]]["hbm_bytes_per_launch"]
                     roof_ref["traffic_source"] = ("profiles/r1_pmc_traffic.json (rocprofv3 --pmc, "

@@ -418,11 +418,12 @@ __global__ __launch_bounds__(kWave) void k_refb_prep_lane(RItems it) {
   prep_write(it, rec + band, job, band, blk, xshift, rshift, p, r_null, flip, m, s);
 }
 
-/* n = 16*E coefficients per 16-lane row, four bands per wavefront; lane l of the
-   row owns coding positions l*E .. l*E+E-1 of the band. */
-template <int E>
+/* n = G*E coefficients per group of G lanes (G = 16: a DPP row, G = 4: a quad),
+   64/G bands per wavefront; lane l of the group owns coding positions l*E ..
+   l*E+E-1 of the band. */
+template <int E, int G>
 __global__ __launch_bounds__(kWave) void k_refb_prep_row(RItems it) {
-  constexpr int n = 16*E;
+  constexpr int n = G*E;
   __shared__ unsigned short s_scan[n];
   const int item = find_item(it, blockIdx.x);
   const int job = it.job[item];
@@ -432,10 +433,10 @@ __global__ __launch_bounds__(kWave) void k_refb_prep_row(RItems it) {
   const int lane = threadIdx.x;
   for (int j = lane; j < n; j += kWave) s_scan[j] = gRScanPk[off + j];
   __syncthreads();
-  const int row = lane >> 4;
-  const int l = lane & 15;
+  const int row = lane/G;
+  const int l = lane%G;
   const long nblocks = jb.nblocks;
-  const long blk0 = (long)(blockIdx.x - it.wg_start[item])*4 + row;
+  const long blk0 = (long)(blockIdx.x - it.wg_start[item])*(kWave/G) + row;
   const bool live = blk0 < nblocks;
   const long blk = live ? blk0 : nblocks - 1;
   const int w = jb.w;
@@ -477,9 +478,9 @@ __global__ __launch_bounds__(kWave) void k_refb_prep_row(RItems it) {
     sr += tr*tr;
     nz |= rv[e] != 0;
   }
-  sx = row_sum(sx);
-  sr = row_sum(sr);
-  const int r_null = row_max(nz) == 0;
+  sx = grp_sum<G>(sx);
+  sr = grp_sum<G>(sr);
+  const int r_null = grp_max<G>(nz) == 0;
   int xshift = 8 + 1 + odq_ilog(n + sx)/2 - 15;
   xshift = xshift > 0 ? xshift : 0;
   int rshift = 8 + 1 + odq_ilog(n + sr)/2 - 14;
@@ -497,9 +498,9 @@ __global__ __launch_bounds__(kWave) void k_refb_prep_row(RItems it) {
     accx += x16[e]*x16[e];
     accr += r16[e]*r16[e];
   }
-  corr = row_sum(corr);
-  accx = row_sum(accx);
-  accr = row_sum(accr);
+  corr = grp_sum<G>(corr);
+  accx = grp_sum<G>(accx);
+  accr = grp_sum<G>(accr);
   const PrepScalars p = prep_scalars(accx, accr, corr, xshift, rshift, q0, beta, cfl_enabled,
    is_keyframe, r_null);
   int m = 0;
@@ -526,14 +527,16 @@ __global__ __launch_bounds__(kWave) void k_refb_prep_row(RItems it) {
     }
     OD_ARGMAX_STEP(OD_DPP_XOR1)
     OD_ARGMAX_STEP(OD_DPP_XOR2)
-    OD_ARGMAX_STEP(OD_DPP_HALF_MIRROR)
-    OD_ARGMAX_STEP(OD_DPP_MIRROR)
+    if (G == 16) {
+      OD_ARGMAX_STEP(OD_DPP_HALF_MIRROR)
+      OD_ARGMAX_STEP(OD_DPP_MIRROR)
+    }
 #undef OD_ARGMAX_STEP
     m = bi;
     int rm = 0;
 #pragma unroll
     for (int e = 0; e < E; e++) if (l*E + e == m) rm = r16[e];
-    rm = row_sum(rm);
+    rm = grp_sum<G>(rm);
     s = rm > 0 ? 1 : -1;
     const int upd = (int16_t)(rm + odq_shr_round(p.gr*s, rshift));
     int32_t l2r = 0;
@@ -544,8 +547,8 @@ __global__ __launch_bounds__(kWave) void k_refb_prep_row(RItems it) {
       l2r += odq_mult16_16(r16[e], r16[e]);
       proj += odq_mult16_16(r16[e], x16[e]);
     }
-    l2r = row_sum(l2r);
-    proj = row_sum(proj);
+    l2r = grp_sum<G>(l2r);
+    proj = grp_sum<G>(proj);
     int16_t proj_1;
     int outshift;
     householder_consts(l2r, proj, &proj_1, &outshift);
@@ -928,11 +931,11 @@ __device__ __forceinline__ uint32_t pack_pulses(int s0, int y0, int s1, int y1) 
   return pack16(s0 ? -y0 : y0, s1 ? -y1 : y1);
 }
 
-/* One band per 16-lane row (pvq_row.cuh): bands of 16*E coefficients (E = 2: 32,
-   E = 8: 128), all state in registers; lane l of the row owns positions l*E ..
-   l*E+E-1.  The decisions of a row are uniform over its lanes (every lane
-   evaluates them on the same record and items). */
-template <int E>
+/* One band per group of G lanes (pvq_row.cuh): bands of G*E coefficients (G = 16,
+   E = 8: 128; G = 4, E = 8: 32), all state in registers; lane l of the group owns
+   positions l*E .. l*E+E-1.  The decisions of a group are uniform over its lanes
+   (every lane evaluates them on the same record and items). */
+template <int E, int G>
 struct RowVector {
   int ax[E];
   int sg[E];
@@ -951,15 +954,16 @@ struct RowVector {
       sg[e] = v < 0;
       y[e] = 0;
     }
-    if (pad && l == 15) {
+    if (pad && l == G - 1) {
       ax[E - 1] = 0;
       sg[E - 1] = 0;
     }
-    od_row_norm<E>(ax, &xx, &norm_1);
+    od_row_norm<E, G>(ax, &xx, &norm_1);
   }
   __device__ __forceinline__ double search(int n_true, int k, int prev_k, double g2, double lambda) {
     double yy;
-    return od_pvq_search_row<E>(ax, y, row, l, n_true, k, prev_k, g2, lambda, force, xx, norm_1, &yy);
+    return od_pvq_search_row<E, G>(ax, y, row, l, n_true, k, prev_k, g2, lambda, force, xx, norm_1,
+     &yy);
   }
   __device__ __forceinline__ void store(int16_t *dst) {
     int16_t *p = dst + l*E;
@@ -977,18 +981,18 @@ struct RowVector {
   }
 };
 
-template <int E>
+template <int E, int G>
 __global__ __launch_bounds__(kWave) void k_refb_search_row(RItems it) {
   od_rsqrt_init(threadIdx.x);
   const int item = find_item(it, blockIdx.x);
   const RJob &jb = g_rjobs[it.job[item]];
   const int lane = threadIdx.x;
-  RowVector<E> v;
-  v.row = lane >> 4;
-  v.l = lane & 15;
+  RowVector<E, G> v;
+  v.row = lane/G;
+  v.l = lane%G;
   v.force = it.perturb >> 1;
   const long nblocks = jb.nblocks;
-  const long pos = (long)(blockIdx.x - it.wg_start[item])*4 + v.row;
+  const long pos = (long)(blockIdx.x - it.wg_start[item])*(kWave/G) + v.row;
   const bool live = pos < nblocks;
   /* rows beyond the end redo the last band without storing anything */
   const long blk = jb.ids[(long)it.band[item]*nblocks + (live ? pos : nblocks - 1)];
@@ -1547,12 +1551,14 @@ extern "C" int odhip_pvq_ref_bands_multi(const odhip_pvq_refjob *jobs, int njobs
       items_begin(pi, pvq_norm_lambda);
       for (int j = 0; j < njobs; j++) {
         for (int b = 1; b < host[j].nb_bands; b++) {
-          if (host[j].off[b + 1] - host[j].off[b] == sz) items_add(pi, j, b, (host[j].nblocks + 3)/4);
+          if (host[j].off[b + 1] - host[j].off[b] == sz) {
+            items_add(pi, j, b, sz == 32 ? (host[j].nblocks + 15)/16 : (host[j].nblocks + 3)/4);
+          }
         }
       }
       if (!pi.nitems) continue;
-      if (sz == 32) k_refb_prep_row<2><<<pi.wg_start[pi.nitems], kWave, 0, s>>>(pi);
-      else k_refb_prep_row<8><<<pi.wg_start[pi.nitems], kWave, 0, s>>>(pi);
+      if (sz == 32) k_refb_prep_row<8, 4><<<pi.wg_start[pi.nitems], kWave, 0, s>>>(pi);
+      else k_refb_prep_row<8, 16><<<pi.wg_start[pi.nitems], kWave, 0, s>>>(pi);
     }
   }
   k_refb_cands<<<it.wg_start[it.nitems], kWave, 0, s>>>(it);
@@ -1588,7 +1594,7 @@ extern "C" int odhip_pvq_ref_bands_multi(const odhip_pvq_refjob *jobs, int njobs
       for (int j = 0; j < njobs; j++) {
         for (int b = 0; b < host[j].nb_bands; b++) {
           if (host[j].off[b + 1] - host[j].off[b] == sizes[i]) {
-            items_add(it, j, b, (host[j].nblocks + 3)/4);
+            items_add(it, j, b, sizes[i] == 32 ? (host[j].nblocks + 15)/16 : (host[j].nblocks + 3)/4);
           }
         }
       }
@@ -1596,10 +1602,10 @@ extern "C" int odhip_pvq_ref_bands_multi(const odhip_pvq_refjob *jobs, int njobs
       if (sizes[i] == 128) {
         const bool prof = g_prof_on && g_prof_n < kProfSlots;
         if (prof) (void)hipEventRecord(g_prof_ev[g_prof_n][0], s);
-        k_refb_search_row<8><<<it.wg_start[it.nitems], kWave, 0, s>>>(it);
+        k_refb_search_row<8, 16><<<it.wg_start[it.nitems], kWave, 0, s>>>(it);
         if (prof) (void)hipEventRecord(g_prof_ev[g_prof_n++][1], s);
       }
-      else k_refb_search_row<2><<<it.wg_start[it.nitems], kWave, 0, s>>>(it);
+      else k_refb_search_row<8, 4><<<it.wg_start[it.nitems], kWave, 0, s>>>(it);
       continue;
     }
     items_all(it, host, njobs, pvq_norm_lambda, sizes[i]);

@@ -4,9 +4,11 @@
    frame batch holds too few 128-coefficient bands to fill the chip one band per
    lane and each band runs a chain of up to 14 searches.
 
-   A band of up to 16*E coefficients (E = 2: n = 31/32, E = 8: n = 127/128) is
-   held in VGPRs in BLOCKED index order (lane l of the row owns j = l*E ..
-   l*E+E-1), so lane order is index order.  The cross-lane steps are DPP row
+   A band of up to G*E coefficients is held by a GROUP of G lanes (G = 16, a DPP
+   row, E = 8: n = 127/128; G = 4, a quad, E = 8: n = 31/32 - sixteen bands per
+   wavefront, per-candidate bookkeeping replicated 4x instead of 16x) in VGPRs in
+   BLOCKED index order (lane l of the group owns j = l*E .. l*E+E-1), so lane
+   order is index order.  The cross-lane steps are DPP row
    operations (VALU, no LDS), two wave ballots and a few ds_bpermute broadcasts.
    n_true = 16*E - 1 (the reflected vector of a with-reference search) is
    handled by a PAD in the last position: |x| = 0, y = 0, and its candidate is
@@ -42,76 +44,102 @@
 
 namespace {
 
-__device__ __forceinline__ double row_sum(double v) {
+/* Group reductions: G = 16 (a DPP row) or G = 4 (a quad: the first two steps). */
+template <int G>
+__device__ __forceinline__ int grp_sum(int v) {
   v += row_mov<OD_DPP_XOR1>(v);
   v += row_mov<OD_DPP_XOR2>(v);
-  v += row_mov<OD_DPP_HALF_MIRROR>(v);
-  v += row_mov<OD_DPP_MIRROR>(v);
+  if (G == 16) {
+    v += row_mov<OD_DPP_HALF_MIRROR>(v);
+    v += row_mov<OD_DPP_MIRROR>(v);
+  }
   return v;
 }
 
-__device__ __forceinline__ int row_min(int v) {
+template <int G>
+__device__ __forceinline__ double grp_sum(double v) {
+  v += row_mov<OD_DPP_XOR1>(v);
+  v += row_mov<OD_DPP_XOR2>(v);
+  if (G == 16) {
+    v += row_mov<OD_DPP_HALF_MIRROR>(v);
+    v += row_mov<OD_DPP_MIRROR>(v);
+  }
+  return v;
+}
+
+template <int G>
+__device__ __forceinline__ int grp_min(int v) {
   v = min(v, row_mov<OD_DPP_XOR1>(v));
   v = min(v, row_mov<OD_DPP_XOR2>(v));
-  v = min(v, row_mov<OD_DPP_HALF_MIRROR>(v));
-  v = min(v, row_mov<OD_DPP_MIRROR>(v));
+  if (G == 16) {
+    v = min(v, row_mov<OD_DPP_HALF_MIRROR>(v));
+    v = min(v, row_mov<OD_DPP_MIRROR>(v));
+  }
   return v;
 }
 
-__device__ __forceinline__ int row_max(int v) {
+template <int G>
+__device__ __forceinline__ int grp_max(int v) {
   v = max(v, row_mov<OD_DPP_XOR1>(v));
   v = max(v, row_mov<OD_DPP_XOR2>(v));
-  v = max(v, row_mov<OD_DPP_HALF_MIRROR>(v));
-  v = max(v, row_mov<OD_DPP_MIRROR>(v));
+  if (G == 16) {
+    v = max(v, row_mov<OD_DPP_HALF_MIRROR>(v));
+    v = max(v, row_mov<OD_DPP_MIRROR>(v));
+  }
   return v;
 }
 
-__device__ __forceinline__ float row_max(float v) {
+template <int G>
+__device__ __forceinline__ float grp_max(float v) {
   v = fmaxf(v, __int_as_float(row_mov<OD_DPP_XOR1>(__float_as_int(v))));
   v = fmaxf(v, __int_as_float(row_mov<OD_DPP_XOR2>(__float_as_int(v))));
-  v = fmaxf(v, __int_as_float(row_mov<OD_DPP_HALF_MIRROR>(__float_as_int(v))));
-  v = fmaxf(v, __int_as_float(row_mov<OD_DPP_MIRROR>(__float_as_int(v))));
+  if (G == 16) {
+    v = fmaxf(v, __int_as_float(row_mov<OD_DPP_HALF_MIRROR>(__float_as_int(v))));
+    v = fmaxf(v, __int_as_float(row_mov<OD_DPP_MIRROR>(__float_as_int(v))));
+  }
   return v;
 }
 
-/* 16-bit slice of a wave ballot belonging to this lane's row. */
-__device__ __forceinline__ unsigned row_ballot(bool p, int row) {
+/* G-bit slice of a wave ballot belonging to this lane's group. */
+template <int G>
+__device__ __forceinline__ unsigned grp_ballot(bool p, int grp) {
   const unsigned long long m = __ballot(p);
-  return (unsigned)(m >> (16*row)) & 0xffffu;
+  return (unsigned)(m >> (G*grp)) & ((1u << G) - 1u);
 }
 
-/* Value of `v` in lane `src` (0..15) of this lane's row. */
-__device__ __forceinline__ int row_bcast(int v, int row, int src) {
-  return __shfl(v, 16*row + src, 64);
+/* Value of `v` in lane `src` (0..G-1) of this lane's group. */
+template <int G>
+__device__ __forceinline__ int grp_bcast(int v, int grp, int src) {
+  return __shfl(v, G*grp + src, 64);
 }
 
-__device__ __forceinline__ double row_bcast(double v, int row, int src) {
-  return __shfl(v, 16*row + src, 64);
+template <int G>
+__device__ __forceinline__ double grp_bcast(double v, int grp, int src) {
+  return __shfl(v, G*grp + src, 64);
 }
 
-/* ax[e] = |x16|, y[e] = pulse magnitudes (input when prev_k > 0); row = lane/16,
-   l = lane%16.  Every lane of a row must call with the same arguments; rows of
-   a wavefront may differ (or not call at all).  With n_true == 16*E - 1 the
-   caller sets ax[E-1] = y[E-1] = 0 in lane 15.  Every lane of the row returns
-   the same cosine distance. */
+/* The 16-lane forms used by the preparation kernels. */
+__device__ __forceinline__ double row_sum(double v) { return grp_sum<16>(v); }
+__device__ __forceinline__ int row_max(int v) { return grp_max<16>(v); }
+
 /* xx = sum x^2 of the band (every lane of the row) and 1/sqrt(1e-30 + xx)
    (:107-109, :147): properties of the vector, computed once per chain. */
-template <int E>
+template <int E, int G>
 __device__ __forceinline__ void od_row_norm(const int (&ax)[E], double *xx_out, double *norm_1_out) {
   double xx = 0;
 #pragma unroll
   for (int e = 0; e < E; e++) xx += (double)ax[e]*(double)ax[e];
-  xx = row_sum(xx);
+  xx = grp_sum<G>(xx);
   *xx_out = xx;
   *norm_1_out = __ddiv_rn(1., __dsqrt_rn(1e-30 + xx));
 }
 
-template <int E>
+template <int E, int G>
 __device__ __forceinline__ double od_pvq_search_row(const int (&ax)[E], int (&y)[E], int row,
  int l, int n_true, int k, int prev_k, double g2, double pvq_norm_lambda, int force_scan,
  double xx, double norm_1, double *yy_out) {
-  constexpr int n = 16*E;
-  const bool pad_lane = n_true != n && l == 15;
+  constexpr int n = G*E;
+  const bool pad_lane = n_true != n && l == G - 1;
   const double lambda = __ddiv_rn(pvq_norm_lambda, 1e-30 + g2);
   double xy = 0;
   double yy = 0;
@@ -128,7 +156,7 @@ __device__ __forceinline__ double od_pvq_search_row(const int (&ax)[E], int (&y)
     double l1 = 0;
 #pragma unroll
     for (int e = 0; e < E; e++) l1 += (double)ax[e];
-    l1 = row_sum(l1);
+    l1 = grp_sum<G>(l1);
     const double l1_inv = __ddiv_rn(1., l1 > 1e-100 ? l1 : 1e-100);
 #pragma unroll
     for (int e = 0; e < E; e++) {
@@ -144,9 +172,9 @@ __device__ __forceinline__ double od_pvq_search_row(const int (&ax)[E], int (&y)
 #pragma unroll
     for (int e = 0; e < E; e++) y[e] = 0;
   }
-  xy = row_sum(xy);
-  yy = row_sum(yy);
-  i = row_sum(i);
+  xy = grp_sum<G>(xy);
+  yy = grp_sum<G>(yy);
+  i = grp_sum<G>(i);
   const int rdo_pulses = 1 + k/4;
   const int n_greedy = k - rdo_pulses;
   const double delta_rate = __ddiv_rn(3., (double)n_true);
@@ -173,11 +201,11 @@ __device__ __forceinline__ double od_pvq_search_row(const int (&ax)[E], int (&y)
     }
     /* proposal: best float key of the row, lowest lane on equal keys */
     const float key = (float)ba*__frcp_rn((float)bb);
-    const float kmax = row_max(key);
-    const unsigned wmask = row_ballot(key == kmax, row);
+    const float kmax = grp_max<G>(key);
+    const unsigned wmask = grp_ballot<G>(key == kmax, row);
     const int wl = wmask ? __ffs(wmask) - 1 : 0;
-    const double wa = row_bcast(ba, row, wl);
-    const double wb = row_bcast(bb, row, wl);
+    const double wa = grp_bcast<G>(ba, row, wl);
+    const double wb = grp_bcast<G>(bb, row, wl);
     /* verification against the proposal */
     bool bad = force_scan != 0 || wmask == 0;
     int first_dup = n;
@@ -189,7 +217,7 @@ __device__ __forceinline__ double od_pvq_search_row(const int (&ax)[E], int (&y)
       else if (!loses) bad = true;
     }
     int pos;
-    if (row_ballot(bad && on, row) != 0) {
+    if (grp_ballot<G>(bad && on, row) != 0) {
       /* literal scan, src/pvq_encoder.c:172-183 */
       double sa = 0;
       double sb = 1;
@@ -205,8 +233,8 @@ __device__ __forceinline__ double od_pvq_search_row(const int (&ax)[E], int (&y)
             cb = b[t];
           }
         }
-        ca = row_bcast(ca, row, j/E);
-        cb = row_bcast(cb, row, j/E);
+        ca = grp_bcast<G>(ca, row, j/E);
+        cb = grp_bcast<G>(cb, row, j/E);
         if (j == 0 || ca*sb > sa*cb) {
           sa = ca;
           sb = cb;
@@ -214,7 +242,7 @@ __device__ __forceinline__ double od_pvq_search_row(const int (&ax)[E], int (&y)
         }
       }
     }
-    else pos = row_min(first_dup);
+    else pos = grp_min<G>(first_dup);
     /* xy += x[pos]; yy += 2*y[pos] + 1; y[pos]++ */
     int px = 0;
     int py = 0;
@@ -226,8 +254,8 @@ __device__ __forceinline__ double od_pvq_search_row(const int (&ax)[E], int (&y)
         y[e]++;
       }
     }
-    px = row_bcast(px, row, pos/E);
-    py = row_bcast(py, row, pos/E);
+    px = grp_bcast<G>(px, row, pos/E);
+    py = grp_bcast<G>(py, row, pos/E);
     if (on) {
       xy = xy + (double)px;
       yy = yy + (double)(2*py) + 1;
@@ -270,8 +298,10 @@ __device__ __forceinline__ double od_pvq_search_row(const int (&ax)[E], int (&y)
     }
     OD_RDO_STEP(OD_DPP_XOR1)
     OD_RDO_STEP(OD_DPP_XOR2)
-    OD_RDO_STEP(OD_DPP_HALF_MIRROR)
-    OD_RDO_STEP(OD_DPP_MIRROR)
+    if (G == 16) {
+      OD_RDO_STEP(OD_DPP_HALF_MIRROR)
+      OD_RDO_STEP(OD_DPP_MIRROR)
+    }
 #undef OD_RDO_STEP
     const int pos = bi;
     int px = 0;
@@ -284,8 +314,8 @@ __device__ __forceinline__ double od_pvq_search_row(const int (&ax)[E], int (&y)
         y[e]++;
       }
     }
-    px = row_bcast(px, row, pos/E);
-    py = row_bcast(py, row, pos/E);
+    px = grp_bcast<G>(px, row, pos/E);
+    py = grp_bcast<G>(py, row, pos/E);
     if (on) {
       xy = xy + (double)px;
       yy = yy + (double)(2*py) + 1;
