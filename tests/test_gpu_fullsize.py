@@ -193,3 +193,153 @@ def test_1080p_band_stage_properties_and_oracle_subset(hip):
                     assert c["dist"][blk, band, slot] == cnd.dist
                     assert np.array_equal(c["y"][slot, blk, a:b], np.array(cnd.y[:m], np.int32))
     assert nsearched > 500000
+
+
+def test_1080p_with_reference_stage_properties_and_oracle_subset(hip):
+    """The with-reference stage on the chroma planes of a whole 1080p frame, with the
+    chroma-from-luma references the bench builds (upper-left quarter of the luma
+    reconstruction's dequantised coefficients, one level up): properties of every
+    candidate of every band, run-to-run identity (uncertainty list and counting
+    sort use atomics; results must not depend on the order), the chosen synthesis
+    against an independent per-band recomputation, and oracle parity of complete
+    bands (record, candidates, pulses) on a random subset."""
+    import os
+    import sys
+    import torch
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from _refbands import Mismatch, compare_bands, oracle_traces
+    y_, cb, cr = bench.synth_frame_np(0, 77)
+    qt = hip.QuantTables.load()
+    lam = hip.OD_PVQ_LAMBDA
+    W, H = 1920, 1088
+    # luma reconstruction coefficients
+    luma = hip.forward_pyramid(torch.from_numpy(y_[None]).cuda(), 0, 1920, 1080)
+    ljobs = []
+    for bs in range(5):
+        qm, qmi = qt.qm_slices(0, bs)
+        ljobs.append(hip.PvqJob(luma[bs], bs, torch.from_numpy(qm).cuda(), torch.from_numpy(qmi).cuda(),
+                                qt.q_band(0, bs), qt.beta_band(0, bs), dq=torch.zeros_like(luma[bs])))
+    hip.pvq_noref_bands_multi(ljobs, lam)
+    hip.pvq_select_synth_noref_multi(ljobs, lam)
+    chroma = hip.forward_pyramid(torch.from_numpy(np.stack([cb, cr])).cuda(), 1, 1920, 1080)
+    jobs = []
+    for bs in range(4):
+        n = 4 << bs
+        dq = ljobs[bs + 1].dq
+        corner = dq.view(1, H // (2 * n), 2 * n, W // (2 * n), 2 * n)[:, :, :n, :, :n]
+        ref = corner.reshape(1, H // 2, W // 2).contiguous()
+        ref = torch.cat([ref, ref], dim=0).contiguous()
+        qm, qmi = qt.qm_slices(1, bs)
+        jobs.append(hip.PvqRefJob(chroma[bs], ref, bs, torch.from_numpy(qm).cuda(),
+                                  torch.from_numpy(qmi).cuda(), qt.q_band(1, bs), qt.beta_band(1, bs),
+                                  1, 1))
+    hip.pvq_ref_bands_multi(jobs, lam)
+    torch.cuda.synchronize()
+    first = [(j.band.clone(), j.items.clone(), j.y.clone()) for j in jobs]
+    hip.pvq_ref_bands_multi(jobs, lam)
+    hip.pvq_ref_select_synth_multi(jobs, lam)
+    torch.cuda.synchronize()
+    rng = np.random.RandomState(3)
+    nsearched = 0
+    nflip = 0
+    for bs, (job, (band0, items0, y0)) in enumerate(zip(jobs, first)):
+        assert torch.equal(job.band, band0), bs
+        u = job.unpack()
+        rec, items, y = u["rec"], u["items"], u["y"].astype(np.int64)
+        B, nb = rec.shape
+        nitems = rec["nitems"]
+        ntheta = rec["ntheta"]
+        assert (nitems <= 14).all() and (ntheta <= 12).all() and (ntheta <= nitems).all()
+        ran = (rec["flags"] & hip.REFBAND_THETA) != 0
+        assert ((ntheta > 0) <= ran).all()
+        assert ((rec["corr"] > 0) | ~ran).all()
+        assert (np.abs(rec["corr"]) <= 1).all() and (rec["dist0"] >= 0).all()
+        nflip += int(((rec["flags"][:, 0] & hip.REFBAND_FLIP) != 0).sum())
+        # the flip is a property of the block: identical over its bands
+        fl = (rec["flags"] & hip.REFBAND_FLIP) != 0
+        assert (fl == fl[:, :1]).all()
+        offs = job.offsets
+        for b in range(nb):
+            a, e = offs[b], offs[b + 1]
+            for s in range(14):
+                it = items[:, b, s]
+                valid = s < nitems[:, b]
+                searched = valid & ((it["flags"] & 1) != 0)
+                with_ref = (it["flags"] & 2) != 0
+                assert (with_ref[valid] == (s < ntheta[:, b])[valid]).all()
+                own = searched & (it["yslot"] == s)
+                nn = np.where(with_ref, e - a - 1, e - a)
+                ys = y[s][:, a:e]
+                # a search that stored its vector placed exactly k pulses
+                for width in (e - a - 1, e - a):
+                    sel = own & (nn == width)
+                    assert (np.abs(ys[sel][:, :width]).sum(1) == it["k"][sel]).all(), (bs, b, s)
+                assert (it["dist"][searched] >= 0).all()
+                assert (np.abs(it["cos_dist"][searched]) <= 1 + 1e-12).all()
+                shared = searched & (it["yslot"] >= 0) & (it["yslot"] != s)
+                assert (it["yslot"][shared] < s).all()
+                nsearched += int(searched.sum())
+        # run-to-run identity of everything a consumer reads (slots beyond nitems and the
+        # result fields of unsearched candidates are not written)
+        job.items, keep = items0, job.items
+        items_first = job.unpack()["items"]
+        job.items = keep
+        for s in range(14):
+            valid = s < nitems
+            for f in ("gain", "theta", "ts", "k"):
+                assert (items[f][:, :, s][valid] == items_first[f][:, :, s][valid]).all()
+            done = valid & ((items["flags"][:, :, s] & 1) != 0)
+            for f in ("qcg", "qtheta", "flags", "yslot", "cos_dist", "dist"):
+                assert (items[f][:, :, s][done] == items_first[f][:, :, s][done]).all(), (bs, s, f)
+        y_first = y0.cpu().numpy()
+        for b in range(nb):
+            a, e = offs[b], offs[b + 1]
+            for s in range(14):
+                own = (s < nitems[:, b]) & ((items["flags"][:, b, s] & 1) != 0) & (items["yslot"][:, b, s] == s)
+                assert np.array_equal(u["y"][s][own][:, a:e - 1], y_first[s][own][:, a:e - 1]), (bs, b, s)
+    assert nsearched > 500000 and nflip > 1000
+    # oracle parity of whole bands on random blocks of every level
+    mm = Mismatch()
+    for bs, job in enumerate(jobs):
+        n = 4 << bs
+        coef = job.coef.cpu().numpy()
+        ref = job.ref.cpu().numpy()
+        qm, qmi = qt.qm_slices(1, bs)
+        nplanes, h, w = coef.shape
+        bw = w // n
+        for _ in range(12):
+            p = int(rng.randint(nplanes))
+            by = int(rng.randint(h // n))
+            bx = int(rng.randint(bw))
+            sub_c = np.ascontiguousarray(coef[p:p + 1, by * n:(by + 1) * n, bx * n:(bx + 1) * n])
+            sub_r = np.ascontiguousarray(ref[p:p + 1, by * n:(by + 1) * n, bx * n:(bx + 1) * n])
+            traces, _ = oracle_traces(sub_c, sub_r, bs, qm, qmi, qt.q_band(1, bs), qt.beta_band(1, bs),
+                                      1, 1, lam)
+            blk = (p * (h // n) + by) * bw + bx
+            compare_bands(hip, _OneBlock(job, blk), traces, mm)
+    assert mm.total() == 0, mm.summary()
+    assert mm.checked["item.y"] > 500
+    # dequantised planes: DC passed through, everything finite and bounded
+    for job in jobs:
+        dq = job.dq.cpu().numpy()
+        coef = job.coef.cpu().numpy()
+        n = 4 << job.bs
+        assert np.array_equal(dq[:, ::n, ::n], coef[:, ::n, ::n])
+        assert np.abs(dq.astype(np.int64)).max() < 1 << 24
+
+
+class _OneBlock:
+    """View of a PvqRefJob restricted to one block, for _refbands.compare_bands."""
+
+    def __init__(self, job, blk):
+        self.job, self.blk, self.bs = job, blk, job.bs
+
+    def unpack(self):
+        if not hasattr(self.job, "_unpacked"):
+            self.job._unpacked = self.job.unpack()
+        u = self.job._unpacked
+        b = self.blk
+        return {"rec": u["rec"][b:b + 1], "items": u["items"][b:b + 1], "y": u["y"][:, b:b + 1],
+                "choice": u["choice"][b:b + 1], "r16": u["r16"][b:b + 1], "x16": u["x16"][b:b + 1],
+                "xr": u["xr"][b:b + 1]}
