@@ -630,3 +630,19 @@ def pvq_ref_profile_read(max_n=256):
     if n < 0:
         raise DaalaHipError("odhip_pvq_ref_profile_read failed with code %d" % n)
     return [buf[i] for i in range(n)]
+
+
+def image_planes_copy_pad(src, plane_w, plane_h, out=None):
+    """od_img_plane_copy_pad for a batch of planes: src uint8 [nplanes, pic_h, pic_w]
+    -> uint8 [nplanes, plane_h, plane_w] (picture copied, padding low-pass
+    extended as the reference's input queue does)."""
+    import torch
+    _need(src, torch.uint8, "src")
+    nplanes, pic_h, pic_w = src.shape
+    if out is None:
+        out = torch.empty((nplanes, plane_h, plane_w), dtype=torch.uint8, device=src.device)
+    _check(lib().odhip_image_planes_copy_pad(_p(out), plane_w, ctypes.c_long(plane_h * plane_w),
+                                             plane_w, plane_h, _p(src) if src.numel() else None,
+                                             pic_w, ctypes.c_long(pic_h * pic_w), pic_w, pic_h,
+                                             nplanes, _stream()), "odhip_image_planes_copy_pad")
+    return out

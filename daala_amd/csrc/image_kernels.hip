@@ -1,0 +1,119 @@
+/* image_kernels.hip - the input side of the path:
+   od_img_plane_copy_pad (reference src/encode.c:752-837; called for every plane
+   by daala_image_copy_pad :1896-1909 when a frame enters the input queue,
+   od_input_queue_add :272-287): copy the picture into the padded plane the
+   encoder codes, then extend it into the padding by a [1 2 1]/4 low-pass of the
+   previous column (right side, picture rows only) and of the previous row
+   (bottom, the whole padded width).  8-bit planes (xstride 1).
+
+   k_img_copy   the picture region of every plane, 16 bytes per thread where the
+                alignment allows
+   k_img_pad    one workgroup per plane: the extension is a recurrence over the
+                padded columns, then over the padded rows (at most 63 of each);
+                the previous column / row lives in LDS, every step is parallel
+                over the other dimension.  The last picture row's extension is
+                kept in LDS for the bottom pass. */
+#include "../../include/daala_hip.h"
+#include "od_common.cuh"
+
+namespace {
+
+constexpr int kMaxDim = 8192;
+constexpr int kPadThreads = 1024;
+
+__global__ __launch_bounds__(256) void k_img_copy(uint8_t *dst, int dst_stride, long dst_plane_stride,
+ const uint8_t *src, int src_stride, long src_plane_stride, int pic_w, int pic_h) {
+  const int p = blockIdx.z;
+  const int y = blockIdx.y;
+  const int x = (blockIdx.x*256 + threadIdx.x)*16;
+  if (x >= pic_w) return;
+  const uint8_t *s = src + p*src_plane_stride + (long)y*src_stride + x;
+  uint8_t *d = dst + p*dst_plane_stride + (long)y*dst_stride + x;
+  if (x + 16 <= pic_w && (((uintptr_t)s | (uintptr_t)d) & 15) == 0) {
+    *reinterpret_cast<uint4 *>(d) = *reinterpret_cast<const uint4 *>(s);
+  }
+  else {
+    const int n = pic_w - x < 16 ? pic_w - x : 16;
+    for (int i = 0; i < n; i++) d[i] = s[i];
+  }
+}
+
+__global__ __launch_bounds__(kPadThreads) void k_img_pad(uint8_t *dst, int dst_stride,
+ long dst_plane_stride, int plane_w, int plane_h, int pic_w, int pic_h) {
+  __shared__ uint8_t buf[2][kMaxDim];
+  __shared__ uint8_t last_row[64];     /* extension of picture row pic_h - 1 */
+  uint8_t *d = dst + blockIdx.x*dst_plane_stride;
+  const int tid = threadIdx.x;
+  if (pic_w == 0 || pic_h == 0) {
+    for (long i = tid; i < (long)plane_w*plane_h; i += kPadThreads) {
+      d[(i/plane_w)*dst_stride + i%plane_w] = 0;
+    }
+    return;
+  }
+  /* right side, src/encode.c:778-806 */
+  int cur = 0;
+  if (pic_w < plane_w) {
+    for (int y = tid; y < pic_h; y += kPadThreads) buf[0][y] = d[(long)y*dst_stride + pic_w - 1];
+    __syncthreads();
+    for (int x = pic_w; x < plane_w; x++) {
+      for (int y = tid; y < pic_h; y += kPadThreads) {
+        const int c = buf[cur][y];
+        const int u = buf[cur][y > 0 ? y - 1 : y];
+        const int dn = buf[cur][y + 1 < pic_h ? y + 1 : y];
+        const uint8_t v = (uint8_t)((2*c + u + dn + 2) >> 2);
+        buf[cur ^ 1][y] = v;
+        d[(long)y*dst_stride + x] = v;
+        if (y == pic_h - 1) last_row[x - pic_w] = v;
+      }
+      __syncthreads();
+      cur ^= 1;
+    }
+  }
+  /* bottom, :808-834 */
+  if (pic_h < plane_h) {
+    cur = 0;
+    for (int x = tid; x < plane_w; x += kPadThreads) {
+      buf[0][x] = x < pic_w ? d[(long)(pic_h - 1)*dst_stride + x] : last_row[x - pic_w];
+    }
+    __syncthreads();
+    for (int y = pic_h; y < plane_h; y++) {
+      for (int x = tid; x < plane_w; x += kPadThreads) {
+        const int c = buf[cur][x];
+        const int l = buf[cur][x - (x > 0)];
+        const int r = buf[cur][x + (x + 1 < plane_w)];
+        const uint8_t v = (uint8_t)((2*c + l + r + 2) >> 2);
+        buf[cur ^ 1][x] = v;
+        d[(long)y*dst_stride + x] = v;
+      }
+      __syncthreads();
+      cur ^= 1;
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int odhip_image_planes_copy_pad(uint8_t *d_dst, int dst_stride, long dst_plane_stride,
+ int plane_w, int plane_h, const uint8_t *d_src, int src_stride, long src_plane_stride, int pic_w,
+ int pic_h, int nplanes, odhip_stream stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (nplanes == 0) return ODHIP_SUCCESS;
+  if (!d_dst || nplanes < 0 || plane_w <= 0 || plane_h <= 0 || plane_w > kMaxDim || plane_h > kMaxDim
+   || pic_w < 0 || pic_h < 0 || pic_w > plane_w || pic_h > plane_h || dst_stride < plane_w) {
+    return ODHIP_EINVAL;
+  }
+  /* last_row holds one superblock of padded columns */
+  if (pic_w > 0 && pic_h > 0 && plane_w - pic_w > 64) return ODHIP_EINVAL;
+  if (pic_w > 0 && pic_h > 0) {
+    if (!d_src || src_stride < pic_w) return ODHIP_EINVAL;
+    const dim3 grid((unsigned)((pic_w + 16*256 - 1)/(16*256)), (unsigned)pic_h, (unsigned)nplanes);
+    if (grid.y > 65535u || grid.z > 65535u) return ODHIP_EINVAL;
+    k_img_copy<<<grid, 256, 0, s>>>(d_dst, dst_stride, dst_plane_stride, d_src, src_stride,
+     src_plane_stride, pic_w, pic_h);
+  }
+  if (pic_w == 0 || pic_h == 0 || pic_w < plane_w || pic_h < plane_h) {
+    k_img_pad<<<(unsigned)nplanes, kPadThreads, 0, s>>>(d_dst, dst_stride, dst_plane_stride, plane_w,
+     plane_h, pic_w, pic_h);
+  }
+  return odhip_check_launch();
+}

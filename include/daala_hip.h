@@ -536,6 +536,21 @@ int odhip_dering_planes(int16_t *d_y, const int16_t *d_x, int stride, int nhsb, 
  long bskip_plane_stride, const int32_t *d_thresholds, int ncand, int overlap, int coeff_shift,
  odhip_stream stream);
 
+/* ---- input side: padding a picture to the coded frame size ----
+
+   od_img_plane_copy_pad (src/encode.c:752-837; daala_image_copy_pad :1896-1909,
+   called when a frame enters the input queue) for a batch of 8-bit planes of one
+   size: the pic_w x pic_h picture at d_src (row stride src_stride, planes
+   src_plane_stride bytes apart) is copied into the plane_w x plane_h plane at
+   d_dst and extended into the padding by the reference's [1 2 1]/4 low-pass
+   recurrences (right side over the picture rows, then the bottom over the whole
+   width).  plane_w = frame_width >> xdec, pic_w = (pic_width + xdec) >> xdec, and
+   likewise for the heights; at most 64 padded columns / rows, sides up to 8192.
+   pic_w == 0 or pic_h == 0 clears the plane (:764-770). */
+int odhip_image_planes_copy_pad(uint8_t *d_dst, int dst_stride, long dst_plane_stride,
+ int plane_w, int plane_h, const uint8_t *d_src, int src_stride, long src_plane_stride,
+ int pic_w, int pic_h, int nplanes, odhip_stream stream);
+
 /* ---- frame cache: one batched pyramid serving every per-block fdct_2d call ---
 
    The samples a block of level bs sees in the reference encoder depend only on

@@ -464,6 +464,45 @@ int odo_band_offsets(int bs, int *out) {
   return OD_NBANDS[bs];
 }
 
+/* od_img_plane_copy_pad, src/encode.c:752-837, 8-bit planes (xstride 1): copy
+   the picture, then extend it into the padding by a [1 2 1]/4 low-pass of the
+   previous column (right side, rows of the picture only) and of the previous
+   row (bottom, the whole padded width).  SURVEY.md 8(f) rank 4, input side. */
+void odo_img_plane_copy_pad(uint8_t *dst, int dstride, int plane_w, int plane_h,
+ const uint8_t *src, int sstride, int pic_w, int pic_h) {
+  int x;
+  int y;
+  if (pic_w == 0 || pic_h == 0) {
+    for (y = 0; y < plane_h; y++) memset(dst + y*dstride, 0, plane_w);
+    return;
+  }
+  for (y = 0; y < pic_h; y++) memcpy(dst + y*dstride, src + y*sstride, pic_w);
+  for (x = pic_w; x < plane_w; x++) {
+    for (y = 0; y < pic_h; y++) {
+      int c;
+      int u;
+      int d;
+      c = dst[y*dstride + x - 1];
+      u = dst[(y > 0 ? y - 1 : y)*dstride + x - 1];
+      d = dst[(y + 1 < pic_h ? y + 1 : y)*dstride + x - 1];
+      dst[y*dstride + x] = (uint8_t)((2*c + u + d + 2) >> 2);
+    }
+  }
+  for (y = pic_h; y < plane_h; y++) {
+    const uint8_t *up;
+    up = dst + (y - 1)*dstride;
+    for (x = 0; x < plane_w; x++) {
+      int c;
+      int l;
+      int r;
+      c = up[x];
+      l = up[x - (x > 0)];
+      r = up[x + (x + 1 < plane_w)];
+      dst[y*dstride + x] = (uint8_t)((2*c + l + r + 2) >> 2);
+    }
+  }
+}
+
 /* ======================================================================== */
 /* PVQ fixed-point helpers (src/pvq.c, src/odintrin.h:164-199)               */
 /* ======================================================================== */

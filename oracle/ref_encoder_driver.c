@@ -307,3 +307,72 @@ REF_EXPORT int ref_pvq_encode_block(od_coeff *ref, const od_coeff *in, od_coeff 
   daala_encode_free(enc);
   return ret;
 }
+
+/* The padded input image the REAL encoder keeps for a picture of w x h
+   (daala_image_copy_pad -> od_img_plane_copy_pad, src/encode.c:752-837,:1896-1909):
+   daala_encode_img_in queues the frame (src/encode.c:3216-3219,
+   od_input_queue_add :272-287), nothing is encoded.  planes[pli] receives the
+   plane_w x plane_h region (frame_width >> xdec by frame_height >> ydec, tightly
+   packed); dims[2*pli], dims[2*pli + 1] its size.  Returns 0 or a negative
+   OD_E* code. */
+REF_EXPORT int ref_image_copy_pad(const unsigned char *frame, int w, int h,
+ unsigned char *const planes[3], int *dims) {
+  daala_info di;
+  daala_enc_ctx *enc;
+  daala_image img;
+  daala_image *pad;
+  int pli;
+  int ret;
+  daala_info_init(&di);
+  di.pic_width = w;
+  di.pic_height = h;
+  di.bitdepth_mode = OD_BITDEPTH_MODE_8;
+  di.timebase_numerator = 30;
+  di.timebase_denominator = 1;
+  di.frame_duration = 1;
+  di.pixel_aspect_numerator = 1;
+  di.pixel_aspect_denominator = 1;
+  di.nplanes = 3;
+  di.plane_info[1].xdec = di.plane_info[1].ydec = 1;
+  di.plane_info[2].xdec = di.plane_info[2].ydec = 1;
+  di.keyframe_rate = 1;
+  enc = daala_encode_create(&di);
+  if (enc == NULL) return -1;
+  memset(&img, 0, sizeof(img));
+  img.nplanes = 3;
+  img.width = w;
+  img.height = h;
+  img.planes[0].data = (unsigned char *)frame;
+  img.planes[0].xstride = 1;
+  img.planes[0].ystride = w;
+  img.planes[0].bitdepth = 8;
+  for (pli = 1; pli < 3; pli++) {
+    img.planes[pli].data = (unsigned char *)frame + (long)w*h
+     + (pli - 1)*(long)((w + 1) >> 1)*((h + 1) >> 1);
+    img.planes[pli].xdec = 1;
+    img.planes[pli].ydec = 1;
+    img.planes[pli].xstride = 1;
+    img.planes[pli].ystride = (w + 1) >> 1;
+    img.planes[pli].bitdepth = 8;
+  }
+  ret = daala_encode_img_in(enc, &img, 0);
+  if (ret < 0) {
+    daala_encode_free(enc);
+    return ret;
+  }
+  pad = &enc->input_queue.images[enc->input_queue.input_head];
+  for (pli = 0; pli < 3; pli++) {
+    int pw;
+    int ph;
+    int y;
+    pw = pad->width >> pad->planes[pli].xdec;
+    ph = pad->height >> pad->planes[pli].ydec;
+    dims[2*pli] = pw;
+    dims[2*pli + 1] = ph;
+    for (y = 0; y < ph; y++) {
+      memcpy(planes[pli] + (long)y*pw, pad->planes[pli].data + (long)y*pad->planes[pli].ystride, pw);
+    }
+  }
+  daala_encode_free(enc);
+  return 0;
+}

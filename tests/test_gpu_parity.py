@@ -243,3 +243,27 @@ def test_per_call_surfaces(hip):
     o.odo_apply_postfilter_frame_sbs(P(a), W, 2, 2, 0, 0)
     L.od_apply_postfilter_frame_sbs_hip(P(b), W, 2, 2, 0, 0, 0, None, 0)
     assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("pic,plane", [((70, 50), (128, 64)), ((1920, 1080), (1920, 1088)),
+                                       ((960, 540), (960, 544)), ((33, 17), (64, 64)),
+                                       ((64, 64), (64, 64)), ((65, 129), (128, 192)),
+                                       ((1, 1), (32, 32)), ((0, 0), (64, 64))])
+def test_image_planes_copy_pad_matches_oracle(hip, pic, plane):
+    """odhip_image_planes_copy_pad (od_img_plane_copy_pad, src/encode.c:752-837) on a
+    batch of planes vs the oracle (pinned to the reference encoder's padded input)."""
+    import torch
+    o = oracle()
+    (pw, ph), (fw, fh) = pic, plane
+    rng = np.random.RandomState(pw * 7 + ph)
+    nplanes = 3
+    src = rng.randint(0, 256, size=(nplanes, ph, pw)).astype(np.uint8)
+    out = torch.full((nplanes, fh, fw), 77, dtype=torch.uint8, device="cuda")
+    hip.image_planes_copy_pad(torch.from_numpy(src).cuda(), fw, fh, out=out)
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    for p in range(nplanes):
+        want = np.zeros((fh, fw), np.uint8)
+        s = np.ascontiguousarray(src[p]) if pw and ph else np.zeros((1, 1), np.uint8)
+        o.odo_img_plane_copy_pad(P(want), fw, fw, fh, P(s), max(pw, 1), pw, ph)
+        assert np.array_equal(got[p], want), (pic, p)

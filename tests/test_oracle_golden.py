@@ -318,3 +318,50 @@ def test_cfl_flip_vs_reference_random():
             r.ref_pvq_encode_block(P(r1), P(x), P(out), 37, 1, bs, P(beta), 1, P(qm), P(qmi), 1)
             o.odo_cfl_flip(P(r2), P(x), P(qm), bs)
             assert np.array_equal(r1, r2)
+
+
+def _pad_planes(o, fr, w, h):
+    cw, ch = (w + 1) // 2, (h + 1) // 2
+    fw, fh = (w + 63) // 64 * 64, (h + 63) // 64 * 64
+    off = 0
+    out = []
+    for pli, (pw, ph) in enumerate(((w, h), (cw, ch), (cw, ch))):
+        src = np.ascontiguousarray(fr[off:off + pw * ph].reshape(ph, pw))
+        off += pw * ph
+        s = 1 if pli else 0
+        dst = np.zeros((fh >> s, fw >> s), np.uint8)
+        o.odo_img_plane_copy_pad(P(dst), fw >> s, fw >> s, fh >> s, P(src), pw, pw, ph)
+        out.append(dst)
+    return out
+
+
+def test_image_pad_golden():
+    """odo_img_plane_copy_pad against the padded input planes of the reference
+    encoder (tools/make_golden_pad.py)."""
+    g = load("image_pad.npz")
+    o = oracle()
+    i = 0
+    while "frame%d" % i in g:
+        w, h = (int(v) for v in g["size%d" % i])
+        got = _pad_planes(o, g["frame%d" % i], w, h)
+        for pli in range(3):
+            assert np.array_equal(got[pli], g["pad%d_%d" % (i, pli)]), (w, h, pli)
+        i += 1
+    assert i >= 5
+
+
+@pytest.mark.skipif(ref() is None, reason="oracle/_ref not present")
+def test_image_pad_vs_reference_random():
+    o, r = oracle(), ref()
+    rng = np.random.RandomState(17)
+    for (w, h) in [(1, 1), (2, 3), (63, 65), (100, 37), (129, 64), (320, 180)]:
+        cw, ch = (w + 1) // 2, (h + 1) // 2
+        fr = rng.randint(0, 256, size=w * h + 2 * cw * ch).astype(np.uint8)
+        fw, fh = (w + 63) // 64 * 64, (h + 63) // 64 * 64
+        outs = [np.zeros((fh >> s, fw >> s), np.uint8) for s in (0, 1, 1)]
+        arr = (ctypes.c_void_p * 3)(*[a.ctypes.data for a in outs])
+        dims = (ctypes.c_int * 6)()
+        assert r.ref_image_copy_pad(P(fr), w, h, arr, dims) == 0
+        got = _pad_planes(o, fr, w, h)
+        for pli in range(3):
+            assert np.array_equal(got[pli], outs[pli]), (w, h, pli)
