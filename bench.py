@@ -7,6 +7,8 @@ One STEP = one pass of the block-transform hot path over a batch of F synthetic
 1920x1080 4:2:0 frames (coded size 1920x1088) already resident
 in HBM, per GPU:
 
+  0. odhip_image_planes_copy_pad   the 1920x1080 pictures -> the padded 1920x1088
+                             planes the encoder codes (od_img_plane_copy_pad)
   1. odhip_forward_pyramid   pixels -> coefficients, superblock-edge lapping,
                              and for EVERY block size 64..4 the split
                              pre-filter + 2-D fDCT of every block (luma 5
@@ -82,10 +84,17 @@ def synth_frame_np(index, seed):
     return planes
 
 
+def picture_planes(planes):
+    """The 1920x1080 picture of a generated frame (the generator fills the coded
+    1920x1088 size; the encoder's input is the picture, the rest is padding)."""
+    return [planes[0][:PIC_H], planes[1][:PIC_H // 2], planes[2][:PIC_H // 2]]
+
+
 def synth_frames(nframes, seed, device):
-    """F frames resident in HBM: luma [F,h,w], chroma [2F,h/2,w/2] (all Cb, then all Cr)."""
+    """F pictures resident in HBM: luma [F,1080,1920], chroma [2F,540,960] (all Cb,
+    then all Cr)."""
     import torch
-    fr = [synth_frame_np(i, seed) for i in range(nframes)]
+    fr = [picture_planes(synth_frame_np(i, seed)) for i in range(nframes)]
     luma = torch.from_numpy(np.stack([f[0] for f in fr])).to(device)
     chroma = torch.from_numpy(np.stack([f[1] for f in fr] + [f[2] for f in fr])).to(device)
     return luma.contiguous(), chroma.contiguous()
@@ -105,12 +114,17 @@ class Pipeline:
         self.F = nframes
         self.qt = D.QuantTables.load()
         self.lam = D.OD_PVQ_LAMBDA
-        self.luma, self.chroma = synth_frames(nframes, 1234 + int(os.environ.get("RANK", 0)), device)
+        self.luma_pic, self.chroma_pic = synth_frames(nframes, 1234 + int(os.environ.get("RANK", 0)),
+                                                      device)
+        # padded planes the encoder codes (od_img_plane_copy_pad, done on the GPU every step)
+        self.luma = D.image_planes_copy_pad(self.luma_pic, W, H)
+        self.chroma = D.image_planes_copy_pad(self.chroma_pic, W // 2, H // 2)
         self.sets = []
         self.jobs = []
-        for name, px, dec, pli in (("luma", self.luma, 0, 0), ("chroma", self.chroma, 1, 1)):
+        for name, px, pic, dec, pli in (("luma", self.luma, self.luma_pic, 0, 0),
+                                        ("chroma", self.chroma, self.chroma_pic, 1, 1)):
             levels = D.forward_pyramid(px, dec, PIC_W, PIC_H)
-            s = dict(name=name, px=px, dec=dec, pli=pli, levels=levels, jobs=[],
+            s = dict(name=name, px=px, pic=pic, dec=dec, pli=pli, levels=levels, jobs=[],
                      recon=[torch.empty_like(px) for _ in range(5 - dec)])
             for bs in range(5 - dec):
                 qm, qmi = self.qt.qm_slices(pli, bs)
@@ -172,6 +186,9 @@ class Pipeline:
         if self.chroma_cfl:
             return self._step_cfl(record)
         for s in self.sets:
+            self._timed("image_copy_pad_" + s["name"],
+                        lambda: D.image_planes_copy_pad(s["pic"], W >> s["dec"], H >> s["dec"],
+                                                        out=s["px"]), record)
             self._timed("forward_pyramid_" + s["name"],
                         lambda: D.forward_pyramid(s["px"], s["dec"], PIC_W, PIC_H,
                                                   levels=s["levels"]), record)
@@ -192,6 +209,8 @@ class Pipeline:
         luma, chroma = self.sets
         main = torch.cuda.current_stream()
         self.side.wait_stream(main)
+        self._timed("image_copy_pad_luma",
+                    lambda: D.image_planes_copy_pad(luma["pic"], W, H, out=luma["px"]), record)
         self._timed("forward_pyramid_luma",
                     lambda: D.forward_pyramid(luma["px"], 0, PIC_W, PIC_H, levels=luma["levels"]),
                     record)
@@ -202,6 +221,9 @@ class Pipeline:
                     lambda: D.inverse_levels_pvq(luma["jobs"], 0, PIC_W, PIC_H, outs=luma["recon"]),
                     record)
         with torch.cuda.stream(self.side):
+            self._timed("image_copy_pad_chroma",
+                        lambda: D.image_planes_copy_pad(chroma["pic"], W // 2, H // 2,
+                                                        out=chroma["px"]), record)
             self._timed("forward_pyramid_chroma",
                         lambda: D.forward_pyramid(chroma["px"], 1, PIC_W, PIC_H,
                                                   levels=chroma["levels"]), record)
@@ -269,6 +291,9 @@ def algorithmic_bytes(F):
             bands_b += nblk * (8 * coded[bs] + 64 * nbands[bs])
             synth_b += nblk * (8 * coded[bs] + 64 * nbands[bs])
     return {
+        # od_img_plane_copy_pad: picture read, padded plane written
+        "image_copy_pad_luma": F * (PIC_W * PIC_H + W * H),
+        "image_copy_pad_chroma": 2 * F * ((PIC_W // 2) * (PIC_H // 2) + (W // 2) * (H // 2)),
         "forward_pyramid_luma": luma_px * 21,      # 1 B read + 5 levels x 4 B written
         "forward_pyramid_chroma": chroma_px * 17,  # 1 B read + 4 levels x 4 B written
         # dequantise-on-load inverse: per level 4 B per CODED coefficient read
@@ -312,15 +337,20 @@ def cpu_baseline(qt, chroma_cfl, min_seconds=12.0, max_frames=32):
         r.ref_stage_plane.restype = ctypes.c_long
         r.ref_stage_plane_cfl.restype = ctypes.c_long
     while busy < min_seconds and nframes < max_frames:
-        planes = synth_frame_np(1000 + nframes, 1234)  # generation is not timed
+        pics = picture_planes(synth_frame_np(1000 + nframes, 1234))  # generation is not timed
         ldq = [np.zeros((H, W), np.int32) for _ in range(5)] if chroma_cfl else None
         refs = None
-        for pli, px, dec in ((0, planes[0], 0), (1, planes[1], 1), (2, planes[2], 1)):
+        for pli, pic, dec in ((0, pics[0], 0), (1, pics[1], 1), (2, pics[2], 1)):
             p = 1 if pli else 0
-            h, w = px.shape
+            h, w = H >> dec, W >> dec
             qm_off, qb, bb = tables[p]
+            pic = np.ascontiguousarray(pic)
+            px = np.zeros((h, w), np.uint8)
             recon = np.zeros_like(px)
             t0 = time.perf_counter()
+            # od_img_plane_copy_pad (static in the reference's encode.c: the pinned restatement)
+            oracle().odo_img_plane_copy_pad(P(px), w, w, h, P(pic), pic.shape[1], pic.shape[1],
+                                            pic.shape[0])
             if r is None:
                 o = oracle()
                 o.odo_stage_plane.restype = ctypes.c_long
@@ -347,11 +377,11 @@ def cpu_baseline(qt, chroma_cfl, min_seconds=12.0, max_frames=32):
                     c = ldq[bs + 1].reshape(H // (2 * n), 2 * n, W // (2 * n), 2 * n)[:, :n, :, :n]
                     refs.append(np.ascontiguousarray(c.reshape(H // 2, W // 2)))
         nframes += 1
-    what = ("forward pyramid + pvq_theta (luma: no-reference bands; chroma: WITH the "
+    what = ("padding + forward pyramid + pvq_theta (luma: no-reference bands; chroma: WITH the "
             "chroma-from-luma reference) + inverse" if chroma_cfl else
-            "forward pyramid + pvq_theta noref bands + inverse")
+            "padding + forward pyramid + pvq_theta noref bands + inverse")
     return {"value": blocks / busy, "unit": "blocks/s", "cores": 1, "kind": kind,
-            "sample": "%d synthetic 1920x1088 4:2:0 frames of the bench generator (%d blocks) in "
+            "sample": "%d synthetic 1920x1080 4:2:0 pictures of the bench generator (%d blocks) in "
                       "%.1f s: %s of every block at every level, reference C functions, single "
                       "thread" % (nframes, blocks, busy, what)}
 
