@@ -497,7 +497,7 @@ REFITEM_RECORD = np.dtype([("gain", "<i4"), ("theta", "<i4"), ("ts", "<i4"), ("k
                            ("cos_dist", "<f8"), ("dist", "<f8")])
 assert REFITEM_RECORD.itemsize == 48
 REFBAND_R_NULL, REFBAND_THETA, REFBAND_NOREF, REFBAND_FLIP, REFBAND_UNCERTAIN = 1, 2, 4, 8, 16
-REFITEM_SEARCHED, REFITEM_WITH_REF = 1, 2
+REFITEM_SEARCHED, REFITEM_WITH_REF, REFITEM_K_RANGE = 1, 2, 4
 
 
 class _RefJob(ctypes.Structure):

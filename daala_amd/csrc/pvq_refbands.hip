@@ -826,6 +826,15 @@ __device__ __forceinline__ void refb_loops(const RJob &jb, int band, long blk, b
         if (writer) ip.tail[idx*ip.stride] = make_int4(qcg, qtheta, ODHIP_REFITEM_WITH_REF, -1);
         continue;
       }
+      if (k > ODHIP_PVQ_MAX_K) {
+        /* pulses are stored as int16: reported, never searched or chosen (the
+           candidates are sorted by K, so every later one is skipped as well) */
+        if (writer) {
+          ip.tail[idx*ip.stride] = make_int4(qcg, qtheta, ODHIP_REFITEM_WITH_REF | ODHIP_REFITEM_K_RANGE,
+           -1);
+        }
+        continue;
+      }
       const double sin_prod = ((odq_pvq_sin(theta)*t1)*odq_pvq_sin(qtheta))*t1;
       if (k == 0) {
         cos_dist = 0;
@@ -861,6 +870,10 @@ __device__ __forceinline__ void refb_loops(const RJob &jb, int band, long blk, b
       dist *= s2;
       if (dist > dist0 && k != 0) {
         if (writer) ip.tail[idx*ip.stride] = make_int4(qcg, 0, 0, -1);
+        continue;
+      }
+      if (k > ODHIP_PVQ_MAX_K) {
+        if (writer) ip.tail[idx*ip.stride] = make_int4(qcg, 0, ODHIP_REFITEM_K_RANGE, -1);
         continue;
       }
       const double cos_dist = dbg ? 0.5 : v.search(n, k, prev_k, (qcg*(double)cg)*s2, lambda);

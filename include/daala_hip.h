@@ -435,6 +435,8 @@ typedef struct {
 
 #define ODHIP_REFITEM_SEARCHED 1    /* not pruned (:531, :588)                          */
 #define ODHIP_REFITEM_WITH_REF 2    /* theta candidate                                  */
+#define ODHIP_REFITEM_K_RANGE 4     /* K above ODHIP_PVQ_MAX_K: pulses would not fit the
+                                       int16 vectors; reported, never searched or chosen */
 typedef struct {
   int32_t gain;           /* i                                                  */
   int32_t theta;          /* j, -1 for a no-reference candidate                 */

@@ -229,3 +229,38 @@ def test_chroma_from_luma_planes_match_the_compiled_reference(hip):
         assert np.abs(cdq[bs]).sum() > 0
     got = hip.inverse_level(jobs[3].dq, 1, 3, W, H)[0].cpu().numpy()
     assert np.array_equal(got, crecon), "reconstructed chroma pixels (32x32 level)"
+
+
+def test_pulse_counts_beyond_the_int16_vectors_are_reported_not_searched(hip):
+    """Quantiser 1 on large coefficients asks for K far above ODHIP_PVQ_MAX_K
+    (32767): such candidates are flagged ODHIP_REFITEM_K_RANGE, never searched,
+    never chosen; everything that is searched still equals the oracle."""
+    import torch
+    lam = hip.OD_PVQ_LAMBDA
+    rng = np.random.RandomState(123)
+    qt = hip.QuantTables.load()
+    bs = 2
+    qm, qmi = qt.qm_slices(0, bs)
+    nb = hip.pvq_band_layout(bs)[0]
+    x, r = make_planes(rng, 1, 32, 32, bs, zero_ref_frac=0.0)
+    x = (x.astype(np.int64) * 64).clip(-(1 << 21), 1 << 21).astype(np.int32)
+    r = (r.astype(np.int64) * 64).clip(-(1 << 21), 1 << 21).astype(np.int32)
+    job = hip.PvqRefJob(_cuda(x), _cuda(r), bs, _cuda(qm), _cuda(qmi), [1] * nb, [4096] * nb, 0, 0)
+    hip.pvq_ref_bands_multi([job], lam)
+    hip.pvq_ref_select_synth_multi([job], lam)
+    torch.cuda.synchronize()
+    u = job.unpack()
+    items, rec, ch = u["items"], u["rec"], u["choice"]
+    big = 0
+    for blk in range(rec.shape[0]):
+        for b in range(nb):
+            for i in range(int(rec[blk, b]["nitems"])):
+                it = items[blk, b, i]
+                fl = int(it["flags"])
+                if fl & hip.REFITEM_K_RANGE:
+                    big += 1
+                    assert int(it["k"]) > 32767 and not (fl & hip.REFITEM_SEARCHED)
+                    assert int(ch[blk, b, 0]) != i
+                elif fl & hip.REFITEM_SEARCHED:
+                    assert int(it["k"]) <= 32767
+    assert big > 0
