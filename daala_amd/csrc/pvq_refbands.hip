@@ -165,7 +165,7 @@ __global__ __launch_bounds__(kWave) void k_theta_probe(const double *corr, doubl
    Householder pivot is the first largest |r| (src/pvq.c:505-512; |r16| < 2^15
    by construction of rshift, so the int16 running maximum of the reference
    cannot wrap). */
-__device__ unsigned short gRScanPk[OD_SCAN_LEN];   /* y << 8 | x */
+__device__ __attribute__((aligned(16))) unsigned short gRScanPk[OD_SCAN_LEN];   /* y << 8 | x */
 
 struct PrepScalars {
   int32_t g, gr, cg, cgr, gain_offset;
@@ -1250,57 +1250,97 @@ __global__ __launch_bounds__(kWave) void k_refb_choose(RItems it) {
   ch[3] = make_int4(xm, m, proj_1, outshift);
 }
 
+/* Eight consecutive coding positions of one block per thread: a chunk never
+   straddles a band (bands start at 1, 16, 24, 32, 64, ...; the chunk at 0 holds
+   the DC, which is passed through, and the first seven coefficients of band 0).
+   Pulses, reference, inverse QM and scan positions are 16-byte loads. */
 __global__ __launch_bounds__(256) void k_refb_synth(RItems it) {
   const int item = find_item(it, blockIdx.x);
   const RJob &jb = g_rjobs[it.job[item]];
   const int len = jb.len;
+  const int cpb = len >> 3;                       /* chunks per block */
   const long t = (long)(blockIdx.x - it.wg_start[item])*256 + threadIdx.x;
-  const long blk = t/len;
+  const long blk = t/cpb;
   if (blk >= jb.nblocks) return;
-  const int c = (int)(t - blk*len);
+  const int c0 = (int)(t - blk*cpb) << 3;
   const long base = block_base(jb, blk);
   od_coeff *out = jb.dq + base;
-  if (c == 0) {
-    out[0] = jb.coef[base];
-    return;
-  }
-  const int band = gRBandOf[c];
+  const int w = jb.w;
+  const int band = gRBandOf[c0 ? c0 : 1];
   const int off = jb.off[band];
-  const int i = c - off;
-  const int pk = gRScanPk[c];
-  const long p = (long)(pk >> 8)*jb.w + (pk & 255);
+  const uint4 sc4 = *reinterpret_cast<const uint4 *>(gRScanPk + c0);
+  const unsigned scw[4] = {sc4.x, sc4.y, sc4.z, sc4.w};
+  long pos[8];
+#pragma unroll
+  for (int e = 0; e < 8; e++) {
+    const unsigned pk = (scw[e >> 1] >> (16*(e & 1))) & 0xffffu;
+    pos[e] = (long)(pk >> 8)*w + (pk & 255);
+  }
   const int4 *ch = reinterpret_cast<const int4 *>(jb.choice + (blk*jb.nb_bands + band)*16);
   const int4 a = ch[2];
   const int mode = a.x;
+  const int first = c0 == 0;                       /* element 0 is the DC */
+  if (first) out[0] = jb.coef[base];
   if (mode == 0) {
-    out[p] = 0;
+#pragma unroll
+    for (int e = 0; e < 8; e++) if (!(first && e == 0)) out[pos[e]] = 0;
     return;
   }
   if (mode == 1 || mode == 4) {
-    const od_coeff rv = jb.ref[base + p];
-    out[p] = mode == 4 ? -rv : rv;
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+      if (first && e == 0) continue;
+      const od_coeff rv = jb.ref[base + pos[e]];
+      out[pos[e]] = mode == 4 ? -rv : rv;
+    }
     return;
   }
   const int yslot = a.y;
   const int32_t scale = a.z;
   const int qshift = a.w;
-  const int qmi = jb.qm_inv[c];
-  const int16_t *yp = jb.y + ((long)yslot*jb.nblocks + blk)*len + off;
+  const uint4 q4 = *reinterpret_cast<const uint4 *>(jb.qm_inv + c0);
+  const unsigned qw[4] = {q4.x, q4.y, q4.z, q4.w};
+  unsigned yw[4] = {0, 0, 0, 0};
+  int yprev = 0;                                   /* pulse just before the chunk */
+  if (yslot >= 0) {
+    const int16_t *yp = jb.y + ((long)yslot*jb.nblocks + blk)*len + c0;
+    const uint4 y4 = *reinterpret_cast<const uint4 *>(yp);
+    yw[0] = y4.x;
+    yw[1] = y4.y;
+    yw[2] = y4.z;
+    yw[3] = y4.w;
+    if (mode == 3 && c0 > off) yprev = yp[-1];
+  }
   if (mode == 2) {
-    const int32_t x = (int32_t)odq_mult16_32_q16(yslot >= 0 ? yp[i] : 0, scale);
-    out[p] = odq_shr_round(x*qmi, qshift);
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+      if (first && e == 0) continue;
+      const int yv = (int16_t)(yw[e >> 1] >> (16*(e & 1)));
+      const int qmi = (int16_t)(qw[e >> 1] >> (16*(e & 1)));
+      const int32_t x = (int32_t)odq_mult16_32_q16(yv, scale);
+      out[pos[e]] = odq_shr_round(x*qmi, qshift);
+    }
     return;
   }
   const int4 b = ch[3];
   const int m = b.y;
-  const int16_t xi = i == m ? (int16_t)b.x
-   : (int16_t)odq_mult16_32_q16(yslot >= 0 ? yp[i < m ? i : i - 1] : 0, scale);
-  int32_t tmp = odq_mult16_16(jb.r16[blk*len + c], b.z);
-  tmp = b.w >= 0 ? odq_shr_round(tmp, b.w) : odq_shl32(tmp, -b.w);
-  const int16_t v = (int16_t)(xi - tmp);
-  out[p] = odq_shr_round(v*qmi, qshift);
+  const uint4 r4 = *reinterpret_cast<const uint4 *>(jb.r16 + blk*len + c0);
+  const unsigned rw[4] = {r4.x, r4.y, r4.z, r4.w};
+#pragma unroll
+  for (int e = 0; e < 8; e++) {
+    if (first && e == 0) continue;
+    const int i = c0 + e - off;                    /* position inside the band */
+    const int yv = (int16_t)(yw[e >> 1] >> (16*(e & 1)));
+    const int ym1 = e == 0 ? yprev : (int)(int16_t)(yw[(e - 1) >> 1] >> (16*((e - 1) & 1)));
+    const int qmi = (int16_t)(qw[e >> 1] >> (16*(e & 1)));
+    const int ri = (int16_t)(rw[e >> 1] >> (16*(e & 1)));
+    const int16_t xi = i == m ? (int16_t)b.x : (int16_t)odq_mult16_32_q16(i < m ? yv : ym1, scale);
+    int32_t tmp = odq_mult16_16(ri, b.z);
+    tmp = b.w >= 0 ? odq_shr_round(tmp, b.w) : odq_shl32(tmp, -b.w);
+    const int16_t v = (int16_t)(xi - tmp);
+    out[pos[e]] = odq_shr_round(v*qmi, qshift);
+  }
 }
-
 
 /* ---- host side --------------------------------------------------------------------- */
 bool g_tables_uploaded = false;
@@ -1724,7 +1764,7 @@ extern "C" int odhip_pvq_ref_select_synth_multi(const odhip_pvq_refjob *jobs, in
     else k_refb_choose<8><<<grid, kWave, 0, s>>>(it);
   }
   items_begin(it, pvq_norm_lambda);
-  for (int j = 0; j < njobs; j++) items_add(it, j, 0, (host[j].nblocks*host[j].len + 255)/256);
+  for (int j = 0; j < njobs; j++) items_add(it, j, 0, (host[j].nblocks*(host[j].len >> 3) + 255)/256);
   k_refb_synth<<<it.wg_start[it.nitems], 256, 0, s>>>(it);
   return odhip_check_launch();
 }
