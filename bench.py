@@ -233,10 +233,9 @@ class Pipeline:
             self._timed("pvq_ref_select_synth",
                         lambda: D.pvq_ref_select_synth_multi(self.refjobs, self.lam), record)
 
-            def chroma_inverse():
-                for bs, rj in enumerate(self.refjobs):
-                    D.inverse_level(rj.dq, 1, bs, PIC_W, PIC_H, out=chroma["recon"][bs])
-            self._timed("inverse_chroma", chroma_inverse, record)
+            self._timed("inverse_chroma",
+                        lambda: D.inverse_levels([rj.dq for rj in self.refjobs], 1, [0, 1, 2, 3],
+                                                 PIC_W, PIC_H, outs=chroma["recon"]), record)
         main.wait_stream(self.side)
 
     def ref128_bytes(self):

@@ -646,3 +646,22 @@ def image_planes_copy_pad(src, plane_w, plane_h, out=None):
                                              pic_w, ctypes.c_long(pic_h * pic_w), pic_w, pic_h,
                                              nplanes, _stream()), "odhip_image_planes_copy_pad")
     return out
+
+
+def inverse_levels(coefs, dec, leaf_bs, pic_w, pic_h, outs=None):
+    """inverse_level for several partition levels of one plane set in one set of
+    launches: coefs[i] (int32 [nplanes, h, w]) at level leaf_bs[i] -> outs[i]."""
+    import torch
+    nplanes, h, w = coefs[0].shape
+    if outs is None:
+        outs = [torch.empty((nplanes, h, w), dtype=torch.uint8, device=coefs[0].device) for _ in coefs]
+    n = len(coefs)
+    for c in coefs:
+        _need(c, torch.int32, "coef")
+        assert c.shape == coefs[0].shape
+    px = (ctypes.c_void_p * n)(*[o.data_ptr() for o in outs])
+    cf = (ctypes.c_void_p * n)(*[c.data_ptr() for c in coefs])
+    lv = (ctypes.c_int * n)(*[int(v) for v in leaf_bs])
+    _check(lib().odhip_inverse_levels(px, w, ctypes.c_long(h * w), cf, lv, n, nplanes, w, h, int(dec),
+                                      int(pic_w), int(pic_h), _stream()), "odhip_inverse_levels")
+    return outs

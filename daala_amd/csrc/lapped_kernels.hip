@@ -961,6 +961,36 @@ extern "C" int odhip_inverse_level(uint8_t *d_px, int px_stride, long px_plane_s
   return inverse_launch(ia, nplanes, dec, (hipStream_t)stream);
 }
 
+/* odhip_inverse_level for several partition levels of ONE plane set in a single
+   set of launches: level leaf_bs[i] is reconstructed from d_coef[i] into d_px[i]. */
+extern "C" int odhip_inverse_levels(uint8_t *const *d_px, int px_stride, long px_plane_stride,
+ const od_coeff *const *d_coef, const int *leaf_bs, int nlevels, int nplanes, int w, int h, int dec,
+ int pic_w, int pic_h, odhip_stream stream) {
+  if (!d_px || !d_coef || !leaf_bs || nlevels <= 0 || nlevels > kMaxInvLevels || nplanes <= 0
+   || (dec != 0 && dec != 1)) {
+    return ODHIP_EINVAL;
+  }
+  const int tile = 64 >> dec;
+  if (w <= 0 || h <= 0 || w % tile || h % tile || (px_stride & 3) || (px_plane_stride & 3)) {
+    return ODHIP_EINVAL;
+  }
+  InverseArgs ia[kMaxInvLevels];
+  memset(ia, 0, sizeof(ia));
+  for (int i = 0; i < nlevels; i++) {
+    if (!d_px[i] || !d_coef[i] || leaf_bs[i] < 0 || leaf_bs[i] > 4 - dec) return ODHIP_EINVAL;
+    ia[i].coef = d_coef[i];
+    ia[i].px = d_px[i];
+    ia[i].px_stride = px_stride;
+    ia[i].px_plane_stride = px_plane_stride;
+    ia[i].w = w;
+    ia[i].h = h;
+    ia[i].pic_w = pic_w;
+    ia[i].pic_h = pic_h;
+    ia[i].leaf_bs = leaf_bs[i];
+  }
+  return inverse_launch(ia, nlevels, nplanes, dec, (hipStream_t)stream);
+}
+
 namespace {
 
 int pvq_inverse_args(InverseArgs &ia, uint8_t *d_px, int px_stride, long px_plane_stride,

@@ -178,6 +178,13 @@ int odhip_inverse_level(uint8_t *d_px, int px_stride, long px_plane_stride,
  const od_coeff *d_coef, int nplanes, int w, int h, int dec, int leaf_bs,
  int pic_w, int pic_h, odhip_stream stream);
 
+/* odhip_inverse_level for several partition levels of ONE plane set (same
+   nplanes, w, h, dec; at most 5) in a single set of launches: level leaf_bs[i]
+   is reconstructed from d_coef[i] into d_px[i] (distinct buffers, same strides). */
+int odhip_inverse_levels(uint8_t *const *d_px, int px_stride, long px_plane_stride,
+ const od_coeff *const *d_coef, const int *leaf_bs, int nlevels, int nplanes, int w, int h,
+ int dec, int pic_w, int pic_h, odhip_stream stream);
+
 /* Batched pvq_search_rdo_double: band b has d_x[b*n .. b*n+n) int16,
    d_k[b], d_g2[b], optional d_prev_k[b] (NULL = 0; when > 0 d_y holds the
    previous pulses), writes d_y[b*n ..) and d_cos[b].  n <= 128. */

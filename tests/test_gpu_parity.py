@@ -267,3 +267,19 @@ def test_image_planes_copy_pad_matches_oracle(hip, pic, plane):
         s = np.ascontiguousarray(src[p]) if pw and ph else np.zeros((1, 1), np.uint8)
         o.odo_img_plane_copy_pad(P(want), fw, fw, fh, P(s), max(pw, 1), pw, ph)
         assert np.array_equal(got[p], want), (pic, p)
+
+
+def test_inverse_levels_equals_inverse_level_per_level(hip):
+    """odhip_inverse_levels (several partition levels of one plane set in one set of
+    launches) gives exactly what odhip_inverse_level gives level by level."""
+    import torch
+    rng = np.random.RandomState(4)
+    for dec, (h, w) in ((0, (128, 192)), (1, (64, 96))):
+        top = 4 - dec
+        coefs = [torch.from_numpy(rng.randint(-3000, 3000, size=(2, h, w)).astype(np.int32)).cuda()
+                 for _ in range(top + 1)]
+        got = hip.inverse_levels(coefs, dec, list(range(top + 1)), 2 * w if dec else w, 2 * h - 5 if dec else h - 5)
+        torch.cuda.synchronize()
+        for bs in range(top + 1):
+            want = hip.inverse_level(coefs[bs], dec, bs, 2 * w if dec else w, 2 * h - 5 if dec else h - 5)
+            assert torch.equal(got[bs], want), (dec, bs)
