@@ -227,15 +227,21 @@ class Pipeline:
             self._timed("forward_pyramid_chroma",
                         lambda: D.forward_pyramid(chroma["px"], 1, PIC_W, PIC_H,
                                                   levels=chroma["levels"]), record)
-            # includes odhip_pvq_ref_resolve (waits for this stream only)
-            self._timed("pvq_ref_bands", lambda: D.pvq_ref_bands_multi(self.refjobs, self.lam),
-                        record)
-            self._timed("pvq_ref_select_synth",
-                        lambda: D.pvq_ref_select_synth_multi(self.refjobs, self.lam), record)
+            # the count of bands inside the device-acos margin travels to the host behind
+            # the stage; choice, synthesis and inverse are enqueued without waiting for it
+            self._timed("pvq_ref_bands",
+                        lambda: D.pvq_ref_bands_multi(self.refjobs, self.lam, resolve="async"), record)
 
-            self._timed("inverse_chroma",
-                        lambda: D.inverse_levels([rj.dq for rj in self.refjobs], 1, [0, 1, 2, 3],
-                                                 PIC_W, PIC_H, outs=chroma["recon"]), record)
+            def tail():
+                self._timed("pvq_ref_select_synth",
+                            lambda: D.pvq_ref_select_synth_multi(self.refjobs, self.lam), record)
+                self._timed("inverse_chroma",
+                            lambda: D.inverse_levels([rj.dq for rj in self.refjobs], 1, [0, 1, 2, 3],
+                                                     PIC_W, PIC_H, outs=chroma["recon"]), record)
+            tail()
+            if D.pvq_ref_resolve_finish(self.refjobs, self.lam) > 0:
+                tail()      # a listed band got the host's theta: redo what consumed it
+
         main.wait_stream(self.side)
 
     def ref128_bytes(self):

@@ -589,9 +589,23 @@ def pvq_ref_bands_multi(jobs, pvq_norm_lambda, resolve=True):
                                            _stream()), "odhip_pvq_ref_bands_multi")
     if not resolve:
         return 0
+    if resolve == "async":
+        _check(lib().odhip_pvq_ref_resolve_begin(_stream()), "odhip_pvq_ref_resolve_begin")
+        return 0
     n = lib().odhip_pvq_ref_resolve(arr, len(jobs), ctypes.c_double(pvq_norm_lambda), _stream())
     if n < 0:
         raise DaalaHipError("odhip_pvq_ref_resolve failed with code %d" % n)
+    return n
+
+
+def pvq_ref_resolve_finish(jobs, pvq_norm_lambda):
+    """Second half of pvq_ref_bands_multi(..., resolve="async"): waits for the count
+    of bands inside the device-acos margin only; 0 (normal) or the number of bands
+    re-run with the host's theta - then the caller repeats choice / synthesis."""
+    n = lib().odhip_pvq_ref_resolve_finish(_refjobs_array(jobs), len(jobs),
+                                           ctypes.c_double(pvq_norm_lambda), _stream())
+    if n < 0:
+        raise DaalaHipError("odhip_pvq_ref_resolve_finish failed with code %d" % n)
     return n
 
 

@@ -1676,6 +1676,37 @@ extern "C" int odhip_pvq_ref_bands_multi(const odhip_pvq_refjob *jobs, int njobs
   return odhip_check_launch();
 }
 
+namespace {
+unsigned *g_unc_host = nullptr;     /* pinned mirror of g_unc_count */
+hipEvent_t g_unc_event = nullptr;
+}  // namespace
+
+/* The count of listed bands travels to pinned host memory behind the band stage;
+   nothing waits for it here. */
+extern "C" int odhip_pvq_ref_resolve_begin(odhip_stream stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (!g_unc_host) {
+    ODHIP_TRY(hipHostMalloc((void **)&g_unc_host, sizeof(unsigned), hipHostMallocDefault));
+    ODHIP_TRY(hipEventCreateWithFlags(&g_unc_event, hipEventDisableTiming));
+  }
+  *g_unc_host = 0xffffffffu;
+  ODHIP_TRY(hipMemcpyFromSymbolAsync(g_unc_host, HIP_SYMBOL(g_unc_count), sizeof(unsigned), 0,
+   hipMemcpyDeviceToHost, s));
+  ODHIP_TRY(hipEventRecord(g_unc_event, s));
+  return ODHIP_SUCCESS;
+}
+
+extern "C" int odhip_pvq_ref_resolve(const odhip_pvq_refjob *jobs, int njobs,
+ double pvq_norm_lambda, odhip_stream stream);
+
+extern "C" int odhip_pvq_ref_resolve_finish(const odhip_pvq_refjob *jobs, int njobs,
+ double pvq_norm_lambda, odhip_stream stream) {
+  if (!g_unc_event) return ODHIP_EINVAL;
+  ODHIP_TRY(hipEventSynchronize(g_unc_event));
+  if (*g_unc_host == 0) return 0;
+  return odhip_pvq_ref_resolve(jobs, njobs, pvq_norm_lambda, stream);
+}
+
 extern "C" int odhip_pvq_ref_resolve(const odhip_pvq_refjob *jobs, int njobs,
  double pvq_norm_lambda, odhip_stream stream) {
   hipStream_t s = (hipStream_t)stream;

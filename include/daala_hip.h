@@ -505,6 +505,16 @@ int odhip_pvq_ref_bands_multi(const odhip_pvq_refjob *jobs, int njobs,
    negative ODHIP_E* code.  Results are exact only after this call. */
 int odhip_pvq_ref_resolve(const odhip_pvq_refjob *jobs, int njobs,
  double pvq_norm_lambda, odhip_stream stream);
+/* The same without a host wait in the middle of a pipeline: _begin (right after
+   odhip_pvq_ref_bands_multi, same stream) sends the count of listed bands to
+   pinned host memory; the caller enqueues whatever follows (choice, synthesis,
+   inverse) speculatively; _finish waits for the count only, returns 0 when no band
+   is listed (the normal case) and otherwise does what odhip_pvq_ref_resolve does
+   and returns how many bands were re-run - the caller then repeats the steps that
+   consumed the candidates. */
+int odhip_pvq_ref_resolve_begin(odhip_stream stream);
+int odhip_pvq_ref_resolve_finish(const odhip_pvq_refjob *jobs, int njobs,
+ double pvq_norm_lambda, odhip_stream stream);
 int odhip_pvq_ref_select_synth_multi(const odhip_pvq_refjob *jobs, int njobs,
  double pvq_norm_lambda, odhip_stream stream);
 /* Profiling aid (bench.py), as odhip_pvq_profile: while enabled,

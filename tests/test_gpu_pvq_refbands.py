@@ -127,6 +127,10 @@ def test_uncertain_theta_is_settled_by_the_host(hip):
         rerun = hip.pvq_ref_bands_multi(jobs, lam, resolve=True)
         torch.cuda.synchronize()
         assert rerun == flagged
+        # the same through the two-phase form (no host wait inside the stage)
+        hip.pvq_ref_bands_multi(jobs, lam, resolve="async")
+        assert hip.pvq_ref_resolve_finish(jobs, lam) == flagged
+        torch.cuda.synchronize()
     finally:
         hip.pvq_ref_set_theta_margin(0, False)
     mm = Mismatch()
