@@ -59,6 +59,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 W, H, PIC_W, PIC_H = 1920, 1088, 1920, 1080
+DEFAULT_FRAMES = 16   # per GPU per step; profiles/ holds the rocprofv3 runs of this default command
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
 
 
@@ -244,6 +245,21 @@ class Pipeline:
 
         main.wait_stream(self.side)
 
+    def pyramid_alone_ms(self, n=10):
+        """Average duration of the luma forward pyramid launched on an otherwise idle GPU."""
+        t, D = self.torch, self.D
+        luma = self.sets[0]
+        t.cuda.synchronize()
+        a = t.cuda.Event(enable_timing=True)
+        b = t.cuda.Event(enable_timing=True)
+        D.forward_pyramid(luma["px"], 0, PIC_W, PIC_H, levels=luma["levels"])
+        a.record()
+        for _ in range(n):
+            D.forward_pyramid(luma["px"], 0, PIC_W, PIC_H, levels=luma["levels"])
+        b.record()
+        t.cuda.synchronize()
+        return a.elapsed_time(b) / n
+
     def ref128_bytes(self):
         """Algorithmic bytes and band count of one k_refb_search_row<8> launch,
         counted from the records and candidate vectors the last step left."""
@@ -396,7 +412,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--frames", type=int, default=8, help="1080p frames per GPU per step")
+    ap.add_argument("--frames", type=int, default=DEFAULT_FRAMES, help="1080p frames per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--chroma-noref", action="store_true",
                     help="chroma through pvq_theta's no-reference path (default: with the "
@@ -442,6 +458,9 @@ def main():
     dt = time.perf_counter() - t0
     search_ms = D.pvq_profile_read()
     D.pvq_profile(False)
+    # The filter + DCT kernel on its own (after the timed steps): in the step it shares the
+    # GPU with the other stream's kernels, which stretches its duration.
+    fd_alone = pipe.pyramid_alone_ms()
     ref_search_ms = D.pvq_ref_profile_read()
     D.pvq_ref_profile(False)
     if dist is not None:
@@ -490,8 +509,8 @@ def main():
             with open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")) as f:
                 tr = json.load(f)["kernels"]
             key = [k_ for k_ in tr if k_.startswith("k_search<128")]
-            # the committed PMC run is of the default command (8 frames, chroma with reference)
-            if key and args.frames == 8 and cfl:
+            # the committed PMC run is of the default command (DEFAULT_FRAMES, chroma with reference)
+            if key and args.frames == DEFAULT_FRAMES and cfl:
                 roof["traffic"] = tr[key[0]]["hbm_bytes_per_launch"]
                 roof["traffic_source"] = "profiles/r1_pmc_traffic.json (rocprofv3 --pmc, same command)"
                 vi = tr[key[0]].get("valu_wave_instructions")
@@ -527,7 +546,7 @@ def main():
                 with open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")) as f:
                     tr = json.load(f)["kernels"]
                 key = [k_ for k_ in tr if k_.startswith("k_refb_search_row<8, 16>")]
-                if key and args.frames == 8:
+                if key and args.frames == DEFAULT_FRAMES:
                     roof_ref["traffic"] = tr[key[0]]["hbm_bytes_per_launch"]
                     roof_ref["traffic_source"] = ("profiles/r1_pmc_traffic.json (rocprofv3 --pmc, "
                                                   "same command)")
@@ -550,10 +569,24 @@ def main():
                         "candidate per pulse, DESIGN.md), HBM is quoted because SURVEY 8(d) prices "
                         "it against HBM; see roofline_filter_dct for the stage the north star "
                         "prices at >= 60 % of HBM")
+        fd_gbs = ab["forward_pyramid_luma"] / (fd_alone * 1e-3) / 1e9
         roof_fd = {"kernel": "k_forward_pyramid64x2 (forward_pyramid_luma)", "bound": "hbm",
-                   "achieved": fd["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                   "frac": fd["frac_of_hbm_peak"], "traffic": None,
-                   "algorithmic_bytes_per_launch": ab["forward_pyramid_luma"]}
+                   "achieved": round(fd_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                   "frac": round(fd_gbs / HBM_PEAK_GBS, 4), "traffic": None,
+                   "avg_ms_per_launch": round(fd_alone, 4), "launches": 10,
+                   "algorithmic_bytes_per_launch": ab["forward_pyramid_luma"],
+                   "in_step": {"avg_ms_per_launch": fd["avg_ms_per_launch"],
+                               "achieved_GBs": fd["achieved_GBs"], "frac": fd["frac_of_hbm_peak"]},
+                   "note": "timed alone after the steps (HIP events, 10 launches); in_step = the same "
+                           "launch inside the step, where it shares the GPU with the other stream"}
+        try:
+            with open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")) as f:
+                tr = json.load(f)["kernels"]
+            key = [k_ for k_ in tr if k_.startswith("k_forward_pyramid64x2")]
+            if key and args.frames == DEFAULT_FRAMES:
+                roof_fd["traffic"] = tr[key[0]]["hbm_bytes_per_launch"]
+        except (OSError, ValueError, KeyError):
+            pass
         line = {
             "metric": "1080p all-intra transform blocks/s (filter+DCT+PVQ)",
             "value": total_blocks / dt,
