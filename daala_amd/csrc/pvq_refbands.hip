@@ -792,7 +792,7 @@ __global__ __launch_bounds__(kWave) void k_refb_cands_list(const Unc *list, int 
    `writer`: this lane records the band's results (one lane per band). */
 template <class V>
 __device__ __forceinline__ void refb_loops(const RJob &jb, int band, long blk, bool writer,
- bool may_store, double lambda, V &v, int dbg = 0) {
+ bool may_store, double lambda, V &v) {
   const odhip_pvq_refband r = jb.rec[blk*jb.nb_bands + band];
   const int off = jb.off[band];
   const int n = jb.off[band + 1] - off;
@@ -841,7 +841,7 @@ __device__ __forceinline__ void refb_loops(const RJob &jb, int band, long blk, b
         cur_slot = -1;
       }
       else if (k != prev_k) {
-        cos_dist = dbg ? 0.5 : v.search(n - 1, k, prev_k, ((qcg*(double)cg)*sin_prod)*s2, lambda);
+        cos_dist = v.search(n - 1, k, prev_k, ((qcg*(double)cg)*sin_prod)*s2, lambda);
         cur_slot = idx;
         if (may_store) v.store(yout + ((long)idx*nblocks + blk)*len + off);
       }
@@ -876,7 +876,7 @@ __device__ __forceinline__ void refb_loops(const RJob &jb, int band, long blk, b
         if (writer) ip.tail[idx*ip.stride] = make_int4(qcg, 0, ODHIP_REFITEM_K_RANGE, -1);
         continue;
       }
-      const double cos_dist = dbg ? 0.5 : v.search(n, k, prev_k, (qcg*(double)cg)*s2, lambda);
+      const double cos_dist = v.search(n, k, prev_k, (qcg*(double)cg)*s2, lambda);
       prev_k = k;
       if (may_store) v.store(yout + ((long)idx*nblocks + blk)*len + off);
       dist = (1.4*(qcg - cg))*(qcg - cg) + (qcg*(double)cg)*(2 - 2*cos_dist);
@@ -1009,7 +1009,7 @@ __global__ __launch_bounds__(kWave) void k_refb_search_row(RItems it) {
   const bool live = pos < nblocks;
   /* rows beyond the end redo the last band without storing anything */
   const long blk = jb.ids[(long)it.band[item]*nblocks + (live ? pos : nblocks - 1)];
-  refb_loops(jb, it.band[item], blk, live && v.l == 0, live, it.lambda, v, it.perturb & 4);
+  refb_loops(jb, it.band[item], blk, live && v.l == 0, live, it.lambda, v);
 }
 
 /* The short bands (N = 15, 8): one band per lane, the band in registers
@@ -1074,7 +1074,7 @@ __global__ __launch_bounds__(kWave) void k_refb_search_regs(RItems it) {
   if (pos >= jb.nblocks) return;
   const long blk = jb.ids[(long)it.band[item]*jb.nblocks + pos];
   RegVector<N> v;
-  refb_loops(jb, it.band[item], blk, true, true, it.lambda, v, it.perturb & 4);
+  refb_loops(jb, it.band[item], blk, true, true, it.lambda, v);
 }
 
 
@@ -1465,7 +1465,6 @@ void items_begin(RItems &it, double lambda) {
   it.lambda = lambda;
   it.margin = g_margin;
   it.perturb = g_perturb;
-  if (getenv("ODHIP_REF_DEBUG_NOSEARCH")) it.perturb |= 4;   /* timing experiments only */
 }
 
 void items_add(RItems &it, int job, int band, long wgs) {
