@@ -14,6 +14,7 @@
 #include "daala/codec.h"
 #include "daala/daalaenc.h"
 #include "state.h"
+#include "encint.h"
 
 #define REF_EXPORT __attribute__((visibility("default")))
 
@@ -94,9 +95,34 @@ REF_EXPORT void ref_get_dct_call_counts(long *fdct, long *idct) {
    tightly packed) as all-intra (keyframe_rate = 1).  Packets are appended to
    out[]; pkt_bytes[i] receives the size of data packet i.  Returns the number
    of data packets, or a negative OD_E* code. */
+static int ref_encode_core(const unsigned char *frames, int w, int h,
+ int nframes, int quality, int complexity, int count_calls,
+ unsigned char *out, long out_cap, long *pkt_bytes, const int *global_index);
+
 REF_EXPORT int ref_encode_yuv420(const unsigned char *frames, int w, int h,
  int nframes, int quality, int complexity, int count_calls,
  unsigned char *out, long out_cap, long *pkt_bytes) {
+  return ref_encode_core(frames, w, h, nframes, quality, complexity, count_calls, out, out_cap,
+   pkt_bytes, NULL);
+}
+
+/* A SHARD of an all-intra encode: frame f of this call is frame
+   global_index[f] of the whole sequence.  The only per-frame state of an
+   all-intra encode that reaches the packet bytes is the display frame number
+   coded in the frame header (OD_REORDER_INDEX(curr_display_order),
+   src/encode.c:3043), which the input queue takes from its frame counter
+   (src/encode.c:309-324); the shard seeds that counter before it queues each of
+   its frames, so its packets are the sequential encoder's byte for byte. */
+REF_EXPORT int ref_encode_yuv420_shard(const unsigned char *frames, int w, int h,
+ int nframes, const int *global_index, int quality, int complexity,
+ unsigned char *out, long out_cap, long *pkt_bytes) {
+  return ref_encode_core(frames, w, h, nframes, quality, complexity, 0, out, out_cap, pkt_bytes,
+   global_index);
+}
+
+static int ref_encode_core(const unsigned char *frames, int w, int h,
+ int nframes, int quality, int complexity, int count_calls,
+ unsigned char *out, long out_cap, long *pkt_bytes, const int *global_index) {
   daala_info di;
   daala_comment dc;
   daala_enc_ctx *enc;
@@ -193,6 +219,10 @@ REF_EXPORT int ref_encode_yuv420(const unsigned char *frames, int w, int h,
       img.planes[2].xstride = 1;
       img.planes[2].ystride = (w + 1) >> 1;
       img.planes[2].bitdepth = 8;
+      if (global_index != NULL) {
+        /* the queue is empty here (every packet was drained above) */
+        ((struct daala_enc_ctx *)enc)->input_queue.frame_number = global_index[f];
+      }
       ret = daala_encode_img_in(enc, &img, 0);
       if (ret < 0) return ret;
     }
