@@ -679,3 +679,20 @@ def inverse_levels(coefs, dec, leaf_bs, pic_w, pic_h, outs=None):
     _check(lib().odhip_inverse_levels(px, w, ctypes.c_long(h * w), cf, lv, n, nplanes, w, h, int(dec),
                                       int(pic_w), int(pic_h), _stream()), "odhip_inverse_levels")
     return outs
+
+
+def cfl_refs_from_luma(luma_jobs, refs=None, copies=2):
+    """Chroma-from-luma reference planes from the luma band stage's chosen candidates
+    (od_resample_luma_coeffs, non-TF branch): luma_jobs[j] at level bs >= 1 -> refs[j]
+    int32 [copies*nplanes, h/2, w/2] for the chroma level bs - 1."""
+    import torch
+    if refs is None:
+        refs = []
+        for j in luma_jobs:
+            nplanes, h, w = j.coef.shape
+            refs.append(torch.empty((copies * nplanes, h // 2, w // 2), dtype=torch.int32,
+                                    device=j.coef.device))
+    ptrs = (ctypes.c_void_p * len(refs))(*[r.data_ptr() for r in refs])
+    _check(lib().odhip_cfl_refs_from_luma(_jobs_array(luma_jobs), len(luma_jobs), ptrs, int(copies),
+                                          _stream()), "odhip_cfl_refs_from_luma")
+    return refs

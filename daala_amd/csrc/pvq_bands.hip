@@ -824,6 +824,54 @@ __global__ __launch_bounds__(256) void k_synth(Items it) {
   *reinterpret_cast<int4 *>(jb.dq + idx) = make_int4(out[0], out[1], out[2], out[3]);
 }
 
+/* ---- chroma-from-luma predictions ------------------------------------------------
+   od_resample_luma_coeffs (reference src/intra.c:72-109) for 4:2:0 when the luma
+   block is at least 8x8 (:97-108): the prediction of the chroma block is the
+   upper-left quarter of the decoded luma block's coefficients.  Here the decoded
+   luma coefficients are not read from a plane: they are dequantised on the fly
+   from the chosen pulses of the luma band stage (od_pvq_synthesis_partial noref,
+   src/pvq.c:1081-1092, the arithmetic of k_synth), the DC passed through as
+   k_synth passes it.  One output coefficient per thread; the result is written
+   `copies` times (Cb and Cr share the prediction). */
+struct CflOut {
+  od_coeff *ref[kMaxJobs];
+  int copies;
+};
+
+__global__ __launch_bounds__(256) void k_cfl_ref(Items it, CflOut out) {
+  const int item = find_item(it, blockIdx.x);
+  const int job = it.job[item];
+  const DJob &jb = g_jobs[job];
+  const int N = 4 << jb.bs;
+  const int n = N >> 1;
+  const int cw = jb.w >> 1;
+  const int chh = jb.h >> 1;
+  const long t = (long)(blockIdx.x - it.wg_start[item])*256 + threadIdx.x;
+  const long per = (long)cw*chh;
+  if (t >= per*jb.nplanes) return;
+  const int p = (int)(t/per);
+  const int rem = (int)(t - p*per);
+  const int y = rem/cw;
+  const int x = rem - y*cw;
+  const int by = y/n;
+  const int v = y - by*n;
+  const int bx = x/n;
+  const int u = x - bx*n;
+  const long blk = ((long)p*jb.bh + by)*jb.bw + bx;
+  const int c = gInvScan[v*32 + u];
+  int val = 0;
+  if (c == 0) val = jb.coef[(long)p*jb.w*jb.h + (long)by*N*jb.w + bx*N];
+  else if (c > 0 && c < jb.len) {
+    const int4 ch = reinterpret_cast<const int4 *>(jb.choice)[blk*jb.nb_bands + gBandOf[c]];
+    if (ch.y != 0) {
+      const int yv = jb.y[((long)ch.x*jb.nblocks + blk)*jb.len + c];
+      val = odq_shr_round(odq_mult16_32_q16(yv, ch.z)*jb.qm_inv[c], ch.w);
+    }
+  }
+  od_coeff *dst = out.ref[job] + t;
+  for (int k = 0; k < out.copies; k++) dst[k*per*jb.nplanes] = val;
+}
+
 /* ---- host side ----------------------------------------------------------------- */
 bool g_tables_uploaded = false;
 
@@ -1187,6 +1235,31 @@ extern "C" int odhip_pvq_choose_multi(const odhip_pvq_job *jobs, int njobs,
     items_add(it, j, 0, (host[j].nblocks*host[j].nb_bands + 255)/256);
   }
   k_choose<<<it.wg_start[it.nitems], 256, 0, s>>>(it);
+  return odhip_check_launch();
+}
+
+extern "C" int odhip_cfl_refs_from_luma(const odhip_pvq_job *luma_jobs, int njobs,
+ od_coeff *const *d_ref, int copies, odhip_stream stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (!d_ref || copies < 1 || copies > 4) return ODHIP_EINVAL;
+  DJob host[kMaxJobs];
+  int rc = fill_jobs(luma_jobs, njobs, 2, host);
+  if (rc) return rc;
+  CflOut out;
+  memset(&out, 0, sizeof(out));
+  out.copies = copies;
+  Items it;
+  items_begin(it, 0.);
+  for (int j = 0; j < njobs; j++) {
+    if (!d_ref[j] || !luma_jobs[j].d_qm_inv || host[j].bs < 1 || (host[j].w & 1) || (host[j].h & 1)) {
+      return ODHIP_EINVAL;
+    }
+    out.ref[j] = d_ref[j];
+    items_add(it, j, 0, ((long)host[j].nplanes*(host[j].w >> 1)*(host[j].h >> 1) + 255)/256);
+  }
+  rc = upload_jobs(host, njobs, s);
+  if (rc) return rc;
+  k_cfl_ref<<<it.wg_start[it.nitems], 256, 0, s>>>(it, out);
   return odhip_check_launch();
 }
 

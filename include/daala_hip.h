@@ -281,6 +281,20 @@ int odhip_pvq_choose_multi(const odhip_pvq_job *jobs, int njobs,
 int odhip_inverse_level_pvq(uint8_t *d_px, int px_stride, long px_plane_stride,
  const odhip_pvq_job *job, int dec, int pic_w, int pic_h, odhip_stream stream);
 
+/* Chroma-from-luma predictions of a 4:2:0 keyframe: od_resample_luma_coeffs
+   (src/intra.c:72-109) for luma blocks of 8x8 and larger (:97-108: the upper-left
+   quarter of the decoded luma block's coefficients), fed directly by the luma band
+   stage - the decoded coefficients are dequantised on the fly from the chosen
+   pulses (cands.y, cands.choice after odhip_pvq_choose_multi) exactly as
+   odhip_pvq_select_synth_noref would write them; no dequantised luma plane is
+   needed.  luma_jobs[j] (level bs >= 1, blocks of N = 4 << bs; needs d_qm_inv)
+   yields the reference planes of the chroma level bs - 1 (blocks of N/2) in
+   d_ref[j]: `copies` consecutive plane sets of [nplanes][h/2][w/2] (Cb and Cr
+   share the prediction: copies = 2), ready to be odhip_pvq_refjob.d_ref.  The 4x4
+   luma case (:77-96, a TF upsampling) is not implemented. */
+int odhip_cfl_refs_from_luma(const odhip_pvq_job *luma_jobs, int njobs, od_coeff *const *d_ref,
+ int copies, odhip_stream stream);
+
 /* Profiling aid (bench.py): while enabled, odhip_pvq_noref_bands_multi brackets
    its dominant kernel - the search of the 128-coefficient bands,
    k_search<128,2,1> - with HIP events on the stream the kernel is launched on

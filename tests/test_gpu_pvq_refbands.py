@@ -268,3 +268,41 @@ def test_pulse_counts_beyond_the_int16_vectors_are_reported_not_searched(hip):
                 elif fl & hip.REFITEM_SEARCHED:
                     assert int(it["k"]) <= 32767
     assert big > 0
+
+
+def test_cfl_refs_from_luma_equal_the_quarter_of_the_dequantised_luma_planes(hip):
+    """odhip_cfl_refs_from_luma (od_resample_luma_coeffs for luma blocks >= 8x8, fed
+    by the chosen luma candidates) against the construction from the dequantised
+    luma planes that odhip_pvq_select_synth_noref_multi writes (themselves checked
+    against the oracle in test_gpu_pvq_bands.py): the upper-left quarter of every
+    luma block, for Cb and Cr."""
+    import torch
+    from _libs import synth_frame
+    lam = hip.OD_PVQ_LAMBDA
+    W, H = 192, 128
+    rng = np.random.RandomState(31)
+    px = np.stack([np.clip(synth_frame(W, H, seed=3 + i)[0].astype(int)
+                           + rng.randint(-40, 41, size=(H, W)), 0, 255).astype(np.uint8) for i in range(2)])
+    qt = hip.QuantTables.load()
+    levels = hip.forward_pyramid(_cuda(px), 0, W, H)
+    jobs = []
+    for bs in range(5):
+        qm, qmi = qt.qm_slices(0, bs)
+        jobs.append(hip.PvqJob(levels[bs], bs, _cuda(qm), _cuda(qmi), qt.q_band(0, bs),
+                               qt.beta_band(0, bs), dq=torch.zeros_like(levels[bs])))
+    hip.pvq_noref_bands_multi(jobs, lam)
+    hip.pvq_choose_multi(jobs, lam)
+    refs = hip.cfl_refs_from_luma(jobs[1:], copies=2)
+    hip.pvq_select_synth_noref_multi(jobs, lam)
+    torch.cuda.synchronize()
+    nonzero = 0
+    for bs in range(4):
+        n = 4 << bs
+        dq = jobs[bs + 1].dq
+        corner = dq.view(2, H // (2 * n), 2 * n, W // (2 * n), 2 * n)[:, :, :n, :, :n]
+        want = corner.reshape(2, H // 2, W // 2)
+        want = torch.cat([want, want], dim=0)
+        assert refs[bs].shape == want.shape
+        assert torch.equal(refs[bs], want), "chroma level %d" % bs
+        nonzero += int((want != 0).sum())
+    assert nonzero > 5000
