@@ -34,11 +34,13 @@ metric counts those blocks.  Entropy coding / rate pricing stay on the host in
 the reference's own C (SURVEY.md hard part 1) and are not part of the step; the
 choice between PVQ candidates is therefore made on distortion alone.
 
-The chroma-from-luma reference planes are built once, before timing, from this
-pipeline's own luma reconstruction (upper-left quarter of the co-located luma
-block's dequantised coefficients: od_resample_luma_coeffs, src/intra.c:97-108)
-and are resident in HBM like the pictures.  --chroma-noref runs chroma through
-the no-reference path instead (the workload of the first round-1 bench lines).
+The chroma-from-luma reference planes of a step are produced inside the step from
+that step's luma band stage (odhip_cfl_refs_from_luma = od_resample_luma_coeffs,
+src/intra.c:97-108, on the chosen luma candidates); the chroma chain waits for them
+on its own stream while the luma chain of the NEXT step already runs (two reference
+buffers; software pipelining over steps, as a frame-parallel encoder would run).
+--chroma-noref runs chroma through the no-reference path instead (the workload of the
+first round-1 bench lines).
 
 N > 1: frames are sharded over ranks (independent all-intra frames, no
 data-path collective) -> weak scaling, F frames per GPU.
@@ -141,34 +143,33 @@ class Pipeline:
             self._setup_chroma_cfl(device)
 
     def _setup_chroma_cfl(self, device):
-        """--chroma-cfl: keyframe chroma goes through pvq_theta's WITH-reference
-        path, as in the reference encoder (chroma-from-luma, src/encode.c:1683).
-        The reference planes are built once, before timing, from the luma
-        reconstruction of this pipeline: the low-frequency n x n corner of the
-        co-located 2n x 2n luma block's dequantised coefficients (the shape of
-        od_resample_luma_coeffs' output when the luma block is not split
-        further), and stay resident in HBM like the pictures."""
+        """Keyframe chroma goes through pvq_theta's WITH-reference path, as in the
+        reference encoder (chroma-from-luma, src/encode.c:1680-1687).  The reference
+        planes of a step come from THAT step's luma band stage
+        (odhip_cfl_refs_from_luma = od_resample_luma_coeffs on the chosen luma
+        candidates), in two alternating buffers so that the luma chain of step i+1
+        can run while the chroma chain of step i still reads its references."""
         D, torch = self.D, self.torch
         luma, chroma = self.sets
-        D.pvq_noref_bands_multi(luma["jobs"], self.lam)
-        for job in luma["jobs"]:
-            job.dq = torch.zeros_like(job.coef)
-        D.pvq_select_synth_noref_multi(luma["jobs"], self.lam)
-        torch.cuda.synchronize()
-        for bs in range(4):
-            n = 4 << bs
-            dq = luma["jobs"][bs + 1].dq                       # [F, H, W], blocks of 2n
-            F, h, w = dq.shape
-            corner = dq.view(F, h // (2 * n), 2 * n, w // (2 * n), 2 * n)[:, :, :n, :, :n]
-            ref = corner.reshape(F, h // 2, w // 2).contiguous()
-            ref = torch.cat([ref, ref], dim=0).contiguous()     # Cb planes, then Cr planes
-            cj = chroma["jobs"][bs]
-            self.refjobs.append(D.PvqRefJob(cj.coef, ref, bs, cj.qm, cj.qm_inv,
-                                            self.qt.q_band(1, bs), self.qt.beta_band(1, bs), 1, 1))
-        for job in luma["jobs"]:
-            job.dq = None
         self.noref_jobs = luma["jobs"]
         self.side = torch.cuda.Stream(device=device)
+        D.pvq_noref_bands_multi(luma["jobs"], self.lam)
+        D.pvq_choose_multi(luma["jobs"], self.lam)
+        self.refs = [D.cfl_refs_from_luma(luma["jobs"][1:], copies=2) for _ in range(2)]
+        self.refjobs = [[], []]
+        for bs in range(4):
+            cj = chroma["jobs"][bs]
+            first = D.PvqRefJob(cj.coef, self.refs[0][bs], bs, cj.qm, cj.qm_inv,
+                                self.qt.q_band(1, bs), self.qt.beta_band(1, bs), 1, 1)
+            self.refjobs[0].append(first)
+            self.refjobs[1].append(D.PvqRefJob(cj.coef, self.refs[1][bs], bs, cj.qm, cj.qm_inv,
+                                               self.qt.q_band(1, bs), self.qt.beta_band(1, bs), 1, 1,
+                                               share=first))
+        self.ev_refs = [torch.cuda.Event() for _ in range(2)]     # references of parity p written
+        self.ev_used = [torch.cuda.Event() for _ in range(2)]     # ... and no longer read
+        self.nstep = 0
+        self.pending = None
+        torch.cuda.synchronize()
 
     def _timed(self, key, fn, record):
         if not record:
@@ -203,13 +204,41 @@ class Pipeline:
                         lambda: D.inverse_levels_pvq(s["jobs"], s["dec"], PIC_W, PIC_H,
                                                      outs=s["recon"]), record)
 
+    def _chroma_tail(self, jobs, record):
+        D = self.D
+        chroma = self.sets[1]
+        self._timed("pvq_ref_select_synth", lambda: D.pvq_ref_select_synth_multi(jobs, self.lam), record)
+        self._timed("inverse_chroma",
+                    lambda: D.inverse_levels([rj.dq for rj in jobs], 1, [0, 1, 2, 3], PIC_W, PIC_H,
+                                             outs=chroma["recon"]), record)
+
+    def _finish_pending(self, record):
+        """The count of bands inside the device-acos margin of the previous step's
+        with-reference stage: checked one step late, so the host never waits inside a
+        step; a listed band whose theta the host corrects (never seen outside the
+        forced tests) repeats what consumed it."""
+        if self.pending is None:
+            return
+        jobs, self.pending = self.pending, None
+        with self.torch.cuda.stream(self.side):
+            if self.D.pvq_ref_resolve_finish(jobs, self.lam) > 0:
+                self._chroma_tail(jobs, record)
+
+    def flush(self):
+        if self.chroma_cfl:
+            self._finish_pending(False)
+
     def _step_cfl(self, record):
-        """Luma (no-reference path) on the current stream, chroma (with-reference
-        path, reference planes resident) on a side stream; joined at the end."""
+        """Software-pipelined over steps: luma (no-reference path) on the current stream,
+        chroma (with-reference path) on a side stream.  The chroma chain of a step waits
+        for that step's chroma-from-luma references (written by the luma chain after its
+        choice); the luma chain of the NEXT step overlaps with it."""
         D, torch = self.D, self.torch
         luma, chroma = self.sets
         main = torch.cuda.current_stream()
-        self.side.wait_stream(main)
+        par = self.nstep & 1
+        self.nstep += 1
+        jobs = self.refjobs[par]
         self._timed("image_copy_pad_luma",
                     lambda: D.image_planes_copy_pad(luma["pic"], W, H, out=luma["px"]), record)
         self._timed("forward_pyramid_luma",
@@ -218,9 +247,15 @@ class Pipeline:
         self._timed("pvq_noref_bands", lambda: D.pvq_noref_bands_multi(self.noref_jobs, self.lam),
                     record)
         self._timed("pvq_choose", lambda: D.pvq_choose_multi(self.noref_jobs, self.lam), record)
+        main.wait_event(self.ev_used[par])      # step i-2 no longer reads this reference buffer
+        self._timed("cfl_refs_from_luma",
+                    lambda: D.cfl_refs_from_luma(self.noref_jobs[1:], refs=self.refs[par], copies=2),
+                    record)
+        self.ev_refs[par].record(main)
         self._timed("dequant_inverse_luma",
                     lambda: D.inverse_levels_pvq(luma["jobs"], 0, PIC_W, PIC_H, outs=luma["recon"]),
                     record)
+        self._finish_pending(record)
         with torch.cuda.stream(self.side):
             self._timed("image_copy_pad_chroma",
                         lambda: D.image_planes_copy_pad(chroma["pic"], W // 2, H // 2,
@@ -228,22 +263,12 @@ class Pipeline:
             self._timed("forward_pyramid_chroma",
                         lambda: D.forward_pyramid(chroma["px"], 1, PIC_W, PIC_H,
                                                   levels=chroma["levels"]), record)
-            # the count of bands inside the device-acos margin travels to the host behind
-            # the stage; choice, synthesis and inverse are enqueued without waiting for it
+            self.side.wait_event(self.ev_refs[par])
             self._timed("pvq_ref_bands",
-                        lambda: D.pvq_ref_bands_multi(self.refjobs, self.lam, resolve="async"), record)
-
-            def tail():
-                self._timed("pvq_ref_select_synth",
-                            lambda: D.pvq_ref_select_synth_multi(self.refjobs, self.lam), record)
-                self._timed("inverse_chroma",
-                            lambda: D.inverse_levels([rj.dq for rj in self.refjobs], 1, [0, 1, 2, 3],
-                                                     PIC_W, PIC_H, outs=chroma["recon"]), record)
-            tail()
-            if D.pvq_ref_resolve_finish(self.refjobs, self.lam) > 0:
-                tail()      # a listed band got the host's theta: redo what consumed it
-
-        main.wait_stream(self.side)
+                        lambda: D.pvq_ref_bands_multi(jobs, self.lam, resolve="async"), record)
+            self._chroma_tail(jobs, record)
+            self.ev_used[par].record(self.side)
+        self.pending = jobs
 
     def pyramid_alone_ms(self, n=10):
         """Average duration of the luma forward pyramid launched on an otherwise idle GPU."""
@@ -266,7 +291,7 @@ class Pipeline:
         t = self.torch
         total = 0
         bands = 0
-        for job in self.refjobs:
+        for job in self.refjobs[0]:
             for b in range(job.nb):
                 if job.offsets[b + 1] - job.offsets[b] != 128:
                     continue
@@ -390,13 +415,15 @@ def cpu_baseline(qt, chroma_cfl, min_seconds=12.0, max_frames=32):
                                                 qm_off, qb, bb, lam, P(recon), None, arr)
             busy += time.perf_counter() - t0
             if chroma_cfl and pli == 0:
-                # chroma-from-luma predictions (a strided copy in the reference,
-                # od_resample_luma_coeffs; not timed on either side)
+                # chroma-from-luma predictions: od_resample_luma_coeffs for luma blocks one
+                # size up (src/intra.c:97-108, a strided copy), timed like the GPU's kernel
+                t0 = time.perf_counter()
                 refs = []
                 for bs in range(4):
                     n = 4 << bs
                     c = ldq[bs + 1].reshape(H // (2 * n), 2 * n, W // (2 * n), 2 * n)[:, :n, :, :n]
                     refs.append(np.ascontiguousarray(c.reshape(H // 2, W // 2)))
+                busy += time.perf_counter() - t0
         nframes += 1
     what = ("padding + forward pyramid + pvq_theta (luma: no-reference bands; chroma: WITH the "
             "chroma-from-luma reference) + inverse" if chroma_cfl else
@@ -440,6 +467,7 @@ def main():
     pipe = Pipeline(D, args.frames, device, chroma_cfl=cfl)
     for _ in range(args.warmup):
         pipe.step()
+    pipe.flush()
 
     def barrier():
         if dist is not None:
@@ -453,6 +481,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         pipe.step(record=True)
+    pipe.flush()
     torch.cuda.synchronize()
     barrier()
     dt = time.perf_counter() - t0

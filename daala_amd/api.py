@@ -515,7 +515,10 @@ class PvqRefJob:
     """One (plane set, reference plane set, block size) unit of the with-reference
     band stage (odhip_pvq_refjob); owns its output and work buffers."""
 
-    def __init__(self, coef, ref, bs, qm, qm_inv, q_band, beta_band, is_keyframe, pli, rate=None):
+    def __init__(self, coef, ref, bs, qm, qm_inv, q_band, beta_band, is_keyframe, pli, rate=None,
+                 share=None):
+        """share: another PvqRefJob of the same shape whose output and work buffers this
+        one uses too (same planes, another reference buffer: double-buffered references)."""
         import torch
         _need(coef, torch.int32, "coef")
         _need(ref, torch.int32, "ref")
@@ -530,6 +533,11 @@ class PvqRefJob:
         self.q_band = (ctypes.c_int32 * 12)(*[int(v) for v in q_band])
         self.beta_band = (ctypes.c_int32 * 12)(*[int(v) for v in beta_band])
         dev = coef.device
+        if share is not None:
+            assert share.coef.shape == coef.shape and share.bs == self.bs
+            for f in ("band", "items", "y", "r16", "x16", "xr", "choice", "dq"):
+                setattr(self, f, getattr(share, f))
+            return
         self.band = torch.zeros((B, self.nb, 64), dtype=torch.uint8, device=dev)
         self.items = torch.zeros((3, self.nb, REF_SLOTS, B, 16), dtype=torch.uint8, device=dev)
         self.y = torch.zeros((REF_SLOTS, B, self.len), dtype=torch.int16, device=dev)
