@@ -704,3 +704,9 @@ def cfl_refs_from_luma(luma_jobs, refs=None, copies=2):
     _check(lib().odhip_cfl_refs_from_luma(_jobs_array(luma_jobs), len(luma_jobs), ptrs, int(copies),
                                           _stream()), "odhip_cfl_refs_from_luma")
     return refs
+
+
+def pvq_ref_set_context(ctx):
+    """Selects which of the two library contexts the following pvq_ref_* calls of this
+    thread use (one call sequence may be in flight per context)."""
+    _check(lib().odhip_pvq_ref_set_context(int(ctx)), "odhip_pvq_ref_set_context")

@@ -50,7 +50,14 @@
 
 namespace {
 
-constexpr int kMaxJobs = 16;
+/* Two CONTEXTS: independent calls (e.g. the Cb and the Cr planes of a batch on two
+   streams) may be in flight at once, one per context.  A context owns half of the
+   device job table (kJobsPerCtx slots; it.job[] holds the absolute slot, so the
+   kernels and the per-(job, band) sort arrays need no context argument), its
+   uncertainty list, its scratch, its side streams and its pinned counter. */
+constexpr int kCtx = 2;
+constexpr int kJobsPerCtx = 8;
+constexpr int kMaxJobs = kCtx*kJobsPerCtx;
 constexpr int kMaxItems = kMaxJobs*ODHIP_MAX_BANDS;
 constexpr int kSlots = ODHIP_PVQ_REF_SLOTS;
 constexpr int kUncCap = 1 << 16;
@@ -111,8 +118,8 @@ struct Unc {
 
 __device__ RJob g_rjobs[kMaxJobs];
 __constant__ unsigned char kRScanXY[OD_SCAN_LEN][2];
-__device__ unsigned g_unc_count;
-__device__ Unc g_unc[kUncCap];
+__device__ unsigned g_unc_count[kCtx];
+__device__ Unc g_unc[kCtx][kUncCap];
 
 __device__ __forceinline__ int find_item(const RItems &it, int wg) {
   int lo = 0;
@@ -227,7 +234,8 @@ __device__ __forceinline__ void prep_write(const RItems &it, odhip_pvq_refband *
     if (fabs(u - rint(u)) < it.margin) {
       flags |= ODHIP_REFBAND_UNCERTAIN;
       if (it.perturb & 1) theta += 1;
-      const unsigned slot = atomicAdd(&g_unc_count, 1u);
+      const int ctx = job/kJobsPerCtx;
+      const unsigned slot = atomicAdd(&g_unc_count[ctx], 1u);
       if (slot < (unsigned)kUncCap) {
         Unc e;
         e.job = job;
@@ -235,7 +243,7 @@ __device__ __forceinline__ void prep_write(const RItems &it, odhip_pvq_refband *
         e.blk = (unsigned)blk;
         e.theta = theta;
         e.corr = p.corr;
-        g_unc[slot] = e;
+        g_unc[ctx][slot] = e;
       }
     }
   }
@@ -1417,6 +1425,8 @@ int fill_job(RJob &d, const odhip_pvq_refjob &j, int mode) {
   return ODHIP_SUCCESS;
 }
 
+thread_local int t_ctx = 0;     /* context of the calling thread's next calls */
+
 /* Library scratch of the sorted searches (keys, sorted block indices), grown on
    demand and kept for the life of the process.  One band-stage call may be in
    flight per process. */
@@ -1424,10 +1434,11 @@ struct RScratch {
   unsigned short *keys;
   unsigned *ids;
   size_t cap;    /* (band, block) pairs */
-} g_rscr = {nullptr, nullptr, 0};
+} g_rscr_all[kCtx] = {{nullptr, nullptr, 0}, {nullptr, nullptr, 0}};
+#define g_rscr g_rscr_all[t_ctx]
 
 int stage_jobs(const odhip_pvq_refjob *jobs, int njobs, int mode, RJob *host, hipStream_t s) {
-  if (!jobs || njobs <= 0 || njobs > kMaxJobs) return ODHIP_EINVAL;
+  if (!jobs || njobs <= 0 || njobs > kJobsPerCtx) return ODHIP_EINVAL;
   int rc = upload_tables();
   if (rc) return rc;
   size_t pairs = 0;
@@ -1455,8 +1466,8 @@ int stage_jobs(const odhip_pvq_refjob *jobs, int njobs, int mode, RJob *host, hi
       pairs += (size_t)host[i].nblocks*host[i].nb_bands;
     }
   }
-  ODHIP_TRY(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_rjobs), host, sizeof(RJob)*njobs, 0,
-   hipMemcpyHostToDevice, s));
+  ODHIP_TRY(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_rjobs), host, sizeof(RJob)*njobs,
+   sizeof(RJob)*kJobsPerCtx*t_ctx, hipMemcpyHostToDevice, s));
   return ODHIP_SUCCESS;
 }
 
@@ -1469,7 +1480,7 @@ void items_begin(RItems &it, double lambda) {
 
 void items_add(RItems &it, int job, int band, long wgs) {
   if (wgs <= 0) return;
-  it.job[it.nitems] = (unsigned char)job;
+  it.job[it.nitems] = (unsigned char)(kJobsPerCtx*t_ctx + job);
   it.band[it.nitems] = (unsigned char)band;
   it.wg_start[it.nitems + 1] = it.wg_start[it.nitems] + (int)wgs;
   it.nitems++;
@@ -1488,9 +1499,12 @@ void items_all(RItems &it, const RJob *host, int njobs, double lambda, int n_onl
 
 /* Side streams for the searches of the four band sizes (independent launches;
    the no-reference stage measured the same fork at 1.40 -> 1.19 ms). */
-hipStream_t g_rside[2] = {nullptr, nullptr};
-hipEvent_t g_rfork = nullptr;
-hipEvent_t g_rjoin[2] = {nullptr, nullptr};
+hipStream_t g_rside_all[kCtx][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+hipEvent_t g_rfork_all[kCtx] = {nullptr, nullptr};
+hipEvent_t g_rjoin_all[kCtx][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+#define g_rside g_rside_all[t_ctx]
+#define g_rfork g_rfork_all[t_ctx]
+#define g_rjoin g_rjoin_all[t_ctx]
 
 int rfork(hipStream_t s, hipStream_t side[2]) {
   if (getenv("ODHIP_PVQ_SERIAL")) return ODHIP_SUCCESS;
@@ -1573,13 +1587,14 @@ extern "C" int odhip_pvq_ref_bands_multi(const odhip_pvq_refjob *jobs, int njobs
   if (rc) return rc;
   void *cnt = nullptr;
   ODHIP_TRY(hipGetSymbolAddress(&cnt, HIP_SYMBOL(g_unc_count)));
-  ODHIP_TRY(hipMemsetAsync(cnt, 0, sizeof(unsigned), s));
+  ODHIP_TRY(hipMemsetAsync((unsigned *)cnt + t_ctx, 0, sizeof(unsigned), s));
   {
-    /* consumed and cleared by k_refb_prefix; cleared here as well so that a call
-       that failed half way cannot poison the next sort */
+    /* consumed and cleared by k_refb_prefix; cleared here as well (this context's
+       slice) so that a call that failed half way cannot poison the next sort */
     void *hist = nullptr;
     ODHIP_TRY(hipGetSymbolAddress(&hist, HIP_SYMBOL(g_rhist)));
-    ODHIP_TRY(hipMemsetAsync(hist, 0, sizeof(unsigned)*kMaxItems*kSortBins, s));
+    const size_t slice = (size_t)kJobsPerCtx*ODHIP_MAX_BANDS*kSortBins;
+    ODHIP_TRY(hipMemsetAsync((unsigned *)hist + slice*t_ctx, 0, sizeof(unsigned)*slice, s));
   }
   RItems it;
   items_all(it, host, njobs, pvq_norm_lambda, 0);
@@ -1652,7 +1667,7 @@ extern "C" int odhip_pvq_ref_bands_multi(const odhip_pvq_refjob *jobs, int njobs
       }
       if (!it.nitems) continue;
       if (sizes[i] == 128) {
-        const bool prof = g_prof_on && g_prof_n < kProfSlots;
+        const bool prof = g_prof_on && t_ctx == 0 && g_prof_n < kProfSlots;
         if (prof) (void)hipEventRecord(g_prof_ev[g_prof_n][0], s);
         k_refb_search_row<8, 16><<<it.wg_start[it.nitems], kWave, 0, s>>>(it);
         if (prof) (void)hipEventRecord(g_prof_ev[g_prof_n++][1], s);
@@ -1676,9 +1691,19 @@ extern "C" int odhip_pvq_ref_bands_multi(const odhip_pvq_refjob *jobs, int njobs
 }
 
 namespace {
-unsigned *g_unc_host = nullptr;     /* pinned mirror of g_unc_count */
-hipEvent_t g_unc_event = nullptr;
+unsigned *g_unc_host_all[kCtx] = {nullptr, nullptr};     /* pinned mirrors of g_unc_count */
+hipEvent_t g_unc_event_all[kCtx] = {nullptr, nullptr};
+#define g_unc_host g_unc_host_all[t_ctx]
+#define g_unc_event g_unc_event_all[t_ctx]
 }  // namespace
+
+/* Selects the context (0 or 1) of the calling thread's subsequent
+   odhip_pvq_ref_* calls. */
+extern "C" int odhip_pvq_ref_set_context(int ctx) {
+  if (ctx < 0 || ctx >= kCtx) return ODHIP_EINVAL;
+  t_ctx = ctx;
+  return ODHIP_SUCCESS;
+}
 
 /* The count of listed bands travels to pinned host memory behind the band stage;
    nothing waits for it here. */
@@ -1689,8 +1714,8 @@ extern "C" int odhip_pvq_ref_resolve_begin(odhip_stream stream) {
     ODHIP_TRY(hipEventCreateWithFlags(&g_unc_event, hipEventDisableTiming));
   }
   *g_unc_host = 0xffffffffu;
-  ODHIP_TRY(hipMemcpyFromSymbolAsync(g_unc_host, HIP_SYMBOL(g_unc_count), sizeof(unsigned), 0,
-   hipMemcpyDeviceToHost, s));
+  ODHIP_TRY(hipMemcpyFromSymbolAsync(g_unc_host, HIP_SYMBOL(g_unc_count), sizeof(unsigned),
+   sizeof(unsigned)*t_ctx, hipMemcpyDeviceToHost, s));
   ODHIP_TRY(hipEventRecord(g_unc_event, s));
   return ODHIP_SUCCESS;
 }
@@ -1711,7 +1736,7 @@ extern "C" int odhip_pvq_ref_resolve(const odhip_pvq_refjob *jobs, int njobs,
   hipStream_t s = (hipStream_t)stream;
   ODHIP_TRY(hipStreamSynchronize(s));
   unsigned count = 0;
-  ODHIP_TRY(hipMemcpyFromSymbol(&count, HIP_SYMBOL(g_unc_count), sizeof(count)));
+  ODHIP_TRY(hipMemcpyFromSymbol(&count, HIP_SYMBOL(g_unc_count), sizeof(count), sizeof(count)*t_ctx));
   if (count == 0) return 0;
   if (count > (unsigned)kUncCap) {
     fprintf(stderr, "libdaalahip: %u bands inside the theta margin exceed the list (%d)\n", count,
@@ -1720,7 +1745,8 @@ extern "C" int odhip_pvq_ref_resolve(const odhip_pvq_refjob *jobs, int njobs,
   }
   Unc *list = (Unc *)malloc(sizeof(Unc)*count);
   if (!list) return ODHIP_EFAULT;
-  if (hipMemcpyFromSymbol(list, HIP_SYMBOL(g_unc), sizeof(Unc)*count) != hipSuccess) {
+  if (hipMemcpyFromSymbol(list, HIP_SYMBOL(g_unc), sizeof(Unc)*count,
+   sizeof(Unc)*(size_t)kUncCap*t_ctx) != hipSuccess) {
     free(list);
     return ODHIP_EFAULT;
   }
@@ -1745,7 +1771,7 @@ extern "C" int odhip_pvq_ref_resolve(const odhip_pvq_refjob *jobs, int njobs,
     return rc;
   }
   for (unsigned i = 0; i < nfix; i++) {
-    if (list[i].job >= njobs) {
+    if (list[i].job < kJobsPerCtx*t_ctx || list[i].job >= kJobsPerCtx*t_ctx + njobs) {
       free(list);
       return ODHIP_EINVAL;
     }

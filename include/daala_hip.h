@@ -508,7 +508,13 @@ typedef struct {
                                 d_coef; DC passed through; uncoded positions 0 */
 } odhip_pvq_refjob;
 
-/* At most 16 jobs per call, all on one stream; one call in flight per process. */
+/* At most 8 jobs per call, all on one stream.  The stage keeps per-call state in
+   the library (job table, scratch, uncertainty list): ONE call sequence (bands ->
+   resolve -> select_synth) may be in flight per CONTEXT.  There are two contexts;
+   odhip_pvq_ref_set_context(0 | 1) selects the one the calling thread's next
+   odhip_pvq_ref_* calls use (default 0), so that e.g. the Cb and the Cr planes of
+   a batch can run on two streams at once. */
+int odhip_pvq_ref_set_context(int ctx);
 int odhip_pvq_ref_bands_multi(const odhip_pvq_refjob *jobs, int njobs,
  double pvq_norm_lambda, odhip_stream stream);
 /* Settles the bands odhip_pvq_ref_bands_multi flagged ODHIP_REFBAND_UNCERTAIN:
@@ -534,7 +540,7 @@ int odhip_pvq_ref_select_synth_multi(const odhip_pvq_refjob *jobs, int njobs,
 /* Profiling aid (bench.py), as odhip_pvq_profile: while enabled,
    odhip_pvq_ref_bands_multi brackets the dominant kernel of this stage - the
    row-parallel search of the 128-coefficient bands, k_refb_search_row<8> - with
-   HIP events on the stream the kernel is launched on. */
+   HIP events on the stream the kernel is launched on (calls of context 0 only). */
 int odhip_pvq_ref_profile(int enable);
 int odhip_pvq_ref_profile_read(float *ms, int max_n);
 /* Test hooks: the uncertainty margin (default 1e-9; <= 0 restores it) and, when

@@ -306,3 +306,51 @@ def test_cfl_refs_from_luma_equal_the_quarter_of_the_dequantised_luma_planes(hip
         assert torch.equal(refs[bs], want), "chroma level %d" % bs
         nonzero += int((want != 0).sum())
     assert nonzero > 5000
+
+
+def test_two_contexts_in_flight_give_the_sequential_results(hip):
+    """Two call sequences (bands -> resolve -> select_synth) on two streams, one per
+    library context, interleaved from one host thread: records, candidates, pulses,
+    choices and dequantised planes equal those of the same jobs run one after the
+    other in context 0."""
+    import torch
+    lam = hip.OD_PVQ_LAMBDA
+    rng = np.random.RandomState(55)
+
+    def make(seed):
+        r = np.random.RandomState(seed)
+        return [_job(hip, r, bs, 1, 1, h=64, w=128)[0] for bs in (0, 1, 2, 3)]
+
+    seq = [make(1), make(2)]
+    for jobs in seq:
+        hip.pvq_ref_bands_multi(jobs, lam)
+        hip.pvq_ref_select_synth_multi(jobs, lam)
+    torch.cuda.synchronize()
+    par = [make(1), make(2)]
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    try:
+        for c in (0, 1):
+            hip.pvq_ref_set_context(c)
+            with torch.cuda.stream(streams[c]):
+                hip.pvq_ref_bands_multi(par[c], lam, resolve="async")
+        for c in (1, 0):
+            hip.pvq_ref_set_context(c)
+            with torch.cuda.stream(streams[c]):
+                hip.pvq_ref_select_synth_multi(par[c], lam)
+                assert hip.pvq_ref_resolve_finish(par[c], lam) == 0
+    finally:
+        hip.pvq_ref_set_context(0)
+    torch.cuda.synchronize()
+    for a, b in zip(seq[0] + seq[1], par[0] + par[1]):
+        assert torch.equal(a.band, b.band)
+        assert torch.equal(a.choice, b.choice)
+        assert torch.equal(a.dq, b.dq)
+        ua, ub = a.unpack(), b.unpack()
+        nit = ua["rec"]["nitems"]
+        for s in range(14):
+            valid = s < nit
+            for f in ("gain", "theta", "ts", "k"):
+                assert (ua["items"][f][:, :, s][valid] == ub["items"][f][:, :, s][valid]).all()
+            done = valid & ((ua["items"]["flags"][:, :, s] & 1) != 0)
+            for f in ("flags", "yslot", "cos_dist", "dist"):
+                assert (ua["items"][f][:, :, s][done] == ub["items"][f][:, :, s][done]).all()
