@@ -479,8 +479,11 @@ def main():
     D.pvq_ref_profile(True)
     barrier()
     t0 = time.perf_counter()
+    host_s = 0.0
     for _ in range(args.steps):
+        h0 = time.perf_counter()
         pipe.step(record=True)
+        host_s += time.perf_counter() - h0
     pipe.flush()
     torch.cuda.synchronize()
     barrier()
@@ -624,6 +627,9 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
+            # time the host spends enqueuing a step (it runs ahead of the GPU unless this
+            # approaches ms_per_step)
+            "host_enqueue_ms_per_step": host_s / args.steps * 1e3,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
