@@ -872,6 +872,74 @@ __global__ __launch_bounds__(256) void k_cfl_ref(Items it, CflOut out) {
   for (int k = 0; k < out.copies; k++) dst[k*per*jb.nplanes] = val;
 }
 
+/* Decoded coefficient (v, u), v, u < 2, of the 4x4 luma block blk of a level-0
+   job: the DC passed through, the others dequantised from the chosen pulses. */
+__device__ __forceinline__ int cfl_luma4(const DJob &jb, long blk, int p, int by, int bx, int v, int u) {
+  const int c = gInvScan[v*32 + u];
+  if (c == 0) return jb.coef[(long)p*jb.w*jb.h + (long)by*4*jb.w + bx*4];
+  const int4 ch = reinterpret_cast<const int4 *>(jb.choice)[blk*jb.nb_bands];
+  if (ch.y == 0) return 0;
+  const int yv = jb.y[((long)ch.x*jb.nblocks + blk)*jb.len + c];
+  return odq_shr_round(odq_mult16_32_q16(yv, ch.z)*jb.qm_inv[c], ch.w);
+}
+
+/* The 4x4 luma case of od_resample_luma_coeffs (src/intra.c:77-89): the four 4x4
+   luma blocks over a 4x4 chroma block are merged by od_tf_up_hv_lp
+   (src/tf.c:82-108, OD_HAAR_KERNEL src/tf.h:34-45) and scaled by
+   OD_CFL_SCALING4 (src/intra.c:65-70).  One output coefficient per thread: it
+   evaluates the Haar kernel of its 2x2 group and keeps its own output. */
+__device__ const short kCflScaling4[4][4] = {
+  {128, 128, 100, 36}, {128, 80, 71, 35}, {100, 71, 35, 31}, {36, 35, 31, 18}};
+
+__global__ __launch_bounds__(256) void k_cfl_ref_tf(Items it, CflOut out) {
+  const int item = find_item(it, blockIdx.x);
+  const int job = it.job[item];
+  const DJob &jb = g_jobs[job];
+  const int cw = jb.w >> 1;
+  const int chh = jb.h >> 1;
+  const long t = (long)(blockIdx.x - it.wg_start[item])*256 + threadIdx.x;
+  const long per = (long)cw*chh;
+  if (t >= per*jb.nplanes) return;
+  const int p = (int)(t/per);
+  const int rem = (int)(t - p*per);
+  const int y = rem/cw;
+  const int x = rem - y*cw;
+  const int cby = y >> 2;
+  const int i = y & 3;
+  const int cbx = x >> 2;
+  const int j = x & 3;
+  const int gy = i >> 1;          /* the loop indices y, x of od_tf_up_hv_lp */
+  const int gx = j >> 1;
+  int v[4];
+#pragma unroll
+  for (int q = 0; q < 4; q++) {   /* ll, lh (right block), hl (lower block), hh */
+    const int by = 2*cby + (q >> 1);
+    const int bx = 2*cbx + (q & 1);
+    const long blk = ((long)p*jb.bh + by)*jb.bw + bx;
+    v[q] = cfl_luma4(jb, blk, p, by, bx, gy, gx);
+  }
+  int ll = v[0];
+  int lh = v[1];
+  int hl = v[2];
+  int hh = v[3];
+  /* OD_HAAR_KERNEL(ll, hl, lh, hh) */
+  ll += lh;
+  hh -= hl;
+  const int tt = (ll - hh) >> 1;
+  hl = tt - hl;
+  lh = tt - lh;
+  ll -= hl;
+  hh += lh;
+  const int vswap = gy & 1;
+  const int hswap = gx & 1;
+  const int row_first = (i & 1) == vswap;       /* rows 2y + vswap hold ll / lh */
+  const int col_first = (j & 1) == hswap;       /* columns 2x + hswap hold ll / hl */
+  const int val0 = row_first ? (col_first ? ll : lh) : (col_first ? hl : hh);
+  const int val = (kCflScaling4[j][i]*val0 + 64) >> 7;
+  od_coeff *dst = out.ref[job] + t;
+  for (int k = 0; k < out.copies; k++) dst[k*per*jb.nplanes] = val;
+}
+
 /* ---- host side ----------------------------------------------------------------- */
 bool g_tables_uploaded = false;
 
@@ -1251,15 +1319,23 @@ extern "C" int odhip_cfl_refs_from_luma(const odhip_pvq_job *luma_jobs, int njob
   Items it;
   items_begin(it, 0.);
   for (int j = 0; j < njobs; j++) {
-    if (!d_ref[j] || !luma_jobs[j].d_qm_inv || host[j].bs < 1 || (host[j].w & 1) || (host[j].h & 1)) {
-      return ODHIP_EINVAL;
-    }
+    if (!d_ref[j] || !luma_jobs[j].d_qm_inv || (host[j].w & 7) || (host[j].h & 7)) return ODHIP_EINVAL;
     out.ref[j] = d_ref[j];
-    items_add(it, j, 0, ((long)host[j].nplanes*(host[j].w >> 1)*(host[j].h >> 1) + 255)/256);
+    if (host[j].bs >= 1) {
+      items_add(it, j, 0, ((long)host[j].nplanes*(host[j].w >> 1)*(host[j].h >> 1) + 255)/256);
+    }
   }
   rc = upload_jobs(host, njobs, s);
   if (rc) return rc;
-  k_cfl_ref<<<it.wg_start[it.nitems], 256, 0, s>>>(it, out);
+  if (it.nitems) k_cfl_ref<<<it.wg_start[it.nitems], 256, 0, s>>>(it, out);
+  /* level-0 jobs: the TF branch */
+  items_begin(it, 0.);
+  for (int j = 0; j < njobs; j++) {
+    if (host[j].bs == 0) {
+      items_add(it, j, 0, ((long)host[j].nplanes*(host[j].w >> 1)*(host[j].h >> 1) + 255)/256);
+    }
+  }
+  if (it.nitems) k_cfl_ref_tf<<<it.wg_start[it.nitems], 256, 0, s>>>(it, out);
   return odhip_check_launch();
 }
 

@@ -290,8 +290,11 @@ int odhip_inverse_level_pvq(uint8_t *d_px, int px_stride, long px_plane_stride,
    needed.  luma_jobs[j] (level bs >= 1, blocks of N = 4 << bs; needs d_qm_inv)
    yields the reference planes of the chroma level bs - 1 (blocks of N/2) in
    d_ref[j]: `copies` consecutive plane sets of [nplanes][h/2][w/2] (Cb and Cr
-   share the prediction: copies = 2), ready to be odhip_pvq_refjob.d_ref.  The 4x4
-   luma case (:77-96, a TF upsampling) is not implemented. */
+   share the prediction: copies = 2), ready to be odhip_pvq_refjob.d_ref.  A
+   level-0 job (4x4 luma blocks) yields the 4x4 chroma predictions of the 4:2:0
+   TF branch (:77-89: od_tf_up_hv_lp of the four luma blocks over the chroma block,
+   src/tf.c:82-108, then OD_CFL_SCALING4), the alternative prediction of chroma
+   level 0 when the luma partition there is 4x4. */
 int odhip_cfl_refs_from_luma(const odhip_pvq_job *luma_jobs, int njobs, od_coeff *const *d_ref,
  int copies, odhip_stream stream);
 

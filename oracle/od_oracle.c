@@ -503,6 +503,65 @@ void odo_img_plane_copy_pad(uint8_t *dst, int dstride, int plane_w, int plane_h,
   }
 }
 
+/* od_resample_luma_coeffs, src/intra.c:72-109, for 4:2:0 (xdec = ydec = 1): the
+   chroma-from-luma prediction of a chroma block of side n = 4 << bs from the
+   decoded luma coefficients of the co-located 2n x 2n area (decoded_luma, row
+   stride dlstride).  luma_bs == 0 (the luma area is four 4x4 blocks, so the chroma
+   block is 4x4): od_tf_up_hv_lp (src/tf.c:82-108) merges the 2x2 low-frequency
+   corners of the four blocks with the Haar kernel OD_HAAR_KERNEL (src/tf.h:34-45),
+   then OD_CFL_SCALING4 (src/intra.c:65-70).  Otherwise the luma area is one block
+   and the prediction is its upper-left quarter (:97-108). */
+void odo_resample_luma_coeffs(odo_coeff *chroma_pred, int cpstride,
+ const odo_coeff *decoded_luma, int dlstride, int bs, int luma_bs) {
+  static const int16_t scaling4[4][4] = {
+    {128, 128, 100, 36}, {128, 80, 71, 35}, {100, 71, 35, 31}, {36, 35, 31, 18}};
+  int n;
+  int x;
+  int y;
+  n = 4 << bs;
+  if (luma_bs == 0) {
+    for (y = 0; y < n >> 1; y++) {
+      int vswap;
+      vswap = y & 1;
+      for (x = 0; x < n >> 1; x++) {
+        odo_coeff ll;
+        odo_coeff lh;
+        odo_coeff hl;
+        odo_coeff hh;
+        odo_coeff t;
+        int hswap;
+        ll = decoded_luma[y*dlstride + x];
+        lh = decoded_luma[y*dlstride + x + n];
+        hl = decoded_luma[(y + n)*dlstride + x];
+        hh = decoded_luma[(y + n)*dlstride + x + n];
+        /* OD_HAAR_KERNEL(ll, hl, lh, hh): lh and hl swapped, src/tf.c:99-100 */
+        ll += lh;
+        hh -= hl;
+        t = (ll - hh) >> 1;
+        hl = t - hl;
+        lh = t - lh;
+        ll -= hl;
+        hh += lh;
+        hswap = x & 1;
+        chroma_pred[(2*y + vswap)*cpstride + 2*x + hswap] = ll;
+        chroma_pred[(2*y + vswap)*cpstride + 2*x + 1 - hswap] = lh;
+        chroma_pred[(2*y + 1 - vswap)*cpstride + 2*x + hswap] = hl;
+        chroma_pred[(2*y + 1 - vswap)*cpstride + 2*x + 1 - hswap] = hh;
+      }
+    }
+    for (y = 0; y < 4; y++) {
+      for (x = 0; x < 4; x++) {
+        chroma_pred[y*cpstride + x] = (scaling4[x][y]*chroma_pred[y*cpstride + x] + 64) >> 7;
+      }
+    }
+  }
+  else {
+    for (y = 0; y < n; y++) {
+      for (x = 0; x < n; x++) chroma_pred[y*cpstride + x] = decoded_luma[y*dlstride + x];
+    }
+  }
+}
+
 /* ======================================================================== */
 /* PVQ fixed-point helpers (src/pvq.c, src/odintrin.h:164-199)               */
 /* ======================================================================== */

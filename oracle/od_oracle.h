@@ -58,6 +58,8 @@ void odo_inverse_level_plane(uint8_t *px, int px_stride, odo_coeff *c, const odo
 void odo_raster_to_coding_order(odo_coeff *dst, int n, const odo_coeff *src, int stride);
 void odo_coding_order_to_raster(odo_coeff *dst, int stride, const odo_coeff *src, int n);
 int odo_band_offsets(int bs, int *out);
+void odo_resample_luma_coeffs(odo_coeff *chroma_pred, int cpstride,
+ const odo_coeff *decoded_luma, int dlstride, int bs, int luma_bs);
 void odo_img_plane_copy_pad(uint8_t *dst, int dstride, int plane_w, int plane_h,
  const uint8_t *src, int sstride, int pic_w, int pic_h);
 

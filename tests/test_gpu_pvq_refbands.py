@@ -306,6 +306,23 @@ def test_cfl_refs_from_luma_equal_the_quarter_of_the_dequantised_luma_planes(hip
         assert torch.equal(refs[bs], want), "chroma level %d" % bs
         nonzero += int((want != 0).sum())
     assert nonzero > 5000
+    # 4x4 luma blocks: the TF branch (od_tf_up_hv_lp + OD_CFL_SCALING4) against the oracle's
+    # od_resample_luma_coeffs (pinned to the reference) on the dequantised level-0 plane
+    from _libs import P, oracle
+    o = oracle()
+    tf = hip.cfl_refs_from_luma(jobs[:1], copies=2)[0].cpu().numpy()
+    dq0 = jobs[0].dq.cpu().numpy()
+    tfnz = 0
+    for p in range(2):
+        for by in range(H // 8):
+            for bx in range(W // 8):
+                area = np.ascontiguousarray(dq0[p, by * 8:by * 8 + 8, bx * 8:bx * 8 + 8])
+                want4 = np.zeros((4, 4), np.int32)
+                o.odo_resample_luma_coeffs(P(want4), 4, P(area), 8, 0, 0)
+                for cp in (p, p + 2):
+                    assert np.array_equal(tf[cp, by * 4:by * 4 + 4, bx * 4:bx * 4 + 4], want4), (p, by, bx)
+                tfnz += int((want4 != 0).sum())
+    assert tfnz > 2000
 
 
 def test_two_contexts_in_flight_give_the_sequential_results(hip):

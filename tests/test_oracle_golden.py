@@ -365,3 +365,20 @@ def test_image_pad_vs_reference_random():
         got = _pad_planes(o, fr, w, h)
         for pli in range(3):
             assert np.array_equal(got[pli], outs[pli]), (w, h, pli)
+
+
+@pytest.mark.skipif(ref() is None, reason="oracle/_ref not present")
+def test_resample_luma_coeffs_vs_reference_random():
+    """odo_resample_luma_coeffs (4:2:0: the TF branch for 4x4 luma blocks and the
+    quarter copy) against the reference's od_resample_luma_coeffs (src/intra.c:72)."""
+    o, r = oracle(), ref()
+    rng = np.random.RandomState(72)
+    for bs, luma_bs in [(0, 0), (0, 1), (1, 2), (2, 3), (3, 4)]:
+        n = 4 << bs
+        for _ in range(40):
+            luma = (rng.laplace(size=(2 * n, 2 * n)) * rng.choice([10, 300, 20000])).astype(np.int32)
+            a = np.full((n, n + 3), -7, np.int32)
+            b = a.copy()
+            r.od_resample_luma_coeffs(P(a), n + 3, P(luma), 2 * n, 1, 1, bs, luma_bs)
+            o.odo_resample_luma_coeffs(P(b), n + 3, P(luma), 2 * n, bs, luma_bs)
+            assert np.array_equal(a, b), (bs, luma_bs)
