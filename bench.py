@@ -285,6 +285,23 @@ class Pipeline:
         t.cuda.synchronize()
         return a.elapsed_time(b) / n
 
+    def copy_ceiling_gbs(self, n=10):
+        """Same-run practical HBM ceiling: a 1 GiB device-to-device copy,
+        read + written bytes per second."""
+        t = self.torch
+        a = t.empty(1 << 30, dtype=t.uint8, device=self.luma.device)
+        b = t.empty_like(a)
+        b.copy_(a)
+        t.cuda.synchronize()
+        e0 = t.cuda.Event(enable_timing=True)
+        e1 = t.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            b.copy_(a)
+        e1.record()
+        t.cuda.synchronize()
+        return 2.0 * (1 << 30) * n / (e0.elapsed_time(e1) * 1e-3) / 1e9
+
     def ref128_bytes(self):
         """Algorithmic bytes and band count of one k_refb_search_row<8> launch,
         counted from the records and candidate vectors the last step left."""
@@ -493,6 +510,7 @@ def main():
     # The filter + DCT kernel on its own (after the timed steps): in the step it shares the
     # GPU with the other stream's kernels, which stretches its duration.
     fd_alone = pipe.pyramid_alone_ms()
+    copy_gbs = pipe.copy_ceiling_gbs()
     ref_search_ms = D.pvq_ref_profile_read()
     D.pvq_ref_profile(False)
     if dist is not None:
@@ -609,7 +627,12 @@ def main():
                    "algorithmic_bytes_per_launch": ab["forward_pyramid_luma"],
                    "in_step": {"avg_ms_per_launch": fd["avg_ms_per_launch"],
                                "achieved_GBs": fd["achieved_GBs"], "frac": fd["frac_of_hbm_peak"]},
-                   "note": "timed alone after the steps (HIP events, 10 launches); in_step = the same "
+                   "copy_1GiB_GBs": round(copy_gbs, 1),
+                   "frac_of_copy": round(fd_gbs / copy_gbs, 4),
+                   "note": "copy_1GiB_GBs = the same run's device-to-device copy of 1 GiB (read + "
+                           "written), the practical ceiling SURVEY 8(d) asks for beside the 8 TB/s "
+                           "spec; "
+                           "timed alone after the steps (HIP events, 10 launches); in_step = the same "
                            "launch inside the step, where it shares the GPU with the other stream"}
         try:
             with open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")) as f:
