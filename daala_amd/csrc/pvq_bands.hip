@@ -91,7 +91,7 @@ __device__ DJob g_jobs[kMaxJobs];
    their table into LDS first - a constant-memory access with 64 different
    addresses serialises. */
 __constant__ unsigned char kScanXY[OD_SCAN_LEN][2];
-__device__ unsigned short gScanXY[OD_SCAN_LEN];  /* y << 8 | x */
+__device__ __attribute__((aligned(16))) unsigned short gScanXY[OD_SCAN_LEN];  /* y << 8 | x */
 __device__ short gInvScan[32*32];                /* raster (y*32 + x) -> coding index, -1 */
 __device__ unsigned char gBandOf[OD_SCAN_LEN];
 
@@ -838,6 +838,12 @@ struct CflOut {
   int copies;
 };
 
+/* Eight consecutive coding positions of one luma block per thread.  The scan is
+   nested: the first n*n coding positions of a 2n x 2n block are its n x n corner
+   (for 64x64 blocks only 512 of the corner's 1024 positions are coded; the host
+   clears those planes first), and a chunk of eight never straddles a band, so
+   pulses, inverse QM and scan positions are 16-byte loads and one choice record
+   serves the chunk. */
 __global__ __launch_bounds__(256) void k_cfl_ref(Items it, CflOut out) {
   const int item = find_item(it, blockIdx.x);
   const int job = it.job[item];
@@ -845,31 +851,46 @@ __global__ __launch_bounds__(256) void k_cfl_ref(Items it, CflOut out) {
   const int N = 4 << jb.bs;
   const int n = N >> 1;
   const int cw = jb.w >> 1;
-  const int chh = jb.h >> 1;
+  const int ncode = n*n < jb.len ? n*n : jb.len;       /* coded positions inside the corner */
+  const int cpb = ncode >> 3;
   const long t = (long)(blockIdx.x - it.wg_start[item])*256 + threadIdx.x;
-  const long per = (long)cw*chh;
-  if (t >= per*jb.nplanes) return;
-  const int p = (int)(t/per);
-  const int rem = (int)(t - p*per);
-  const int y = rem/cw;
-  const int x = rem - y*cw;
-  const int by = y/n;
-  const int v = y - by*n;
-  const int bx = x/n;
-  const int u = x - bx*n;
-  const long blk = ((long)p*jb.bh + by)*jb.bw + bx;
-  const int c = gInvScan[v*32 + u];
-  int val = 0;
-  if (c == 0) val = jb.coef[(long)p*jb.w*jb.h + (long)by*N*jb.w + bx*N];
-  else if (c > 0 && c < jb.len) {
-    const int4 ch = reinterpret_cast<const int4 *>(jb.choice)[blk*jb.nb_bands + gBandOf[c]];
-    if (ch.y != 0) {
-      const int yv = jb.y[((long)ch.x*jb.nblocks + blk)*jb.len + c];
-      val = odq_shr_round(odq_mult16_32_q16(yv, ch.z)*jb.qm_inv[c], ch.w);
-    }
+  const long blk = t/cpb;
+  if (blk >= jb.nblocks) return;
+  const int c0 = (int)(t - blk*cpb) << 3;
+  const long per_blocks = (long)jb.bw*jb.bh;
+  const int p = (int)(blk/per_blocks);
+  const int rem = (int)(blk - p*per_blocks);
+  const int by = rem/jb.bw;
+  const int bx = rem - by*jb.bw;
+  const long per = (long)cw*(jb.h >> 1);
+  od_coeff *dst = out.ref[job] + p*per + (long)by*n*cw + bx*n;
+  const long copy_stride = per*jb.nplanes;
+  const uint4 sc4 = *reinterpret_cast<const uint4 *>(gScanXY + c0);
+  const unsigned scw[4] = {sc4.x, sc4.y, sc4.z, sc4.w};
+  const int4 ch = reinterpret_cast<const int4 *>(jb.choice)[blk*jb.nb_bands + gBandOf[c0 ? c0 : 1]];
+  unsigned yw[4] = {0, 0, 0, 0};
+  if (ch.y != 0) {
+    const uint4 y4 = *reinterpret_cast<const uint4 *>(jb.y + ((long)ch.x*jb.nblocks + blk)*jb.len + c0);
+    yw[0] = y4.x;
+    yw[1] = y4.y;
+    yw[2] = y4.z;
+    yw[3] = y4.w;
   }
-  od_coeff *dst = out.ref[job] + t;
-  for (int k = 0; k < out.copies; k++) dst[k*per*jb.nplanes] = val;
+  const uint4 q4 = *reinterpret_cast<const uint4 *>(jb.qm_inv + c0);
+  const unsigned qw[4] = {q4.x, q4.y, q4.z, q4.w};
+#pragma unroll
+  for (int e = 0; e < 8; e++) {
+    const unsigned pk = (scw[e >> 1] >> (16*(e & 1))) & 0xffffu;
+    int val;
+    if (c0 == 0 && e == 0) val = jb.coef[(long)p*jb.w*jb.h + (long)by*N*jb.w + bx*N];
+    else {
+      const int yv = (int16_t)(yw[e >> 1] >> (16*(e & 1)));
+      const int qmi = (int16_t)(qw[e >> 1] >> (16*(e & 1)));
+      val = odq_shr_round(odq_mult16_32_q16(yv, ch.z)*qmi, ch.w);
+    }
+    od_coeff *d = dst + (long)(pk >> 8)*cw + (pk & 255);
+    for (int k = 0; k < out.copies; k++) d[k*copy_stride] = val;
+  }
 }
 
 /* Decoded coefficient (v, u), v, u < 2, of the 4x4 luma block blk of a level-0
@@ -1322,7 +1343,14 @@ extern "C" int odhip_cfl_refs_from_luma(const odhip_pvq_job *luma_jobs, int njob
     if (!d_ref[j] || !luma_jobs[j].d_qm_inv || (host[j].w & 7) || (host[j].h & 7)) return ODHIP_EINVAL;
     out.ref[j] = d_ref[j];
     if (host[j].bs >= 1) {
-      items_add(it, j, 0, ((long)host[j].nplanes*(host[j].w >> 1)*(host[j].h >> 1) + 255)/256);
+      const int n = 2 << host[j].bs;
+      const int ncode = n*n < host[j].len ? n*n : host[j].len;
+      items_add(it, j, 0, (host[j].nblocks*(ncode >> 3) + 255)/256);
+      if (n*n > ncode) {
+        /* 64x64 luma blocks: half of the 32x32 corner is not coded */
+        ODHIP_TRY(hipMemsetAsync(d_ref[j], 0, sizeof(od_coeff)*(size_t)copies*host[j].nplanes
+         *(host[j].w >> 1)*(host[j].h >> 1), s));
+      }
     }
   }
   rc = upload_jobs(host, njobs, s);
