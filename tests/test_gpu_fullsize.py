@@ -195,7 +195,31 @@ def test_1080p_band_stage_properties_and_oracle_subset(hip):
     assert nsearched > 500000
 
 
-def test_1080p_with_reference_stage_properties_and_oracle_subset(hip):
+def _natural_like_frame(seed):
+    """A 1920x1088 4:2:0 frame of the second kind SURVEY.md 8(d) asks for: a sum of 2-D
+    cosines plus separable AR(1) noise (rho = 0.95, the model of the reference's
+    dcttest, src/dct.c:4968), chroma = smoothed, subsampled luma with its own gain and
+    a little independent noise (so that luma-derived predictions really correlate)."""
+    rng = np.random.RandomState(seed)
+    h, w = 1088, 1920
+    yy, xx = np.mgrid[0:h, 0:w]
+    img = 40 * np.cos(xx * 0.013 + yy * 0.007) + 25 * np.cos(xx * 0.041 - yy * 0.029) \
+        + 12 * np.cos(xx * 0.11 + 1.0) * np.cos(yy * 0.09)
+    e = rng.normal(size=(h, w)) * 6
+    for ax in (0, 1):               # separable AR(1), rho = 0.95
+        e = np.moveaxis(e, ax, 0)
+        for i in range(1, e.shape[0]):
+            e[i] += 0.95 * e[i - 1]
+        e = np.moveaxis(e, 0, ax) * 0.31
+    luma = np.clip(128 + img + e * 4, 0, 255)
+    sub = luma.reshape(h // 2, 2, w // 2, 2).mean(axis=(1, 3))
+    cb = np.clip(128 + 0.5 * (sub - 128) + rng.normal(size=sub.shape) * 2, 0, 255)
+    cr = np.clip(128 - 0.35 * (sub - 128) + rng.normal(size=sub.shape) * 2, 0, 255)
+    return luma.astype(np.uint8), cb.astype(np.uint8), cr.astype(np.uint8)
+
+
+@pytest.mark.parametrize("content", ["bench", "natural"])
+def test_1080p_with_reference_stage_properties_and_oracle_subset(hip, content):
     """The with-reference stage on the chroma planes of a whole 1080p frame, with the
     chroma-from-luma references the bench builds (upper-left quarter of the luma
     reconstruction's dequantised coefficients, one level up): properties of every
@@ -209,7 +233,7 @@ def test_1080p_with_reference_stage_properties_and_oracle_subset(hip):
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     import bench
     from _refbands import Mismatch, compare_bands, oracle_traces
-    y_, cb, cr = bench.synth_frame_np(0, 77)
+    y_, cb, cr = bench.synth_frame_np(0, 77) if content == "bench" else _natural_like_frame(5)
     qt = hip.QuantTables.load()
     lam = hip.OD_PVQ_LAMBDA
     W, H = 1920, 1088
@@ -298,7 +322,7 @@ def test_1080p_with_reference_stage_properties_and_oracle_subset(hip):
             for s in range(14):
                 own = (s < nitems[:, b]) & ((items["flags"][:, b, s] & 1) != 0) & (items["yslot"][:, b, s] == s)
                 assert np.array_equal(u["y"][s][own][:, a:e - 1], y_first[s][own][:, a:e - 1]), (bs, b, s)
-    assert nsearched > 500000 and nflip > 1000
+    assert nsearched > 300000 and nflip > 1000
     # oracle parity of whole bands on random blocks of every level
     mm = Mismatch()
     for bs, job in enumerate(jobs):
