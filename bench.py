@@ -87,6 +87,32 @@ def synth_frame_np(index, seed):
     return planes
 
 
+def natural_like_frame_np(index, seed):
+    """The second kind of synthetic content SURVEY.md 8(d) asks for: a sum of 2-D cosines
+    plus separable AR(1) noise (rho = 0.95, the model of the reference's dcttest,
+    src/dct.c:4968); chroma = subsampled luma with its own gain plus a little independent
+    noise, so that luma-derived predictions correlate with chroma as in natural video."""
+    rng = np.random.RandomState(seed + 7919 * index)
+    yy, xx = np.mgrid[0:H, 0:W]
+    img = 40 * np.cos((xx + 5 * index) * 0.013 + yy * 0.007) + 25 * np.cos(xx * 0.041 - yy * 0.029) \
+        + 12 * np.cos(xx * 0.11 + 1.0) * np.cos(yy * 0.09)
+    e = rng.normal(size=(H, W)) * 6
+    for ax in (0, 1):
+        e = np.moveaxis(e, ax, 0)
+        for i in range(1, e.shape[0]):
+            e[i] += 0.95 * e[i - 1]
+        e = np.moveaxis(e, 0, ax) * 0.31
+    luma = np.clip(128 + img + e * 4, 0, 255)
+    sub = luma.reshape(H // 2, 2, W // 2, 2).mean(axis=(1, 3))
+    cb = np.clip(128 + 0.5 * (sub - 128) + rng.normal(size=sub.shape) * 2, 0, 255)
+    cr = np.clip(128 - 0.35 * (sub - 128) + rng.normal(size=sub.shape) * 2, 0, 255)
+    return [luma.astype(np.uint8), cb.astype(np.uint8), cr.astype(np.uint8)]
+
+
+CONTENT = {"checker": synth_frame_np, "natural": natural_like_frame_np}
+GENERATOR = synth_frame_np
+
+
 def picture_planes(planes):
     """The 1920x1080 picture of a generated frame (the generator fills the coded
     1920x1088 size; the encoder's input is the picture, the rest is padding)."""
@@ -97,7 +123,7 @@ def synth_frames(nframes, seed, device):
     """F pictures resident in HBM: luma [F,1080,1920], chroma [2F,540,960] (all Cb,
     then all Cr)."""
     import torch
-    fr = [picture_planes(synth_frame_np(i, seed)) for i in range(nframes)]
+    fr = [picture_planes(GENERATOR(i, seed)) for i in range(nframes)]
     luma = torch.from_numpy(np.stack([f[0] for f in fr])).to(device)
     chroma = torch.from_numpy(np.stack([f[1] for f in fr] + [f[2] for f in fr])).to(device)
     return luma.contiguous(), chroma.contiguous()
@@ -400,7 +426,7 @@ def cpu_baseline(qt, chroma_cfl, min_seconds=12.0, max_frames=32):
         r.ref_stage_plane.restype = ctypes.c_long
         r.ref_stage_plane_cfl.restype = ctypes.c_long
     while busy < min_seconds and nframes < max_frames:
-        pics = picture_planes(synth_frame_np(1000 + nframes, 1234))  # generation is not timed
+        pics = picture_planes(GENERATOR(1000 + nframes, 1234))  # generation is not timed
         ldq = [np.zeros((H, W), np.int32) for _ in range(5)] if chroma_cfl else None
         refs = None
         for pli, pic, dec in ((0, pics[0], 0), (1, pics[1], 1), (2, pics[2], 1)):
@@ -458,6 +484,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--frames", type=int, default=DEFAULT_FRAMES, help="1080p frames per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--content", choices=sorted(CONTENT), default="checker",
+                    help="synthetic picture generator: 'checker' (smooth texture + 32-pixel checker "
+                         "edges + uniform noise, independent chroma) or 'natural' (cosines + AR(1) "
+                         "noise, chroma correlated with luma)")
     ap.add_argument("--chroma-noref", action="store_true",
                     help="chroma through pvq_theta's no-reference path (default: with the "
                          "chroma-from-luma reference, as the reference encoder codes keyframes)")
@@ -467,6 +497,8 @@ def main():
     import torch
     import daala_amd as D
 
+    global GENERATOR
+    GENERATOR = CONTENT[args.content]
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -663,7 +695,7 @@ def main():
                        "every block of every level" + (
                            "; chroma through the with-reference (chroma-from-luma) PVQ path"
                            if cfl else "; chroma through the no-reference PVQ path"),
-                       "frames_per_gpu_per_step": args.frames,
+                       "frames_per_gpu_per_step": args.frames, "content": args.content,
                        "blocks_per_frame": bpf, "quality": "-v 20 (quantizer 243)",
                        "sharding": "frames over ranks, no data-path collective"},
             "roofline": roof,
