@@ -710,3 +710,26 @@ def pvq_ref_set_context(ctx):
     """Selects which of the two library contexts the following pvq_ref_* calls of this
     thread use (one call sequence may be in flight per context)."""
     _check(lib().odhip_pvq_ref_set_context(int(ctx)), "odhip_pvq_ref_set_context")
+
+
+def pvq_ref_choose_multi(jobs, pvq_norm_lambda):
+    """The with-reference stage's choice alone (choice records incl. the synthesis
+    parameters), for inverse_levels_pvq_ref."""
+    _check(lib().odhip_pvq_ref_choose_multi(_refjobs_array(jobs), len(jobs),
+                                            ctypes.c_double(pvq_norm_lambda), _stream()),
+           "odhip_pvq_ref_choose_multi")
+
+
+def inverse_levels_pvq_ref(jobs, dec, pic_w, pic_h, outs=None):
+    """Inverse of several partition levels of one plane set fed by the with-reference
+    band stage: dequantise-on-load from the chosen candidates (no dequantised plane)."""
+    import torch
+    nplanes, h, w = jobs[0].coef.shape
+    if outs is None:
+        outs = [torch.empty((nplanes, h, w), dtype=torch.uint8, device=jobs[0].coef.device)
+                for _ in jobs]
+    px = (ctypes.c_void_p * len(jobs))(*[o.data_ptr() for o in outs])
+    _check(lib().odhip_inverse_levels_pvq_ref(px, w, ctypes.c_long(h * w), _refjobs_array(jobs),
+                                              len(jobs), int(dec), int(pic_w), int(pic_h), _stream()),
+           "odhip_inverse_levels_pvq_ref")
+    return outs

@@ -27,6 +27,7 @@
 #include <string.h>
 #include "od_common.cuh"
 #include "od_tile.cuh"
+#include "od_pvq_math.cuh"
 #include "gen/od_scan_tables.h"
 
 namespace {
@@ -545,6 +546,12 @@ struct InverseArgs {
   long nblocks;
   int len;
   int nb_bands;
+  /* With-reference source (odhip_inverse_levels_pvq_ref): y / choice are those of an
+     odhip_pvq_refjob (choice: [nblocks][nb_bands][16] ints, the synthesis parameters
+     in words 8..15), r16 the QM-scaled reference after od_compute_householder, ref
+     the reference plane itself (skip-copy bands). */
+  const int16_t *r16;
+  const od_coeff *ref;
 };
 
 /* Several partition levels of one plane set in ONE launch (blockIdx.z = level *
@@ -557,7 +564,7 @@ struct InverseArgsMulti {
   int nplanes;
 };
 
-__device__ unsigned short gInvScanXY[OD_SCAN_LEN];  /* y << 8 | x of coding index j */
+__device__ __attribute__((aligned(16))) unsigned short gInvScanXY[OD_SCAN_LEN];  /* y << 8 | x of coding index j */
 __device__ unsigned char gInvBandOf[OD_SCAN_LEN];
 
 /* od_coeff_to_ref_buf, src/state.c:1296-1304. */
@@ -589,7 +596,115 @@ __device__ __forceinline__ void inverse_leaf(int *t, int tid) {
   __syncthreads();
 }
 
+/* Dequantise-on-load of a with-reference band stage's choice (the per-coefficient
+   part of od_pvq_synthesis_partial, src/pvq.c:1081-1114, as k_refb_synth computes
+   it, but into the LDS tile instead of a plane): eight consecutive coding
+   positions of one block per thread; a chunk never straddles a band. */
 template <int TILE>
+__device__ __forceinline__ void inverse_load_ref(int *t, const InverseArgs &a, int plane, long plane_off,
+ int x0, int y0, int tid) {
+  using G = Geo<TILE>;
+  constexpr int P = G::kPitch;
+  constexpr int NT = G::kNT;
+  const int sh = a.leaf_bs + 2;
+  const int nbw = TILE >> sh;
+  const int nbsb = nbw*nbw;
+  const int bw = a.w >> sh;
+  const int bh = a.h >> sh;
+  if ((a.len >> sh) < (1 << sh)) {            /* 32x32 / 64x64: uncoded positions are zero */
+    for (int i = tid; i < TILE*P/4; i += NT) reinterpret_cast<int4 *>(t)[i] = make_int4(0, 0, 0, 0);
+    __syncthreads();
+  }
+  const int cpb = a.len >> 3;
+  const int4 *choice4 = a.choice;
+  for (int c = tid; c < nbsb*cpb; c += NT) {
+    const int b = c/cpb;
+    const int c0 = (c - b*cpb) << 3;
+    const int lby = b/nbw;
+    const int lbx = b - lby*nbw;
+    const long blk = ((long)plane*bh + (y0 >> sh) + lby)*bw + (x0 >> sh) + lbx;
+    const int band = gInvBandOf[c0 ? c0 : 1];
+    const int4 ca = choice4[(blk*a.nb_bands + band)*4 + 2];   /* mode, slot, scale, qshift */
+    const int mode = ca.x;
+    const int base = (lby << sh)*P + (lbx << sh);
+    const uint4 sc4 = *reinterpret_cast<const uint4 *>(gInvScanXY + c0);
+    const unsigned scw[4] = {sc4.x, sc4.y, sc4.z, sc4.w};
+    int pos[8];
+    long gpos[8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+      const unsigned pk = (scw[e >> 1] >> (16*(e & 1))) & 0xffffu;
+      pos[e] = base + (int)(pk >> 8)*P + (int)(pk & 255);
+      gpos[e] = (long)(y0 + (lby << sh) + (int)(pk >> 8))*a.w + x0 + (lbx << sh) + (int)(pk & 255);
+    }
+    const int first = c0 == 0;
+    if (first) t[pos[0]] = a.coef[plane_off + gpos[0]];
+    if (mode == 0) {
+#pragma unroll
+      for (int e = 0; e < 8; e++) if (!(first && e == 0)) t[pos[e]] = 0;
+      continue;
+    }
+    if (mode == 1 || mode == 4) {
+#pragma unroll
+      for (int e = 0; e < 8; e++) {
+        if (first && e == 0) continue;
+        const od_coeff rv = a.ref[plane_off + gpos[e]];
+        t[pos[e]] = mode == 4 ? -rv : rv;
+      }
+      continue;
+    }
+    /* first coding position of the band (OD_BAND_OFFSETS, src/partition.c:77-91) */
+    const int off = c0 < 16 ? 1 : c0 < 24 ? 16 : c0 < 32 ? 24 : c0 < 64 ? 32 : c0 < 96 ? 64
+     : c0 < 128 ? 96 : c0 < 256 ? 128 : c0 < 384 ? 256 : 384;
+    const int yslot = ca.y;
+    const int32_t scale = ca.z;
+    const int qshift = ca.w;
+    const uint4 q4 = *reinterpret_cast<const uint4 *>(a.qm_inv + c0);
+    const unsigned qw[4] = {q4.x, q4.y, q4.z, q4.w};
+    unsigned yw[4] = {0, 0, 0, 0};
+    int yprev = 0;
+    if (yslot >= 0) {
+      const int16_t *yp = a.y + ((long)yslot*a.nblocks + blk)*a.len + c0;
+      const uint4 y4 = *reinterpret_cast<const uint4 *>(yp);
+      yw[0] = y4.x;
+      yw[1] = y4.y;
+      yw[2] = y4.z;
+      yw[3] = y4.w;
+      if (mode == 3 && c0 > off) yprev = yp[-1];
+    }
+    if (mode == 2) {
+#pragma unroll
+      for (int e = 0; e < 8; e++) {
+        if (first && e == 0) continue;
+        const int yv = (int16_t)(yw[e >> 1] >> (16*(e & 1)));
+        const int qmi = (int16_t)(qw[e >> 1] >> (16*(e & 1)));
+        const int32_t x = (int32_t)odq_mult16_32_q16(yv, scale);
+        t[pos[e]] = odq_shr_round(x*qmi, qshift);
+      }
+      continue;
+    }
+    const int4 cb = choice4[(blk*a.nb_bands + band)*4 + 3];   /* xm, m, proj_1, outshift */
+    const int m = cb.y;
+    const uint4 r4 = *reinterpret_cast<const uint4 *>(a.r16 + blk*a.len + c0);
+    const unsigned rw[4] = {r4.x, r4.y, r4.z, r4.w};
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+      if (first && e == 0) continue;
+      const int i = c0 + e - off;
+      const int yv = (int16_t)(yw[e >> 1] >> (16*(e & 1)));
+      const int ym1 = e == 0 ? yprev : (int)(int16_t)(yw[(e - 1) >> 1] >> (16*((e - 1) & 1)));
+      const int qmi = (int16_t)(qw[e >> 1] >> (16*(e & 1)));
+      const int ri = (int16_t)(rw[e >> 1] >> (16*(e & 1)));
+      const int16_t xi = i == m ? (int16_t)cb.x : (int16_t)odq_mult16_32_q16(i < m ? yv : ym1, scale);
+      int32_t tmp = odq_mult16_16(ri, cb.z);
+      tmp = cb.w >= 0 ? odq_shr_round(tmp, cb.w) : odq_shl32(tmp, -cb.w);
+      const int16_t v = (int16_t)(xi - tmp);
+      t[pos[e]] = odq_shr_round(v*qmi, qshift);
+    }
+  }
+}
+
+template <int TILE, bool REF = false>
 __global__ __launch_bounds__(Geo<TILE>::kNT) void k_inverse_sb(InverseArgsMulti mm) {
   using G = Geo<TILE>;
   constexpr int P = G::kPitch;
@@ -601,7 +716,10 @@ __global__ __launch_bounds__(Geo<TILE>::kNT) void k_inverse_sb(InverseArgsMulti 
   const int plane = blockIdx.z % mm.nplanes;
   const InverseArgs &a = mm.a[blockIdx.z / mm.nplanes];
   const long plane_off = (long)plane*a.w*a.h;
-  if (a.y) {
+  if constexpr (REF) {
+    inverse_load_ref<TILE>(t, a, plane, plane_off, x0, y0, tid);
+  }
+  else if (a.y) {
     /* Dequantise on load: x = y*scale (Q16, no rounding), out = SHR_ROUND(x *
        qm_inv, qshift) (od_pvq_synthesis_partial noref, src/pvq.c:1081-1092),
        scattered to raster inside LDS (od_coding_order_to_raster,
@@ -868,7 +986,8 @@ extern "C" int odhip_forward_pyramid(od_coeff *const d_levels[ODHIP_NBSIZES],
 namespace {
 
 /* All levels share w, h, nplanes and dec (one plane set). */
-int inverse_launch(const InverseArgs *levels, int nlevels, int nplanes, int dec, hipStream_t s) {
+int inverse_launch(const InverseArgs *levels, int nlevels, int nplanes, int dec, hipStream_t s,
+ bool ref = false) {
   if (nlevels <= 0 || nlevels > kMaxInvLevels) return ODHIP_EINVAL;
   const int tile = 64 >> dec;
   const int w = levels[0].w;
@@ -907,7 +1026,11 @@ int inverse_launch(const InverseArgs *levels, int nlevels, int nplanes, int dec,
     em.a[l].tile = tile;
   }
   const dim3 grid(w/tile, h/tile, nplanes*nlevels);
-  if (dec) k_inverse_sb<32><<<grid, Geo<32>::kNT, 0, s>>>(im);
+  if (ref) {
+    if (dec) k_inverse_sb<32, true><<<grid, Geo<32>::kNT, 0, s>>>(im);
+    else k_inverse_sb<64, true><<<grid, Geo<64>::kNT, 0, s>>>(im);
+  }
+  else if (dec) k_inverse_sb<32><<<grid, Geo<32>::kNT, 0, s>>>(im);
   else k_inverse_sb<64><<<grid, Geo<64>::kNT, 0, s>>>(im);
   if (nv > 0) k_edge_rows<<<dim3((h + 255)/256, nv, nplanes*nlevels), 256, 0, s>>>(em);
   if (nh > 0) k_edge_cols<<<dim3((w + 255)/256, nh, nplanes*nlevels), 256, 0, s>>>(em);
@@ -1055,4 +1178,53 @@ extern "C" int odhip_inverse_levels_pvq(uint8_t *const *d_px, int px_stride, lon
   const int rc = upload_inv_tables();
   if (rc) return rc;
   return inverse_launch(ia, njobs, jobs[0].nplanes, dec, (hipStream_t)stream);
+}
+
+/* odhip_inverse_levels_pvq for the WITH-reference band stage: the chosen candidates
+   of jobs[i] (choice records of odhip_pvq_ref_select_synth_multi or
+   odhip_pvq_ref_choose_multi) are dequantised while the superblock tile is loaded -
+   od_pvq_synthesis_partial with or without reference, the skip-copy and skip-zero
+   bands included - so the dequantised plane never exists in HBM. */
+extern "C" int odhip_inverse_levels_pvq_ref(uint8_t *const *d_px, int px_stride, long px_plane_stride,
+ const odhip_pvq_refjob *jobs, int njobs, int dec, int pic_w, int pic_h, odhip_stream stream) {
+  if (!d_px || !jobs || njobs <= 0 || njobs > kMaxInvLevels || (dec != 0 && dec != 1)) return ODHIP_EINVAL;
+  const int tile = 64 >> dec;
+  InverseArgs ia[kMaxInvLevels];
+  memset(ia, 0, sizeof(ia));
+  for (int i = 0; i < njobs; i++) {
+    const odhip_pvq_refjob &j = jobs[i];
+    if (!d_px[i] || !j.d_coef || !j.d_ref || !j.y || !j.r16 || !j.choice || !j.d_qm_inv || j.nplanes <= 0
+     || j.nplanes != jobs[0].nplanes || j.w != jobs[0].w || j.h != jobs[0].h) {
+      return ODHIP_EINVAL;
+    }
+    const int w = j.w;
+    const int h = j.h;
+    const int bs = j.bs;
+    if (w <= 0 || h <= 0 || w % tile || h % tile || (px_stride & 3) || (px_plane_stride & 3) || bs < 0
+     || bs > 4 - dec || ((uintptr_t)j.y & 15) || ((uintptr_t)j.choice & 15) || ((uintptr_t)j.r16 & 15)
+     || ((uintptr_t)j.d_qm_inv & 15)) {
+      return ODHIP_EINVAL;
+    }
+    const int n = 4 << bs;
+    ia[i].coef = j.d_coef;
+    ia[i].px = d_px[i];
+    ia[i].px_stride = px_stride;
+    ia[i].px_plane_stride = px_plane_stride;
+    ia[i].w = w;
+    ia[i].h = h;
+    ia[i].pic_w = pic_w;
+    ia[i].pic_h = pic_h;
+    ia[i].leaf_bs = bs;
+    ia[i].y = j.y;
+    ia[i].choice = reinterpret_cast<const int4 *>(j.choice);
+    ia[i].qm_inv = j.d_qm_inv;
+    ia[i].nblocks = (long)j.nplanes*(w/n)*(h/n);
+    ia[i].len = n*n < OD_SCAN_LEN ? n*n : OD_SCAN_LEN;
+    ia[i].nb_bands = OD_NBANDS[bs];
+    ia[i].r16 = j.r16;
+    ia[i].ref = j.d_ref;
+  }
+  const int rc = upload_inv_tables();
+  if (rc) return rc;
+  return inverse_launch(ia, njobs, jobs[0].nplanes, dec, (hipStream_t)stream, true);
 }

@@ -1385,7 +1385,9 @@ int fill_job(RJob &d, const odhip_pvq_refjob &j, int mode) {
    || ((uintptr_t)j.choice & 15)) {
     return ODHIP_EINVAL;
   }
-  if (mode == 0 ? (!j.d_qm || !j.x16 || !j.xr) : (!j.d_qm_inv || !j.choice || !j.d_dq)) {
+  /* mode 0: band stage; 1: choice + synthesis; 2: choice only */
+  if (mode == 0 ? (!j.d_qm || !j.x16 || !j.xr) : mode == 1 ? (!j.d_qm_inv || !j.choice || !j.d_dq)
+   : !j.choice) {
     return ODHIP_EINVAL;
   }
   const int n = 4 << j.bs;
@@ -1795,13 +1797,28 @@ extern "C" int odhip_pvq_ref_resolve(const odhip_pvq_refjob *jobs, int njobs,
   return (int)nfix;
 }
 
+namespace {
+int ref_select(const odhip_pvq_refjob *jobs, int njobs, double pvq_norm_lambda, hipStream_t s,
+ bool synth);
+}  // namespace
+
 extern "C" int odhip_pvq_ref_select_synth_multi(const odhip_pvq_refjob *jobs, int njobs,
  double pvq_norm_lambda, odhip_stream stream) {
-  hipStream_t s = (hipStream_t)stream;
+  return ref_select(jobs, njobs, pvq_norm_lambda, (hipStream_t)stream, true);
+}
+
+extern "C" int odhip_pvq_ref_choose_multi(const odhip_pvq_refjob *jobs, int njobs,
+ double pvq_norm_lambda, odhip_stream stream) {
+  return ref_select(jobs, njobs, pvq_norm_lambda, (hipStream_t)stream, false);
+}
+
+namespace {
+int ref_select(const odhip_pvq_refjob *jobs, int njobs, double pvq_norm_lambda, hipStream_t s,
+ bool synth) {
   RJob host[kMaxJobs];
-  int rc = stage_jobs(jobs, njobs, 1, host, s);
+  int rc = stage_jobs(jobs, njobs, synth ? 1 : 2, host, s);
   if (rc) return rc;
-  for (int j = 0; j < njobs; j++) {
+  for (int j = 0; synth && j < njobs; j++) {
     /* 32x32 and 64x64 blocks code their lowest 512 coefficients only */
     if (host[j].bs >= 3) {
       ODHIP_TRY(hipMemsetAsync(host[j].dq, 0, sizeof(od_coeff)*(size_t)host[j].nplanes*host[j].w
@@ -1819,8 +1836,10 @@ extern "C" int odhip_pvq_ref_select_synth_multi(const odhip_pvq_refjob *jobs, in
     else if (sizes[i] == 15) k_refb_choose<15><<<grid, kWave, 0, s>>>(it);
     else k_refb_choose<8><<<grid, kWave, 0, s>>>(it);
   }
+  if (!synth) return odhip_check_launch();
   items_begin(it, pvq_norm_lambda);
   for (int j = 0; j < njobs; j++) items_add(it, j, 0, (host[j].nblocks*(host[j].len >> 3) + 255)/256);
   k_refb_synth<<<it.wg_start[it.nitems], 256, 0, s>>>(it);
   return odhip_check_launch();
 }
+}  // namespace

@@ -546,6 +546,18 @@ int odhip_pvq_ref_select_synth_multi(const odhip_pvq_refjob *jobs, int njobs,
    HIP events on the stream the kernel is launched on (calls of context 0 only). */
 int odhip_pvq_ref_profile(int enable);
 int odhip_pvq_ref_profile_read(float *ms, int max_n);
+/* The choice alone (fills `choice` incl. the synthesis parameters), for callers that
+   dequantise inside the inverse stage: odhip_inverse_levels_pvq_ref reconstructs the
+   partition levels jobs[i].bs of ONE plane set (same nplanes, w, h, dec; at most 5
+   jobs) into d_px[i], dequantising the chosen candidates of the with-reference
+   stage while the superblock tile is loaded (od_pvq_synthesis_partial with or
+   without reference, skip-copy and skip-zero bands included; DCs from d_coef); the
+   dequantised plane never exists in HBM.  Same pixels as
+   odhip_pvq_ref_select_synth_multi followed by odhip_inverse_levels. */
+int odhip_pvq_ref_choose_multi(const odhip_pvq_refjob *jobs, int njobs,
+ double pvq_norm_lambda, odhip_stream stream);
+int odhip_inverse_levels_pvq_ref(uint8_t *const *d_px, int px_stride, long px_plane_stride,
+ const odhip_pvq_refjob *jobs, int njobs, int dec, int pic_w, int pic_h, odhip_stream stream);
 /* Test hooks: the uncertainty margin (default 1e-9; <= 0 restores it) and, when
    perturb != 0, a deliberately wrong device theta (+1) for the listed bands, so
    that tests exercise the host-libm path on real data. */

@@ -371,3 +371,39 @@ def test_two_contexts_in_flight_give_the_sequential_results(hip):
             done = valid & ((ua["items"]["flags"][:, :, s] & 1) != 0)
             for f in ("flags", "yslot", "cos_dist", "dist"):
                 assert (ua["items"][f][:, :, s][done] == ub["items"][f][:, :, s][done]).all()
+
+
+@pytest.mark.parametrize("is_keyframe,pli,dec", [(1, 1, 1), (0, 0, 0), (0, 1, 1)])
+def test_inverse_fed_by_the_with_reference_stage_equals_synthesis_plus_inverse(hip, is_keyframe, pli, dec):
+    """odhip_pvq_ref_choose_multi + odhip_inverse_levels_pvq_ref (dequantise-on-load:
+    with-reference and no-reference synthesis, skip-copy and skip-zero bands, inside
+    the inverse kernel's tile load) give exactly the pixels of
+    odhip_pvq_ref_select_synth_multi + odhip_inverse_levels on the dequantised planes,
+    whose planes are checked against the oracle / the compiled reference above."""
+    import torch
+    lam = hip.OD_PVQ_LAMBDA
+    rng = np.random.RandomState(70 + 2 * is_keyframe + pli)
+    top = 4 - dec
+    h, w = 64, 128
+    jobs = [_job(hip, rng, bs, is_keyframe, pli, h=h, w=w)[0] for bs in range(top + 1)]
+    hip.pvq_ref_bands_multi(jobs, lam)
+    hip.pvq_ref_select_synth_multi(jobs, lam)
+    pic = (2 * w - 6, 2 * h - 10) if dec else (w - 6, h - 10)
+    want = hip.inverse_levels([j.dq for j in jobs], dec, list(range(top + 1)), pic[0], pic[1])
+    torch.cuda.synchronize()
+    modes = set()
+    for j in jobs:
+        j.choice.zero_()
+        j.dq.fill_(12345)          # the fused path must not need it
+    hip.pvq_ref_choose_multi(jobs, lam)
+    got = hip.inverse_levels_pvq_ref(jobs, dec, pic[0], pic[1])
+    torch.cuda.synchronize()
+    for bs in range(top + 1):
+        assert torch.equal(got[bs], want[bs]), (is_keyframe, pli, bs)
+        modes |= set(np.unique(jobs[bs].choice.cpu().numpy()[:, :, 8]).tolist())
+        assert int(jobs[bs].dq[0, 0, 1]) == 12345
+    # the data exercises with-reference and no-reference synthesis and zero bands
+    # (skip-copy bands, mode 1 / 4, only exist on inter frames)
+    assert {0, 2, 3} <= modes
+    if not is_keyframe:
+        assert modes & {1, 4}
