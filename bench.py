@@ -22,10 +22,12 @@ in HBM, per GPU:
                              Householder reflection, theta, up to 12 (gain,
                              theta) candidates + 2 no-reference candidates per
                              band with chained K-pulse searches
-             odhip_pvq_ref_select_synth_multi   choice, skip rules, synthesis
-  3. for every level: inverse (luma: dequantisation of the chosen pulses on
-                             load; iDCT, split post-filters, superblock-edge
-                             post-filter, coefficient -> pixel)
+             odhip_pvq_ref_choose_multi         choice, skip rules, band-wide part of
+                             the synthesis
+  3. for every level: inverse (dequantisation of the chosen pulses while the
+                             tiles are loaded - with and without reference; iDCT,
+                             split post-filters, superblock-edge post-filter,
+                             coefficient -> pixel)
 
 i.e. every block the reference's block-size RDO would evaluate goes through
 prefilter + fDCT + PVQ + dequantisation + iDCT + postfilter exactly once:
@@ -233,10 +235,11 @@ class Pipeline:
     def _chroma_tail(self, jobs, record):
         D = self.D
         chroma = self.sets[1]
-        self._timed("pvq_ref_select_synth", lambda: D.pvq_ref_select_synth_multi(jobs, self.lam), record)
-        self._timed("inverse_chroma",
-                    lambda: D.inverse_levels([rj.dq for rj in jobs], 1, [0, 1, 2, 3], PIC_W, PIC_H,
-                                             outs=chroma["recon"]), record)
+        # choice, then the inverse of all four levels with the chosen candidates dequantised
+        # while the tiles are loaded (no dequantised chroma plane in HBM)
+        self._timed("pvq_ref_choose", lambda: D.pvq_ref_choose_multi(jobs, self.lam), record)
+        self._timed("dequant_inverse_chroma",
+                    lambda: D.inverse_levels_pvq_ref(jobs, 1, PIC_W, PIC_H, outs=chroma["recon"]), record)
 
     def _finish_pending(self, record):
         """The count of bands inside the device-acos margin of the previous step's
