@@ -299,12 +299,36 @@ __global__ __launch_bounds__(kWave) void k_refb_prep_lane(RItems it) {
   int xv[N];
   int rv[N];
   int qm[N];
+  if constexpr (N == 15) {
+    /* band 0 is the 4x4 low-frequency corner without the DC: four 16-byte row segments
+       of x and of r (adjacent lanes = adjacent blocks: contiguous for 4x4 blocks),
+       permuted to coding order through the compile-time scan */
+    int4 xr4[4];
+    int4 rr4[4];
 #pragma unroll
-  for (int i = 0; i < N; i++) {
-    const long p = (long)kRScanXY[off + i][1]*w + kRScanXY[off + i][0];
-    xv[i] = x0[p];
-    rv[i] = r0[p];
-    qm[i] = qmp[i];
+    for (int y = 0; y < 4; y++) {
+      xr4[y] = *reinterpret_cast<const int4 *>(x0 + (long)y*w);
+      rr4[y] = *reinterpret_cast<const int4 *>(r0 + (long)y*w);
+    }
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+      const int sx = OD_SCAN_XY[1 + i][0];
+      const int sy = OD_SCAN_XY[1 + i][1];
+      const int4 a = xr4[sy];
+      const int4 b = rr4[sy];
+      xv[i] = sx == 0 ? a.x : sx == 1 ? a.y : sx == 2 ? a.z : a.w;
+      rv[i] = sx == 0 ? b.x : sx == 1 ? b.y : sx == 2 ? b.z : b.w;
+      qm[i] = qmp[i];
+    }
+  }
+  else {
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+      const long p = (long)kRScanXY[off + i][1]*w + kRScanXY[off + i][0];
+      xv[i] = x0[p];
+      rv[i] = r0[p];
+      qm[i] = qmp[i];
+    }
   }
   int flip = 0;
   if (cfl_enabled) {
@@ -1392,6 +1416,8 @@ int fill_job(RJob &d, const odhip_pvq_refjob &j, int mode) {
   }
   const int n = 4 << j.bs;
   if (j.w <= 0 || j.h <= 0 || j.w % n || j.h % n) return ODHIP_EINVAL;
+  /* 16-byte row loads of the coefficient and reference planes */
+  if (mode == 0 && (((uintptr_t)j.d_coef & 15) || ((uintptr_t)j.d_ref & 15))) return ODHIP_EINVAL;
   memset(&d, 0, sizeof(d));
   d.coef = j.d_coef;
   d.ref = j.d_ref;
