@@ -85,10 +85,12 @@ __device__ __forceinline__ double od_pvq_search_regs(const int (&ax)[N], int (&y
     int pos = 0;
     double best_xy = -10;
     double best_yy = 1;
+    /* yy + 2*y_j + 1 (:175) is an integer below 2^31: formed in integers, converted once */
+    const int yyp1 = (int)yy + 1;
 #pragma unroll
     for (int j = 0; j < N; j++) {
       double tmp_xy = xy + x[j];
-      const double tmp_yy = yy + (double)(2*y[j]) + 1;
+      const double tmp_yy = (double)(yyp1 + 2*y[j]);
       tmp_xy = tmp_xy*tmp_xy;
       if (j == N - 1 && padded) tmp_xy = -1;   /* PAD: loses every comparison */
       if (j == 0) {
@@ -121,6 +123,8 @@ __device__ __forceinline__ double od_pvq_search_regs(const int (&ax)[N], int (&y
   double pen[N];
 #pragma unroll
   for (int j = 0; j < N; j++) pen[j] = (lambda*j)*(delta_rate + j*accel_rate);
+  /* (2*t)*norm_1 == t*(2*norm_1): scaling by two is exact */
+  const double norm2 = 2*norm_1;
   for (; i < k; i++) {
     /* od_rsqrt_table(yy + 2*y_j + 1) for every candidate straight from the LDS
        table (the reference's four-entry cache :199-200 holds the same values) */
@@ -131,7 +135,7 @@ __device__ __forceinline__ double od_pvq_search_regs(const int (&ax)[N], int (&y
     for (int j = 0; j < N; j++) {
       double tmp_xy = xy + x[j];
       const double tmp_yy = od_rsqrt_table(yyi + 2*y[j] + 1);
-      tmp_xy = ((2*tmp_xy)*norm_1)*tmp_yy - pen[j];
+      tmp_xy = (tmp_xy*norm2)*tmp_yy - pen[j];
       if (j == N - 1 && padded) tmp_xy = -1.7976931348623157e308;   /* PAD */
       if (j == 0) best_cost = tmp_xy;
       else {

@@ -188,11 +188,13 @@ __device__ __forceinline__ double od_pvq_search_row(const int (&ax)[E], int (&y)
     double b[E];
     double ba = 0;
     double bb = 1;
+    /* yy + 2*y_j + 1 (:175) is an integer below 2^31: formed in integers, converted once */
+    const int yyp1 = (int)yy + 1;
 #pragma unroll
     for (int e = 0; e < E; e++) {
       const double t = xy + (double)ax[e];
       a[e] = t*t;
-      b[e] = yy + (double)(2*y[e]) + 1;
+      b[e] = (double)(yyp1 + 2*y[e]);
       if (e == E - 1 && pad_lane) a[e] = -1;   /* PAD: loses every comparison */
       if (e == 0 || a[e]*bb > ba*b[e]) {
         ba = a[e];
@@ -268,6 +270,8 @@ __device__ __forceinline__ double od_pvq_search_row(const int (&ax)[E], int (&y)
   double pen[E];
 #pragma unroll
   for (int e = 0; e < E; e++) pen[e] = (lambda*(l*E + e))*delta_rate;
+  /* (2*t)*norm_1 == t*(2*norm_1): scaling by two is exact */
+  const double norm2 = 2*norm_1;
   while (__any(i < k)) {
     const bool on = i < k;
     /* od_rsqrt_table(yy + 2*y_j + 1) for every candidate straight from the LDS
@@ -280,7 +284,7 @@ __device__ __forceinline__ double od_pvq_search_row(const int (&ax)[E], int (&y)
       const int j = l*E + e;
       double tmp_xy = xy + (double)ax[e];
       const double r = od_rsqrt_table(yyi + 2*y[e] + 1);
-      tmp_xy = ((2*tmp_xy)*norm_1)*r - pen[e];
+      tmp_xy = (tmp_xy*norm2)*r - pen[e];
       if (e == E - 1 && pad_lane) tmp_xy = -1.7976931348623157e308;   /* PAD */
       if (e == 0 || tmp_xy > bc) {
         bc = tmp_xy;
