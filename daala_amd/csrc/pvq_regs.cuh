@@ -32,9 +32,9 @@ template <int N>
 __device__ __forceinline__ double od_pvq_search_regs(const int (&ax)[N], int (&y)[N], int n, int k,
  int prev_k, double g2, double pvq_norm_lambda, double xx, double norm_1, double *yy_out) {
   const bool padded = n != N;
-  double x[N];
-#pragma unroll
-  for (int j = 0; j < N; j++) x[j] = (double)ax[j];
+  /* |x_j| is converted where it is used: a second, double copy of the band costs 2N
+     VGPRs and an occupancy step */
+#define OD_XD(j) ((double)ax[j])
   const double lambda = __ddiv_rn(pvq_norm_lambda, 1e-30 + g2);
   double xy = 0;
   double yy = 0;
@@ -42,7 +42,7 @@ __device__ __forceinline__ double od_pvq_search_regs(const int (&ax)[N], int (&y
   if (prev_k > 0 && prev_k <= k) {
 #pragma unroll
     for (int j = 0; j < N; j++) {
-      xy += x[j]*y[j];
+      xy += OD_XD(j)*y[j];
       yy += (double)(y[j]*y[j]);
       i += y[j];
     }
@@ -50,15 +50,15 @@ __device__ __forceinline__ double od_pvq_search_regs(const int (&ax)[N], int (&y
   else if (k > 2) {
     double l1_norm = 0;
 #pragma unroll
-    for (int j = 0; j < N; j++) l1_norm += x[j];
+    for (int j = 0; j < N; j++) l1_norm += OD_XD(j);
     const double l1_inv = __ddiv_rn(1., l1_norm > 1e-100 ? l1_norm : 1e-100);
 #pragma unroll
     for (int j = 0; j < N; j++) {
-      const double tmp = (k*x[j])*l1_inv;
+      const double tmp = (k*OD_XD(j))*l1_inv;
       int yj = (int)floor(tmp);
       yj = yj > 0 ? yj : 0;
       y[j] = yj;
-      xy += x[j]*yj;
+      xy += OD_XD(j)*yj;
       yy += (double)(yj*yj);
       i += yj;
     }
@@ -89,7 +89,7 @@ __device__ __forceinline__ double od_pvq_search_regs(const int (&ax)[N], int (&y
     const int yyp1 = (int)yy + 1;
 #pragma unroll
     for (int j = 0; j < N; j++) {
-      double tmp_xy = xy + x[j];
+      double tmp_xy = xy + OD_XD(j);
       const double tmp_yy = (double)(yyp1 + 2*y[j]);
       tmp_xy = tmp_xy*tmp_xy;
       if (j == N - 1 && padded) tmp_xy = -1;   /* PAD: loses every comparison */
@@ -133,7 +133,7 @@ __device__ __forceinline__ double od_pvq_search_regs(const int (&ax)[N], int (&y
     double best_cost = -1e5;
 #pragma unroll
     for (int j = 0; j < N; j++) {
-      double tmp_xy = xy + x[j];
+      double tmp_xy = xy + OD_XD(j);
       const double tmp_yy = od_rsqrt_table(yyi + 2*y[j] + 1);
       tmp_xy = (tmp_xy*norm2)*tmp_yy - pen[j];
       if (j == N - 1 && padded) tmp_xy = -1.7976931348623157e308;   /* PAD */
@@ -157,6 +157,7 @@ __device__ __forceinline__ double od_pvq_search_regs(const int (&ax)[N], int (&y
     xy = xy + (double)xp;
     yy = yy + (double)(2*yp) + 1;
   }
+#undef OD_XD
   *yy_out = yy;
   return __ddiv_rn(xy, 1e-100 + __dsqrt_rn(xx*yy));
 }
