@@ -180,7 +180,9 @@ class Pipeline:
         D, torch = self.D, self.torch
         luma, chroma = self.sets
         self.noref_jobs = luma["jobs"]
-        self.side = torch.cuda.Stream(device=device)
+        # ODHIP_PVQ_SERIAL=1 (profiling: exclusive kernel durations) keeps everything on one stream
+        self.side = (torch.cuda.current_stream() if os.environ.get("ODHIP_PVQ_SERIAL")
+                     else torch.cuda.Stream(device=device))
         D.pvq_noref_bands_multi(luma["jobs"], self.lam)
         D.pvq_choose_multi(luma["jobs"], self.lam)
         self.refs = [D.cfl_refs_from_luma(luma["jobs"][1:], copies=2) for _ in range(2)]
