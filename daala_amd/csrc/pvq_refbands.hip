@@ -983,7 +983,7 @@ __device__ __forceinline__ uint32_t pack_pulses(int s0, int y0, int s1, int y1) 
 template <int E, int G>
 struct RowVector {
   int ax[E];
-  int sg[E];
+  unsigned sg;      /* bit e: coefficient e is negative */
   int y[E];
   int row;
   int l;
@@ -992,16 +992,17 @@ struct RowVector {
   double norm_1;
   __device__ __forceinline__ void load(const int16_t *src, bool pad) {
     const int16_t *p = src + l*E;
+    sg = 0;
 #pragma unroll
     for (int e = 0; e < E; e++) {
       const int v = p[e];
       ax[e] = abs(v);
-      sg[e] = v < 0;
+      sg |= (unsigned)(v < 0) << e;
       y[e] = 0;
     }
     if (pad && l == G - 1) {
       ax[E - 1] = 0;
-      sg[E - 1] = 0;
+      sg &= ~(1u << (E - 1));
     }
     od_row_norm<E, G>(ax, &xx, &norm_1);
   }
@@ -1013,14 +1014,14 @@ struct RowVector {
   __device__ __forceinline__ void store(int16_t *dst) {
     int16_t *p = dst + l*E;
     if constexpr (E == 8) {
-      *reinterpret_cast<uint4 *>(p) = make_uint4(pack_pulses(sg[0], y[0], sg[1], y[1]),
-       pack_pulses(sg[2], y[2], sg[3], y[3]), pack_pulses(sg[4], y[4], sg[5], y[5]),
-       pack_pulses(sg[6], y[6], sg[7], y[7]));
+      *reinterpret_cast<uint4 *>(p) = make_uint4(pack_pulses(sg & 1, y[0], sg & 2, y[1]),
+       pack_pulses(sg & 4, y[2], sg & 8, y[3]), pack_pulses(sg & 16, y[4], sg & 32, y[5]),
+       pack_pulses(sg & 64, y[6], sg & 128, y[7]));
     }
     else {
 #pragma unroll
       for (int e = 0; e < E; e += 2) {
-        *reinterpret_cast<uint32_t *>(p + e) = pack_pulses(sg[e], y[e], sg[e + 1], y[e + 1]);
+        *reinterpret_cast<uint32_t *>(p + e) = pack_pulses(sg & (1u << e), y[e], sg & (2u << e), y[e + 1]);
       }
     }
   }
@@ -1051,12 +1052,13 @@ template <int N>
 struct RegVector {
   static constexpr int SH = N == 15 ? 1 : 0;
   int ax[N];
-  int sg[N];
+  unsigned sg;      /* bit i: coefficient i is negative */
   int y[N];
   double xx;
   double norm_1;
   __device__ __forceinline__ void load(const int16_t *src, bool pad) {
     const uint4 *p = reinterpret_cast<const uint4 *>(src - SH);
+    sg = 0;
     uint32_t w[(N + SH)/2];
 #pragma unroll
     for (int q = 0; q < (N + SH)/8; q++) {
@@ -1070,12 +1072,12 @@ struct RegVector {
     for (int i = 0; i < N; i++) {
       const int t = (int16_t)(w[(i + SH) >> 1] >> (16*((i + SH) & 1)));
       ax[i] = abs(t);
-      sg[i] = t < 0;
+      sg |= (unsigned)(t < 0) << i;
       y[i] = 0;
     }
     if (pad) {
       ax[N - 1] = 0;
-      sg[N - 1] = 0;
+      sg &= ~(1u << (N - 1));
     }
     od_regs_norm<N>(ax, &xx, &norm_1);
   }
@@ -1088,7 +1090,7 @@ struct RegVector {
     int t[N + SH];
     if (SH) t[0] = 0;
 #pragma unroll
-    for (int i = 0; i < N; i++) t[i + SH] = sg[i] ? -y[i] : y[i];
+    for (int i = 0; i < N; i++) t[i + SH] = (sg >> i) & 1 ? -y[i] : y[i];
 #pragma unroll
     for (int q = 0; q < (N + SH)/8; q++) {
       p[q] = make_uint4(pack16(t[8*q], t[8*q + 1]), pack16(t[8*q + 2], t[8*q + 3]),
