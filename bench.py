@@ -486,8 +486,9 @@ def cpu_baseline(qt, chroma_cfl, min_seconds=12.0, max_frames=32):
             "padding + forward pyramid + pvq_theta noref bands + inverse")
     return {"value": blocks / busy, "unit": "blocks/s", "cores": 1, "kind": kind,
             "sample": "%d synthetic 1920x1080 4:2:0 pictures of the bench generator (%d blocks) in "
-                      "%.1f s: %s of every block at every level, reference C functions, single "
-                      "thread" % (nframes, blocks, busy, what)}
+                      "%.1f s: %s of every block at every level, %s, single "
+                      "thread" % (nframes, blocks, busy, what,
+                                  "reference C functions" if kind == "reference" else "oracle port")}
 
 
 def main():
