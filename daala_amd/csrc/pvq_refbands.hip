@@ -321,6 +321,46 @@ __global__ __launch_bounds__(kWave) void k_refb_prep_lane(RItems it) {
       qm[i] = qmp[i];
     }
   }
+  else if (off == 16) {
+    /* band 1: columns 4..7 of rows 0 and 1 - two 16-byte row segments */
+    int4 xr4[2];
+    int4 rr4[2];
+#pragma unroll
+    for (int y = 0; y < 2; y++) {
+      xr4[y] = *reinterpret_cast<const int4 *>(x0 + (long)y*w + 4);
+      rr4[y] = *reinterpret_cast<const int4 *>(r0 + (long)y*w + 4);
+    }
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+      const int sx = OD_SCAN_XY[16 + (i < 8 ? i : 0)][0] - 4;
+      const int sy = OD_SCAN_XY[16 + (i < 8 ? i : 0)][1];
+      const int4 a = xr4[sy & 1];
+      const int4 b = rr4[sy & 1];
+      xv[i] = sx == 0 ? a.x : sx == 1 ? a.y : sx == 2 ? a.z : a.w;
+      rv[i] = sx == 0 ? b.x : sx == 1 ? b.y : sx == 2 ? b.z : b.w;
+      qm[i] = qmp[i];
+    }
+  }
+  else if (off == 24) {
+    /* band 2: columns 0..1 of rows 4..7 - four 8-byte row segments */
+    int2 xr2[4];
+    int2 rr2[4];
+#pragma unroll
+    for (int y = 0; y < 4; y++) {
+      xr2[y] = *reinterpret_cast<const int2 *>(x0 + (long)(4 + y)*w);
+      rr2[y] = *reinterpret_cast<const int2 *>(r0 + (long)(4 + y)*w);
+    }
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+      const int sx = OD_SCAN_XY[24 + (i < 8 ? i : 0)][0];
+      const int sy = OD_SCAN_XY[24 + (i < 8 ? i : 0)][1] - 4;
+      const int2 a = xr2[sy & 3];
+      const int2 b = rr2[sy & 3];
+      xv[i] = sx == 0 ? a.x : a.y;
+      rv[i] = sx == 0 ? b.x : b.y;
+      qm[i] = qmp[i];
+    }
+  }
   else {
 #pragma unroll
     for (int i = 0; i < N; i++) {
