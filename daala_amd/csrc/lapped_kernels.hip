@@ -25,7 +25,7 @@
 #include "../../include/daala_hip.h"
 #include <stdlib.h>
 #include <string.h>
-#include "od_common.cuh"
+#include "od_ctx.cuh"
 #include "od_tile.cuh"
 #include "od_pvq_math.cuh"
 #include "gen/od_scan_tables.h"
@@ -948,10 +948,17 @@ __global__ __launch_bounds__(256) void k_edge_cols(EdgeArgsMulti mm) {
   p[3*a.px_stride] = od_to_px(t3);
 }
 
-/* Scratch for the edge strips; grows on demand, one per process (the library is
-   used with one stream per process in the sharded driver). */
-od_coeff *g_strips = nullptr;
-size_t g_strips_bytes = 0;
+/* Scratch for the edge strips between k_inverse_sb and k_edge_rows / k_edge_cols:
+   owned by the calling thread's current context (od_ctx.cuh), grown on demand.
+   Two inverse calls in flight at once (e.g. the luma and the chroma chain of a
+   step on two streams) must use two contexts. */
+struct LappedState {
+  od_coeff *strips = nullptr;
+  size_t bytes = 0;
+  ~LappedState() {
+    if (strips) (void)hipFree(strips);
+  }
+};
 
 }  // namespace
 
@@ -997,14 +1004,17 @@ int inverse_launch(const InverseArgs *levels, int nlevels, int nplanes, int dec,
   const size_t vs_words = ((size_t)nplanes*nv*h*4 + 3) & ~(size_t)3;
   const size_t hs_words = ((size_t)nplanes*nh*4*w + 3) & ~(size_t)3;
   const size_t need = ((vs_words + hs_words)*nlevels + 4)*sizeof(od_coeff);
-  if (need > g_strips_bytes) {
+  ODHIP_CTX_OR_RETURN(ctx);
+  LappedState &st = *odhip_ctx_state<LappedState>(ctx, ODHIP_SLOT_LAPPED);
+  if (need > st.bytes) {
     ODHIP_TRY(hipStreamSynchronize(s));
-    if (g_strips) ODHIP_TRY(hipFree(g_strips));
-    g_strips = nullptr;
-    g_strips_bytes = 0;
-    ODHIP_TRY(hipMalloc((void **)&g_strips, need));
-    g_strips_bytes = need;
+    if (st.strips) ODHIP_TRY(hipFree(st.strips));
+    st.strips = nullptr;
+    st.bytes = 0;
+    ODHIP_TRY(hipMalloc((void **)&st.strips, need));
+    st.bytes = need;
   }
+  od_coeff *const g_strips = st.strips;
   InverseArgsMulti im;
   EdgeArgsMulti em;
   memset(&im, 0, sizeof(im));
@@ -1041,10 +1051,9 @@ int inverse_launch(InverseArgs ia, int nplanes, int dec, hipStream_t s) {
   return inverse_launch(&ia, 1, nplanes, dec, s);
 }
 
-bool g_inv_tables = false;
+odhip_device_once g_inv_tables;
 
-int upload_inv_tables(void) {
-  if (g_inv_tables) return ODHIP_SUCCESS;
+int upload_inv_tables_now(void) {
   unsigned short packed[OD_SCAN_LEN];
   unsigned char band_of[OD_SCAN_LEN];
   for (int j = 0; j < OD_SCAN_LEN; j++) {
@@ -1055,8 +1064,11 @@ int upload_inv_tables(void) {
   }
   ODHIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(gInvScanXY), packed, sizeof(packed)));
   ODHIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(gInvBandOf), band_of, sizeof(band_of)));
-  g_inv_tables = true;
   return ODHIP_SUCCESS;
+}
+
+int upload_inv_tables(void) {
+  return odhip_once_per_device(g_inv_tables, upload_inv_tables_now);
 }
 
 }  // namespace

@@ -36,7 +36,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <type_traits>
-#include "od_common.cuh"
+#include "od_ctx.cuh"
 #include "od_pvq_math.cuh"
 #include "gen/od_scan_tables.h"
 #include "pvq_search.cuh"
@@ -80,12 +80,14 @@ struct Items {
   int nitems;
   int reserved;
   double lambda;
+  const DJob *jobs;        /* the calling context's device job table [kMaxJobs]   */
+  unsigned *sort;          /* its counting-sort arrays: histogram, bin starts and
+                              cursors, kMaxItems*kKeyBins words each              */
   int wg_start[kMaxItems + 1];
   unsigned char job[kMaxItems];
   unsigned char band[kMaxItems];
 };
 
-__device__ DJob g_jobs[kMaxJobs];
 /* Scan tables.  kScanXY is indexed wave-uniformly by the one-band-per-lane
    preparation kernel (scalar loads); the kernels that index per lane copy
    their table into LDS first - a constant-memory access with 64 different
@@ -289,7 +291,7 @@ __device__ __forceinline__ void od_prep_lane(const DJob &jb, int band, int off, 
 
 __global__ __launch_bounds__(kWave) void k_prep_lane(Items it) {
   const int item = find_item(it, blockIdx.x);
-  const DJob &jb = g_jobs[it.job[item]];
+  const DJob &jb = it.jobs[it.job[item]];
   const int band = it.band[item];
   const int off = jb.off[band];
   const int n = jb.off[band + 1] - off;
@@ -325,7 +327,7 @@ __global__ __launch_bounds__(kWave) void k_prep_corner(Items it) {
   constexpr int NC = C*C;
   constexpr int NBANDS = C == 4 ? 1 : 4;
   const int item = find_item(it, blockIdx.x);
-  const DJob &jb = g_jobs[it.job[item]];
+  const DJob &jb = it.jobs[it.job[item]];
   const BlockPos bp = locate(jb, (long)(blockIdx.x - it.wg_start[item])*kWave + threadIdx.x);
   PrepCtx cx[NBANDS];
 #pragma unroll
@@ -390,7 +392,7 @@ __global__ __launch_bounds__(kWave) void k_prep_wide(Items it) {
   constexpr int E = 8;
   constexpr int n = 16*E;
   const int item = find_item(it, blockIdx.x);
-  const DJob &jb = g_jobs[it.job[item]];
+  const DJob &jb = it.jobs[it.job[item]];
   const int band = it.band[item];
   const int off = jb.off[band];
   const int lane = threadIdx.x;
@@ -443,9 +445,10 @@ __global__ __launch_bounds__(kWave) void k_prep_wide(Items it) {
    one another in memory as well as in pulse count.  Heavy-first matters: one
    wavefront of 128-coefficient bands with K = 90 runs for ~250 us, as long as
    the rest of its launch. */
-__device__ unsigned g_hist[kMaxItems*kKeyBins];      /* zero between calls */
-__device__ unsigned g_binstart[kMaxItems*kKeyBins];
-__device__ unsigned g_cursor[kMaxItems*kKeyBins];
+/* it.sort: histogram (zero between calls), bin starts, cursors. */
+__device__ __forceinline__ unsigned *sort_hist(const Items &it) { return it.sort; }
+__device__ __forceinline__ unsigned *sort_binstart(const Items &it) { return it.sort + kMaxItems*kKeyBins; }
+__device__ __forceinline__ unsigned *sort_cursor(const Items &it) { return it.sort + 2*kMaxItems*kKeyBins; }
 
 __device__ __forceinline__ int item_id(const Items &it, int item) {
   return it.job[item]*ODHIP_MAX_BANDS + it.band[item];
@@ -454,7 +457,7 @@ __device__ __forceinline__ int item_id(const Items &it, int item) {
 __global__ __launch_bounds__(256) void k_hist(Items it) {
   __shared__ unsigned h[kKeyBins];
   const int item = find_item(it, blockIdx.x);
-  const DJob &jb = g_jobs[it.job[item]];
+  const DJob &jb = it.jobs[it.job[item]];
   const unsigned short *keys = jb.keys + (long)it.band[item]*jb.nblocks;
   for (int b = threadIdx.x; b < kKeyBins; b += 256) h[b] = 0;
   __syncthreads();
@@ -462,7 +465,7 @@ __global__ __launch_bounds__(256) void k_hist(Items it) {
   const long end = start + kSortChunk < jb.nblocks ? start + kSortChunk : jb.nblocks;
   for (long i = start + threadIdx.x; i < end; i += 256) atomicAdd(&h[keys[i]], 1u);
   __syncthreads();
-  unsigned *gh = g_hist + item_id(it, item)*kKeyBins;
+  unsigned *gh = sort_hist(it) + item_id(it, item)*kKeyBins;
   for (int b = threadIdx.x; b < kKeyBins; b += 256) {
     if (h[b]) atomicAdd(&gh[b], h[b]);
   }
@@ -473,7 +476,7 @@ __global__ __launch_bounds__(256) void k_hist(Items it) {
 __global__ __launch_bounds__(256) void k_prefix(Items it) {
   __shared__ unsigned part[256];
   const int id = item_id(it, blockIdx.x);
-  unsigned *gh = g_hist + id*kKeyBins;
+  unsigned *gh = sort_hist(it) + id*kKeyBins;
   unsigned c[kKeyBins/256];
   unsigned sum = 0;
   for (int i = 0; i < kKeyBins/256; i++) {
@@ -491,8 +494,8 @@ __global__ __launch_bounds__(256) void k_prefix(Items it) {
   }
   unsigned run = part[threadIdx.x] - sum;
   for (int i = 0; i < kKeyBins/256; i++) {
-    g_binstart[id*kKeyBins + threadIdx.x*(kKeyBins/256) + i] = run;
-    g_cursor[id*kKeyBins + threadIdx.x*(kKeyBins/256) + i] = 0;
+    sort_binstart(it)[id*kKeyBins + threadIdx.x*(kKeyBins/256) + i] = run;
+    sort_cursor(it)[id*kKeyBins + threadIdx.x*(kKeyBins/256) + i] = 0;
     run += c[i];
   }
 }
@@ -500,7 +503,7 @@ __global__ __launch_bounds__(256) void k_prefix(Items it) {
 __global__ __launch_bounds__(256) void k_scatter(Items it) {
   __shared__ unsigned h[kKeyBins];
   const int item = find_item(it, blockIdx.x);
-  const DJob &jb = g_jobs[it.job[item]];
+  const DJob &jb = it.jobs[it.job[item]];
   const long ibase = (long)it.band[item]*jb.nblocks;
   const unsigned short *keys = jb.keys + ibase;
   for (int b = threadIdx.x; b < kKeyBins; b += 256) h[b] = 0;
@@ -520,7 +523,7 @@ __global__ __launch_bounds__(256) void k_scatter(Items it) {
   __syncthreads();
   const int id = item_id(it, item);
   for (int b = threadIdx.x; b < kKeyBins; b += 256) {
-    if (h[b]) h[b] = g_binstart[id*kKeyBins + b] + atomicAdd(&g_cursor[id*kKeyBins + b], h[b]);
+    if (h[b]) h[b] = sort_binstart(it)[id*kKeyBins + b] + atomicAdd(&sort_cursor(it)[id*kKeyBins + b], h[b]);
   }
   __syncthreads();
 #pragma unroll
@@ -574,7 +577,7 @@ __global__ __launch_bounds__(kWave, (S == 2 ? 2 : 1)) void k_search(Items it) {
     for (int i = 0; i < kRsqN/kWave; i++) rsq[i*kWave + lane] = r[i];
   }
   const int item = find_item(it, blockIdx.x);
-  const DJob &jb = g_jobs[it.job[item]];
+  const DJob &jb = it.jobs[it.job[item]];
   const int band = it.band[item];
   const int half = S == 2 ? lane & 1 : 0;
   const int off = jb.off[band] - PAD + half*NL;
@@ -714,7 +717,7 @@ __global__ __launch_bounds__(kWave, (S == 2 ? 2 : 1)) void k_search(Items it) {
    qshift}. */
 __global__ __launch_bounds__(256) void k_choose(Items it) {
   const int item = find_item(it, blockIdx.x);
-  const DJob &jb = g_jobs[it.job[item]];
+  const DJob &jb = it.jobs[it.job[item]];
   const long sb = (long)(blockIdx.x - it.wg_start[item])*256 + threadIdx.x;
   if (sb >= jb.nblocks*jb.nb_bands) return;
   const int band = (int)(sb % jb.nb_bands);
@@ -769,7 +772,7 @@ __global__ __launch_bounds__(256) void k_choose(Items it) {
    src/state.c:1347-1358).  Every store is a coalesced 16-byte row segment. */
 __global__ __launch_bounds__(256) void k_synth(Items it) {
   const int item = find_item(it, blockIdx.x);
-  const DJob &jb = g_jobs[it.job[item]];
+  const DJob &jb = it.jobs[it.job[item]];
   __shared__ short s_inv[32*32];
   __shared__ unsigned char s_band[OD_SCAN_LEN];
   for (int i = threadIdx.x; i < 32*32; i += 256) s_inv[i] = gInvScan[i];
@@ -847,7 +850,7 @@ struct CflOut {
 __global__ __launch_bounds__(256) void k_cfl_ref(Items it, CflOut out) {
   const int item = find_item(it, blockIdx.x);
   const int job = it.job[item];
-  const DJob &jb = g_jobs[job];
+  const DJob &jb = it.jobs[job];
   const int N = 4 << jb.bs;
   const int n = N >> 1;
   const int cw = jb.w >> 1;
@@ -915,7 +918,7 @@ __device__ const short kCflScaling4[4][4] = {
 __global__ __launch_bounds__(256) void k_cfl_ref_tf(Items it, CflOut out) {
   const int item = find_item(it, blockIdx.x);
   const int job = it.job[item];
-  const DJob &jb = g_jobs[job];
+  const DJob &jb = it.jobs[job];
   const int cw = jb.w >> 1;
   const int chh = jb.h >> 1;
   const long t = (long)(blockIdx.x - it.wg_start[item])*256 + threadIdx.x;
@@ -962,10 +965,9 @@ __global__ __launch_bounds__(256) void k_cfl_ref_tf(Items it, CflOut out) {
 }
 
 /* ---- host side ----------------------------------------------------------------- */
-bool g_tables_uploaded = false;
+odhip_device_once g_tables_once;
 
-int upload_tables(void) {
-  if (g_tables_uploaded) return ODHIP_SUCCESS;
+int upload_tables_now(void) {
   short inv[32*32];
   unsigned char band_of[OD_SCAN_LEN];
   for (int i = 0; i < 32*32; i++) inv[i] = -1;
@@ -983,7 +985,63 @@ int upload_tables(void) {
   ODHIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(gBandOf), band_of, sizeof(band_of)));
   k_rsq_fill<<<1, kRsqN, 0, 0>>>();
   ODHIP_TRY(hipDeviceSynchronize());
-  g_tables_uploaded = true;
+  return ODHIP_SUCCESS;
+}
+
+int upload_tables(void) {
+  return odhip_once_per_device(g_tables_once, upload_tables_now);
+}
+
+/* Everything the band stage keeps between calls, owned by the calling thread's
+   current context (od_ctx.cuh): ONE call sequence may be in flight per context. */
+constexpr int kProfSlots = 256;
+struct Scratch {
+  int16_t *x16 = nullptr;
+  size_t x16_cap = 0;     /* elements */
+  unsigned short *keys = nullptr;
+  unsigned *ids = nullptr;
+  size_t band_cap = 0;    /* (band, block) pairs */
+};
+struct BandState {
+  DJob *d_jobs = nullptr;          /* device job table [kMaxJobs]                  */
+  unsigned *d_sort = nullptr;      /* histogram / bin starts / cursors             */
+  Scratch scr;                     /* x16, sort keys, sorted ids; grown on demand  */
+  hipStream_t side[2] = {nullptr, nullptr};   /* kernels that may overlap          */
+  hipEvent_t fork = nullptr;
+  hipEvent_t join[2] = {nullptr, nullptr};
+  bool prof_on = false;            /* odhip_pvq_profile                            */
+  bool prof_made = false;
+  int prof_n = 0;
+  hipEvent_t prof_ev[kProfSlots][2];
+  ~BandState() {
+    if (d_jobs) (void)hipFree(d_jobs);
+    if (d_sort) (void)hipFree(d_sort);
+    if (scr.x16) (void)hipFree(scr.x16);
+    if (scr.keys) (void)hipFree(scr.keys);
+    if (scr.ids) (void)hipFree(scr.ids);
+    for (int i = 0; i < 2; i++) {
+      if (side[i]) (void)hipStreamDestroy(side[i]);
+      if (join[i]) (void)hipEventDestroy(join[i]);
+    }
+    if (fork) (void)hipEventDestroy(fork);
+    if (prof_made) {
+      for (int i = 0; i < kProfSlots; i++) {
+        (void)hipEventDestroy(prof_ev[i][0]);
+        (void)hipEventDestroy(prof_ev[i][1]);
+      }
+    }
+  }
+};
+
+int band_state(BandState **out) {
+  ODHIP_CTX_OR_RETURN(ctx);
+  BandState *st = odhip_ctx_state<BandState>(ctx, ODHIP_SLOT_BANDS);
+  if (!st->d_jobs) {
+    ODHIP_TRY(hipMalloc((void **)&st->d_jobs, sizeof(DJob)*kMaxJobs));
+    ODHIP_TRY(hipMalloc((void **)&st->d_sort, sizeof(unsigned)*3*kMaxItems*kKeyBins));
+    ODHIP_TRY(hipMemset(st->d_sort, 0, sizeof(unsigned)*3*kMaxItems*kKeyBins));
+  }
+  *out = st;
   return ODHIP_SUCCESS;
 }
 
@@ -1043,33 +1101,22 @@ int fill_jobs(const odhip_pvq_job *jobs, int njobs, int mode, DJob *host) {
   return ODHIP_SUCCESS;
 }
 
-int upload_jobs(const DJob *host, int njobs, hipStream_t s) {
+int upload_jobs(BandState &st, const DJob *host, int njobs, hipStream_t s) {
   /* Pageable source: the runtime stages the bytes before returning, so `host`
-     may live on the caller's stack; stream order protects g_jobs itself. */
-  ODHIP_TRY(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_jobs), host, sizeof(DJob)*njobs, 0,
-   hipMemcpyHostToDevice, s));
+     may live on the caller's stack; stream order protects the table itself. */
+  ODHIP_TRY(hipMemcpyAsync(st.d_jobs, host, sizeof(DJob)*njobs, hipMemcpyHostToDevice, s));
   return ODHIP_SUCCESS;
 }
 
-int stage_jobs(const odhip_pvq_job *jobs, int njobs, int mode, DJob *host,
+int stage_jobs(BandState &st, const odhip_pvq_job *jobs, int njobs, int mode, DJob *host,
  hipStream_t s) {
   const int rc = fill_jobs(jobs, njobs, mode, host);
   if (rc) return rc;
-  return upload_jobs(host, njobs, s);
+  return upload_jobs(st, host, njobs, s);
 }
 
-/* Library scratch of the sorted band stage, grown on demand and kept for the
-   life of the process.  One band-stage call may be in flight per process (calls
-   are ordered on the caller's stream). */
-struct Scratch {
-  int16_t *x16;
-  size_t x16_cap;     /* elements */
-  unsigned short *keys;
-  unsigned *ids;
-  size_t band_cap;    /* (band, block) pairs */
-} g_scr = {nullptr, 0, nullptr, nullptr, 0};
-
-int scratch_reserve(size_t x16_elems, size_t band_elems, hipStream_t s) {
+int scratch_reserve(BandState &st, size_t x16_elems, size_t band_elems, hipStream_t s) {
+  Scratch &g_scr = st.scr;
   if (x16_elems > g_scr.x16_cap) {
     ODHIP_TRY(hipStreamSynchronize(s));
     if (g_scr.x16) ODHIP_TRY(hipFree(g_scr.x16));
@@ -1092,40 +1139,38 @@ int scratch_reserve(size_t x16_elems, size_t band_elems, hipStream_t s) {
   return ODHIP_SUCCESS;
 }
 
-/* Side streams for kernels that may overlap (created once per process). */
-hipStream_t g_side[2] = {nullptr, nullptr};
-hipEvent_t g_fork = nullptr;
-hipEvent_t g_join[2] = {nullptr, nullptr};
-
-int fork_streams(hipStream_t s, hipStream_t side[2]) {
+/* Side streams for kernels that may overlap (created once per context). */
+int fork_streams(BandState &st, hipStream_t s, hipStream_t side[2]) {
   if (getenv("ODHIP_PVQ_SERIAL")) return ODHIP_SUCCESS;
-  if (!g_fork) {
-    ODHIP_TRY(hipEventCreateWithFlags(&g_fork, hipEventDisableTiming));
+  if (!st.fork) {
+    ODHIP_TRY(hipEventCreateWithFlags(&st.fork, hipEventDisableTiming));
     for (int i = 0; i < 2; i++) {
-      ODHIP_TRY(hipStreamCreateWithFlags(&g_side[i], hipStreamNonBlocking));
-      ODHIP_TRY(hipEventCreateWithFlags(&g_join[i], hipEventDisableTiming));
+      ODHIP_TRY(hipStreamCreateWithFlags(&st.side[i], hipStreamNonBlocking));
+      ODHIP_TRY(hipEventCreateWithFlags(&st.join[i], hipEventDisableTiming));
     }
   }
-  ODHIP_TRY(hipEventRecord(g_fork, s));
+  ODHIP_TRY(hipEventRecord(st.fork, s));
   for (int i = 0; i < 2; i++) {
-    ODHIP_TRY(hipStreamWaitEvent(g_side[i], g_fork, 0));
-    side[i] = g_side[i];
+    ODHIP_TRY(hipStreamWaitEvent(st.side[i], st.fork, 0));
+    side[i] = st.side[i];
   }
   return ODHIP_SUCCESS;
 }
 
-int join_streams(hipStream_t s, hipStream_t side[2]) {
+int join_streams(BandState &st, hipStream_t s, hipStream_t side[2]) {
   for (int i = 0; i < 2; i++) {
     if (side[i] == s) continue;
-    ODHIP_TRY(hipEventRecord(g_join[i], side[i]));
-    ODHIP_TRY(hipStreamWaitEvent(s, g_join[i], 0));
+    ODHIP_TRY(hipEventRecord(st.join[i], side[i]));
+    ODHIP_TRY(hipStreamWaitEvent(s, st.join[i], 0));
   }
   return ODHIP_SUCCESS;
 }
 
-void items_begin(Items &it, double lambda) {
+void items_begin(Items &it, const BandState &st, double lambda) {
   memset(&it, 0, sizeof(it));
   it.lambda = lambda;
+  it.jobs = st.d_jobs;
+  it.sort = st.d_sort;
   const char *e = getenv("ODHIP_PVQ_FORCE_SEQ");
   it.reserved = e && e[0] == '1';   /* pair-mode search: always take the sequential combine */
 }
@@ -1138,19 +1183,11 @@ void items_add(Items &it, int job, int band, long wgs) {
   it.nitems++;
 }
 
-/* Profiling aid (odhip_pvq_profile): HIP events around the dominant kernel of
-   the band stage, on the stream it is launched on. */
-constexpr int kProfSlots = 256;
-bool g_prof_on = false;
-int g_prof_n = 0;
-hipEvent_t g_prof_ev[kProfSlots][2];
-bool g_prof_made = false;
-
 template <int N, int S, int NB>
-void launch_search(const DJob *host, int njobs, double lambda, hipStream_t s) {
+void launch_search(BandState &st, const DJob *host, int njobs, double lambda, hipStream_t s) {
   constexpr int per_wave = kWave/S*NB;
   Items it;
-  items_begin(it, lambda);
+  items_begin(it, st, lambda);
   for (int j = 0; j < njobs; j++) {
     for (int b = 0; b < host[j].nb_bands; b++) {
       if (host[j].off[b + 1] - host[j].off[b] == N) {
@@ -1160,34 +1197,44 @@ void launch_search(const DJob *host, int njobs, double lambda, hipStream_t s) {
   }
   if (!it.nitems) return;
   constexpr size_t lds = kRsqN*sizeof(double) + (size_t)(N/S)*kPitch*4;
-  const bool prof = N == 128 && g_prof_on && g_prof_n < kProfSlots;
-  if (prof) (void)hipEventRecord(g_prof_ev[g_prof_n][0], s);
+  /* odhip_pvq_profile: HIP events around the dominant kernel of the band stage, on
+     the stream it is launched on */
+  const bool prof = N == 128 && st.prof_on && st.prof_n < kProfSlots;
+  if (prof) (void)hipEventRecord(st.prof_ev[st.prof_n][0], s);
   k_search<N, S, NB><<<it.wg_start[it.nitems], kWave, lds, s>>>(it);
-  if (prof) (void)hipEventRecord(g_prof_ev[g_prof_n++][1], s);
+  if (prof) (void)hipEventRecord(st.prof_ev[st.prof_n++][1], s);
 }
 
 }  // namespace
 
 extern "C" int odhip_pvq_profile(int enable) {
-  if (enable && !g_prof_made) {
+  BandState *stp;
+  int rc = band_state(&stp);
+  if (rc) return rc;
+  BandState &st = *stp;
+  if (enable && !st.prof_made) {
     for (int i = 0; i < kProfSlots; i++) {
-      ODHIP_TRY(hipEventCreate(&g_prof_ev[i][0]));
-      ODHIP_TRY(hipEventCreate(&g_prof_ev[i][1]));
+      ODHIP_TRY(hipEventCreate(&st.prof_ev[i][0]));
+      ODHIP_TRY(hipEventCreate(&st.prof_ev[i][1]));
     }
-    g_prof_made = true;
+    st.prof_made = true;
   }
-  g_prof_on = enable != 0;
-  g_prof_n = 0;
+  st.prof_on = enable != 0;
+  st.prof_n = 0;
   return ODHIP_SUCCESS;
 }
 
 extern "C" int odhip_pvq_profile_read(float *ms, int max_n) {
+  BandState *stp;
+  int rc = band_state(&stp);
+  if (rc) return rc;
+  BandState &st = *stp;
   int n = 0;
-  for (; n < g_prof_n && n < max_n; n++) {
-    ODHIP_TRY(hipEventSynchronize(g_prof_ev[n][1]));
-    ODHIP_TRY(hipEventElapsedTime(&ms[n], g_prof_ev[n][0], g_prof_ev[n][1]));
+  for (; n < st.prof_n && n < max_n; n++) {
+    ODHIP_TRY(hipEventSynchronize(st.prof_ev[n][1]));
+    ODHIP_TRY(hipEventElapsedTime(&ms[n], st.prof_ev[n][0], st.prof_ev[n][1]));
   }
-  g_prof_n = 0;
+  st.prof_n = 0;
   return n;
 }
 
@@ -1202,6 +1249,12 @@ extern "C" int odhip_pvq_band_layout(int bs, int *nb_bands, int *offsets, int *l
 
 extern "C" int odhip_pvq_noref_bands_multi(const odhip_pvq_job *jobs, int njobs,
  double pvq_norm_lambda, odhip_stream stream) {
+  BandState *stp;
+  {
+    const int rc0 = band_state(&stp);
+    if (rc0) return rc0;
+  }
+  BandState &st = *stp;
   hipStream_t s = (hipStream_t)stream;
   const double lambda = pvq_norm_lambda;
   DJob host[kMaxJobs];
@@ -1217,36 +1270,36 @@ extern "C" int odhip_pvq_noref_bands_multi(const odhip_pvq_job *jobs, int njobs,
       if (n != 8 && n != 15 && n != 32 && n != 128) return ODHIP_EINVAL;
     }
   }
-  rc = scratch_reserve(x16_elems, band_elems, s);
+  rc = scratch_reserve(st, x16_elems, band_elems, s);
   if (rc) return rc;
   x16_elems = 0;
   band_elems = 0;
   for (int j = 0; j < njobs; j++) {
-    host[j].x16 = g_scr.x16 + x16_elems;
-    host[j].keys = g_scr.keys + band_elems;
-    host[j].ids = g_scr.ids + band_elems;
+    host[j].x16 = st.scr.x16 + x16_elems;
+    host[j].keys = st.scr.keys + band_elems;
+    host[j].ids = st.scr.ids + band_elems;
     x16_elems += (size_t)host[j].nblocks*host[j].len;
     band_elems += (size_t)host[j].nblocks*host[j].nb_bands;
   }
-  rc = upload_jobs(host, njobs, s);
+  rc = upload_jobs(st, host, njobs, s);
   if (rc) return rc;
   hipStream_t side[2] = {s, s};
-  if (fork_streams(s, side) != ODHIP_SUCCESS) return ODHIP_EFAULT;
+  if (fork_streams(st, s, side) != ODHIP_SUCCESS) return ODHIP_EFAULT;
   Items it;
   /* prep: the low-frequency corner of every block one block per lane (bands
      0..3), the remaining 32-coefficient bands one band per lane, the
      128-coefficient bands one per 16-lane row */
-  items_begin(it, lambda);
+  items_begin(it, st, lambda);
   for (int j = 0; j < njobs; j++) {
     if (host[j].bs == 0) items_add(it, j, 0, (host[j].nblocks + kWave - 1)/kWave);
   }
   if (it.nitems) k_prep_corner<4><<<it.wg_start[it.nitems], kWave, 0, s>>>(it);
-  items_begin(it, lambda);
+  items_begin(it, st, lambda);
   for (int j = 0; j < njobs; j++) {
     if (host[j].bs > 0) items_add(it, j, 0, (host[j].nblocks + kWave - 1)/kWave);
   }
   if (it.nitems) k_prep_corner<8><<<it.wg_start[it.nitems], kWave, 0, s>>>(it);
-  items_begin(it, lambda);
+  items_begin(it, st, lambda);
   for (int j = 0; j < njobs; j++) {
     for (int b = 4; b < host[j].nb_bands; b++) {
       const int n = host[j].off[b + 1] - host[j].off[b];
@@ -1254,18 +1307,18 @@ extern "C" int odhip_pvq_noref_bands_multi(const odhip_pvq_job *jobs, int njobs,
     }
   }
   if (it.nitems) k_prep_lane<<<it.wg_start[it.nitems], kWave, 0, side[1]>>>(it);
-  items_begin(it, lambda);
+  items_begin(it, st, lambda);
   for (int j = 0; j < njobs; j++) {
     for (int b = 0; b < host[j].nb_bands; b++) {
       if (host[j].off[b + 1] - host[j].off[b] == 128) items_add(it, j, b, (host[j].nblocks + 3)/4);
     }
   }
   if (it.nitems) k_prep_wide<<<it.wg_start[it.nitems], kWave, 0, side[0]>>>(it);
-  if (join_streams(s, side) != ODHIP_SUCCESS) return ODHIP_EFAULT;
+  if (join_streams(st, s, side) != ODHIP_SUCCESS) return ODHIP_EFAULT;
   /* counting sort of every item's blocks by pulse class */
   Items all;
-  items_begin(all, lambda);
-  items_begin(it, lambda);
+  items_begin(all, st, lambda);
+  items_begin(it, st, lambda);
   for (int j = 0; j < njobs; j++) {
     for (int b = 0; b < host[j].nb_bands; b++) {
       items_add(it, j, b, (host[j].nblocks + kSortChunk - 1)/kSortChunk);
@@ -1275,36 +1328,40 @@ extern "C" int odhip_pvq_noref_bands_multi(const odhip_pvq_job *jobs, int njobs,
   {
     /* the histograms are consumed and cleared by k_prefix; clear them here as
        well so that a call that failed half way cannot poison the next sort */
-    void *hist = nullptr;
-    ODHIP_TRY(hipGetSymbolAddress(&hist, HIP_SYMBOL(g_hist)));
-    ODHIP_TRY(hipMemsetAsync(hist, 0, sizeof(unsigned)*kMaxItems*kKeyBins, s));
+    ODHIP_TRY(hipMemsetAsync(st.d_sort, 0, sizeof(unsigned)*kMaxItems*kKeyBins, s));
   }
   k_hist<<<it.wg_start[it.nitems], 256, 0, s>>>(it);
   k_prefix<<<all.nitems, 256, 0, s>>>(all);
   k_scatter<<<it.wg_start[it.nitems], 256, 0, s>>>(it);
   /* search: the band sizes are independent launches on forked streams */
-  if (fork_streams(s, side) != ODHIP_SUCCESS) return ODHIP_EFAULT;
-  launch_search<128, 2, 1>(host, njobs, lambda, s);
-  launch_search<32, 1, 1>(host, njobs, lambda, side[0]);
-  launch_search<15, 1, 1>(host, njobs, lambda, side[1]);
-  launch_search<8, 1, 1>(host, njobs, lambda, side[1]);
-  if (join_streams(s, side) != ODHIP_SUCCESS) return ODHIP_EFAULT;
+  if (fork_streams(st, s, side) != ODHIP_SUCCESS) return ODHIP_EFAULT;
+  launch_search<128, 2, 1>(st, host, njobs, lambda, s);
+  launch_search<32, 1, 1>(st, host, njobs, lambda, side[0]);
+  launch_search<15, 1, 1>(st, host, njobs, lambda, side[1]);
+  launch_search<8, 1, 1>(st, host, njobs, lambda, side[1]);
+  if (join_streams(st, s, side) != ODHIP_SUCCESS) return ODHIP_EFAULT;
   return odhip_check_launch();
 }
 
 extern "C" int odhip_pvq_select_synth_noref_multi(const odhip_pvq_job *jobs, int njobs,
  double pvq_norm_lambda, odhip_stream stream) {
+  BandState *stp;
+  {
+    const int rc0 = band_state(&stp);
+    if (rc0) return rc0;
+  }
+  BandState &st = *stp;
   hipStream_t s = (hipStream_t)stream;
   DJob host[kMaxJobs];
-  int rc = stage_jobs(jobs, njobs, 1, host, s);
+  int rc = stage_jobs(st, jobs, njobs, 1, host, s);
   if (rc) return rc;
   Items it;
-  items_begin(it, pvq_norm_lambda);
+  items_begin(it, st, pvq_norm_lambda);
   for (int j = 0; j < njobs; j++) {
     items_add(it, j, 0, (host[j].nblocks*host[j].nb_bands + 255)/256);
   }
   k_choose<<<it.wg_start[it.nitems], 256, 0, s>>>(it);
-  items_begin(it, pvq_norm_lambda);
+  items_begin(it, st, pvq_norm_lambda);
   for (int j = 0; j < njobs; j++) {
     items_add(it, j, 0, (long)host[j].nplanes*host[j].h*((host[j].w + 1023) >> 10));
   }
@@ -1314,12 +1371,18 @@ extern "C" int odhip_pvq_select_synth_noref_multi(const odhip_pvq_job *jobs, int
 
 extern "C" int odhip_pvq_choose_multi(const odhip_pvq_job *jobs, int njobs,
  double pvq_norm_lambda, odhip_stream stream) {
+  BandState *stp;
+  {
+    const int rc0 = band_state(&stp);
+    if (rc0) return rc0;
+  }
+  BandState &st = *stp;
   hipStream_t s = (hipStream_t)stream;
   DJob host[kMaxJobs];
-  int rc = stage_jobs(jobs, njobs, 2, host, s);
+  int rc = stage_jobs(st, jobs, njobs, 2, host, s);
   if (rc) return rc;
   Items it;
-  items_begin(it, pvq_norm_lambda);
+  items_begin(it, st, pvq_norm_lambda);
   for (int j = 0; j < njobs; j++) {
     items_add(it, j, 0, (host[j].nblocks*host[j].nb_bands + 255)/256);
   }
@@ -1329,6 +1392,12 @@ extern "C" int odhip_pvq_choose_multi(const odhip_pvq_job *jobs, int njobs,
 
 extern "C" int odhip_cfl_refs_from_luma(const odhip_pvq_job *luma_jobs, int njobs,
  od_coeff *const *d_ref, int copies, odhip_stream stream) {
+  BandState *stp;
+  {
+    const int rc0 = band_state(&stp);
+    if (rc0) return rc0;
+  }
+  BandState &st = *stp;
   hipStream_t s = (hipStream_t)stream;
   if (!d_ref || copies < 1 || copies > 4) return ODHIP_EINVAL;
   DJob host[kMaxJobs];
@@ -1338,7 +1407,7 @@ extern "C" int odhip_cfl_refs_from_luma(const odhip_pvq_job *luma_jobs, int njob
   memset(&out, 0, sizeof(out));
   out.copies = copies;
   Items it;
-  items_begin(it, 0.);
+  items_begin(it, st, 0.);
   for (int j = 0; j < njobs; j++) {
     if (!d_ref[j] || !luma_jobs[j].d_qm_inv || (host[j].w & 7) || (host[j].h & 7)) return ODHIP_EINVAL;
     out.ref[j] = d_ref[j];
@@ -1353,11 +1422,11 @@ extern "C" int odhip_cfl_refs_from_luma(const odhip_pvq_job *luma_jobs, int njob
       }
     }
   }
-  rc = upload_jobs(host, njobs, s);
+  rc = upload_jobs(st, host, njobs, s);
   if (rc) return rc;
   if (it.nitems) k_cfl_ref<<<it.wg_start[it.nitems], 256, 0, s>>>(it, out);
   /* level-0 jobs: the TF branch */
-  items_begin(it, 0.);
+  items_begin(it, st, 0.);
   for (int j = 0; j < njobs; j++) {
     if (host[j].bs == 0) {
       items_add(it, j, 0, ((long)host[j].nplanes*(host[j].w >> 1)*(host[j].h >> 1) + 255)/256);

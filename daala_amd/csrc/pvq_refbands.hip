@@ -40,7 +40,7 @@
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
-#include "od_common.cuh"
+#include "od_ctx.cuh"
 #include "od_pvq_math.cuh"
 #include "gen/od_scan_tables.h"
 #define OD_RSQ_TABLE_N 512
@@ -50,14 +50,11 @@
 
 namespace {
 
-/* Two CONTEXTS: independent calls (e.g. the Cb and the Cr planes of a batch on two
-   streams) may be in flight at once, one per context.  A context owns half of the
-   device job table (kJobsPerCtx slots; it.job[] holds the absolute slot, so the
-   kernels and the per-(job, band) sort arrays need no context argument), its
-   uncertainty list, its scratch, its side streams and its pinned counter. */
-constexpr int kCtx = 2;
-constexpr int kJobsPerCtx = 8;
-constexpr int kMaxJobs = kCtx*kJobsPerCtx;
+/* All state between calls (device job table, uncertainty list, sort arrays, scratch,
+   side streams, pinned counter) belongs to the calling thread's current context
+   (od_ctx.cuh): independent call sequences (e.g. the Cb and the Cr planes of a
+   batch on two streams) run in two contexts. */
+constexpr int kMaxJobs = 8;
 constexpr int kMaxItems = kMaxJobs*ODHIP_MAX_BANDS;
 constexpr int kSlots = ODHIP_PVQ_REF_SLOTS;
 constexpr int kUncCap = 1 << 16;
@@ -96,11 +93,17 @@ struct RJob {
   int off[ODHIP_MAX_BANDS + 1];
 };
 
+struct Unc;
 struct RItems {
   int nitems;
   int perturb;
   double lambda;
   double margin;
+  const RJob *jobs;        /* the context's device job table [kMaxJobs]            */
+  unsigned *unc_count;     /* its uncertainty list: counter ...                    */
+  Unc *unc;                /* ... and entries [kUncCap]                            */
+  unsigned *rhist;         /* counting sort: histogram (zero between calls) ...    */
+  unsigned *rcursor;       /* ... and cursors, kMaxItems*kSortBins words each      */
   int wg_start[kMaxItems + 1];
   unsigned char job[kMaxItems];
   unsigned char band[kMaxItems];
@@ -116,10 +119,7 @@ struct Unc {
   double corr;
 };
 
-__device__ RJob g_rjobs[kMaxJobs];
 __constant__ unsigned char kRScanXY[OD_SCAN_LEN][2];
-__device__ unsigned g_unc_count[kCtx];
-__device__ Unc g_unc[kCtx][kUncCap];
 
 __device__ __forceinline__ int find_item(const RItems &it, int wg) {
   int lo = 0;
@@ -234,8 +234,7 @@ __device__ __forceinline__ void prep_write(const RItems &it, odhip_pvq_refband *
     if (fabs(u - rint(u)) < it.margin) {
       flags |= ODHIP_REFBAND_UNCERTAIN;
       if (it.perturb & 1) theta += 1;
-      const int ctx = job/kJobsPerCtx;
-      const unsigned slot = atomicAdd(&g_unc_count[ctx], 1u);
+      const unsigned slot = atomicAdd(it.unc_count, 1u);
       if (slot < (unsigned)kUncCap) {
         Unc e;
         e.job = job;
@@ -243,7 +242,7 @@ __device__ __forceinline__ void prep_write(const RItems &it, odhip_pvq_refband *
         e.blk = (unsigned)blk;
         e.theta = theta;
         e.corr = p.corr;
-        g_unc[ctx][slot] = e;
+        it.unc[slot] = e;
       }
     }
   }
@@ -276,7 +275,7 @@ template <int N>
 __global__ __launch_bounds__(kWave) void k_refb_prep_lane(RItems it) {
   const int item = find_item(it, blockIdx.x);
   const int job = it.job[item];
-  const RJob &jb = g_rjobs[job];
+  const RJob &jb = it.jobs[job];
   const int band = it.band[item];
   const long blk = (long)(blockIdx.x - it.wg_start[item])*kWave + threadIdx.x;
   if (blk >= jb.nblocks) return;
@@ -499,7 +498,7 @@ __global__ __launch_bounds__(kWave) void k_refb_prep_row(RItems it) {
   __shared__ unsigned short s_scan[n];
   const int item = find_item(it, blockIdx.x);
   const int job = it.job[item];
-  const RJob &jb = g_rjobs[job];
+  const RJob &jb = it.jobs[job];
   const int band = it.band[item];
   const int off = jb.off[band];
   const int lane = threadIdx.x;
@@ -695,8 +694,6 @@ __device__ __forceinline__ int od_work_bin(int pulses) {   /* 0..kSortBins-1, mo
   return b < kSortBins ? b : kSortBins - 1;
 }
 
-__device__ unsigned g_rhist[kMaxItems*kSortBins];     /* zero between calls */
-__device__ unsigned g_rcursor[kMaxItems*kSortBins];
 
 __device__ __forceinline__ int item_slot(const RItems &it, int item) {
   return it.job[item]*ODHIP_MAX_BANDS + it.band[item];
@@ -705,7 +702,7 @@ __device__ __forceinline__ int item_slot(const RItems &it, int item) {
 __global__ __launch_bounds__(256) void k_refb_hist(RItems it) {
   __shared__ unsigned h[kSortBins];
   const int item = find_item(it, blockIdx.x);
-  const RJob &jb = g_rjobs[it.job[item]];
+  const RJob &jb = it.jobs[it.job[item]];
   const long nblocks = jb.nblocks;
   const unsigned short *keys = jb.keys + (long)it.band[item]*nblocks;
   h[threadIdx.x] = 0;
@@ -717,7 +714,7 @@ __global__ __launch_bounds__(256) void k_refb_hist(RItems it) {
   }
   __syncthreads();
   const unsigned c = h[threadIdx.x];
-  if (c) atomicAdd(&g_rhist[item_slot(it, item)*kSortBins + threadIdx.x], c);
+  if (c) atomicAdd(&it.rhist[item_slot(it, item)*kSortBins + threadIdx.x], c);
 }
 
 /* One workgroup per item: exclusive prefix over the classes -> start cursors;
@@ -725,8 +722,8 @@ __global__ __launch_bounds__(256) void k_refb_hist(RItems it) {
 __global__ __launch_bounds__(256) void k_refb_prefix(RItems it) {
   __shared__ unsigned h[kSortBins];
   const int slot = item_slot(it, blockIdx.x);
-  h[threadIdx.x] = g_rhist[slot*kSortBins + threadIdx.x];
-  g_rhist[slot*kSortBins + threadIdx.x] = 0;
+  h[threadIdx.x] = it.rhist[slot*kSortBins + threadIdx.x];
+  it.rhist[slot*kSortBins + threadIdx.x] = 0;
   __syncthreads();
   if (threadIdx.x == 0) {
     unsigned acc = 0;
@@ -737,14 +734,14 @@ __global__ __launch_bounds__(256) void k_refb_prefix(RItems it) {
     }
   }
   __syncthreads();
-  g_rcursor[slot*kSortBins + threadIdx.x] = h[threadIdx.x];
+  it.rcursor[slot*kSortBins + threadIdx.x] = h[threadIdx.x];
 }
 
 __global__ __launch_bounds__(256) void k_refb_scatter(RItems it) {
   __shared__ unsigned h[kSortBins];
   __shared__ unsigned base[kSortBins];
   const int item = find_item(it, blockIdx.x);
-  const RJob &jb = g_rjobs[it.job[item]];
+  const RJob &jb = it.jobs[it.job[item]];
   const long nblocks = jb.nblocks;
   const unsigned short *keys = jb.keys + (long)it.band[item]*nblocks;
   unsigned *ids = jb.ids + (long)it.band[item]*nblocks;
@@ -764,7 +761,7 @@ __global__ __launch_bounds__(256) void k_refb_scatter(RItems it) {
   }
   __syncthreads();
   const unsigned c = h[threadIdx.x];
-  base[threadIdx.x] = c ? atomicAdd(&g_rcursor[item_slot(it, item)*kSortBins + threadIdx.x], c) : 0;
+  base[threadIdx.x] = c ? atomicAdd(&it.rcursor[item_slot(it, item)*kSortBins + threadIdx.x], c) : 0;
   __syncthreads();
 #pragma unroll
   for (int t = 0; t < kSortChunk/256; t++) {
@@ -840,17 +837,17 @@ __device__ __forceinline__ void refb_candidates(const RJob &jb, int band, long b
 
 __global__ __launch_bounds__(kWave) void k_refb_cands(RItems it) {
   const int item = find_item(it, blockIdx.x);
-  const RJob &jb = g_rjobs[it.job[item]];
+  const RJob &jb = it.jobs[it.job[item]];
   const long blk = (long)(blockIdx.x - it.wg_start[item])*kWave + threadIdx.x;
   if (blk >= jb.nblocks) return;
   refb_candidates(jb, it.band[item], blk, -1);
 }
 
-__global__ __launch_bounds__(kWave) void k_refb_cands_list(const Unc *list, int count) {
+__global__ __launch_bounds__(kWave) void k_refb_cands_list(const RJob *jobs, const Unc *list, int count) {
   const int i = blockIdx.x*kWave + threadIdx.x;
   if (i >= count) return;
   const Unc e = list[i];
-  refb_candidates(g_rjobs[e.job], e.band, e.blk, e.theta);
+  refb_candidates(jobs[e.job], e.band, e.blk, e.theta);
 }
 
 /* ---- the candidate loops -----------------------------------------------------------
@@ -991,7 +988,7 @@ __global__ __launch_bounds__(kWave) void k_refb_search(RItems it) {
   extern __shared__ __attribute__((aligned(16))) unsigned short lds[];
   od_rsqrt_init(threadIdx.x);
   const int item = find_item(it, blockIdx.x);
-  const RJob &jb = g_rjobs[it.job[item]];
+  const RJob &jb = it.jobs[it.job[item]];
   const int band = it.band[item];
   const int n = jb.off[band + 1] - jb.off[band];
   const long pos = (long)(blockIdx.x - it.wg_start[item])*kWave + threadIdx.x;
@@ -1002,12 +999,13 @@ __global__ __launch_bounds__(kWave) void k_refb_search(RItems it) {
 }
 
 /* One listed band per wavefront (lane 0): the list is a handful of bands. */
-__global__ __launch_bounds__(kWave) void k_refb_search_list(const Unc *list, int count, double lambda) {
+__global__ __launch_bounds__(kWave) void k_refb_search_list(const RJob *jobs, const Unc *list, int count,
+ double lambda) {
   extern __shared__ __attribute__((aligned(16))) unsigned short lds[];
   od_rsqrt_init(threadIdx.x);
   if (threadIdx.x != 0 || (int)blockIdx.x >= count) return;
   const Unc e = list[blockIdx.x];
-  const RJob &jb = g_rjobs[e.job];
+  const RJob &jb = jobs[e.job];
   LdsVector v = {(short *)lds, lds + 128*kWave, 0, jb.off[e.band + 1] - jb.off[e.band], 0};
   refb_loops(jb, e.band, e.blk, true, true, lambda, v);
 }
@@ -1071,7 +1069,7 @@ template <int E, int G>
 __global__ __launch_bounds__(kWave) void k_refb_search_row(RItems it) {
   od_rsqrt_init(threadIdx.x);
   const int item = find_item(it, blockIdx.x);
-  const RJob &jb = g_rjobs[it.job[item]];
+  const RJob &jb = it.jobs[it.job[item]];
   const int lane = threadIdx.x;
   RowVector<E, G> v;
   v.row = lane/G;
@@ -1143,7 +1141,7 @@ template <int N>
 __global__ __launch_bounds__(kWave) void k_refb_search_regs(RItems it) {
   od_rsqrt_init(threadIdx.x);
   const int item = find_item(it, blockIdx.x);
-  const RJob &jb = g_rjobs[it.job[item]];
+  const RJob &jb = it.jobs[it.job[item]];
   const long pos = (long)(blockIdx.x - it.wg_start[item])*kWave + threadIdx.x;
   if (pos >= jb.nblocks) return;
   const long blk = jb.ids[(long)it.band[item]*jb.nblocks + pos];
@@ -1180,7 +1178,7 @@ __global__ __launch_bounds__(kWave) void k_refb_choose(RItems it) {
   constexpr int SH = N == 15 ? 1 : 0;     /* the 15-coefficient band is read from the DC slot on */
   constexpr int NW = (N + SH)/2;
   const int item = find_item(it, blockIdx.x);
-  const RJob &jb = g_rjobs[it.job[item]];
+  const RJob &jb = it.jobs[it.job[item]];
   const int band = it.band[item];
   const long blk = (long)(blockIdx.x - it.wg_start[item])*kWave + threadIdx.x;
   if (blk >= jb.nblocks) return;
@@ -1330,7 +1328,7 @@ __global__ __launch_bounds__(kWave) void k_refb_choose(RItems it) {
    Pulses, reference, inverse QM and scan positions are 16-byte loads. */
 __global__ __launch_bounds__(256) void k_refb_synth(RItems it) {
   const int item = find_item(it, blockIdx.x);
-  const RJob &jb = g_rjobs[it.job[item]];
+  const RJob &jb = it.jobs[it.job[item]];
   const int len = jb.len;
   const int cpb = len >> 3;                       /* chunks per block */
   const long t = (long)(blockIdx.x - it.wg_start[item])*256 + threadIdx.x;
@@ -1417,12 +1415,12 @@ __global__ __launch_bounds__(256) void k_refb_synth(RItems it) {
 }
 
 /* ---- host side --------------------------------------------------------------------- */
-bool g_tables_uploaded = false;
+odhip_device_once g_tables_once;
+/* test hooks (odhip_pvq_ref_set_theta_margin): process-wide, set before any call */
 double g_margin = kDefaultMargin;
 int g_perturb = 0;
 
-int upload_tables(void) {
-  if (g_tables_uploaded) return ODHIP_SUCCESS;
+int upload_tables_now(void) {
   ODHIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(kRScanXY), OD_SCAN_XY, sizeof(OD_SCAN_XY)));
   unsigned short packed[OD_SCAN_LEN];
   for (int j = 0; j < OD_SCAN_LEN; j++) packed[j] = (unsigned short)(OD_SCAN_XY[j][1] << 8 | OD_SCAN_XY[j][0]);
@@ -1436,8 +1434,11 @@ int upload_tables(void) {
   ODHIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(gRBandOf), band_of, sizeof(band_of)));
   od_rsqrt_fill_launch();
   ODHIP_TRY(hipDeviceSynchronize());
-  g_tables_uploaded = true;
   return ODHIP_SUCCESS;
+}
+
+int upload_tables(void) {
+  return odhip_once_per_device(g_tables_once, upload_tables_now);
 }
 
 /* mode 0: band stage; 1: choice + synthesis */
@@ -1495,20 +1496,75 @@ int fill_job(RJob &d, const odhip_pvq_refjob &j, int mode) {
   return ODHIP_SUCCESS;
 }
 
-thread_local int t_ctx = 0;     /* context of the calling thread's next calls */
+/* Everything the stage keeps between calls, owned by the calling thread's current
+   context: ONE call sequence (bands -> resolve -> choice / synthesis) may be in
+   flight per context. */
+constexpr int kProfSlots = 256;
+struct RefState {
+  RJob *d_jobs = nullptr;            /* device job table [kMaxJobs]                 */
+  unsigned *d_unc_count = nullptr;   /* bands inside the theta margin: counter ...  */
+  Unc *d_unc = nullptr;              /* ... and list [kUncCap]                      */
+  unsigned *d_sort = nullptr;        /* histogram + cursors of the counting sort    */
+  unsigned short *keys = nullptr;    /* sort keys / sorted block indices of every   */
+  unsigned *ids = nullptr;           /* (band, block) pair; grown on demand         */
+  size_t cap = 0;
+  hipStream_t side[2] = {nullptr, nullptr};   /* searches of the four band sizes    */
+  hipEvent_t fork = nullptr;
+  hipEvent_t join[2] = {nullptr, nullptr};
+  unsigned *unc_host = nullptr;      /* pinned mirror of the counter                */
+  hipEvent_t unc_event = nullptr;
+  bool prof_on = false;              /* odhip_pvq_ref_profile                       */
+  bool prof_made = false;
+  int prof_n = 0;
+  hipEvent_t prof_ev[kProfSlots][2];
+  ~RefState() {
+    if (d_jobs) (void)hipFree(d_jobs);
+    if (d_unc_count) (void)hipFree(d_unc_count);
+    if (d_unc) (void)hipFree(d_unc);
+    if (d_sort) (void)hipFree(d_sort);
+    if (keys) (void)hipFree(keys);
+    if (ids) (void)hipFree(ids);
+    for (int i = 0; i < 2; i++) {
+      if (side[i]) (void)hipStreamDestroy(side[i]);
+      if (join[i]) (void)hipEventDestroy(join[i]);
+    }
+    if (fork) (void)hipEventDestroy(fork);
+    if (unc_host) (void)hipHostFree(unc_host);
+    if (unc_event) (void)hipEventDestroy(unc_event);
+    if (prof_made) {
+      for (int i = 0; i < kProfSlots; i++) {
+        (void)hipEventDestroy(prof_ev[i][0]);
+        (void)hipEventDestroy(prof_ev[i][1]);
+      }
+    }
+  }
+};
 
-/* Library scratch of the sorted searches (keys, sorted block indices), grown on
-   demand and kept for the life of the process.  One band-stage call may be in
-   flight per process. */
-struct RScratch {
-  unsigned short *keys;
-  unsigned *ids;
-  size_t cap;    /* (band, block) pairs */
-} g_rscr_all[kCtx] = {{nullptr, nullptr, 0}, {nullptr, nullptr, 0}};
-#define g_rscr g_rscr_all[t_ctx]
+int ref_state(RefState **out) {
+  ODHIP_CTX_OR_RETURN(ctx);
+  RefState *st = odhip_ctx_state<RefState>(ctx, ODHIP_SLOT_REFBANDS);
+  if (!st->d_jobs) {
+    ODHIP_TRY(hipMalloc((void **)&st->d_jobs, sizeof(RJob)*kMaxJobs));
+    ODHIP_TRY(hipMalloc((void **)&st->d_unc_count, sizeof(unsigned)));
+    ODHIP_TRY(hipMalloc((void **)&st->d_unc, sizeof(Unc)*kUncCap));
+    ODHIP_TRY(hipMalloc((void **)&st->d_sort, sizeof(unsigned)*2*kMaxItems*kSortBins));
+    ODHIP_TRY(hipMemset(st->d_unc_count, 0, sizeof(unsigned)));
+    ODHIP_TRY(hipMemset(st->d_sort, 0, sizeof(unsigned)*2*kMaxItems*kSortBins));
+  }
+  *out = st;
+  return ODHIP_SUCCESS;
+}
+#define REF_STATE_OR_RETURN(st) \
+  RefState *st##_p; \
+  { \
+    const int rc0_ = ref_state(&st##_p); \
+    if (rc0_) return rc0_; \
+  } \
+  RefState &st = *st##_p
 
-int stage_jobs(const odhip_pvq_refjob *jobs, int njobs, int mode, RJob *host, hipStream_t s) {
-  if (!jobs || njobs <= 0 || njobs > kJobsPerCtx) return ODHIP_EINVAL;
+int stage_jobs(RefState &st, const odhip_pvq_refjob *jobs, int njobs, int mode, RJob *host,
+ hipStream_t s) {
+  if (!jobs || njobs <= 0 || njobs > kMaxJobs) return ODHIP_EINVAL;
   int rc = upload_tables();
   if (rc) return rc;
   size_t pairs = 0;
@@ -1518,47 +1574,51 @@ int stage_jobs(const odhip_pvq_refjob *jobs, int njobs, int mode, RJob *host, hi
     pairs += (size_t)host[i].nblocks*host[i].nb_bands;
   }
   if (mode == 0) {
-    if (pairs > g_rscr.cap) {
+    if (pairs > st.cap) {
       ODHIP_TRY(hipStreamSynchronize(s));
-      if (g_rscr.keys) ODHIP_TRY(hipFree(g_rscr.keys));
-      if (g_rscr.ids) ODHIP_TRY(hipFree(g_rscr.ids));
-      g_rscr.keys = nullptr;
-      g_rscr.ids = nullptr;
-      g_rscr.cap = 0;
-      ODHIP_TRY(hipMalloc((void **)&g_rscr.keys, pairs*sizeof(unsigned short)));
-      ODHIP_TRY(hipMalloc((void **)&g_rscr.ids, pairs*sizeof(unsigned)));
-      g_rscr.cap = pairs;
+      if (st.keys) ODHIP_TRY(hipFree(st.keys));
+      if (st.ids) ODHIP_TRY(hipFree(st.ids));
+      st.keys = nullptr;
+      st.ids = nullptr;
+      st.cap = 0;
+      ODHIP_TRY(hipMalloc((void **)&st.keys, pairs*sizeof(unsigned short)));
+      ODHIP_TRY(hipMalloc((void **)&st.ids, pairs*sizeof(unsigned)));
+      st.cap = pairs;
     }
     pairs = 0;
     for (int i = 0; i < njobs; i++) {
-      host[i].keys = g_rscr.keys + pairs;
-      host[i].ids = g_rscr.ids + pairs;
+      host[i].keys = st.keys + pairs;
+      host[i].ids = st.ids + pairs;
       pairs += (size_t)host[i].nblocks*host[i].nb_bands;
     }
   }
-  ODHIP_TRY(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_rjobs), host, sizeof(RJob)*njobs,
-   sizeof(RJob)*kJobsPerCtx*t_ctx, hipMemcpyHostToDevice, s));
+  ODHIP_TRY(hipMemcpyAsync(st.d_jobs, host, sizeof(RJob)*njobs, hipMemcpyHostToDevice, s));
   return ODHIP_SUCCESS;
 }
 
-void items_begin(RItems &it, double lambda) {
+void items_begin(RItems &it, const RefState &st, double lambda) {
   memset(&it, 0, sizeof(it));
   it.lambda = lambda;
   it.margin = g_margin;
   it.perturb = g_perturb;
+  it.jobs = st.d_jobs;
+  it.unc_count = st.d_unc_count;
+  it.unc = st.d_unc;
+  it.rhist = st.d_sort;
+  it.rcursor = st.d_sort + kMaxItems*kSortBins;
 }
 
 void items_add(RItems &it, int job, int band, long wgs) {
   if (wgs <= 0) return;
-  it.job[it.nitems] = (unsigned char)(kJobsPerCtx*t_ctx + job);
+  it.job[it.nitems] = (unsigned char)job;
   it.band[it.nitems] = (unsigned char)band;
   it.wg_start[it.nitems + 1] = it.wg_start[it.nitems] + (int)wgs;
   it.nitems++;
 }
 
 /* All (job, band) items; n_only > 0 keeps the bands of that size. */
-void items_all(RItems &it, const RJob *host, int njobs, double lambda, int n_only) {
-  items_begin(it, lambda);
+void items_all(RItems &it, const RefState &st, const RJob *host, int njobs, double lambda, int n_only) {
+  items_begin(it, st, lambda);
   for (int j = 0; j < njobs; j++) {
     for (int b = 0; b < host[j].nb_bands; b++) {
       if (n_only > 0 && host[j].off[b + 1] - host[j].off[b] != n_only) continue;
@@ -1569,70 +1629,59 @@ void items_all(RItems &it, const RJob *host, int njobs, double lambda, int n_onl
 
 /* Side streams for the searches of the four band sizes (independent launches;
    the no-reference stage measured the same fork at 1.40 -> 1.19 ms). */
-hipStream_t g_rside_all[kCtx][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
-hipEvent_t g_rfork_all[kCtx] = {nullptr, nullptr};
-hipEvent_t g_rjoin_all[kCtx][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
-#define g_rside g_rside_all[t_ctx]
-#define g_rfork g_rfork_all[t_ctx]
-#define g_rjoin g_rjoin_all[t_ctx]
-
-int rfork(hipStream_t s, hipStream_t side[2]) {
+int rfork(RefState &st, hipStream_t s, hipStream_t side[2]) {
   if (getenv("ODHIP_PVQ_SERIAL")) return ODHIP_SUCCESS;
-  if (!g_rfork) {
-    ODHIP_TRY(hipEventCreateWithFlags(&g_rfork, hipEventDisableTiming));
+  if (!st.fork) {
+    ODHIP_TRY(hipEventCreateWithFlags(&st.fork, hipEventDisableTiming));
     for (int i = 0; i < 2; i++) {
-      ODHIP_TRY(hipStreamCreateWithFlags(&g_rside[i], hipStreamNonBlocking));
-      ODHIP_TRY(hipEventCreateWithFlags(&g_rjoin[i], hipEventDisableTiming));
+      ODHIP_TRY(hipStreamCreateWithFlags(&st.side[i], hipStreamNonBlocking));
+      ODHIP_TRY(hipEventCreateWithFlags(&st.join[i], hipEventDisableTiming));
     }
   }
-  ODHIP_TRY(hipEventRecord(g_rfork, s));
+  ODHIP_TRY(hipEventRecord(st.fork, s));
   for (int i = 0; i < 2; i++) {
-    ODHIP_TRY(hipStreamWaitEvent(g_rside[i], g_rfork, 0));
-    side[i] = g_rside[i];
+    ODHIP_TRY(hipStreamWaitEvent(st.side[i], st.fork, 0));
+    side[i] = st.side[i];
   }
   return ODHIP_SUCCESS;
 }
 
-int rjoin(hipStream_t s, hipStream_t side[2]) {
+int rjoin(RefState &st, hipStream_t s, hipStream_t side[2]) {
   for (int i = 0; i < 2; i++) {
     if (side[i] == s) continue;
-    ODHIP_TRY(hipEventRecord(g_rjoin[i], side[i]));
-    ODHIP_TRY(hipStreamWaitEvent(s, g_rjoin[i], 0));
+    ODHIP_TRY(hipEventRecord(st.join[i], side[i]));
+    ODHIP_TRY(hipStreamWaitEvent(s, st.join[i], 0));
   }
   return ODHIP_SUCCESS;
 }
-
-/* Profiling aid (odhip_pvq_ref_profile): HIP events around the dominant kernel of
-   the stage - the row-parallel search of the 128-coefficient bands - on the
-   stream it is launched on. */
-constexpr int kProfSlots = 256;
-bool g_prof_on = false;
-bool g_prof_made = false;
-int g_prof_n = 0;
-hipEvent_t g_prof_ev[kProfSlots][2];
 
 }  // namespace
 
+/* Profiling aid: HIP events around the dominant kernel of the stage - the
+   row-parallel search of the 128-coefficient bands - on the stream it is launched
+   on, for the calls of the current context. */
 extern "C" int odhip_pvq_ref_profile(int enable) {
-  if (enable && !g_prof_made) {
+  REF_STATE_OR_RETURN(st);
+  if (enable && !st.prof_made) {
     for (int i = 0; i < kProfSlots; i++) {
-      ODHIP_TRY(hipEventCreate(&g_prof_ev[i][0]));
-      ODHIP_TRY(hipEventCreate(&g_prof_ev[i][1]));
+      ODHIP_TRY(hipEventCreate(&st.prof_ev[i][0]));
+      ODHIP_TRY(hipEventCreate(&st.prof_ev[i][1]));
     }
-    g_prof_made = true;
+    st.prof_made = true;
   }
-  g_prof_on = enable != 0;
-  g_prof_n = 0;
+  st.prof_on = enable != 0;
+  st.prof_n = 0;
   return ODHIP_SUCCESS;
 }
 
 extern "C" int odhip_pvq_ref_profile_read(float *ms, int max_n) {
+  REF_STATE_OR_RETURN(st);
   int n = 0;
-  for (; n < g_prof_n && n < max_n; n++) {
-    ODHIP_TRY(hipEventSynchronize(g_prof_ev[n][1]));
-    ODHIP_TRY(hipEventElapsedTime(&ms[n], g_prof_ev[n][0], g_prof_ev[n][1]));
+  for (; n < st.prof_n && n < max_n; n++) {
+    ODHIP_TRY(hipEventSynchronize(st.prof_ev[n][1]));
+    ODHIP_TRY(hipEventElapsedTime(&ms[n], st.prof_ev[n][0], st.prof_ev[n][1]));
   }
-  g_prof_n = 0;
+  st.prof_n = 0;
   return n;
 }
 
@@ -1652,32 +1701,26 @@ extern "C" int odhip_pvq_ref_theta_probe(const double *d_corr, double *d_t, long
 extern "C" int odhip_pvq_ref_bands_multi(const odhip_pvq_refjob *jobs, int njobs,
  double pvq_norm_lambda, odhip_stream stream) {
   hipStream_t s = (hipStream_t)stream;
+  REF_STATE_OR_RETURN(st);
   RJob host[kMaxJobs];
-  int rc = stage_jobs(jobs, njobs, 0, host, s);
+  int rc = stage_jobs(st, jobs, njobs, 0, host, s);
   if (rc) return rc;
-  void *cnt = nullptr;
-  ODHIP_TRY(hipGetSymbolAddress(&cnt, HIP_SYMBOL(g_unc_count)));
-  ODHIP_TRY(hipMemsetAsync((unsigned *)cnt + t_ctx, 0, sizeof(unsigned), s));
-  {
-    /* consumed and cleared by k_refb_prefix; cleared here as well (this context's
-       slice) so that a call that failed half way cannot poison the next sort */
-    void *hist = nullptr;
-    ODHIP_TRY(hipGetSymbolAddress(&hist, HIP_SYMBOL(g_rhist)));
-    const size_t slice = (size_t)kJobsPerCtx*ODHIP_MAX_BANDS*kSortBins;
-    ODHIP_TRY(hipMemsetAsync((unsigned *)hist + slice*t_ctx, 0, sizeof(unsigned)*slice, s));
-  }
+  ODHIP_TRY(hipMemsetAsync(st.d_unc_count, 0, sizeof(unsigned), s));
+  /* the histogram is consumed and cleared by k_refb_prefix; cleared here as well so
+     that a call that failed half way cannot poison the next sort */
+  ODHIP_TRY(hipMemsetAsync(st.d_sort, 0, sizeof(unsigned)*kMaxItems*kSortBins, s));
   RItems it;
-  items_all(it, host, njobs, pvq_norm_lambda, 0);
+  items_all(it, st, host, njobs, pvq_norm_lambda, 0);
   if (!it.nitems) return ODHIP_SUCCESS;
   /* band 0 of every block first (it decides the chroma-from-luma flip of the
      block), then the 8-coefficient bands per lane and the 32- / 128-coefficient
      bands per row */
   {
     RItems pi;
-    items_begin(pi, pvq_norm_lambda);
+    items_begin(pi, st, pvq_norm_lambda);
     for (int j = 0; j < njobs; j++) items_add(pi, j, 0, (host[j].nblocks + kWave - 1)/kWave);
     k_refb_prep_lane<15><<<pi.wg_start[pi.nitems], kWave, 0, s>>>(pi);
-    items_begin(pi, pvq_norm_lambda);
+    items_begin(pi, st, pvq_norm_lambda);
     for (int j = 0; j < njobs; j++) {
       for (int b = 1; b < host[j].nb_bands; b++) {
         if (host[j].off[b + 1] - host[j].off[b] == 8) items_add(pi, j, b, (host[j].nblocks + kWave - 1)/kWave);
@@ -1685,7 +1728,7 @@ extern "C" int odhip_pvq_ref_bands_multi(const odhip_pvq_refjob *jobs, int njobs
     }
     if (pi.nitems) k_refb_prep_lane<8><<<pi.wg_start[pi.nitems], kWave, 0, s>>>(pi);
     for (int sz = 32; sz <= 128; sz *= 4) {
-      items_begin(pi, pvq_norm_lambda);
+      items_begin(pi, st, pvq_norm_lambda);
       for (int j = 0; j < njobs; j++) {
         for (int b = 1; b < host[j].nb_bands; b++) {
           if (host[j].off[b + 1] - host[j].off[b] == sz) {
@@ -1703,8 +1746,8 @@ extern "C" int odhip_pvq_ref_bands_multi(const odhip_pvq_refjob *jobs, int njobs
   {
     RItems chunks;
     RItems all;
-    items_begin(chunks, pvq_norm_lambda);
-    items_begin(all, pvq_norm_lambda);
+    items_begin(chunks, st, pvq_norm_lambda);
+    items_begin(all, st, pvq_norm_lambda);
     for (int j = 0; j < njobs; j++) {
       for (int b = 0; b < host[j].nb_bands; b++) {
         items_add(chunks, j, b, (host[j].nblocks + kSortChunk - 1)/kSortChunk);
@@ -1719,13 +1762,13 @@ extern "C" int odhip_pvq_ref_bands_multi(const odhip_pvq_refjob *jobs, int njobs
   const bool lane_only = getenv("ODHIP_PVQ_REF_LANE") != nullptr;
   static const int sizes[4] = {128, 32, 15, 8};
   hipStream_t side[2] = {s, s};
-  if (rfork(s, side) != ODHIP_SUCCESS) return ODHIP_EFAULT;
+  if (rfork(st, s, side) != ODHIP_SUCCESS) return ODHIP_EFAULT;
   const hipStream_t main_stream = s;
   for (int i = 0; i < 4; i++) {
     /* 128 on the caller's stream, 15 and 8 on one side stream, 32 on the other */
     s = sizes[i] == 128 ? main_stream : sizes[i] == 32 ? side[0] : side[1];
     if (sizes[i] >= 32 && !lane_only) {
-      items_begin(it, pvq_norm_lambda);
+      items_begin(it, st, pvq_norm_lambda);
       const char *e = getenv("ODHIP_PVQ_FORCE_SEQ");
       if (e && e[0] == '1') it.perturb |= 2;   /* every greedy pulse by the literal scan */
       for (int j = 0; j < njobs; j++) {
@@ -1737,15 +1780,15 @@ extern "C" int odhip_pvq_ref_bands_multi(const odhip_pvq_refjob *jobs, int njobs
       }
       if (!it.nitems) continue;
       if (sizes[i] == 128) {
-        const bool prof = g_prof_on && t_ctx == 0 && g_prof_n < kProfSlots;
-        if (prof) (void)hipEventRecord(g_prof_ev[g_prof_n][0], s);
+        const bool prof = st.prof_on && st.prof_n < kProfSlots;
+        if (prof) (void)hipEventRecord(st.prof_ev[st.prof_n][0], s);
         k_refb_search_row<8, 16><<<it.wg_start[it.nitems], kWave, 0, s>>>(it);
-        if (prof) (void)hipEventRecord(g_prof_ev[g_prof_n++][1], s);
+        if (prof) (void)hipEventRecord(st.prof_ev[st.prof_n++][1], s);
       }
       else k_refb_search_row<8, 4><<<it.wg_start[it.nitems], kWave, 0, s>>>(it);
       continue;
     }
-    items_all(it, host, njobs, pvq_norm_lambda, sizes[i]);
+    items_all(it, st, host, njobs, pvq_norm_lambda, sizes[i]);
     if (!it.nitems) continue;
     if (sizes[i] < 32 && !lane_only) {
       if (sizes[i] == 15) k_refb_search_regs<15><<<it.wg_start[it.nitems], kWave, 0, s>>>(it);
@@ -1756,37 +1799,22 @@ extern "C" int odhip_pvq_ref_bands_multi(const odhip_pvq_refjob *jobs, int njobs
     k_refb_search<<<it.wg_start[it.nitems], kWave, lds, s>>>(it);
   }
   s = main_stream;
-  if (rjoin(s, side) != ODHIP_SUCCESS) return ODHIP_EFAULT;
+  if (rjoin(st, s, side) != ODHIP_SUCCESS) return ODHIP_EFAULT;
   return odhip_check_launch();
-}
-
-namespace {
-unsigned *g_unc_host_all[kCtx] = {nullptr, nullptr};     /* pinned mirrors of g_unc_count */
-hipEvent_t g_unc_event_all[kCtx] = {nullptr, nullptr};
-#define g_unc_host g_unc_host_all[t_ctx]
-#define g_unc_event g_unc_event_all[t_ctx]
-}  // namespace
-
-/* Selects the context (0 or 1) of the calling thread's subsequent
-   odhip_pvq_ref_* calls. */
-extern "C" int odhip_pvq_ref_set_context(int ctx) {
-  if (ctx < 0 || ctx >= kCtx) return ODHIP_EINVAL;
-  t_ctx = ctx;
-  return ODHIP_SUCCESS;
 }
 
 /* The count of listed bands travels to pinned host memory behind the band stage;
    nothing waits for it here. */
 extern "C" int odhip_pvq_ref_resolve_begin(odhip_stream stream) {
   hipStream_t s = (hipStream_t)stream;
-  if (!g_unc_host) {
-    ODHIP_TRY(hipHostMalloc((void **)&g_unc_host, sizeof(unsigned), hipHostMallocDefault));
-    ODHIP_TRY(hipEventCreateWithFlags(&g_unc_event, hipEventDisableTiming));
+  REF_STATE_OR_RETURN(st);
+  if (!st.unc_host) {
+    ODHIP_TRY(hipHostMalloc((void **)&st.unc_host, sizeof(unsigned), hipHostMallocDefault));
+    ODHIP_TRY(hipEventCreateWithFlags(&st.unc_event, hipEventDisableTiming));
   }
-  *g_unc_host = 0xffffffffu;
-  ODHIP_TRY(hipMemcpyFromSymbolAsync(g_unc_host, HIP_SYMBOL(g_unc_count), sizeof(unsigned),
-   sizeof(unsigned)*t_ctx, hipMemcpyDeviceToHost, s));
-  ODHIP_TRY(hipEventRecord(g_unc_event, s));
+  *st.unc_host = 0xffffffffu;
+  ODHIP_TRY(hipMemcpyAsync(st.unc_host, st.d_unc_count, sizeof(unsigned), hipMemcpyDeviceToHost, s));
+  ODHIP_TRY(hipEventRecord(st.unc_event, s));
   return ODHIP_SUCCESS;
 }
 
@@ -1795,18 +1823,20 @@ extern "C" int odhip_pvq_ref_resolve(const odhip_pvq_refjob *jobs, int njobs,
 
 extern "C" int odhip_pvq_ref_resolve_finish(const odhip_pvq_refjob *jobs, int njobs,
  double pvq_norm_lambda, odhip_stream stream) {
-  if (!g_unc_event) return ODHIP_EINVAL;
-  ODHIP_TRY(hipEventSynchronize(g_unc_event));
-  if (*g_unc_host == 0) return 0;
+  REF_STATE_OR_RETURN(st);
+  if (!st.unc_event) return ODHIP_EINVAL;
+  ODHIP_TRY(hipEventSynchronize(st.unc_event));
+  if (*st.unc_host == 0) return 0;
   return odhip_pvq_ref_resolve(jobs, njobs, pvq_norm_lambda, stream);
 }
 
 extern "C" int odhip_pvq_ref_resolve(const odhip_pvq_refjob *jobs, int njobs,
  double pvq_norm_lambda, odhip_stream stream) {
   hipStream_t s = (hipStream_t)stream;
+  REF_STATE_OR_RETURN(st);
   ODHIP_TRY(hipStreamSynchronize(s));
   unsigned count = 0;
-  ODHIP_TRY(hipMemcpyFromSymbol(&count, HIP_SYMBOL(g_unc_count), sizeof(count), sizeof(count)*t_ctx));
+  ODHIP_TRY(hipMemcpy(&count, st.d_unc_count, sizeof(count), hipMemcpyDeviceToHost));
   if (count == 0) return 0;
   if (count > (unsigned)kUncCap) {
     fprintf(stderr, "libdaalahip: %u bands inside the theta margin exceed the list (%d)\n", count,
@@ -1815,8 +1845,7 @@ extern "C" int odhip_pvq_ref_resolve(const odhip_pvq_refjob *jobs, int njobs,
   }
   Unc *list = (Unc *)malloc(sizeof(Unc)*count);
   if (!list) return ODHIP_EFAULT;
-  if (hipMemcpyFromSymbol(list, HIP_SYMBOL(g_unc), sizeof(Unc)*count,
-   sizeof(Unc)*(size_t)kUncCap*t_ctx) != hipSuccess) {
+  if (hipMemcpy(list, st.d_unc, sizeof(Unc)*count, hipMemcpyDeviceToHost) != hipSuccess) {
     free(list);
     return ODHIP_EFAULT;
   }
@@ -1835,13 +1864,13 @@ extern "C" int odhip_pvq_ref_resolve(const odhip_pvq_refjob *jobs, int njobs,
     return 0;
   }
   RJob host[kMaxJobs];
-  int rc = stage_jobs(jobs, njobs, 0, host, s);
+  int rc = stage_jobs(st, jobs, njobs, 0, host, s);
   if (rc) {
     free(list);
     return rc;
   }
   for (unsigned i = 0; i < nfix; i++) {
-    if (list[i].job < kJobsPerCtx*t_ctx || list[i].job >= kJobsPerCtx*t_ctx + njobs) {
+    if (list[i].job < 0 || list[i].job >= njobs) {
       free(list);
       return ODHIP_EINVAL;
     }
@@ -1853,9 +1882,9 @@ extern "C" int odhip_pvq_ref_resolve(const odhip_pvq_refjob *jobs, int njobs,
     if (d_list) (void)hipFree(d_list);
     return ODHIP_EFAULT;
   }
-  k_refb_cands_list<<<(nfix + kWave - 1)/kWave, kWave, 0, s>>>(d_list, (int)nfix);
-  k_refb_search_list<<<nfix, kWave, (size_t)2*128*kWave*sizeof(unsigned short), s>>>(d_list,
-   (int)nfix, pvq_norm_lambda);
+  k_refb_cands_list<<<(nfix + kWave - 1)/kWave, kWave, 0, s>>>(st.d_jobs, d_list, (int)nfix);
+  k_refb_search_list<<<nfix, kWave, (size_t)2*128*kWave*sizeof(unsigned short), s>>>(st.d_jobs,
+   d_list, (int)nfix, pvq_norm_lambda);
   rc = odhip_check_launch();
   hipError_t e = hipStreamSynchronize(s);
   free(list);
@@ -1883,8 +1912,9 @@ extern "C" int odhip_pvq_ref_choose_multi(const odhip_pvq_refjob *jobs, int njob
 namespace {
 int ref_select(const odhip_pvq_refjob *jobs, int njobs, double pvq_norm_lambda, hipStream_t s,
  bool synth) {
+  REF_STATE_OR_RETURN(st);
   RJob host[kMaxJobs];
-  int rc = stage_jobs(jobs, njobs, synth ? 1 : 2, host, s);
+  int rc = stage_jobs(st, jobs, njobs, synth ? 1 : 2, host, s);
   if (rc) return rc;
   for (int j = 0; synth && j < njobs; j++) {
     /* 32x32 and 64x64 blocks code their lowest 512 coefficients only */
@@ -1896,7 +1926,7 @@ int ref_select(const odhip_pvq_refjob *jobs, int njobs, double pvq_norm_lambda, 
   RItems it;
   static const int sizes[4] = {128, 32, 15, 8};
   for (int i = 0; i < 4; i++) {
-    items_all(it, host, njobs, pvq_norm_lambda, sizes[i]);
+    items_all(it, st, host, njobs, pvq_norm_lambda, sizes[i]);
     if (!it.nitems) continue;
     const unsigned grid = it.wg_start[it.nitems];
     if (sizes[i] == 128) k_refb_choose<128><<<grid, kWave, 0, s>>>(it);
@@ -1905,7 +1935,7 @@ int ref_select(const odhip_pvq_refjob *jobs, int njobs, double pvq_norm_lambda, 
     else k_refb_choose<8><<<grid, kWave, 0, s>>>(it);
   }
   if (!synth) return odhip_check_launch();
-  items_begin(it, pvq_norm_lambda);
+  items_begin(it, st, pvq_norm_lambda);
   for (int j = 0; j < njobs; j++) items_add(it, j, 0, (host[j].nblocks*(host[j].len >> 3) + 255)/256);
   k_refb_synth<<<it.wg_start[it.nitems], 256, 0, s>>>(it);
   return odhip_check_launch();

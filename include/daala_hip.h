@@ -133,6 +133,76 @@ double od_pvq_search_rdo_double_hip(const int16_t *xcoeff, int n, int k,
 int odhip_init(int device);
 const char *odhip_version(void);
 
+/* Contexts (shaped after the reference's per-od_state backend
+   installation, src/x86/x86state.c:39-97: nothing is process-global).  Every
+   piece of state the batched entry points keep between calls - edge strips of
+   the inverse stage, scratch / job tables / side streams / sort arrays /
+   profiling events of the two PVQ band stages, the list of bands inside the
+   device-acos margin - is owned by an odhip_ctx.  The batched odhip_* functions
+   below use the CURRENT context of the calling thread: the one passed to
+   odhip_make_current, or (NULL / never called) a default context the thread gets
+   for the HIP device that is current when it calls in.  Rules:
+     - one call sequence in flight per context (calls of a context are ordered on
+       the caller's stream; scratch is reused from call to call);
+     - sequences that overlap - two streams, e.g. the luma and the chroma chain of
+       a frame batch, or two host threads, or two devices - use one context each;
+     - a context belongs to the device it was created for; calling with another
+       current device returns ODHIP_EINVAL.
+   odhip_create returns NULL when the device does not exist; odhip_destroy waits
+   for the device to go idle, then frees everything the context owns. */
+typedef struct odhip_ctx odhip_ctx;
+odhip_ctx *odhip_create(int device);
+void odhip_destroy(odhip_ctx *ctx);
+int odhip_make_current(odhip_ctx *ctx);    /* also makes ctx's device current */
+odhip_ctx *odhip_get_current(void);        /* NULL = the thread's default context */
+int odhip_ctx_device(const odhip_ctx *ctx);
+
+/* ---- quantiser set-up (host) ----------------------------
+
+   What the reference derives on the host per encoder / per frame and the band
+   stages take as plain data:
+     odhip_init_qm        od_init_qm, src/pvq.c:322-381 (same arguments: x, x_inv
+                          of ODHIP_QM_BUFFER_SIZE int16, qm = an 8x8 Q4 matrix):
+                          per-coefficient QM with magnitude compensation (Q11) and
+                          its inverse (Q12) in coding order, for every block size
+                          and both decimations; block (bs, xydec) starts at
+                          odhip_qm_offset(bs, xydec) (od_qm_offset, src/pvq.c:306).
+                          Entries the reference leaves unwritten (32x32 / 64x64
+                          blocks have coding positions for 512 coefficients only)
+                          are zero here.
+     odhip_interp_qm      od_interp_qm as the frame header code selects its
+                          entries per plane (src/encode.c:2903-2940, :3052-3072)
+                          from the encoder's default matrices: pvq_qm_q4 of plane
+                          pli for rc.base_quantizer.
+     odhip_qm_get_index   od_qm_get_index, src/pvq.c:408-413.
+     odhip_quant_setup    both of the above into one odhip_quant: quantizer =
+                          od_state.quantizer (0 = lossless), base_quantizer =
+                          rc.base_quantizer, hvs_qm = OD_SET_QM (1 = HVS, the
+                          encoder's default), use_masking = OD_SET_ACTIVITY_MASKING.
+     odhip_quant_bands    per band of block size bs in plane pli: the step
+                          max(1, q0*pvq_qm_q4[index(bs, i + 1)] >> 4) with q0 =
+                          max(1, quantizer) (src/pvq_encoder.c:874,
+                          src/encode.c:1336) and OD_PVQ_BETA[masking][pli][bs][i]
+                          (Q12, src/pvq.c:243-268); returns the number of bands. */
+#define ODHIP_QM_SIZE 30              /* OD_QM_SIZE, src/pvq.h:108 */
+#define ODHIP_QM_BUFFER_SIZE 10912    /* OD_QM_BUFFER_SIZE, src/pvq.h:72-74 */
+typedef struct {
+  int quantizer;
+  int base_quantizer;
+  int use_masking;
+  int hvs_qm;
+  uint8_t pvq_qm_q4[3][ODHIP_QM_SIZE];
+  int16_t qm[ODHIP_QM_BUFFER_SIZE];
+  int16_t qm_inv[ODHIP_QM_BUFFER_SIZE];
+} odhip_quant;
+void odhip_init_qm(int16_t *x, int16_t *x_inv, const int *qm);
+int odhip_qm_offset(int bs, int xydec);
+int odhip_qm_get_index(int bs, int band);
+int odhip_interp_qm(uint8_t out[ODHIP_QM_SIZE], int base_quantizer, int use_masking, int pli);
+int odhip_quant_setup(odhip_quant *qt, int base_quantizer, int quantizer, int use_masking,
+ int hvs_qm);
+int odhip_quant_bands(const odhip_quant *qt, int pli, int bs, int32_t *q_band, int32_t *beta_band);
+
 /* nblocks contiguous N x N tiles, N = 4 << ln; d_out may equal d_in.
    exact32 != 0 forces exact 32-bit products (arbitrary input); 0 uses the
    24-bit multiplier, valid while |intermediate| < 2^23 (always true for data
@@ -511,12 +581,13 @@ typedef struct {
                                 d_coef; DC passed through; uncoded positions 0 */
 } odhip_pvq_refjob;
 
-/* At most 8 jobs per call, all on one stream.  The stage keeps per-call state in
-   the library (job table, scratch, uncertainty list): ONE call sequence (bands ->
-   resolve -> select_synth) may be in flight per CONTEXT.  There are two contexts;
-   odhip_pvq_ref_set_context(0 | 1) selects the one the calling thread's next
-   odhip_pvq_ref_* calls use (default 0), so that e.g. the Cb and the Cr planes of
-   a batch can run on two streams at once. */
+/* At most 8 jobs per call, all on one stream.  The stage keeps per-call state
+   (job table, scratch, uncertainty list) in the current odhip_ctx: ONE call
+   sequence (bands -> resolve -> select_synth) may be in flight per context.
+   odhip_pvq_ref_set_context(0 | 1) is round 1's form of that: it selects which of
+   the calling thread's two DEFAULT contexts the next calls use while no explicit
+   context is current (so that e.g. the Cb and the Cr planes of a batch can run on
+   two streams at once); new code creates contexts with odhip_create. */
 int odhip_pvq_ref_set_context(int ctx);
 int odhip_pvq_ref_bands_multi(const odhip_pvq_refjob *jobs, int njobs,
  double pvq_norm_lambda, odhip_stream stream);
@@ -543,7 +614,7 @@ int odhip_pvq_ref_select_synth_multi(const odhip_pvq_refjob *jobs, int njobs,
 /* Profiling aid (bench.py), as odhip_pvq_profile: while enabled,
    odhip_pvq_ref_bands_multi brackets the dominant kernel of this stage - the
    row-parallel search of the 128-coefficient bands, k_refb_search_row<8> - with
-   HIP events on the stream the kernel is launched on (calls of context 0 only). */
+   HIP events on the stream the kernel is launched on (calls of the current context). */
 int odhip_pvq_ref_profile(int enable);
 int odhip_pvq_ref_profile_read(float *ms, int max_n);
 /* The choice alone (fills `choice` incl. the synthesis parameters), for callers that

@@ -297,6 +297,71 @@ REF_EXPORT int ref_dump_quant_tables(int quality, int *quantizer,
   return OD_QM_SIZE;
 }
 
+/* ref_dump_quant_tables with the knobs a17 depends on: activity masking on/off
+   (OD_SET_MASKING) and flat / HVS matrices (OD_SET_QM); also returns
+   rc.base_quantizer, the argument of od_interp_qm (src/encode.c:3056).  qm /
+   qm_inv may be NULL. */
+REF_EXPORT int ref_dump_quant_tables2(int quality, int use_masking, int hvs_qm, int *quantizer,
+ int *base_quantizer, unsigned char *pvq_qm_q4, int16_t *qm, int16_t *qm_inv) {
+  daala_info di;
+  daala_comment dc;
+  daala_enc_ctx *enc;
+  daala_packet dp;
+  daala_image img;
+  unsigned char *buf;
+  int complexity;
+  int pli;
+  int ret;
+  daala_info_init(&di);
+  di.pic_width = 64;
+  di.pic_height = 64;
+  di.bitdepth_mode = OD_BITDEPTH_MODE_8;
+  di.timebase_numerator = 30;
+  di.timebase_denominator = 1;
+  di.frame_duration = 1;
+  di.pixel_aspect_numerator = 1;
+  di.pixel_aspect_denominator = 1;
+  di.nplanes = 3;
+  di.plane_info[0].xdec = di.plane_info[0].ydec = 0;
+  di.plane_info[1].xdec = di.plane_info[1].ydec = 1;
+  di.plane_info[2].xdec = di.plane_info[2].ydec = 1;
+  di.keyframe_rate = 1;
+  enc = daala_encode_create(&di);
+  if (enc == NULL) return -1;
+  daala_comment_init(&dc);
+  complexity = 2;
+  daala_encode_ctl(enc, OD_SET_QUANT, &quality, sizeof(quality));
+  daala_encode_ctl(enc, OD_SET_COMPLEXITY, &complexity, sizeof(complexity));
+  daala_encode_ctl(enc, OD_SET_ACTIVITY_MASKING, &use_masking, sizeof(use_masking));
+  daala_encode_ctl(enc, OD_SET_QM, &hvs_qm, sizeof(hvs_qm));
+  while ((ret = daala_encode_flush_header(enc, &dc, &dp)) > 0);
+  buf = (unsigned char *)malloc(64*64*3/2);
+  memset(buf, 128, 64*64*3/2);
+  memset(&img, 0, sizeof(img));
+  img.nplanes = 3;
+  img.width = img.height = 64;
+  for (pli = 0; pli < 3; pli++) {
+    img.planes[pli].data = buf + (pli == 0 ? 0 : pli == 1 ? 4096 : 5120);
+    img.planes[pli].xdec = img.planes[pli].ydec = pli > 0;
+    img.planes[pli].xstride = 1;
+    img.planes[pli].ystride = pli ? 32 : 64;
+    img.planes[pli].bitdepth = 8;
+  }
+  daala_encode_img_in(enc, &img, 0);
+  while (daala_encode_packet_out(enc, 1, &dp));
+  *quantizer = enc->state.quantizer;
+  *base_quantizer = enc->rc.base_quantizer;
+  for (pli = 0; pli < 3; pli++) {
+    memcpy(pvq_qm_q4 + pli*OD_QM_SIZE, enc->state.pvq_qm_q4[pli], OD_QM_SIZE);
+  }
+  if (qm) memcpy(qm, enc->state.qm, OD_QM_BUFFER_SIZE*sizeof(*qm));
+  if (qm_inv) memcpy(qm_inv, enc->state.qm_inv, OD_QM_BUFFER_SIZE*sizeof(*qm_inv));
+  free(buf);
+  daala_comment_clear(&dc);
+  daala_encode_free(enc);
+  return OD_QM_SIZE;
+}
+
 /* One block through the REAL od_pvq_encode (src/pvq_encoder.c:789-979) on a
    fresh encoder context: range coder and adaptation state reset as at the
    start of a frame (src/encode.c:3029,3080).  `ref` is mutated exactly as the
