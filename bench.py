@@ -121,248 +121,61 @@ def picture_planes(planes):
     return [planes[0][:PIC_H], planes[1][:PIC_H // 2], planes[2][:PIC_H // 2]]
 
 
-def synth_frames(nframes, seed, device):
-    """F pictures resident in HBM: luma [F,1080,1920], chroma [2F,540,960] (all Cb,
-    then all Cr)."""
-    import torch
+def synth_pictures(nframes, seed):
+    """F pictures as the pipe takes them: luma [F,1080,1920], chroma [2F,540,960] (all Cb,
+    then all Cr), host arrays; uploaded once, resident in HBM for every step."""
     fr = [picture_planes(GENERATOR(i, seed)) for i in range(nframes)]
-    luma = torch.from_numpy(np.stack([f[0] for f in fr])).to(device)
-    chroma = torch.from_numpy(np.stack([f[1] for f in fr] + [f[2] for f in fr])).to(device)
-    return luma.contiguous(), chroma.contiguous()
+    luma = np.stack([f[0] for f in fr])
+    chroma = np.stack([f[1] for f in fr] + [f[2] for f in fr])
+    return np.ascontiguousarray(luma), np.ascontiguousarray(chroma)
 
 
-class Pipeline:
-    """The GPU step.  All buffers are allocated once; a step only launches
-    kernels: 2 pyramid launches, the multi-job PVQ band stage and choice covering
-    all nine (plane set, level) jobs, and one inverse launch group per plane set
-    (all its levels)."""
-
-    def __init__(self, D, nframes, device, chroma_cfl=False):
-        import torch
-        self.D = D
-        self.chroma_cfl = chroma_cfl
-        self.torch = torch
-        self.F = nframes
-        self.qt = D.QuantTables.load()
-        self.lam = D.OD_PVQ_LAMBDA
-        self.luma_pic, self.chroma_pic = synth_frames(nframes, 1234 + int(os.environ.get("RANK", 0)),
-                                                      device)
-        # padded planes the encoder codes (od_img_plane_copy_pad, done on the GPU every step)
-        self.luma = D.image_planes_copy_pad(self.luma_pic, W, H)
-        self.chroma = D.image_planes_copy_pad(self.chroma_pic, W // 2, H // 2)
-        self.sets = []
-        self.jobs = []
-        for name, px, pic, dec, pli in (("luma", self.luma, self.luma_pic, 0, 0),
-                                        ("chroma", self.chroma, self.chroma_pic, 1, 1)):
-            levels = D.forward_pyramid(px, dec, PIC_W, PIC_H)
-            s = dict(name=name, px=px, pic=pic, dec=dec, pli=pli, levels=levels, jobs=[],
-                     recon=[torch.empty_like(px) for _ in range(5 - dec)])
-            for bs in range(5 - dec):
-                qm, qmi = self.qt.qm_slices(pli, bs)
-                job = D.PvqJob(levels[bs], bs, torch.from_numpy(qm).to(device),
-                               torch.from_numpy(qmi).to(device), self.qt.q_band(pli, bs),
-                               self.qt.beta_band(pli, bs))
-                s["jobs"].append(job)
-                self.jobs.append(job)
-            self.sets.append(s)
-        self.timers = {}
-        self.refjobs = []
-        if chroma_cfl:
-            self._setup_chroma_cfl(device)
-
-    def _setup_chroma_cfl(self, device):
-        """Keyframe chroma goes through pvq_theta's WITH-reference path, as in the
-        reference encoder (chroma-from-luma, src/encode.c:1680-1687).  The reference
-        planes of a step come from THAT step's luma band stage
-        (odhip_cfl_refs_from_luma = od_resample_luma_coeffs on the chosen luma
-        candidates), in two alternating buffers so that the luma chain of step i+1
-        can run while the chroma chain of step i still reads its references."""
-        D, torch = self.D, self.torch
-        luma, chroma = self.sets
-        self.noref_jobs = luma["jobs"]
-        # ODHIP_PVQ_SERIAL=1 (profiling: exclusive kernel durations) keeps everything on one stream
-        self.side = (torch.cuda.current_stream() if os.environ.get("ODHIP_PVQ_SERIAL")
-                     else torch.cuda.Stream(device=device))
-        D.pvq_noref_bands_multi(luma["jobs"], self.lam)
-        D.pvq_choose_multi(luma["jobs"], self.lam)
-        self.refs = [D.cfl_refs_from_luma(luma["jobs"][1:], copies=2) for _ in range(2)]
-        self.refjobs = [[], []]
-        for bs in range(4):
-            cj = chroma["jobs"][bs]
-            first = D.PvqRefJob(cj.coef, self.refs[0][bs], bs, cj.qm, cj.qm_inv,
-                                self.qt.q_band(1, bs), self.qt.beta_band(1, bs), 1, 1)
-            self.refjobs[0].append(first)
-            self.refjobs[1].append(D.PvqRefJob(cj.coef, self.refs[1][bs], bs, cj.qm, cj.qm_inv,
-                                               self.qt.q_band(1, bs), self.qt.beta_band(1, bs), 1, 1,
-                                               share=first))
-        self.ev_refs = [torch.cuda.Event() for _ in range(2)]     # references of parity p written
-        self.ev_used = [torch.cuda.Event() for _ in range(2)]     # ... and no longer read
-        self.nstep = 0
-        self.pending = None
-        torch.cuda.synchronize()
-
-    def _timed(self, key, fn, record):
-        if not record:
-            return fn()
-        t = self.torch
-        a = t.cuda.Event(enable_timing=True)
-        b = t.cuda.Event(enable_timing=True)
-        a.record()
-        r = fn()
-        b.record()
-        self.timers.setdefault(key, []).append((a, b))
-        return r
-
-    def step(self, record=False):
-        D = self.D
-        if self.chroma_cfl:
-            return self._step_cfl(record)
-        for s in self.sets:
-            self._timed("image_copy_pad_" + s["name"],
-                        lambda: D.image_planes_copy_pad(s["pic"], W >> s["dec"], H >> s["dec"],
-                                                        out=s["px"]), record)
-            self._timed("forward_pyramid_" + s["name"],
-                        lambda: D.forward_pyramid(s["px"], s["dec"], PIC_W, PIC_H,
-                                                  levels=s["levels"]), record)
-        self._timed("pvq_noref_bands", lambda: D.pvq_noref_bands_multi(self.jobs, self.lam),
-                    record)
-        self._timed("pvq_choose", lambda: D.pvq_choose_multi(self.jobs, self.lam), record)
-        for s in self.sets:
-            # every level of the plane set in one set of launches, one
-            # reconstruction per level (what a block-size decision compares)
-            self._timed("dequant_inverse_" + s["name"],
-                        lambda: D.inverse_levels_pvq(s["jobs"], s["dec"], PIC_W, PIC_H,
-                                                     outs=s["recon"]), record)
-
-    def _chroma_tail(self, jobs, record):
-        D = self.D
-        chroma = self.sets[1]
-        # choice, then the inverse of all four levels with the chosen candidates dequantised
-        # while the tiles are loaded (no dequantised chroma plane in HBM)
-        self._timed("pvq_ref_choose", lambda: D.pvq_ref_choose_multi(jobs, self.lam), record)
-        self._timed("dequant_inverse_chroma",
-                    lambda: D.inverse_levels_pvq_ref(jobs, 1, PIC_W, PIC_H, outs=chroma["recon"]), record)
-
-    def _finish_pending(self, record):
-        """The count of bands inside the device-acos margin of the previous step's
-        with-reference stage: checked one step late, so the host never waits inside a
-        step; a listed band whose theta the host corrects (never seen outside the
-        forced tests) repeats what consumed it."""
-        if self.pending is None:
-            return
-        jobs, self.pending = self.pending, None
-        with self.torch.cuda.stream(self.side):
-            if self.D.pvq_ref_resolve_finish(jobs, self.lam) > 0:
-                self._chroma_tail(jobs, record)
-
-    def flush(self):
-        if self.chroma_cfl:
-            self._finish_pending(False)
-
-    def _step_cfl(self, record):
-        """Software-pipelined over steps: luma (no-reference path) on the current stream,
-        chroma (with-reference path) on a side stream.  The chroma chain of a step waits
-        for that step's chroma-from-luma references (written by the luma chain after its
-        choice); the luma chain of the NEXT step overlaps with it."""
-        D, torch = self.D, self.torch
-        luma, chroma = self.sets
-        main = torch.cuda.current_stream()
-        par = self.nstep & 1
-        self.nstep += 1
-        jobs = self.refjobs[par]
-        self._timed("image_copy_pad_luma",
-                    lambda: D.image_planes_copy_pad(luma["pic"], W, H, out=luma["px"]), record)
-        self._timed("forward_pyramid_luma",
-                    lambda: D.forward_pyramid(luma["px"], 0, PIC_W, PIC_H, levels=luma["levels"]),
-                    record)
-        self._timed("pvq_noref_bands", lambda: D.pvq_noref_bands_multi(self.noref_jobs, self.lam),
-                    record)
-        self._timed("pvq_choose", lambda: D.pvq_choose_multi(self.noref_jobs, self.lam), record)
-        main.wait_event(self.ev_used[par])      # step i-2 no longer reads this reference buffer
-        self._timed("cfl_refs_from_luma",
-                    lambda: D.cfl_refs_from_luma(self.noref_jobs[1:], refs=self.refs[par], copies=2),
-                    record)
-        self.ev_refs[par].record(main)
-        self._timed("dequant_inverse_luma",
-                    lambda: D.inverse_levels_pvq(luma["jobs"], 0, PIC_W, PIC_H, outs=luma["recon"]),
-                    record)
-        self._finish_pending(record)
-        with torch.cuda.stream(self.side):
-            self._timed("image_copy_pad_chroma",
-                        lambda: D.image_planes_copy_pad(chroma["pic"], W // 2, H // 2,
-                                                        out=chroma["px"]), record)
-            self._timed("forward_pyramid_chroma",
-                        lambda: D.forward_pyramid(chroma["px"], 1, PIC_W, PIC_H,
-                                                  levels=chroma["levels"]), record)
-            self.side.wait_event(self.ev_refs[par])
-            self._timed("pvq_ref_bands",
-                        lambda: D.pvq_ref_bands_multi(jobs, self.lam, resolve="async"), record)
-            self._chroma_tail(jobs, record)
-            self.ev_used[par].record(self.side)
-        self.pending = jobs
-
-    def pyramid_alone_ms(self, n=10):
-        """Average duration of the luma forward pyramid launched on an otherwise idle GPU."""
-        t, D = self.torch, self.D
-        luma = self.sets[0]
-        t.cuda.synchronize()
-        a = t.cuda.Event(enable_timing=True)
-        b = t.cuda.Event(enable_timing=True)
-        D.forward_pyramid(luma["px"], 0, PIC_W, PIC_H, levels=luma["levels"])
-        a.record()
-        for _ in range(n):
-            D.forward_pyramid(luma["px"], 0, PIC_W, PIC_H, levels=luma["levels"])
-        b.record()
-        t.cuda.synchronize()
-        return a.elapsed_time(b) / n
-
-    def copy_ceiling_gbs(self, n=10):
-        """Same-run practical HBM ceiling: a 1 GiB device-to-device copy,
-        read + written bytes per second."""
-        t = self.torch
-        a = t.empty(1 << 30, dtype=t.uint8, device=self.luma.device)
-        b = t.empty_like(a)
+def copy_ceiling_gbs(device, n=10):
+    """Same-run practical HBM ceiling: a 1 GiB device-to-device copy,
+    read + written bytes per second."""
+    import torch as t
+    a = t.empty(1 << 30, dtype=t.uint8, device=device)
+    b = t.empty_like(a)
+    b.copy_(a)
+    t.cuda.synchronize()
+    e0 = t.cuda.Event(enable_timing=True)
+    e1 = t.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
         b.copy_(a)
-        t.cuda.synchronize()
-        e0 = t.cuda.Event(enable_timing=True)
-        e1 = t.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(n):
-            b.copy_(a)
-        e1.record()
-        t.cuda.synchronize()
-        return 2.0 * (1 << 30) * n / (e0.elapsed_time(e1) * 1e-3) / 1e9
+    e1.record()
+    t.cuda.synchronize()
+    return 2.0 * (1 << 30) * n / (e0.elapsed_time(e1) * 1e-3) / 1e9
 
-    def ref128_bytes(self):
-        """Algorithmic bytes and band count of one k_refb_search_row<8> launch,
-        counted from the records and candidate vectors the last step left."""
-        t = self.torch
-        total = 0
-        bands = 0
-        for job in self.refjobs[0]:
-            for b in range(job.nb):
-                if job.offsets[b + 1] - job.offsets[b] != 128:
-                    continue
-                rec = job.band[:, b, :].contiguous().view(t.int32)       # [B][16]
-                nitems = rec[:, 10].to(t.int64)
-                ntheta = rec[:, 11].to(t.int64)
-                tail = job.items[1, b].contiguous().view(t.int32)        # [slot][B][4]
-                slot = t.arange(tail.shape[0], device=tail.device).view(-1, 1)
-                valid = slot < nitems.view(1, -1)
-                searched = valid & ((tail[:, :, 2] & 1) != 0)
-                stored = searched & (tail[:, :, 3] == slot)
-                total += int((64 + 254 * (ntheta > 0) + 256 * (nitems > ntheta) + 32 * nitems).sum())
-                total += int(16 * searched.sum() + 256 * stored.sum())
-                bands += rec.shape[0]
-        return total, bands
 
-    def kernel_ms(self):
-        """Average milliseconds per launch group and groups per run, per class."""
-        out = {}
-        for key, evs in self.timers.items():
-            ms = [a.elapsed_time(b) for a, b in evs]
-            out[key] = (float(np.mean(ms)), len(ms))
-        return out
+def ref128_bytes(D, pipe):
+    """Algorithmic bytes and band count of one k_refb_search_row<8,16> launch, counted
+    from the records and candidate vectors the last step left: per band the 64 B record,
+    the 254 B reflected vector (+ 256 B x16 when the no-reference candidates run), per
+    candidate 16 B in + 16 B out (+ 16 B result when searched), and 256 B of pulses per
+    search that stored its vector."""
+    total = 0
+    bands = 0
+    for bs in range(4):
+        nb, offs, _ = D.pvq_band_layout(bs)
+        which = [b for b in range(nb) if offs[b + 1] - offs[b] == 128]
+        if not which:
+            continue
+        B = pipe.nblocks(1, bs)
+        rec = pipe.read(D.BUF_BAND, 1, bs, dtype=np.int32).reshape(B, nb, 16)
+        items = pipe.read(D.BUF_ITEMS, 1, bs, dtype=np.int32).reshape(3, nb, D.REF_SLOTS, B, 4)
+        slot = np.arange(D.REF_SLOTS).reshape(-1, 1)
+        for b in which:
+            nitems = rec[:, b, 10].astype(np.int64)
+            ntheta = rec[:, b, 11].astype(np.int64)
+            tail = items[1, b]                               # [slot][B][4]
+            valid = slot < nitems.reshape(1, -1)
+            searched = valid & ((tail[:, :, 2] & 1) != 0)
+            stored = searched & (tail[:, :, 3] == slot)
+            total += int((64 + 254 * (ntheta > 0) + 256 * (nitems > ntheta) + 32 * nitems).sum())
+            total += int(16 * searched.sum() + 256 * stored.sum())
+            bands += B
+    return total, bands
 
 
 def algorithmic_bytes(F):
@@ -399,96 +212,175 @@ def algorithmic_bytes(F):
     }
 
 
-def cpu_baseline(qt, chroma_cfl, min_seconds=12.0, max_frames=32):
-    """The same per-block work on ONE host core with the reference's own C
-    functions (oracle/_ref, kind 'reference') or, when that library is absent,
-    the oracle port (no-reference chroma only).  Bounded sample: whole frames of
-    the bench generator until at least `min_seconds` of CPU work (about 10-30 s)."""
+def _pin(core):
+    try:
+        os.sched_setaffinity(0, {core})
+        return True
+    except (AttributeError, OSError):
+        return False
+
+
+def cpu_leg(qt, chroma_cfl, first_pictures, min_frames=5, min_seconds=10.0, max_frames=24):
+    """The same per-block work on ONE pinned host core with the reference's own C
+    functions (oracle/_ref): whole pictures of the bench generator, one timing per
+    picture, until >= min_frames pictures and >= min_seconds of CPU work.  The first
+    picture is the GPU batch's frame 0 (its reconstruction is what `verified` compares).
+    Returns (per-picture rates, blocks per picture, recon of the first picture)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
-    from _libs import P, oracle, ref
-    r = ref()
-    kind = "reference" if r is not None else "port"
-    degraded = r is None and chroma_cfl
-    if degraded:
-        # oracle/_ref (the compiled reference, prebuilt by build()) did not travel: time the
-        # oracle port, which has the no-reference stage only, and say so in `sample`
-        chroma_cfl = False
-    tables = []
-    for p in (0, 1):
-        qm_off = (ctypes.c_int * 5)(*[int(qt.qm_offset[bs][p]) for bs in range(5)])
-        qb = (ctypes.c_int * 60)()
-        bb = (ctypes.c_int * 60)()
-        for bs in range(5):
-            for i, v in enumerate(qt.q_band(p, bs)):
-                qb[bs * 12 + i] = v
-            for i, v in enumerate(qt.beta_band(p, bs)):
-                bb[bs * 12 + i] = v
-        tables.append((qm_off, qb, bb))
-    qm = np.ascontiguousarray(qt.qm)
-    qmi = np.ascontiguousarray(qt.qm_inv)
-    lam = ctypes.c_double(0.147)
-    blocks = 0
-    nframes = 0
+    import _pipeline_check as C
+    rates = []
     busy = 0.0
-    if r is not None:
-        r.ref_stage_plane.restype = ctypes.c_long
-        r.ref_stage_plane_cfl.restype = ctypes.c_long
-    while busy < min_seconds and nframes < max_frames:
-        pics = picture_planes(GENERATOR(1000 + nframes, 1234))  # generation is not timed
-        ldq = [np.zeros((H, W), np.int32) for _ in range(5)] if chroma_cfl else None
-        refs = None
-        for pli, pic, dec in ((0, pics[0], 0), (1, pics[1], 1), (2, pics[2], 1)):
-            p = 1 if pli else 0
-            h, w = H >> dec, W >> dec
-            qm_off, qb, bb = tables[p]
-            pic = np.ascontiguousarray(pic)
-            px = np.zeros((h, w), np.uint8)
-            recon = np.zeros_like(px)
-            t0 = time.perf_counter()
-            # od_img_plane_copy_pad (static in the reference's encode.c: the pinned restatement)
-            oracle().odo_img_plane_copy_pad(P(px), w, w, h, P(pic), pic.shape[1], pic.shape[1],
-                                            pic.shape[0])
-            if r is None:
-                o = oracle()
-                o.odo_stage_plane.restype = ctypes.c_long
-                blocks += o.odo_stage_plane(P(px), w, w, h, dec, PIC_W, PIC_H, p, P(qm), P(qmi),
-                                            qm_off, qb, bb, lam, 1, P(recon))
-            elif not chroma_cfl:
-                blocks += r.ref_stage_plane(P(px), w, w, h, dec, PIC_W, PIC_H, p, P(qm), P(qmi),
-                                            qm_off, qb, bb, lam, P(recon))
-            elif pli == 0:
-                arr = (ctypes.c_void_p * 5)(*[a.ctypes.data for a in ldq])
-                blocks += r.ref_stage_plane_cfl(P(px), w, w, h, 0, PIC_W, PIC_H, 0, P(qm), P(qmi),
-                                                qm_off, qb, bb, lam, P(recon), arr, None)
-            else:
-                arr = (ctypes.c_void_p * 5)(*([a.ctypes.data for a in refs] + [None]))
-                blocks += r.ref_stage_plane_cfl(P(px), w, w, h, 1, PIC_W, PIC_H, 1, P(qm), P(qmi),
-                                                qm_off, qb, bb, lam, P(recon), None, arr)
-            busy += time.perf_counter() - t0
-            if chroma_cfl and pli == 0:
-                # chroma-from-luma predictions: od_resample_luma_coeffs for luma blocks one
-                # size up (src/intra.c:97-108, a strided copy), timed like the GPU's kernel
-                t0 = time.perf_counter()
-                refs = []
-                for bs in range(4):
-                    n = 4 << bs
-                    c = ldq[bs + 1].reshape(H // (2 * n), 2 * n, W // (2 * n), 2 * n)[:, :n, :, :n]
-                    refs.append(np.ascontiguousarray(c.reshape(H // 2, W // 2)))
-                busy += time.perf_counter() - t0
-        nframes += 1
-    if degraded:
-        what = ("padding + forward pyramid + pvq_theta noref bands (oracle/_ref absent: chroma through "
-                "the no-reference port, less work than the GPU step) + inverse")
-    else:
-        what = None
-    what = what or ("padding + forward pyramid + pvq_theta (luma: no-reference bands; chroma: WITH the "
-            "chroma-from-luma reference) + inverse" if chroma_cfl else
-            "padding + forward pyramid + pvq_theta noref bands + inverse")
-    return {"value": blocks / busy, "unit": "blocks/s", "cores": 1, "kind": kind,
-            "sample": "%d synthetic 1920x1080 4:2:0 pictures of the bench generator (%d blocks) in "
-                      "%.1f s: %s of every block at every level, %s, single "
-                      "thread" % (nframes, blocks, busy, what,
-                                  "reference C functions" if kind == "reference" else "oracle port")}
+    first = None
+    blocks = 0
+    n = 0
+    while n < max_frames and (n < min_frames or busy < min_seconds):
+        pics = first_pictures if n == 0 else picture_planes(GENERATOR(1000 + n, 1234))
+        recon, blocks, dt = C.cpu_frame(qt, pics, PIC_W, PIC_H, chroma_cfl=chroma_cfl)
+        if n == 0:
+            first = recon
+        rates.append(blocks / dt)
+        busy += dt
+        n += 1
+    return rates, blocks, first, busy
+
+
+def cpu_worker(args):
+    """`bench.py --cpu-worker CORE`: one pinned process of the all-cores CPU figure."""
+    import daala_amd as D
+    global GENERATOR
+    GENERATOR = CONTENT[args.content]
+    _pin(args.cpu_worker)
+    qt = D.QuantTables.load()
+    first = picture_planes(GENERATOR(2000 + args.cpu_worker, 1234))
+    rates, blocks, _, busy = cpu_leg(qt, not args.chroma_noref, first, min_frames=2, min_seconds=0.0,
+                                     max_frames=2)
+    print(json.dumps({"blocks": blocks * len(rates), "seconds": busy}))
+
+
+def cpu_baseline(D, qt, chroma_cfl, args, gpu_frame0):
+    """cpu_baseline (one pinned core, median of >= 5 pictures), the all-cores figure
+    (one pinned process per core, independent pictures - all-intra frames are
+    independent), and the whole-frame verification of the GPU path against it."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from _libs import ref
+    import _pipeline_check as C
+    if ref() is None:
+        # oracle/_ref (the compiled reference, prebuilt by build()) did not travel
+        return None, None, {"verified": None, "why": "oracle/_ref/libdaalaref.so absent"}
+    prev = os.sched_getaffinity(0) if hasattr(os, "sched_getaffinity") else None
+    pinned = _pin(0)
+    rates, blocks, recon0, busy = cpu_leg(qt, chroma_cfl, gpu_frame0)
+    if prev is not None:
+        os.sched_setaffinity(0, prev)
+    what = ("padding + forward pyramid + pvq_theta with closed-form pricing (luma: no-reference "
+            "bands; chroma: WITH the chroma-from-luma reference) + inverse" if chroma_cfl else
+            "padding + forward pyramid + pvq_theta noref bands (closed-form pricing) + inverse")
+    base = {"value": float(np.median(rates)), "unit": "blocks/s", "cores": 1, "kind": "reference",
+            "pinned_to_core_0": pinned, "runs": len(rates),
+            "min": float(min(rates)), "max": float(max(rates)),
+            "scope": "the transform/PVQ stage only (the whole reference encoder, with entropy coding "
+                     "and block-size RDO, runs 7.2e4 blocks/s on the survey host, SURVEY.md section 6)",
+            "sample": "median of %d synthetic 1920x1080 4:2:0 pictures of the bench generator (%d blocks "
+                      "each, %.1f s in all): %s of every block at every level, reference C functions "
+                      "(plain C build; its x86 intrinsics cover only the 4x4 / 8x8 transforms of this "
+                      "stage), single pinned thread" % (len(rates), blocks, busy, what)}
+    # all cores: one pinned process per core, two pictures each
+    host = None
+    ncores = len(prev) if prev else (os.cpu_count() or 1)
+    if ncores > 1 and not args.no_cpu_allcores:
+        import subprocess
+        cmd = [sys.executable, os.path.abspath(__file__), "--content", args.content]
+        if args.chroma_noref:
+            cmd.append("--chroma-noref")
+        cores = sorted(prev)[:ncores] if prev else list(range(ncores))
+        t0 = time.perf_counter()
+        procs = [subprocess.Popen(cmd + ["--cpu-worker", str(c)], stdout=subprocess.PIPE, text=True)
+                 for c in cores]
+        done = []
+        for pr in procs:
+            out, _ = pr.communicate()
+            try:
+                done.append(json.loads(out.strip().splitlines()[-1]))
+            except (ValueError, IndexError):
+                pass
+        wall = time.perf_counter() - t0
+        if len(done) == len(procs):
+            host = {"value": sum(d["blocks"] / d["seconds"] for d in done), "unit": "blocks/s",
+                    "cores": len(done), "kind": "reference",
+                    "sample": "%d pinned processes x 2 pictures each (independent all-intra frames), "
+                              "sum of the per-process rates; %.1f s wall incl. start-up" % (len(done), wall)}
+    # whole-frame verification: the GPU stages with the host pricing every candidate in
+    # between (closed form, the reference's own od_pvq_rate) must reproduce the CPU leg's
+    # reconstruction of the batch's frame 0 at every level of all three planes
+    gpu = C.gpu_priced_frame(D, qt, gpu_frame0, PIC_W, PIC_H, chroma_cfl=chroma_cfl)
+    bad = C.compare_frame(gpu, recon0)
+    ver = {"verified": not bad,
+           "what": "frame 0 of the batch, whole frame: every reconstructed pixel of every partition "
+                   "level of Y, Cb, Cr from the GPU stages (host-priced choice) == the reference C "
+                   "functions' (cpu_baseline leg)",
+           "planes_levels_compared": 13, "mismatches": bad}
+    return base, host, ver
+
+
+def pipeline_digest(D, pipe):
+    """SHA-256 over every reconstructed plane and choice record of the pipe."""
+    import hashlib
+    h = hashlib.sha256()
+    for set_ in (0, 1):
+        for bs in range(5 - set_):
+            h.update(pipe.read(D.BUF_RECON, set_, bs).tobytes())
+            h.update(pipe.read(D.BUF_CHOICE, set_, bs).tobytes())
+    return h.hexdigest()
+
+
+def load_pmc(tag_order=("r2", "r1")):
+    for tag in tag_order:
+        path = os.path.join(ROOT, "profiles", "%s_pmc_traffic.json" % tag)
+        try:
+            with open(path) as f:
+                return json.load(f)["kernels"], "profiles/%s_pmc_traffic.json" % tag
+        except (OSError, ValueError, KeyError):
+            continue
+    return {}, None
+
+
+# gfx950: 256 CUs x 4 SIMDs; one fp64 VALU wave-instruction issues in about 4 cycles per
+# SIMD at the 2.4 GHz peak clock (tools/ubench/fp64_rate.hip measures 4.9-5.2 for
+# v_add/mul/fma_f64, DESIGN.md) -> the issue-rate roof used for the search kernels
+VALU_PEAK_GINSTR = 1024 * 2.4 / 4.0
+
+
+def search_roofline(name, kernel_prefix, ms_excl, ms_in_step, launches, alg_bytes, bands, step_ms, pmc, src):
+    """roofline object of a K-pulse search kernel: fp64 VALU issue is its roof (the HBM
+    figure SURVEY 8(d) asks for is kept as `hbm`)."""
+    hbm = alg_bytes / (ms_excl * 1e-3) / 1e9
+    out = {"kernel": name, "bound": "valu-fp64", "achieved": None, "peak": round(VALU_PEAK_GINSTR, 1),
+           "unit": "G wave-instructions/s", "frac": None, "traffic": None,
+           "avg_ms_per_launch": round(ms_excl, 4), "avg_ms_per_launch_in_step": round(ms_in_step, 4),
+           "launches": launches, "share_of_step": round(ms_in_step / step_ms, 4),
+           "algorithmic_bytes_per_launch": alg_bytes, "bands_per_launch": bands,
+           "hbm": {"achieved": round(hbm, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                   "frac": round(hbm / HBM_PEAK_GBS, 4)},
+           "timing": "HIP events on the stream the kernel is launched on; avg_ms_per_launch = exclusive "
+                     "(a serial replay of the same step after the timed region), _in_step = inside the "
+                     "timed, two-stream step"}
+    key = [k for k in pmc if k.startswith(kernel_prefix)]
+    if key:
+        ent = pmc[key[0]]
+        out["traffic"] = ent.get("hbm_bytes_per_launch")
+        out["traffic_source"] = "%s (rocprofv3 --pmc, same command)" % src
+        vi = ent.get("valu_wave_instructions")
+        if vi:
+            g = vi / (ms_excl * 1e-3) / 1e9
+            out["achieved"] = round(g, 1)
+            out["frac"] = round(g / VALU_PEAK_GINSTR, 4)
+            out["valu_wave_instructions_per_launch"] = vi
+            out["valu_source"] = "%s (SQ_INSTS_VALU per launch, workload-deterministic)" % src
+    if out["frac"] is None:
+        # no counter file for this workload: fall back to the HBM figure
+        out.update({"bound": "hbm", "achieved": round(hbm, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(hbm / HBM_PEAK_GBS, 4)})
+    return out
 
 
 def main():
@@ -498,6 +390,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--frames", type=int, default=DEFAULT_FRAMES, help="1080p frames per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cpu-allcores", action="store_true")
+    ap.add_argument("--cpu-worker", type=int, default=None, help=argparse.SUPPRESS)
     ap.add_argument("--content", choices=sorted(CONTENT), default="checker",
                     help="synthetic picture generator: 'checker' (smooth texture + 32-pixel checker "
                          "edges + uniform noise, independent chroma) or 'natural' (cosines + AR(1) "
@@ -507,6 +401,8 @@ def main():
                          "chroma-from-luma reference, as the reference encoder codes keyframes)")
     ap.add_argument("--chroma-cfl", action="store_true", help="(default; kept for old command lines)")
     args = ap.parse_args()
+    if args.cpu_worker is not None:
+        return cpu_worker(args)
 
     import torch
     import daala_amd as D
@@ -527,7 +423,11 @@ def main():
     device = torch.device("cuda", local_rank)
 
     cfl = not args.chroma_noref
-    pipe = Pipeline(D, args.frames, device, chroma_cfl=cfl)
+    qt = D.QuantTables.load()
+    luma_pic, chroma_pic = synth_pictures(args.frames, 1234 + rank)
+    pipe = D.Pipe(qt, args.frames, PIC_W, PIC_H, chroma_cfl=cfl, device=local_rank,
+                  serial=bool(os.environ.get("ODHIP_PVQ_SERIAL")))
+    pipe.set_pictures(luma_pic, chroma_pic)
     for _ in range(args.warmup):
         pipe.step()
     pipe.flush()
@@ -537,134 +437,104 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # HIP events around the dominant kernel, on the stream it is launched on
-    D.pvq_profile(True)
-    D.pvq_ref_profile(True)
+    # HIP events around every stage and around the dominant kernel of each band stage,
+    # on the streams they are launched on (odhip_pipe_record)
+    pipe.record(True)
     barrier()
     t0 = time.perf_counter()
     host_s = 0.0
     for _ in range(args.steps):
         h0 = time.perf_counter()
-        pipe.step(record=True)
+        pipe.step()
         host_s += time.perf_counter() - h0
+    h0 = time.perf_counter()
     pipe.flush()
+    host_wait_s = time.perf_counter() - h0
     torch.cuda.synchronize()
     barrier()
     dt = time.perf_counter() - t0
-    search_ms = D.pvq_profile_read()
-    D.pvq_profile(False)
+    kms = pipe.timings()
+    search_ms = pipe.search_timings(False)
+    ref_search_ms = pipe.search_timings(True)
+    pipe.record(False)
     # The filter + DCT kernel on its own (after the timed steps): in the step it shares the
     # GPU with the other stream's kernels, which stretches its duration.
-    fd_alone = pipe.pyramid_alone_ms()
-    copy_gbs = pipe.copy_ceiling_gbs()
-    ref_search_ms = D.pvq_ref_profile_read()
-    D.pvq_ref_profile(False)
+    fd_alone = pipe.time_pyramid(10)
+    copy_gbs = copy_ceiling_gbs(device)
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
     if rank == 0:
+        # exclusive durations and the pipelined == serial check: the same steps replayed on
+        # ONE stream (own pipe, same pictures), after the timed region
+        digest = pipeline_digest(D, pipe)
+        r_bytes, r_bands = ref128_bytes(D, pipe) if cfl else (0, 0)
+        serial = D.Pipe(qt, args.frames, PIC_W, PIC_H, chroma_cfl=cfl, device=local_rank, serial=True)
+        serial.set_pictures(luma_pic, chroma_pic)
+        serial.step()
+        serial.flush()
+        serial.record(True)
+        for _ in range(3):
+            serial.step()
+        serial.flush()
+        serial.sync()
+        excl = serial.timings()
+        search_excl = serial.search_timings(False)
+        ref_search_excl = serial.search_timings(True)
+        serial_digest = pipeline_digest(D, serial)
+        serial.destroy()
+
         bpf = blocks_per_frame()
         total_blocks = world * args.frames * args.steps * bpf
-        kms = pipe.kernel_ms()
+        step_ms = dt / args.steps * 1e3
         ab = algorithmic_bytes(args.frames)
         kernels = {}
         for key, (ms, count) in kms.items():
             ent = {"avg_ms_per_launch": round(ms, 4), "launches": count,
-                   "share_of_step": round(ms * count / args.steps / (dt / args.steps * 1e3), 4)}
+                   "share_of_step": round(ms * count / args.steps / step_ms, 4)}
+            if key in excl:
+                ent["exclusive_avg_ms"] = round(excl[key][0], 4)
             if key in ab:
                 ent["algorithmic_bytes_per_launch"] = ab[key]
                 ent["achieved_GBs"] = round(ab[key] / (ms * 1e-3) / 1e9, 1)
                 ent["frac_of_hbm_peak"] = round(ent["achieved_GBs"] / HBM_PEAK_GBS, 4)
             kernels[key] = ent
-        # roofline = the single kernel with the largest share of the step: the
-        # search of the 128-coefficient PVQ bands.  Its duration is measured by
-        # the library with HIP events on the stream the kernel is launched on
-        # (odhip_pvq_profile); the rocprofv3 summary under profiles/ shows the same
-        # kernel.  Algorithmic bytes per band: 2n B x16 in + 32 B record head in,
-        # 2 x 2n B pulses + 32 B record tail out = 6n + 64 = 832 B.
+        pmc, pmc_src = load_pmc()
+        if args.frames != DEFAULT_FRAMES or not cfl or args.content != "checker":
+            pmc, pmc_src = {}, None       # the committed counters are of the default command
+        # roofline = the single kernel with the largest EXCLUSIVE time among the kernels
+        # the library brackets: the two K-pulse searches of the 128-coefficient bands.
         n128 = 0
         for (w, h, planes, top) in ((W, H, args.frames, 4), (W // 2, H // 2, 2 * args.frames, 3)):
             if cfl and top == 3:
                 continue     # chroma goes through the with-reference stage
             for bs in range(top + 1):
                 n128 += planes * (w // (4 << bs)) * (h // (4 << bs)) * [0, 0, 1, 3, 3][bs]
-        s_ms = float(np.mean(search_ms)) if search_ms else float("nan")
-        s_bytes = n128 * (6 * 128 + 64)
-        roof = {"kernel": "k_search<128,2,1> (PVQ search of the 128-coefficient bands)",
-                "bound": "hbm", "achieved": round(s_bytes / (s_ms * 1e-3) / 1e9, 1),
-                "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(s_bytes / (s_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
-                "avg_ms_per_launch": round(s_ms, 4), "launches": len(search_ms),
-                "share_of_step": round(s_ms / (dt / args.steps * 1e3), 4),
-                "algorithmic_bytes_per_launch": s_bytes, "bands_per_launch": n128}
-        # HBM traffic of that kernel from the committed PMC run of this command
-        # (tools/profile_round.sh; bench.py cannot collect counters itself)
-        try:
-            with open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")) as f:
-                tr = json.load(f)["kernels"]
-            key = [k_ for k_ in tr if k_.startswith("k_search<128")]
-            # the committed PMC run is of the default command (DEFAULT_FRAMES, chroma with reference)
-            if key and args.frames == DEFAULT_FRAMES and cfl:
-                roof["traffic"] = tr[key[0]]["hbm_bytes_per_launch"]
-                roof["traffic_source"] = "profiles/r1_pmc_traffic.json (rocprofv3 --pmc, same command)"
-                vi = tr[key[0]].get("valu_wave_instructions")
-                ex = tr[key[0]].get("exclusive_avg_us")
-                if vi and ex:
-                    # secondary number SURVEY 8(d) asks for: achieved VALU issue.  1024 SIMDs,
-                    # one wave-instruction per 4 cycles at the 2.4 GHz peak clock.
-                    roof["valu"] = {"wave_instructions_per_launch": vi, "exclusive_ms": round(ex / 1e3, 4),
-                                    "issue_frac_of_peak": round(vi * 4 / (1024 * 2.4e9 * ex * 1e-6), 3),
-                                    "source": "same PMC run (SQ_INSTS_VALU) and its serialised kernel trace"}
-        except (OSError, ValueError, KeyError):
-            pass
-        roof_noref = roof
+        # k_search<128,2,1>: per band 2n B x16 in + 32 B record head in, 2 x 2n B pulses +
+        # 32 B record tail out = 6n + 64 = 832 B
+        roof_noref = search_roofline(
+            "k_search<128,2,1> (PVQ search of the 128-coefficient luma bands, no reference)",
+            "k_search<128", float(np.mean(search_excl)), float(np.mean(search_ms)), len(search_ms),
+            n128 * (6 * 128 + 64), n128, step_ms, pmc, pmc_src)
+        roof = roof_noref
+        roof_ref = None
         if cfl and ref_search_ms:
-            # The with-reference stage's search of the 128-coefficient bands (one band
-            # per 16-lane row), timed the same way (odhip_pvq_ref_profile).  Algorithmic
-            # bytes per launch are counted from what the launch produced: per band the
-            # 64 B record, the 254 B reflected vector (+ 256 B x16 when the no-reference
-            # candidates run), per candidate 16 B in + 16 B out (+ 16 B result when
-            # searched), and 256 B of pulses per search that stored its vector.
-            r_ms = float(np.mean(ref_search_ms))
-            r_bytes, r_bands = pipe.ref128_bytes()
-            roof_ref = {"kernel": "k_refb_search_row<8,16> (with-reference candidate chains of the "
-                                  "128-coefficient chroma bands, one band per 16-lane row)",
-                        "bound": "hbm", "achieved": round(r_bytes / (r_ms * 1e-3) / 1e9, 1),
-                        "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(r_bytes / (r_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                        "traffic": None, "avg_ms_per_launch": round(r_ms, 4),
-                        "launches": len(ref_search_ms),
-                        "share_of_step": round(r_ms / (dt / args.steps * 1e3), 4),
-                        "algorithmic_bytes_per_launch": r_bytes, "bands_per_launch": r_bands}
-            try:
-                with open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")) as f:
-                    tr = json.load(f)["kernels"]
-                key = [k_ for k_ in tr if k_.startswith("k_refb_search_row<8, 16>")]
-                if key and args.frames == DEFAULT_FRAMES:
-                    roof_ref["traffic"] = tr[key[0]]["hbm_bytes_per_launch"]
-                    roof_ref["traffic_source"] = ("profiles/r1_pmc_traffic.json (rocprofv3 --pmc, "
-                                                  "same command)")
-                    vi = tr[key[0]].get("valu_wave_instructions")
-                    ex = tr[key[0]].get("exclusive_avg_us")
-                    if vi and ex:
-                        roof_ref["valu"] = {"wave_instructions_per_launch": vi,
-                                            "exclusive_ms": round(ex / 1e3, 4),
-                                            "issue_frac_of_peak": round(vi * 4 / (1024 * 2.4e9 * ex * 1e-6), 3),
-                                            "source": "same PMC run (SQ_INSTS_VALU) and its serialised "
-                                                      "kernel trace"}
-            except (OSError, ValueError, KeyError):
-                pass
-            if r_ms >= s_ms:
+            roof_ref = search_roofline(
+                "k_refb_search_row<8,16> (with-reference candidate chains of the 128-coefficient "
+                "chroma bands, one band per 16-lane row)", "k_refb_search_row<8, 16>",
+                float(np.mean(ref_search_excl)), float(np.mean(ref_search_ms)), len(ref_search_ms),
+                r_bytes, r_bands, step_ms, pmc, pmc_src)
+            if roof_ref["avg_ms_per_launch"] >= roof_noref["avg_ms_per_launch"]:
                 roof = roof_ref
+        roof["note"] = ("the kernel with the largest exclusive duration of the step.  The K-pulse search "
+                        "is fp64 VALU-issue bound (13-14 VALU instructions per candidate per pulse, "
+                        "DESIGN.md): achieved = SQ_INSTS_VALU per launch (rocprofv3 --pmc, committed "
+                        "profile of this command) / exclusive duration measured live; `hbm` is the "
+                        "algorithmic-bytes figure SURVEY 8(d) asks for.  roofline_filter_dct is the stage "
+                        "the north star prices at >= 60 % of HBM")
         fd = kernels["forward_pyramid_luma"]
-        roof["note"] = ("largest single kernel of the step; it overlaps with the other band-size "
-                        "searches on forked streams, so its share is of wall time, not exclusive. "
-                        "The K-pulse search is fp64 VALU-issue bound (13 VALU instructions per "
-                        "candidate per pulse, DESIGN.md), HBM is quoted because SURVEY 8(d) prices "
-                        "it against HBM; see roofline_filter_dct for the stage the north star "
-                        "prices at >= 60 % of HBM")
         fd_gbs = ab["forward_pyramid_luma"] / (fd_alone * 1e-3) / 1e9
         roof_fd = {"kernel": "k_forward_pyramid64x2 (forward_pyramid_luma)", "bound": "hbm",
                    "achieved": round(fd_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -676,18 +546,12 @@ def main():
                    "copy_1GiB_GBs": round(copy_gbs, 1),
                    "frac_of_copy": round(fd_gbs / copy_gbs, 4),
                    "note": "copy_1GiB_GBs = the same run's device-to-device copy of 1 GiB (read + "
-                           "written), the practical ceiling SURVEY 8(d) asks for beside the 8 TB/s "
-                           "spec; "
+                           "written), the practical ceiling SURVEY 8(d) asks for beside the 8 TB/s spec; "
                            "timed alone after the steps (HIP events, 10 launches); in_step = the same "
                            "launch inside the step, where it shares the GPU with the other stream"}
-        try:
-            with open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")) as f:
-                tr = json.load(f)["kernels"]
-            key = [k_ for k_ in tr if k_.startswith("k_forward_pyramid64x2")]
-            if key and args.frames == DEFAULT_FRAMES:
-                roof_fd["traffic"] = tr[key[0]]["hbm_bytes_per_launch"]
-        except (OSError, ValueError, KeyError):
-            pass
+        key = [k_ for k_ in pmc if k_.startswith("k_forward_pyramid64x2")]
+        if key:
+            roof_fd["traffic"] = pmc[key[0]]["hbm_bytes_per_launch"]
         line = {
             "metric": "1080p all-intra transform blocks/s (filter+DCT+PVQ)",
             "value": total_blocks / dt,
@@ -695,32 +559,51 @@ def main():
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3,
-            # time the host spends enqueuing a step (it runs ahead of the GPU unless this
-            # approaches ms_per_step)
-            "host_enqueue_ms_per_step": host_s / args.steps * 1e3,
+            "ms_per_step": step_ms,
+            # the host's share: one C call per step (odhip_pipe_step) enqueues ~100 launches;
+            # host_wait = the device-acos margin check of the last step (odhip_pipe_flush)
+            "host_launch_ms_per_step": host_s / args.steps * 1e3,
+            "host_wait_ms_total": host_wait_s * 1e3,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "int32 (lifting DCT/filters) + f64 (PVQ search)",
             "data": "synthetic",
             "config": {"workload": "configs[1]: 1920x1080 4:2:0 all-intra frames, full "
-                       "4/8/16/32/64 lapped-DCT pyramid + PVQ noref bands + inverse, "
-                       "every block of every level" + (
-                           "; chroma through the with-reference (chroma-from-luma) PVQ path"
+                       "4/8/16/32/64 lapped-DCT pyramid + PVQ band stages + inverse, every block of "
+                       "every level" + (
+                           "; luma through pvq_theta's no-reference path, chroma through the "
+                           "with-reference (chroma-from-luma) path"
                            if cfl else "; chroma through the no-reference PVQ path"),
                        "frames_per_gpu_per_step": args.frames, "content": args.content,
                        "blocks_per_frame": bpf, "quality": "-v 20 (quantizer 243)",
+                       "choice": "on distortion alone inside the timed step (od_pvq_rate is host state "
+                                 "in the reference); `verified` runs the host-priced choice",
+                       "inputs": "resident in HBM (PCIe-inclusive rates: DESIGN.md section 5)",
+                       "driver": "odhip_pipe_step: one C call per step, two streams, one odhip_ctx "
+                                 "per chain",
                        "sharding": "frames over ranks, no data-path collective"},
             "roofline": roof,
             "roofline_filter_dct": roof_fd,
             "roofline_noref_search": roof_noref if roof is not roof_noref else None,
+            "roofline_ref_search": roof_ref if (roof_ref is not None and roof is not roof_ref) else None,
+            "pipelined_equals_serial": digest == serial_digest,
+            "theta_margin_reruns": pipe.theta_reruns(),
             "kernels": kernels,
         }
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(pipe.qt, cfl)
-            line["speedup_vs_cpu_baseline"] = line["value"] / line["cpu_baseline"]["value"]
+            frame0 = [luma_pic[0], chroma_pic[0], chroma_pic[args.frames]]
+            base, host, ver = cpu_baseline(D, qt, cfl, args, frame0)
+            if base is not None:
+                line["cpu_baseline"] = base
+                line["speedup_vs_cpu_baseline"] = line["value"] / base["value"]
+            if host is not None:
+                line["cpu_baseline_all_cores"] = host
+                line["speedup_vs_all_host_cores"] = line["value"] / host["value"]
+            line["verified"] = ver["verified"]
+            line["verification"] = ver
         print(json.dumps(line))
+    pipe.destroy()
     if dist is not None:
         dist.destroy_process_group()
 

@@ -21,5 +21,7 @@ from .api import (DaalaHipError, lib, lib_path, init, fdct2d_batch, idct2d_batch
                   REFITEM_RECORD, REFBAND_R_NULL, REFBAND_THETA, REFBAND_NOREF, REFBAND_FLIP,
                   REFBAND_UNCERTAIN, REFITEM_SEARCHED, REFITEM_WITH_REF, REFITEM_K_RANGE, pvq_ref_profile,
                   pvq_ref_profile_read, image_planes_copy_pad, inverse_levels, pvq_ref_resolve_finish, cfl_refs_from_luma, pvq_ref_set_context,
-                  pvq_ref_choose_multi, inverse_levels_pvq_ref)
+                  pvq_ref_choose_multi, inverse_levels_pvq_ref, Context, Pipe, PIPE_STAGES,
+                  BUF_PIC, BUF_PX, BUF_LEVEL, BUF_RECON, BUF_BAND, BUF_Y, BUF_CHOICE, BUF_ITEMS,
+                  BUF_REF, BUF_RATE)
 from .quant import QuantTables, OD_PVQ_LAMBDA  # noqa: F401

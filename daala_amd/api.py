@@ -733,3 +733,150 @@ def inverse_levels_pvq_ref(jobs, dec, pic_w, pic_h, outs=None):
                                               len(jobs), int(dec), int(pic_w), int(pic_h), _stream()),
            "odhip_inverse_levels_pvq_ref")
     return outs
+
+
+# ---- contexts ------------------------------------------------------------------------
+class Context:
+    """odhip_ctx: owner of the library state one call sequence needs (daala_hip.h).
+    `with ctx:` makes it the calling thread's current context."""
+
+    def __init__(self, device=0):
+        lib().odhip_create.restype = ctypes.c_void_p
+        self.handle = lib().odhip_create(int(device))
+        if not self.handle:
+            raise DaalaHipError("odhip_create(%d) failed" % device)
+        self._prev = []
+
+    def __enter__(self):
+        lib().odhip_get_current.restype = ctypes.c_void_p
+        self._prev.append(lib().odhip_get_current())
+        _check(lib().odhip_make_current(ctypes.c_void_p(self.handle)), "odhip_make_current")
+        return self
+
+    def __exit__(self, *exc):
+        _check(lib().odhip_make_current(ctypes.c_void_p(self._prev.pop())), "odhip_make_current")
+
+    def destroy(self):
+        if self.handle:
+            lib().odhip_destroy(ctypes.c_void_p(self.handle))
+            self.handle = None
+
+
+# ---- odhip_pipe: the frame-batch step as one C call -----------------------------------
+PIPE_STAGES = ("image_copy_pad_luma", "forward_pyramid_luma", "pvq_noref_bands", "pvq_choose",
+               "cfl_refs_from_luma", "dequant_inverse_luma", "image_copy_pad_chroma",
+               "forward_pyramid_chroma", "pvq_ref_bands", "pvq_ref_choose", "dequant_inverse_chroma")
+(BUF_PIC, BUF_PX, BUF_LEVEL, BUF_RECON, BUF_BAND, BUF_Y, BUF_CHOICE, BUF_ITEMS, BUF_REF,
+ BUF_RATE) = range(10)
+
+
+class _PipeConfig(ctypes.Structure):
+    _fields_ = [("device", ctypes.c_int), ("frames", ctypes.c_int), ("pic_w", ctypes.c_int),
+                ("pic_h", ctypes.c_int), ("chroma_cfl", ctypes.c_int), ("serial", ctypes.c_int),
+                ("pvq_norm_lambda", ctypes.c_double), ("quant", ctypes.c_void_p)]
+
+
+class Pipe:
+    """ctypes mirror of odhip_pipe (include/daala_hip.h): F resident 4:2:0 pictures,
+    one C call per step.  Buffers are read / written as numpy arrays."""
+
+    def __init__(self, quant, frames, pic_w, pic_h, chroma_cfl=True, serial=False, device=0,
+                 pvq_norm_lambda=0.147):
+        L = lib()
+        L.odhip_pipe_create.restype = ctypes.c_void_p
+        L.odhip_pipe_theta_reruns.restype = ctypes.c_long
+        cfg = _PipeConfig(int(device), int(frames), int(pic_w), int(pic_h), int(bool(chroma_cfl)),
+                          int(bool(serial)), float(pvq_norm_lambda),
+                          ctypes.cast(ctypes.byref(quant.c), ctypes.c_void_p))
+        self.h = L.odhip_pipe_create(ctypes.byref(cfg))
+        if not self.h:
+            raise DaalaHipError("odhip_pipe_create failed")
+        self.frames, self.pic_w, self.pic_h = int(frames), int(pic_w), int(pic_h)
+        self.W, self.H = (pic_w + 63) & ~63, (pic_h + 63) & ~63
+        self.chroma_cfl = bool(chroma_cfl)
+
+    def _p(self):
+        return ctypes.c_void_p(self.h)
+
+    def destroy(self):
+        if self.h:
+            lib().odhip_pipe_destroy(self._p())
+            self.h = None
+
+    def set_pictures(self, luma, chroma):
+        """luma uint8 [F, pic_h, pic_w], chroma uint8 [2F, pic_h/2, pic_w/2] (all Cb, then
+        all Cr): numpy arrays (uploaded) or CUDA tensors (device copy)."""
+        dev = hasattr(luma, "data_ptr")
+        pl = luma.data_ptr() if dev else np.ascontiguousarray(luma, np.uint8).ctypes.data
+        pc = chroma.data_ptr() if dev else np.ascontiguousarray(chroma, np.uint8).ctypes.data
+        assert tuple(luma.shape) == (self.frames, self.pic_h, self.pic_w)
+        assert tuple(chroma.shape) == (2 * self.frames, self.pic_h // 2, self.pic_w // 2)
+        _check(lib().odhip_pipe_set_pictures(self._p(), ctypes.c_void_p(pl), ctypes.c_void_p(pc),
+                                             int(dev)), "odhip_pipe_set_pictures")
+
+    def step(self):
+        _check(lib().odhip_pipe_step(self._p()), "odhip_pipe_step")
+
+    def flush(self):
+        _check(lib().odhip_pipe_flush(self._p()), "odhip_pipe_flush")
+
+    def sync(self):
+        _check(lib().odhip_pipe_sync(self._p()), "odhip_pipe_sync")
+
+    def stage(self, name, parity=0):
+        _check(lib().odhip_pipe_stage(self._p(), PIPE_STAGES.index(name), int(parity)),
+               "odhip_pipe_stage(%s)" % name)
+
+    def buffer(self, what, set_, level=0, parity=0):
+        ptr = ctypes.c_void_p()
+        n = ctypes.c_size_t()
+        _check(lib().odhip_pipe_buffer(self._p(), int(what), int(set_), int(level), int(parity),
+                                       ctypes.byref(ptr), ctypes.byref(n)), "odhip_pipe_buffer")
+        return ptr.value, n.value
+
+    def read(self, what, set_, level=0, parity=0, dtype=np.uint8):
+        ptr, n = self.buffer(what, set_, level, parity)
+        out = np.empty(n, np.uint8)
+        _check(lib().odhip_pipe_read(self._p(), out.ctypes.data_as(ctypes.c_void_p),
+                                     ctypes.c_void_p(ptr), ctypes.c_size_t(n)), "odhip_pipe_read")
+        return out.view(dtype)
+
+    def write(self, what, set_, level, data, parity=0):
+        ptr, n = self.buffer(what, set_, level, parity)
+        data = np.ascontiguousarray(data)
+        assert data.nbytes == n, (data.nbytes, n)
+        _check(lib().odhip_pipe_write(self._p(), ctypes.c_void_p(ptr),
+                                      data.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(n)),
+               "odhip_pipe_write")
+
+    def record(self, enable):
+        _check(lib().odhip_pipe_record(self._p(), int(bool(enable))), "odhip_pipe_record")
+
+    def timings(self):
+        """{stage: (average ms per launch group, groups)} of the recorded steps."""
+        ms = (ctypes.c_double * len(PIPE_STAGES))()
+        cnt = (ctypes.c_int * len(PIPE_STAGES))()
+        _check(lib().odhip_pipe_timings(self._p(), ms, cnt), "odhip_pipe_timings")
+        return {PIPE_STAGES[i]: (ms[i], cnt[i]) for i in range(len(PIPE_STAGES)) if cnt[i]}
+
+    def search_timings(self, chroma, max_n=256):
+        buf = (ctypes.c_float * max_n)()
+        n = lib().odhip_pipe_search_timings(self._p(), int(bool(chroma)), buf, max_n)
+        if n < 0:
+            raise DaalaHipError("odhip_pipe_search_timings failed with code %d" % n)
+        return [buf[i] for i in range(n)]
+
+    def time_pyramid(self, n=10):
+        ms = ctypes.c_double()
+        _check(lib().odhip_pipe_time_pyramid(self._p(), int(n), ctypes.byref(ms)),
+               "odhip_pipe_time_pyramid")
+        return ms.value
+
+    def theta_reruns(self):
+        return int(lib().odhip_pipe_theta_reruns(self._p()))
+
+    def nblocks(self, set_, level):
+        n = 4 << level
+        dec = 1 if set_ else 0
+        planes = self.frames * (2 if set_ else 1)
+        return planes * ((self.W >> dec) // n) * ((self.H >> dec) // n)

@@ -89,6 +89,12 @@ extern "C" odhip_ctx *odhip_get_current(void) {
   return t_state.current;
 }
 
+extern "C" int odhip_ctx_set_serial(odhip_ctx *ctx, int serial) {
+  if (!ctx) return ODHIP_EINVAL;
+  ctx->serial = serial != 0;
+  return ODHIP_SUCCESS;
+}
+
 extern "C" int odhip_ctx_device(const odhip_ctx *ctx) {
   return ctx ? ctx->device : ODHIP_EINVAL;
 }

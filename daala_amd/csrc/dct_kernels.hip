@@ -215,6 +215,8 @@ extern "C" int odhip_fdct2d_batch(int ln, od_coeff *d_out, const od_coeff *d_in,
   if (ln < 0 || ln >= ODHIP_NBSIZES) return ODHIP_EINVAL;
   if (nblocks <= 0) return nblocks < 0 ? ODHIP_EINVAL : ODHIP_SUCCESS;
   if (!d_out || !d_in) return ODHIP_EINVAL;
+  /* 16-byte vector loads and stores */
+  if (((uintptr_t)d_out | (uintptr_t)d_in) & 15) return ODHIP_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   return exact32 ? launch_batch<false, OdMul32>(ln, d_out, d_in, nblocks, s)
                  : launch_batch<false, OdMul24>(ln, d_out, d_in, nblocks, s);
@@ -225,6 +227,8 @@ extern "C" int odhip_idct2d_batch(int ln, od_coeff *d_out, const od_coeff *d_in,
   if (ln < 0 || ln >= ODHIP_NBSIZES) return ODHIP_EINVAL;
   if (nblocks <= 0) return nblocks < 0 ? ODHIP_EINVAL : ODHIP_SUCCESS;
   if (!d_out || !d_in) return ODHIP_EINVAL;
+  /* 16-byte vector loads and stores */
+  if (((uintptr_t)d_out | (uintptr_t)d_in) & 15) return ODHIP_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   return exact32 ? launch_batch<true, OdMul32>(ln, d_out, d_in, nblocks, s)
                  : launch_batch<true, OdMul24>(ln, d_out, d_in, nblocks, s);
@@ -234,6 +238,7 @@ extern "C" int odhip_fdct2d_plane(int ln, od_coeff *d_out, int out_stride,
  const od_coeff *d_in, int in_stride, int w, int h, int exact32,
  odhip_stream stream) {
   if (ln < 0 || ln >= ODHIP_NBSIZES || !d_out || !d_in) return ODHIP_EINVAL;
+  if (((uintptr_t)d_out | (uintptr_t)d_in) & 15) return ODHIP_EINVAL;   /* 16-byte vectors */
   hipStream_t s = (hipStream_t)stream;
   return exact32
    ? launch_plane<false, OdMul32>(ln, d_out, out_stride, d_in, in_stride, w, h, s)
@@ -244,6 +249,7 @@ extern "C" int odhip_idct2d_plane(int ln, od_coeff *d_out, int out_stride,
  const od_coeff *d_in, int in_stride, int w, int h, int exact32,
  odhip_stream stream) {
   if (ln < 0 || ln >= ODHIP_NBSIZES || !d_out || !d_in) return ODHIP_EINVAL;
+  if (((uintptr_t)d_out | (uintptr_t)d_in) & 15) return ODHIP_EINVAL;   /* 16-byte vectors */
   hipStream_t s = (hipStream_t)stream;
   return exact32
    ? launch_plane<true, OdMul32>(ln, d_out, out_stride, d_in, in_stride, w, h, s)

@@ -25,6 +25,7 @@ enum {
 
 struct odhip_ctx {
   int device;
+  int serial;              /* odhip_ctx_set_serial: no internal side streams */
   void *slot[ODHIP_SLOT_COUNT];
   void (*drop[ODHIP_SLOT_COUNT])(void *);
 };

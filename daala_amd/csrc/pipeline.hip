@@ -1,0 +1,692 @@
+/* pipeline.hip - odhip_pipe: the frame-batch step as ONE C call.
+
+   One step = one pass of the block-transform hot path over F resident 4:2:0
+   pictures (what bench.py times and a frame-parallel all-intra encoder would run
+   per batch; round 1 drove it from Python with ~100 ctypes calls per step):
+
+     luma chain   (context / stream A)       chroma chain (context / stream B)
+       od_img_plane_copy_pad                   od_img_plane_copy_pad
+       forward pyramid, 5 levels               forward pyramid, 4 levels
+       PVQ band stage, no reference            [wait: references of this step]
+       choice                                  PVQ band stage WITH the chroma-from-luma
+       chroma-from-luma references  ------>      reference (src/encode.c:1680-1687)
+       dequantise + inverse, 5 levels          choice, dequantise + inverse, 4 levels
+
+   The two chains are software-pipelined over steps: the luma chain of step i+1
+   overlaps the chroma chain of step i (two reference buffers, events both ways).
+   Each chain has its OWN odhip_ctx - scratch, edge strips, job tables and side
+   streams are never shared between streams - and the pipe owns every device
+   buffer and both streams.
+
+   With cfg.chroma_cfl == 0 chroma goes through the no-reference stage together with
+   luma on one stream (round 1's first workload).  Rate tables (the host's od_pvq_rate
+   results, one double per candidate) are optional per plane set: without them the
+   choice is made on distortion alone.
+
+   Host code only; the kernels are the batched entry points of daala_hip.h. */
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+#include "od_ctx.cuh"
+#include "gen/od_scan_tables.h"
+
+namespace {
+
+constexpr int kStages = ODHIP_PIPE_NSTAGES;
+constexpr int kMaxTimed = 4096;
+
+struct PlaneSet {
+  int dec;
+  int pli;
+  int nplanes;
+  int w, h;          /* coded plane size */
+  int pw, ph;        /* picture size in this plane */
+  int nlev;
+  uint8_t *pic;
+  uint8_t *px;
+  od_coeff *levels[ODHIP_NBSIZES];
+  uint8_t *recon[ODHIP_NBSIZES];
+  int16_t *qm[ODHIP_NBSIZES];
+  int16_t *qm_inv[ODHIP_NBSIZES];
+  int32_t q[ODHIP_NBSIZES][ODHIP_MAX_BANDS];
+  int32_t beta[ODHIP_NBSIZES][ODHIP_MAX_BANDS];
+  long nblocks[ODHIP_NBSIZES];
+};
+
+}  // namespace
+
+struct odhip_pipe {
+  odhip_pipe_config cfg;
+  int pic_w, pic_h, W, H;
+  odhip_ctx *ctx[2];              /* 0: luma chain, 1: chroma chain */
+  hipStream_t stream[2];
+  bool serial;
+  PlaneSet set[2];
+  odhip_pvq_job jobs[2*ODHIP_NBSIZES];       /* luma 0..4, chroma (no-reference mode) 5..8 */
+  int njobs;
+  od_coeff *refs[2][ODHIP_NBSIZES];          /* [parity][chroma level] */
+  odhip_pvq_refjob refjobs[2][ODHIP_NBSIZES];
+  double *rate[2][ODHIP_NBSIZES];
+  hipEvent_t ev_refs[2];
+  hipEvent_t ev_used[2];
+  long nstep;
+  int pending;                    /* parity of the step whose theta list is unchecked, -1 */
+  long reruns;                    /* bands re-run with the host's theta so far */
+  bool record;
+  std::vector<hipEvent_t> timed[kStages];    /* pairs */
+  std::vector<void *> owned;
+};
+
+namespace {
+
+int alloc(odhip_pipe *p, void **out, size_t bytes, bool zero) {
+  void *d = nullptr;
+  ODHIP_TRY(hipMalloc(&d, bytes ? bytes : 16));
+  p->owned.push_back(d);
+  if (zero) ODHIP_TRY(hipMemset(d, 0, bytes ? bytes : 16));
+  *out = d;
+  return ODHIP_SUCCESS;
+}
+#define PIPE_ALLOC(p, ptr, bytes, zero) \
+  do { \
+    const int rc_ = alloc((p), (void **)&(ptr), (bytes), (zero)); \
+    if (rc_) return rc_; \
+  } while (0)
+
+struct Timed {
+  odhip_pipe *p;
+  int stage;
+  hipStream_t s;
+  bool on;
+  Timed(odhip_pipe *p_, int stage_, hipStream_t s_) : p(p_), stage(stage_), s(s_) {
+    on = p->record && p->timed[stage].size() < (size_t)2*kMaxTimed;
+    if (on) mark();
+  }
+  ~Timed() {
+    if (on) mark();
+  }
+  void mark() {
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) {
+      on = false;
+      return;
+    }
+    (void)hipEventRecord(e, s);
+    p->timed[stage].push_back(e);
+  }
+};
+
+int setup_set(odhip_pipe *p, PlaneSet &s, int dec, int pli, int nplanes) {
+  const odhip_quant *qt = p->cfg.quant;
+  s.dec = dec;
+  s.pli = pli;
+  s.nplanes = nplanes;
+  s.w = p->W >> dec;
+  s.h = p->H >> dec;
+  s.pw = (p->pic_w + dec) >> dec;
+  s.ph = (p->pic_h + dec) >> dec;
+  s.nlev = ODHIP_NBSIZES - dec;
+  PIPE_ALLOC(p, s.pic, (size_t)nplanes*s.pw*s.ph, true);
+  PIPE_ALLOC(p, s.px, (size_t)nplanes*s.w*s.h, true);
+  for (int bs = 0; bs < s.nlev; bs++) {
+    const int n = 4 << bs;
+    const int len = n*n < OD_SCAN_LEN ? n*n : OD_SCAN_LEN;
+    PIPE_ALLOC(p, s.levels[bs], sizeof(od_coeff)*(size_t)nplanes*s.w*s.h, true);
+    PIPE_ALLOC(p, s.recon[bs], (size_t)nplanes*s.w*s.h, true);
+    PIPE_ALLOC(p, s.qm[bs], sizeof(int16_t)*len, false);
+    PIPE_ALLOC(p, s.qm_inv[bs], sizeof(int16_t)*len, false);
+    const int off = odhip_qm_offset(bs, dec);
+    ODHIP_TRY(hipMemcpy(s.qm[bs], qt->qm + off, sizeof(int16_t)*len, hipMemcpyHostToDevice));
+    ODHIP_TRY(hipMemcpy(s.qm_inv[bs], qt->qm_inv + off, sizeof(int16_t)*len, hipMemcpyHostToDevice));
+    if (odhip_quant_bands(qt, pli, bs, s.q[bs], s.beta[bs]) < 0) return ODHIP_EINVAL;
+    s.nblocks[bs] = (long)nplanes*(s.w/n)*(s.h/n);
+  }
+  return ODHIP_SUCCESS;
+}
+
+int setup_job(odhip_pipe *p, odhip_pvq_job &j, PlaneSet &s, int bs) {
+  int nb = 0;
+  int len = 0;
+  odhip_pvq_band_layout(bs, &nb, nullptr, &len);
+  memset(&j, 0, sizeof(j));
+  j.d_coef = s.levels[bs];
+  j.nplanes = s.nplanes;
+  j.w = s.w;
+  j.h = s.h;
+  j.bs = bs;
+  j.d_qm = s.qm[bs];
+  j.d_qm_inv = s.qm_inv[bs];
+  j.q_band = s.q[bs];
+  j.beta_band = s.beta[bs];
+  const long B = s.nblocks[bs];
+  PIPE_ALLOC(p, j.cands.band, sizeof(odhip_pvq_band)*(size_t)B*nb, true);
+  PIPE_ALLOC(p, j.cands.y, sizeof(int16_t)*(size_t)2*B*len, true);
+  PIPE_ALLOC(p, j.cands.choice, sizeof(int32_t)*(size_t)B*nb*4, true);
+  return ODHIP_SUCCESS;
+}
+
+int setup_refjob(odhip_pipe *p, odhip_pvq_refjob &j, PlaneSet &s, int bs, const od_coeff *ref,
+ const odhip_pvq_refjob *share) {
+  int nb = 0;
+  int len = 0;
+  odhip_pvq_band_layout(bs, &nb, nullptr, &len);
+  memset(&j, 0, sizeof(j));
+  j.d_coef = s.levels[bs];
+  j.d_ref = ref;
+  j.nplanes = s.nplanes;
+  j.w = s.w;
+  j.h = s.h;
+  j.bs = bs;
+  j.is_keyframe = 1;
+  j.pli = s.pli;
+  j.d_qm = s.qm[bs];
+  j.d_qm_inv = s.qm_inv[bs];
+  j.q_band = s.q[bs];
+  j.beta_band = s.beta[bs];
+  if (share) {
+    /* same planes, the other reference buffer: outputs and work vectors are shared
+       (the chroma chains of consecutive steps run in order on one stream) */
+    j.band = share->band;
+    j.items = share->items;
+    j.y = share->y;
+    j.r16 = share->r16;
+    j.x16 = share->x16;
+    j.xr = share->xr;
+    j.choice = share->choice;
+    return ODHIP_SUCCESS;
+  }
+  const long B = s.nblocks[bs];
+  PIPE_ALLOC(p, j.band, sizeof(odhip_pvq_refband)*(size_t)B*nb, true);
+  PIPE_ALLOC(p, j.items, (size_t)3*nb*ODHIP_PVQ_REF_SLOTS*B*16, true);
+  PIPE_ALLOC(p, j.y, sizeof(int16_t)*(size_t)ODHIP_PVQ_REF_SLOTS*B*len, true);
+  PIPE_ALLOC(p, j.r16, sizeof(int16_t)*(size_t)B*len, true);
+  PIPE_ALLOC(p, j.x16, sizeof(int16_t)*(size_t)B*len, true);
+  PIPE_ALLOC(p, j.xr, sizeof(int16_t)*(size_t)B*len, true);
+  PIPE_ALLOC(p, j.choice, sizeof(int32_t)*(size_t)B*nb*16, true);
+  return ODHIP_SUCCESS;
+}
+
+int pipe_init(odhip_pipe *p) {
+  const odhip_pipe_config &c = p->cfg;
+  ODHIP_TRY(hipSetDevice(c.device));
+  p->pic_w = c.pic_w;
+  p->pic_h = c.pic_h;
+  p->W = (c.pic_w + 63) & ~63;     /* coded frame size, src/state.c:376-379 */
+  p->H = (c.pic_h + 63) & ~63;
+  p->serial = c.serial || getenv("ODHIP_PVQ_SERIAL") != nullptr;
+  for (int i = 0; i < 2; i++) {
+    p->ctx[i] = odhip_create(c.device);
+    if (!p->ctx[i]) return ODHIP_EFAULT;
+    odhip_ctx_set_serial(p->ctx[i], p->serial);
+  }
+  ODHIP_TRY(hipStreamCreateWithFlags(&p->stream[0], hipStreamNonBlocking));
+  if (p->serial) p->stream[1] = p->stream[0];
+  else ODHIP_TRY(hipStreamCreateWithFlags(&p->stream[1], hipStreamNonBlocking));
+  int rc = setup_set(p, p->set[0], 0, 0, c.frames);
+  if (rc) return rc;
+  rc = setup_set(p, p->set[1], 1, 1, 2*c.frames);
+  if (rc) return rc;
+  for (int bs = 0; bs < 5; bs++) {
+    rc = setup_job(p, p->jobs[bs], p->set[0], bs);
+    if (rc) return rc;
+  }
+  p->njobs = 5;
+  if (!c.chroma_cfl) {
+    for (int bs = 0; bs < 4; bs++) {
+      rc = setup_job(p, p->jobs[5 + bs], p->set[1], bs);
+      if (rc) return rc;
+    }
+    p->njobs = 9;
+  }
+  else {
+    PlaneSet &ch = p->set[1];
+    for (int par = 0; par < 2; par++) {
+      for (int bs = 0; bs < 4; bs++) {
+        PIPE_ALLOC(p, p->refs[par][bs], sizeof(od_coeff)*(size_t)ch.nplanes*ch.w*ch.h, true);
+        rc = setup_refjob(p, p->refjobs[par][bs], ch, bs, p->refs[par][bs],
+         par ? &p->refjobs[0][bs] : nullptr);
+        if (rc) return rc;
+      }
+      ODHIP_TRY(hipEventCreateWithFlags(&p->ev_refs[par], hipEventDisableTiming));
+      ODHIP_TRY(hipEventCreateWithFlags(&p->ev_used[par], hipEventDisableTiming));
+    }
+  }
+  p->pending = -1;
+  ODHIP_TRY(hipDeviceSynchronize());
+  return ODHIP_SUCCESS;
+}
+
+/* Makes ctx current for the scope, restores the caller's selection afterwards. */
+struct Current {
+  odhip_ctx *prev;
+  explicit Current(odhip_ctx *c) : prev(odhip_get_current()) {
+    (void)odhip_make_current(c);
+  }
+  ~Current() {
+    (void)odhip_make_current(prev);
+  }
+};
+
+int stage_pad(odhip_pipe *p, int si, hipStream_t s) {
+  PlaneSet &t = p->set[si];
+  Timed tm(p, si ? ODHIP_PIPE_PAD_CHROMA : ODHIP_PIPE_PAD_LUMA, s);
+  return odhip_image_planes_copy_pad(t.px, t.w, (long)t.w*t.h, t.w, t.h, t.pic, t.pw, (long)t.pw*t.ph,
+   t.pw, t.ph, t.nplanes, s);
+}
+
+int stage_pyramid(odhip_pipe *p, int si, hipStream_t s) {
+  PlaneSet &t = p->set[si];
+  Timed tm(p, si ? ODHIP_PIPE_PYRAMID_CHROMA : ODHIP_PIPE_PYRAMID_LUMA, s);
+  return odhip_forward_pyramid(t.levels, t.px, t.w, (long)t.w*t.h, t.nplanes, t.w, t.h, t.dec,
+   p->pic_w, p->pic_h, s);
+}
+
+int stage_inverse_noref(odhip_pipe *p, int si, hipStream_t s) {
+  PlaneSet &t = p->set[si];
+  Timed tm(p, si ? ODHIP_PIPE_INVERSE_CHROMA : ODHIP_PIPE_INVERSE_LUMA, s);
+  return odhip_inverse_levels_pvq(t.recon, t.w, (long)t.w*t.h, p->jobs + (si ? 5 : 0), t.nlev, t.dec,
+   p->pic_w, p->pic_h, s);
+}
+
+int chroma_tail(odhip_pipe *p, int par, hipStream_t s) {
+  PlaneSet &ch = p->set[1];
+  const double lam = p->cfg.pvq_norm_lambda;
+  int rc;
+  {
+    Timed tm(p, ODHIP_PIPE_CHOOSE_CHROMA, s);
+    rc = odhip_pvq_ref_choose_multi(p->refjobs[par], 4, lam, s);
+  }
+  if (rc) return rc;
+  Timed tm(p, ODHIP_PIPE_INVERSE_CHROMA, s);
+  return odhip_inverse_levels_pvq_ref(ch.recon, ch.w, (long)ch.w*ch.h, p->refjobs[par], 4, 1, p->pic_w,
+   p->pic_h, s);
+}
+
+/* The count of bands inside the device-acos margin of the previous step's
+   with-reference stage is checked one step late, so the host never waits inside a
+   step; a listed band whose theta the host corrects (never seen outside the forced
+   tests) repeats what consumed it. */
+int finish_pending(odhip_pipe *p) {
+  if (p->pending < 0) return ODHIP_SUCCESS;
+  const int par = p->pending;
+  p->pending = -1;
+  Current cur(p->ctx[1]);
+  const int n = odhip_pvq_ref_resolve_finish(p->refjobs[par], 4, p->cfg.pvq_norm_lambda, p->stream[1]);
+  if (n < 0) return n;
+  if (n > 0) {
+    p->reruns += n;
+    return chroma_tail(p, par, p->stream[1]);
+  }
+  return ODHIP_SUCCESS;
+}
+
+#define STEP_TRY(expr) \
+  do { \
+    const int rc_ = (expr); \
+    if (rc_) return rc_; \
+  } while (0)
+
+int luma_front(odhip_pipe *p, hipStream_t s) {
+  const double lam = p->cfg.pvq_norm_lambda;
+  STEP_TRY(stage_pad(p, 0, s));
+  STEP_TRY(stage_pyramid(p, 0, s));
+  if (!p->cfg.chroma_cfl) {
+    STEP_TRY(stage_pad(p, 1, s));
+    STEP_TRY(stage_pyramid(p, 1, s));
+  }
+  {
+    Timed tm(p, ODHIP_PIPE_BANDS_LUMA, s);
+    STEP_TRY(odhip_pvq_noref_bands_multi(p->jobs, p->njobs, lam, s));
+  }
+  return ODHIP_SUCCESS;
+}
+
+int luma_choose(odhip_pipe *p, hipStream_t s) {
+  Timed tm(p, ODHIP_PIPE_CHOOSE_LUMA, s);
+  return odhip_pvq_choose_multi(p->jobs, p->njobs, p->cfg.pvq_norm_lambda, s);
+}
+
+int luma_refs(odhip_pipe *p, int par, hipStream_t s) {
+  Timed tm(p, ODHIP_PIPE_CFL_REFS, s);
+  return odhip_cfl_refs_from_luma(p->jobs + 1, 4, p->refs[par], 2, s);
+}
+
+int chroma_bands(odhip_pipe *p, int par, hipStream_t s) {
+  Timed tm(p, ODHIP_PIPE_BANDS_CHROMA, s);
+  STEP_TRY(odhip_pvq_ref_bands_multi(p->refjobs[par], 4, p->cfg.pvq_norm_lambda, s));
+  return odhip_pvq_ref_resolve_begin(s);
+}
+
+int step_noref(odhip_pipe *p) {
+  hipStream_t s = p->stream[0];
+  Current cur(p->ctx[0]);
+  STEP_TRY(luma_front(p, s));
+  STEP_TRY(luma_choose(p, s));
+  STEP_TRY(stage_inverse_noref(p, 0, s));
+  return stage_inverse_noref(p, 1, s);
+}
+
+int step_cfl(odhip_pipe *p) {
+  hipStream_t main = p->stream[0];
+  hipStream_t side = p->stream[1];
+  const int par = (int)(p->nstep & 1);
+  {
+    Current cur(p->ctx[0]);
+    STEP_TRY(luma_front(p, main));
+    STEP_TRY(luma_choose(p, main));
+    /* step i-2 no longer reads this reference buffer */
+    ODHIP_TRY(hipStreamWaitEvent(main, p->ev_used[par], 0));
+    STEP_TRY(luma_refs(p, par, main));
+    ODHIP_TRY(hipEventRecord(p->ev_refs[par], main));
+    STEP_TRY(stage_inverse_noref(p, 0, main));
+  }
+  STEP_TRY(finish_pending(p));
+  {
+    Current cur(p->ctx[1]);
+    STEP_TRY(stage_pad(p, 1, side));
+    STEP_TRY(stage_pyramid(p, 1, side));
+    ODHIP_TRY(hipStreamWaitEvent(side, p->ev_refs[par], 0));
+    STEP_TRY(chroma_bands(p, par, side));
+    STEP_TRY(chroma_tail(p, par, side));
+    ODHIP_TRY(hipEventRecord(p->ev_used[par], side));
+  }
+  p->pending = par;
+  return ODHIP_SUCCESS;
+}
+
+}  // namespace
+
+extern "C" odhip_pipe *odhip_pipe_create(const odhip_pipe_config *cfg) {
+  if (!cfg || !cfg->quant || cfg->frames <= 0 || cfg->pic_w <= 0 || cfg->pic_h <= 0
+   || (cfg->pic_w & 1) || (cfg->pic_h & 1)) {
+    return nullptr;
+  }
+  odhip_pipe *p = new odhip_pipe();
+  p->cfg = *cfg;
+  p->ctx[0] = p->ctx[1] = nullptr;
+  p->stream[0] = p->stream[1] = nullptr;
+  p->njobs = 0;
+  p->nstep = 0;
+  p->reruns = 0;
+  p->record = false;
+  memset(p->rate, 0, sizeof(p->rate));
+  memset(p->refs, 0, sizeof(p->refs));
+  memset(p->ev_refs, 0, sizeof(p->ev_refs));
+  memset(p->ev_used, 0, sizeof(p->ev_used));
+  if (pipe_init(p) != ODHIP_SUCCESS) {
+    odhip_pipe_destroy(p);
+    return nullptr;
+  }
+  /* the quantiser tables were copied to the device; do not keep the caller's pointer */
+  p->cfg.quant = nullptr;
+  return p;
+}
+
+extern "C" void odhip_pipe_destroy(odhip_pipe *p) {
+  if (!p) return;
+  (void)hipSetDevice(p->cfg.device);
+  (void)hipDeviceSynchronize();
+  for (int i = 0; i < 2; i++) {
+    if (p->ctx[i]) odhip_destroy(p->ctx[i]);
+    if (p->ev_refs[i]) (void)hipEventDestroy(p->ev_refs[i]);
+    if (p->ev_used[i]) (void)hipEventDestroy(p->ev_used[i]);
+  }
+  if (p->stream[1] && p->stream[1] != p->stream[0]) (void)hipStreamDestroy(p->stream[1]);
+  if (p->stream[0]) (void)hipStreamDestroy(p->stream[0]);
+  for (int i = 0; i < kStages; i++) {
+    for (hipEvent_t e : p->timed[i]) (void)hipEventDestroy(e);
+  }
+  for (void *d : p->owned) (void)hipFree(d);
+  delete p;
+}
+
+extern "C" int odhip_pipe_set_pictures(odhip_pipe *p, const uint8_t *luma, const uint8_t *chroma,
+ int on_device) {
+  if (!p || !luma || !chroma) return ODHIP_EINVAL;
+  /* a step still in flight may be reading the pictures */
+  const int rc = odhip_pipe_sync(p);
+  if (rc) return rc;
+  const hipMemcpyKind kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+  const PlaneSet &l = p->set[0];
+  const PlaneSet &c = p->set[1];
+  ODHIP_TRY(hipMemcpyAsync(l.pic, luma, (size_t)l.nplanes*l.pw*l.ph, kind, p->stream[0]));
+  ODHIP_TRY(hipMemcpyAsync(c.pic, chroma, (size_t)c.nplanes*c.pw*c.ph, kind, p->stream[0]));
+  ODHIP_TRY(hipStreamSynchronize(p->stream[0]));
+  return ODHIP_SUCCESS;
+}
+
+extern "C" int odhip_pipe_step(odhip_pipe *p) {
+  if (!p) return ODHIP_EINVAL;
+  ODHIP_TRY(hipSetDevice(p->cfg.device));
+  const int rc = p->cfg.chroma_cfl ? step_cfl(p) : step_noref(p);
+  p->nstep++;
+  return rc;
+}
+
+extern "C" int odhip_pipe_flush(odhip_pipe *p) {
+  if (!p) return ODHIP_EINVAL;
+  return finish_pending(p);
+}
+
+extern "C" int odhip_pipe_sync(odhip_pipe *p) {
+  if (!p) return ODHIP_EINVAL;
+  ODHIP_TRY(hipStreamSynchronize(p->stream[0]));
+  if (p->stream[1] != p->stream[0]) ODHIP_TRY(hipStreamSynchronize(p->stream[1]));
+  return ODHIP_SUCCESS;
+}
+
+/* The stages one at a time, in order on the luma stream (tests, the priced
+   verification flow of bench.py: the host prices candidates between the band
+   stage and the choice).  parity selects the reference buffer. */
+extern "C" int odhip_pipe_stage(odhip_pipe *p, int stage, int parity) {
+  if (!p || stage < 0 || stage >= kStages || (parity != 0 && parity != 1)) return ODHIP_EINVAL;
+  ODHIP_TRY(hipSetDevice(p->cfg.device));
+  hipStream_t s = p->stream[0];
+  const bool cfl = p->cfg.chroma_cfl != 0;
+  const double lam = p->cfg.pvq_norm_lambda;
+  const bool chroma_stage = stage == ODHIP_PIPE_PAD_CHROMA || stage == ODHIP_PIPE_PYRAMID_CHROMA
+   || stage == ODHIP_PIPE_BANDS_CHROMA || stage == ODHIP_PIPE_CHOOSE_CHROMA
+   || stage == ODHIP_PIPE_INVERSE_CHROMA;
+  Current cur(p->ctx[chroma_stage && cfl ? 1 : 0]);
+  switch (stage) {
+    case ODHIP_PIPE_PAD_LUMA: return stage_pad(p, 0, s);
+    case ODHIP_PIPE_PYRAMID_LUMA: return stage_pyramid(p, 0, s);
+    case ODHIP_PIPE_PAD_CHROMA: return stage_pad(p, 1, s);
+    case ODHIP_PIPE_PYRAMID_CHROMA: return stage_pyramid(p, 1, s);
+    case ODHIP_PIPE_BANDS_LUMA: {
+      Timed tm(p, stage, s);
+      return odhip_pvq_noref_bands_multi(p->jobs, p->njobs, lam, s);
+    }
+    case ODHIP_PIPE_CHOOSE_LUMA: return luma_choose(p, s);
+    case ODHIP_PIPE_CFL_REFS: return cfl ? luma_refs(p, parity, s) : ODHIP_EINVAL;
+    case ODHIP_PIPE_INVERSE_LUMA: return stage_inverse_noref(p, 0, s);
+    case ODHIP_PIPE_BANDS_CHROMA: {
+      if (!cfl) return ODHIP_SUCCESS;      /* part of ODHIP_PIPE_BANDS_LUMA */
+      STEP_TRY(chroma_bands(p, parity, s));
+      const int n = odhip_pvq_ref_resolve_finish(p->refjobs[parity], 4, lam, s);
+      if (n < 0) return n;
+      p->reruns += n;
+      return ODHIP_SUCCESS;
+    }
+    case ODHIP_PIPE_CHOOSE_CHROMA: {
+      if (!cfl) return ODHIP_SUCCESS;
+      Timed tm(p, stage, s);
+      return odhip_pvq_ref_choose_multi(p->refjobs[parity], 4, lam, s);
+    }
+    case ODHIP_PIPE_INVERSE_CHROMA: {
+      if (!cfl) return stage_inverse_noref(p, 1, s);
+      PlaneSet &ch = p->set[1];
+      Timed tm(p, stage, s);
+      return odhip_inverse_levels_pvq_ref(ch.recon, ch.w, (long)ch.w*ch.h, p->refjobs[parity], 4, 1,
+       p->pic_w, p->pic_h, s);
+    }
+    default: return ODHIP_EINVAL;
+  }
+}
+
+extern "C" int odhip_pipe_buffer(odhip_pipe *p, int what, int set, int level, int parity, void **d_ptr,
+ size_t *bytes) {
+  if (!p || !d_ptr || !bytes || (set != 0 && set != 1) || (parity != 0 && parity != 1)) {
+    return ODHIP_EINVAL;
+  }
+  PlaneSet &t = p->set[set];
+  if (what != ODHIP_PIPE_BUF_PIC && what != ODHIP_PIPE_BUF_PX && (level < 0 || level >= t.nlev)) {
+    return ODHIP_EINVAL;
+  }
+  int nb = 0;
+  int len = 0;
+  if (level >= 0 && level < ODHIP_NBSIZES) odhip_pvq_band_layout(level, &nb, nullptr, &len);
+  const long B = level >= 0 && level < ODHIP_NBSIZES ? t.nblocks[level] : 0;
+  const bool ref = set == 1 && p->cfg.chroma_cfl;
+  const odhip_pvq_job *j = set == 0 ? &p->jobs[level] : (!ref ? &p->jobs[5 + level] : nullptr);
+  const odhip_pvq_refjob *r = ref ? &p->refjobs[parity][level] : nullptr;
+  void *ptr = nullptr;
+  size_t n = 0;
+  switch (what) {
+    case ODHIP_PIPE_BUF_PIC: ptr = t.pic; n = (size_t)t.nplanes*t.pw*t.ph; break;
+    case ODHIP_PIPE_BUF_PX: ptr = t.px; n = (size_t)t.nplanes*t.w*t.h; break;
+    case ODHIP_PIPE_BUF_LEVEL: ptr = t.levels[level]; n = sizeof(od_coeff)*(size_t)t.nplanes*t.w*t.h; break;
+    case ODHIP_PIPE_BUF_RECON: ptr = t.recon[level]; n = (size_t)t.nplanes*t.w*t.h; break;
+    case ODHIP_PIPE_BUF_BAND:
+      ptr = j ? (void *)j->cands.band : (void *)r->band;
+      n = (size_t)64*B*nb;
+      break;
+    case ODHIP_PIPE_BUF_Y:
+      ptr = j ? j->cands.y : r->y;
+      n = sizeof(int16_t)*(size_t)(j ? 2 : ODHIP_PVQ_REF_SLOTS)*B*len;
+      break;
+    case ODHIP_PIPE_BUF_CHOICE:
+      ptr = j ? j->cands.choice : r->choice;
+      n = sizeof(int32_t)*(size_t)B*nb*(j ? 4 : 16);
+      break;
+    case ODHIP_PIPE_BUF_ITEMS:
+      if (!r) return ODHIP_EINVAL;
+      ptr = r->items;
+      n = (size_t)3*nb*ODHIP_PVQ_REF_SLOTS*B*16;
+      break;
+    case ODHIP_PIPE_BUF_REF:
+      if (!r) return ODHIP_EINVAL;
+      ptr = p->refs[parity][level];
+      n = sizeof(od_coeff)*(size_t)t.nplanes*t.w*t.h;
+      break;
+    case ODHIP_PIPE_BUF_RATE: {
+      /* allocated (zero: every candidate free = choice on distortion alone) and
+         attached on first request: [B][nb][2] without reference,
+         [B][nb][ODHIP_PVQ_REF_SLOTS + 1] with */
+      n = sizeof(double)*(size_t)B*nb*(j ? 2 : ODHIP_PVQ_REF_SLOTS + 1);
+      if (!p->rate[set][level]) {
+        ODHIP_TRY(hipSetDevice(p->cfg.device));
+        PIPE_ALLOC(p, p->rate[set][level], n, true);
+        if (j) p->jobs[set ? 5 + level : level].d_rate = p->rate[set][level];
+        else {
+          p->refjobs[0][level].d_rate = p->rate[set][level];
+          p->refjobs[1][level].d_rate = p->rate[set][level];
+        }
+      }
+      ptr = p->rate[set][level];
+      break;
+    }
+    default: return ODHIP_EINVAL;
+  }
+  *d_ptr = ptr;
+  *bytes = n;
+  return ODHIP_SUCCESS;
+}
+
+extern "C" int odhip_pipe_read(odhip_pipe *p, void *host, const void *d_ptr, size_t bytes) {
+  if (!p || !host || !d_ptr) return ODHIP_EINVAL;
+  const int rc = odhip_pipe_sync(p);
+  if (rc) return rc;
+  ODHIP_TRY(hipMemcpy(host, d_ptr, bytes, hipMemcpyDeviceToHost));
+  return ODHIP_SUCCESS;
+}
+
+extern "C" int odhip_pipe_write(odhip_pipe *p, void *d_ptr, const void *host, size_t bytes) {
+  if (!p || !host || !d_ptr) return ODHIP_EINVAL;
+  const int rc = odhip_pipe_sync(p);
+  if (rc) return rc;
+  ODHIP_TRY(hipMemcpy(d_ptr, host, bytes, hipMemcpyHostToDevice));
+  return ODHIP_SUCCESS;
+}
+
+extern "C" int odhip_pipe_record(odhip_pipe *p, int enable) {
+  if (!p) return ODHIP_EINVAL;
+  p->record = enable != 0;
+  for (int i = 0; i < kStages; i++) {
+    for (hipEvent_t e : p->timed[i]) (void)hipEventDestroy(e);
+    p->timed[i].clear();
+  }
+  /* the dominant kernels of the two band stages, on the streams they run on */
+  {
+    Current cur(p->ctx[0]);
+    const int rc = odhip_pvq_profile(enable);
+    if (rc) return rc;
+  }
+  if (p->cfg.chroma_cfl) {
+    Current cur(p->ctx[1]);
+    const int rc = odhip_pvq_ref_profile(enable);
+    if (rc) return rc;
+  }
+  return ODHIP_SUCCESS;
+}
+
+extern "C" int odhip_pipe_timings(odhip_pipe *p, double avg_ms[ODHIP_PIPE_NSTAGES],
+ int count[ODHIP_PIPE_NSTAGES]) {
+  if (!p || !avg_ms || !count) return ODHIP_EINVAL;
+  const int rc = odhip_pipe_sync(p);
+  if (rc) return rc;
+  for (int i = 0; i < kStages; i++) {
+    double sum = 0;
+    int n = 0;
+    for (size_t k = 0; k + 1 < p->timed[i].size(); k += 2) {
+      float ms = 0;
+      ODHIP_TRY(hipEventElapsedTime(&ms, p->timed[i][k], p->timed[i][k + 1]));
+      sum += ms;
+      n++;
+    }
+    avg_ms[i] = n ? sum/n : 0;
+    count[i] = n;
+  }
+  return ODHIP_SUCCESS;
+}
+
+extern "C" int odhip_pipe_search_timings(odhip_pipe *p, int chroma, float *ms, int max_n) {
+  if (!p || !ms) return ODHIP_EINVAL;
+  if (chroma && !p->cfg.chroma_cfl) return 0;
+  Current cur(p->ctx[chroma ? 1 : 0]);
+  return chroma ? odhip_pvq_ref_profile_read(ms, max_n) : odhip_pvq_profile_read(ms, max_n);
+}
+
+/* The luma forward pyramid launched n times on an otherwise idle GPU: average
+   milliseconds per launch (the filter + DCT stage of the north star, timed alone). */
+extern "C" int odhip_pipe_time_pyramid(odhip_pipe *p, int n, double *avg_ms) {
+  if (!p || n <= 0 || !avg_ms) return ODHIP_EINVAL;
+  int rc = odhip_pipe_sync(p);
+  if (rc) return rc;
+  hipStream_t s = p->stream[0];
+  PlaneSet &t = p->set[0];
+  hipEvent_t a = nullptr;
+  hipEvent_t b = nullptr;
+  ODHIP_TRY(hipEventCreate(&a));
+  ODHIP_TRY(hipEventCreate(&b));
+  rc = odhip_forward_pyramid(t.levels, t.px, t.w, (long)t.w*t.h, t.nplanes, t.w, t.h, 0, p->pic_w,
+   p->pic_h, s);
+  (void)hipEventRecord(a, s);
+  for (int i = 0; i < n && !rc; i++) {
+    rc = odhip_forward_pyramid(t.levels, t.px, t.w, (long)t.w*t.h, t.nplanes, t.w, t.h, 0, p->pic_w,
+     p->pic_h, s);
+  }
+  (void)hipEventRecord(b, s);
+  float ms = 0;
+  if (!rc && (hipEventSynchronize(b) != hipSuccess || hipEventElapsedTime(&ms, a, b) != hipSuccess)) {
+    rc = ODHIP_EFAULT;
+  }
+  (void)hipEventDestroy(a);
+  (void)hipEventDestroy(b);
+  *avg_ms = ms/n;
+  return rc;
+}
+
+extern "C" long odhip_pipe_theta_reruns(const odhip_pipe *p) {
+  return p ? p->reruns : 0;
+}

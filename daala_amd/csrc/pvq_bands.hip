@@ -1009,6 +1009,7 @@ struct BandState {
   hipStream_t side[2] = {nullptr, nullptr};   /* kernels that may overlap          */
   hipEvent_t fork = nullptr;
   hipEvent_t join[2] = {nullptr, nullptr};
+  bool serial = false;             /* the context's setting, refreshed per call    */
   bool prof_on = false;            /* odhip_pvq_profile                            */
   bool prof_made = false;
   int prof_n = 0;
@@ -1041,6 +1042,7 @@ int band_state(BandState **out) {
     ODHIP_TRY(hipMalloc((void **)&st->d_sort, sizeof(unsigned)*3*kMaxItems*kKeyBins));
     ODHIP_TRY(hipMemset(st->d_sort, 0, sizeof(unsigned)*3*kMaxItems*kKeyBins));
   }
+  st->serial = ctx->serial != 0;
   *out = st;
   return ODHIP_SUCCESS;
 }
@@ -1141,7 +1143,7 @@ int scratch_reserve(BandState &st, size_t x16_elems, size_t band_elems, hipStrea
 
 /* Side streams for kernels that may overlap (created once per context). */
 int fork_streams(BandState &st, hipStream_t s, hipStream_t side[2]) {
-  if (getenv("ODHIP_PVQ_SERIAL")) return ODHIP_SUCCESS;
+  if (st.serial || getenv("ODHIP_PVQ_SERIAL")) return ODHIP_SUCCESS;
   if (!st.fork) {
     ODHIP_TRY(hipEventCreateWithFlags(&st.fork, hipEventDisableTiming));
     for (int i = 0; i < 2; i++) {

@@ -36,8 +36,11 @@ __global__ __launch_bounds__(kWave) void k_pvq_search(const int16_t *x_in, int n
   const long b = live ? band : nbands - 1;
   const int16_t *xc = x_in + b*n;
   od_coeff *yp = y_io + b*n;
-  const int k = k_in[b];
-  const int prev_k = prev_k_in ? prev_k_in[b] : 0;
+  /* pulse magnitudes live in 16 bits: a K outside 0..65535 is reported (y = 0,
+     cos = NaN), never searched */
+  const bool k_ok = k_in[b] >= 0 && k_in[b] <= 65535;
+  const int k = k_ok ? k_in[b] : 0;
+  const int prev_k = prev_k_in && k_ok ? prev_k_in[b] : 0;
   for (int j = 0; j < n; j++) xs[j*kWave + lane] = xc[j];
   if (prev_k > 0 && prev_k <= k) {
     for (int j = 0; j < n; j++) {
@@ -53,7 +56,7 @@ __global__ __launch_bounds__(kWave) void k_pvq_search(const int16_t *x_in, int n
       const int yj = ys[j*kWave + lane];
       yp[j] = xc[j] < 0 ? -yj : yj;
     }
-    cos_out[band] = c;
+    cos_out[band] = k_ok ? c : __longlong_as_double(0x7ff8000000000000LL);
   }
 }
 

@@ -1513,6 +1513,7 @@ struct RefState {
   hipEvent_t join[2] = {nullptr, nullptr};
   unsigned *unc_host = nullptr;      /* pinned mirror of the counter                */
   hipEvent_t unc_event = nullptr;
+  bool serial = false;               /* the context's setting, refreshed per call   */
   bool prof_on = false;              /* odhip_pvq_ref_profile                       */
   bool prof_made = false;
   int prof_n = 0;
@@ -1551,6 +1552,7 @@ int ref_state(RefState **out) {
     ODHIP_TRY(hipMemset(st->d_unc_count, 0, sizeof(unsigned)));
     ODHIP_TRY(hipMemset(st->d_sort, 0, sizeof(unsigned)*2*kMaxItems*kSortBins));
   }
+  st->serial = ctx->serial != 0;
   *out = st;
   return ODHIP_SUCCESS;
 }
@@ -1630,7 +1632,7 @@ void items_all(RItems &it, const RefState &st, const RJob *host, int njobs, doub
 /* Side streams for the searches of the four band sizes (independent launches;
    the no-reference stage measured the same fork at 1.40 -> 1.19 ms). */
 int rfork(RefState &st, hipStream_t s, hipStream_t side[2]) {
-  if (getenv("ODHIP_PVQ_SERIAL")) return ODHIP_SUCCESS;
+  if (st.serial || getenv("ODHIP_PVQ_SERIAL")) return ODHIP_SUCCESS;
   if (!st.fork) {
     ODHIP_TRY(hipEventCreateWithFlags(&st.fork, hipEventDisableTiming));
     for (int i = 0; i < 2; i++) {

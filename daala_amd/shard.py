@@ -27,7 +27,8 @@ def frames_of_rank(nframes: int, rank: int, world: int) -> List[int]:
 def gather_packets(local: Dict[int, bytes], nframes: int, device=None) -> Optional[List[bytes]]:
     """Collect {frame index: packet bytes} from every rank.  Returns the list of
     packets in frame order on rank 0 (None elsewhere).  Every frame index must be
-    owned by exactly one rank."""
+    owned by exactly one rank: a frame nobody owns (a dropped frame) or two owners
+    raise on every rank; an owned frame may be an empty packet."""
     world = dist.get_world_size()
     rank = dist.get_rank()
     if device is None:
@@ -38,13 +39,17 @@ def gather_packets(local: Dict[int, bytes], nframes: int, device=None) -> Option
     for i, b in local.items():
         if not 0 <= i < nframes:
             raise ValueError("frame index %d out of range" % i)
-        sizes[i] = len(b)
+        sizes[i] = len(b) + 1     # 0 = not owned; an owned empty packet is 1
     all_sizes = [torch.empty_like(sizes) for _ in range(world)]
     dist.all_gather(all_sizes, sizes)
     table = torch.stack(all_sizes)  # [world, nframes]
     owners = (table > 0).sum(0)
-    if int(owners.max()) > 1:
+    if nframes and int(owners.max()) > 1:
         raise ValueError("a frame is owned by more than one rank")
+    if nframes and int(owners.min()) < 1:
+        missing = [int(i) for i in (owners == 0).nonzero().flatten()[:8]]
+        raise ValueError("frames owned by no rank (dropped): %s" % missing)
+    table = (table - 1).clamp(min=0)
     # 2. bytes: each rank concatenates its packets in frame order, padded to the max
     per_rank = table.sum(1)
     cap = int(per_rank.max())

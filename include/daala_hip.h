@@ -23,6 +23,7 @@
    the reference C path; the CPU checker lives in oracle/ (tests only). */
 #ifndef DAALA_HIP_H
 #define DAALA_HIP_H
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -156,6 +157,11 @@ void odhip_destroy(odhip_ctx *ctx);
 int odhip_make_current(odhip_ctx *ctx);    /* also makes ctx's device current */
 odhip_ctx *odhip_get_current(void);        /* NULL = the thread's default context */
 int odhip_ctx_device(const odhip_ctx *ctx);
+/* serial != 0: the band stages of this context launch everything on the caller's
+   stream instead of forking independent kernels onto the context's side streams
+   (exclusive kernel durations for profiling; ODHIP_PVQ_SERIAL=1 does the same for
+   every context). */
+int odhip_ctx_set_serial(odhip_ctx *ctx, int serial);
 
 /* ---- quantiser set-up (host) ----------------------------
 
@@ -203,7 +209,8 @@ int odhip_quant_setup(odhip_quant *qt, int base_quantizer, int quantizer, int us
  int hvs_qm);
 int odhip_quant_bands(const odhip_quant *qt, int pli, int bs, int32_t *q_band, int32_t *beta_band);
 
-/* nblocks contiguous N x N tiles, N = 4 << ln; d_out may equal d_in.
+/* nblocks contiguous N x N tiles, N = 4 << ln; d_out may equal d_in; both 16-byte
+   aligned (ODHIP_EINVAL otherwise: the kernels move 16-byte vectors).
    exact32 != 0 forces exact 32-bit products (arbitrary input); 0 uses the
    24-bit multiplier, valid while |intermediate| < 2^23 (always true for data
    that came from pixels). */
@@ -212,7 +219,8 @@ int odhip_fdct2d_batch(int ln, od_coeff *d_out, const od_coeff *d_in,
 int odhip_idct2d_batch(int ln, od_coeff *d_out, const od_coeff *d_in,
  long nblocks, int exact32, odhip_stream stream);
 
-/* Every N x N block of a w x h plane (w, h multiples of N), strides in
+/* Every N x N block of a w x h plane (w, h multiples of N; pointers 16-byte
+   aligned, strides multiples of 4), strides in
    elements: the `d` plane layout of the reference encoder (block (bx,by)'s
    coefficient (v,u) at [(by*N+v)*stride + bx*N+u]). */
 int odhip_fdct2d_plane(int ln, od_coeff *d_out, int out_stride,
@@ -257,7 +265,9 @@ int odhip_inverse_levels(uint8_t *const *d_px, int px_stride, long px_plane_stri
 
 /* Batched pvq_search_rdo_double: band b has d_x[b*n .. b*n+n) int16,
    d_k[b], d_g2[b], optional d_prev_k[b] (NULL = 0; when > 0 d_y holds the
-   previous pulses), writes d_y[b*n ..) and d_cos[b].  n <= 128. */
+   previous pulses), writes d_y[b*n ..) and d_cos[b].  n <= 128; 0 <= k <= 65535
+   (pulse magnitudes are kept in 16 bits): a band with K outside that range is not
+   searched, its d_y is zero and its d_cos NaN. */
 int odhip_pvq_search_batch(const int16_t *d_x, int n, const int32_t *d_k,
  od_coeff *d_y, const double *d_g2, double pvq_norm_lambda,
  const int32_t *d_prev_k, double *d_cos, long nbands, odhip_stream stream);
@@ -400,7 +410,10 @@ int odhip_pvq_noref_bands(const od_coeff *d_coef, int nplanes, int w, int h,
    od_gain_expand (src/pvq.c:766), od_pvq_synthesis_partial noref
    (src/pvq.c:1037-1093), od_coding_order_to_raster (src/partition.c:176).
    d_rate: [B][nb][2] bits per candidate from the host entropy model, or NULL
-   (distortion-only choice).  d_qg_out: optional [B][nb] chosen gain index. */
+   (distortion-only choice).  There is no slot for the null (gain 0) candidate:
+   its rate is identically zero in the reference (od_pvq_rate returns 0 for k == 0
+   and adds the theta terms only when qg > 0, src/pvq_encoder.c:250-251,:276), so
+   best_cost starts at dist0 exactly as at :417-421.  d_qg_out: optional [B][nb] chosen gain index. */
 int odhip_pvq_select_synth_noref(od_coeff *d_dq, const od_coeff *d_coef,
  int nplanes, int w, int h, int bs, const int16_t *d_qm_inv,
  const int32_t *q_band, const int32_t *beta_band, double pvq_norm_lambda,
@@ -704,6 +717,80 @@ int odhip_cache_lookup(odhip_frame_cache *c, const od_coeff *in, int in_stride,
 void odhip_cache_stats(const odhip_frame_cache *c, long *hits, long *misses);
 void odhip_install_cached_dct_vtbl(odhip_dct_func_2d fdct_2d[ODHIP_NBSIZES],
  odhip_dct_func_2d idct_2d[ODHIP_NBSIZES]);
+
+/* ---- odhip_pipe: the frame-batch step as one C call ------------------------------
+
+   One step = one pass of the hot path over `frames` resident 4:2:0 pictures of
+   pic_w x pic_h (coded size = both rounded up to 64, src/state.c:376-379): input
+   padding, forward pyramid (every level), PVQ band stage of every block of every
+   level (luma: no reference; chroma: WITH the chroma-from-luma reference produced
+   inside the step from the luma choices when chroma_cfl != 0, as the reference codes
+   keyframe chroma, src/encode.c:1680-1687; without reference otherwise), choice,
+   dequantisation + inverse of every level.  The luma and the chroma chain run on the
+   pipe's two streams, each in its own odhip_ctx, software-pipelined over steps (the
+   luma chain of step i+1 overlaps the chroma chain of step i); `serial` (or
+   ODHIP_PVQ_SERIAL=1) puts everything on one stream.  The pipe owns all device
+   memory and both streams.  The quantiser tables are copied at creation.
+
+   odhip_pipe_step enqueues one step and returns (asynchronous); odhip_pipe_flush
+   settles the last step's device-acos margin check (see odhip_pvq_ref_resolve_*);
+   odhip_pipe_sync waits for both streams.  odhip_pipe_stage runs ONE stage in order
+   on the first stream (tests; the flow in which a host prices the candidates between
+   the band stage and the choice); odhip_pipe_buffer hands out the device buffers
+   (ODHIP_PIPE_BUF_RATE allocates the rate table of a (plane set, level) on first
+   use, zero-filled, and from then on the choice of that level is
+   cost = dist + lambda*rate: [B][nb][2] doubles without reference,
+   [B][nb][ODHIP_PVQ_REF_SLOTS + 1] with - the d_rate layouts above);
+   odhip_pipe_read / _write copy after odhip_pipe_sync.  odhip_pipe_record brackets
+   every stage (and the dominant kernel of each band stage) with HIP events on the
+   stream it is launched on; odhip_pipe_timings returns the average milliseconds and
+   the count per stage, odhip_pipe_search_timings the bracketed search kernels
+   (chroma = 0: k_search<128,2,1>; 1: k_refb_search_row<8,16>). */
+typedef struct odhip_pipe odhip_pipe;
+typedef struct {
+  int device;
+  int frames;
+  int pic_w;
+  int pic_h;
+  int chroma_cfl;
+  int serial;
+  double pvq_norm_lambda;       /* OD_PVQ_LAMBDA, src/pvq.h:49 */
+  const odhip_quant *quant;
+} odhip_pipe_config;
+enum {
+  ODHIP_PIPE_PAD_LUMA = 0, ODHIP_PIPE_PYRAMID_LUMA, ODHIP_PIPE_BANDS_LUMA, ODHIP_PIPE_CHOOSE_LUMA,
+  ODHIP_PIPE_CFL_REFS, ODHIP_PIPE_INVERSE_LUMA, ODHIP_PIPE_PAD_CHROMA, ODHIP_PIPE_PYRAMID_CHROMA,
+  ODHIP_PIPE_BANDS_CHROMA, ODHIP_PIPE_CHOOSE_CHROMA, ODHIP_PIPE_INVERSE_CHROMA, ODHIP_PIPE_NSTAGES
+};
+enum {
+  ODHIP_PIPE_BUF_PIC = 0,   /* pictures: luma [F][pic_h][pic_w], chroma [2F][pic_h/2][pic_w/2]
+                               (all Cb, then all Cr)                                   */
+  ODHIP_PIPE_BUF_PX,        /* padded planes                                           */
+  ODHIP_PIPE_BUF_LEVEL,     /* coefficient planes of a pyramid level                   */
+  ODHIP_PIPE_BUF_RECON,     /* reconstructed pixels of a partition level               */
+  ODHIP_PIPE_BUF_BAND,      /* odhip_pvq_band / odhip_pvq_refband records              */
+  ODHIP_PIPE_BUF_Y,         /* pulse vectors                                           */
+  ODHIP_PIPE_BUF_CHOICE,    /* choice records                                          */
+  ODHIP_PIPE_BUF_ITEMS,     /* with-reference candidates (3 planes of 16-byte vectors) */
+  ODHIP_PIPE_BUF_REF,       /* chroma-from-luma reference planes [parity][level]       */
+  ODHIP_PIPE_BUF_RATE       /* rate table (allocated on first request)                 */
+};
+odhip_pipe *odhip_pipe_create(const odhip_pipe_config *cfg);
+void odhip_pipe_destroy(odhip_pipe *p);
+int odhip_pipe_set_pictures(odhip_pipe *p, const uint8_t *luma, const uint8_t *chroma, int on_device);
+int odhip_pipe_step(odhip_pipe *p);
+int odhip_pipe_flush(odhip_pipe *p);
+int odhip_pipe_sync(odhip_pipe *p);
+int odhip_pipe_stage(odhip_pipe *p, int stage, int parity);
+int odhip_pipe_buffer(odhip_pipe *p, int what, int set, int level, int parity, void **d_ptr,
+ size_t *bytes);
+int odhip_pipe_read(odhip_pipe *p, void *host, const void *d_ptr, size_t bytes);
+int odhip_pipe_write(odhip_pipe *p, void *d_ptr, const void *host, size_t bytes);
+int odhip_pipe_record(odhip_pipe *p, int enable);
+int odhip_pipe_timings(odhip_pipe *p, double avg_ms[ODHIP_PIPE_NSTAGES], int count[ODHIP_PIPE_NSTAGES]);
+int odhip_pipe_search_timings(odhip_pipe *p, int chroma, float *ms, int max_n);
+int odhip_pipe_time_pyramid(odhip_pipe *p, int n, double *avg_ms);
+long odhip_pipe_theta_reruns(const odhip_pipe *p);
 
 #ifdef __cplusplus
 }

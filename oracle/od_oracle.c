@@ -1144,6 +1144,15 @@ double odo_pvq_rate_speed1(int qg, int icgr, int theta, int ts, const odo_coeff 
   return odo_pvq_rate_fast(qg, icgr, theta, ts, y0, k, n, is_keyframe, pli);
 }
 
+#define PRICE_NAME(x) odo_##x
+#define PRICE_COEFF odo_coeff
+#define PRICE_RATE(qg, icgr, theta, ts, y, k, n, kf, pli) \
+  odo_pvq_rate_fast(qg, icgr, theta, ts, y, k, n, kf, pli)
+#include "price_batch.inc"
+#undef PRICE_NAME
+#undef PRICE_COEFF
+#undef PRICE_RATE
+
 static int odo_neg_interleave(int x, int ref) { /* src/pvq_encoder.c:235-239 */
   if (x < ref) return -2*(x - ref) - 1;
   if (x < 2*ref) return 2*(x - ref);

@@ -380,6 +380,7 @@ REF_EXPORT double ref_now(void) {
    q_band/beta_band: [5][12] per-band quantiser and beta; qm/qm_inv: coding-order
    tables for this plane's decimation, one slice per bs at qm_off[bs].
    Returns the number of transform blocks processed. */
+static unsigned char *const *g_recon_levels;   /* ref_stage_plane_levels: one recon per level */
 static long stage_plane_core(unsigned char *px, int px_stride, int w, int h,
  int dec, int pic_w, int pic_h, int pli, const int16_t *qm, const int16_t *qm_inv,
  const int *qm_off, const int *q_band, const int *beta_band,
@@ -459,7 +460,8 @@ static long stage_plane_core(unsigned char *px, int px_stride, int w, int h,
       }
     }
     if (dq_out != NULL && dq_out[bs] != NULL) memcpy(dq_out[bs], dq, sizeof(*dq)*w*h);
-    ref_inverse_level_plane(recon_px, w, c, dq, w, h, dec, bs, pic_w, pic_h);
+    ref_inverse_level_plane(g_recon_levels != NULL && g_recon_levels[bs] != NULL
+     ? g_recon_levels[bs] : recon_px, w, c, dq, w, h, dec, bs, pic_w, pic_h);
   }
   for (bs = 0; bs <= top; bs++) free(levels[bs]);
   free(adapt);
@@ -467,6 +469,21 @@ static long stage_plane_core(unsigned char *px, int px_stride, int w, int h,
   free(c);
   return nblocks;
 }
+
+/* Batch pricing with the reference's own od_pvq_rate (speed = 1: closed form; the
+   adaptation context is not read on that path). */
+#define PRICE_NAME(x) ref_##x
+#define PRICE_COEFF od_coeff
+#define PRICE_RATE(qg, icgr, theta, ts, y, k, n, kf, pli) \
+  od_pvq_rate(qg, icgr, theta, ts, NULL, y, k, n, kf, pli, 1)
+REF_EXPORT void ref_price_noref(double *rate, const unsigned char *rec, const int16_t *y, long B,
+ int nb, const int *off, int len, int is_keyframe, int pli);
+REF_EXPORT void ref_price_ref(double *rate, const unsigned char *rec, const unsigned char *items,
+ const int16_t *y, long B, int nb, const int *off, int len, int is_keyframe, int pli);
+#include "price_batch.inc"
+#undef PRICE_NAME
+#undef PRICE_COEFF
+#undef PRICE_RATE
 
 REF_EXPORT long ref_stage_plane(unsigned char *px, int px_stride, int w, int h,
  int dec, int pic_w, int pic_h, int pli, const int16_t *qm, const int16_t *qm_inv,
@@ -491,4 +508,20 @@ REF_EXPORT long ref_stage_plane_cfl(unsigned char *px, int px_stride, int w, int
  od_coeff *const *ref_levels) {
   return stage_plane_core(px, px_stride, w, h, dec, pic_w, pic_h, pli, qm, qm_inv,
    qm_off, q_band, beta_band, pvq_norm_lambda, recon_px, dq_out, ref_levels);
+}
+
+/* ref_stage_plane_cfl keeping the reconstruction of EVERY partition level
+   (recon_levels[bs], w x h each) instead of the last one only: what the full-frame
+   parity checks of the GPU pipeline compare with.  Not thread-safe (test use). */
+REF_EXPORT long ref_stage_plane_levels(unsigned char *px, int px_stride, int w, int h,
+ int dec, int pic_w, int pic_h, int pli, const int16_t *qm, const int16_t *qm_inv,
+ const int *qm_off, const int *q_band, const int *beta_band,
+ double pvq_norm_lambda, unsigned char *const *recon_levels, od_coeff **dq_out,
+ od_coeff *const *ref_levels) {
+  long n;
+  g_recon_levels = recon_levels;
+  n = stage_plane_core(px, px_stride, w, h, dec, pic_w, pic_h, pli, qm, qm_inv,
+   qm_off, q_band, beta_band, pvq_norm_lambda, recon_levels[0], dq_out, ref_levels);
+  g_recon_levels = NULL;
+  return n;
 }

@@ -1,0 +1,169 @@
+"""Whole-frame checker of the GPU frame-batch step (odhip_pipe) - TEST INFRASTRUCTURE,
+shared by tests/test_gpu_pipeline.py, __graft_entry__.smoke() and the cpu_baseline /
+verification leg of bench.py.
+
+cpu_frame()         one 4:2:0 picture through the REFERENCE's own C functions
+                    (oracle/_ref: ref_stage_plane_levels = padding, forward pyramid,
+                    pvq_theta with closed-form pricing on every block of every level -
+                    chroma WITH the chroma-from-luma reference -, inverse), keeping the
+                    reconstruction of every level.
+gpu_priced_frame()  the same picture through an F = 1 odhip_pipe stage by stage, with
+                    the host's part in between: every candidate the band stages
+                    searched is priced with the reference's od_pvq_rate (closed form)
+                    and the rate tables go back for the choice - the split of
+                    pvq_theta DESIGN.md describes, in batch form.
+Both must agree bit for bit on every reconstructed pixel of every level."""
+import ctypes
+import time
+
+import numpy as np
+
+from _libs import P, oracle, ref
+
+NBANDS = [1, 4, 7, 9, 9]
+
+
+def _tables(qt, p):
+    qm_off = (ctypes.c_int * 5)(*[int(qt.qm_offset[bs][p]) for bs in range(5)])
+    qb = (ctypes.c_int * 60)()
+    bb = (ctypes.c_int * 60)()
+    for bs in range(5):
+        for i, v in enumerate(qt.q_band(p, bs)):
+            qb[bs * 12 + i] = v
+        for i, v in enumerate(qt.beta_band(p, bs)):
+            bb[bs * 12 + i] = v
+    return qm_off, qb, bb
+
+
+def cpu_frame(qt, pics, pic_w, pic_h, chroma_cfl=True, lam=0.147):
+    """pics: [Y, Cb, Cr] uint8 pictures.  Returns (recon, blocks, seconds): recon[pli][bs]
+    = uint8 plane of the coded size, reconstructed at uniform partition level bs."""
+    r = ref()
+    assert r is not None, "oracle/_ref/libdaalaref.so not built"
+    r.ref_stage_plane_levels.restype = ctypes.c_long
+    W, H = (pic_w + 63) & ~63, (pic_h + 63) & ~63
+    qm = np.ascontiguousarray(qt.qm)
+    qmi = np.ascontiguousarray(qt.qm_inv)
+    recon = []
+    blocks = 0
+    busy = 0.0
+    ldq = [np.zeros((H, W), np.int32) for _ in range(5)]
+    refs = None
+    for pli, dec in ((0, 0), (1, 1), (2, 1)):
+        p = 1 if pli else 0
+        h, w = H >> dec, W >> dec
+        qm_off, qb, bb = _tables(qt, p)
+        pic = np.ascontiguousarray(pics[pli])
+        px = np.zeros((h, w), np.uint8)
+        nlev = 5 - dec
+        rec = [np.zeros((h, w), np.uint8) for _ in range(nlev)]
+        rec_arr = (ctypes.c_void_p * 5)(*([a.ctypes.data for a in rec] + [None] * (5 - nlev)))
+        t0 = time.perf_counter()
+        # od_img_plane_copy_pad is file-static in the reference's encode.c: the restatement
+        # (pinned to the encoder's own padded input, tests/test_oracle_golden.py)
+        oracle().odo_img_plane_copy_pad(P(px), w, w, h, P(pic), pic.shape[1], pic.shape[1],
+                                        pic.shape[0])
+        if pli == 0:
+            dq = (ctypes.c_void_p * 5)(*[a.ctypes.data for a in ldq])
+            blocks += r.ref_stage_plane_levels(P(px), w, w, h, 0, pic_w, pic_h, 0, P(qm), P(qmi), qm_off,
+                                               qb, bb, ctypes.c_double(lam), rec_arr, dq, None)
+        elif chroma_cfl:
+            arr = (ctypes.c_void_p * 5)(*([a.ctypes.data for a in refs] + [None]))
+            blocks += r.ref_stage_plane_levels(P(px), w, w, h, 1, pic_w, pic_h, 1, P(qm), P(qmi), qm_off,
+                                               qb, bb, ctypes.c_double(lam), rec_arr, None, arr)
+        else:
+            blocks += r.ref_stage_plane_levels(P(px), w, w, h, 1, pic_w, pic_h, 1, P(qm), P(qmi), qm_off,
+                                               qb, bb, ctypes.c_double(lam), rec_arr, None, None)
+        busy += time.perf_counter() - t0
+        if pli == 0 and chroma_cfl:
+            # od_resample_luma_coeffs for luma blocks one size up (src/intra.c:97-108: the
+            # upper-left quarter of the decoded block), timed like the GPU's kernel
+            t0 = time.perf_counter()
+            refs = []
+            for bs in range(4):
+                n = 4 << bs
+                c = ldq[bs + 1].reshape(H // (2 * n), 2 * n, W // (2 * n), 2 * n)[:, :n, :, :n]
+                refs.append(np.ascontiguousarray(c.reshape(H // 2, W // 2)))
+            busy += time.perf_counter() - t0
+        recon.append(rec)
+    return recon, blocks, busy
+
+
+def _price_lib():
+    """The reference's od_pvq_rate when oracle/_ref is here, the restatement otherwise."""
+    r = ref()
+    if r is not None:
+        return r.ref_price_noref, r.ref_price_ref
+    o = oracle()
+    return o.odo_price_noref, o.odo_price_ref
+
+
+def price_levels(D, pipe, set_, with_ref, pli):
+    """Host pricing of every candidate of a plane set's band stage -> its rate tables."""
+    price_noref, price_ref = _price_lib()
+    for bs in range(5 - (1 if set_ else 0)):
+        nb, offs, ln = D.pvq_band_layout(bs)
+        off = (ctypes.c_int * 13)(*offs)
+        B = pipe.nblocks(set_, bs)
+        rec = pipe.read(D.BUF_BAND, set_, bs)
+        y = pipe.read(D.BUF_Y, set_, bs, dtype=np.int16)
+        if with_ref:
+            items = pipe.read(D.BUF_ITEMS, set_, bs)
+            rate = np.zeros((B, nb, 17), np.float64)
+            price_ref(P(rate), P(rec), P(items), P(y), ctypes.c_long(B), nb, off, ln, 1, pli)
+        else:
+            rate = np.zeros((B, nb, 2), np.float64)
+            price_noref(P(rate), P(rec), P(y), ctypes.c_long(B), nb, off, ln, 1, pli)
+        pipe.write(D.BUF_RATE, set_, bs, rate)
+
+
+def gpu_priced_frame(D, qt, pics, pic_w, pic_h, chroma_cfl=True, lam=0.147, frames=None):
+    """pics: [Y, Cb, Cr] of one picture (or stacked [F,...] arrays with frames=F).
+    Returns recon[set][bs] = uint8 [nplanes, H/dec, W/dec]."""
+    F = frames or 1
+    luma = np.ascontiguousarray(pics[0]).reshape(F, pic_h, pic_w)
+    chroma = np.concatenate([np.ascontiguousarray(pics[1]).reshape(F, pic_h // 2, pic_w // 2),
+                             np.ascontiguousarray(pics[2]).reshape(F, pic_h // 2, pic_w // 2)])
+    pipe = D.Pipe(qt, F, pic_w, pic_h, chroma_cfl=chroma_cfl, serial=True, pvq_norm_lambda=lam)
+    try:
+        pipe.set_pictures(luma, chroma)
+        pipe.stage("image_copy_pad_luma")
+        pipe.stage("forward_pyramid_luma")
+        if not chroma_cfl:
+            pipe.stage("image_copy_pad_chroma")
+            pipe.stage("forward_pyramid_chroma")
+        pipe.stage("pvq_noref_bands")
+        price_levels(D, pipe, 0, False, 0)
+        if not chroma_cfl:
+            price_levels(D, pipe, 1, False, 1)
+        pipe.stage("pvq_choose")
+        if chroma_cfl:
+            pipe.stage("cfl_refs_from_luma")
+        pipe.stage("dequant_inverse_luma")
+        if chroma_cfl:
+            pipe.stage("image_copy_pad_chroma")
+            pipe.stage("forward_pyramid_chroma")
+            pipe.stage("pvq_ref_bands")
+            price_levels(D, pipe, 1, True, 1)
+            pipe.stage("pvq_ref_choose")
+        pipe.stage("dequant_inverse_chroma")
+        W, H = pipe.W, pipe.H
+        out = [[pipe.read(D.BUF_RECON, 0, bs).reshape(F, H, W) for bs in range(5)],
+               [pipe.read(D.BUF_RECON, 1, bs).reshape(2 * F, H // 2, W // 2) for bs in range(4)]]
+    finally:
+        pipe.destroy()
+    return out
+
+
+def compare_frame(gpu, cpu, frame=0, frames=1):
+    """Differences between gpu_priced_frame()'s planes of `frame` and cpu_frame()'s: a
+    list of (plane, level, differing pixels); empty = bit-exact."""
+    bad = []
+    for pli in range(3):
+        set_ = 1 if pli else 0
+        plane = frame if pli == 0 else (pli - 1) * frames + frame
+        for bs in range(5 - set_):
+            d = int(np.count_nonzero(gpu[set_][bs][plane] != cpu[pli][bs]))
+            if d:
+                bad.append((pli, bs, d))
+    return bad

@@ -1,0 +1,136 @@
+"""The frame-batch step (odhip_pipe) as bench.py runs it, verified:
+
+(i)  the default two-stream, software-pipelined step at 1080p - luma chain and chroma
+     chain in their own contexts on their own streams, the luma chain of step i + 1
+     overlapping the chroma chain of step i - leaves exactly the records, pulse vectors,
+     choices and reconstructed pixels of the same steps run serially on one stream
+     (round 1's shared edge-strip scratch made this fail silently);
+(ii) a WHOLE 1080p frame (every block of every level of all three planes) through the
+     GPU stages with the host pricing every candidate in between equals the compiled
+     reference's pvq_theta path pixel for pixel, for both synthetic content types."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from _libs import ref  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+PIC_W, PIC_H = 1920, 1080
+
+
+def _bench():
+    import bench
+    return bench
+
+
+def _pictures(gen, nframes, seed):
+    b = _bench()
+    fr = [b.picture_planes(gen(i, seed)) for i in range(nframes)]
+    return (np.stack([f[0] for f in fr]), np.concatenate([np.stack([f[1] for f in fr]),
+                                                          np.stack([f[2] for f in fr])]))
+
+
+def _dump(D, pipe, cfl):
+    out = {}
+    for set_ in (0, 1):
+        for bs in range(5 - set_):
+            out[("recon", set_, bs)] = pipe.read(D.BUF_RECON, set_, bs)
+            out[("choice", set_, bs)] = pipe.read(D.BUF_CHOICE, set_, bs)
+            out[("band", set_, bs)] = pipe.read(D.BUF_BAND, set_, bs)
+            out[("y", set_, bs)] = pipe.read(D.BUF_Y, set_, bs)
+            if set_ and cfl:
+                out[("items", set_, bs)] = pipe.read(D.BUF_ITEMS, set_, bs)
+    return out
+
+
+@pytest.mark.parametrize("cfl", [True, False])
+def test_pipelined_step_equals_serial_step_1080p(cfl):
+    import daala_amd as D
+    D.init(0)
+    b = _bench()
+    qt = D.QuantTables.load()
+    F = 3
+    pipes = [D.Pipe(qt, F, PIC_W, PIC_H, chroma_cfl=cfl, serial=s) for s in (False, True)]
+    try:
+        for rnd, gen in enumerate((b.synth_frame_np, b.natural_like_frame_np)):
+            luma, chroma = _pictures(gen, F, 77 + rnd)
+            dumps = []
+            for pipe in pipes:
+                pipe.set_pictures(luma, chroma)
+                for _ in range(4):
+                    pipe.step()
+                pipe.flush()
+                pipe.sync()
+                dumps.append(_dump(D, pipe, cfl))
+            for key in dumps[0]:
+                assert np.array_equal(dumps[0][key], dumps[1][key]), (rnd, key)
+            # the steps really reconstruct something picture-like at the finest level
+            rec = dumps[0][("recon", 0, 0)].reshape(F, pipes[0].H, pipes[0].W)[:, :PIC_H]
+            assert np.abs(rec.astype(np.int32) - luma).mean() < 12
+    finally:
+        for pipe in pipes:
+            pipe.destroy()
+
+
+@pytest.mark.skipif(ref() is None, reason="oracle/_ref (the compiled reference) not present")
+@pytest.mark.parametrize("content", ["checker", "natural"])
+def test_whole_frame_equals_compiled_reference_1080p(content):
+    import daala_amd as D
+    import _pipeline_check as C
+    D.init(0)
+    b = _bench()
+    qt = D.QuantTables.load()
+    pics = b.picture_planes(b.CONTENT[content](3, 4321))
+    cpu, blocks, _ = C.cpu_frame(qt, pics, PIC_W, PIC_H, chroma_cfl=True)
+    assert blocks == b.blocks_per_frame()
+    gpu = C.gpu_priced_frame(D, qt, pics, PIC_W, PIC_H, chroma_cfl=True)
+    assert C.compare_frame(gpu, cpu) == []
+
+
+@pytest.mark.skipif(ref() is None, reason="oracle/_ref (the compiled reference) not present")
+def test_whole_frame_noref_chroma_and_ragged_size():
+    """Chroma through the no-reference stage, and a picture whose size is not a
+    multiple of the superblock (padding + gated split filters), whole frame."""
+    import daala_amd as D
+    import _pipeline_check as C
+    D.init(0)
+    b = _bench()
+    qt = D.QuantTables.for_quality(40)
+    full = b.synth_frame_np(5, 99)
+    pw, ph = 312, 180
+    pics = [full[0][:ph, :pw], full[1][:ph // 2, :pw // 2], full[2][:ph // 2, :pw // 2]]
+    for cfl in (False, True):
+        cpu, _, _ = C.cpu_frame(qt, pics, pw, ph, chroma_cfl=cfl)
+        gpu = C.gpu_priced_frame(D, qt, pics, pw, ph, chroma_cfl=cfl)
+        assert C.compare_frame(gpu, cpu) == [], cfl
+
+
+def test_two_contexts_keep_their_own_scratch():
+    """Two inverse calls in flight on two streams with one context each reproduce the
+    serial results (the API-level form of (i))."""
+    import torch
+    import daala_amd as D
+    D.init(0)
+    dev = torch.device("cuda", 0)
+    rng = np.random.RandomState(5)
+    coefs = [torch.from_numpy((rng.randint(-300, 300, size=(4, 1088, 1920)) * 16).astype(np.int32)).to(dev),
+             torch.from_numpy((rng.randint(-300, 300, size=(8, 544, 960)) * 16).astype(np.int32)).to(dev)]
+    want = [D.inverse_level(coefs[0], 0, 2, 1920, 1080), D.inverse_level(coefs[1], 1, 1, 1920, 1080)]
+    torch.cuda.synchronize()
+    ctxs = [D.Context(0), D.Context(0)]
+    streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+    outs = [torch.empty_like(w) for w in want]
+    for _ in range(6):
+        for i in (0, 1):
+            with ctxs[i], torch.cuda.stream(streams[i]):
+                D.inverse_level(coefs[i], i, 2 - i, 1920, 1080, out=outs[i])
+    torch.cuda.synchronize()
+    for i in (0, 1):
+        assert torch.equal(outs[i], want[i])
+    for c in ctxs:
+        c.destroy()

@@ -57,6 +57,41 @@ def test_gather_matches_sequential(nframes):
     assert out == [_packet(i) for i in range(nframes)]
 
 
+def _drop_worker(rank, world, port, nframes, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from daala_amd.shard import frames_of_rank, gather_packets
+    # rank 1 loses frame 3: nobody owns it
+    local = {i: _packet(i) for i in frames_of_rank(nframes, rank, world) if i != 3}
+    try:
+        gather_packets(local, nframes)
+        q.put((rank, "no error"))
+    except ValueError as e:
+        q.put((rank, str(e)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_a_dropped_frame_is_an_error_on_every_rank():
+    """A frame no rank owns must not come back as an empty packet (frame 5 of the
+    other tests IS a legitimately empty packet and does come back)."""
+    world, nframes = 2, 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_drop_worker, args=(r, world, port, nframes, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert set(got) == {0, 1}
+    for msg in got.values():
+        assert "owned by no rank" in msg and "3" in msg
+
+
 def test_ownership_partitions_frames():
     from daala_amd.shard import frames_of_rank
     for world in (1, 2, 4, 8):
