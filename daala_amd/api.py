@@ -872,6 +872,10 @@ class Pipe:
                "odhip_pipe_time_pyramid")
         return ms.value
 
+    def host_wait_ms(self):
+        lib().odhip_pipe_host_wait_ms.restype = ctypes.c_double
+        return float(lib().odhip_pipe_host_wait_ms(self._p()))
+
     def theta_reruns(self):
         return int(lib().odhip_pipe_theta_reruns(self._p()))
 

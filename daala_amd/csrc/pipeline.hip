@@ -26,6 +26,7 @@
    Host code only; the kernels are the batched entry points of daala_hip.h. */
 #include <stdlib.h>
 #include <string.h>
+#include <chrono>
 #include <vector>
 #include "od_ctx.cuh"
 #include "gen/od_scan_tables.h"
@@ -72,6 +73,7 @@ struct odhip_pipe {
   long nstep;
   int pending;                    /* parity of the step whose theta list is unchecked, -1 */
   long reruns;                    /* bands re-run with the host's theta so far */
+  double wait_ms;                 /* host time spent waiting for the margin count */
   bool record;
   std::vector<hipEvent_t> timed[kStages];    /* pairs */
   std::vector<void *> owned;
@@ -311,7 +313,9 @@ int finish_pending(odhip_pipe *p) {
   const int par = p->pending;
   p->pending = -1;
   Current cur(p->ctx[1]);
+  const auto t0 = std::chrono::steady_clock::now();
   const int n = odhip_pvq_ref_resolve_finish(p->refjobs[par], 4, p->cfg.pvq_norm_lambda, p->stream[1]);
+  p->wait_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   if (n < 0) return n;
   if (n > 0) {
     p->reruns += n;
@@ -408,6 +412,7 @@ extern "C" odhip_pipe *odhip_pipe_create(const odhip_pipe_config *cfg) {
   p->njobs = 0;
   p->nstep = 0;
   p->reruns = 0;
+  p->wait_ms = 0;
   p->record = false;
   memset(p->rate, 0, sizeof(p->rate));
   memset(p->refs, 0, sizeof(p->refs));
@@ -685,6 +690,12 @@ extern "C" int odhip_pipe_time_pyramid(odhip_pipe *p, int n, double *avg_ms) {
   (void)hipEventDestroy(b);
   *avg_ms = ms/n;
   return rc;
+}
+
+/* Host milliseconds spent so far waiting for the margin counts (the only host waits
+   of a step; everything else in odhip_pipe_step is launch work). */
+extern "C" double odhip_pipe_host_wait_ms(const odhip_pipe *p) {
+  return p ? p->wait_ms : 0;
 }
 
 extern "C" long odhip_pipe_theta_reruns(const odhip_pipe *p) {

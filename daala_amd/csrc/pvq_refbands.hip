@@ -1500,8 +1500,16 @@ int fill_job(RJob &d, const odhip_pvq_refjob &j, int mode) {
    context: ONE call sequence (bands -> resolve -> choice / synthesis) may be in
    flight per context. */
 constexpr int kProfSlots = 256;
+/* Device job tables are cached by content (see pvq_bands.hip): a repeating caller
+   copies nothing, and the host is not stalled by pageable-memory copies. */
+constexpr int kTableSlots = 8;
 struct RefState {
-  RJob *d_jobs = nullptr;            /* device job table [kMaxJobs]                 */
+  RJob *d_jobs = nullptr;            /* kTableSlots device job tables of kMaxJobs   */
+  RJob host_tab[kTableSlots][kMaxJobs];
+  int tab_n[kTableSlots] = {};
+  unsigned long tab_stamp[kTableSlots] = {};
+  unsigned long tab_clock = 0;
+  const RJob *cur = nullptr;         /* the table of the call in progress           */
   unsigned *d_unc_count = nullptr;   /* bands inside the theta margin: counter ...  */
   Unc *d_unc = nullptr;              /* ... and list [kUncCap]                      */
   unsigned *d_sort = nullptr;        /* histogram + cursors of the counting sort    */
@@ -1545,7 +1553,7 @@ int ref_state(RefState **out) {
   ODHIP_CTX_OR_RETURN(ctx);
   RefState *st = odhip_ctx_state<RefState>(ctx, ODHIP_SLOT_REFBANDS);
   if (!st->d_jobs) {
-    ODHIP_TRY(hipMalloc((void **)&st->d_jobs, sizeof(RJob)*kMaxJobs));
+    ODHIP_TRY(hipMalloc((void **)&st->d_jobs, sizeof(RJob)*kMaxJobs*kTableSlots));
     ODHIP_TRY(hipMalloc((void **)&st->d_unc_count, sizeof(unsigned)));
     ODHIP_TRY(hipMalloc((void **)&st->d_unc, sizeof(Unc)*kUncCap));
     ODHIP_TRY(hipMalloc((void **)&st->d_sort, sizeof(unsigned)*2*kMaxItems*kSortBins));
@@ -1594,7 +1602,22 @@ int stage_jobs(RefState &st, const odhip_pvq_refjob *jobs, int njobs, int mode, 
       pairs += (size_t)host[i].nblocks*host[i].nb_bands;
     }
   }
-  ODHIP_TRY(hipMemcpyAsync(st.d_jobs, host, sizeof(RJob)*njobs, hipMemcpyHostToDevice, s));
+  int lru = 0;
+  for (int i = 0; i < kTableSlots; i++) {
+    if (st.tab_n[i] == njobs && memcmp(st.host_tab[i], host, sizeof(RJob)*njobs) == 0) {
+      st.tab_stamp[i] = ++st.tab_clock;
+      st.cur = st.d_jobs + (size_t)i*kMaxJobs;
+      return ODHIP_SUCCESS;
+    }
+    if (st.tab_stamp[i] < st.tab_stamp[lru]) lru = i;
+  }
+  if (st.tab_n[lru]) ODHIP_TRY(hipStreamSynchronize(s));
+  memcpy(st.host_tab[lru], host, sizeof(RJob)*njobs);
+  st.tab_n[lru] = njobs;
+  st.tab_stamp[lru] = ++st.tab_clock;
+  RJob *dst = st.d_jobs + (size_t)lru*kMaxJobs;
+  ODHIP_TRY(hipMemcpy(dst, host, sizeof(RJob)*njobs, hipMemcpyHostToDevice));
+  st.cur = dst;
   return ODHIP_SUCCESS;
 }
 
@@ -1603,7 +1626,7 @@ void items_begin(RItems &it, const RefState &st, double lambda) {
   it.lambda = lambda;
   it.margin = g_margin;
   it.perturb = g_perturb;
-  it.jobs = st.d_jobs;
+  it.jobs = st.cur;
   it.unc_count = st.d_unc_count;
   it.unc = st.d_unc;
   it.rhist = st.d_sort;
@@ -1884,8 +1907,8 @@ extern "C" int odhip_pvq_ref_resolve(const odhip_pvq_refjob *jobs, int njobs,
     if (d_list) (void)hipFree(d_list);
     return ODHIP_EFAULT;
   }
-  k_refb_cands_list<<<(nfix + kWave - 1)/kWave, kWave, 0, s>>>(st.d_jobs, d_list, (int)nfix);
-  k_refb_search_list<<<nfix, kWave, (size_t)2*128*kWave*sizeof(unsigned short), s>>>(st.d_jobs,
+  k_refb_cands_list<<<(nfix + kWave - 1)/kWave, kWave, 0, s>>>(st.cur, d_list, (int)nfix);
+  k_refb_search_list<<<nfix, kWave, (size_t)2*128*kWave*sizeof(unsigned short), s>>>(st.cur,
    d_list, (int)nfix, pvq_norm_lambda);
   rc = odhip_check_launch();
   hipError_t e = hipStreamSynchronize(s);

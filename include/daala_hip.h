@@ -791,6 +791,7 @@ int odhip_pipe_timings(odhip_pipe *p, double avg_ms[ODHIP_PIPE_NSTAGES], int cou
 int odhip_pipe_search_timings(odhip_pipe *p, int chroma, float *ms, int max_n);
 int odhip_pipe_time_pyramid(odhip_pipe *p, int n, double *avg_ms);
 long odhip_pipe_theta_reruns(const odhip_pipe *p);
+double odhip_pipe_host_wait_ms(const odhip_pipe *p);
 
 #ifdef __cplusplus
 }
