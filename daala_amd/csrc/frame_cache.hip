@@ -27,7 +27,35 @@
 #include <stdlib.h>
 #include <string.h>
 #include "../../include/daala_hip.h"
-#include "od_common.cuh"
+#include "od_ctx.cuh"
+#include "gen/od_scan_tables.h"
+
+/* ---- the batched no-reference band stage behind the encoder's pvq_theta ----------
+   odhip_cache_load_bands (after odhip_cache_load_plane of the same plane): the PVQ
+   band stage of EVERY block of EVERY level of the plane in one set of launches
+   (odhip_pvq_noref_bands_multi on the pyramid still resident in HBM), records and
+   pulse vectors copied to pinned host memory.  odhip_cache_band then serves one
+   pvq_theta call of the encoder's block loop - the gains, K, pruning decisions,
+   pulse vectors and distortions of its candidates - whenever that call takes the
+   no-reference path, i.e. its reference vector is null (keyframe luma whose
+   neighbours predict nothing, src/encode.c:874-878, src/pvq_encoder.c:452,:571).
+   The encoder prices the candidates with od_pvq_rate on its live adaptive state
+   (src/pvq_encoder.c:597-599), chooses and synthesises: that part is sequential
+   host state in the reference and stays there. */
+struct BandLevel {
+  odhip_pvq_band *d_band = nullptr;
+  int16_t *d_y = nullptr;
+  int32_t *d_choice = nullptr;
+  int16_t *d_qm = nullptr;
+  odhip_pvq_band *h_band = nullptr;
+  int16_t *h_y = nullptr;
+  long nblocks = 0;
+  int nb = 0;
+  int len = 0;
+  int32_t q[ODHIP_MAX_BANDS];
+  int32_t beta[ODHIP_MAX_BANDS];
+  int off[ODHIP_MAX_BANDS + 1];
+};
 
 struct odhip_frame_cache {
   struct Plane {
@@ -41,8 +69,13 @@ struct odhip_frame_cache {
     od_coeff *h_levels[ODHIP_NBSIZES];
     od_coeff *d_levels[ODHIP_NBSIZES];
     size_t cap;
+    BandLevel *bands;        /* [ODHIP_NBSIZES], allocated by odhip_cache_load_bands */
+    int bands_valid;
   } planes[4];
   hipStream_t stream;
+  odhip_ctx *ctx;
+  long band_hits;
+  long band_misses;
   int pic_w;
   int pic_h;
   int check;
@@ -81,6 +114,16 @@ int plane_reserve(odhip_frame_cache::Plane &p, int w, int h, int dec) {
   return ODHIP_SUCCESS;
 }
 
+void band_level_free(BandLevel &b) {
+  if (b.d_band) (void)hipFree(b.d_band);
+  if (b.d_y) (void)hipFree(b.d_y);
+  if (b.d_choice) (void)hipFree(b.d_choice);
+  if (b.d_qm) (void)hipFree(b.d_qm);
+  if (b.h_band) (void)hipHostFree(b.h_band);
+  if (b.h_y) (void)hipHostFree(b.h_y);
+  b = BandLevel();
+}
+
 typedef void (*dct_fn)(od_coeff *, int, const od_coeff *, int);
 const dct_fn kPerCallFdct[ODHIP_NBSIZES] = {
   od_bin_fdct4x4_hip, od_bin_fdct8x8_hip, od_bin_fdct16x16_hip, od_bin_fdct32x32_hip,
@@ -107,6 +150,9 @@ odhip_frame_cache *odhip_cache_create(void) {
   }
   const char *e = getenv("ODHIP_CACHE_CHECK");
   c->check = e && e[0] == '1';
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  c->ctx = odhip_create(dev);
   return c;
 }
 
@@ -121,7 +167,12 @@ void odhip_cache_destroy(odhip_frame_cache *c) {
       if (p.h_levels[l]) (void)hipHostFree(p.h_levels[l]);
       if (p.d_levels[l]) (void)hipFree(p.d_levels[l]);
     }
+    if (p.bands) {
+      for (int l = 0; l < ODHIP_NBSIZES; l++) band_level_free(p.bands[l]);
+      delete[] p.bands;
+    }
   }
+  if (c->ctx) odhip_destroy(c->ctx);
   (void)hipStreamDestroy(c->stream);
   free(c);
 }
@@ -151,6 +202,7 @@ int odhip_cache_load_plane(odhip_frame_cache *c, int pli, const od_coeff *coef, 
   }
   odhip_frame_cache::Plane &p = c->planes[pli];
   p.valid = 0;
+  p.bands_valid = 0;
   int rc = plane_reserve(p, w, h, dec);
   if (rc) return rc;
   /* od_ref_buf_to_coeff wrote (p - 128) << 4 (src/state.c:1233): recover p. */
@@ -208,6 +260,124 @@ int odhip_cache_lookup(odhip_frame_cache *c, const od_coeff *in, int in_stride, 
   }
   c->misses++;
   return 0;
+}
+
+int odhip_cache_load_bands(odhip_frame_cache *c, int pli, const odhip_quant *qt,
+ double pvq_norm_lambda) {
+  if (!c || pli < 0 || pli >= 4 || !qt || !c->ctx) return ODHIP_EINVAL;
+  odhip_frame_cache::Plane &p = c->planes[pli];
+  if (!p.valid) return ODHIP_EINVAL;
+  p.bands_valid = 0;
+  if (!p.bands) p.bands = new BandLevel[ODHIP_NBSIZES];
+  const int nlev = ODHIP_NBSIZES - p.dec;
+  const int qpli = pli > 2 ? 2 : pli;
+  odhip_pvq_job jobs[ODHIP_NBSIZES];
+  memset(jobs, 0, sizeof(jobs));
+  for (int bs = 0; bs < nlev; bs++) {
+    BandLevel &b = p.bands[bs];
+    const int n = 4 << bs;
+    const long B = (long)(p.w/n)*(p.h/n);
+    int nb = 0;
+    int len = 0;
+    odhip_pvq_band_layout(bs, &nb, b.off, &len);
+    if (b.nblocks != B || b.nb != nb || b.len != len) {
+      band_level_free(b);
+      odhip_pvq_band_layout(bs, &nb, b.off, &len);
+      ODHIP_TRY(hipMalloc((void **)&b.d_band, sizeof(odhip_pvq_band)*(size_t)B*nb));
+      ODHIP_TRY(hipMalloc((void **)&b.d_y, sizeof(int16_t)*(size_t)2*B*len));
+      ODHIP_TRY(hipMalloc((void **)&b.d_choice, sizeof(int32_t)*(size_t)B*nb*4));
+      ODHIP_TRY(hipMalloc((void **)&b.d_qm, sizeof(int16_t)*len));
+      ODHIP_TRY(hipHostMalloc((void **)&b.h_band, sizeof(odhip_pvq_band)*(size_t)B*nb,
+       hipHostMallocDefault));
+      ODHIP_TRY(hipHostMalloc((void **)&b.h_y, sizeof(int16_t)*(size_t)2*B*len, hipHostMallocDefault));
+      ODHIP_TRY(hipMemsetAsync(b.d_y, 0, sizeof(int16_t)*(size_t)2*B*len, c->stream));
+      b.nblocks = B;
+      b.nb = nb;
+      b.len = len;
+    }
+    if (odhip_quant_bands(qt, qpli, bs, b.q, b.beta) != nb) return ODHIP_EINVAL;
+    /* the tables may change from frame to frame (quantiser, matrices): copy per load;
+       the source is the caller's memory, so the copy completes before returning */
+    ODHIP_TRY(hipMemcpy(b.d_qm, qt->qm + odhip_qm_offset(bs, p.dec), sizeof(int16_t)*len,
+     hipMemcpyHostToDevice));
+    odhip_pvq_job &j = jobs[bs];
+    j.d_coef = p.d_levels[bs];
+    j.nplanes = 1;
+    j.w = p.w;
+    j.h = p.h;
+    j.bs = bs;
+    j.d_qm = b.d_qm;
+    j.q_band = b.q;
+    j.beta_band = b.beta;
+    j.cands.band = b.d_band;
+    j.cands.y = b.d_y;
+    j.cands.choice = b.d_choice;
+  }
+  odhip_ctx *prev = odhip_get_current();
+  (void)odhip_make_current(c->ctx);
+  int rc = odhip_pvq_noref_bands_multi(jobs, nlev, pvq_norm_lambda, c->stream);
+  (void)odhip_make_current(prev);
+  if (rc) return rc;
+  for (int bs = 0; bs < nlev; bs++) {
+    BandLevel &b = p.bands[bs];
+    ODHIP_TRY(hipMemcpyAsync(b.h_band, b.d_band, sizeof(odhip_pvq_band)*(size_t)b.nblocks*b.nb,
+     hipMemcpyDeviceToHost, c->stream));
+    ODHIP_TRY(hipMemcpyAsync(b.h_y, b.d_y, sizeof(int16_t)*(size_t)2*b.nblocks*b.len,
+     hipMemcpyDeviceToHost, c->stream));
+  }
+  ODHIP_TRY(hipStreamSynchronize(c->stream));
+  p.bands_valid = 1;
+  return ODHIP_SUCCESS;
+}
+
+int odhip_cache_band(odhip_frame_cache *c, int pli, int bs, int bx, int by, int band,
+ const od_coeff *x0, odhip_band_cands *out) {
+  if (!c || !out || pli < 0 || pli >= 4) return 0;
+  odhip_frame_cache::Plane &p = c->planes[pli];
+  if (!p.valid || !p.bands_valid || bs < 0 || bs > 4 - p.dec) {
+    c->band_misses++;
+    return 0;
+  }
+  const BandLevel &b = p.bands[bs];
+  const int n = 4 << bs;
+  if (bx < 0 || by < 0 || bx >= p.w/n || by >= p.h/n || band < 0 || band >= b.nb) {
+    c->band_misses++;
+    return 0;
+  }
+  const long blk = (long)by*(p.w/n) + bx;
+  const odhip_pvq_band &r = b.h_band[blk*b.nb + band];
+  const int off = b.off[band];
+  const int nn = b.off[band + 1] - off;
+  if (c->check && x0) {
+    /* the band the encoder is about to code must be the band the batch coded */
+    const od_coeff *src = p.h_levels[bs] + ((size_t)by*n*p.w + (size_t)bx*n);
+    for (int i = 0; i < nn; i++) {
+      if (x0[i] != src[(size_t)OD_SCAN_XY[off + i][1]*p.w + OD_SCAN_XY[off + i][0]]) {
+        fprintf(stderr, "libdaalahip: band cache mismatch: plane %d bs %d block (%d,%d) band %d\n", pli,
+         bs, bx, by, band);
+        abort();
+      }
+    }
+  }
+  out->n = nn;
+  out->q = b.q[band];
+  out->beta = b.beta[band];
+  out->cg = r.cg;
+  out->dist0 = r.dist0;
+  for (int s = 0; s < 2; s++) {
+    out->gain[s] = r.gain[s];
+    out->k[s] = r.k[s];
+    out->flags[s] = r.flags[s];
+    out->dist[s] = r.dist[s];
+    out->y[s] = b.h_y + ((size_t)s*b.nblocks + blk)*b.len + off;
+  }
+  c->band_hits++;
+  return 1;
+}
+
+void odhip_cache_band_stats(const odhip_frame_cache *c, long *hits, long *misses) {
+  if (hits) *hits = c->band_hits;
+  if (misses) *misses = c->band_misses;
 }
 
 void odhip_install_cached_dct_vtbl(odhip_dct_func_2d fdct_2d[ODHIP_NBSIZES],

@@ -718,6 +718,46 @@ void odhip_cache_stats(const odhip_frame_cache *c, long *hits, long *misses);
 void odhip_install_cached_dct_vtbl(odhip_dct_func_2d fdct_2d[ODHIP_NBSIZES],
  odhip_dct_func_2d idct_2d[ODHIP_NBSIZES]);
 
+/* ---- frame cache, second half: the batched band stage behind pvq_theta ------------
+
+   odhip_cache_load_bands (after odhip_cache_load_plane(pli), same frame): the
+   no-reference PVQ band stage of every block of every level of that plane in one
+   set of launches on the pyramid still resident in HBM, with the quantiser set-up
+   `qt` (the encoder's state.qm / pvq_qm_q4 / quantizer: odhip_quant_setup, or the
+   caller copies its own tables into an odhip_quant); records and pulse vectors go
+   to pinned host memory.
+
+   odhip_cache_band serves ONE pvq_theta call of the encoder's block loop
+   (src/pvq_encoder.c:333-641) whose reference vector r0 is null - the case in which
+   pvq_theta runs exactly the no-reference candidates (:452 fails, :571-609): block
+   (bx, by) of level bs (block units), band index `band`.  Returns 1 and fills *out
+   (views into the cache, valid until the next load), or 0 (not loaded / out of
+   range: the caller falls back to the reference's own pvq_theta).  x0 is optional:
+   with ODHIP_CACHE_CHECK=1 the band the encoder presents is compared with the band
+   the batch coded and a mismatch aborts.  The caller then does what stays on the
+   host in the reference: per candidate s with flags[s] == 1, cost = dist[s] +
+   lambda*od_pvq_rate(gain[s], 0, -1, 0, adapt, y[s], k[s], n, ...), `cost <=
+   best_cost` starting from best_cost = dist0 (:417-421, :597-609), then skip rule,
+   od_gain_expand and od_pvq_synthesis_partial (:611-633).  INTEGRATION.md section 7
+   shows that glue; tests/interpose/interpose.c is its load-time form. */
+typedef struct {
+  int n;                 /* coefficients of the band                               */
+  int32_t q;             /* the band's quantiser step and beta (Q12) the batch used:   */
+  int32_t beta;          /* the caller checks them against its own pvq_theta arguments */
+  int32_t cg;            /* companded gain of x, Q8                                */
+  int32_t gain[2];       /* candidate gain index i (0 = slot unused)               */
+  int32_t k[2];
+  int32_t flags[2];      /* 1 = searched, 0 = pruned / unused, 2 = K out of range  */
+  double dist0;          /* distortion of the null candidate                       */
+  double dist[2];
+  const int16_t *y[2];   /* signed pulses of the candidate, coding order, n values */
+} odhip_band_cands;
+int odhip_cache_load_bands(odhip_frame_cache *c, int pli, const odhip_quant *qt,
+ double pvq_norm_lambda);
+int odhip_cache_band(odhip_frame_cache *c, int pli, int bs, int bx, int by, int band,
+ const od_coeff *x0, odhip_band_cands *out);
+void odhip_cache_band_stats(const odhip_frame_cache *c, long *hits, long *misses);
+
 /* ---- odhip_pipe: the frame-batch step as one C call ------------------------------
 
    One step = one pass of the hot path over `frames` resident 4:2:0 pictures of

@@ -232,6 +232,28 @@ static int ref_encode_core(const unsigned char *frames, int w, int h,
   return npackets;
 }
 
+/* What the batched band stage needs to know about a live encoder when a frame's
+   luma plane is loaded (tests/interpose's od_apply_prefilter_frame_sbs): exactly the
+   values od_block_encode / od_pvq_encode hand to pvq_theta for that frame
+   (src/encode.c:1336-1359, src/pvq_encoder.c:874).  The tables are copied out;
+   returns 1 when the frame being coded is a keyframe coded with PVQ (the only case
+   the batch serves), else 0. */
+REF_EXPORT int ref_enc_band_setup(const void *encp, int *quantizer, int *use_masking,
+ double *pvq_norm_lambda, unsigned char *pvq_qm_q4, int16_t *qm, int16_t *qm_inv) {
+  const daala_enc_ctx *enc;
+  int pli;
+  enc = (const daala_enc_ctx *)encp;
+  *quantizer = enc->state.quantizer;
+  *use_masking = enc->use_activity_masking;
+  *pvq_norm_lambda = enc->pvq_norm_lambda;
+  for (pli = 0; pli < 3; pli++) {
+    memcpy(pvq_qm_q4 + pli*OD_QM_SIZE, enc->state.pvq_qm_q4[pli], OD_QM_SIZE);
+  }
+  memcpy(qm, enc->state.qm, OD_QM_BUFFER_SIZE*sizeof(*qm));
+  memcpy(qm_inv, enc->state.qm_inv, OD_QM_BUFFER_SIZE*sizeof(*qm_inv));
+  return enc->state.frame_type == OD_I_FRAME && !enc->use_haar_wavelet && !OD_LOSSLESS(enc);
+}
+
 /* Quantiser set-up the reference derives per frame on the host (SURVEY.md
    8(a) row a17): after encoding one frame at `quality`, copies out
    state.quantizer, state.pvq_qm_q4[pli][OD_QM_SIZE] (od_interp_qm,

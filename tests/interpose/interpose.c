@@ -171,6 +171,11 @@ double pvq_search_rdo_double(const int16_t *xcoeff, int n, int k, od_coeff *ypul
 static odhip_frame_cache *g_cache;
 static const od_coeff *g_bases[4];
 static int g_nbases;
+static int g_bands_on;      /* mode 3: the batched band stage behind pvq_theta */
+static void *g_enc;         /* the encoder whose frame is being coded */
+static int g_bands_frame;   /* the current frame's luma bands are loaded */
+long odhip_interposed_theta[4];   /* served from the batch / left to the reference (r0 not null) /
+                                     left to the reference (other reason) / searches the batch saved */
 
 void odhip_interpose_enable_cache(int pic_w, int pic_h) {
   if (!g_cache) g_cache = odhip_cache_create();
@@ -191,6 +196,163 @@ static void interpose_load(const od_coeff *c, int stride, int nhsb, int nvsb, in
     g_bases[g_nbases++] = c;
   }
   odhip_cache_load_plane(g_cache, slot, c, stride, nhsb << 6 >> xdec, nvsb << 6 >> xdec, xdec);
+  if (g_bands_on && slot == 0 && xdec == 0) {
+    /* keyframe luma: the PVQ band stage of every block of every level, now, in one
+       batch, with the quantiser set-up this encoder uses for this frame */
+    typedef int (*setup_fn)(const void *, int *, int *, double *, unsigned char *, int16_t *, int16_t *);
+    static odhip_quant qt;
+    setup_fn setup;
+    double lambda;
+    g_bands_frame = 0;
+    setup = (setup_fn)(g_reference ? dlsym(g_reference, "ref_enc_band_setup")
+     : dlsym(RTLD_DEFAULT, "ref_enc_band_setup"));
+    if (!setup || !g_enc) {
+      fprintf(stderr, "interpose: no encoder to take the quantiser set-up from\n");
+      abort();
+    }
+    if (setup(g_enc, &qt.quantizer, &qt.use_masking, &lambda, &qt.pvq_qm_q4[0][0], qt.qm, qt.qm_inv)) {
+      if (odhip_cache_load_bands(g_cache, 0, &qt, lambda) != 0) {
+        fprintf(stderr, "interpose: odhip_cache_load_bands failed\n");
+        abort();
+      }
+      g_bands_frame = 1;
+    }
+  }
+}
+
+void odhip_interpose_enable_bands(void) {
+  g_bands_on = 1;
+}
+
+void odhip_interpose_band_stats(long *hits, long *misses) {
+  odhip_cache_band_stats(g_cache, hits, misses);
+}
+
+/* daala_encode_img_in (include/daala/daalaenc.h:118): remembers which encoder the
+   following plane loads and block encodes belong to. */
+int daala_encode_img_in(void *enc, void *img, int duration) {
+  typedef int (*fn)(void *, void *, int);
+  static fn next;
+  if (!next) next = NEXT(fn, "daala_encode_img_in");
+  g_enc = enc;
+  g_bands_frame = 0;
+  return next(enc, img, duration);
+}
+
+/* od_pvq_encode (src/pvq_encoder.h:46-49, the boundary symbol of BASELINE.json): the
+   reference's own definition runs; this wrapper only notes WHICH block its pvq_theta
+   calls belong to (bx, by in 4x4 units as src/encode.c:1264-1265 passes them). */
+static __thread int t_pli, t_bs, t_bx, t_by, t_band;
+int od_pvq_encode(void *enc, od_coeff *ref, const od_coeff *in, od_coeff *out, int q0, int pli, int bs,
+ const int16_t *beta, int nodesync, int is_keyframe, int q_scaling, int bx, int by, const int16_t *qm,
+ const int16_t *qm_inv, int speed) {
+  typedef int (*fn)(void *, od_coeff *, const od_coeff *, od_coeff *, int, int, int, const int16_t *, int,
+   int, int, int, int, const int16_t *, const int16_t *, int);
+  static fn next;
+  if (!next) next = NEXT(fn, "od_pvq_encode");
+  t_pli = pli;
+  t_bs = bs;
+  t_bx = bx;
+  t_by = by;
+  t_band = 0;
+  return next(enc, ref, in, out, q0, pli, bs, beta, nodesync, is_keyframe, q_scaling, bx, by, qm, qm_inv,
+   speed);
+}
+
+/* pvq_theta (src/pvq_encoder.c:333-641; file-static in the reference, an ordinary
+   symbol of the test build).  This is the glue INTEGRATION.md section 7 puts at the
+   top of that function: a keyframe luma band whose reference vector is null takes
+   the no-reference path only (:452 fails, :571-609 runs), and every quantity of that
+   path that does not depend on the entropy coder's adaptive state was computed for
+   the whole frame in one batch (odhip_cache_load_bands).  What is left is what the
+   reference keeps on the host: price the candidates with od_pvq_rate on the LIVE
+   state, apply `cost <= best_cost`, the skip rule, and synthesise the winner with the
+   reference's own od_gain_expand / od_pvq_synthesis_partial.  Every other band goes
+   to the reference's pvq_theta untouched. */
+int pvq_theta(od_coeff *out, const od_coeff *x0, const od_coeff *r0, int n, int q0, od_coeff *y,
+ int *itheta, int *max_theta, int *vk, int16_t beta, double *skip_diff, int nodesync, int is_keyframe,
+ int pli, const void *adapt, const int16_t *qm, const int16_t *qm_inv, double pvq_norm_lambda,
+ int speed) {
+  typedef int (*fn)(od_coeff *, const od_coeff *, const od_coeff *, int, int, od_coeff *, int *, int *,
+   int *, int16_t, double *, int, int, int, const void *, const int16_t *, const int16_t *, double, int);
+  typedef double (*rate_fn)(int, int, int, int, const void *, const od_coeff *, int, int, int, int, int);
+  typedef int32_t (*expand_fn)(int32_t, int, int16_t);
+  typedef void (*synth_fn)(od_coeff *, const od_coeff *, const int16_t *, int, int, int32_t, int32_t,
+   int, int, const int16_t *);
+  static fn next;
+  static rate_fn rate;
+  static expand_fn gain_expand;
+  static synth_fn synthesis;
+  odhip_band_cands c;
+  const int band = t_band++;
+  int i;
+  if (!next) next = NEXT(fn, "pvq_theta");
+  if (g_bands_on && g_bands_frame && is_keyframe && pli == 0 && t_pli == 0 && n <= 128) {
+    int null_ref = 1;
+    for (i = 0; i < n; i++) {
+      if (r0[i]) {
+        null_ref = 0;
+        break;
+      }
+    }
+    if (!null_ref) odhip_interposed_theta[1]++;
+    else if (!odhip_cache_band(g_cache, 0, t_bs, t_bx >> t_bs, t_by >> t_bs, band, x0, &c)
+     || c.n != n || c.q != q0 || c.beta != beta || c.flags[0] == 2 || c.flags[1] == 2) {
+      odhip_interposed_theta[2]++;
+    }
+    else {
+      od_coeff y_tmp[128];
+      double best_cost;
+      double best_dist;
+      double skip_dist;
+      int qg;
+      int best_k;
+      int s;
+      if (!rate) {
+        rate = NEXT(rate_fn, "od_pvq_rate");
+        gain_expand = NEXT(expand_fn, "od_gain_expand");
+        synthesis = NEXT(synth_fn, "od_pvq_synthesis_partial");
+      }
+      odhip_interposed_theta[0]++;
+      /* :415-421 with a null reference on a keyframe: the null candidate */
+      qg = 0;
+      best_dist = c.dist0;
+      best_cost = c.dist0 + pvq_norm_lambda*rate(0, 0, -1, 0, adapt, NULL, 0, n, is_keyframe, pli, speed);
+      best_k = 0;
+      *itheta = -1;
+      *max_theta = 0;
+      for (i = 0; i < n; i++) y[i] = 0;
+      skip_dist = c.dist0;        /* :439: the same expression as :417 on a keyframe */
+      /* :578-609: the (at most two) no-reference candidates, in gain order */
+      for (s = 0; s < 2; s++) {
+        double cost;
+        if (c.flags[s] != 1) continue;
+        odhip_interposed_theta[3]++;
+        for (i = 0; i < n; i++) y_tmp[i] = c.y[s][i];
+        cost = c.dist[s] + pvq_norm_lambda*rate(c.gain[s], 0, -1, 0, adapt, y_tmp, c.k[s], n,
+         is_keyframe, pli, speed);
+        if (cost <= best_cost) {
+          best_cost = cost;
+          best_dist = c.dist[s];
+          qg = c.gain[s];
+          best_k = c.k[s];
+          for (i = 0; i < n; i++) y[i] = y_tmp[i];
+        }
+      }
+      /* :611-633: skip rule and the decoder's synthesis */
+      if (qg == 0) for (i = 0; i < n; i++) out[i] = 0;
+      else {
+        int16_t r16[128];
+        for (i = 0; i < n; i++) r16[i] = 0;
+        synthesis(out, y, r16, n, 1, gain_expand(qg << 8, q0, beta), 0, 0, 1, qm_inv);
+      }
+      *vk = best_k;
+      *skip_diff += skip_dist - best_dist;
+      return qg;
+    }
+  }
+  return next(out, x0, r0, n, q0, y, itheta, max_theta, vk, beta, skip_diff, nodesync, is_keyframe, pli,
+   adapt, qm, qm_inv, pvq_norm_lambda, speed);
 }
 
 /* od_dering, src/dering.c:252 (call sites src/encode.c:2787,2826): the function

@@ -26,10 +26,13 @@ r = ctypes.CDLL(os.path.join(ROOT, "oracle", "_ref", "libdaalaref.so"))
 if ipo is not None:
     # pass-through mode (ODHIP_INTERPOSE_PASSTHROUGH=1) calls the reference's own definitions
     ipo.odhip_interpose_set_reference(ctypes.c_void_p(r._handle))
-if interpose == 2:
-    # frame cache: batched pyramid per plane serves every fdct_2d call
+if interpose in (2, 3):
+    # frame cache: batched pyramid per plane serves every fdct_2d call; mode 3 adds the
+    # batched PVQ band stage of keyframe luma behind pvq_theta (host pricing in the loop)
     w, h = int(sys.argv[2]), int(sys.argv[3])
     ipo.odhip_interpose_enable_cache(w, h)
+    if interpose == 3:
+        ipo.odhip_interpose_enable_bands()
     fd = (ctypes.c_void_p * 5)()
     idt = (ctypes.c_void_p * 5)()
     hip.odhip_install_cached_dct_vtbl(fd, idt)
@@ -43,7 +46,20 @@ out = np.zeros(8 << 20, np.uint8)
 sizes = (ctypes.c_long * 16)()
 import time
 t0 = time.perf_counter()
-n = r.ref_encode_yuv420(P(frames), w, h, nframes, 20, 7, 0, P(out), ctypes.c_long(out.size), sizes)
+quality = int(os.environ.get("QUALITY", "20"))
+complexity = int(os.environ.get("COMPLEXITY", "7"))
+if os.environ.get("CONTENT") == "bench":
+    # the bench generator's pictures (any size up to 1920x1080)
+    import bench
+    fr = []
+    for f in range(nframes):
+        pl = bench.picture_planes(bench.synth_frame_np(f, 1234))
+        fr.append(np.concatenate([pl[0][:h, :w].ravel(), pl[1][:h // 2, :w // 2].ravel(),
+                                  pl[2][:h // 2, :w // 2].ravel()]))
+    frames = np.concatenate(fr).astype(np.uint8)
+    out = np.zeros(64 << 20, np.uint8)
+n = r.ref_encode_yuv420(P(frames), w, h, nframes, quality, complexity, 0, P(out), ctypes.c_long(out.size),
+                        sizes)
 seconds = time.perf_counter() - t0
 assert n == nframes, n
 total = sum(sizes[i] for i in range(n))
@@ -52,11 +68,15 @@ if ipo is not None:
     arr = (ctypes.c_long * 6).in_dll(ipo, "odhip_interposed_calls")
     calls = [arr[i] for i in range(6)]
 stats = [0, 0]
-if interpose == 2:
+theta = [0, 0, 0, 0]
+if interpose in (2, 3):
     hits, misses = ctypes.c_long(), ctypes.c_long()
     ipo.odhip_interpose_cache_stats(ctypes.byref(hits), ctypes.byref(misses))
     stats = [hits.value, misses.value]
+if interpose == 3:
+    arr = (ctypes.c_long * 4).in_dll(ipo, "odhip_interposed_theta")
+    theta = [arr[i] for i in range(4)]
 import hashlib
 print(json.dumps({"packets": hashlib.sha256(bytes(out[:total])).hexdigest(),
-                  "sizes": [sizes[i] for i in range(n)], "calls": calls, "cache": stats,
+                  "sizes": [sizes[i] for i in range(n)], "calls": calls, "cache": stats, "theta": theta,
                   "encode_seconds": seconds}))

@@ -95,3 +95,66 @@ def test_reference_encoder_with_interposed_filters_and_pvq_search():
     assert cached["packets"] == plain2["packets"], "packets differ with the frame cache"
     hits, misses = cached["cache"]
     assert hits > 1000 and misses == 0, cached["cache"]
+
+
+@pytest.mark.skipif(ref() is None, reason="oracle/_ref not present")
+def test_batched_band_stage_behind_the_real_encoder_is_byte_identical():
+    """Frame integration with host pricing: the unmodified
+    reference encoder, -z 7 (od_pvq_rate prices with the LIVE adaptive entropy coder),
+    with one batched GPU pass per keyframe - pyramid of every plane + the PVQ band
+    stage of every luma block of every level - serving its fdct_2d calls and every
+    pvq_theta call whose reference vector is null; the host prices, chooses and
+    synthesises.  Packets must be byte-identical to plain C, for several picture
+    sizes / qualities, with every served band checked against the band the encoder
+    presents (ODHIP_CACHE_CHECK=1)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+
+    def run(mode, w, h, **env):
+        e = dict(os.environ)
+        e.update({k: str(v) for k, v in env.items()})
+        p = subprocess.run([sys.executable, os.path.join(here, "interpose", "run_interposed.py"),
+                            str(mode), str(w), str(h)], capture_output=True, text=True, timeout=1500, env=e)
+        assert p.returncode == 0, p.stderr[-3000:]
+        return json.loads(p.stdout.strip().splitlines()[-1])
+
+    for (w, h, nframes, quality, complexity) in ((64, 64, 2, 20, 7), (180, 116, 1, 20, 7),
+                                                 (320, 192, 2, 40, 7), (256, 128, 1, 5, 2)):
+        env = dict(NFRAMES=nframes, QUALITY=quality, COMPLEXITY=complexity,
+                   ODHIP_INTERPOSE_PASSTHROUGH=1)
+        plain = run(0, w, h, **env)
+        batch = run(3, w, h, ODHIP_CACHE_CHECK=1, **env)
+        assert batch["sizes"] == plain["sizes"], (w, h)
+        assert batch["packets"] == plain["packets"], (w, h, quality, complexity)
+        served, with_ref, other, searches = batch["theta"]
+        assert served > 100 and searches > 0, batch["theta"]
+        assert other == 0, batch["theta"]
+
+
+@pytest.mark.skipif(ref() is None, reason="oracle/_ref not present")
+def test_batched_band_stage_1080p_frame_byte_identical():
+    """The same at BASELINE configs[1]'s size: one 1920x1080 keyframe of the bench
+    generator, -v 20 -z 7."""
+    import json
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    res = {}
+    for mode in (0, 3):
+        e = dict(os.environ)
+        e.update(NFRAMES="1", CONTENT="bench", ODHIP_INTERPOSE_PASSTHROUGH="1")
+        p = subprocess.run([sys.executable, os.path.join(here, "interpose", "run_interposed.py"),
+                            str(mode), "1920", "1080"], capture_output=True, text=True, timeout=1500, env=e)
+        assert p.returncode == 0, p.stderr[-3000:]
+        res[mode] = json.loads(p.stdout.strip().splitlines()[-1])
+    assert res[3]["sizes"] == res[0]["sizes"]
+    assert res[3]["packets"] == res[0]["packets"]
+    served, with_ref, other, searches = res[3]["theta"]
+    assert served > 50000 and other == 0, res[3]["theta"]
+    print("1080p keyframe: %d bands from the batch (%d searches), %d bands with a neighbour "
+          "prediction left to the reference; encode %.2f s vs %.2f s plain C"
+          % (served, searches, with_ref, res[3]["encode_seconds"], res[0]["encode_seconds"]))
