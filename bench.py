@@ -322,6 +322,47 @@ def cpu_baseline(D, qt, chroma_cfl, args, gpu_frame0):
     return base, host, ver
 
 
+def sharded_encode_check(rank, world, local_rank, dist, torch):
+    """--gpus N > 1, when the compiled reference travelled with the snapshot: BASELINE
+    configs[4] in miniature on the N GPUs - one 1080p frame per rank through the real
+    encoder with the batched GPU stage bound (tests/_shard_encode.py), packets gathered to
+    rank 0 over RCCL (daala_amd.shard.gather_packets) and compared with the plain C encoder
+    run sequentially.  A CHECK outside the timed region (the encoder's host half is the
+    reference's C, i.e. test infrastructure here), reported separately from `value`."""
+    if not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libdaalaref.so")):
+        return {"ran": False, "why": "oracle/_ref/libdaalaref.so absent"}
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import _shard_encode as S
+    from daala_amd.shard import frames_of_rank, gather_packets
+    nframes = world
+    r, ipo = S.load_batched_encoder(PIC_W, PIC_H, device=local_rank)
+    mine = frames_of_rank(nframes, rank, world)
+    dist.barrier()
+    t0 = time.perf_counter()
+    local = S.encode_owned(r, mine, PIC_W, PIC_H)
+    t_enc = time.perf_counter() - t0
+    torch.cuda.synchronize()
+    dist.barrier()
+    t0 = time.perf_counter()
+    got = gather_packets(local, nframes)
+    torch.cuda.synchronize()
+    t_gather = time.perf_counter() - t0
+    tt = torch.tensor([t_enc, t_gather], dtype=torch.float64, device="cuda")
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    if rank != 0:
+        return None
+    want = S.sequential_digest(nframes, PIC_W, PIC_H)
+    st = S.band_stats(ipo)
+    return {"ran": True, "frames": nframes, "frames_per_rank": 1,
+            "packets_equal_sequential_c_encoder": S.digest(got) == want,
+            "packet_bytes": sum(len(p) for p in got),
+            "encode_s_max_over_ranks": float(tt[0].item()), "gather_ms": float(tt[1].item()) * 1e3,
+            "bands_from_batch_rank0": st[0], "bands_left_to_reference_rank0": st[1] + st[2],
+            "note": "one 1920x1080 keyframe per rank, -v 20 -z 7, real reference encoder (host entropy "
+                    "coding / pricing) with the batched pyramid + luma PVQ band stage behind it; gather = "
+                    "all_gather of sizes + padded all_gather of bytes over RCCL"}
+
+
 def pipeline_digest(D, pipe):
     """SHA-256 over every reconstructed plane and choice record of the pipe."""
     import hashlib
@@ -391,6 +432,8 @@ def main():
     ap.add_argument("--frames", type=int, default=DEFAULT_FRAMES, help="1080p frames per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-cpu-allcores", action="store_true")
+    ap.add_argument("--no-shard-check", action="store_true",
+                    help="N > 1: skip the sharded real-encoder check (frames over ranks, RCCL gather)")
     ap.add_argument("--cpu-worker", type=int, default=None, help=argparse.SUPPRESS)
     ap.add_argument("--content", choices=sorted(CONTENT), default="checker",
                     help="synthetic picture generator: 'checker' (smooth texture + 32-pixel checker "
@@ -467,6 +510,9 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    shard_check = None
+    if dist is not None and not args.no_shard_check:
+        shard_check = sharded_encode_check(rank, world, local_rank, dist, torch)
 
     if rank == 0:
         # exclusive durations and the pipelined == serial check: the same steps replayed on
@@ -595,6 +641,8 @@ def main():
             "theta_margin_reruns": pipe.theta_reruns(),
             "kernels": kernels,
         }
+        if shard_check is not None:
+            line["sharded_encode_check"] = shard_check
         if world == 1 and not args.no_cpu_baseline:
             frame0 = [luma_pic[0], chroma_pic[0], chroma_pic[args.frames]]
             base, host, ver = cpu_baseline(D, qt, cfl, args, frame0)

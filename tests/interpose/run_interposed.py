@@ -43,7 +43,7 @@ elif len(sys.argv) > 3:
 frames = np.concatenate([np.concatenate([p.ravel() for p in synth_frame(w, h, seed=7, phase=5 * f)])
                          for f in range(nframes)]).astype(np.uint8)
 out = np.zeros(8 << 20, np.uint8)
-sizes = (ctypes.c_long * 16)()
+sizes = (ctypes.c_long * 64)()
 import time
 t0 = time.perf_counter()
 quality = int(os.environ.get("QUALITY", "20"))
@@ -77,6 +77,16 @@ if interpose == 3:
     arr = (ctypes.c_long * 4).in_dll(ipo, "odhip_interposed_theta")
     theta = [arr[i] for i in range(4)]
 import hashlib
-print(json.dumps({"packets": hashlib.sha256(bytes(out[:total])).hexdigest(),
+pkt_digest = None
+if os.environ.get("PACKET_DIGEST") == "1":
+    # per-packet framing, as tests/_shard_encode.digest
+    hh = hashlib.sha256()
+    pos = 0
+    for i in range(n):
+        hh.update(int(sizes[i]).to_bytes(8, "little"))
+        hh.update(bytes(out[pos:pos + sizes[i]]))
+        pos += sizes[i]
+    pkt_digest = hh.hexdigest()
+print(json.dumps({"digest": pkt_digest, "packets": hashlib.sha256(bytes(out[:total])).hexdigest(),
                   "sizes": [sizes[i] for i in range(n)], "calls": calls, "cache": stats, "theta": theta,
                   "encode_seconds": seconds}))
