@@ -335,23 +335,37 @@ def sharded_encode_check(rank, world, local_rank, dist, torch):
     import _shard_encode as S
     from daala_amd.shard import frames_of_rank, gather_packets
     nframes = world
-    r, ipo = S.load_batched_encoder(PIC_W, PIC_H, device=local_rank)
-    mine = frames_of_rank(nframes, rank, world)
+    err = None
+    local = {}
+    ipo = None
     dist.barrier()
     t0 = time.perf_counter()
-    local = S.encode_owned(r, mine, PIC_W, PIC_H)
+    try:
+        r, ipo = S.load_batched_encoder(PIC_W, PIC_H, device=local_rank)
+        local = S.encode_owned(r, frames_of_rank(nframes, rank, world), PIC_W, PIC_H)
+    except Exception as e:      # noqa: BLE001 - a failed check must not take the bench line down
+        err = "encode on rank %d: %r" % (rank, e)
     t_enc = time.perf_counter() - t0
     torch.cuda.synchronize()
     dist.barrier()
     t0 = time.perf_counter()
-    got = gather_packets(local, nframes)
+    got = None
+    try:
+        got = gather_packets(local, nframes)      # symmetric collectives on every rank
+    except Exception as e:      # noqa: BLE001
+        err = err or "gather: %r" % (e,)
     torch.cuda.synchronize()
     t_gather = time.perf_counter() - t0
     tt = torch.tensor([t_enc, t_gather], dtype=torch.float64, device="cuda")
     dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    if rank == 0 and (err or got is None):
+        return {"ran": False, "why": err or "gather returned nothing"}
     if rank != 0:
         return None
-    want = S.sequential_digest(nframes, PIC_W, PIC_H)
+    try:
+        want = S.sequential_digest(nframes, PIC_W, PIC_H)
+    except Exception as e:      # noqa: BLE001
+        return {"ran": False, "why": "sequential C encoder: %r" % (e,)}
     st = S.band_stats(ipo)
     return {"ran": True, "frames": nframes, "frames_per_rank": 1,
             "packets_equal_sequential_c_encoder": S.digest(got) == want,
