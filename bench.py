@@ -446,6 +446,8 @@ def main():
     ap.add_argument("--frames", type=int, default=DEFAULT_FRAMES, help="1080p frames per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-cpu-allcores", action="store_true")
+    ap.add_argument("--no-replay", action="store_true",
+                    help="skip the serial replay after the timed region (profiling runs: no extra launches)")
     ap.add_argument("--no-shard-check", action="store_true",
                     help="N > 1: skip the sharded real-encoder check (frames over ranks, RCCL gather)")
     ap.add_argument("--cpu-worker", type=int, default=None, help=argparse.SUPPRESS)
@@ -531,22 +533,26 @@ def main():
     if rank == 0:
         # exclusive durations and the pipelined == serial check: the same steps replayed on
         # ONE stream (own pipe, same pictures), after the timed region
-        digest = pipeline_digest(D, pipe)
         r_bytes, r_bands = ref128_bytes(D, pipe) if cfl else (0, 0)
-        serial = D.Pipe(qt, args.frames, PIC_W, PIC_H, chroma_cfl=cfl, device=local_rank, serial=True)
-        serial.set_pictures(luma_pic, chroma_pic)
-        serial.step()
-        serial.flush()
-        serial.record(True)
-        for _ in range(3):
+        if args.no_replay:
+            digest, serial_digest = None, ""
+            excl, search_excl, ref_search_excl = kms, search_ms, ref_search_ms
+        else:
+            digest = pipeline_digest(D, pipe)
+            serial = D.Pipe(qt, args.frames, PIC_W, PIC_H, chroma_cfl=cfl, device=local_rank, serial=True)
+            serial.set_pictures(luma_pic, chroma_pic)
             serial.step()
-        serial.flush()
-        serial.sync()
-        excl = serial.timings()
-        search_excl = serial.search_timings(False)
-        ref_search_excl = serial.search_timings(True)
-        serial_digest = pipeline_digest(D, serial)
-        serial.destroy()
+            serial.flush()
+            serial.record(True)
+            for _ in range(3):
+                serial.step()
+            serial.flush()
+            serial.sync()
+            excl = serial.timings()
+            search_excl = serial.search_timings(False)
+            ref_search_excl = serial.search_timings(True)
+            serial_digest = pipeline_digest(D, serial)
+            serial.destroy()
 
         bpf = blocks_per_frame()
         total_blocks = world * args.frames * args.steps * bpf
@@ -651,7 +657,7 @@ def main():
             "roofline_filter_dct": roof_fd,
             "roofline_noref_search": roof_noref if roof is not roof_noref else None,
             "roofline_ref_search": roof_ref if (roof_ref is not None and roof is not roof_ref) else None,
-            "pipelined_equals_serial": digest == serial_digest,
+            "pipelined_equals_serial": None if digest is None else digest == serial_digest,
             "theta_margin_reruns": pipe.theta_reruns(),
             "kernels": kernels,
         }

@@ -88,11 +88,10 @@ __device__ __forceinline__ void lds_filter4(E *p, int step) {
 /* Column-direction half of od_prefilter_split / od_postfilter_split for every
    level-LN block of the tile: taps across the horizontal mid-line, gated by
    `hfilter` (derived from the block's x index, src/encode.c:1487). */
-template <int TILE, int LN, bool INV, typename E>
+template <int TILE, int LN, bool INV, int NT = Geo<TILE>::kNT, typename E>
 __device__ __forceinline__ void split_filter_cols(E *t, int tid, int x0, int pic_w) {
   constexpr int N = 4 << LN;
   constexpr int P = Geo<TILE>::kPitch;
-  constexpr int NT = Geo<TILE>::kNT;
   for (int k = tid; k < TILE*(TILE/N); k += NT) {
     const int x = k % TILE;
     const int by = k / TILE;
@@ -103,11 +102,10 @@ __device__ __forceinline__ void split_filter_cols(E *t, int tid, int x0, int pic
 
 /* Row-direction half: taps across the vertical mid-line, gated by `vfilter`
    (from the block's y index, src/encode.c:1488). */
-template <int TILE, int LN, bool INV, typename E>
+template <int TILE, int LN, bool INV, int NT = Geo<TILE>::kNT, typename E>
 __device__ __forceinline__ void split_filter_rows(E *t, int tid, int y0, int pic_h) {
   constexpr int N = 4 << LN;
   constexpr int P = Geo<TILE>::kPitch;
-  constexpr int NT = Geo<TILE>::kNT;
   for (int k = tid; k < TILE*(TILE/N); k += NT) {
     const int y = k % TILE;
     const int bx = k / TILE;
@@ -116,11 +114,10 @@ __device__ __forceinline__ void split_filter_rows(E *t, int tid, int y0, int pic
   }
 }
 
-template <int TILE>
+template <int TILE, int NT = Geo<TILE>::kNT>
 __device__ __forceinline__ void store_tile(od_coeff *plane, int w, int x0, int y0,
  const int *z, int tid) {
   constexpr int P = Geo<TILE>::kPitch;
-  constexpr int NT = Geo<TILE>::kNT;
   for (int i = tid; i < TILE*TILE/4; i += NT) {
     const int y = i/(TILE/4);
     const int x = (i % (TILE/4))*4;
@@ -142,10 +139,9 @@ __device__ __forceinline__ void store_tile(od_coeff *plane, int w, int x0, int y
                                 barrier: its partner reads the same words) writes
                                 zt[bx*N + u'][c], u' in half h
      store   raster (y, x)  <-  zt[bx*N + u'(x)][by*N + v'(y)]                  */
-template <int LN>
+template <int LN, typename T = OdMul24, int NT = Geo<64>::kNT>
 __device__ __forceinline__ void pyramid_level_split64(short *t, int *z, const PyramidArgs &a,
  long plane_off, int x0, int y0, int tid) {
-  using T = OdMul24;
   constexpr int TILE = 64;
   constexpr int N = 4 << LN;
   constexpr int H = N/2;
@@ -170,7 +166,7 @@ __device__ __forceinline__ void pyramid_level_split64(short *t, int *z, const Py
   }
   od_lds_barrier();
   /* The tile is free now: lapping of the next level overlaps the row pass. */
-  split_filter_cols<TILE, LN, false>(t, tid, x0, a.pic_w);
+  split_filter_cols<TILE, LN, false, NT>(t, tid, x0, a.pic_w);
   {
     T in[N];
     T out[H];
@@ -189,7 +185,7 @@ __device__ __forceinline__ void pyramid_level_split64(short *t, int *z, const Py
   od_lds_barrier();
   if (a.levels[LN]) {
     od_coeff *plane = a.levels[LN] + plane_off;
-    for (int i = tid; i < TILE*TILE/4; i += Geo<TILE>::kNT) {
+    for (int i = tid; i < TILE*TILE/4; i += NT) {
       const int y = i/(TILE/4);
       const int x = (i % (TILE/4))*4;
       const int v = y & (N - 1);
@@ -204,20 +200,19 @@ __device__ __forceinline__ void pyramid_level_split64(short *t, int *z, const Py
        make_int4(o[0], o[1], o[2], o[3]);
     }
   }
-  split_filter_rows<TILE, LN, false>(t, tid, y0, a.pic_h);
+  split_filter_rows<TILE, LN, false, NT>(t, tid, y0, a.pic_h);
   od_lds_barrier();
 }
 
 /* 4x4 level: one block per lane, both passes in registers, rows read from the
    tile and written to HBM as 16-byte vectors (16 consecutive lanes = one
    256-byte row segment). */
-template <int TILE>
+template <int TILE, typename T = OdMul24, int NT = Geo<TILE>::kNT>
 __device__ __forceinline__ void pyramid_level4(const short *t, const PyramidArgs &a,
  long plane_off, int x0, int y0, int tid) {
-  using T = OdMul24;
   constexpr int P = Geo<TILE>::kPitch;
   constexpr int NB = TILE/4;
-  for (int blk = tid; blk < NB*NB; blk += Geo<TILE>::kNT) {
+  for (int blk = tid; blk < NB*NB; blk += NT) {
   const int bx = blk % NB;
   const int by = blk/NB;
   T m[4][4];
@@ -252,28 +247,28 @@ __device__ __forceinline__ void pyramid_level4(const short *t, const PyramidArgs
   }
 }
 
-template <int TILE, int LN>
+template <int TILE, int LN, typename T = OdMul24, int NT = Geo<TILE>::kNT>
 __device__ __forceinline__ void pyramid_level(short *t, int *z, const PyramidArgs &a,
  long plane_off, int x0, int y0, int tid) {
-  using T = OdMul24;
-  constexpr int NT = Geo<TILE>::kNT;
   if constexpr (LN == 0) {
-    pyramid_level4<TILE>(t, a, plane_off, x0, y0, tid);
+    pyramid_level4<TILE, T, NT>(t, a, plane_off, x0, y0, tid);
   }
-  else if constexpr (TILE == 64 && LN >= 3 && Geo<TILE>::kNT == 256) {
-    pyramid_level_split64<LN>(t, z, a, plane_off, x0, y0, tid);
-    pyramid_level<TILE, LN - 1>(t, z, a, plane_off, x0, y0, tid);
+  else if constexpr (TILE == 64 && ((LN >= 3 && NT == 256) || (LN == 4 && NT == 128))) {
+    /* half networks: 2*TILE*(TILE/N) lanes = 256 for the 32-point level, 128 for the
+       64-point level */
+    pyramid_level_split64<LN, T, NT>(t, z, a, plane_off, x0, y0, tid);
+    pyramid_level<TILE, LN - 1, T, NT>(t, z, a, plane_off, x0, y0, tid);
   }
   else {
     od_tile_cols<TILE, LN, false, T, NT>(z, t, tid, OdAllBlocks());
     od_lds_barrier();
     od_tile_rows<TILE, LN, false, T, NT>(z, z, tid, OdAllBlocks());
-    split_filter_cols<TILE, LN, false>(t, tid, x0, a.pic_w);
+    split_filter_cols<TILE, LN, false, NT>(t, tid, x0, a.pic_w);
     od_lds_barrier();
-    if (a.levels[LN]) store_tile<TILE>(a.levels[LN] + plane_off, a.w, x0, y0, z, tid);
-    split_filter_rows<TILE, LN, false>(t, tid, y0, a.pic_h);
+    if (a.levels[LN]) store_tile<TILE, NT>(a.levels[LN] + plane_off, a.w, x0, y0, z, tid);
+    split_filter_rows<TILE, LN, false, NT>(t, tid, y0, a.pic_h);
     od_lds_barrier();
-    pyramid_level<TILE, LN - 1>(t, z, a, plane_off, x0, y0, tid);
+    pyramid_level<TILE, LN - 1, T, NT>(t, z, a, plane_off, x0, y0, tid);
   }
 }
 
@@ -375,11 +370,10 @@ __device__ __forceinline__ void sb_edge_rows(short *t, const PyramidArgs &a, int
   }
 }
 
-template <int TILE>
-__global__ __launch_bounds__(Geo<TILE>::kNT) void k_forward_pyramid(PyramidArgs a) {
+template <int TILE, typename T = OdMul24, int NT = Geo<TILE>::kNT>
+__global__ __launch_bounds__(NT) void k_forward_pyramid(PyramidArgs a) {
   using G = Geo<TILE>;
   constexpr int P = G::kPitch;
-  constexpr int NT = G::kNT;
   constexpr int TOP = TILE == 64 ? 4 : 3;
   /* Source tile as int16: (p - 128) << 4 lapped at most once per direction
      stays below 2^13 * 1.78^2 < 2^15 (every sample lies in the support of
@@ -398,7 +392,7 @@ __global__ __launch_bounds__(Geo<TILE>::kNT) void k_forward_pyramid(PyramidArgs 
   od_lds_barrier();
   sb_edge_rows<TILE, NT>(t, a, x0, tid);
   od_lds_barrier();
-  pyramid_level<TILE, TOP>(t, z, a, plane_off, x0, y0, tid);
+  pyramid_level<TILE, TOP, T, NT>(t, z, a, plane_off, x0, y0, tid);
 }
 
 /* TWO horizontally adjacent luma superblocks per 256-thread workgroup.  With
@@ -409,8 +403,8 @@ __global__ __launch_bounds__(Geo<TILE>::kNT) void k_forward_pyramid(PyramidArgs 
      32-point level: 2 tiles x 128 columns (full network)    = 256 lanes
      16/8-point:     generic passes, tile after tile
      4x4:            one block per lane, tile after tile                       */
+template <typename T>
 __global__ __launch_bounds__(256) void k_forward_pyramid64x2(PyramidArgs a) {
-  using T = OdMul24;
   constexpr int TILE = 64;
   using G = Geo<TILE>;
   constexpr int P = G::kPitch;
@@ -520,7 +514,158 @@ __global__ __launch_bounds__(256) void k_forward_pyramid64x2(PyramidArgs a) {
   }
   od_lds_barrier();
   /* ---- 4x4 level ----------------------------------------------------------- */
-  for (int s = 0; s < 2; s++) pyramid_level4<TILE>(t[s], a, plane_off, xb + s*TILE, y0, tid);
+  for (int s = 0; s < 2; s++) pyramid_level4<TILE, T>(t[s], a, plane_off, xb + s*TILE, y0, tid);
+}
+
+/* ONE luma superblock per 128-thread workgroup, and after the 64-point level NO
+   workgroup barrier at all: blocks of 32x32 and smaller never straddle the
+   horizontal mid-line of the superblock, so each of the two waves owns one half
+   (32 rows x 64 columns) of the tile and runs the 32-, 16-, 8- and 4-point levels of
+   its half on its own - column pass, row pass, split pre-filters and stores - with
+   only "my LDS operations have completed" between the phases (LDS operations of one
+   wave execute in order; od_wave_sync waits for their data and keeps the compiler
+   from moving accesses across it).  The two waves of a workgroup and the six
+   workgroups of a CU drift apart, so the arithmetic of one overlaps the stores and
+   LDS traffic of the others instead of all meeting at a barrier eighteen times per
+   superblock. */
+__device__ __forceinline__ void od_wave_sync() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+}
+
+/* Levels LN <= 3 of rows [r0, r0 + 32) of a 64-wide tile, one wave. */
+template <int LN, typename T>
+__device__ __forceinline__ void half_level(short *t, int *z, const PyramidArgs &a, long plane_off,
+ int x0, int y0, int r0, int lane) {
+  constexpr int TILE = 64;
+  constexpr int P = Geo<TILE>::kPitch;
+  constexpr int ROWS = 32;
+  if constexpr (LN == 0) {
+    /* one 4x4 block per lane and iteration, both passes in registers */
+    constexpr int NBX = TILE/4;
+    for (int blk = lane; blk < NBX*(ROWS/4); blk += 64) {
+      const int bx = blk % NBX;
+      const int by = blk/NBX;
+      T m[4][4];
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const short4 v = *reinterpret_cast<const short4 *>(t + (r0 + by*4 + r)*P + bx*4);
+        m[r][0] = T(v.x);
+        m[r][1] = T(v.y);
+        m[r][2] = T(v.z);
+        m[r][3] = T(v.w);
+      }
+#pragma unroll
+      for (int c = 0; c < 4; c++) {
+        T in[4] = {m[0][c], m[1][c], m[2][c], m[3][c]};
+        T out[4];
+        od_fdct4_lift(out, in);
+        m[0][c] = out[0];
+        m[1][c] = out[1];
+        m[2][c] = out[2];
+        m[3][c] = out[3];
+      }
+      if (!a.levels[0]) continue;
+      od_coeff *plane = a.levels[0] + plane_off;
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        T out[4];
+        od_fdct4_lift(out, m[r]);
+        *reinterpret_cast<int4 *>(plane + (long)(y0 + r0 + by*4 + r)*a.w + x0 + bx*4) =
+         make_int4(out[0], out[1], out[2], out[3]);
+      }
+    }
+  }
+  else {
+    constexpr int N = 4 << LN;
+    /* column pass: lane = (column, block row of the half) */
+    for (int k = lane; k < TILE*(ROWS/N); k += 64) {
+      const int x = k % TILE;
+      const int by = k/TILE;
+      const int base = (r0 + by*N)*P + x;
+      T in[N];
+      T out[N];
+#pragma unroll
+      for (int r = 0; r < N; r++) in[r] = T(t[base + r*P]);
+      od_fdct_lift<LN>(out, in);
+#pragma unroll
+      for (int r = 0; r < N; r++) z[base + r*P] = out[r];
+    }
+    od_wave_sync();
+    /* row pass in place: lane = (row of the half, block column), 16 bytes per access */
+    for (int k = lane; k < ROWS*(TILE/N); k += 64) {
+      const int y = k % ROWS;
+      const int bx = k/ROWS;
+      const int base = (r0 + y)*P + bx*N;
+      T in[N];
+      T out[N];
+#pragma unroll
+      for (int c = 0; c < N; c += 4) {
+        const int4 v = *reinterpret_cast<const int4 *>(z + base + c);
+        in[c] = T(v.x);
+        in[c + 1] = T(v.y);
+        in[c + 2] = T(v.z);
+        in[c + 3] = T(v.w);
+      }
+      od_fdct_lift<LN>(out, in);
+#pragma unroll
+      for (int c = 0; c < N; c += 4) {
+        *reinterpret_cast<int4 *>(z + base + c) = make_int4(out[c], out[c + 1], out[c + 2], out[c + 3]);
+      }
+    }
+    /* od_prefilter_split of this level's blocks, column taps (the tile is free) */
+    for (int k = lane; k < TILE*(ROWS/N); k += 64) {
+      const int x = k % TILE;
+      const int by = k/TILE;
+      const int gbx = (x0 + x)/N;
+      if ((gbx + 1)*N <= a.pic_w) lds_filter4<false>(t + (r0 + by*N + N/2 - 2)*P + x, P);
+    }
+    od_wave_sync();
+    if (a.levels[LN]) {
+      od_coeff *plane = a.levels[LN] + plane_off;
+      for (int i = lane; i < ROWS*TILE/4; i += 64) {
+        const int y = r0 + i/(TILE/4);
+        const int x = (i % (TILE/4))*4;
+        *reinterpret_cast<int4 *>(plane + (long)(y0 + y)*a.w + x0 + x) =
+         *reinterpret_cast<const int4 *>(z + y*P + x);
+      }
+    }
+    /* ... and row taps */
+    for (int k = lane; k < ROWS*(TILE/N); k += 64) {
+      const int y = r0 + k % ROWS;
+      const int bx = k/ROWS;
+      const int gby = (y0 + y)/N;
+      if ((gby + 1)*N <= a.pic_h) lds_filter4<false>(t + y*P + bx*N + N/2 - 2, 1);
+    }
+    od_wave_sync();
+    half_level<LN - 1, T>(t, z, a, plane_off, x0, y0, r0, lane);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(128) void k_forward_pyramid_halves(PyramidArgs a) {
+  constexpr int TILE = 64;
+  constexpr int NT = 128;
+  using G = Geo<TILE>;
+  constexpr int P = G::kPitch;
+  __shared__ __attribute__((aligned(16))) short t[G::kHaloWords];
+  __shared__ __attribute__((aligned(16))) int z[TILE*P];
+  const int tid = threadIdx.x;
+  const int x0 = blockIdx.x*TILE;
+  const int y0 = blockIdx.y*TILE;
+  const uint8_t *px = a.px + blockIdx.z*a.px_plane_stride;
+  const long plane_off = (long)blockIdx.z*a.w*a.h;
+  sb_load<TILE, NT>(t, a, px, x0, y0, tid);
+  od_lds_barrier();
+  sb_edge_cols<TILE, NT>(t, a, x0, y0, tid);
+  od_lds_barrier();
+  sb_edge_rows<TILE, NT>(t, a, x0, tid);
+  od_lds_barrier();
+  /* 64-point level: the two waves run the even and the odd half network of every
+     column, then of every row (workgroup barriers inside); its split pre-filter
+     crosses the mid-line between the halves, so one more barrier follows it */
+  pyramid_level_split64<4, T, NT>(t, z, a, plane_off, x0, y0, tid);
+  half_level<3, T>(t, z, a, plane_off, x0, y0, (tid >> 6)*32, tid & 63);
 }
 
 /* ---- inverse ------------------------------------------------------------ */
@@ -982,9 +1127,28 @@ extern "C" int odhip_forward_pyramid(od_coeff *const d_levels[ODHIP_NBSIZES],
   a.pic_h = pic_h;
   const dim3 grid(w/tile, h/tile, nplanes);
   hipStream_t s = (hipStream_t)stream;
-  if (dec) k_forward_pyramid<32><<<grid, Geo<32>::kNT, 0, s>>>(a);
+  /* ODHIP_PYR_VARIANT selects the kernel shapes round 2 measured against each other
+     (tools/pyr_variants.py; all bit-identical): bit 1 = OD_DCT_RSHIFT in two
+     instructions (OdMul24S; default), bit 0 = one luma superblock per 128-thread
+     workgroup instead of two per 256, bit 2 = the same with wave-local levels below
+     64 points (k_forward_pyramid_halves).  16 frames of 1080p: 2 -> 239 us,
+     0 -> 243, 6 -> 245, 3 -> 253, 4 -> 258, 1 -> 259. */
+  static const int variant = getenv("ODHIP_PYR_VARIANT") ? atoi(getenv("ODHIP_PYR_VARIANT")) : 2;
+  if (dec) {
+    if (variant & 2) k_forward_pyramid<32, OdMul24S><<<grid, Geo<32>::kNT, 0, s>>>(a);
+    else k_forward_pyramid<32><<<grid, Geo<32>::kNT, 0, s>>>(a);
+  }
+  else if (variant & 4) {
+    if (variant & 2) k_forward_pyramid_halves<OdMul24S><<<grid, 128, 0, s>>>(a);
+    else k_forward_pyramid_halves<OdMul24><<<grid, 128, 0, s>>>(a);
+  }
+  else if (variant & 1) {
+    if (variant & 2) k_forward_pyramid<64, OdMul24S, 128><<<grid, 128, 0, s>>>(a);
+    else k_forward_pyramid<64, OdMul24, 128><<<grid, 128, 0, s>>>(a);
+  }
   else if ((w/tile) % 2 == 0 && !getenv("ODHIP_PYRAMID_X1")) {
-    k_forward_pyramid64x2<<<dim3(w/(2*tile), h/tile, nplanes), 256, 0, s>>>(a);
+    if (variant & 2) k_forward_pyramid64x2<OdMul24S><<<dim3(w/(2*tile), h/tile, nplanes), 256, 0, s>>>(a);
+    else k_forward_pyramid64x2<OdMul24><<<dim3(w/(2*tile), h/tile, nplanes), 256, 0, s>>>(a);
   }
   else k_forward_pyramid<64><<<grid, Geo<64>::kNT, 0, s>>>(a);
   return odhip_check_launch();

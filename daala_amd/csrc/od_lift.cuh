@@ -40,15 +40,39 @@ struct OdMul24 {
   __device__ __forceinline__ operator int() const { return v; }
 };
 
+/* OdMul24 with OD_DCT_RSHIFT(a, 1) in TWO instructions.  (a + (a < 0)) >> 1 costs
+   v_lshrrev 31 / v_add / v_ashrrev; when |a| < 2^23 the top byte of a is pure sign,
+   so one SDWA subtract of the sign-extended byte 3 (0 or -1) adds the "+1 if
+   negative" and only the shift remains.  The frame pipeline's values peak below
+   2^19 (see above). */
+struct OdMul24S {
+  int v;
+  __device__ __forceinline__ OdMul24S() {}
+  __device__ __forceinline__ OdMul24S(int x) : v(x) {}
+  __device__ __forceinline__ operator int() const { return v; }
+};
+
+__device__ __forceinline__ int od_rs1_sdwa(int a) {
+  int t;
+  asm("v_sub_u32_sdwa %0, %1, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3"
+      : "=v"(t) : "v"(a));
+  return t >> 1;
+}
+
 #define OD_DEF_COEF_OPS(T) \
   __device__ __forceinline__ T operator+(T a, T b) { return T(a.v + b.v); } \
   __device__ __forceinline__ T operator-(T a, T b) { return T(a.v - b.v); } \
   __device__ __forceinline__ T operator-(T a) { return T(-a.v); } \
   __device__ __forceinline__ T &operator+=(T &a, T b) { a.v += b.v; return a; } \
-  __device__ __forceinline__ T &operator-=(T &a, T b) { a.v -= b.v; return a; } \
-  __device__ __forceinline__ T od_rs1(T a) { return T(od_rs1_i32(a.v)); }
+  __device__ __forceinline__ T &operator-=(T &a, T b) { a.v -= b.v; return a; }
+#define OD_DEF_COEF_RS1(T, fn) \
+  __device__ __forceinline__ T od_rs1(T a) { return T(fn(a.v)); }
 OD_DEF_COEF_OPS(OdMul32)
 OD_DEF_COEF_OPS(OdMul24)
+OD_DEF_COEF_OPS(OdMul24S)
+OD_DEF_COEF_RS1(OdMul32, od_rs1_i32)
+OD_DEF_COEF_RS1(OdMul24, od_rs1_i32)
+OD_DEF_COEF_RS1(OdMul24S, od_rs1_sdwa)
 
 /* (a*C + R) >> S with arithmetic shift, the lifting step of src/dct.c. */
 __device__ __forceinline__ OdMul32 od_lift(OdMul32 a, int c, int r, int s) {
@@ -57,6 +81,10 @@ __device__ __forceinline__ OdMul32 od_lift(OdMul32 a, int c, int r, int s) {
 
 __device__ __forceinline__ OdMul24 od_lift(OdMul24 a, int c, int r, int s) {
   return OdMul24((__mul24(a.v, c) + r) >> s);
+}
+
+__device__ __forceinline__ OdMul24S od_lift(OdMul24S a, int c, int r, int s) {
+  return OdMul24S((__mul24(a.v, c) + r) >> s);
 }
 
 #include "gen/od_lifting_gen.h"

@@ -32,6 +32,11 @@ def load_batched_encoder(w, h, device=0):
     if "r" in _state:
         _state["ipo"].odhip_interpose_enable_cache(w, h)
         return _state["r"], _state["ipo"]
+    with open("/proc/self/maps") as f:
+        if "libdaalaref.so" in f.read():
+            # ctypes binds with RTLD_NOW: a reference library loaded earlier has its calls
+            # resolved to its own definitions already and cannot be interposed any more
+            raise RuntimeError("libdaalaref.so was loaded before the interposer in this process")
     os.environ["ODHIP_INTERPOSE_PASSTHROUGH"] = "1"    # per-call surfaces stay the reference's
     hip = ctypes.CDLL(os.path.join(ROOT, "daala_amd", "lib", "libdaalahip.so"), mode=ctypes.RTLD_GLOBAL)
     assert hip.odhip_init(int(device)) == 0

@@ -161,5 +161,9 @@ def test_encoder_example_unmodified_with_libdaalahip_is_byte_identical(tmp_path,
     assert line, err[-1000:]
     calls = [int(v) for v in line[-1].split()[1:]]
     assert all(c > 0 for c in calls), calls
-    assert got == want, "the .ogv written through libdaalahip differs from the plain C one"
+    # every packet and granule position of the container; the raw files differ in the Ogg
+    # stream serial number only when the two runs straddle a second (examples/
+    # encoder_example.c:927-928: srand(time(NULL)); serial = rand())
+    assert ogg_packets(got) == ogg_packets(want), \
+        "the .ogv written through libdaalahip differs from the plain C one"
     assert len(ogg_packets(got)[0]) == 3 + nframes
