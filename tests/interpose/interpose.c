@@ -187,7 +187,19 @@ void odhip_interpose_cache_stats(long *hits, long *misses) {
   odhip_cache_stats(g_cache, hits, misses);
 }
 
+#include <time.h>
+double odhip_interposed_load_ms;   /* wall time spent in the batched GPU pass (incl. PCIe both ways) */
+static void interpose_load_timed(const od_coeff *c, int stride, int nhsb, int nvsb, int xdec);
 static void interpose_load(const od_coeff *c, int stride, int nhsb, int nvsb, int xdec) {
+  struct timespec a;
+  struct timespec b;
+  clock_gettime(CLOCK_MONOTONIC, &a);
+  interpose_load_timed(c, stride, nhsb, nvsb, xdec);
+  clock_gettime(CLOCK_MONOTONIC, &b);
+  odhip_interposed_load_ms += (b.tv_sec - a.tv_sec)*1e3 + (b.tv_nsec - a.tv_nsec)*1e-6;
+}
+
+static void interpose_load_timed(const od_coeff *c, int stride, int nhsb, int nvsb, int xdec) {
   int slot;
   if (!g_cache) return;
   for (slot = 0; slot < g_nbases; slot++) if (g_bases[slot] == c) break;

@@ -69,7 +69,9 @@ if ipo is not None:
     calls = [arr[i] for i in range(6)]
 stats = [0, 0]
 theta = [0, 0, 0, 0]
+gpu_ms = 0.0
 if interpose in (2, 3):
+    gpu_ms = ctypes.c_double.in_dll(ipo, "odhip_interposed_load_ms").value
     hits, misses = ctypes.c_long(), ctypes.c_long()
     ipo.odhip_interpose_cache_stats(ctypes.byref(hits), ctypes.byref(misses))
     stats = [hits.value, misses.value]
@@ -88,5 +90,5 @@ if os.environ.get("PACKET_DIGEST") == "1":
         pos += sizes[i]
     pkt_digest = hh.hexdigest()
 print(json.dumps({"digest": pkt_digest, "packets": hashlib.sha256(bytes(out[:total])).hexdigest(),
-                  "sizes": [sizes[i] for i in range(n)], "calls": calls, "cache": stats, "theta": theta,
+                  "sizes": [sizes[i] for i in range(n)], "calls": calls, "cache": stats, "theta": theta, "gpu_batch_ms": gpu_ms,
                   "encode_seconds": seconds}))

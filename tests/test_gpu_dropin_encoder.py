@@ -156,5 +156,7 @@ def test_batched_band_stage_1080p_frame_byte_identical():
     served, with_ref, other, searches = res[3]["theta"]
     assert served > 50000 and other == 0, res[3]["theta"]
     print("1080p keyframe: %d bands from the batch (%d searches), %d bands with a neighbour "
-          "prediction left to the reference; encode %.2f s vs %.2f s plain C"
-          % (served, searches, with_ref, res[3]["encode_seconds"], res[0]["encode_seconds"]))
+          "prediction left to the reference; encode %.2f s (of which the batched GPU pass incl. PCIe "
+          "both ways %.1f ms) vs %.2f s plain C"
+          % (served, searches, with_ref, res[3]["encode_seconds"], res[3]["gpu_batch_ms"],
+             res[0]["encode_seconds"]))
