@@ -1,54 +1,41 @@
 #!/usr/bin/env python3
 """bench.py - 1080p all-intra transform blocks/s (filter + DCT + PVQ) on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W [--frames F] [--chroma-noref]
+    python bench.py --gpus N --steps K --warmup W [--frames F] [--chroma-noref] [--content natural]
 
 One STEP = one pass of the block-transform hot path over a batch of F synthetic
-1920x1080 4:2:0 frames (coded size 1920x1088) already resident
-in HBM, per GPU:
+1920x1080 4:2:0 frames (coded size 1920x1088) already resident in HBM, per GPU,
+driven by ONE C call (odhip_pipe_step, include/daala_hip.h):
 
-  0. odhip_image_planes_copy_pad   the 1920x1080 pictures -> the padded 1920x1088
-                             planes the encoder codes (od_img_plane_copy_pad)
-  1. odhip_forward_pyramid   pixels -> coefficients, superblock-edge lapping,
-                             and for EVERY block size 64..4 the split
-                             pre-filter + 2-D fDCT of every block (luma 5
-                             levels, chroma 4)
-  2. luma: odhip_pvq_noref_bands_multi   every level: QM scaling, gain, both gain
-                             candidates (K, pruning, K-pulse search, distortion)
-           odhip_pvq_choose_multi        choice, od_gain_expand, synthesis scale
-     chroma: odhip_pvq_ref_bands_multi (+ odhip_pvq_ref_resolve) - pvq_theta WITH
-                             the chroma-from-luma reference, as the reference
-                             encoder codes keyframe chroma: sign flip,
-                             Householder reflection, theta, up to 12 (gain,
-                             theta) candidates + 2 no-reference candidates per
-                             band with chained K-pulse searches
-             odhip_pvq_ref_choose_multi         choice, skip rules, band-wide part of
-                             the synthesis
-  3. for every level: inverse (dequantisation of the chosen pulses while the
-                             tiles are loaded - with and without reference; iDCT,
-                             split post-filters, superblock-edge post-filter,
-                             coefficient -> pixel)
+  luma chain   (own odhip_ctx, stream A)       chroma chain (own odhip_ctx, stream B)
+    od_img_plane_copy_pad                        od_img_plane_copy_pad
+    forward pyramid: 64..4, 5 levels             forward pyramid, 4 levels
+    PVQ band stage, no reference                 [waits for this step's references]
+    choice                                       PVQ band stage WITH the chroma-from-luma
+    chroma-from-luma references ------------>      reference (pvq_theta's theta path)
+    dequantise + inverse, 5 levels               choice, dequantise + inverse, 4 levels
 
 i.e. every block the reference's block-size RDO would evaluate goes through
 prefilter + fDCT + PVQ + dequantisation + iDCT + postfilter exactly once:
-260 610 transform blocks per frame (173 910 luma + 2 x 43 350 chroma).  The
-metric counts those blocks.  Entropy coding / rate pricing stay on the host in
-the reference's own C (SURVEY.md hard part 1) and are not part of the step; the
-choice between PVQ candidates is therefore made on distortion alone.
+260 610 transform blocks per frame (173 910 luma + 2 x 43 350 chroma).  The metric
+counts those blocks.  The two chains are software-pipelined over steps.
 
-The chroma-from-luma reference planes of a step are produced inside the step from
-that step's luma band stage (odhip_cfl_refs_from_luma = od_resample_luma_coeffs,
-src/intra.c:97-108, on the chosen luma candidates); the chroma chain waits for them
-on its own stream while the luma chain of the NEXT step already runs (two reference
-buffers; software pipelining over steps, as a frame-parallel encoder would run).
---chroma-noref runs chroma through the no-reference path instead (the workload of the
-first round-1 bench lines).
+Entropy coding / rate pricing are host state in the reference (SURVEY.md hard part
+1): inside the timed step the choice between PVQ candidates is made on distortion
+alone.  `verified` therefore runs frame 0 of the batch through the SAME GPU stages
+with the host pricing every candidate in between (closed-form od_pvq_rate) and
+compares every reconstructed pixel of every level with the cpu_baseline leg (the
+reference's own C functions); `pipelined_equals_serial` replays the timed pictures
+on one stream and compares every plane and choice record.
 
-N > 1: frames are sharded over ranks (independent all-intra frames, no
-data-path collective) -> weak scaling, F frames per GPU.
+N > 1: frames are sharded over ranks (independent all-intra frames, no data-path
+collective) -> weak scaling, F frames per GPU; `sharded_encode_check` then encodes
+one 1080p frame per rank with the real encoder + the batched GPU stage and gathers
+the packets over RCCL (outside the timed region).
 
-Prints ONE JSON line (rank 0).  `roofline` is for the kernel that dominates the
-step; `kernels` lists every kernel class of the step the same way.
+Prints ONE JSON line (rank 0).  `roofline` is for the kernel with the largest
+exclusive duration (fp64 VALU issue is its roof); `roofline_filter_dct` for the
+filter + DCT stage against HBM; `kernels` lists every stage.
 """
 import argparse
 import ctypes
