@@ -758,6 +758,22 @@ int odhip_cache_band(odhip_frame_cache *c, int pli, int bs, int bx, int by, int 
  const od_coeff *x0, odhip_band_cands *out);
 void odhip_cache_band_stats(const odhip_frame_cache *c, long *hits, long *misses);
 
+/* ---- YUV4MPEG2 input (host; SURVEY.md 8(f) rank 4, input side) ---------------------
+
+   The reference reads its input in examples/encoder_example.c:89-160, :190-400,
+   :449-508.  odhip_y4m_open parses the stream header (W, H, F, I, C tags) of a
+   progressive 8-bit 4:2:0 file (C420, C420jpeg, C420mpeg2, C420paldv or no C tag);
+   anything else - 4:4:4, 4:2:2, 4:1:1, mono, 10..16-bit, interlaced - returns NULL with
+   *err = ODHIP_EIMPL (ODHIP_EINVAL: unreadable / not a YUV4MPEG2 stream).
+   odhip_y4m_read reads one FRAME into tightly packed planes (luma w x h, chroma
+   ((w + 1) >> 1) x ((h + 1) >> 1): what odhip_pipe_set_pictures takes, one picture
+   at a time); returns 1, 0 at the end of the stream, a negative code on loss of
+   framing or a short read. */
+typedef struct odhip_y4m odhip_y4m;
+odhip_y4m *odhip_y4m_open(const char *path, int *pic_w, int *pic_h, int *fps_n, int *fps_d, int *err);
+int odhip_y4m_read(odhip_y4m *y, uint8_t *luma, uint8_t *cb, uint8_t *cr);
+void odhip_y4m_close(odhip_y4m *y);
+
 /* ---- odhip_pipe: the frame-batch step as one C call ------------------------------
 
    One step = one pass of the hot path over `frames` resident 4:2:0 pictures of
