@@ -884,3 +884,27 @@ class Pipe:
         dec = 1 if set_ else 0
         planes = self.frames * (2 if set_ else 1)
         return planes * ((self.W >> dec) // n) * ((self.H >> dec) // n)
+
+
+# ---- od_compute_dist (block-size RDO distortion) ---------------------------------------
+def compute_dist(x, y, bs, use_masking=1, flat_qm=0, coded_quantizer=40):
+    """od_compute_dist of every (4 << bs)-square block of x (source) against y
+    (reconstruction): int32 CUDA tensors [nplanes, h, w].  The device computes everything up
+    to the libm call, the host applies pow (odhip_dist_finish).  Returns (dist float64 numpy
+    [nplanes, h/n, w/n], parts float64 numpy [nplanes, h/8, w/8, 3])."""
+    import torch
+    _need(x, torch.int32, "x")
+    _need(y, torch.int32, "y")
+    assert x.shape == y.shape
+    nplanes, h, w = x.shape
+    n = 4 << bs
+    parts = torch.empty((nplanes, h // 8, w // 8, 3), dtype=torch.float64, device=x.device)
+    _check(lib().odhip_dist_parts(_p(parts), _p(x), _p(y), nplanes, w, h, int(bs), int(use_masking),
+                                  int(flat_qm), _stream()), "odhip_dist_parts")
+    hp = parts.cpu().numpy()
+    dist = np.zeros((nplanes, h // n, w // n), np.float64)
+    _check(lib().odhip_dist_finish(dist.ctypes.data_as(ctypes.c_void_p),
+                                   hp.ctypes.data_as(ctypes.c_void_p), nplanes, w, h, int(bs),
+                                   int(use_masking), int(flat_qm), int(coded_quantizer)),
+           "odhip_dist_finish")
+    return dist, hp

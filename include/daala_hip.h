@@ -674,6 +674,27 @@ int odhip_dering_planes(int16_t *d_y, const int16_t *d_x, int stride, int nhsb, 
  long bskip_plane_stride, const int32_t *d_thresholds, int ncand, int overlap, int coeff_shift,
  odhip_stream stream);
 
+/* ---- od_compute_dist: the block-size RDO's distortion ----------
+
+   od_compute_dist(enc, x, y, n) (src/encode.c:1202-1226, od_compute_dist_8x8
+   :1113-1169, od_compute_var_4x4 :1082-1103) for EVERY n x n block (n = 4 << bs, bs =
+   1..4) of a batch of plane pairs x (source) / y (reconstruction), both od_coeff planes
+   of w x h (multiples of n) in the lapped domain, as the encoder compares them at
+   src/encode.c:1418-1421, :1797-1798.  Split at the libm call:
+     odhip_dist_parts   (device) per 8x8 block three doubles: the sum of the squared
+                        [1 5 1]^2 low-passed error, vardist, and the ARGUMENT of pow
+                        (.25 + var_stat/256) - d_parts [plane][h/8][w/8][3];
+     odhip_dist_finish  (host)   activity = calibration*pow(arg, -1/6) with the host
+                        libm the reference calls, activity^2*(0.92/7^4*sum + vardist), the
+                        sum over the block's 8x8 blocks in raster order and the
+                        coded-quantiser factor: dist [plane][h/n][w/n].
+   use_masking = enc->use_activity_masking, flat_qm = (enc->qm == OD_FLAT_QM: plain
+   squared error), coded_quantizer = state.coded_quantizer. */
+int odhip_dist_parts(double *d_parts, const od_coeff *d_x, const od_coeff *d_y, int nplanes, int w,
+ int h, int bs, int use_masking, int flat_qm, odhip_stream stream);
+int odhip_dist_finish(double *dist, const double *parts, int nplanes, int w, int h, int bs,
+ int use_masking, int flat_qm, int coded_quantizer);
+
 /* ---- input side: padding a picture to the coded frame size ----
 
    od_img_plane_copy_pad (src/encode.c:752-837; daala_image_copy_pad :1896-1909,

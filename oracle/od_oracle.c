@@ -1836,3 +1836,110 @@ long odo_stage_plane(const uint8_t *px, int px_stride, int w, int h, int dec,
   free(c);
   return nblocks;
 }
+
+/* ---- od_compute_dist, src/encode.c:1082-1226 -------------
+   The block-size RDO's distortion between a source block x and a reconstruction y,
+   both n x n in the lapped domain, n = 8..64.  HVS matrices (the default): error
+   low-passed by [1 5 1]/7 in both directions, then per 8x8 block an activity-masked
+   sum of the filtered error energy and a variance-difference term; flat matrices:
+   plain squared error.  libm: sqrt (exact) and pow (host libm, as in the reference). */
+static int odo_var_4x4(const odo_coeff *x, int stride) {   /* :1082-1103 */
+  int sum;
+  int s2;
+  int i;
+  int j;
+  sum = 0;
+  s2 = 0;
+  for (i = 0; i < 4; i++) {
+    for (j = 0; j < 4; j++) {
+      int t;
+      t = x[i*stride + j] >> 2;
+      sum += t;
+      s2 += t*t;
+    }
+  }
+  return s2 - (sum*sum >> 4);
+}
+
+/* The libm-free part of od_compute_dist_8x8 (:1113-1169): parts[0] = sum of squared
+   low-passed error, parts[1] = vardist, parts[2] = the argument of pow. */
+void odo_dist_8x8_parts(double parts[3], const odo_coeff *x, const odo_coeff *y,
+ const odo_coeff *e_lp, int stride, int use_masking) {
+  double sum;
+  double mean_var;
+  double vardist;
+  int min_var;
+  int i;
+  int j;
+  vardist = 0;
+  min_var = 0x7fffffff;
+  mean_var = 0;
+  for (i = 0; i < 3; i++) {
+    for (j = 0; j < 3; j++) {
+      int varx;
+      int vary;
+      varx = odo_var_4x4(x + 2*i*stride + 2*j, stride);
+      vary = odo_var_4x4(y + 2*i*stride + 2*j, stride);
+      min_var = varx < min_var ? varx : min_var;
+      mean_var += 1./(1 + varx);
+      vardist += varx - 2*sqrt(varx*(double)vary) + vary;
+    }
+  }
+  sum = 0;
+  for (i = 0; i < 8; i++) {
+    for (j = 0; j < 8; j++) sum += e_lp[i*stride + j]*(double)e_lp[i*stride + j];
+  }
+  parts[0] = sum;
+  parts[1] = vardist;
+  parts[2] = .25 + (use_masking ? 9./mean_var : (double)min_var)/(1 << 2*4);
+}
+
+static double odo_dist_8x8_finish(const double parts[3], int use_masking) {   /* :1158-1169 */
+  double activity;
+  double sum;
+  activity = (use_masking ? 1.95 : 1.62)*pow(parts[2], -1./6);
+  sum = parts[0]*(0.92/(7*7*7*7));
+  return activity*activity*(sum + parts[1]);
+}
+
+double odo_compute_dist(const odo_coeff *x, const odo_coeff *y, int n, int flat_qm, int use_masking,
+ int coded_quantizer) {
+  static odo_coeff e[64*64];
+  static odo_coeff tmp[64*64];
+  static odo_coeff e_lp[64*64];
+  double sum;
+  int i;
+  int j;
+  sum = 0;
+  if (flat_qm) {
+    for (i = 0; i < n*n; i++) {
+      double t;
+      t = x[i] - y[i];
+      sum += t*t;
+    }
+    return sum;
+  }
+  for (i = 0; i < n*n; i++) e[i] = x[i] - y[i];
+  for (i = 0; i < n; i++) {
+    tmp[i*n] = 5*e[i*n] + 2*e[i*n + 1];
+    tmp[i*n + n - 1] = 5*e[i*n + n - 1] + 2*e[i*n + n - 2];
+    for (j = 1; j < n - 1; j++) tmp[i*n + j] = 5*e[i*n + j] + e[i*n + j - 1] + e[i*n + j + 1];
+  }
+  for (j = 0; j < n; j++) {
+    e_lp[j] = 5*tmp[j] + 2*tmp[n + j];
+    e_lp[(n - 1)*n + j] = 5*tmp[(n - 1)*n + j] + 2*tmp[(n - 2)*n + j];
+  }
+  for (i = 1; i < n - 1; i++) {
+    for (j = 0; j < n; j++) e_lp[i*n + j] = 5*tmp[i*n + j] + tmp[(i - 1)*n + j] + tmp[(i + 1)*n + j];
+  }
+  for (i = 0; i < n; i += 8) {
+    for (j = 0; j < n; j += 8) {
+      double parts[3];
+      odo_dist_8x8_parts(parts, x + i*n + j, y + i*n + j, e_lp + i*n + j, n, use_masking);
+      sum += odo_dist_8x8_finish(parts, use_masking);
+    }
+  }
+  sum *= coded_quantizer >= 47 ? 1.2 : coded_quantizer <= 36 ? 1.7
+   : 1.7 + (1.2 - 1.7)*(coded_quantizer - 36)/(47 - 36);
+  return sum;
+}

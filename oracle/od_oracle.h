@@ -143,4 +143,9 @@ double odo_now(void);
 #ifdef __cplusplus
 }
 #endif
+/* od_compute_dist, src/encode.c:1082-1226 */
+void odo_dist_8x8_parts(double parts[3], const odo_coeff *x, const odo_coeff *y,
+ const odo_coeff *e_lp, int stride, int use_masking);
+double odo_compute_dist(const odo_coeff *x, const odo_coeff *y, int n, int flat_qm, int use_masking,
+ int coded_quantizer);
 #endif
