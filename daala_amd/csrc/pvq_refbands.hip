@@ -770,8 +770,14 @@ __global__ __launch_bounds__(256) void k_refb_scatter(RItems it) {
 }
 
 /* ---- candidate lists -------------------------------------------------------------- */
+/* The list is built in LDS (stage[slot][lane]: the stable insertion walks it
+   backwards) and written to the head plane once, slot by slot - adjacent lanes are
+   adjacent blocks, so every slot is one coalesced 1 KiB store per wavefront.  Round 1
+   inserted directly in the head plane: a read-modify-write chain through HBM per
+   candidate (242 us per 16-frame launch). */
 __device__ __forceinline__ void refb_candidates(const RJob &jb, int band, long blk,
- int theta_override) {
+ int theta_override, int4 (*stage)[kWave]) {
+  const int lane = threadIdx.x;
   odhip_pvq_refband *rp = jb.rec + blk*jb.nb_bands + band;
   odhip_pvq_refband r = *rp;
   if (theta_override >= 0) r.theta = theta_override;
@@ -800,13 +806,13 @@ __device__ __forceinline__ void refb_candidates(const RJob &jb, int band, long b
            (glibc's qsort is a stable merge sort at this size) */
         int pos = nitems;
         while (pos > 0) {
-          const int4 q = ip.head[(pos - 1)*ip.stride];
+          const int4 q = stage[pos - 1][lane];
           const int cmp = q.w == c.w ? q.x - c.x : q.w - c.w;
           if (cmp <= 0) break;
-          ip.head[pos*ip.stride] = q;
+          stage[pos][lane] = q;
           pos--;
         }
-        ip.head[pos*ip.stride] = c;
+        stage[pos][lane] = c;
         nitems++;
       }
     }
@@ -819,11 +825,12 @@ __device__ __forceinline__ void refb_candidates(const RJob &jb, int band, long b
     const int gain_bound = r.cg >> ODQ_CGAIN_SHIFT;
     for (int i = gain_bound > 1 ? gain_bound : 1; i <= gain_bound + 1; i++) {
       const int kk = odq_compute_k_noref(odq_shl32(i, ODQ_CGAIN_SHIFT), n, beta);
-      ip.head[nitems*ip.stride] = make_int4(i, -1, 0, kk);
+      stage[nitems][lane] = make_int4(i, -1, 0, kk);
       kmax_noref = kk > kmax_noref ? kk : kmax_noref;
       nitems++;
     }
   }
+  for (int i = 0; i < nitems; i++) ip.head[i*ip.stride] = stage[i][lane];
   /* third vector of the record: {m, s, flags | theta | nitems | ntheta} */
   int4 v;
   v.x = (int)((uint32_t)(uint16_t)r.m | (uint32_t)(uint8_t)r.s << 16 | (uint32_t)flags << 24);
@@ -839,15 +846,17 @@ __global__ __launch_bounds__(kWave) void k_refb_cands(RItems it) {
   const int item = find_item(it, blockIdx.x);
   const RJob &jb = it.jobs[it.job[item]];
   const long blk = (long)(blockIdx.x - it.wg_start[item])*kWave + threadIdx.x;
+  __shared__ int4 stage[kSlots][kWave];
   if (blk >= jb.nblocks) return;
-  refb_candidates(jb, it.band[item], blk, -1);
+  refb_candidates(jb, it.band[item], blk, -1, stage);
 }
 
 __global__ __launch_bounds__(kWave) void k_refb_cands_list(const RJob *jobs, const Unc *list, int count) {
+  __shared__ int4 stage[kSlots][kWave];
   const int i = blockIdx.x*kWave + threadIdx.x;
   if (i >= count) return;
   const Unc e = list[i];
-  refb_candidates(jobs[e.job], e.band, e.blk, e.theta);
+  refb_candidates(jobs[e.job], e.band, e.blk, e.theta, stage);
 }
 
 /* ---- the candidate loops -----------------------------------------------------------
@@ -1199,29 +1208,54 @@ __global__ __launch_bounds__(kWave) void k_refb_choose(RItems it) {
   int32_t best_qtheta = 0;
   int chosen = -1;
   int yslot = -1;
-  for (int idx = 0; idx < r.nitems; idx++) {
-    const int4 tail = ip.tail[idx*ip.stride];    /* qcg, qtheta, flags, yslot */
+  /* Every candidate's result and tail vector is requested before the first one is
+     looked at (static slots, predicated on the band's candidate count): one exposed
+     memory latency per band instead of one per candidate - the loop was a serial chain
+     of up to fourteen dependent round trips.  The head {gain, theta, ts, k} is read for
+     the winner only. */
+  int4 tails[kSlots];
+  int dlo[kSlots];
+  int dhi[kSlots];
+#pragma unroll
+  for (int idx = 0; idx < kSlots; idx++) {
+    tails[idx] = make_int4(0, 0, 0, -1);
+    dlo[idx] = 0;
+    dhi[idx] = 0;
+    if (idx < r.nitems) {
+      tails[idx] = ip.tail[idx*ip.stride];      /* qcg, qtheta, flags, yslot */
+      const int4 res = ip.res[idx*ip.stride];   /* cos_dist, dist */
+      dlo[idx] = res.z;
+      dhi[idx] = res.w;
+    }
+  }
+#pragma unroll
+  for (int idx = 0; idx < kSlots; idx++) {
+    if (idx >= r.nitems) continue;
+    const int4 tail = tails[idx];
     if (!(tail.z & ODHIP_REFITEM_SEARCHED)) continue;
-    const int4 head = ip.head[idx*ip.stride];    /* gain, theta, ts, k */
-    const int4 res = ip.res[idx*ip.stride];      /* cos_dist, dist */
-    const double cost = __hiloint2double(res.w, res.z) + lambda*(rate ? rate[1 + idx] : 0.);
+    const double cost = __hiloint2double(dhi[idx], dlo[idx]) + lambda*(rate ? rate[1 + idx] : 0.);
     if (idx < r.ntheta ? cost < best_cost : cost <= best_cost) {
       best_cost = cost;
-      qg = head.x;
-      best_k = head.w;
       chosen = idx;
       yslot = tail.w;
       if (idx < r.ntheta) {
         best_qtheta = tail.y;
-        itheta = head.y;
-        max_theta = head.z;
         noref = 0;
       }
-      else {
-        noref = 1;
-        itheta = -1;
-        max_theta = 0;
-      }
+      else noref = 1;
+    }
+  }
+  if (chosen >= 0) {
+    const int4 head = ip.head[chosen*ip.stride];    /* gain, theta, ts, k */
+    qg = head.x;
+    best_k = head.w;
+    if (noref) {
+      itheta = -1;
+      max_theta = 0;
+    }
+    else {
+      itheta = head.y;
+      max_theta = head.z;
     }
   }
   /* :611-622 */
