@@ -15,8 +15,17 @@
 
 namespace {
 
-constexpr int kNT = 256;
 constexpr int kTile = 64;
+
+/* Threads per 64x64 tile: a pass has 64*(64/N) column (row) tasks.  The 64-point passes
+   have 64: one wave per tile (its barriers become wave-local) measured 44.6 % of HBM
+   against 42.2 % with 256 threads; the 32-point level (128 tasks) measured 63 % with 128
+   threads against 65.5 % with 256 and keeps 256.  Both are bound by the per-lane network
+   (1300 dependent-ish operations per 64-point transform), not by idle waves. */
+template <int LN>
+struct DctGeo {
+  static constexpr int kNT = LN == 4 ? 64 : 256;
+};
 
 /* Addressing of a workgroup's 64x64 tile in global memory. */
 struct BatchMap {
@@ -58,6 +67,7 @@ template <int LN, bool INV, typename T, typename InMap, typename OutMap>
 __device__ __forceinline__ void dct2d_tile(od_coeff *out, const od_coeff *in,
  const InMap &imap, const OutMap &omap) {
   constexpr int P = OdTile<kTile>::kPitch;
+  constexpr int kNT = DctGeo<LN>::kNT;
   __shared__ __attribute__((aligned(16))) int tile[OdTile<kTile>::kWords];
   const int tid = threadIdx.x;
   /* Global -> LDS, 16 B per lane, consecutive lanes consecutive addresses
@@ -95,7 +105,7 @@ __device__ __forceinline__ void dct2d_tile(od_coeff *out, const od_coeff *in,
 }
 
 template <int LN, bool INV, typename T>
-__global__ __launch_bounds__(kNT) void k_dct2d_batch(od_coeff *out,
+__global__ __launch_bounds__(DctGeo<LN>::kNT) void k_dct2d_batch(od_coeff *out,
  const od_coeff *in, long nblocks) {
   constexpr int N = 4 << LN;
   constexpr int kPerWg = (kTile/N)*(kTile/N);
@@ -107,7 +117,7 @@ __global__ __launch_bounds__(kNT) void k_dct2d_batch(od_coeff *out,
 }
 
 template <int LN, bool INV, typename T>
-__global__ __launch_bounds__(kNT) void k_dct2d_plane(od_coeff *out,
+__global__ __launch_bounds__(DctGeo<LN>::kNT) void k_dct2d_plane(od_coeff *out,
  int out_stride, const od_coeff *in, int in_stride, int w, int h) {
   constexpr int N = 4 << LN;
   PlaneMap im;
@@ -131,11 +141,11 @@ int launch_batch(int ln, od_coeff *out, const od_coeff *in, long nblocks,
   const long grid = (nblocks + per - 1)/per;
   if (grid > 0x7fffffffL) return ODHIP_EINVAL;
   switch (ln) {
-    case 0: k_dct2d_batch<0, INV, T><<<(unsigned)grid, kNT, 0, s>>>(out, in, nblocks); break;
-    case 1: k_dct2d_batch<1, INV, T><<<(unsigned)grid, kNT, 0, s>>>(out, in, nblocks); break;
-    case 2: k_dct2d_batch<2, INV, T><<<(unsigned)grid, kNT, 0, s>>>(out, in, nblocks); break;
-    case 3: k_dct2d_batch<3, INV, T><<<(unsigned)grid, kNT, 0, s>>>(out, in, nblocks); break;
-    case 4: k_dct2d_batch<4, INV, T><<<(unsigned)grid, kNT, 0, s>>>(out, in, nblocks); break;
+    case 0: k_dct2d_batch<0, INV, T><<<(unsigned)grid, DctGeo<0>::kNT, 0, s>>>(out, in, nblocks); break;
+    case 1: k_dct2d_batch<1, INV, T><<<(unsigned)grid, DctGeo<1>::kNT, 0, s>>>(out, in, nblocks); break;
+    case 2: k_dct2d_batch<2, INV, T><<<(unsigned)grid, DctGeo<2>::kNT, 0, s>>>(out, in, nblocks); break;
+    case 3: k_dct2d_batch<3, INV, T><<<(unsigned)grid, DctGeo<3>::kNT, 0, s>>>(out, in, nblocks); break;
+    case 4: k_dct2d_batch<4, INV, T><<<(unsigned)grid, DctGeo<4>::kNT, 0, s>>>(out, in, nblocks); break;
     default: return ODHIP_EINVAL;
   }
   return odhip_check_launch();
@@ -150,11 +160,11 @@ int launch_plane(int ln, od_coeff *out, int out_stride, const od_coeff *in,
   }
   const dim3 grid((w + kTile - 1)/kTile, (h + kTile - 1)/kTile);
   switch (ln) {
-    case 0: k_dct2d_plane<0, INV, T><<<grid, kNT, 0, s>>>(out, out_stride, in, in_stride, w, h); break;
-    case 1: k_dct2d_plane<1, INV, T><<<grid, kNT, 0, s>>>(out, out_stride, in, in_stride, w, h); break;
-    case 2: k_dct2d_plane<2, INV, T><<<grid, kNT, 0, s>>>(out, out_stride, in, in_stride, w, h); break;
-    case 3: k_dct2d_plane<3, INV, T><<<grid, kNT, 0, s>>>(out, out_stride, in, in_stride, w, h); break;
-    case 4: k_dct2d_plane<4, INV, T><<<grid, kNT, 0, s>>>(out, out_stride, in, in_stride, w, h); break;
+    case 0: k_dct2d_plane<0, INV, T><<<grid, DctGeo<0>::kNT, 0, s>>>(out, out_stride, in, in_stride, w, h); break;
+    case 1: k_dct2d_plane<1, INV, T><<<grid, DctGeo<1>::kNT, 0, s>>>(out, out_stride, in, in_stride, w, h); break;
+    case 2: k_dct2d_plane<2, INV, T><<<grid, DctGeo<2>::kNT, 0, s>>>(out, out_stride, in, in_stride, w, h); break;
+    case 3: k_dct2d_plane<3, INV, T><<<grid, DctGeo<3>::kNT, 0, s>>>(out, out_stride, in, in_stride, w, h); break;
+    case 4: k_dct2d_plane<4, INV, T><<<grid, DctGeo<4>::kNT, 0, s>>>(out, out_stride, in, in_stride, w, h); break;
     default: return ODHIP_EINVAL;
   }
   return odhip_check_launch();

@@ -13,7 +13,7 @@ for extra in "" "--frames 8"; do
 import json,os
 p=os.path.join(os.environ["GRAFT_REPO_ROOT"],"gpurun_out/quick/b.json")
 d=json.loads(open(p).read().strip().splitlines()[-1])
-print({k:d[k] for k in ("value","ms_per_step","host_launch_ms_per_step","host_wait_ms_total","pipelined_equals_serial")})
+print({k:d[k] for k in ("value","ms_per_step","host_launch_ms_per_step","host_wait_ms_per_step","pipelined_equals_serial")})
 print("filter_dct", d["roofline_filter_dct"]["avg_ms_per_launch"], d["roofline_filter_dct"]["frac"])
 print("roof", d["roofline"]["kernel"][:24], d["roofline"]["frac"], d["roofline"]["avg_ms_per_launch"])
 print(" ".join("%s=%.3f/%.3f" % (k[:18], v["avg_ms_per_launch"], v.get("exclusive_avg_ms",0)) for k,v in d["kernels"].items()))
