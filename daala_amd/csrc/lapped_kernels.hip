@@ -849,6 +849,181 @@ __device__ __forceinline__ void inverse_load_ref(int *t, const InverseArgs &a, i
   }
 }
 
+/* Everything but the 2-sample strips along interior superblock edges is final after
+   the tile's own post-filters: convert and store it (the strips are stored too and
+   overwritten by k_edge_rows / k_edge_cols).  The strips go out as od_coeff so that the
+   edge post-filter, which couples neighbouring superblocks, can run on them: 4 B read
+   + 1 B written per pixel plus ~12 % for the strips, instead of an int32 round trip of
+   the whole plane. */
+template <int TILE>
+__device__ __forceinline__ void inverse_store(const int *t, const InverseArgs &a, int plane, int x0,
+ int y0, int tid) {
+  constexpr int P = Geo<TILE>::kPitch;
+  constexpr int NT = Geo<TILE>::kNT;
+  const int w = a.w;
+  const int h = a.h;
+  uint8_t *px = a.px + plane*a.px_plane_stride;
+  for (int i = tid; i < TILE*TILE/4; i += NT) {
+    const int y = i/(TILE/4);
+    const int x = (i % (TILE/4))*4;
+    const int4 v = *reinterpret_cast<const int4 *>(t + y*P + x);
+    uchar4 o;
+    o.x = od_to_px(v.x);
+    o.y = od_to_px(v.y);
+    o.z = od_to_px(v.z);
+    o.w = od_to_px(v.w);
+    *reinterpret_cast<uchar4 *>(px + (long)(y0 + y)*a.px_stride + x0 + x) = o;
+  }
+  const int nv = w/TILE - 1;
+  const int nh = h/TILE - 1;
+  const int sbx = blockIdx.x;
+  const int sby = blockIdx.y;
+  od_coeff *vs = a.vs + (long)plane*nv*h*4;
+  od_coeff *hs = a.hs + (long)plane*nh*4*w;
+  for (int i = tid; i < 2*TILE; i += NT) {
+    const int right = i/TILE;
+    const int r = i % TILE;
+    if (right ? sbx < nv : sbx > 0) {
+      const int e = right ? sbx : sbx - 1;
+      const int c = right ? TILE - 2 : 0;
+      int2 v;
+      v.x = t[r*P + c];
+      v.y = t[r*P + c + 1];
+      *reinterpret_cast<int2 *>(vs + ((long)e*h + y0 + r)*4 + (right ? 0 : 2)) = v;
+    }
+  }
+  for (int i = tid; i < 4*TILE; i += NT) {
+    const int k = i/TILE;          /* 0,1: top rows 0,1; 2,3: bottom rows TILE-2, TILE-1 */
+    const int c = i % TILE;
+    const bool bottom = k >= 2;
+    if (bottom ? sby < nh : sby > 0) {
+      const int e = bottom ? sby : sby - 1;
+      const int r = bottom ? TILE - 4 + k : k;
+      hs[((long)e*4 + (bottom ? k - 2 : k + 2))*w + x0 + c] = t[r*P + c];
+    }
+  }
+}
+
+/* ---- inverse at an ARBITRARY partition (the decoder's reconstruction) ----------------
+   The block-size map of od_state (bsize, one entry per 8x8 luma area: 0 = four 4x4
+   blocks, 1 = 8x8, ... 4 = 64x64; src/state.h:250-259, OD_BLOCK_SIZE4x4
+   src/block_size.h:32-35) says where od_decode_recursive / od_encode_recursive
+   (src/decode.c:603-660, src/encode.c:1657-1810) stopped splitting.  The recursion is
+   replayed level by level inside the tile: at level L the blocks that are LEAVES of
+   size L are inverse-transformed, then the nodes of size L that were SPLIT get their
+   od_postfilter_split (their subtrees are complete: every level below ran first;
+   regions of different nodes are disjoint, so the order between them is free).  A
+   chroma plane of a 4:2:0 frame codes the block of a luma block one size down, 4x4 for
+   both 8x8 and 4x4 luma (bs = OD_MAXI(obs, xdec) - xdec, src/encode.c:1674-1680). */
+struct PartLeaf {
+  const unsigned char *map;   /* LDS: leaf level per 8x8-luma unit of the tile, 8 per row */
+  int level;
+  int dec;
+  /* block (bx, by) of size 4 << level, in block units of the tile */
+  __device__ __forceinline__ int at(int bx, int by) const {
+    const int u = (4 << level) >> (3 - dec);     /* map units per block side (0 for 4x4 luma) */
+    return u ? map[(by*u)*8 + bx*u] : map[(by >> 1)*8 + (bx >> 1)];
+  }
+};
+struct PartIsLeaf : PartLeaf {
+  __device__ __forceinline__ bool operator()(int bx, int by) const { return at(bx, by) == level; }
+};
+
+template <int TILE, int LN, bool INV, typename Pred>
+__device__ __forceinline__ void split_filter_cols_if(int *t, int tid, int x0, int pic_w, Pred split) {
+  constexpr int N = 4 << LN;
+  constexpr int P = Geo<TILE>::kPitch;
+  constexpr int NT = Geo<TILE>::kNT;
+  for (int k = tid; k < TILE*(TILE/N); k += NT) {
+    const int x = k % TILE;
+    const int by = k / TILE;
+    const int gbx = (x0 + x)/N;
+    if (split(x/N, by) && (gbx + 1)*N <= pic_w) lds_filter4<INV>(t + (by*N + N/2 - 2)*P + x, P);
+  }
+}
+
+template <int TILE, int LN, bool INV, typename Pred>
+__device__ __forceinline__ void split_filter_rows_if(int *t, int tid, int y0, int pic_h, Pred split) {
+  constexpr int N = 4 << LN;
+  constexpr int P = Geo<TILE>::kPitch;
+  constexpr int NT = Geo<TILE>::kNT;
+  for (int k = tid; k < TILE*(TILE/N); k += NT) {
+    const int y = k % TILE;
+    const int bx = k / TILE;
+    const int gby = (y0 + y)/N;
+    if (split(bx, y/N) && (gby + 1)*N <= pic_h) lds_filter4<INV>(t + y*P + bx*N + N/2 - 2, 1);
+  }
+}
+
+template <int TILE, int LN>
+__device__ __forceinline__ void inverse_part_levels(int *t, const unsigned char *map, const InverseArgs &a,
+ int x0, int y0, int tid) {
+  using T = OdMul24;
+  constexpr int NT = Geo<TILE>::kNT;
+  constexpr int TOP = TILE == 64 ? 4 : 3;
+  constexpr int DEC = TILE == 64 ? 0 : 1;
+  PartIsLeaf leaf;
+  leaf.map = map;
+  leaf.level = LN;
+  leaf.dec = DEC;
+  od_tile_rows<TILE, LN, true, T, NT>(t, t, tid, leaf);
+  __syncthreads();
+  od_tile_cols<TILE, LN, true, T, NT>(t, t, tid, leaf);
+  __syncthreads();
+  if constexpr (LN >= 1) {
+    /* od_postfilter_split of the nodes of this size that were split (src/filter.c:
+       1510-1525: rows first, then columns) */
+    const PartLeaf node = leaf;
+    auto split = [&](int bx, int by) { return node.at(bx, by) < LN; };
+    split_filter_rows_if<TILE, LN, true>(t, tid, y0, a.pic_h, split);
+    __syncthreads();
+    split_filter_cols_if<TILE, LN, true>(t, tid, x0, a.pic_w, split);
+    __syncthreads();
+  }
+  if constexpr (LN < TOP) inverse_part_levels<TILE, LN + 1>(t, map, a, x0, y0, tid);
+}
+
+struct InversePartArgs {
+  InverseArgs a;
+  const unsigned char *bsize;    /* frame f's map at bsize + f*bsize_frame_stride */
+  int bstride;
+  long bsize_frame_stride;
+  int planes_per_frame;          /* consecutive planes that share one map */
+  int nplanes;
+};
+
+template <int TILE>
+__global__ __launch_bounds__(Geo<TILE>::kNT) void k_inverse_part(InversePartArgs pa) {
+  using G = Geo<TILE>;
+  constexpr int P = G::kPitch;
+  constexpr int NT = G::kNT;
+  constexpr int DEC = TILE == 64 ? 0 : 1;
+  __shared__ __attribute__((aligned(16))) int t[TILE*P];
+  __shared__ unsigned char map[64];
+  const InverseArgs &a = pa.a;
+  const int tid = threadIdx.x;
+  const int x0 = blockIdx.x*TILE;
+  const int y0 = blockIdx.y*TILE;
+  const int plane = blockIdx.z;
+  const long plane_off = (long)plane*a.w*a.h;
+  if (tid < 64) {
+    const unsigned char *bs = pa.bsize + (plane/pa.planes_per_frame)*pa.bsize_frame_stride
+     + (long)(blockIdx.y*8 + (tid >> 3))*pa.bstride + blockIdx.x*8 + (tid & 7);
+    int v = *bs;
+    if (DEC) v = (v > 1 ? v : 1) - 1;      /* the chroma block of that luma block */
+    map[tid] = (unsigned char)v;
+  }
+  for (int i = tid; i < TILE*TILE/4; i += NT) {
+    const int y = i/(TILE/4);
+    const int x = (i % (TILE/4))*4;
+    *reinterpret_cast<int4 *>(t + y*P + x) =
+     *reinterpret_cast<const int4 *>(a.coef + plane_off + (long)(y0 + y)*a.w + x0 + x);
+  }
+  __syncthreads();
+  inverse_part_levels<TILE, 0>(t, map, a, x0, y0, tid);
+  inverse_store<TILE>(t, a, plane, x0, y0, tid);
+}
+
 template <int TILE, bool REF = false>
 __global__ __launch_bounds__(Geo<TILE>::kNT) void k_inverse_sb(InverseArgsMulti mm) {
   using G = Geo<TILE>;
@@ -969,54 +1144,7 @@ __global__ __launch_bounds__(Geo<TILE>::kNT) void k_inverse_sb(InverseArgsMulti 
       break;
   }
   inverse_split_levels<TILE, 1>(t, a, x0, y0, tid);
-  /* Everything but the 2-sample strips along interior superblock edges is
-     final: convert and store it (the strips are stored too and overwritten by
-     k_edge_rows / k_edge_cols).  The strips go out as od_coeff so that the
-     edge post-filter, which couples neighbouring superblocks, can run on them:
-     4 B read + 1 B written per pixel plus ~12 % for the strips, instead of an
-     int32 round trip of the whole plane. */
-  const int w = a.w;
-  const int h = a.h;
-  uint8_t *px = a.px + plane*a.px_plane_stride;
-  for (int i = tid; i < TILE*TILE/4; i += NT) {
-    const int y = i/(TILE/4);
-    const int x = (i % (TILE/4))*4;
-    const int4 v = *reinterpret_cast<const int4 *>(t + y*P + x);
-    uchar4 o;
-    o.x = od_to_px(v.x);
-    o.y = od_to_px(v.y);
-    o.z = od_to_px(v.z);
-    o.w = od_to_px(v.w);
-    *reinterpret_cast<uchar4 *>(px + (long)(y0 + y)*a.px_stride + x0 + x) = o;
-  }
-  const int nv = w/TILE - 1;
-  const int nh = h/TILE - 1;
-  const int sbx = blockIdx.x;
-  const int sby = blockIdx.y;
-  od_coeff *vs = a.vs + (long)plane*nv*h*4;
-  od_coeff *hs = a.hs + (long)plane*nh*4*w;
-  for (int i = tid; i < 2*TILE; i += NT) {
-    const int right = i/TILE;
-    const int r = i % TILE;
-    if (right ? sbx < nv : sbx > 0) {
-      const int e = right ? sbx : sbx - 1;
-      const int c = right ? TILE - 2 : 0;
-      int2 v;
-      v.x = t[r*P + c];
-      v.y = t[r*P + c + 1];
-      *reinterpret_cast<int2 *>(vs + ((long)e*h + y0 + r)*4 + (right ? 0 : 2)) = v;
-    }
-  }
-  for (int i = tid; i < 4*TILE; i += NT) {
-    const int k = i/TILE;          /* 0,1: top rows 0,1; 2,3: bottom rows TILE-2, TILE-1 */
-    const int c = i % TILE;
-    const bool bottom = k >= 2;
-    if (bottom ? sby < nh : sby > 0) {
-      const int e = bottom ? sby : sby - 1;
-      const int r = bottom ? TILE - 4 + k : k;
-      hs[((long)e*4 + (bottom ? k - 2 : k + 2))*w + x0 + c] = t[r*P + c];
-    }
-  }
+  inverse_store<TILE>(t, a, plane, x0, y0, tid);
 }
 
 struct EdgeArgs {
@@ -1236,6 +1364,74 @@ int upload_inv_tables(void) {
 }
 
 }  // namespace
+
+/* The decoder's reconstruction of a batch of frames at their own partitions:
+   od_decode_recursive's idct_2d + od_postfilter_split (src/decode.c:482-660), then
+   od_apply_postfilter_frame_sbs and od_coeff_to_ref_plane (src/decode.c:988-996,
+   src/state.c:1281-1345), from the dequantised coefficient planes and the block-size
+   map. */
+extern "C" int odhip_inverse_partition(uint8_t *d_px, int px_stride, long px_plane_stride,
+ const od_coeff *d_coef, int nplanes, int w, int h, int dec, const uint8_t *d_bsize, int bstride,
+ long bsize_frame_stride, int planes_per_frame, int pic_w, int pic_h, odhip_stream stream) {
+  if (!d_px || !d_coef || !d_bsize || nplanes <= 0 || planes_per_frame <= 0 || (dec != 0 && dec != 1)) {
+    return ODHIP_EINVAL;
+  }
+  const int tile = 64 >> dec;
+  if (w <= 0 || h <= 0 || w % tile || h % tile || (px_stride & 3) || (px_plane_stride & 3)
+   || bstride < (w/tile)*8 || ((uintptr_t)d_coef & 15)) {
+    return ODHIP_EINVAL;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  const int nv = w/tile - 1;
+  const int nh = h/tile - 1;
+  const size_t vs_words = ((size_t)nplanes*nv*h*4 + 3) & ~(size_t)3;
+  const size_t hs_words = ((size_t)nplanes*nh*4*w + 3) & ~(size_t)3;
+  const size_t need = (vs_words + hs_words + 4)*sizeof(od_coeff);
+  ODHIP_CTX_OR_RETURN(ctx);
+  LappedState &st = *odhip_ctx_state<LappedState>(ctx, ODHIP_SLOT_LAPPED);
+  if (need > st.bytes) {
+    ODHIP_TRY(hipStreamSynchronize(s));
+    if (st.strips) ODHIP_TRY(hipFree(st.strips));
+    st.strips = nullptr;
+    st.bytes = 0;
+    ODHIP_TRY(hipMalloc((void **)&st.strips, need));
+    st.bytes = need;
+  }
+  InversePartArgs pa;
+  memset(&pa, 0, sizeof(pa));
+  pa.a.coef = d_coef;
+  pa.a.px = d_px;
+  pa.a.px_stride = px_stride;
+  pa.a.px_plane_stride = px_plane_stride;
+  pa.a.w = w;
+  pa.a.h = h;
+  pa.a.pic_w = pic_w;
+  pa.a.pic_h = pic_h;
+  pa.a.vs = st.strips;
+  pa.a.hs = st.strips + vs_words;
+  pa.bsize = d_bsize;
+  pa.bstride = bstride;
+  pa.bsize_frame_stride = bsize_frame_stride;
+  pa.planes_per_frame = planes_per_frame;
+  pa.nplanes = nplanes;
+  EdgeArgsMulti em;
+  memset(&em, 0, sizeof(em));
+  em.nplanes = nplanes;
+  em.a[0].vs = pa.a.vs;
+  em.a[0].hs = pa.a.hs;
+  em.a[0].px = d_px;
+  em.a[0].px_stride = px_stride;
+  em.a[0].px_plane_stride = px_plane_stride;
+  em.a[0].w = w;
+  em.a[0].h = h;
+  em.a[0].tile = tile;
+  const dim3 grid(w/tile, h/tile, nplanes);
+  if (dec) k_inverse_part<32><<<grid, Geo<32>::kNT, 0, s>>>(pa);
+  else k_inverse_part<64><<<grid, Geo<64>::kNT, 0, s>>>(pa);
+  if (nv > 0) k_edge_rows<<<dim3((h + 255)/256, nv, nplanes), 256, 0, s>>>(em);
+  if (nh > 0) k_edge_cols<<<dim3((w + 255)/256, nh, nplanes), 256, 0, s>>>(em);
+  return odhip_check_launch();
+}
 
 extern "C" int odhip_inverse_level(uint8_t *d_px, int px_stride, long px_plane_stride,
  const od_coeff *d_coef, int nplanes, int w, int h, int dec, int leaf_bs,

@@ -311,4 +311,33 @@ double od_pvq_search_rdo_double_hip(const int16_t *xcoeff, int n, int k,
   return *(double *)(host + off_cos);
 }
 
+/* Host-pointer form of odhip_inverse_partition for one plane (the decoder-side check
+   of tests/interpose: the reference decoder's dtmp plane and bsize map in, pixels
+   out): stages through device scratch, synchronous. */
+int odhip_inverse_partition_host(uint8_t *px, int px_stride, const od_coeff *coef, int w, int h, int dec,
+ const uint8_t *bsize, int bstride, int pic_w, int pic_h) {
+  if (!px || !coef || !bsize || w <= 0 || h <= 0 || (dec != 0 && dec != 1) || px_stride < w) {
+    return ODHIP_EINVAL;
+  }
+  const int tile = 64 >> dec;
+  if (w % tile || h % tile) return ODHIP_EINVAL;
+  Scratch &s = g_scratch;
+  const size_t cbytes = (size_t)w*h*sizeof(od_coeff);
+  const int mrows = (h/tile)*8;
+  const int mcols = (w/tile)*8;
+  const size_t mbytes = (size_t)mrows*mcols;
+  /* buffer 0: coefficients, then the compact map; buffer 1: pixels */
+  char *d0 = (char *)s.get(0, cbytes + mbytes + 16);
+  uint8_t *d_px = (uint8_t *)s.get(1, (size_t)w*h);
+  HIP_OR_DIE(hipMemcpyAsync(d0, coef, cbytes, hipMemcpyHostToDevice, s.stream));
+  HIP_OR_DIE(hipMemcpy2DAsync(d0 + cbytes, mcols, bsize, bstride, mcols, mrows, hipMemcpyHostToDevice,
+   s.stream));
+  const int rc = odhip_inverse_partition(d_px, w, (long)w*h, (const od_coeff *)d0, 1, w, h, dec,
+   (const uint8_t *)(d0 + cbytes), mcols, 0, 1, pic_w, pic_h, s.stream);
+  if (rc) return rc;
+  HIP_OR_DIE(hipMemcpy2DAsync(px, px_stride, d_px, w, w, h, hipMemcpyDeviceToHost, s.stream));
+  HIP_OR_DIE(hipStreamSynchronize(s.stream));
+  return ODHIP_SUCCESS;
+}
+
 }  /* extern "C" */

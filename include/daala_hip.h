@@ -263,6 +263,25 @@ int odhip_inverse_levels(uint8_t *const *d_px, int px_stride, long px_plane_stri
  const od_coeff *const *d_coef, const int *leaf_bs, int nlevels, int nplanes, int w, int h,
  int dec, int pic_w, int pic_h, odhip_stream stream);
 
+/* Inverse at an ARBITRARY partition: the decoder's reconstruction of nplanes planes
+   from their dequantised coefficient planes (d_coef, layout as above) and the
+   block-size map of their frames: idct_2d of every leaf block, od_postfilter_split of
+   every split node (od_decode_recursive, src/decode.c:603-660; the encoder's final pass
+   src/encode.c:1657-1810 is the same), od_apply_postfilter_frame_sbs, od_coeff_to_ref_plane.
+   d_bsize: od_state.bsize (src/state.h:250-259) - one byte per 8x8 LUMA area, 0 = four
+   4x4 blocks ... 4 = one 64x64 block, rows of bstride bytes, origin at the frame's
+   first superblock (the reference's pointer already skips its one-superblock border);
+   plane p uses the map at d_bsize + (p / planes_per_frame)*bsize_frame_stride (luma:
+   planes_per_frame = 1; 4:2:0 chroma with Cb and Cr of a frame adjacent: 2).  dec = 1
+   derives the chroma blocks (one size down, 4x4 for 8x8 and 4x4 luma). */
+int odhip_inverse_partition(uint8_t *d_px, int px_stride, long px_plane_stride,
+ const od_coeff *d_coef, int nplanes, int w, int h, int dec, const uint8_t *d_bsize, int bstride,
+ long bsize_frame_stride, int planes_per_frame, int pic_w, int pic_h, odhip_stream stream);
+/* The same for ONE plane with host pointers (synchronous; staging through device
+   scratch): coef = the decoder's state.dtmp[pli] (stride w), bsize = state.bsize. */
+int odhip_inverse_partition_host(uint8_t *px, int px_stride, const od_coeff *coef, int w, int h, int dec,
+ const uint8_t *bsize, int bstride, int pic_w, int pic_h);
+
 /* Batched pvq_search_rdo_double: band b has d_x[b*n .. b*n+n) int16,
    d_k[b], d_g2[b], optional d_prev_k[b] (NULL = 0; when > 0 d_y holds the
    previous pulses), writes d_y[b*n ..) and d_cos[b].  n <= 128; 0 <= k <= 65535

@@ -493,3 +493,134 @@ REF_EXPORT int ref_image_copy_pad(const unsigned char *frame, int w, int h,
   daala_encode_free(enc);
   return 0;
 }
+
+/* ---- decoder side ------------------------------------------------------------------
+   ref_roundtrip_yuv420: encodes like ref_encode_yuv420 but keeps the three header
+   packets, then feeds headers and data packets to the REAL reference decoder
+   (daala_decode_header_in / _create / _packet_in / _img_out, include/daala/daaladec.h)
+   and copies every decoded picture (planar 4:2:0, tightly packed) to decoded[].
+   Returns the number of decoded frames or a negative code.  The GPU decode check
+   (tests/interpose's od_apply_postfilter_frame_sbs inside the decoder) rides on it. */
+#include "daala/daaladec.h"
+REF_EXPORT int ref_roundtrip_yuv420(const unsigned char *frames, int w, int h, int nframes,
+ int quality, int complexity, unsigned char *decoded) {
+  daala_info di;
+  daala_info di2;
+  daala_comment dc;
+  daala_comment dc2;
+  daala_setup_info *ds;
+  daala_enc_ctx *enc;
+  daala_dec_ctx *dec;
+  daala_packet dp;
+  daala_image img;
+  daala_image out;
+  long frame_bytes;
+  int ndecoded;
+  int f;
+  int ret;
+  int pli;
+  daala_info_init(&di);
+  di.pic_width = w;
+  di.pic_height = h;
+  di.bitdepth_mode = OD_BITDEPTH_MODE_8;
+  di.timebase_numerator = 30;
+  di.timebase_denominator = 1;
+  di.frame_duration = 1;
+  di.pixel_aspect_numerator = 1;
+  di.pixel_aspect_denominator = 1;
+  di.nplanes = 3;
+  di.plane_info[0].xdec = di.plane_info[0].ydec = 0;
+  di.plane_info[1].xdec = di.plane_info[1].ydec = 1;
+  di.plane_info[2].xdec = di.plane_info[2].ydec = 1;
+  di.keyframe_rate = 1;
+  enc = daala_encode_create(&di);
+  if (enc == NULL) return -1;
+  daala_comment_init(&dc);
+  daala_encode_ctl(enc, OD_SET_QUANT, &quality, sizeof(quality));
+  daala_encode_ctl(enc, OD_SET_COMPLEXITY, &complexity, sizeof(complexity));
+  daala_info_init(&di2);
+  daala_comment_init(&dc2);
+  ds = NULL;
+  dec = NULL;
+  for (;;) {
+    ret = daala_encode_flush_header(enc, &dc, &dp);
+    if (ret < 0) return ret;
+    if (ret == 0) break;
+    ret = daala_decode_header_in(&di2, &dc2, &ds, &dp);
+    if (ret < 0) return ret;
+  }
+  dec = daala_decode_create(&di2, ds);
+  if (dec == NULL) return -3;
+  memset(&img, 0, sizeof(img));
+  img.nplanes = 3;
+  img.width = w;
+  img.height = h;
+  frame_bytes = (long)w*h + 2L*((w + 1) >> 1)*((h + 1) >> 1);
+  ndecoded = 0;
+  for (f = 0; f <= nframes; f++) {
+    int last;
+    last = f == nframes;
+    while (daala_encode_packet_out(enc, last, &dp)) {
+      ret = daala_decode_packet_in(dec, &dp);
+      if (ret < 0) return ret;
+      while (daala_decode_img_out(dec, &out) > 0) {
+        unsigned char *dst;
+        dst = decoded + ndecoded*frame_bytes;
+        for (pli = 0; pli < 3; pli++) {
+          int pw;
+          int ph;
+          int y;
+          pw = (w + out.planes[pli].xdec) >> out.planes[pli].xdec;
+          ph = (h + out.planes[pli].ydec) >> out.planes[pli].ydec;
+          for (y = 0; y < ph; y++) {
+            memcpy(dst + y*pw, out.planes[pli].data + (long)y*out.planes[pli].ystride, pw);
+          }
+          dst += (long)pw*ph;
+        }
+        ndecoded++;
+      }
+    }
+    if (!last) {
+      unsigned char *base;
+      base = (unsigned char *)frames + f*frame_bytes;
+      for (pli = 0; pli < 3; pli++) {
+        img.planes[pli].xdec = img.planes[pli].ydec = pli > 0;
+        img.planes[pli].xstride = 1;
+        img.planes[pli].ystride = pli ? (w + 1) >> 1 : w;
+        img.planes[pli].bitdepth = 8;
+      }
+      img.planes[0].data = base;
+      img.planes[1].data = base + (long)w*h;
+      img.planes[2].data = img.planes[1].data + (long)((w + 1) >> 1)*((h + 1) >> 1);
+      ret = daala_encode_img_in(enc, &img, 0);
+      if (ret < 0) return ret;
+    }
+  }
+  daala_setup_free(ds);
+  daala_decode_free(dec);
+  daala_comment_clear(&dc);
+  daala_comment_clear(&dc2);
+  daala_encode_free(enc);
+  return ndecoded;
+}
+
+/* What a reconstruction check needs from an od_state (the first member of both
+   daala_enc_ctx and daala_dec_ctx): which plane a ctmp pointer is, that plane's
+   dequantised coefficients, the block-size map and the geometry. */
+REF_EXPORT int ref_state_recon_view(void *statep, const od_coeff *c, const od_coeff **d,
+ const unsigned char **bsize, int *bstride, int *pic_w, int *pic_h) {
+  od_state *state;
+  int pli;
+  state = (od_state *)statep;
+  for (pli = 0; pli < state->info.nplanes; pli++) {
+    if (state->ctmp[pli] == c) {
+      *d = state->dtmp[pli];
+      *bsize = state->bsize;
+      *bstride = state->bstride;
+      *pic_w = state->info.pic_width;
+      *pic_h = state->info.pic_height;
+      return pli;
+    }
+  }
+  return -1;
+}

@@ -136,9 +136,83 @@ void od_apply_prefilter_frame_sbs(od_coeff *c, int stride, int nhsb, int nvsb, i
   od_apply_prefilter_frame_sbs_hip(c, stride, nhsb, nvsb, xdec, ydec);
 }
 
+/* ---- mode 4: GPU decode check -------------------------------------------------------
+   Inside the REAL reference decoder, at the moment it has decoded every block of a frame
+   (state.dtmp = the dequantised coefficients, state.bsize = the partition, state.ctmp =
+   its own block-by-block reconstruction) and is about to lap across superblock edges
+   (src/decode.c:988-996): odhip_inverse_partition reconstructs the plane from dtmp and
+   bsize alone, the reference finishes its own (od_apply_postfilter_frame_sbs, then the
+   pixel conversion of od_coeff_to_ref_buf, src/state.c:1296-1304, applied here to its
+   coefficients), and the two planes of pixels must be identical. */
+static void *g_dec;
+static int g_decode_check;
+long odhip_interposed_decode[3];     /* planes checked, pixels compared, pixels that differ */
+
+void odhip_interpose_enable_decode_check(void) {
+  g_decode_check = 1;
+}
+
+int daala_decode_packet_in(void *dec, const void *dp) {
+  typedef int (*fn)(void *, const void *);
+  static fn next;
+  if (!next) next = NEXT(fn, "daala_decode_packet_in");
+  g_dec = dec;
+  return next(dec, dp);
+}
+
+static int interpose_decode_check(od_coeff *c, int stride, int nhsb, int nvsb, int xdec,
+ void (*reference)(od_coeff *, int, int, int, int, int, int, unsigned char *, int), int ydec, int q,
+ unsigned char *skip, int skip_stride) {
+  typedef int (*view_fn)(void *, const od_coeff *, const od_coeff **, const unsigned char **, int *, int *,
+   int *);
+  view_fn view;
+  const od_coeff *d;
+  const unsigned char *bsize;
+  unsigned char *gpu;
+  int bstride;
+  int pic_w;
+  int pic_h;
+  int w;
+  int h;
+  long i;
+  view = (view_fn)(g_reference ? dlsym(g_reference, "ref_state_recon_view")
+   : dlsym(RTLD_DEFAULT, "ref_state_recon_view"));
+  if (!view) {
+    fprintf(stderr, "interpose: ref_state_recon_view not found\n");
+    abort();
+  }
+  /* not one of the decoder's planes (an encoder in the same process laps its own) */
+  if (view(g_dec, c, &d, &bsize, &bstride, &pic_w, &pic_h) < 0) return 0;
+  w = nhsb << 6 >> xdec;
+  h = nvsb << 6 >> xdec;
+  if (stride != w) abort();
+  gpu = (unsigned char *)malloc((size_t)w*h);
+  if (odhip_inverse_partition_host(gpu, w, d, w, h, xdec, bsize, bstride, pic_w, pic_h) != 0) {
+    fprintf(stderr, "interpose: odhip_inverse_partition_host failed\n");
+    abort();
+  }
+  reference(c, stride, nhsb, nvsb, xdec, ydec, q, skip, skip_stride);
+  odhip_interposed_decode[0]++;
+  for (i = 0; i < (long)w*h; i++) {
+    int v;
+    v = ((c[i] + 8) >> 4) + 128;
+    v = v < 0 ? 0 : v > 255 ? 255 : v;
+    odhip_interposed_decode[1]++;
+    if (v != gpu[i]) odhip_interposed_decode[2]++;
+  }
+  free(gpu);
+  return 1;
+}
+
 void od_apply_postfilter_frame_sbs(od_coeff *c, int stride, int nhsb, int nvsb, int xdec,
  int ydec, int q, unsigned char *skip, int skip_stride) {
   odhip_interposed_calls[3]++;
+  if (g_decode_check && g_dec) {
+    typedef void (*fn)(od_coeff *, int, int, int, int, int, int, unsigned char *, int);
+    static fn next;
+    if (!next) next = NEXT(fn, "od_apply_postfilter_frame_sbs");
+    if (interpose_decode_check(c, stride, nhsb, nvsb, xdec, next, ydec, q, skip, skip_stride)) return;
+  }
   if (passthrough()) {
     typedef void (*fn)(od_coeff *, int, int, int, int, int, int, unsigned char *, int);
     static fn next;
