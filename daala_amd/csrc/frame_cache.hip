@@ -69,13 +69,20 @@ struct odhip_frame_cache {
     od_coeff *h_levels[ODHIP_NBSIZES];
     od_coeff *d_levels[ODHIP_NBSIZES];
     size_t cap;
+    unsigned long long px_hash;   /* FNV-1a of the pixels the cached pyramid was made from */
     BandLevel *bands;        /* [ODHIP_NBSIZES], allocated by odhip_cache_load_bands */
     int bands_valid;
+    int bands_quantizer;     /* the set-up the cached band stage was run with */
+    int bands_masking;
+    double bands_lambda;
+    uint8_t bands_qm4[ODHIP_QM_SIZE];
+    unsigned long long bands_qm_hash;
   } planes[4];
   hipStream_t stream;
   odhip_ctx *ctx;
   long band_hits;
   long band_misses;
+  long reloads_skipped;
   int pic_w;
   int pic_h;
   int check;
@@ -201,18 +208,32 @@ int odhip_cache_load_plane(odhip_frame_cache *c, int pli, const od_coeff *coef, 
     return ODHIP_EINVAL;
   }
   odhip_frame_cache::Plane &p = c->planes[pli];
+  const bool same_shape = p.valid && p.w == w && p.h == h && p.dec == dec && p.base == coef;
+  const int was_bands = p.bands_valid;
   p.valid = 0;
   p.bands_valid = 0;
   int rc = plane_reserve(p, w, h, dec);
   if (rc) return rc;
   /* od_ref_buf_to_coeff wrote (p - 128) << 4 (src/state.c:1233): recover p. */
   const size_t n = (size_t)w*h;
+  unsigned long long hash = 1469598103934665603ULL;
   for (size_t i = 0; i < n; i++) {
     const int v = coef[i];
     const int px = (v >> 4) + 128;
     if ((v & 15) || px < 0 || px > 255) return ODHIP_EINVAL;  /* not a fresh 8-bit plane */
     p.h_px[i] = (uint8_t)px;
+    hash = (hash ^ (unsigned)px)*1099511628211ULL;
   }
+  /* The encoder converts and laps the same input once per RDO pass (src/encode.c:
+     2560-2572 runs for OD_ENCODE_RDO and for OD_ENCODE_REAL): the second load of
+     identical pixels keeps the pyramid (and the band stage) it already has. */
+  if (same_shape && hash == p.px_hash && !c->check) {
+    p.valid = 1;
+    p.bands_valid = was_bands;
+    c->reloads_skipped++;
+    return ODHIP_SUCCESS;
+  }
+  p.px_hash = hash;
   ODHIP_TRY(hipMemcpyAsync(p.d_px, p.h_px, n, hipMemcpyHostToDevice, c->stream));
   od_coeff *levels[ODHIP_NBSIZES];
   for (int i = 0; i < ODHIP_NBSIZES; i++) levels[i] = p.d_levels[i];
@@ -267,7 +288,21 @@ int odhip_cache_load_bands(odhip_frame_cache *c, int pli, const odhip_quant *qt,
   if (!c || pli < 0 || pli >= 4 || !qt || !c->ctx) return ODHIP_EINVAL;
   odhip_frame_cache::Plane &p = c->planes[pli];
   if (!p.valid) return ODHIP_EINVAL;
+  /* kept by a skipped reload of the same pixels: still valid if the quantiser set-up is
+     the one it was made with */
+  unsigned long long qm_hash = 1469598103934665603ULL;
+  for (int i = 0; i < ODHIP_QM_BUFFER_SIZE; i++) qm_hash = (qm_hash ^ (uint16_t)qt->qm[i])*1099511628211ULL;
+  if (p.bands_valid && p.bands && p.bands_qm_hash == qm_hash && p.bands_quantizer == qt->quantizer && p.bands_lambda == pvq_norm_lambda
+   && memcmp(p.bands_qm4, qt->pvq_qm_q4[pli > 2 ? 2 : pli], ODHIP_QM_SIZE) == 0
+   && p.bands_masking == qt->use_masking && !c->check) {
+    return ODHIP_SUCCESS;
+  }
   p.bands_valid = 0;
+  p.bands_quantizer = qt->quantizer;
+  p.bands_lambda = pvq_norm_lambda;
+  p.bands_masking = qt->use_masking;
+  p.bands_qm_hash = qm_hash;
+  memcpy(p.bands_qm4, qt->pvq_qm_q4[pli > 2 ? 2 : pli], ODHIP_QM_SIZE);
   if (!p.bands) p.bands = new BandLevel[ODHIP_NBSIZES];
   const int nlev = ODHIP_NBSIZES - p.dec;
   const int qpli = pli > 2 ? 2 : pli;
