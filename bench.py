@@ -20,13 +20,17 @@ prefilter + fDCT + PVQ + dequantisation + iDCT + postfilter exactly once:
 260 610 transform blocks per frame (173 910 luma + 2 x 43 350 chroma).  The metric
 counts those blocks.  The two chains are software-pipelined over steps.
 
-Entropy coding / rate pricing are host state in the reference (SURVEY.md hard part
-1): inside the timed step the choice between PVQ candidates is made on distortion
-alone.  `verified` therefore runs frame 0 of the batch through the SAME GPU stages
-with the host pricing every candidate in between (closed-form od_pvq_rate) and
-compares every reconstructed pixel of every level with the cpu_baseline leg (the
-reference's own C functions); `pipelined_equals_serial` replays the timed pictures
-on one stream and compares every plane and choice record.
+The choice between PVQ candidates inside the timed step is pvq_theta's: distortion +
+lambda * od_pvq_rate, the rate in its closed form (speed > 0, src/pvq_encoder.c:250-264,
+what the reference's block-size RDO prices with below complexity 5) evaluated ON THE
+DEVICE in the choice kernels; a decision too close for the device's log to settle is
+left to the host libm (`price_margin_reruns`).  `verified` compares every reconstructed
+pixel of every level of frame 0 AS THE TIMED PIPELINE LEFT IT with the cpu_baseline leg
+(the reference's own C functions: pvq_theta with the same closed-form pricing);
+`pipelined_equals_serial` replays the timed pictures on one stream and compares every
+plane and choice record.  --no-price: the choice on distortion alone (round 1's step;
+`verified` then runs the host-priced flow stage by stage).  The live-entropy-coder rate
+(speed 0) stays host state: INTEGRATION.md section 7.
 
 N > 1: frames are sharded over ranks (independent all-intra frames, no data-path
 collective) -> weak scaling, F frames per GPU; `sharded_encode_check` then encodes
@@ -244,7 +248,7 @@ def cpu_worker(args):
     print(json.dumps({"blocks": blocks * len(rates), "seconds": busy}))
 
 
-def cpu_baseline(D, qt, chroma_cfl, args, gpu_frame0):
+def cpu_baseline(D, qt, chroma_cfl, args, gpu_frame0, timed_recon=None):
     """cpu_baseline (one pinned core, median of >= 5 pictures), the all-cores figure
     (one pinned process per core, independent pictures - all-intra frames are
     independent), and the whole-frame verification of the GPU path against it."""
@@ -302,13 +306,19 @@ def cpu_baseline(D, qt, chroma_cfl, args, gpu_frame0):
     # whole-frame verification: the GPU stages with the host pricing every candidate in
     # between (closed form, the reference's own od_pvq_rate) must reproduce the CPU leg's
     # reconstruction of the batch's frame 0 at every level of all three planes
-    gpu = C.gpu_priced_frame(D, qt, gpu_frame0, PIC_W, PIC_H, chroma_cfl=chroma_cfl)
-    bad = C.compare_frame(gpu, recon0)
-    ver = {"verified": not bad,
-           "what": "frame 0 of the batch, whole frame: every reconstructed pixel of every partition "
-                   "level of Y, Cb, Cr from the GPU stages (host-priced choice) == the reference C "
-                   "functions' (cpu_baseline leg)",
-           "planes_levels_compared": 13, "mismatches": bad}
+    if timed_recon is not None:
+        # price = 1: what the TIMED pipeline left in its buffers after the last step
+        bad = C.compare_frame(timed_recon, recon0, frame=0, frames=args.frames)
+        what = ("frame 0 of the batch as the timed pipeline reconstructed it in its last step (device-"
+                "priced choice), whole frame: every reconstructed pixel of every partition level of Y, "
+                "Cb, Cr == the reference C functions' (cpu_baseline leg)")
+    else:
+        gpu = C.gpu_priced_frame(D, qt, gpu_frame0, PIC_W, PIC_H, chroma_cfl=chroma_cfl)
+        bad = C.compare_frame(gpu, recon0)
+        what = ("frame 0 of the batch, whole frame: every reconstructed pixel of every partition "
+                "level of Y, Cb, Cr from the GPU stages (host-priced choice) == the reference C "
+                "functions' (cpu_baseline leg)")
+    ver = {"verified": not bad, "what": what, "planes_levels_compared": 13, "mismatches": bad}
     return base, host, ver
 
 
@@ -438,6 +448,8 @@ def main():
     ap.add_argument("--no-cpu-allcores", action="store_true")
     ap.add_argument("--no-replay", action="store_true",
                     help="skip the serial replay after the timed region (profiling runs: no extra launches)")
+    ap.add_argument("--no-price", action="store_true",
+                    help="choose on distortion alone inside the step (no od_pvq_rate)")
     ap.add_argument("--no-shard-check", action="store_true",
                     help="N > 1: skip the sharded real-encoder check (frames over ranks, RCCL gather)")
     ap.add_argument("--cpu-worker", type=int, default=None, help=argparse.SUPPRESS)
@@ -474,8 +486,9 @@ def main():
     cfl = not args.chroma_noref
     qt = D.QuantTables.load()
     luma_pic, chroma_pic = synth_pictures(args.frames, 1234 + rank)
+    price = not args.no_price
     pipe = D.Pipe(qt, args.frames, PIC_W, PIC_H, chroma_cfl=cfl, device=local_rank,
-                  serial=bool(os.environ.get("ODHIP_PVQ_SERIAL")))
+                  serial=bool(os.environ.get("ODHIP_PVQ_SERIAL")), price=price)
     pipe.set_pictures(luma_pic, chroma_pic)
     for _ in range(args.warmup):
         pipe.step()
@@ -529,7 +542,8 @@ def main():
             excl, search_excl, ref_search_excl = kms, search_ms, ref_search_ms
         else:
             digest = pipeline_digest(D, pipe)
-            serial = D.Pipe(qt, args.frames, PIC_W, PIC_H, chroma_cfl=cfl, device=local_rank, serial=True)
+            serial = D.Pipe(qt, args.frames, PIC_W, PIC_H, chroma_cfl=cfl, device=local_rank, serial=True,
+                            price=price)
             serial.set_pictures(luma_pic, chroma_pic)
             serial.step()
             serial.flush()
@@ -620,8 +634,10 @@ def main():
             "ms_per_step": step_ms,
             # the host's share: one C call per step (odhip_pipe_step).  launch = enqueuing the
             # ~100 kernel launches of a step; wait = blocked on the count of bands inside the
-            # device-acos margin of the PREVIOUS step's chroma band stage (the only host wait:
-            # it keeps the host one step ahead of the GPU, by design)
+            # device-acos margin of the PREVIOUS step's chroma band stage and, with pricing,
+            # on the counts of priced decisions inside the device-log margin (this step's luma
+            # choice, the previous step's chroma choice) - the host never computes in a step
+            # unless a count is non-zero
             "host_launch_ms_per_step": (host_s * 1e3 - (wait_ms - host_wait_s * 1e3)) / args.steps,
             "host_wait_ms_per_step": wait_ms / args.steps,
             "host_note": "launch = host time enqueuing a step (the host's share of the step: it must stay well "
@@ -640,8 +656,11 @@ def main():
                            if cfl else "; chroma through the no-reference PVQ path"),
                        "frames_per_gpu_per_step": args.frames, "content": args.content,
                        "blocks_per_frame": bpf, "quality": "-v 20 (quantizer 243)",
-                       "choice": "on distortion alone inside the timed step (od_pvq_rate is host state "
-                                 "in the reference); `verified` runs the host-priced choice",
+                       "choice": ("pvq_theta's: distortion + lambda * od_pvq_rate, closed-form rate (speed > 0, "
+                                  "src/pvq_encoder.c:250-264) evaluated on the device inside the timed step"
+                                  if price else
+                                  "on distortion alone inside the timed step; `verified` runs the "
+                                  "host-priced choice"),
                        "inputs": "resident in HBM (PCIe-inclusive rates: DESIGN.md section 5)",
                        "driver": "odhip_pipe_step: one C call per step, two streams, one odhip_ctx "
                                  "per chain",
@@ -652,13 +671,20 @@ def main():
             "roofline_ref_search": roof_ref if (roof_ref is not None and roof is not roof_ref) else None,
             "pipelined_equals_serial": None if digest is None else digest == serial_digest,
             "theta_margin_reruns": pipe.theta_reruns(),
+            "price_margin_reruns": pipe.price_reruns() if price else None,
             "kernels": kernels,
         }
         if shard_check is not None:
             line["sharded_encode_check"] = shard_check
         if world == 1 and not args.no_cpu_baseline:
             frame0 = [luma_pic[0], chroma_pic[0], chroma_pic[args.frames]]
-            base, host, ver = cpu_baseline(D, qt, cfl, args, frame0)
+            timed_recon = None
+            if price:
+                F = args.frames
+                timed_recon = [[pipe.read(D.BUF_RECON, 0, bs).reshape(F, H, W) for bs in range(5)],
+                               [pipe.read(D.BUF_RECON, 1, bs).reshape(2 * F, H // 2, W // 2)
+                                for bs in range(4)]]
+            base, host, ver = cpu_baseline(D, qt, cfl, args, frame0, timed_recon)
             if base is not None:
                 line["cpu_baseline"] = base
                 line["speedup_vs_cpu_baseline"] = line["value"] / base["value"]

@@ -19,9 +19,9 @@ from .api import (DaalaHipError, lib, lib_path, init, fdct2d_batch, idct2d_batch
                   PvqRefJob, pvq_ref_bands_multi, pvq_ref_select_synth_multi,
                   pvq_ref_set_theta_margin, pvq_ref_theta_probe, REF_SLOTS, REFBAND_RECORD,
                   REFITEM_RECORD, REFBAND_R_NULL, REFBAND_THETA, REFBAND_NOREF, REFBAND_FLIP,
-                  REFBAND_UNCERTAIN, REFITEM_SEARCHED, REFITEM_WITH_REF, REFITEM_K_RANGE, pvq_ref_profile,
+                  REFBAND_UNCERTAIN, REFITEM_SEARCHED, REFITEM_WITH_REF, REFITEM_K_RANGE, REFITEM_MOMENT_SHIFT, pvq_ref_profile,
                   pvq_ref_profile_read, image_planes_copy_pad, inverse_levels, pvq_ref_resolve_finish, cfl_refs_from_luma, pvq_ref_set_context,
                   pvq_ref_choose_multi, inverse_levels_pvq_ref, Context, Pipe, PIPE_STAGES,
                   BUF_PIC, BUF_PX, BUF_LEVEL, BUF_RECON, BUF_BAND, BUF_Y, BUF_CHOICE, BUF_ITEMS,
-                  BUF_REF, BUF_RATE, compute_dist)
+                  BUF_REF, BUF_RATE, compute_dist, set_price_tol_scale)
 from .quant import QuantTables, OD_PVQ_LAMBDA  # noqa: F401

@@ -30,6 +30,14 @@ def lib():
             raise DaalaHipError(
                 "%s not built: run `python -m daala_amd.build` "
                 "(there is no CPU fallback)" % path)
+        # PyTorch-ROCm ships its own copy of the HIP runtime; when it is going to be used in
+        # this process (device tensors, streams) it has to be the one the process binds
+        # first - the library loaded first would otherwise bring /opt/rocm's copy and
+        # torch.cuda then finds no device.  A pure-C consumer never gets here.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = ctypes.CDLL(path)
         L.odhip_version.restype = ctypes.c_char_p
         L.od_pvq_search_rdo_double_hip.restype = ctypes.c_double
@@ -237,7 +245,7 @@ _CAND_FIELDS = ("band", "y", "choice", "cos_dist")
 # odhip_pvq_band (include/daala_hip.h): one 64-byte record per (block, band)
 BAND_RECORD = np.dtype([("cg", "<i4"), ("gain", "<i4", (2,)), ("k", "<i2", (2,)),
                         ("flags", "u1", (2,)), ("reserved0", "u1", (6,)), ("dist0", "<f8"),
-                        ("yy", "<i4", (2,)), ("dist", "<f8", (2,)), ("reserved1", "u1", (8,))])
+                        ("yy", "<i4", (2,)), ("dist", "<f8", (2,)), ("moment", "<i4", (2,))])
 assert BAND_RECORD.itemsize == 64
 
 
@@ -357,11 +365,11 @@ def alloc_pvq_cands(nblocks, bs, device, cos_dist=False):
 
 def unpack_cands(cands):
     """Host copy of a cands dict as numpy arrays keyed by field name: the record
-    fields (cg, gain, k, flags, dist0, yy, dist: [B][nb] or [B][nb][2]) plus y,
+    fields (cg, gain, k, flags, dist0, yy, dist, moment: [B][nb] or [B][nb][2]) plus y,
     choice and, when present, cos_dist."""
     rec = cands["band"].cpu().numpy().view(BAND_RECORD)[..., 0]
     out = {name: np.ascontiguousarray(rec[name]) for name in
-           ("cg", "gain", "k", "flags", "dist0", "yy", "dist")}
+           ("cg", "gain", "k", "flags", "dist0", "yy", "dist", "moment")}
     out["y"] = cands["y"].cpu().numpy()
     out["choice"] = cands["choice"].cpu().numpy()
     if cands.get("cos_dist") is not None:
@@ -498,6 +506,7 @@ REFITEM_RECORD = np.dtype([("gain", "<i4"), ("theta", "<i4"), ("ts", "<i4"), ("k
 assert REFITEM_RECORD.itemsize == 48
 REFBAND_R_NULL, REFBAND_THETA, REFBAND_NOREF, REFBAND_FLIP, REFBAND_UNCERTAIN = 1, 2, 4, 8, 16
 REFITEM_SEARCHED, REFITEM_WITH_REF, REFITEM_K_RANGE = 1, 2, 4
+REFITEM_MOMENT_SHIFT = 8
 
 
 class _RefJob(ctypes.Structure):
@@ -773,6 +782,7 @@ PIPE_STAGES = ("image_copy_pad_luma", "forward_pyramid_luma", "pvq_noref_bands",
 class _PipeConfig(ctypes.Structure):
     _fields_ = [("device", ctypes.c_int), ("frames", ctypes.c_int), ("pic_w", ctypes.c_int),
                 ("pic_h", ctypes.c_int), ("chroma_cfl", ctypes.c_int), ("serial", ctypes.c_int),
+                ("price", ctypes.c_int), ("reserved", ctypes.c_int),
                 ("pvq_norm_lambda", ctypes.c_double), ("quant", ctypes.c_void_p)]
 
 
@@ -781,12 +791,15 @@ class Pipe:
     one C call per step.  Buffers are read / written as numpy arrays."""
 
     def __init__(self, quant, frames, pic_w, pic_h, chroma_cfl=True, serial=False, device=0,
-                 pvq_norm_lambda=0.147):
+                 pvq_norm_lambda=0.147, price=False):
+        """price=True: the choices price every candidate with od_pvq_rate's closed form on
+        the device (odhip_pvq_*choose_priced_*), nothing for the host to do in a step."""
         L = lib()
         L.odhip_pipe_create.restype = ctypes.c_void_p
         L.odhip_pipe_theta_reruns.restype = ctypes.c_long
+        L.odhip_pipe_price_reruns.restype = ctypes.c_long
         cfg = _PipeConfig(int(device), int(frames), int(pic_w), int(pic_h), int(bool(chroma_cfl)),
-                          int(bool(serial)), float(pvq_norm_lambda),
+                          int(bool(serial)), int(bool(price)), 0, float(pvq_norm_lambda),
                           ctypes.cast(ctypes.byref(quant.c), ctypes.c_void_p))
         self.h = L.odhip_pipe_create(ctypes.byref(cfg))
         if not self.h:
@@ -879,6 +892,10 @@ class Pipe:
     def theta_reruns(self):
         return int(lib().odhip_pipe_theta_reruns(self._p()))
 
+    def price_reruns(self):
+        """Priced choices re-decided with the host libm so far (price=True pipes)."""
+        return int(lib().odhip_pipe_price_reruns(self._p()))
+
     def nblocks(self, set_, level):
         n = 4 << level
         dec = 1 if set_ else 0
@@ -908,3 +925,11 @@ def compute_dist(x, y, bs, use_masking=1, flat_qm=0, coded_quantizer=40):
                                    int(use_masking), int(flat_qm), int(coded_quantizer)),
            "odhip_dist_finish")
     return dist, hp
+
+
+def set_price_tol_scale(scale):
+    """Test hook: multiplies the margin inside which a priced choice is left to the host
+    libm (odhip_pvq_price_set_tol_scale / odhip_pvq_ref_price_set_tol_scale); 1 restores it."""
+    L = lib()
+    L.odhip_pvq_price_set_tol_scale(ctypes.c_double(float(scale)))
+    L.odhip_pvq_ref_price_set_tol_scale(ctypes.c_double(float(scale)))

@@ -230,3 +230,42 @@ __device__ __forceinline__ int odq_compute_k_ref(int itheta, int n) {
   const int32_t v = odq_vshr_round((odq_shl32(itheta, 15) - 6554)*(int64_t)rt, 10 + 15);
   return v > 1 ? v : 1;
 }
+
+/* od_pvq_rate with speed > 0 (src/pvq_encoder.c:247-287: the closed form the reference's
+   RDO pass prices with below complexity 5, src/encode.c:1359) from the candidate's
+   "centre of mass" sum = SUM i*|y_i| over its n - (theta != -1) coded positions.
+   Written once for both sides of the library: ODQ_RATE_LOG is the device's log in the
+   choice kernels and the HOST libm's log where flagged bands are re-decided - the two
+   may differ in the last place, which is why a choice whose costs come within
+   ODQ_RATE_TOL of each other is never taken from the device (see k_choose). */
+#define ODQ_RATE_BODY(LOGFN, DIV) \
+  double rate; \
+  if (k == 0) rate = 0; \
+  else { \
+    const double f = DIV((double)sum, (double)(k*n)); \
+    const double a = DIV(LOGFN(((double)(n*2))*(f + .025))*k, (double)n); \
+    rate = ((1 + .4*f)*n)*(1.4426950408889634073599246810019*LOGFN(1 + (0 > a ? 0 : a))) + 3; \
+  } \
+  if (qg > 0 && theta >= 0) { \
+    rate += .9*(1.4426950408889634073599246810019*LOGFN((double)ts)); \
+    if (is_keyframe && pli == 0) rate += 6; \
+    if (qg == icgr) rate -= .5; \
+  } \
+  return rate;
+
+__device__ __forceinline__ double odq_pvq_rate_fast(int sum, int k, int n, int qg, int icgr, int theta,
+ int ts, int is_keyframe, int pli) {
+  ODQ_RATE_BODY(log, __ddiv_rn)
+}
+
+static inline double odq_host_div(double a, double b) { return a/b; }
+static inline double odq_pvq_rate_fast_host(int sum, int k, int n, int qg, int icgr, int theta, int ts,
+ int is_keyframe, int pli) {
+  ODQ_RATE_BODY(log, odq_host_div)
+}
+
+/* |cost_a - cost_b| at or below this is "too close to call on the device". */
+__host__ __device__ static inline double odq_rate_tol(double a, double b) {
+  const double m = (a < 0 ? -a : a) + (b < 0 ? -b : b);
+  return 1e-10*m + 1e-10;
+}

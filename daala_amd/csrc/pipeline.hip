@@ -73,6 +73,7 @@ struct odhip_pipe {
   long nstep;
   int pending;                    /* parity of the step whose theta list is unchecked, -1 */
   long reruns;                    /* bands re-run with the host's theta so far */
+  long price_reruns;              /* priced choices re-decided with the host libm so far */
   double wait_ms;                 /* host time spent waiting for the margin count */
   bool record;
   std::vector<hipEvent_t> timed[kStages];    /* pairs */
@@ -89,6 +90,12 @@ int alloc(odhip_pipe *p, void **out, size_t bytes, bool zero) {
   *out = d;
   return ODHIP_SUCCESS;
 }
+#define STEP_TRY(expr) \
+  do { \
+    const int rc_ = (expr); \
+    if (rc_) return rc_; \
+  } while (0)
+
 #define PIPE_ALLOC(p, ptr, bytes, zero) \
   do { \
     const int rc_ = alloc((p), (void **)&(ptr), (bytes), (zero)); \
@@ -296,7 +303,8 @@ int chroma_tail(odhip_pipe *p, int par, hipStream_t s) {
   int rc;
   {
     Timed tm(p, ODHIP_PIPE_CHOOSE_CHROMA, s);
-    rc = odhip_pvq_ref_choose_multi(p->refjobs[par], 4, lam, s);
+    rc = p->cfg.price ? odhip_pvq_ref_choose_priced_multi(p->refjobs[par], 4, lam, s)
+     : odhip_pvq_ref_choose_multi(p->refjobs[par], 4, lam, s);
   }
   if (rc) return rc;
   Timed tm(p, ODHIP_PIPE_INVERSE_CHROMA, s);
@@ -319,16 +327,26 @@ int finish_pending(odhip_pipe *p) {
   if (n < 0) return n;
   if (n > 0) {
     p->reruns += n;
-    return chroma_tail(p, par, p->stream[1]);
+    STEP_TRY(chroma_tail(p, par, p->stream[1]));
+  }
+  if (p->cfg.price) {
+    /* the chroma choices of that step: listed bands are re-decided with the host libm and
+       the inverse that consumed them runs again (the buffers are intact until the next
+       chroma chain is enqueued, below) */
+    const auto t1 = std::chrono::steady_clock::now();
+    const int m = odhip_pvq_ref_choose_priced_resolve(p->refjobs[par], 4, p->cfg.pvq_norm_lambda,
+     p->stream[1]);
+    p->wait_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count();
+    if (m < 0) return m;
+    if (m > 0) {
+      p->price_reruns += m;
+      PlaneSet &ch = p->set[1];
+      STEP_TRY(odhip_inverse_levels_pvq_ref(ch.recon, ch.w, (long)ch.w*ch.h, p->refjobs[par], 4, 1, p->pic_w,
+       p->pic_h, p->stream[1]));
+    }
   }
   return ODHIP_SUCCESS;
 }
-
-#define STEP_TRY(expr) \
-  do { \
-    const int rc_ = (expr); \
-    if (rc_) return rc_; \
-  } while (0)
 
 int luma_front(odhip_pipe *p, hipStream_t s) {
   const double lam = p->cfg.pvq_norm_lambda;
@@ -346,8 +364,25 @@ int luma_front(odhip_pipe *p, hipStream_t s) {
 }
 
 int luma_choose(odhip_pipe *p, hipStream_t s) {
-  Timed tm(p, ODHIP_PIPE_CHOOSE_LUMA, s);
-  return odhip_pvq_choose_multi(p->jobs, p->njobs, p->cfg.pvq_norm_lambda, s);
+  const double lam = p->cfg.pvq_norm_lambda;
+  if (!p->cfg.price) {
+    Timed tm(p, ODHIP_PIPE_CHOOSE_LUMA, s);
+    return odhip_pvq_choose_multi(p->jobs, p->njobs, lam, s);
+  }
+  {
+    Timed tm(p, ODHIP_PIPE_CHOOSE_LUMA, s);
+    STEP_TRY(odhip_pvq_choose_priced_multi(p->jobs, p->njobs, lam, s));
+  }
+  /* The luma choices feed this step's chroma references and inverse: a band whose priced
+     decision is too close to take from the device is settled (host libm) before they are
+     enqueued.  The host waits here for the luma front of this step while the chroma chain
+     of the previous step keeps the GPU busy. */
+  const auto t0 = std::chrono::steady_clock::now();
+  const int n = odhip_pvq_choose_priced_resolve(p->jobs, p->njobs, lam, s);
+  p->wait_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  if (n < 0) return n;
+  p->price_reruns += n;
+  return ODHIP_SUCCESS;
 }
 
 int luma_refs(odhip_pipe *p, int par, hipStream_t s) {
@@ -412,6 +447,7 @@ extern "C" odhip_pipe *odhip_pipe_create(const odhip_pipe_config *cfg) {
   p->njobs = 0;
   p->nstep = 0;
   p->reruns = 0;
+  p->price_reruns = 0;
   p->wait_ms = 0;
   p->record = false;
   memset(p->rate, 0, sizeof(p->rate));
@@ -515,8 +551,17 @@ extern "C" int odhip_pipe_stage(odhip_pipe *p, int stage, int parity) {
     }
     case ODHIP_PIPE_CHOOSE_CHROMA: {
       if (!cfl) return ODHIP_SUCCESS;
-      Timed tm(p, stage, s);
-      return odhip_pvq_ref_choose_multi(p->refjobs[parity], 4, lam, s);
+      {
+        Timed tm(p, stage, s);
+        STEP_TRY(p->cfg.price ? odhip_pvq_ref_choose_priced_multi(p->refjobs[parity], 4, lam, s)
+         : odhip_pvq_ref_choose_multi(p->refjobs[parity], 4, lam, s));
+      }
+      if (p->cfg.price) {
+        const int m = odhip_pvq_ref_choose_priced_resolve(p->refjobs[parity], 4, lam, s);
+        if (m < 0) return m;
+        p->price_reruns += m;
+      }
+      return ODHIP_SUCCESS;
     }
     case ODHIP_PIPE_INVERSE_CHROMA: {
       if (!cfl) return stage_inverse_noref(p, 1, s);
@@ -696,6 +741,10 @@ extern "C" int odhip_pipe_time_pyramid(odhip_pipe *p, int n, double *avg_ms) {
    of a step; everything else in odhip_pipe_step is launch work). */
 extern "C" double odhip_pipe_host_wait_ms(const odhip_pipe *p) {
   return p ? p->wait_ms : 0;
+}
+
+extern "C" long odhip_pipe_price_reruns(const odhip_pipe *p) {
+  return p ? p->price_reruns : 0;
 }
 
 extern "C" long odhip_pipe_theta_reruns(const odhip_pipe *p) {

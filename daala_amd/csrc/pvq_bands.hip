@@ -76,6 +76,14 @@ struct DJob {
   int off[ODHIP_MAX_BANDS + 1];
 };
 
+/* A band whose priced choice the host (re)decides: candidate rates from the host libm. */
+struct PUnc {
+  int job;
+  unsigned sb;             /* blk*nb_bands + band */
+  double rate[2];
+};
+constexpr int kPUncCap = 1 << 16;
+
 struct Items {
   int nitems;
   int reserved;
@@ -83,6 +91,9 @@ struct Items {
   const DJob *jobs;        /* the calling context's device job table [kMaxJobs]   */
   unsigned *sort;          /* its counting-sort arrays: histogram, bin starts and
                               cursors, kMaxItems*kKeyBins words each              */
+  unsigned *pcount;        /* priced choice: bands too close to call on the device */
+  struct PUnc *plist;      /* ... and their list [kPUncCap]                       */
+  double tol_scale;        /* test hook: multiplies the decision margin           */
   int wg_start[kMaxItems + 1];
   unsigned char job[kMaxItems];
   unsigned char band[kMaxItems];
@@ -647,6 +658,8 @@ __global__ __launch_bounds__(kWave, (S == 2 ? 2 : 1)) void k_search(Items it) {
     int prev_k = 0;
     int yy0 = 0;
     int yy1 = 0;
+    int mom0 = 0;
+    int mom1 = 0;
     double dist0 = 0;
     double dist1 = 0;
 #pragma unroll 1
@@ -676,6 +689,10 @@ __global__ __launch_bounds__(kWave, (S == 2 ? 2 : 1)) void k_search(Items it) {
         yy0 = yyc;
         dist0 = distc;
       }
+      /* od_pvq_rate's centre-of-mass sum SUM i*|y_i| (src/pvq_encoder.c:258-259), taken
+         while the pulses pass through on their way out: the priced choice then never
+         reads the vectors again */
+      int mom = 0;
       if (live) {
         if (cosd && half == 0) cosd[2*(blk*nb_bands + band) + c] = on ? cos_dist : 0.;
         int4 *yo = reinterpret_cast<int4 *>(yout + ((long)c*nblocks + blk)*len);
@@ -696,15 +713,19 @@ __global__ __launch_bounds__(kWave, (S == 2 ? 2 : 1)) void k_search(Items it) {
             const int s0 = (int)(short)d[t] >> 31;
             const int s1 = d[t] >> 31;
             o[t] = (((y0 ^ s0) - s0) & 0xffff) | ((y1 ^ s1) - s1) << 16;
+            mom += (half*NL + j0)*y0 + (half*NL + j0 + 1)*y1;     /* y0 = 0 where j0 < 0 */
           }
           yo[v] = make_int4(o[0], o[1], o[2], o[3]);
         }
       }
+      if (S == 2) mom += row_mov<OD_DPP_XOR1>(mom);    /* the two halves of the band */
+      if (c) mom1 = mom;
+      else mom0 = mom;
     }
     if (live && half == 0) {
       int4 *out = reinterpret_cast<int4 *>(recs + blk*nb_bands) + 2;
       out[0] = make_int4(yy0, yy1, __double2loint(dist0), __double2hiint(dist0));
-      out[1] = make_int4(__double2loint(dist1), __double2hiint(dist1), 0, 0);
+      out[1] = make_int4(__double2loint(dist1), __double2hiint(dist1), mom0, mom1);
     }
   }
 }
@@ -715,11 +736,16 @@ __global__ __launch_bounds__(kWave, (S == 2 ? 2 : 1)) void k_search(Items it) {
    then od_gain_expand (src/pvq.c:766-811) and the synthesis scale of
    od_pvq_synthesis_partial (src/pvq.c:1057-1078).  choice = {sel, qg, scale,
    qshift}. */
-__global__ __launch_bounds__(256) void k_choose(Items it) {
-  const int item = find_item(it, blockIdx.x);
-  const DJob &jb = it.jobs[it.job[item]];
-  const long sb = (long)(blockIdx.x - it.wg_start[item])*256 + threadIdx.x;
-  if (sb >= jb.nblocks*jb.nb_bands) return;
+/* PRICE = 0: cost = dist + lambda*rate with the host's rate table (or no rate at all);
+   PRICE = 1: the rate is od_pvq_rate's closed form (speed > 0) evaluated HERE from the
+   candidate's pulses with the device's log.  The device's and the host libm's log may
+   differ in the last place, so a comparison whose two costs lie within odq_rate_tol of each
+   other is not trusted: the band is listed, odhip_pvq_choose_priced_resolve recomputes its
+   rates with the host's libm (the function the reference calls) and k_choose_list decides
+   it again; PRICE = 2 is that second decision (rates given per band). */
+template <int PRICE>
+__device__ __forceinline__ void choose_band(const Items &it, int job, const DJob &jb, long sb,
+ const double *given) {
   const int band = (int)(sb % jb.nb_bands);
   const int qb = jb.q[band];
   const int betab = jb.beta[band];
@@ -732,18 +758,40 @@ __global__ __launch_bounds__(256) void k_choose(Items it) {
   const int4 r2 = r[2];
   const int4 r3 = r[3];
   const int yys[2] = {r2.x, r2.y};
+  const int moms[2] = {r3.z, r3.w};
   const double dists[2] = {__hiloint2double(r2.w, r2.z), __hiloint2double(r3.y, r3.x)};
   double best_cost = __hiloint2double(r1.w, r1.z);
   int qg = 0;
   int sel = 0;
+  bool close = false;
   for (int c = 0; c < 2; c++) {
     if (hd.flags[c] != 1) continue;
     double cost = dists[c];
-    if (rate) cost = cost + it.lambda*rate[2*sb + c];
+    if (PRICE == 0) {
+      if (rate) cost = cost + it.lambda*rate[2*sb + c];
+    }
+    else if (PRICE == 1) {
+      const int n = jb.off[band + 1] - jb.off[band];
+      cost = cost + it.lambda*odq_pvq_rate_fast(moms[c], hd.k[c], n, hd.gain[c], 0, -1, 0, 1, 0);
+      const double d = cost - best_cost;
+      if ((d < 0 ? -d : d) <= it.tol_scale*odq_rate_tol(cost, best_cost)) close = true;
+    }
+    else cost = cost + it.lambda*given[c];
     if (cost <= best_cost) {
       best_cost = cost;
       qg = hd.gain[c];
       sel = c;
+    }
+  }
+  if (PRICE == 1 && close) {
+    const unsigned slot = atomicAdd(it.pcount, 1u);
+    if (slot < (unsigned)kPUncCap) {
+      PUnc e;
+      e.job = job;
+      e.sb = (unsigned)sb;
+      e.rate[0] = 0;
+      e.rate[1] = 0;
+      it.plist[slot] = e;
     }
   }
   int32_t scale = 0;
@@ -762,6 +810,23 @@ __global__ __launch_bounds__(256) void k_choose(Items it) {
   }
   choice[sb] = make_int4(sel, qg, scale, qshift);
   if (qg_out) qg_out[sb] = qg;
+}
+
+template <int PRICE>
+__global__ __launch_bounds__(256) void k_choose(Items it) {
+  const int item = find_item(it, blockIdx.x);
+  const int job = it.job[item];
+  const DJob &jb = it.jobs[job];
+  const long sb = (long)(blockIdx.x - it.wg_start[item])*256 + threadIdx.x;
+  if (sb >= jb.nblocks*jb.nb_bands) return;
+  choose_band<PRICE>(it, job, jb, sb, nullptr);
+}
+
+__global__ __launch_bounds__(kWave) void k_choose_list(Items it, const PUnc *list, int count) {
+  const int i = blockIdx.x*kWave + threadIdx.x;
+  if (i >= count) return;
+  const PUnc e = list[i];
+  choose_band<2>(it, e.job, it.jobs[e.job], e.sb, list[i].rate);
 }
 
 /* ---- synthesis: four horizontally adjacent coefficients per lane -------------
@@ -966,6 +1031,7 @@ __global__ __launch_bounds__(256) void k_cfl_ref_tf(Items it, CflOut out) {
 
 /* ---- host side ----------------------------------------------------------------- */
 odhip_device_once g_tables_once;
+double g_price_tol_scale = 1.;   /* test hook (odhip_pvq_price_set_tol_scale): process-wide */
 
 int upload_tables_now(void) {
   short inv[32*32];
@@ -1010,6 +1076,10 @@ struct Scratch {
 constexpr int kTableSlots = 8;
 struct BandState {
   DJob *d_jobs = nullptr;          /* kTableSlots device job tables of kMaxJobs    */
+  unsigned *d_pcount = nullptr;    /* priced choice: bands too close to call ...   */
+  PUnc *d_plist = nullptr;         /* ... and their list                           */
+  unsigned *pcount_host = nullptr; /* pinned mirror of the counter                 */
+  hipEvent_t pcount_event = nullptr;
   DJob host_tab[kTableSlots][kMaxJobs];
   int tab_n[kTableSlots] = {};
   unsigned long tab_stamp[kTableSlots] = {};
@@ -1027,6 +1097,10 @@ struct BandState {
   hipEvent_t prof_ev[kProfSlots][2];
   ~BandState() {
     if (d_jobs) (void)hipFree(d_jobs);
+    if (d_pcount) (void)hipFree(d_pcount);
+    if (d_plist) (void)hipFree(d_plist);
+    if (pcount_host) (void)hipHostFree(pcount_host);
+    if (pcount_event) (void)hipEventDestroy(pcount_event);
     if (d_sort) (void)hipFree(d_sort);
     if (scr.x16) (void)hipFree(scr.x16);
     if (scr.keys) (void)hipFree(scr.keys);
@@ -1052,6 +1126,9 @@ int band_state(BandState **out) {
     ODHIP_TRY(hipMalloc((void **)&st->d_jobs, sizeof(DJob)*kMaxJobs*kTableSlots));
     ODHIP_TRY(hipMalloc((void **)&st->d_sort, sizeof(unsigned)*3*kMaxItems*kKeyBins));
     ODHIP_TRY(hipMemset(st->d_sort, 0, sizeof(unsigned)*3*kMaxItems*kKeyBins));
+    ODHIP_TRY(hipMalloc((void **)&st->d_pcount, sizeof(unsigned)));
+    ODHIP_TRY(hipMalloc((void **)&st->d_plist, sizeof(PUnc)*kPUncCap));
+    ODHIP_TRY(hipMemset(st->d_pcount, 0, sizeof(unsigned)));
   }
   st->serial = ctx->serial != 0;
   *out = st;
@@ -1200,6 +1277,9 @@ void items_begin(Items &it, const BandState &st, double lambda) {
   it.lambda = lambda;
   it.jobs = st.cur;
   it.sort = st.d_sort;
+  it.pcount = st.d_pcount;
+  it.plist = st.d_plist;
+  it.tol_scale = g_price_tol_scale;
   const char *e = getenv("ODHIP_PVQ_FORCE_SEQ");
   it.reserved = e && e[0] == '1';   /* pair-mode search: always take the sequential combine */
 }
@@ -1389,7 +1469,7 @@ extern "C" int odhip_pvq_select_synth_noref_multi(const odhip_pvq_job *jobs, int
   for (int j = 0; j < njobs; j++) {
     items_add(it, j, 0, (host[j].nblocks*host[j].nb_bands + 255)/256);
   }
-  k_choose<<<it.wg_start[it.nitems], 256, 0, s>>>(it);
+  k_choose<0><<<it.wg_start[it.nitems], 256, 0, s>>>(it);
   items_begin(it, st, pvq_norm_lambda);
   for (int j = 0; j < njobs; j++) {
     items_add(it, j, 0, (long)host[j].nplanes*host[j].h*((host[j].w + 1023) >> 10));
@@ -1415,8 +1495,114 @@ extern "C" int odhip_pvq_choose_multi(const odhip_pvq_job *jobs, int njobs,
   for (int j = 0; j < njobs; j++) {
     items_add(it, j, 0, (host[j].nblocks*host[j].nb_bands + 255)/256);
   }
-  k_choose<<<it.wg_start[it.nitems], 256, 0, s>>>(it);
+  k_choose<0><<<it.wg_start[it.nitems], 256, 0, s>>>(it);
   return odhip_check_launch();
+}
+
+/* The choice with od_pvq_rate's closed form evaluated on the device (see choose_band). */
+extern "C" int odhip_pvq_choose_priced_multi(const odhip_pvq_job *jobs, int njobs,
+ double pvq_norm_lambda, odhip_stream stream) {
+  BandState *stp;
+  {
+    const int rc0 = band_state(&stp);
+    if (rc0) return rc0;
+  }
+  BandState &st = *stp;
+  hipStream_t s = (hipStream_t)stream;
+  DJob host[kMaxJobs];
+  int rc = stage_jobs(st, jobs, njobs, 2, host, s);
+  if (rc) return rc;
+  ODHIP_TRY(hipMemsetAsync(st.d_pcount, 0, sizeof(unsigned), s));
+  Items it;
+  items_begin(it, st, pvq_norm_lambda);
+  for (int j = 0; j < njobs; j++) {
+    items_add(it, j, 0, (host[j].nblocks*host[j].nb_bands + 255)/256);
+  }
+  k_choose<1><<<it.wg_start[it.nitems], 256, 0, s>>>(it);
+  /* the count of listed bands travels to pinned host memory behind the kernel */
+  if (!st.pcount_host) {
+    ODHIP_TRY(hipHostMalloc((void **)&st.pcount_host, sizeof(unsigned), hipHostMallocDefault));
+    ODHIP_TRY(hipEventCreateWithFlags(&st.pcount_event, hipEventDisableTiming));
+  }
+  *st.pcount_host = 0xffffffffu;
+  ODHIP_TRY(hipMemcpyAsync(st.pcount_host, st.d_pcount, sizeof(unsigned), hipMemcpyDeviceToHost, s));
+  ODHIP_TRY(hipEventRecord(st.pcount_event, s));
+  return odhip_check_launch();
+}
+
+/* Waits for the stream, then settles the bands odhip_pvq_choose_priced_multi listed:
+   their candidates' rates are recomputed with the HOST libm's log (src/pvq_encoder.c:263,
+   the call the reference makes) and the bands decided again.  Returns how many (normally
+   0), or a negative code.  Pass the same jobs. */
+extern "C" int odhip_pvq_choose_priced_resolve(const odhip_pvq_job *jobs, int njobs,
+ double pvq_norm_lambda, odhip_stream stream) {
+  BandState *stp;
+  {
+    const int rc0 = band_state(&stp);
+    if (rc0) return rc0;
+  }
+  BandState &st = *stp;
+  hipStream_t s = (hipStream_t)stream;
+  /* normal case: only the count is waited for (it was sent right behind the choice) */
+  if (!st.pcount_event) return ODHIP_EINVAL;
+  ODHIP_TRY(hipEventSynchronize(st.pcount_event));
+  if (*st.pcount_host == 0) return 0;
+  ODHIP_TRY(hipStreamSynchronize(s));
+  unsigned count = 0;
+  ODHIP_TRY(hipMemcpy(&count, st.d_pcount, sizeof(count), hipMemcpyDeviceToHost));
+  if (count == 0) return 0;
+  if (count > (unsigned)kPUncCap) {
+    fprintf(stderr, "libdaalahip: %u priced bands inside the decision margin exceed the list (%d)\n", count,
+     kPUncCap);
+    return ODHIP_EFAULT;
+  }
+  DJob host[kMaxJobs];
+  int rc = stage_jobs(st, jobs, njobs, 2, host, s);
+  if (rc) return rc;
+  PUnc *list = (PUnc *)malloc(sizeof(PUnc)*count);
+  if (!list) return ODHIP_EFAULT;
+  rc = ODHIP_SUCCESS;
+  if (hipMemcpy(list, st.d_plist, sizeof(PUnc)*count, hipMemcpyDeviceToHost) != hipSuccess) rc = ODHIP_EFAULT;
+  for (unsigned i = 0; i < count && !rc; i++) {
+    if (list[i].job < 0 || list[i].job >= njobs) {
+      rc = ODHIP_EINVAL;
+      break;
+    }
+    const DJob &jb = host[list[i].job];
+    const long sb = list[i].sb;
+    const int band = (int)(sb % jb.nb_bands);
+    const int n = jb.off[band + 1] - jb.off[band];
+    odhip_pvq_band rec;
+    if (hipMemcpy(&rec, jb.rec + sb, sizeof(rec), hipMemcpyDeviceToHost) != hipSuccess) {
+      rc = ODHIP_EFAULT;
+      break;
+    }
+    for (int c = 0; c < 2; c++) {
+      list[i].rate[c] = 0;
+      if (rec.flags[c] != 1) continue;
+      list[i].rate[c] = odq_pvq_rate_fast_host(rec.moment[c], rec.k[c], n, rec.gain[c], 0, -1, 0, 1, 0);
+    }
+  }
+  PUnc *d_list = nullptr;
+  if (!rc && (hipMalloc((void **)&d_list, sizeof(PUnc)*count) != hipSuccess
+   || hipMemcpy(d_list, list, sizeof(PUnc)*count, hipMemcpyHostToDevice) != hipSuccess)) {
+    rc = ODHIP_EFAULT;
+  }
+  free(list);
+  if (!rc) {
+    Items it;
+    items_begin(it, st, pvq_norm_lambda);
+    k_choose_list<<<(count + kWave - 1)/kWave, kWave, 0, s>>>(it, d_list, (int)count);
+    rc = odhip_check_launch();
+    if (hipStreamSynchronize(s) != hipSuccess) rc = ODHIP_EFAULT;
+  }
+  if (d_list) (void)hipFree(d_list);
+  return rc ? rc : (int)count;
+}
+
+/* Test hook: scales the decision margin of the priced choices (1 restores it). */
+extern "C" void odhip_pvq_price_set_tol_scale(double scale) {
+  g_price_tol_scale = scale > 0 ? scale : 1.;
 }
 
 extern "C" int odhip_cfl_refs_from_luma(const odhip_pvq_job *luma_jobs, int njobs,

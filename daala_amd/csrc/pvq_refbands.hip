@@ -94,6 +94,17 @@ struct RJob {
 };
 
 struct Unc;
+/* A band whose priced choice the host (re)decides: rate[0] = the initial candidate,
+   rate[1 + i] = candidate i, from the host libm. */
+struct PUncR {
+  int job;
+  int band;
+  unsigned blk;
+  int reserved;
+  double rate[ODHIP_PVQ_REF_SLOTS + 1];
+};
+constexpr int kPUncCap = 1 << 14;
+
 struct RItems {
   int nitems;
   int perturb;
@@ -104,6 +115,9 @@ struct RItems {
   Unc *unc;                /* ... and entries [kUncCap]                            */
   unsigned *rhist;         /* counting sort: histogram (zero between calls) ...    */
   unsigned *rcursor;       /* ... and cursors, kMaxItems*kSortBins words each      */
+  unsigned *pcount;        /* priced choice: bands too close to call on the device */
+  struct PUncR *plist;     /* ... and their list [kPUncCap]                        */
+  double tol_scale;        /* test hook: multiplies the decision margin            */
   int wg_start[kMaxItems + 1];
   unsigned char job[kMaxItems];
   unsigned char band[kMaxItems];
@@ -867,6 +881,10 @@ __global__ __launch_bounds__(kWave) void k_refb_cands_list(const RJob *jobs, con
                             of it - the n - 1 reflected coefficients)
      V::search(n, k, prev_k, g2, lambda)   pvq_search_rdo_double on it
      V::store(dst)          the signed pulses, coding order
+     V::moment()            SUM i*|y_i| of the pulses it holds (od_pvq_rate's centre-of-
+                            mass sum, src/pvq_encoder.c:258-259), kept in the item's
+                            flags word above ODHIP_REFITEM_MOMENT_SHIFT so that the priced
+                            choice never reads the vectors
    `writer`: this lane records the band's results (one lane per band). */
 template <class V>
 __device__ __forceinline__ void refb_loops(const RJob &jb, int band, long blk, bool writer,
@@ -886,6 +904,7 @@ __device__ __forceinline__ void refb_loops(const RJob &jb, int band, long blk, b
     v.load(jb.xr + blk*len + off, true);
     int prev_k = 0;
     int cur_slot = -1;
+    int cur_mom = 0;
     double cos_dist = 0;
     const int32_t theta = r.theta;
     int4 hnext = ip.head[0];
@@ -917,10 +936,12 @@ __device__ __forceinline__ void refb_loops(const RJob &jb, int band, long blk, b
       if (k == 0) {
         cos_dist = 0;
         cur_slot = -1;
+        cur_mom = 0;
       }
       else if (k != prev_k) {
         cos_dist = v.search(n - 1, k, prev_k, ((qcg*(double)cg)*sin_prod)*s2, lambda);
         cur_slot = idx;
+        cur_mom = v.moment();
         if (may_store) v.store(yout + ((long)idx*nblocks + blk)*len + off);
       }
       prev_k = k;
@@ -930,7 +951,7 @@ __device__ __forceinline__ void refb_loops(const RJob &jb, int band, long blk, b
       dist *= s2;
       if (writer) {
         ip.tail[idx*ip.stride] = make_int4(qcg, qtheta,
-         ODHIP_REFITEM_WITH_REF | ODHIP_REFITEM_SEARCHED, cur_slot);
+         ODHIP_REFITEM_WITH_REF | ODHIP_REFITEM_SEARCHED | cur_mom << ODHIP_REFITEM_MOMENT_SHIFT, cur_slot);
         ip.res[idx*ip.stride] = make_int4(__double2loint(cos_dist), __double2hiint(cos_dist),
          __double2loint(dist), __double2hiint(dist));
       }
@@ -956,11 +977,12 @@ __device__ __forceinline__ void refb_loops(const RJob &jb, int band, long blk, b
       }
       const double cos_dist = v.search(n, k, prev_k, (qcg*(double)cg)*s2, lambda);
       prev_k = k;
+      const int mom = v.moment();
       if (may_store) v.store(yout + ((long)idx*nblocks + blk)*len + off);
       dist = (1.4*(qcg - cg))*(qcg - cg) + (qcg*(double)cg)*(2 - 2*cos_dist);
       dist *= s2;
       if (writer) {
-        ip.tail[idx*ip.stride] = make_int4(qcg, 0, ODHIP_REFITEM_SEARCHED, idx);
+        ip.tail[idx*ip.stride] = make_int4(qcg, 0, ODHIP_REFITEM_SEARCHED | mom << ODHIP_REFITEM_MOMENT_SHIFT, idx);
         ip.res[idx*ip.stride] = make_int4(__double2loint(cos_dist), __double2hiint(cos_dist),
          __double2loint(dist), __double2hiint(dist));
       }
@@ -989,6 +1011,11 @@ struct LdsVector {
       const int yj = ys[j*kWave + lane];
       dst[j] = (int16_t)(xs[j*kWave + lane] < 0 ? -yj : yj);
     }
+  }
+  __device__ __forceinline__ int moment() const {
+    int m = 0;
+    for (int j = 1; j < cur; j++) m += j*ys[j*kWave + lane];
+    return m;
   }
   int cur;
 };
@@ -1057,6 +1084,12 @@ struct RowVector {
     double yy;
     return od_pvq_search_row<E, G>(ax, y, row, l, n_true, k, prev_k, g2, lambda, force, xx, norm_1,
      &yy);
+  }
+  __device__ __forceinline__ int moment() const {
+    int m = 0;
+#pragma unroll
+    for (int e = 0; e < E; e++) m += (l*E + e)*y[e];
+    return grp_sum<G>(m);
   }
   __device__ __forceinline__ void store(int16_t *dst) {
     int16_t *p = dst + l*E;
@@ -1132,6 +1165,12 @@ struct RegVector {
     double yy;
     return od_pvq_search_regs<N>(ax, y, n_true, k, prev_k, g2, lambda, xx, norm_1, &yy);
   }
+  __device__ __forceinline__ int moment() const {
+    int m = 0;
+#pragma unroll
+    for (int i = 1; i < N; i++) m += i*y[i];
+    return m;
+  }
   __device__ __forceinline__ void store(int16_t *dst) {
     uint4 *p = reinterpret_cast<uint4 *>(dst - SH);
     int t[N + SH];
@@ -1182,24 +1221,26 @@ __device__ __forceinline__ int neg_interleave(int x, int ref) { /* src/pvq_encod
 
 __device__ unsigned char gRBandOf[OD_SCAN_LEN];
 
-template <int N>
-__global__ __launch_bounds__(kWave) void k_refb_choose(RItems it) {
+/* PRICE = 0: the host's rate table (or none); 1: od_pvq_rate's closed form (speed > 0,
+   src/pvq_encoder.c:247-287) evaluated here from every searched candidate's pulses with the
+   device's log - a comparison whose two costs lie within odq_rate_tol of each other is not
+   trusted and the band is listed for odhip_pvq_ref_choose_priced_resolve, which prices it
+   with the host libm; 2: that second decision (rates given per band). */
+template <int N, int PRICE>
+__device__ __forceinline__ void refb_choose_band(const RItems &it, int job, const RJob &jb, int band,
+ long blk, const double *given) {
   constexpr int SH = N == 15 ? 1 : 0;     /* the 15-coefficient band is read from the DC slot on */
   constexpr int NW = (N + SH)/2;
-  const int item = find_item(it, blockIdx.x);
-  const RJob &jb = it.jobs[it.job[item]];
-  const int band = it.band[item];
-  const long blk = (long)(blockIdx.x - it.wg_start[item])*kWave + threadIdx.x;
-  if (blk >= jb.nblocks) return;
   const long bi = blk*jb.nb_bands + band;
   const odhip_pvq_refband r = jb.rec[bi];
   const ItemPtr ip = item_ptr(jb, band, blk);
-  const double *rate = jb.rate ? jb.rate + bi*(kSlots + 1) : nullptr;
+  const double *rate = PRICE == 2 ? given : PRICE == 0 && jb.rate ? jb.rate + bi*(kSlots + 1) : nullptr;
   const double lambda = it.lambda;
   const int off = jb.off[band];
   const int cfl_enabled = jb.is_keyframe && jb.pli != 0;
-  /* :417-455 */
+  /* :417-455 (the initial candidate places no pulse and has qg = 0: its rate is 0) */
   double best_cost = r.dist0 + lambda*(rate ? rate[0] : 0.);
+  bool close = false;
   int qg = 0;
   int noref = jb.is_keyframe ? 1 : 0;
   int itheta = jb.is_keyframe ? -1 : 0;
@@ -1233,7 +1274,17 @@ __global__ __launch_bounds__(kWave) void k_refb_choose(RItems it) {
     if (idx >= r.nitems) continue;
     const int4 tail = tails[idx];
     if (!(tail.z & ODHIP_REFITEM_SEARCHED)) continue;
-    const double cost = __hiloint2double(dhi[idx], dlo[idx]) + lambda*(rate ? rate[1 + idx] : 0.);
+    double cost = __hiloint2double(dhi[idx], dlo[idx]);
+    if (PRICE == 1) {
+      const int4 hd = ip.head[idx*ip.stride];     /* gain, theta, ts, k */
+      const bool with_ref = idx < r.ntheta;
+      const int sum = (int)((unsigned)tail.z >> ODHIP_REFITEM_MOMENT_SHIFT);
+      cost = cost + lambda*odq_pvq_rate_fast(sum, hd.w, N, hd.x, with_ref ? r.icgr : 0, with_ref ? hd.y : -1,
+       with_ref ? hd.z : 0, jb.is_keyframe, jb.pli);
+      const double d = cost - best_cost;
+      if ((d < 0 ? -d : d) <= it.tol_scale*odq_rate_tol(cost, best_cost)) close = true;
+    }
+    else cost = cost + lambda*(rate ? rate[1 + idx] : 0.);
     if (idx < r.ntheta ? cost < best_cost : cost <= best_cost) {
       best_cost = cost;
       chosen = idx;
@@ -1243,6 +1294,15 @@ __global__ __launch_bounds__(kWave) void k_refb_choose(RItems it) {
         noref = 0;
       }
       else noref = 1;
+    }
+  }
+  if (PRICE == 1 && close) {
+    const unsigned slot = atomicAdd(it.pcount, 1u);
+    if (slot < (unsigned)kPUncCap) {
+      PUncR *e = it.plist + slot;
+      e->job = job;
+      e->band = band;
+      e->blk = (unsigned)blk;
     }
   }
   if (chosen >= 0) {
@@ -1356,6 +1416,27 @@ __global__ __launch_bounds__(kWave) void k_refb_choose(RItems it) {
   ch[3] = make_int4(xm, m, proj_1, outshift);
 }
 
+template <int N, int PRICE>
+__global__ __launch_bounds__(kWave) void k_refb_choose(RItems it) {
+  const int item = find_item(it, blockIdx.x);
+  const int job = it.job[item];
+  const RJob &jb = it.jobs[job];
+  const long blk = (long)(blockIdx.x - it.wg_start[item])*kWave + threadIdx.x;
+  if (blk >= jb.nblocks) return;
+  refb_choose_band<N, PRICE>(it, job, jb, it.band[item], blk, nullptr);
+}
+
+/* The listed bands of size N decided again with the host's rates. */
+template <int N>
+__global__ __launch_bounds__(kWave) void k_refb_choose_list(RItems it, const PUncR *list, int count) {
+  const int i = blockIdx.x*kWave + threadIdx.x;
+  if (i >= count) return;
+  const PUncR *e = list + i;
+  const RJob &jb = it.jobs[e->job];
+  if (jb.off[e->band + 1] - jb.off[e->band] != N) return;
+  refb_choose_band<N, 2>(it, e->job, jb, e->band, e->blk, e->rate);
+}
+
 /* Eight consecutive coding positions of one block per thread: a chunk never
    straddles a band (bands start at 1, 16, 24, 32, 64, ...; the chunk at 0 holds
    the DC, which is passed through, and the first seven coefficients of band 0).
@@ -1453,6 +1534,7 @@ odhip_device_once g_tables_once;
 /* test hooks (odhip_pvq_ref_set_theta_margin): process-wide, set before any call */
 double g_margin = kDefaultMargin;
 int g_perturb = 0;
+double g_price_tol_scale = 1.;   /* odhip_pvq_ref_price_set_tol_scale */
 
 int upload_tables_now(void) {
   ODHIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(kRScanXY), OD_SCAN_XY, sizeof(OD_SCAN_XY)));
@@ -1539,6 +1621,10 @@ constexpr int kProfSlots = 256;
 constexpr int kTableSlots = 8;
 struct RefState {
   RJob *d_jobs = nullptr;            /* kTableSlots device job tables of kMaxJobs   */
+  unsigned *d_pcount = nullptr;      /* priced choice: bands too close to call ...  */
+  PUncR *d_plist = nullptr;          /* ... and their list                          */
+  unsigned *pcount_host = nullptr;   /* pinned mirror of the counter                */
+  hipEvent_t pcount_event = nullptr;
   RJob host_tab[kTableSlots][kMaxJobs];
   int tab_n[kTableSlots] = {};
   unsigned long tab_stamp[kTableSlots] = {};
@@ -1562,6 +1648,10 @@ struct RefState {
   hipEvent_t prof_ev[kProfSlots][2];
   ~RefState() {
     if (d_jobs) (void)hipFree(d_jobs);
+    if (d_pcount) (void)hipFree(d_pcount);
+    if (d_plist) (void)hipFree(d_plist);
+    if (pcount_host) (void)hipHostFree(pcount_host);
+    if (pcount_event) (void)hipEventDestroy(pcount_event);
     if (d_unc_count) (void)hipFree(d_unc_count);
     if (d_unc) (void)hipFree(d_unc);
     if (d_sort) (void)hipFree(d_sort);
@@ -1592,6 +1682,9 @@ int ref_state(RefState **out) {
     ODHIP_TRY(hipMalloc((void **)&st->d_unc, sizeof(Unc)*kUncCap));
     ODHIP_TRY(hipMalloc((void **)&st->d_sort, sizeof(unsigned)*2*kMaxItems*kSortBins));
     ODHIP_TRY(hipMemset(st->d_unc_count, 0, sizeof(unsigned)));
+    ODHIP_TRY(hipMalloc((void **)&st->d_pcount, sizeof(unsigned)));
+    ODHIP_TRY(hipMalloc((void **)&st->d_plist, sizeof(PUncR)*kPUncCap));
+    ODHIP_TRY(hipMemset(st->d_pcount, 0, sizeof(unsigned)));
     ODHIP_TRY(hipMemset(st->d_sort, 0, sizeof(unsigned)*2*kMaxItems*kSortBins));
   }
   st->serial = ctx->serial != 0;
@@ -1665,6 +1758,9 @@ void items_begin(RItems &it, const RefState &st, double lambda) {
   it.unc = st.d_unc;
   it.rhist = st.d_sort;
   it.rcursor = st.d_sort + kMaxItems*kSortBins;
+  it.pcount = st.d_pcount;
+  it.plist = st.d_plist;
+  it.tol_scale = g_price_tol_scale;
 }
 
 void items_add(RItems &it, int job, int band, long wgs) {
@@ -1955,7 +2051,7 @@ extern "C" int odhip_pvq_ref_resolve(const odhip_pvq_refjob *jobs, int njobs,
 
 namespace {
 int ref_select(const odhip_pvq_refjob *jobs, int njobs, double pvq_norm_lambda, hipStream_t s,
- bool synth);
+ bool synth, bool price = false);
 }  // namespace
 
 extern "C" int odhip_pvq_ref_select_synth_multi(const odhip_pvq_refjob *jobs, int njobs,
@@ -1970,7 +2066,7 @@ extern "C" int odhip_pvq_ref_choose_multi(const odhip_pvq_refjob *jobs, int njob
 
 namespace {
 int ref_select(const odhip_pvq_refjob *jobs, int njobs, double pvq_norm_lambda, hipStream_t s,
- bool synth) {
+ bool synth, bool price) {
   REF_STATE_OR_RETURN(st);
   RJob host[kMaxJobs];
   int rc = stage_jobs(st, jobs, njobs, synth ? 1 : 2, host, s);
@@ -1982,16 +2078,32 @@ int ref_select(const odhip_pvq_refjob *jobs, int njobs, double pvq_norm_lambda, 
        *host[j].h, s));
     }
   }
+  if (price) ODHIP_TRY(hipMemsetAsync(st.d_pcount, 0, sizeof(unsigned), s));
   RItems it;
   static const int sizes[4] = {128, 32, 15, 8};
   for (int i = 0; i < 4; i++) {
     items_all(it, st, host, njobs, pvq_norm_lambda, sizes[i]);
     if (!it.nitems) continue;
     const unsigned grid = it.wg_start[it.nitems];
-    if (sizes[i] == 128) k_refb_choose<128><<<grid, kWave, 0, s>>>(it);
-    else if (sizes[i] == 32) k_refb_choose<32><<<grid, kWave, 0, s>>>(it);
-    else if (sizes[i] == 15) k_refb_choose<15><<<grid, kWave, 0, s>>>(it);
-    else k_refb_choose<8><<<grid, kWave, 0, s>>>(it);
+    if (price) {
+      if (sizes[i] == 128) k_refb_choose<128, 1><<<grid, kWave, 0, s>>>(it);
+      else if (sizes[i] == 32) k_refb_choose<32, 1><<<grid, kWave, 0, s>>>(it);
+      else if (sizes[i] == 15) k_refb_choose<15, 1><<<grid, kWave, 0, s>>>(it);
+      else k_refb_choose<8, 1><<<grid, kWave, 0, s>>>(it);
+    }
+    else if (sizes[i] == 128) k_refb_choose<128, 0><<<grid, kWave, 0, s>>>(it);
+    else if (sizes[i] == 32) k_refb_choose<32, 0><<<grid, kWave, 0, s>>>(it);
+    else if (sizes[i] == 15) k_refb_choose<15, 0><<<grid, kWave, 0, s>>>(it);
+    else k_refb_choose<8, 0><<<grid, kWave, 0, s>>>(it);
+  }
+  if (price) {
+    if (!st.pcount_host) {
+      ODHIP_TRY(hipHostMalloc((void **)&st.pcount_host, sizeof(unsigned), hipHostMallocDefault));
+      ODHIP_TRY(hipEventCreateWithFlags(&st.pcount_event, hipEventDisableTiming));
+    }
+    *st.pcount_host = 0xffffffffu;
+    ODHIP_TRY(hipMemcpyAsync(st.pcount_host, st.d_pcount, sizeof(unsigned), hipMemcpyDeviceToHost, s));
+    ODHIP_TRY(hipEventRecord(st.pcount_event, s));
   }
   if (!synth) return odhip_check_launch();
   items_begin(it, st, pvq_norm_lambda);
@@ -2000,3 +2112,92 @@ int ref_select(const odhip_pvq_refjob *jobs, int njobs, double pvq_norm_lambda, 
   return odhip_check_launch();
 }
 }  // namespace
+
+/* The choice alone with od_pvq_rate's closed form (speed > 0) evaluated on the device from
+   every searched candidate's pulses (see refb_choose_band); odhip_pvq_ref_choose_priced_resolve
+   waits for the stream and settles the bands whose decision was too close to take from the
+   device's log with the host libm.  Returns how many (normally 0) or a negative code. */
+extern "C" int odhip_pvq_ref_choose_priced_multi(const odhip_pvq_refjob *jobs, int njobs,
+ double pvq_norm_lambda, odhip_stream stream) {
+  return ref_select(jobs, njobs, pvq_norm_lambda, (hipStream_t)stream, false, true);
+}
+
+extern "C" int odhip_pvq_ref_choose_priced_resolve(const odhip_pvq_refjob *jobs, int njobs,
+ double pvq_norm_lambda, odhip_stream stream) {
+  hipStream_t s = (hipStream_t)stream;
+  REF_STATE_OR_RETURN(st);
+  if (!st.pcount_event) return ODHIP_EINVAL;
+  ODHIP_TRY(hipEventSynchronize(st.pcount_event));
+  if (*st.pcount_host == 0) return 0;
+  ODHIP_TRY(hipStreamSynchronize(s));
+  unsigned count = 0;
+  ODHIP_TRY(hipMemcpy(&count, st.d_pcount, sizeof(count), hipMemcpyDeviceToHost));
+  if (count == 0) return 0;
+  if (count > (unsigned)kPUncCap) {
+    fprintf(stderr, "libdaalahip: %u priced bands inside the decision margin exceed the list (%d)\n", count,
+     kPUncCap);
+    return ODHIP_EFAULT;
+  }
+  RJob host[kMaxJobs];
+  int rc = stage_jobs(st, jobs, njobs, 2, host, s);
+  if (rc) return rc;
+  PUncR *list = (PUncR *)malloc(sizeof(PUncR)*count);
+  if (!list) return ODHIP_EFAULT;
+  if (hipMemcpy(list, st.d_plist, sizeof(PUncR)*count, hipMemcpyDeviceToHost) != hipSuccess) rc = ODHIP_EFAULT;
+  for (unsigned i = 0; i < count && !rc; i++) {
+    PUncR &e = list[i];
+    if (e.job < 0 || e.job >= njobs) {
+      rc = ODHIP_EINVAL;
+      break;
+    }
+    const RJob &jb = host[e.job];
+    const int n = jb.off[e.band + 1] - jb.off[e.band];
+    const long B = jb.nblocks;
+    odhip_pvq_refband rec;
+    if (hipMemcpy(&rec, jb.rec + (long)e.blk*jb.nb_bands + e.band, sizeof(rec), hipMemcpyDeviceToHost)
+     != hipSuccess) {
+      rc = ODHIP_EFAULT;
+      break;
+    }
+    const int4 *head = reinterpret_cast<const int4 *>(jb.items) + (long)e.band*kSlots*B + e.blk;
+    const int4 *tail = head + (long)jb.nb_bands*kSlots*B;
+    for (int c = 0; c <= kSlots; c++) e.rate[c] = 0;
+    for (int idx = 0; idx < rec.nitems && idx < kSlots && !rc; idx++) {
+      int4 hd;
+      int4 tl;
+      if (hipMemcpy(&hd, head + (long)idx*B, sizeof(hd), hipMemcpyDeviceToHost) != hipSuccess
+       || hipMemcpy(&tl, tail + (long)idx*B, sizeof(tl), hipMemcpyDeviceToHost) != hipSuccess) {
+        rc = ODHIP_EFAULT;
+        break;
+      }
+      if (!(tl.z & ODHIP_REFITEM_SEARCHED)) continue;
+      const bool with_ref = idx < rec.ntheta;
+      const int sum = (int)((unsigned)tl.z >> ODHIP_REFITEM_MOMENT_SHIFT);
+      e.rate[1 + idx] = odq_pvq_rate_fast_host(sum, hd.w, n, hd.x, with_ref ? rec.icgr : 0,
+       with_ref ? hd.y : -1, with_ref ? hd.z : 0, jb.is_keyframe, jb.pli);
+    }
+  }
+  PUncR *d_list = nullptr;
+  if (!rc && (hipMalloc((void **)&d_list, sizeof(PUncR)*count) != hipSuccess
+   || hipMemcpy(d_list, list, sizeof(PUncR)*count, hipMemcpyHostToDevice) != hipSuccess)) {
+    rc = ODHIP_EFAULT;
+  }
+  free(list);
+  if (!rc) {
+    RItems it;
+    items_begin(it, st, pvq_norm_lambda);
+    const unsigned grid = (count + kWave - 1)/kWave;
+    k_refb_choose_list<128><<<grid, kWave, 0, s>>>(it, d_list, (int)count);
+    k_refb_choose_list<32><<<grid, kWave, 0, s>>>(it, d_list, (int)count);
+    k_refb_choose_list<15><<<grid, kWave, 0, s>>>(it, d_list, (int)count);
+    k_refb_choose_list<8><<<grid, kWave, 0, s>>>(it, d_list, (int)count);
+    rc = odhip_check_launch();
+    if (hipStreamSynchronize(s) != hipSuccess) rc = ODHIP_EFAULT;
+  }
+  if (d_list) (void)hipFree(d_list);
+  return rc ? rc : (int)count;
+}
+
+extern "C" void odhip_pvq_ref_price_set_tol_scale(double scale) {
+  g_price_tol_scale = scale > 0 ? scale : 1.;
+}

@@ -320,7 +320,8 @@ typedef struct {
   double dist0;        /* distortion of the null (gain 0) candidate                */
   int32_t yy[2];       /* sum of squared pulses of the candidate                   */
   double dist[2];      /* distortion of the candidate                              */
-  uint8_t reserved1[8];
+  int32_t moment[2];   /* SUM i*|y_i| of the candidate's pulses: od_pvq_rate's
+                          centre-of-mass sum (src/pvq_encoder.c:258-259)           */
 } odhip_pvq_band;
 
 typedef struct {
@@ -563,6 +564,9 @@ typedef struct {
 #define ODHIP_REFITEM_WITH_REF 2    /* theta candidate                                  */
 #define ODHIP_REFITEM_K_RANGE 4     /* K above ODHIP_PVQ_MAX_K: pulses would not fit the
                                        int16 vectors; reported, never searched or chosen */
+#define ODHIP_REFITEM_MOMENT_SHIFT 8 /* flags >> 8: SUM i*|y_i| of the candidate's pulses
+                                       (od_pvq_rate's centre-of-mass sum, :258-259; below
+                                       2^24 for n <= 128, K <= 32767), 0 when not searched */
 typedef struct {
   int32_t gain;           /* i                                                  */
   int32_t theta;          /* j, -1 for a no-reference candidate                 */
@@ -570,7 +574,7 @@ typedef struct {
   int32_t k;
   int32_t qcg;
   int32_t qtheta;
-  int32_t flags;          /* ODHIP_REFITEM_*                                    */
+  int32_t flags;          /* ODHIP_REFITEM_* in bits 0-7, the pulse moment above  */
   int32_t yslot;          /* slot holding this candidate's pulses (a candidate
                              with the K of its predecessor shares its slot,
                              :539-544); -1 = all zero                           */
@@ -758,6 +762,38 @@ void odhip_cache_stats(const odhip_frame_cache *c, long *hits, long *misses);
 void odhip_install_cached_dct_vtbl(odhip_dct_func_2d fdct_2d[ODHIP_NBSIZES],
  odhip_dct_func_2d idct_2d[ODHIP_NBSIZES]);
 
+/* ---- pricing on the device: od_pvq_rate's closed form (the
+   speed > 0 half) --------------------------------------------------------------------
+
+   od_pvq_rate (src/pvq_encoder.c:247-287) has two modes.  speed == 0 (the default
+   complexity) runs the real codeword coder on a copy of the live adaptive context:
+   sequential host state, not batchable.  speed > 0 - what the
+   block-size RDO pass prices with below complexity 5, src/encode.c:1359 - is a closed
+   form in (K, n, the centre of mass of the pulse vector, theta terms): a pure function of
+   the candidate.  odhip_pvq_choose_priced_multi / odhip_pvq_ref_choose_priced_multi are
+   odhip_pvq_choose_multi / odhip_pvq_ref_choose_multi with that rate evaluated ON THE
+   DEVICE from the pulses the searches stored - no rate table, no candidate export.
+
+   Its two libm calls (log) are not reproducible bit for bit on the device; the costs
+   they enter are compared with each other, so a decision is taken from the device only
+   when the two costs differ by more than 1e-10 of their magnitude (the two logs agree to
+   ~1e-16).  A band with a closer decision is listed; *_priced_resolve (same jobs, same
+   stream, after the *_priced_multi call) waits for the count of listed bands only -
+   normally 0 - and otherwise recomputes those bands' rates with the HOST libm, the
+   function the reference calls, and decides them again.  It returns the number of
+   bands re-decided; consumers of the choice records enqueued before it must then be
+   repeated.  *_price_set_tol_scale multiplies the margin (test hook). */
+int odhip_pvq_choose_priced_multi(const odhip_pvq_job *jobs, int njobs, double pvq_norm_lambda,
+ odhip_stream stream);
+int odhip_pvq_choose_priced_resolve(const odhip_pvq_job *jobs, int njobs, double pvq_norm_lambda,
+ odhip_stream stream);
+void odhip_pvq_price_set_tol_scale(double scale);
+int odhip_pvq_ref_choose_priced_multi(const odhip_pvq_refjob *jobs, int njobs, double pvq_norm_lambda,
+ odhip_stream stream);
+int odhip_pvq_ref_choose_priced_resolve(const odhip_pvq_refjob *jobs, int njobs, double pvq_norm_lambda,
+ odhip_stream stream);
+void odhip_pvq_ref_price_set_tol_scale(double scale);
+
 /* ---- frame cache, second half: the batched band stage behind pvq_theta ------------
 
    odhip_cache_load_bands (after odhip_cache_load_plane(pli), same frame): the
@@ -850,6 +886,10 @@ typedef struct {
   int pic_h;
   int chroma_cfl;
   int serial;
+  int price;                    /* 1: the choice prices every candidate with od_pvq_rate's
+                                   closed form on the device (odhip_pvq_*choose_priced_*);
+                                   0: on distortion alone, or with rate tables             */
+  int reserved;
   double pvq_norm_lambda;       /* OD_PVQ_LAMBDA, src/pvq.h:49 */
   const odhip_quant *quant;
 } odhip_pipe_config;
@@ -887,6 +927,7 @@ int odhip_pipe_timings(odhip_pipe *p, double avg_ms[ODHIP_PIPE_NSTAGES], int cou
 int odhip_pipe_search_timings(odhip_pipe *p, int chroma, float *ms, int max_n);
 int odhip_pipe_time_pyramid(odhip_pipe *p, int n, double *avg_ms);
 long odhip_pipe_theta_reruns(const odhip_pipe *p);
+long odhip_pipe_price_reruns(const odhip_pipe *p);
 double odhip_pipe_host_wait_ms(const odhip_pipe *p);
 
 #ifdef __cplusplus

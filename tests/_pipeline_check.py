@@ -12,7 +12,10 @@ gpu_priced_frame()  the same picture through an F = 1 odhip_pipe stage by stage,
                     searched is priced with the reference's od_pvq_rate (closed form)
                     and the rate tables go back for the choice - the split of
                     pvq_theta DESIGN.md describes, in batch form.
-Both must agree bit for bit on every reconstructed pixel of every level."""
+gpu_device_priced() the same picture(s) through odhip_pipe_step with price = 1: the
+                    closed form evaluated on the device inside the choice kernels, one C
+                    call per step, nothing in between.
+All must agree bit for bit on every reconstructed pixel of every level."""
 import ctypes
 import time
 
@@ -153,6 +156,31 @@ def gpu_priced_frame(D, qt, pics, pic_w, pic_h, chroma_cfl=True, lam=0.147, fram
     finally:
         pipe.destroy()
     return out
+
+
+def gpu_device_priced(D, qt, pics, pic_w, pic_h, chroma_cfl=True, lam=0.147, frames=None, serial=False,
+                      steps=None):
+    """The F pictures through `steps` odhip_pipe_step calls (each codes all F) of a price=1
+    pipe.  Returns (recon like gpu_priced_frame(), bands the host libm re-decided)."""
+    F = frames or 1
+    luma = np.ascontiguousarray(pics[0]).reshape(F, pic_h, pic_w)
+    chroma = np.concatenate([np.ascontiguousarray(pics[1]).reshape(F, pic_h // 2, pic_w // 2),
+                             np.ascontiguousarray(pics[2]).reshape(F, pic_h // 2, pic_w // 2)])
+    pipe = D.Pipe(qt, F, pic_w, pic_h, chroma_cfl=chroma_cfl, serial=serial, pvq_norm_lambda=lam,
+                  price=True)
+    try:
+        pipe.set_pictures(luma, chroma)
+        for _ in range(steps or 2):
+            pipe.step()
+        pipe.flush()
+        pipe.sync()
+        W, H = pipe.W, pipe.H
+        out = [[pipe.read(D.BUF_RECON, 0, bs).reshape(F, H, W) for bs in range(5)],
+               [pipe.read(D.BUF_RECON, 1, bs).reshape(2 * F, H // 2, W // 2) for bs in range(4)]]
+        reruns = pipe.price_reruns()
+    finally:
+        pipe.destroy()
+    return out, reruns
 
 
 def compare_frame(gpu, cpu, frame=0, frames=1):

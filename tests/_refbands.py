@@ -186,6 +186,8 @@ def compare_bands(hip, job, traces, mm):
                 mm.check("item.y", not wy.any(), wi)
             else:
                 mm.check("item.y", np.array_equal(y[slot, blk, off:off + nn].astype(np.int32), wy), wi)
+            # the centre-of-mass sum od_pvq_rate prices with, kept above the flag bits
+            mm.check("item.moment", fl >> hip.REFITEM_MOMENT_SHIFT == int((np.arange(nn) * np.abs(wy)).sum()), wi)
 
 
 def host_rates(job, traces, is_keyframe, pli):

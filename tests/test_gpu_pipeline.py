@@ -7,7 +7,11 @@
      (round 1's shared edge-strip scratch made this fail silently);
 (ii) a WHOLE 1080p frame (every block of every level of all three planes) through the
      GPU stages with the host pricing every candidate in between equals the compiled
-     reference's pvq_theta path pixel for pixel, for both synthetic content types."""
+     reference's pvq_theta path pixel for pixel, for both synthetic content types;
+(iii) the same whole frames through price = 1 steps - od_pvq_rate's closed form evaluated
+     on the device inside the choice kernels, one C call per step, the configuration
+     bench.py times - equal the compiled reference too, also with the decision margin
+     forced wide so that the host-libm path re-decides bands."""
 import os
 import sys
 
@@ -48,14 +52,14 @@ def _dump(D, pipe, cfl):
     return out
 
 
-@pytest.mark.parametrize("cfl", [True, False])
-def test_pipelined_step_equals_serial_step_1080p(cfl):
+@pytest.mark.parametrize("cfl,price", [(True, False), (False, False), (True, True), (False, True)])
+def test_pipelined_step_equals_serial_step_1080p(cfl, price):
     import daala_amd as D
     D.init(0)
     b = _bench()
     qt = D.QuantTables.load()
     F = 3
-    pipes = [D.Pipe(qt, F, PIC_W, PIC_H, chroma_cfl=cfl, serial=s) for s in (False, True)]
+    pipes = [D.Pipe(qt, F, PIC_W, PIC_H, chroma_cfl=cfl, serial=s, price=price) for s in (False, True)]
     try:
         for rnd, gen in enumerate((b.synth_frame_np, b.natural_like_frame_np)):
             luma, chroma = _pictures(gen, F, 77 + rnd)
@@ -90,6 +94,51 @@ def test_whole_frame_equals_compiled_reference_1080p(content):
     assert blocks == b.blocks_per_frame()
     gpu = C.gpu_priced_frame(D, qt, pics, PIC_W, PIC_H, chroma_cfl=True)
     assert C.compare_frame(gpu, cpu) == []
+
+
+@pytest.mark.skipif(ref() is None, reason="oracle/_ref (the compiled reference) not present")
+@pytest.mark.parametrize("content", ["checker", "natural"])
+def test_device_priced_steps_equal_compiled_reference_1080p(content):
+    """(iii): two 1080p pictures per step, pipelined, priced on the device."""
+    import daala_amd as D
+    import _pipeline_check as C
+    D.init(0)
+    b = _bench()
+    qt = D.QuantTables.load()
+    F = 2
+    fr = [b.picture_planes(b.CONTENT[content](3 + i, 4321)) for i in range(F)]
+    pics = [np.stack([f[p] for f in fr]) for p in range(3)]
+    gpu, reruns = C.gpu_device_priced(D, qt, pics, PIC_W, PIC_H, chroma_cfl=True, frames=F, steps=3)
+    for i in range(F):
+        cpu, _, _ = C.cpu_frame(qt, fr[i], PIC_W, PIC_H, chroma_cfl=True)
+        assert C.compare_frame(gpu, cpu, frame=i, frames=F) == [], (content, i)
+    print("%s: %d priced decisions left to the host libm in 3 steps of %d frames" % (content, reruns, F))
+
+
+@pytest.mark.skipif(ref() is None, reason="oracle/_ref (the compiled reference) not present")
+def test_device_priced_host_libm_path_forced():
+    """With the margin scaled up every contested decision is listed and re-decided from
+    rates the HOST libm computes: same pixels, and the path really ran."""
+    import daala_amd as D
+    import _pipeline_check as C
+    D.init(0)
+    b = _bench()
+    qt = D.QuantTables.for_quality(40)
+    full = b.natural_like_frame_np(5, 99)
+    pw, ph = 312, 180
+    pics = [full[0][:ph, :pw], full[1][:ph // 2, :pw // 2], full[2][:ph // 2, :pw // 2]]
+    try:
+        for cfl in (False, True):
+            cpu, _, _ = C.cpu_frame(qt, pics, pw, ph, chroma_cfl=cfl)
+            for scale in (1., 1e7, 1e12):
+                D.set_price_tol_scale(scale)
+                for serial in (False, True):
+                    gpu, reruns = C.gpu_device_priced(D, qt, pics, pw, ph, chroma_cfl=cfl, serial=serial)
+                    assert C.compare_frame(gpu, cpu) == [], (cfl, scale, serial)
+                    if scale > 1e10:
+                        assert reruns > 100, reruns
+    finally:
+        D.set_price_tol_scale(1.)
 
 
 @pytest.mark.skipif(ref() is None, reason="oracle/_ref (the compiled reference) not present")

@@ -127,6 +127,7 @@ def test_band_stage_matches_oracle(hip, pli, dec):
                             assert c["dist"][blk, band, slot] == cnd.dist
                             yy = np.array(cnd.y[:m], np.int32)
                             assert np.array_equal(c["y"][slot, blk, a:b], yy)
+                            assert c["moment"][blk, band, slot] == int((np.arange(m) * np.abs(yy)).sum())
                             if cnd.dist <= best_cost:
                                 best_cost, best_qg, best_y = cnd.dist, cnd.gain, yy
                     assert qg[blk, band] == best_qg
