@@ -697,6 +697,38 @@ int odhip_dering_planes(int16_t *d_y, const int16_t *d_x, int stride, int nhsb, 
  long bskip_plane_stride, const int32_t *d_thresholds, int ncand, int overlap, int coeff_shift,
  odhip_stream stream);
 
+/* ---- the deringing level search of a frame behind od_dering -----------------------
+
+   After coding a frame the reference searches the deringing level superblock by
+   superblock (src/encode.c:2697-2832): od_dering on the luma superblock for each of
+   the five non-zero levels, then on the three planes with the level chosen - up to
+   4 080 calls per 1080p frame, every one reading the same unfiltered copy of the frame
+   (state->etmp) and skip map.  An odhip_dering_cache serves them from batched passes:
+   the first call with a (plane, threshold) pair filters every superblock of the plane
+   in one launch (odhip_dering_planes) and keeps the filtered plane on the host; that
+   call and all later ones with the same pair copy their superblock out (and, for luma,
+   the directions od_dering returns in dir[][]).  The level decision, its cost and the
+   adaptation stay in the encoder.
+
+   odhip_dering_cache_begin marks a new frame (the planes and the skip map have been
+   rewritten: where the encoder copies ctmp to etmp, src/encode.c:2700-2707).
+   odhip_dering_cache_call has od_dering's arguments minus the function table; x must
+   point into the plane at the superblock (as the encoder's call sites do, :2787,:2826)
+   and bskip into the skip map likewise.  Glue in a reference build:
+     odhip_dering_cache_begin(cache);                                    at :2697
+     #define od_dering(vtbl, ...) odhip_dering_cache_call(cache, __VA_ARGS__)
+   Partial superblocks and chroma calls that precede every luma call of the frame go
+   to the per-call path od_dering_hip.  One cache per encoder (it binds the thread's
+   current odhip_ctx at creation). */
+typedef struct odhip_dering_cache odhip_dering_cache;
+odhip_dering_cache *odhip_dering_cache_create(void);
+void odhip_dering_cache_destroy(odhip_dering_cache *c);
+void odhip_dering_cache_begin(odhip_dering_cache *c);
+int odhip_dering_cache_call(odhip_dering_cache *c, int16_t *y, int ystride, const int16_t *x, int xstride,
+ int nhb, int nvb, int sbx, int sby, int nhsb, int nvsb, int xdec, int dir[8][8], int pli,
+ unsigned char *bskip, int skip_stride, int threshold, int overlap, int coeff_shift);
+void odhip_dering_cache_stats(const odhip_dering_cache *c, long *launches, long *served);
+
 /* ---- od_compute_dist: the block-size RDO's distortion ----------
 
    od_compute_dist(enc, x, y, n) (src/encode.c:1202-1226, od_compute_dist_8x8

@@ -204,9 +204,31 @@ static int interpose_decode_check(od_coeff *c, int stride, int nhsb, int nvsb, i
   return 1;
 }
 
+/* ---- the deringing level search from batched passes (odhip_dering_cache) ------------
+   ODHIP_INTERPOSE_DERING_CACHE=1: every od_dering call of the encoder's level search
+   (src/encode.c:2787,:2826) is served by odhip_dering_cache_call; the frame boundary is
+   the superblock-edge postfilter the encoder runs just before the search (:2670-2677) -
+   in a reference build that is one line at :2697. */
+static odhip_dering_cache *g_dering_cache;
+long odhip_interposed_dering[2];      /* batched launches, calls served */
+
+static int dering_cache_enabled(void) {
+  static int v = -1;
+  if (v < 0) {
+    const char *e = getenv("ODHIP_INTERPOSE_DERING_CACHE");
+    v = e && e[0] == '1';
+  }
+  return v;
+}
+
+void odhip_interpose_dering_stats(void) {
+  odhip_dering_cache_stats(g_dering_cache, &odhip_interposed_dering[0], &odhip_interposed_dering[1]);
+}
+
 void od_apply_postfilter_frame_sbs(od_coeff *c, int stride, int nhsb, int nvsb, int xdec,
  int ydec, int q, unsigned char *skip, int skip_stride) {
   odhip_interposed_calls[3]++;
+  if (dering_cache_enabled() && g_dering_cache) odhip_dering_cache_begin(g_dering_cache);
   if (g_decode_check && g_dec) {
     typedef void (*fn)(od_coeff *, int, int, int, int, int, int, unsigned char *, int);
     static fn next;
@@ -447,6 +469,50 @@ void od_dering(const void *vtbl, int16_t *y, int ystride, const int16_t *x, int 
  int sbx, int sby, int nhsb, int nvsb, int xdec, int dir[8][8], int pli, unsigned char *bskip,
  int skip_stride, int threshold, int overlap, int coeff_shift) {
   odhip_interposed_calls[5]++;
+  if (dering_cache_enabled()) {
+    if (!g_dering_cache) {
+      if (odhip_init(0) != 0 || !(g_dering_cache = odhip_dering_cache_create())) {
+        fprintf(stderr, "interpose: odhip_dering_cache_create failed\n");
+        abort();
+      }
+    }
+    if (odhip_dering_cache_call(g_dering_cache, y, ystride, x, xstride, nhb, nvb, sbx, sby, nhsb, nvsb, xdec,
+     dir, pli, bskip, skip_stride, threshold, overlap, coeff_shift) != 0) {
+      fprintf(stderr, "interpose: odhip_dering_cache_call failed (no CPU fallback)\n");
+      abort();
+    }
+    if (getenv("ODHIP_DERING_CHECK")) {
+      /* every served superblock against the reference's own od_dering */
+      typedef void (*fn)(const void *, int16_t *, int, const int16_t *, int, int, int, int, int, int, int, int,
+       int (*)[8], int, unsigned char *, int, int, int, int);
+      static fn next;
+      int16_t want[64*64];
+      int wdir[8][8];
+      const int n = 64 >> xdec;
+      int i;
+      int j;
+      if (!next) next = NEXT(fn, "od_dering");
+      for (i = 0; i < 8; i++) for (j = 0; j < 8; j++) wdir[i][j] = dir[i][j];
+      next(vtbl, want, n, x, xstride, nhb, nvb, sbx, sby, nhsb, nvsb, xdec, wdir, pli, bskip, skip_stride,
+       threshold, overlap, coeff_shift);
+      for (i = 0; i < n; i++) {
+        for (j = 0; j < n; j++) {
+          if (want[i*n + j] != y[i*ystride + j]) {
+            fprintf(stderr, "interpose: dering cache mismatch pli %d sb (%d, %d) thr %d at (%d, %d)\n", pli, sbx,
+             sby, threshold, i, j);
+            abort();
+          }
+        }
+      }
+      for (i = 0; i < 8; i++) for (j = 0; j < 8; j++) {
+        if (wdir[i][j] != dir[i][j]) {
+          fprintf(stderr, "interpose: dering cache direction mismatch\n");
+          abort();
+        }
+      }
+    }
+    return;
+  }
   if (passthrough()) {
     typedef void (*fn)(const void *, int16_t *, int, const int16_t *, int, int, int, int, int, int, int, int,
      int (*)[8], int, unsigned char *, int, int, int, int);

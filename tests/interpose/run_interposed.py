@@ -78,6 +78,11 @@ if interpose in (2, 3):
 if interpose == 3:
     arr = (ctypes.c_long * 4).in_dll(ipo, "odhip_interposed_theta")
     theta = [arr[i] for i in range(4)]
+dering = [0, 0]
+if ipo is not None and os.environ.get("ODHIP_INTERPOSE_DERING_CACHE") == "1":
+    ipo.odhip_interpose_dering_stats()
+    arr = (ctypes.c_long * 2).in_dll(ipo, "odhip_interposed_dering")
+    dering = [arr[0], arr[1]]      # batched launches, od_dering calls served from them
 import hashlib
 pkt_digest = None
 if os.environ.get("PACKET_DIGEST") == "1":
@@ -90,5 +95,6 @@ if os.environ.get("PACKET_DIGEST") == "1":
         pos += sizes[i]
     pkt_digest = hh.hexdigest()
 print(json.dumps({"digest": pkt_digest, "packets": hashlib.sha256(bytes(out[:total])).hexdigest(),
-                  "sizes": [sizes[i] for i in range(n)], "calls": calls, "cache": stats, "theta": theta, "gpu_batch_ms": gpu_ms,
+                  "sizes": [sizes[i] for i in range(n)], "calls": calls, "cache": stats, "theta": theta, "dering": dering,
+                  "gpu_batch_ms": gpu_ms,
                   "encode_seconds": seconds}))

@@ -160,3 +160,38 @@ def test_batched_band_stage_1080p_frame_byte_identical():
           "both ways %.1f ms) vs %.2f s plain C"
           % (served, searches, with_ref, res[3]["encode_seconds"], res[3]["gpu_batch_ms"],
              res[0]["encode_seconds"]))
+
+
+@pytest.mark.skipif(ref() is None, reason="oracle/_ref not present")
+def test_dering_level_search_from_batched_passes_is_byte_identical():
+    """SURVEY.md 8(f) rank 1 at the frame level: every od_dering call of the encoder's
+    deringing level search (five luma levels per superblock, then the three planes with
+    the level chosen, src/encode.c:2697-2832) served by odhip_dering_cache - one launch per
+    (plane, threshold) pair filters every superblock of the plane.  Packets must be
+    byte-identical; with ODHIP_DERING_CHECK every served superblock and direction array is
+    also compared with the reference's own od_dering."""
+    import json
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+
+    def run(mode, w, h, **env):
+        e = dict(os.environ)
+        e.update({k: str(v) for k, v in env.items()})
+        p = subprocess.run([sys.executable, os.path.join(here, "interpose", "run_interposed.py"),
+                            str(mode), str(w), str(h)], capture_output=True, text=True, timeout=1500, env=e)
+        assert p.returncode == 0, p.stderr[-3000:]
+        return json.loads(p.stdout.strip().splitlines()[-1])
+
+    for (w, h, nframes, quality) in ((320, 192, 2, 20), (180, 116, 2, 40), (256, 128, 1, 5)):
+        env = dict(NFRAMES=nframes, QUALITY=quality, COMPLEXITY=7, ODHIP_INTERPOSE_PASSTHROUGH=1)
+        plain = run(0, w, h, **env)
+        cached = run(1, w, h, ODHIP_INTERPOSE_DERING_CACHE=1, ODHIP_DERING_CHECK=1, **env)
+        assert cached["sizes"] == plain["sizes"], (w, h)
+        assert cached["packets"] == plain["packets"], (w, h, quality)
+        launches, served = cached["dering"]
+        assert served > 0 and launches > 0, cached["dering"]
+        # one launch per (plane, threshold) pair per frame, at most 5 + 2 * 5
+        assert launches <= 15 * nframes, cached["dering"]
+        assert served == cached["calls"][5], (cached["dering"], cached["calls"])
