@@ -211,7 +211,7 @@ def _pin(core):
         return False
 
 
-def cpu_leg(qt, chroma_cfl, first_pictures, min_frames=5, min_seconds=10.0, max_frames=24):
+def cpu_leg(qt, chroma_cfl, first_pictures, min_frames=5, min_seconds=10.0, max_frames=24, lib=None):
     """The same per-block work on ONE pinned host core with the reference's own C
     functions (oracle/_ref): whole pictures of the bench generator, one timing per
     picture, until >= min_frames pictures and >= min_seconds of CPU work.  The first
@@ -226,7 +226,7 @@ def cpu_leg(qt, chroma_cfl, first_pictures, min_frames=5, min_seconds=10.0, max_
     n = 0
     while n < max_frames and (n < min_frames or busy < min_seconds):
         pics = first_pictures if n == 0 else picture_planes(GENERATOR(1000 + n, 1234))
-        recon, blocks, dt = C.cpu_frame(qt, pics, PIC_W, PIC_H, chroma_cfl=chroma_cfl)
+        recon, blocks, dt = C.cpu_frame(qt, pics, PIC_W, PIC_H, chroma_cfl=chroma_cfl, lib=lib)
         if n == 0:
             first = recon
         rates.append(blocks / dt)
@@ -261,6 +261,22 @@ def cpu_baseline(D, qt, chroma_cfl, args, gpu_frame0, timed_recon=None):
     prev = os.sched_getaffinity(0) if hasattr(os, "sched_getaffinity") else None
     pinned = _pin(0)
     rates, blocks, recon0, busy = cpu_leg(qt, chroma_cfl, gpu_frame0)
+    # the x86-intrinsics build of the reference (BASELINE.md section 3 asks for both): same
+    # pinned core, median of 5 pictures; its reconstruction of frame 0 must equal the C build's
+    simd = None
+    from _libs import ref_simd
+    if ref_simd() is not None and ref_simd().ref_stage_simd() > 0:
+        srates, _, srecon0, sbusy = cpu_leg(qt, chroma_cfl, gpu_frame0, min_frames=5, min_seconds=0.0,
+                                            max_frames=5, lib=ref_simd())
+        same = all(np.array_equal(a, b) for pa, pb in zip(recon0, srecon0) for a, b in zip(pa, pb))
+        simd = {"value": float(np.median(srates)), "unit": "blocks/s", "cores": 1, "kind": "reference",
+                "runs": len(srates), "min": float(min(srates)), "max": float(max(srates)),
+                "isa": {1: "SSE2", 2: "SSE4.1", 3: "SSE4.1 + AVX2"}[ref_simd().ref_stage_simd()],
+                "equals_plain_c": bool(same),
+                "sample": "the same stage with the reference's x86 intrinsics compiled in "
+                          "(oracle/_ref/libdaalaref_simd.so): they exist for the 4x4 and 8x8 transforms only "
+                          "(src/x86/x86state.c:66-90), so the figure moves by the share of those transforms; "
+                          "median of %d pictures, %.1f s, same pinned core" % (len(srates), sbusy)}
     if prev is not None:
         os.sched_setaffinity(0, prev)
     what = ("padding + forward pyramid + pvq_theta with closed-form pricing (luma: no-reference "
@@ -319,6 +335,8 @@ def cpu_baseline(D, qt, chroma_cfl, args, gpu_frame0, timed_recon=None):
                 "level of Y, Cb, Cr from the GPU stages (host-priced choice) == the reference C "
                 "functions' (cpu_baseline leg)")
     ver = {"verified": not bad, "what": what, "planes_levels_compared": 13, "mismatches": bad}
+    if simd is not None:
+        base["simd_build"] = simd
     return base, host, ver
 
 

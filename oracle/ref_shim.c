@@ -32,6 +32,62 @@
 
 #define REF_EXPORT __attribute__((visibility("default")))
 
+/* ---- the 2-D transform tables the stage wrappers below dispatch through -----------
+   Plain build (libdaalaref.so): the C tables OD_FDCT_2D_C / OD_IDCT_2D_C.  The
+   -DOD_X86ASM build (libdaalaref_simd.so, the reference's x86 sources compiled with their
+   own flags, Makefile.am:48-60,136-141) applies what od_state_opt_vtbl_init_x86 applies
+   (src/x86/x86state.c:66-90): SSE4.1 / AVX2 versions of the 4x4 and 8x8 transforms, the
+   only parts of this stage the reference has intrinsics for.  ref_stage_simd() reports
+   which. */
+static od_dct_func_2d ref_fdct_tab[OD_NBSIZES + 1];
+static od_dct_func_2d ref_idct_tab[OD_NBSIZES + 1];
+static int ref_tab_state = -1;
+#if defined(OD_X86ASM)
+# include "x86/cpu.h"
+# include "x86/x86int.h"
+#endif
+
+static void ref_tabs_init(void) {
+  int i;
+  if (ref_tab_state >= 0) return;
+  for (i = 0; i <= OD_NBSIZES; i++) {
+    ref_fdct_tab[i] = OD_FDCT_2D_C[i];
+    ref_idct_tab[i] = OD_IDCT_2D_C[i];
+  }
+  ref_tab_state = 0;
+#if defined(OD_X86ASM)
+  {
+    uint32_t flags;
+    flags = od_cpu_flags_get();
+    if (flags & OD_CPU_X86_SSE2) {
+      ref_fdct_tab[0] = od_bin_fdct4x4_sse2;
+      ref_idct_tab[0] = od_bin_idct4x4_sse2;
+      ref_fdct_tab[1] = od_bin_fdct8x8_sse2;
+      ref_idct_tab[1] = od_bin_idct8x8_sse2;
+      ref_tab_state = 1;
+      if (flags & OD_CPU_X86_SSE4_1) {
+        ref_fdct_tab[0] = od_bin_fdct4x4_sse41;
+        ref_idct_tab[0] = od_bin_idct4x4_sse41;
+        ref_fdct_tab[1] = od_bin_fdct8x8_sse41;
+        ref_idct_tab[1] = od_bin_idct8x8_sse41;
+        ref_tab_state = 2;
+      }
+      if (flags & OD_CPU_X86_AVX2) {
+        ref_fdct_tab[1] = od_bin_fdct8x8_avx2;
+        ref_idct_tab[1] = od_bin_idct8x8_avx2;
+        ref_tab_state = 3;
+      }
+    }
+  }
+#endif
+}
+
+/* 0: C tables; 1 / 2 / 3: SSE2 / SSE4.1 / SSE4.1 + AVX2 transforms for 4x4 and 8x8. */
+REF_EXPORT int ref_stage_simd(void) {
+  ref_tabs_init();
+  return ref_tab_state;
+}
+
 /* ---- 1-D / 2-D transforms (src/dct.c:54-84 tables) ---------------------- */
 REF_EXPORT void ref_fdct_1d(int ln, od_coeff *y, const od_coeff *x,
  int xstride) {
@@ -138,7 +194,8 @@ static void ref_pyramid_rec(od_coeff **levels, od_coeff *c, int w, int bx,
   int bo;
   n = 4 << bs;
   bo = by*n*w + bx*n;
-  (*OD_FDCT_2D_C[bs])(levels[bs] + bo, w, c + bo, w);
+  ref_tabs_init();
+  (*ref_fdct_tab[bs])(levels[bs] + bo, w, c + bo, w);
   if (bs > 0) {
     int hfilter;
     int vfilter;
@@ -186,7 +243,8 @@ static void ref_inverse_rec(od_coeff *c, const od_coeff *d, int w, int bx,
   n = 4 << bs;
   bo = by*n*w + bx*n;
   if (bs == leaf_bs) {
-    (*OD_IDCT_2D_C[bs])(c + bo, w, d + bo, w);
+    ref_tabs_init();
+    (*ref_idct_tab[bs])(c + bo, w, d + bo, w);
   }
   else {
     int hfilter;

@@ -38,6 +38,12 @@ def ref():
     return lib
 
 
+def ref_simd():
+    """The same reference library built with its x86 intrinsics (oracle/Makefile); None when
+    not built."""
+    return _load(os.path.join(ROOT, "oracle", "_ref", "libdaalaref_simd.so"))
+
+
 def P(a):
     """numpy array -> void* (array must stay alive and be C-contiguous)."""
     assert a.flags["C_CONTIGUOUS"]

@@ -38,10 +38,11 @@ def _tables(qt, p):
     return qm_off, qb, bb
 
 
-def cpu_frame(qt, pics, pic_w, pic_h, chroma_cfl=True, lam=0.147):
+def cpu_frame(qt, pics, pic_w, pic_h, chroma_cfl=True, lam=0.147, lib=None):
     """pics: [Y, Cb, Cr] uint8 pictures.  Returns (recon, blocks, seconds): recon[pli][bs]
-    = uint8 plane of the coded size, reconstructed at uniform partition level bs."""
-    r = ref()
+    = uint8 plane of the coded size, reconstructed at uniform partition level bs.  lib:
+    another build of the reference (the x86-intrinsics one) instead of oracle/_ref's default."""
+    r = lib if lib is not None else ref()
     assert r is not None, "oracle/_ref/libdaalaref.so not built"
     r.ref_stage_plane_levels.restype = ctypes.c_long
     W, H = (pic_w + 63) & ~63, (pic_h + 63) & ~63
