@@ -297,14 +297,18 @@ int stage_inverse_noref(odhip_pipe *p, int si, hipStream_t s) {
    p->pic_w, p->pic_h, s);
 }
 
-int chroma_tail(odhip_pipe *p, int par, hipStream_t s) {
+/* rerun: the band stage of some bands was repeated with the host's theta - every band is
+   decided again from the candidate records; otherwise, with pricing, only the bands the band
+   stage did not decide itself (odhip_pvq_ref_bands_priced_multi). */
+int chroma_tail(odhip_pipe *p, int par, hipStream_t s, bool rerun = false) {
   PlaneSet &ch = p->set[1];
   const double lam = p->cfg.pvq_norm_lambda;
   int rc;
   {
     Timed tm(p, ODHIP_PIPE_CHOOSE_CHROMA, s);
-    rc = p->cfg.price ? odhip_pvq_ref_choose_priced_multi(p->refjobs[par], 4, lam, s)
-     : odhip_pvq_ref_choose_multi(p->refjobs[par], 4, lam, s);
+    rc = !p->cfg.price ? odhip_pvq_ref_choose_multi(p->refjobs[par], 4, lam, s)
+     : rerun ? odhip_pvq_ref_choose_priced_multi(p->refjobs[par], 4, lam, s)
+     : odhip_pvq_ref_choose_priced_rest_multi(p->refjobs[par], 4, lam, s);
   }
   if (rc) return rc;
   Timed tm(p, ODHIP_PIPE_INVERSE_CHROMA, s);
@@ -327,7 +331,7 @@ int finish_pending(odhip_pipe *p) {
   if (n < 0) return n;
   if (n > 0) {
     p->reruns += n;
-    STEP_TRY(chroma_tail(p, par, p->stream[1]));
+    STEP_TRY(chroma_tail(p, par, p->stream[1], true));
   }
   if (p->cfg.price) {
     /* the chroma choices of that step: listed bands are re-decided with the host libm and
@@ -357,8 +361,10 @@ int luma_front(odhip_pipe *p, hipStream_t s) {
     STEP_TRY(stage_pyramid(p, 1, s));
   }
   {
+    /* with pricing the searches make the choice themselves (no separate choice kernel) */
     Timed tm(p, ODHIP_PIPE_BANDS_LUMA, s);
-    STEP_TRY(odhip_pvq_noref_bands_multi(p->jobs, p->njobs, lam, s));
+    STEP_TRY(p->cfg.price ? odhip_pvq_noref_bands_priced_multi(p->jobs, p->njobs, lam, s)
+     : odhip_pvq_noref_bands_multi(p->jobs, p->njobs, lam, s));
   }
   return ODHIP_SUCCESS;
 }
@@ -369,10 +375,7 @@ int luma_choose(odhip_pipe *p, hipStream_t s) {
     Timed tm(p, ODHIP_PIPE_CHOOSE_LUMA, s);
     return odhip_pvq_choose_multi(p->jobs, p->njobs, lam, s);
   }
-  {
-    Timed tm(p, ODHIP_PIPE_CHOOSE_LUMA, s);
-    STEP_TRY(odhip_pvq_choose_priced_multi(p->jobs, p->njobs, lam, s));
-  }
+  /* (the choice was made inside the band stage: odhip_pvq_noref_bands_priced_multi) */
   /* The luma choices feed this step's chroma references and inverse: a band whose priced
      decision is too close to take from the device is settled (host libm) before they are
      enqueued.  The host waits here for the luma front of this step while the chroma chain
@@ -392,7 +395,8 @@ int luma_refs(odhip_pipe *p, int par, hipStream_t s) {
 
 int chroma_bands(odhip_pipe *p, int par, hipStream_t s) {
   Timed tm(p, ODHIP_PIPE_BANDS_CHROMA, s);
-  STEP_TRY(odhip_pvq_ref_bands_multi(p->refjobs[par], 4, p->cfg.pvq_norm_lambda, s));
+  STEP_TRY(p->cfg.price ? odhip_pvq_ref_bands_priced_multi(p->refjobs[par], 4, p->cfg.pvq_norm_lambda, s)
+   : odhip_pvq_ref_bands_multi(p->refjobs[par], 4, p->cfg.pvq_norm_lambda, s));
   return odhip_pvq_ref_resolve_begin(s);
 }
 
@@ -536,7 +540,8 @@ extern "C" int odhip_pipe_stage(odhip_pipe *p, int stage, int parity) {
     case ODHIP_PIPE_PYRAMID_CHROMA: return stage_pyramid(p, 1, s);
     case ODHIP_PIPE_BANDS_LUMA: {
       Timed tm(p, stage, s);
-      return odhip_pvq_noref_bands_multi(p->jobs, p->njobs, lam, s);
+      return p->cfg.price ? odhip_pvq_noref_bands_priced_multi(p->jobs, p->njobs, lam, s)
+       : odhip_pvq_noref_bands_multi(p->jobs, p->njobs, lam, s);
     }
     case ODHIP_PIPE_CHOOSE_LUMA: return luma_choose(p, s);
     case ODHIP_PIPE_CFL_REFS: return cfl ? luma_refs(p, parity, s) : ODHIP_EINVAL;

@@ -94,6 +94,8 @@ struct Items {
   unsigned *pcount;        /* priced choice: bands too close to call on the device */
   struct PUnc *plist;      /* ... and their list [kPUncCap]                       */
   double tol_scale;        /* test hook: multiplies the decision margin           */
+  int fuse;                /* the search kernels also make the priced choice      */
+  int reserved1;
   int wg_start[kMaxItems + 1];
   unsigned char job[kMaxItems];
   unsigned char band[kMaxItems];
@@ -564,6 +566,11 @@ struct BandFetch {
   int4 x[NV];
 };
 
+template <int PRICE>
+__device__ __forceinline__ void choose_core(const Items &it, int job, const DJob &jb, long sb, int band,
+ const RecHead &hd, double best_cost, int yy0, int yy1, int mom0, int mom1, double dist0, double dist1,
+ const double *given);
+
 /* N = band size, S = lanes per band (pvq_lane.cuh: S = 2 for the 128-coefficient
    band), NB = groups per wavefront. */
 template <int N, int S, int NB>
@@ -726,6 +733,12 @@ __global__ __launch_bounds__(kWave, (S == 2 ? 2 : 1)) void k_search(Items it) {
       int4 *out = reinterpret_cast<int4 *>(recs + blk*nb_bands) + 2;
       out[0] = make_int4(yy0, yy1, __double2loint(dist0), __double2hiint(dist0));
       out[1] = make_int4(__double2loint(dist1), __double2hiint(dist1), mom0, mom1);
+      /* the priced choice right here, from the registers (odhip_pvq_noref_bands_priced_multi):
+         the record is still written - the host-libm resolve of a listed band reads it */
+      if (it.fuse) {
+        choose_core<1>(it, it.job[item], jb, blk*nb_bands + band, band, hd,
+         __hiloint2double(cur.head[1].w, cur.head[1].z), yy0, yy1, mom0, mom1, dist0, dist1, nullptr);
+      }
     }
   }
 }
@@ -743,24 +756,20 @@ __global__ __launch_bounds__(kWave, (S == 2 ? 2 : 1)) void k_search(Items it) {
    other is not trusted: the band is listed, odhip_pvq_choose_priced_resolve recomputes its
    rates with the host's libm (the function the reference calls) and k_choose_list decides
    it again; PRICE = 2 is that second decision (rates given per band). */
+/* The decision itself, on values: from the record (k_choose) or straight from the
+   registers of the search that produced them (k_search with Items::fuse). */
 template <int PRICE>
-__device__ __forceinline__ void choose_band(const Items &it, int job, const DJob &jb, long sb,
+__device__ __forceinline__ void choose_core(const Items &it, int job, const DJob &jb, long sb, int band,
+ const RecHead &hd, double best_cost, int yy0, int yy1, int mom0, int mom1, double dist0, double dist1,
  const double *given) {
-  const int band = (int)(sb % jb.nb_bands);
   const int qb = jb.q[band];
   const int betab = jb.beta[band];
   const double *const rate = jb.rate;
   int4 *const choice = reinterpret_cast<int4 *>(jb.choice);
   int32_t *const qg_out = jb.qg_out;
-  const int4 *r = reinterpret_cast<const int4 *>(jb.rec + sb);
-  const RecHead hd = rec_head_load(jb.rec + sb);
-  const int4 r1 = r[1];
-  const int4 r2 = r[2];
-  const int4 r3 = r[3];
-  const int yys[2] = {r2.x, r2.y};
-  const int moms[2] = {r3.z, r3.w};
-  const double dists[2] = {__hiloint2double(r2.w, r2.z), __hiloint2double(r3.y, r3.x)};
-  double best_cost = __hiloint2double(r1.w, r1.z);
+  const int yys[2] = {yy0, yy1};
+  const int moms[2] = {mom0, mom1};
+  const double dists[2] = {dist0, dist1};
   int qg = 0;
   int sel = 0;
   bool close = false;
@@ -810,6 +819,19 @@ __device__ __forceinline__ void choose_band(const Items &it, int job, const DJob
   }
   choice[sb] = make_int4(sel, qg, scale, qshift);
   if (qg_out) qg_out[sb] = qg;
+}
+
+template <int PRICE>
+__device__ __forceinline__ void choose_band(const Items &it, int job, const DJob &jb, long sb,
+ const double *given) {
+  const int band = (int)(sb % jb.nb_bands);
+  const int4 *r = reinterpret_cast<const int4 *>(jb.rec + sb);
+  const RecHead hd = rec_head_load(jb.rec + sb);
+  const int4 r1 = r[1];
+  const int4 r2 = r[2];
+  const int4 r3 = r[3];
+  choose_core<PRICE>(it, job, jb, sb, band, hd, __hiloint2double(r1.w, r1.z), r2.x, r2.y, r3.z, r3.w,
+   __hiloint2double(r2.w, r2.z), __hiloint2double(r3.y, r3.x), given);
 }
 
 template <int PRICE>
@@ -1293,10 +1315,11 @@ void items_add(Items &it, int job, int band, long wgs) {
 }
 
 template <int N, int S, int NB>
-void launch_search(BandState &st, const DJob *host, int njobs, double lambda, hipStream_t s) {
+void launch_search(BandState &st, const DJob *host, int njobs, double lambda, hipStream_t s, bool fuse) {
   constexpr int per_wave = kWave/S*NB;
   Items it;
   items_begin(it, st, lambda);
+  it.fuse = fuse;
   for (int j = 0; j < njobs; j++) {
     for (int b = 0; b < host[j].nb_bands; b++) {
       if (host[j].off[b + 1] - host[j].off[b] == N) {
@@ -1356,8 +1379,22 @@ extern "C" int odhip_pvq_band_layout(int bs, int *nb_bands, int *offsets, int *l
   return ODHIP_SUCCESS;
 }
 
-extern "C" int odhip_pvq_noref_bands_multi(const odhip_pvq_job *jobs, int njobs,
- double pvq_norm_lambda, odhip_stream stream) {
+namespace {
+
+/* The count of bands the priced choice listed travels to pinned host memory behind it. */
+int price_count_begin(BandState &st, hipStream_t s) {
+  if (!st.pcount_host) {
+    ODHIP_TRY(hipHostMalloc((void **)&st.pcount_host, sizeof(unsigned), hipHostMallocDefault));
+    ODHIP_TRY(hipEventCreateWithFlags(&st.pcount_event, hipEventDisableTiming));
+  }
+  *st.pcount_host = 0xffffffffu;
+  ODHIP_TRY(hipMemcpyAsync(st.pcount_host, st.d_pcount, sizeof(unsigned), hipMemcpyDeviceToHost, s));
+  ODHIP_TRY(hipEventRecord(st.pcount_event, s));
+  return ODHIP_SUCCESS;
+}
+
+int noref_bands(const odhip_pvq_job *jobs, int njobs, double pvq_norm_lambda, odhip_stream stream,
+ bool fuse) {
   BandState *stp;
   {
     const int rc0 = band_state(&stp);
@@ -1369,6 +1406,7 @@ extern "C" int odhip_pvq_noref_bands_multi(const odhip_pvq_job *jobs, int njobs,
   DJob host[kMaxJobs];
   int rc = fill_jobs(jobs, njobs, 0, host);
   if (rc) return rc;
+  if (fuse) ODHIP_TRY(hipMemsetAsync(st.d_pcount, 0, sizeof(unsigned), s));
   size_t x16_elems = 0;
   size_t band_elems = 0;
   for (int j = 0; j < njobs; j++) {
@@ -1444,12 +1482,31 @@ extern "C" int odhip_pvq_noref_bands_multi(const odhip_pvq_job *jobs, int njobs,
   k_scatter<<<it.wg_start[it.nitems], 256, 0, s>>>(it);
   /* search: the band sizes are independent launches on forked streams */
   if (fork_streams(st, s, side) != ODHIP_SUCCESS) return ODHIP_EFAULT;
-  launch_search<128, 2, 1>(st, host, njobs, lambda, s);
-  launch_search<32, 1, 1>(st, host, njobs, lambda, side[0]);
-  launch_search<15, 1, 1>(st, host, njobs, lambda, side[1]);
-  launch_search<8, 1, 1>(st, host, njobs, lambda, side[1]);
+  launch_search<128, 2, 1>(st, host, njobs, lambda, s, fuse);
+  launch_search<32, 1, 1>(st, host, njobs, lambda, side[0], fuse);
+  launch_search<15, 1, 1>(st, host, njobs, lambda, side[1], fuse);
+  launch_search<8, 1, 1>(st, host, njobs, lambda, side[1], fuse);
   if (join_streams(st, s, side) != ODHIP_SUCCESS) return ODHIP_EFAULT;
+  if (fuse) {
+    const int rc2 = price_count_begin(st, s);
+    if (rc2) return rc2;
+  }
   return odhip_check_launch();
+}
+
+}  // namespace
+
+extern "C" int odhip_pvq_noref_bands_multi(const odhip_pvq_job *jobs, int njobs,
+ double pvq_norm_lambda, odhip_stream stream) {
+  return noref_bands(jobs, njobs, pvq_norm_lambda, stream, false);
+}
+
+/* The band stage AND the priced choice of odhip_pvq_choose_priced_multi in one pass: the
+   search kernels decide each band from the values they hold in registers (no separate
+   choice kernel reading the records back).  Follow with odhip_pvq_choose_priced_resolve. */
+extern "C" int odhip_pvq_noref_bands_priced_multi(const odhip_pvq_job *jobs, int njobs,
+ double pvq_norm_lambda, odhip_stream stream) {
+  return noref_bands(jobs, njobs, pvq_norm_lambda, stream, true);
 }
 
 extern "C" int odhip_pvq_select_synth_noref_multi(const odhip_pvq_job *jobs, int njobs,
@@ -1519,14 +1576,8 @@ extern "C" int odhip_pvq_choose_priced_multi(const odhip_pvq_job *jobs, int njob
     items_add(it, j, 0, (host[j].nblocks*host[j].nb_bands + 255)/256);
   }
   k_choose<1><<<it.wg_start[it.nitems], 256, 0, s>>>(it);
-  /* the count of listed bands travels to pinned host memory behind the kernel */
-  if (!st.pcount_host) {
-    ODHIP_TRY(hipHostMalloc((void **)&st.pcount_host, sizeof(unsigned), hipHostMallocDefault));
-    ODHIP_TRY(hipEventCreateWithFlags(&st.pcount_event, hipEventDisableTiming));
-  }
-  *st.pcount_host = 0xffffffffu;
-  ODHIP_TRY(hipMemcpyAsync(st.pcount_host, st.d_pcount, sizeof(unsigned), hipMemcpyDeviceToHost, s));
-  ODHIP_TRY(hipEventRecord(st.pcount_event, s));
+  rc = price_count_begin(st, s);
+  if (rc) return rc;
   return odhip_check_launch();
 }
 

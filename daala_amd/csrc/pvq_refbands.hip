@@ -118,6 +118,8 @@ struct RItems {
   unsigned *pcount;        /* priced choice: bands too close to call on the device */
   struct PUncR *plist;     /* ... and their list [kPUncCap]                        */
   double tol_scale;        /* test hook: multiplies the decision margin            */
+  int fuse;                /* the per-lane searches also make the priced choice    */
+  int reserved1;
   int wg_start[kMaxItems + 1];
   unsigned char job[kMaxItems];
   unsigned char band[kMaxItems];
@@ -886,9 +888,30 @@ __global__ __launch_bounds__(kWave) void k_refb_cands_list(const RJob *jobs, con
                             flags word above ODHIP_REFITEM_MOMENT_SHIFT so that the priced
                             choice never reads the vectors
    `writer`: this lane records the band's results (one lane per band). */
-template <class V>
+/* What the choice among a band's candidates keeps (src/pvq_encoder.c:417-609). */
+struct RefBest {
+  double best_cost;
+  int chosen;              /* item, -1 = the initial candidate */
+  int yslot;
+  int noref;
+  int32_t qtheta;
+  int gain;                /* the winner's head {gain, theta, ts, k} */
+  int theta;
+  int ts;
+  int k;
+  bool close;              /* a comparison too close for the device's log */
+};
+
+/* refb_loops offers every searched candidate, in the reference's order, to a decider:
+   nothing (the choice is a later kernel's) or FuseDecide below. */
+struct NoDecide {
+  template <class V>
+  __device__ __forceinline__ void offer(int, bool, const int4 &, int32_t, int, double, int, const V &) {}
+};
+
+template <class V, class D>
 __device__ __forceinline__ void refb_loops(const RJob &jb, int band, long blk, bool writer,
- bool may_store, double lambda, V &v) {
+ bool may_store, double lambda, V &v, D &dec) {
   const odhip_pvq_refband r = jb.rec[blk*jb.nb_bands + band];
   const int off = jb.off[band];
   const int n = jb.off[band + 1] - off;
@@ -955,6 +978,7 @@ __device__ __forceinline__ void refb_loops(const RJob &jb, int band, long blk, b
         ip.res[idx*ip.stride] = make_int4(__double2loint(cos_dist), __double2hiint(cos_dist),
          __double2loint(dist), __double2hiint(dist));
       }
+      dec.offer(idx, true, h, qtheta, cur_slot, dist, cur_mom, v);
     }
   }
   if (r.nitems > r.ntheta) {
@@ -986,6 +1010,7 @@ __device__ __forceinline__ void refb_loops(const RJob &jb, int band, long blk, b
         ip.res[idx*ip.stride] = make_int4(__double2loint(cos_dist), __double2hiint(cos_dist),
          __double2loint(dist), __double2hiint(dist));
       }
+      dec.offer(idx, false, h, 0, idx, dist, mom, v);
     }
   }
 }
@@ -1031,7 +1056,8 @@ __global__ __launch_bounds__(kWave) void k_refb_search(RItems it) {
   if (pos >= jb.nblocks) return;
   const long blk = jb.ids[(long)band*jb.nblocks + pos];
   LdsVector v = {(short *)lds, lds + n*kWave, (int)threadIdx.x, n, 0};
-  refb_loops(jb, band, blk, true, true, it.lambda, v);
+  NoDecide nd;
+  refb_loops(jb, band, blk, true, true, it.lambda, v, nd);
 }
 
 /* One listed band per wavefront (lane 0): the list is a handful of bands. */
@@ -1043,7 +1069,8 @@ __global__ __launch_bounds__(kWave) void k_refb_search_list(const RJob *jobs, co
   const Unc e = list[blockIdx.x];
   const RJob &jb = jobs[e.job];
   LdsVector v = {(short *)lds, lds + 128*kWave, 0, jb.off[e.band + 1] - jb.off[e.band], 0};
-  refb_loops(jb, e.band, e.blk, true, true, lambda, v);
+  NoDecide nd;
+  refb_loops(jb, e.band, e.blk, true, true, lambda, v, nd);
 }
 
 __device__ __forceinline__ uint32_t pack_pulses(int s0, int y0, int s1, int y1) {
@@ -1122,7 +1149,8 @@ __global__ __launch_bounds__(kWave) void k_refb_search_row(RItems it) {
   const bool live = pos < nblocks;
   /* rows beyond the end redo the last band without storing anything */
   const long blk = jb.ids[(long)it.band[item]*nblocks + (live ? pos : nblocks - 1)];
-  refb_loops(jb, it.band[item], blk, live && v.l == 0, live, it.lambda, v);
+  NoDecide nd;
+  refb_loops(jb, it.band[item], blk, live && v.l == 0, live, it.lambda, v, nd);
 }
 
 /* The short bands (N = 15, 8): one band per lane, the band in registers
@@ -1185,17 +1213,6 @@ struct RegVector {
   }
 };
 
-template <int N>
-__global__ __launch_bounds__(kWave) void k_refb_search_regs(RItems it) {
-  od_rsqrt_init(threadIdx.x);
-  const int item = find_item(it, blockIdx.x);
-  const RJob &jb = it.jobs[it.job[item]];
-  const long pos = (long)(blockIdx.x - it.wg_start[item])*kWave + threadIdx.x;
-  if (pos >= jb.nblocks) return;
-  const long blk = jb.ids[(long)it.band[item]*jb.nblocks + pos];
-  RegVector<N> v;
-  refb_loops(jb, it.band[item], blk, true, true, it.lambda, v);
-}
 
 
 /* ---- choice + synthesis -----------------------------------------------------------
@@ -1221,6 +1238,10 @@ __device__ __forceinline__ int neg_interleave(int x, int ref) { /* src/pvq_encod
 
 __device__ unsigned char gRBandOf[OD_SCAN_LEN];
 
+template <int N, class YGet>
+__device__ __forceinline__ void refb_finish(const RItems &it, int job, const RJob &jb, int band, long blk,
+ const odhip_pvq_refband &r, const RefBest &best, YGet yget);
+
 /* PRICE = 0: the host's rate table (or none); 1: od_pvq_rate's closed form (speed > 0,
    src/pvq_encoder.c:247-287) evaluated here from every searched candidate's pulses with the
    device's log - a comparison whose two costs lie within odq_rate_tol of each other is not
@@ -1237,15 +1258,10 @@ __device__ __forceinline__ void refb_choose_band(const RItems &it, int job, cons
   const double *rate = PRICE == 2 ? given : PRICE == 0 && jb.rate ? jb.rate + bi*(kSlots + 1) : nullptr;
   const double lambda = it.lambda;
   const int off = jb.off[band];
-  const int cfl_enabled = jb.is_keyframe && jb.pli != 0;
   /* :417-455 (the initial candidate places no pulse and has qg = 0: its rate is 0) */
   double best_cost = r.dist0 + lambda*(rate ? rate[0] : 0.);
   bool close = false;
-  int qg = 0;
   int noref = jb.is_keyframe ? 1 : 0;
-  int itheta = jb.is_keyframe ? -1 : 0;
-  int max_theta = 0;
-  int best_k = 0;
   int32_t best_qtheta = 0;
   int chosen = -1;
   int yslot = -1;
@@ -1296,7 +1312,65 @@ __device__ __forceinline__ void refb_choose_band(const RItems &it, int job, cons
       else noref = 1;
     }
   }
-  if (PRICE == 1 && close) {
+  RefBest best;
+  best.best_cost = best_cost;
+  best.chosen = chosen;
+  best.yslot = yslot;
+  best.noref = noref;
+  best.qtheta = best_qtheta;
+  best.gain = best.theta = best.ts = best.k = 0;
+  best.close = PRICE == 1 && close;
+  if (chosen >= 0) {
+    const int4 head = ip.head[chosen*ip.stride];    /* gain, theta, ts, k */
+    best.gain = head.x;
+    best.theta = head.y;
+    best.ts = head.z;
+    best.k = head.w;
+  }
+  /* the winner's pulses, as packed 16-byte pieces */
+  uint32_t yw[NW];
+  if (yslot >= 0) {
+    const uint4 *yp = reinterpret_cast<const uint4 *>(jb.y + ((long)yslot*jb.nblocks + blk)*jb.len
+     + off - SH);
+    if constexpr (NW >= 4) {
+#pragma unroll
+      for (int v = 0; v < NW/4; v++) {
+        const uint4 q = yp[v];
+        yw[4*v] = q.x;
+        yw[4*v + 1] = q.y;
+        yw[4*v + 2] = q.z;
+        yw[4*v + 3] = q.w;
+      }
+    }
+  }
+  else {
+#pragma unroll
+    for (int v = 0; v < NW; v++) yw[v] = 0;
+  }
+  refb_finish<N>(it, job, jb, band, blk, r, best,
+   [&](int i) -> int { return (int16_t)(yw[(i + SH) >> 1] >> (16*((i + SH) & 1))); });
+}
+
+/* Everything after the decision: the band is listed when a comparison was too close, the
+   skip rules (:611-622), and what od_pvq_synthesis_partial needs of the whole band
+   (:623-633, src/pvq.c:1037-1115); yget(i) = the winner's signed pulse i. */
+template <int N, class YGet>
+__device__ __forceinline__ void refb_finish(const RItems &it, int job, const RJob &jb, int band, long blk,
+ const odhip_pvq_refband &r, const RefBest &best, YGet yget) {
+  constexpr int SH = N == 15 ? 1 : 0;
+  constexpr int NW = (N + SH)/2;
+  const long bi = blk*jb.nb_bands + band;
+  const int off = jb.off[band];
+  const int cfl_enabled = jb.is_keyframe && jb.pli != 0;
+  const int chosen = best.chosen;
+  const int yslot = best.yslot;
+  const int noref = best.noref;
+  const int32_t best_qtheta = best.qtheta;
+  int qg = 0;
+  int itheta = jb.is_keyframe ? -1 : 0;
+  int max_theta = 0;
+  int best_k = 0;
+  if (best.close) {
     const unsigned slot = atomicAdd(it.pcount, 1u);
     if (slot < (unsigned)kPUncCap) {
       PUncR *e = it.plist + slot;
@@ -1306,16 +1380,15 @@ __device__ __forceinline__ void refb_choose_band(const RItems &it, int job, cons
     }
   }
   if (chosen >= 0) {
-    const int4 head = ip.head[chosen*ip.stride];    /* gain, theta, ts, k */
-    qg = head.x;
-    best_k = head.w;
+    qg = best.gain;
+    best_k = best.k;
     if (noref) {
       itheta = -1;
       max_theta = 0;
     }
     else {
-      itheta = head.y;
-      max_theta = head.z;
+      itheta = best.theta;
+      max_theta = best.ts;
     }
   }
   /* :611-622 */
@@ -1341,26 +1414,6 @@ __device__ __forceinline__ void refb_choose_band(const RItems &it, int job, cons
      src/pvq.c:1037-1115 */
   const int32_t g = odq_gain_expand(odq_shl32(qg, ODQ_CGAIN_SHIFT) + (noref ? 0 : r.gain_offset),
    jb.q[band], jb.beta[band]);
-  uint32_t yw[NW];
-  if (yslot >= 0) {
-    const uint4 *yp = reinterpret_cast<const uint4 *>(jb.y + ((long)yslot*jb.nblocks + blk)*jb.len
-     + off - SH);
-    if constexpr (NW >= 4) {
-#pragma unroll
-      for (int v = 0; v < NW/4; v++) {
-        const uint4 q = yp[v];
-        yw[4*v] = q.x;
-        yw[4*v + 1] = q.y;
-        yw[4*v + 2] = q.z;
-        yw[4*v + 3] = q.w;
-      }
-    }
-  }
-  else {
-#pragma unroll
-    for (int v = 0; v < NW; v++) yw[v] = 0;
-  }
-  auto yget = [&](int i) -> int { return (int16_t)(yw[(i + SH) >> 1] >> (16*((i + SH) & 1))); };
   const int nn = N - (!noref);
   int yy = 0;
 #pragma unroll
@@ -1414,6 +1467,85 @@ __device__ __forceinline__ void refb_choose_band(const RItems &it, int job, cons
   householder_consts(l2r, proj, &proj_1, &outshift);
   ch[2] = make_int4(3, yslot, scale, qshift);
   ch[3] = make_int4(xm, m, proj_1, outshift);
+}
+
+/* The running choice of a band searched one per lane (RegVector): every searched candidate
+   is priced with od_pvq_rate's closed form as it comes out of the search, in the
+   reference's order and with its comparisons (`<` for theta candidates, :559; `<=` for the
+   no-reference ones, :601), and the winner's signed pulses are kept in registers - what
+   k_refb_choose<N, 1> does from the candidate records, without reading them back. */
+template <int N>
+struct FuseDecide {
+  RefBest b;
+  int y[N];
+  double lambda;
+  double tol_scale;
+  int icgr;
+  int is_keyframe;
+  int pli;
+  __device__ __forceinline__ void init(const odhip_pvq_refband &r, const RJob &jb, double lam, double tol) {
+    b.best_cost = r.dist0;       /* the initial candidate places no pulse: its rate is 0 */
+    b.chosen = -1;
+    b.yslot = -1;
+    b.noref = jb.is_keyframe ? 1 : 0;
+    b.qtheta = 0;
+    b.gain = b.theta = b.ts = b.k = 0;
+    b.close = false;
+    lambda = lam;
+    tol_scale = tol;
+    icgr = r.icgr;
+    is_keyframe = jb.is_keyframe;
+    pli = jb.pli;
+#pragma unroll
+    for (int i = 0; i < N; i++) y[i] = 0;
+  }
+  __device__ __forceinline__ void offer(int idx, bool with_ref, const int4 &h, int32_t qtheta, int slot,
+   double dist, int mom, const RegVector<N> &v) {
+    const double cost = dist + lambda*odq_pvq_rate_fast(mom, h.w, N, h.x, with_ref ? icgr : 0,
+     with_ref ? h.y : -1, with_ref ? h.z : 0, is_keyframe, pli);
+    const double d = cost - b.best_cost;
+    if ((d < 0 ? -d : d) <= tol_scale*odq_rate_tol(cost, b.best_cost)) b.close = true;
+    if (with_ref ? cost < b.best_cost : cost <= b.best_cost) {
+      b.best_cost = cost;
+      b.chosen = idx;
+      b.yslot = slot;
+      b.noref = !with_ref;
+      if (with_ref) b.qtheta = qtheta;
+      b.gain = h.x;
+      b.theta = h.y;
+      b.ts = h.z;
+      b.k = h.w;
+#pragma unroll
+      for (int i = 0; i < N; i++) y[i] = slot < 0 ? 0 : ((v.sg >> i) & 1 ? -v.y[i] : v.y[i]);
+    }
+  }
+};
+
+/* FUSE: odhip_pvq_ref_bands_priced_multi - the lane also decides its band and writes the
+   choice record (the candidate records are still written: a listed band's resolve and the
+   theta-margin re-run read them). */
+template <int N, bool FUSE>
+__global__ __launch_bounds__(kWave) void k_refb_search_regs(RItems it) {
+  od_rsqrt_init(threadIdx.x);
+  const int item = find_item(it, blockIdx.x);
+  const int job = it.job[item];
+  const RJob &jb = it.jobs[job];
+  const long pos = (long)(blockIdx.x - it.wg_start[item])*kWave + threadIdx.x;
+  if (pos >= jb.nblocks) return;
+  const int band = it.band[item];
+  const long blk = jb.ids[(long)band*jb.nblocks + pos];
+  RegVector<N> v;
+  if constexpr (FUSE) {
+    const odhip_pvq_refband r = jb.rec[blk*jb.nb_bands + band];
+    FuseDecide<N> dec;
+    dec.init(r, jb, it.lambda, it.tol_scale);
+    refb_loops(jb, band, blk, true, true, it.lambda, v, dec);
+    refb_finish<N>(it, job, jb, band, blk, r, dec.b, [&](int i) -> int { return dec.y[i]; });
+  }
+  else {
+    NoDecide nd;
+    refb_loops(jb, band, blk, true, true, it.lambda, v, nd);
+  }
 }
 
 template <int N, int PRICE>
@@ -1853,13 +1985,35 @@ extern "C" int odhip_pvq_ref_theta_probe(const double *d_corr, double *d_t, long
   return odhip_check_launch();
 }
 
+namespace {
+int ref_bands(const odhip_pvq_refjob *jobs, int njobs, double pvq_norm_lambda, odhip_stream stream, bool fuse);
+}
+
 extern "C" int odhip_pvq_ref_bands_multi(const odhip_pvq_refjob *jobs, int njobs,
  double pvq_norm_lambda, odhip_stream stream) {
+  return ref_bands(jobs, njobs, pvq_norm_lambda, stream, false);
+}
+
+/* The band stage with the priced choice of the bands searched one per lane (the 15- and
+   8-coefficient bands, 77 % of all bands) made inside their search kernels; follow with
+   odhip_pvq_ref_choose_priced_rest_multi for the 32- and 128-coefficient bands and with
+   odhip_pvq_ref_choose_priced_resolve.  A job must carry its choice buffer. */
+extern "C" int odhip_pvq_ref_bands_priced_multi(const odhip_pvq_refjob *jobs, int njobs,
+ double pvq_norm_lambda, odhip_stream stream) {
+  for (int j = 0; jobs && j < njobs; j++) {
+    if (!jobs[j].choice) return ODHIP_EINVAL;
+  }
+  return ref_bands(jobs, njobs, pvq_norm_lambda, stream, true);
+}
+
+namespace {
+int ref_bands(const odhip_pvq_refjob *jobs, int njobs, double pvq_norm_lambda, odhip_stream stream, bool fuse) {
   hipStream_t s = (hipStream_t)stream;
   REF_STATE_OR_RETURN(st);
   RJob host[kMaxJobs];
   int rc = stage_jobs(st, jobs, njobs, 0, host, s);
   if (rc) return rc;
+  if (fuse) ODHIP_TRY(hipMemsetAsync(st.d_pcount, 0, sizeof(unsigned), s));
   ODHIP_TRY(hipMemsetAsync(st.d_unc_count, 0, sizeof(unsigned), s));
   /* the histogram is consumed and cleared by k_refb_prefix; cleared here as well so
      that a call that failed half way cannot poison the next sort */
@@ -1946,8 +2100,13 @@ extern "C" int odhip_pvq_ref_bands_multi(const odhip_pvq_refjob *jobs, int njobs
     items_all(it, st, host, njobs, pvq_norm_lambda, sizes[i]);
     if (!it.nitems) continue;
     if (sizes[i] < 32 && !lane_only) {
-      if (sizes[i] == 15) k_refb_search_regs<15><<<it.wg_start[it.nitems], kWave, 0, s>>>(it);
-      else k_refb_search_regs<8><<<it.wg_start[it.nitems], kWave, 0, s>>>(it);
+      const int wgs = it.wg_start[it.nitems];
+      if (fuse) {
+        if (sizes[i] == 15) k_refb_search_regs<15, true><<<wgs, kWave, 0, s>>>(it);
+        else k_refb_search_regs<8, true><<<wgs, kWave, 0, s>>>(it);
+      }
+      else if (sizes[i] == 15) k_refb_search_regs<15, false><<<wgs, kWave, 0, s>>>(it);
+      else k_refb_search_regs<8, false><<<wgs, kWave, 0, s>>>(it);
       continue;
     }
     const size_t lds = (size_t)2*sizes[i]*kWave*sizeof(unsigned short);
@@ -1957,6 +2116,7 @@ extern "C" int odhip_pvq_ref_bands_multi(const odhip_pvq_refjob *jobs, int njobs
   if (rjoin(st, s, side) != ODHIP_SUCCESS) return ODHIP_EFAULT;
   return odhip_check_launch();
 }
+}  // namespace
 
 /* The count of listed bands travels to pinned host memory behind the band stage;
    nothing waits for it here. */
@@ -2051,7 +2211,7 @@ extern "C" int odhip_pvq_ref_resolve(const odhip_pvq_refjob *jobs, int njobs,
 
 namespace {
 int ref_select(const odhip_pvq_refjob *jobs, int njobs, double pvq_norm_lambda, hipStream_t s,
- bool synth, bool price = false);
+ bool synth, bool price = false, bool rest_only = false);
 }  // namespace
 
 extern "C" int odhip_pvq_ref_select_synth_multi(const odhip_pvq_refjob *jobs, int njobs,
@@ -2066,7 +2226,7 @@ extern "C" int odhip_pvq_ref_choose_multi(const odhip_pvq_refjob *jobs, int njob
 
 namespace {
 int ref_select(const odhip_pvq_refjob *jobs, int njobs, double pvq_norm_lambda, hipStream_t s,
- bool synth, bool price) {
+ bool synth, bool price, bool rest_only) {
   REF_STATE_OR_RETURN(st);
   RJob host[kMaxJobs];
   int rc = stage_jobs(st, jobs, njobs, synth ? 1 : 2, host, s);
@@ -2078,10 +2238,12 @@ int ref_select(const odhip_pvq_refjob *jobs, int njobs, double pvq_norm_lambda, 
        *host[j].h, s));
     }
   }
-  if (price) ODHIP_TRY(hipMemsetAsync(st.d_pcount, 0, sizeof(unsigned), s));
+  /* rest_only: the per-lane bands were decided (and their close calls listed) inside
+     odhip_pvq_ref_bands_priced_multi, which also cleared the counter */
+  if (price && !rest_only) ODHIP_TRY(hipMemsetAsync(st.d_pcount, 0, sizeof(unsigned), s));
   RItems it;
   static const int sizes[4] = {128, 32, 15, 8};
-  for (int i = 0; i < 4; i++) {
+  for (int i = 0; i < (rest_only ? 2 : 4); i++) {
     items_all(it, st, host, njobs, pvq_norm_lambda, sizes[i]);
     if (!it.nitems) continue;
     const unsigned grid = it.wg_start[it.nitems];
@@ -2120,6 +2282,14 @@ int ref_select(const odhip_pvq_refjob *jobs, int njobs, double pvq_norm_lambda, 
 extern "C" int odhip_pvq_ref_choose_priced_multi(const odhip_pvq_refjob *jobs, int njobs,
  double pvq_norm_lambda, odhip_stream stream) {
   return ref_select(jobs, njobs, pvq_norm_lambda, (hipStream_t)stream, false, true);
+}
+
+/* After odhip_pvq_ref_bands_priced_multi: the priced choice of the bands it did not decide
+   (32 and 128 coefficients, searched one per group of lanes), and the count of listed
+   bands of both on its way to the host. */
+extern "C" int odhip_pvq_ref_choose_priced_rest_multi(const odhip_pvq_refjob *jobs, int njobs,
+ double pvq_norm_lambda, odhip_stream stream) {
+  return ref_select(jobs, njobs, pvq_norm_lambda, (hipStream_t)stream, false, true, true);
 }
 
 extern "C" int odhip_pvq_ref_choose_priced_resolve(const odhip_pvq_refjob *jobs, int njobs,

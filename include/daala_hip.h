@@ -819,10 +819,27 @@ int odhip_pvq_choose_priced_multi(const odhip_pvq_job *jobs, int njobs, double p
  odhip_stream stream);
 int odhip_pvq_choose_priced_resolve(const odhip_pvq_job *jobs, int njobs, double pvq_norm_lambda,
  odhip_stream stream);
+/* odhip_pvq_noref_bands_multi AND odhip_pvq_choose_priced_multi in one pass: the search
+   kernels decide each band from the values they hold in registers, so no choice kernel
+   reads the records back (they are still written: the resolve of a listed band and any
+   host that wants the candidates read them).  Follow with odhip_pvq_choose_priced_resolve. */
+int odhip_pvq_noref_bands_priced_multi(const odhip_pvq_job *jobs, int njobs, double pvq_norm_lambda,
+ odhip_stream stream);
 void odhip_pvq_price_set_tol_scale(double scale);
 int odhip_pvq_ref_choose_priced_multi(const odhip_pvq_refjob *jobs, int njobs, double pvq_norm_lambda,
  odhip_stream stream);
 int odhip_pvq_ref_choose_priced_resolve(const odhip_pvq_refjob *jobs, int njobs, double pvq_norm_lambda,
+ odhip_stream stream);
+/* The same split as odhip_pvq_noref_bands_priced_multi: the band stage with the priced choice
+   of the bands searched one per lane (15 and 8 coefficients: 77 % of the bands of a 4:2:0
+   chroma plane) made INSIDE their search kernels, from the registers; then the choice
+   kernels for the rest (32 and 128 coefficients) and the count of listed bands.  The
+   candidate records are written as always (the theta-margin re-run and the price-margin
+   resolve read them; after a theta-margin re-run use odhip_pvq_ref_choose_priced_multi, which
+   decides every band from the records). */
+int odhip_pvq_ref_bands_priced_multi(const odhip_pvq_refjob *jobs, int njobs, double pvq_norm_lambda,
+ odhip_stream stream);
+int odhip_pvq_ref_choose_priced_rest_multi(const odhip_pvq_refjob *jobs, int njobs, double pvq_norm_lambda,
  odhip_stream stream);
 void odhip_pvq_ref_price_set_tol_scale(double scale);
 
