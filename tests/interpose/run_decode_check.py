@@ -18,16 +18,23 @@ from _libs import P, synth_frame  # noqa: E402
 w, h, nframes = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
 quality = int(os.environ.get("QUALITY", "20"))
 check = os.environ.get("DECODE_CHECK", "1") == "1"
+# DERING_CACHE=1: encoder AND decoder take every od_dering call from batched GPU passes
+# (odhip_dering_cache), each served superblock compared with the reference's own od_dering
+dering = os.environ.get("DERING_CACHE") == "1"
+if dering:
+    os.environ["ODHIP_INTERPOSE_DERING_CACHE"] = "1"
+    os.environ["ODHIP_DERING_CHECK"] = "1"
 os.environ["ODHIP_INTERPOSE_PASSTHROUGH"] = "1"
 hip = ctypes.CDLL(os.path.join(ROOT, "daala_amd", "lib", "libdaalahip.so"), mode=ctypes.RTLD_GLOBAL)
 ipo = None
-if check:
+if check or dering:
     assert hip.odhip_init(0) == 0
     ipo = ctypes.CDLL(os.path.join(ROOT, "tests", "interpose", "libinterpose.so"), mode=ctypes.RTLD_GLOBAL)
 r = ctypes.CDLL(os.path.join(ROOT, "oracle", "_ref", "libdaalaref.so"))
 if ipo is not None:
     ipo.odhip_interpose_set_reference(ctypes.c_void_p(r._handle))
-    ipo.odhip_interpose_enable_decode_check()
+    if check:
+        ipo.odhip_interpose_enable_decode_check()
 if os.environ.get("CONTENT") == "bench":
     import bench
     fr = []
@@ -47,5 +54,10 @@ if ipo is not None:
     arr = (ctypes.c_long * 3).in_dll(ipo, "odhip_interposed_decode")
     stats = [arr[i] for i in range(3)]
 err = float(np.abs(decoded.astype(np.int32) - frames.astype(np.int32)).mean())
-print(json.dumps({"decoded": hashlib.sha256(decoded.tobytes()).hexdigest(), "check": stats,
+dstats = [0, 0]
+if dering:
+    ipo.odhip_interpose_dering_stats()
+    arr = (ctypes.c_long * 2).in_dll(ipo, "odhip_interposed_dering")
+    dstats = [arr[0], arr[1]]
+print(json.dumps({"decoded": hashlib.sha256(decoded.tobytes()).hexdigest(), "check": stats, "dering": dstats,
                   "mean_abs_error_vs_source": err}))

@@ -47,3 +47,17 @@ def test_gpu_reconstruction_1080p_frame():
     res = _run(1920, 1080, 1, CONTENT="bench")
     planes, pixels, bad = res["check"]
     assert planes == 3 and bad == 0, res["check"]
+
+
+@pytest.mark.skipif(not HAVE_REF, reason="oracle/_ref not present")
+def test_decoder_dering_from_batched_passes():
+    """The decoder applies the transmitted deringing level superblock by superblock
+    (src/decode.c: od_dering per plane); with odhip_dering_cache bound (encoder and decoder)
+    every call is served from one launch per (plane, threshold), each served superblock is
+    compared with the reference's od_dering, and the decoded clip is unchanged."""
+    for (w, h, nframes, quality) in ((320, 192, 2, 20), (180, 116, 2, 60)):
+        plain = _run(w, h, nframes, QUALITY=quality, DECODE_CHECK=0)
+        res = _run(w, h, nframes, QUALITY=quality, DECODE_CHECK=0, DERING_CACHE=1)
+        assert res["decoded"] == plain["decoded"], (w, h)
+        launches, served = res["dering"]
+        assert served > 0 and 0 < launches < served, res["dering"]
