@@ -23,5 +23,6 @@ from .api import (DaalaHipError, lib, lib_path, init, fdct2d_batch, idct2d_batch
                   pvq_ref_profile_read, image_planes_copy_pad, inverse_levels, pvq_ref_resolve_finish, cfl_refs_from_luma, pvq_ref_set_context,
                   pvq_ref_choose_multi, inverse_levels_pvq_ref, Context, Pipe, PIPE_STAGES,
                   BUF_PIC, BUF_PX, BUF_LEVEL, BUF_RECON, BUF_BAND, BUF_Y, BUF_CHOICE, BUF_ITEMS,
-                  BUF_REF, BUF_RATE, compute_dist, set_price_tol_scale)
+                  BUF_REF, BUF_RATE, compute_dist, set_price_tol_scale, px_dtype,
+                  image_planes_copy_pad16)
 from .quant import QuantTables, OD_PVQ_LAMBDA  # noqa: F401

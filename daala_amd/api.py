@@ -152,11 +152,23 @@ def dering_planes(x, xdec, dirs, pli, bskip, thresholds, overlap=1, coeff_shift=
 
 
 # ---- fused lapped stage -----------------------------------------------------
-def forward_pyramid(px, dec, pic_w, pic_h, levels=None, want=None):
-    """px: uint8 [nplanes, h, w] CUDA.  Returns a list of int32 [nplanes, h, w]
-    tensors, index bs = 0..4-dec (None where `want` excludes a level)."""
+def px_dtype():
+    """torch dtype of picture planes in the calling thread's current context: uint8, or int16
+    samples at 12 bits when the context is in full-precision-references mode
+    (Context.set_fpr, odhip_ctx_set_fpr)."""
     import torch
-    _need(px, torch.uint8, "px")
+    L = lib()
+    L.odhip_get_current.restype = ctypes.c_void_p
+    cur = L.odhip_get_current()
+    return torch.int16 if cur and L.odhip_ctx_get_fpr(ctypes.c_void_p(cur)) == 1 else torch.uint8
+
+
+def forward_pyramid(px, dec, pic_w, pic_h, levels=None, want=None):
+    """px: uint8 (int16 in a full-precision-references context) [nplanes, h, w] CUDA.
+    Returns a list of int32 [nplanes, h, w] tensors, index bs = 0..4-dec (None where
+    `want` excludes a level)."""
+    import torch
+    _need(px, px_dtype(), "px")
     nplanes, h, w = px.shape
     top = 4 - dec
     if levels is None:
@@ -180,7 +192,7 @@ def inverse_level(coef, dec, leaf_bs, pic_w, pic_h, out=None):
     _need(coef, torch.int32, "coef")
     nplanes, h, w = coef.shape
     if out is None:
-        out = torch.empty((nplanes, h, w), dtype=torch.uint8, device=coef.device)
+        out = torch.empty((nplanes, h, w), dtype=px_dtype(), device=coef.device)
     _check(lib().odhip_inverse_level(_p(out), w, ctypes.c_long(h * w), _p(coef), nplanes,
                                      w, h, int(dec), int(leaf_bs), int(pic_w), int(pic_h),
                                      _stream()), "odhip_inverse_level")
@@ -448,7 +460,7 @@ def inverse_level_pvq(job, dec, pic_w, pic_h, out=None):
     import torch
     nplanes, h, w = job.coef.shape
     if out is None:
-        out = torch.empty((nplanes, h, w), dtype=torch.uint8, device=job.coef.device)
+        out = torch.empty((nplanes, h, w), dtype=px_dtype(), device=job.coef.device)
     st = job.struct()
     _check(lib().odhip_inverse_level_pvq(_p(out), w, ctypes.c_long(h * w), ctypes.byref(st),
                                          int(dec), int(pic_w), int(pic_h), _stream()),
@@ -462,7 +474,7 @@ def inverse_levels_pvq(jobs, dec, pic_w, pic_h, outs=None):
     import torch
     nplanes, h, w = jobs[0].coef.shape
     if outs is None:
-        outs = [torch.empty((nplanes, h, w), dtype=torch.uint8, device=jobs[0].coef.device)
+        outs = [torch.empty((nplanes, h, w), dtype=px_dtype(), device=jobs[0].coef.device)
                 for _ in jobs]
     ptrs = (ctypes.c_void_p * len(jobs))(*[o.data_ptr() for o in outs])
     _check(lib().odhip_inverse_levels_pvq(ptrs, w, ctypes.c_long(h * w), _jobs_array(jobs),
@@ -679,13 +691,30 @@ def image_planes_copy_pad(src, plane_w, plane_h, out=None):
     return out
 
 
+def image_planes_copy_pad16(src, plane_w, plane_h, src_bitdepth=8, out=None):
+    """od_img_plane_copy_pad for an encoder with full-precision references: src uint8
+    (src_bitdepth 8) or int16 (10 / 12) [nplanes, pic_h, pic_w] -> int16 samples at 12 bits
+    [nplanes, plane_h, plane_w]."""
+    import torch
+    _need(src, torch.uint8 if src_bitdepth == 8 else torch.int16, "src")
+    nplanes, pic_h, pic_w = src.shape
+    if out is None:
+        out = torch.empty((nplanes, plane_h, plane_w), dtype=torch.int16, device=src.device)
+    _check(lib().odhip_image_planes_copy_pad16(_p(out), plane_w, ctypes.c_long(plane_h * plane_w),
+                                               plane_w, plane_h, _p(src) if src.numel() else None,
+                                               int(src_bitdepth), pic_w, ctypes.c_long(pic_h * pic_w),
+                                               pic_w, pic_h, nplanes, _stream()),
+           "odhip_image_planes_copy_pad16")
+    return out
+
+
 def inverse_levels(coefs, dec, leaf_bs, pic_w, pic_h, outs=None):
     """inverse_level for several partition levels of one plane set in one set of
     launches: coefs[i] (int32 [nplanes, h, w]) at level leaf_bs[i] -> outs[i]."""
     import torch
     nplanes, h, w = coefs[0].shape
     if outs is None:
-        outs = [torch.empty((nplanes, h, w), dtype=torch.uint8, device=coefs[0].device) for _ in coefs]
+        outs = [torch.empty((nplanes, h, w), dtype=px_dtype(), device=coefs[0].device) for _ in coefs]
     n = len(coefs)
     for c in coefs:
         _need(c, torch.int32, "coef")
@@ -735,7 +764,7 @@ def inverse_levels_pvq_ref(jobs, dec, pic_w, pic_h, outs=None):
     import torch
     nplanes, h, w = jobs[0].coef.shape
     if outs is None:
-        outs = [torch.empty((nplanes, h, w), dtype=torch.uint8, device=jobs[0].coef.device)
+        outs = [torch.empty((nplanes, h, w), dtype=px_dtype(), device=jobs[0].coef.device)
                 for _ in jobs]
     px = (ctypes.c_void_p * len(jobs))(*[o.data_ptr() for o in outs])
     _check(lib().odhip_inverse_levels_pvq_ref(px, w, ctypes.c_long(h * w), _refjobs_array(jobs),
@@ -764,6 +793,12 @@ class Context:
 
     def __exit__(self, *exc):
         _check(lib().odhip_make_current(ctypes.c_void_p(self._prev.pop())), "odhip_make_current")
+
+    def set_fpr(self, on=True):
+        """Full-precision references: picture planes of this context's calls are int16
+        samples at 12 bits (odhip_ctx_set_fpr)."""
+        _check(lib().odhip_ctx_set_fpr(ctypes.c_void_p(self.handle), int(bool(on))), "odhip_ctx_set_fpr")
+        return self
 
     def destroy(self):
         if self.handle:

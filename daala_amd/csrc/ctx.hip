@@ -95,6 +95,18 @@ extern "C" int odhip_ctx_set_serial(odhip_ctx *ctx, int serial) {
   return ODHIP_SUCCESS;
 }
 
+/* Full-precision references (daala_info.full_precision_references, src/encode.c:212-213,
+   src/state.c:256-258): see include/daala_hip.h. */
+extern "C" int odhip_ctx_set_fpr(odhip_ctx *ctx, int on) {
+  if (!ctx) return ODHIP_EINVAL;
+  ctx->fpr = on != 0;
+  return ODHIP_SUCCESS;
+}
+
+extern "C" int odhip_ctx_get_fpr(const odhip_ctx *ctx) {
+  return ctx ? ctx->fpr : ODHIP_EINVAL;
+}
+
 extern "C" int odhip_ctx_device(const odhip_ctx *ctx) {
   return ctx ? ctx->device : ODHIP_EINVAL;
 }

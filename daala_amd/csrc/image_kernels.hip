@@ -4,7 +4,9 @@
    od_input_queue_add :272-287): copy the picture into the padded plane the
    encoder codes, then extend it into the padding by a [1 2 1]/4 low-pass of the
    previous column (right side, picture rows only) and of the previous row
-   (bottom, the whole padded width).  8-bit planes (xstride 1).
+   (bottom, the whole padded width).  8-bit planes (xstride 1), and - for an encoder with
+   full-precision references - 16-bit planes at 12 bits (xstride 2, :791-803, :821-832),
+   whose copy step is od_img_plane_copy's bit-depth conversion (src/state.c:93-213).
 
    k_img_copy   the picture region of every plane, 16 bytes per thread where the
                 alignment allows
@@ -38,11 +40,26 @@ __global__ __launch_bounds__(256) void k_img_copy(uint8_t *dst, int dst_stride, 
   }
 }
 
-__global__ __launch_bounds__(kPadThreads) void k_img_pad(uint8_t *dst, int dst_stride,
+/* Full-precision references: an 8-bit source (uint8_t samples) or a 10 / 12-bit one
+   (int16_t samples) shifted up into 12 bits and clamped, src/state.c:141-160 / :186-197. */
+__global__ __launch_bounds__(256) void k_img_copy16(uint16_t *dst, int dst_stride, long dst_plane_stride,
+ const void *src, int src_bitdepth, int src_stride, long src_plane_stride, int pic_w, int pic_h) {
+  const int p = blockIdx.z;
+  const int y = blockIdx.y;
+  const int x = blockIdx.x*256 + threadIdx.x;
+  if (x >= pic_w) return;
+  const long at = p*src_plane_stride + (long)y*src_stride + x;
+  const int v = src_bitdepth > 8 ? static_cast<const int16_t *>(src)[at] << (12 - src_bitdepth)
+   : static_cast<const uint8_t *>(src)[at] << 4;
+  dst[p*dst_plane_stride + (long)y*dst_stride + x] = (uint16_t)min(max(v, 0), 4095);
+}
+
+template <typename S>
+__global__ __launch_bounds__(kPadThreads) void k_img_pad(S *dst, int dst_stride,
  long dst_plane_stride, int plane_w, int plane_h, int pic_w, int pic_h) {
-  __shared__ uint8_t buf[2][kMaxDim];
-  __shared__ uint8_t last_row[64];     /* extension of picture row pic_h - 1 */
-  uint8_t *d = dst + blockIdx.x*dst_plane_stride;
+  __shared__ S buf[2][kMaxDim];
+  __shared__ S last_row[64];     /* extension of picture row pic_h - 1 */
+  S *d = dst + blockIdx.x*dst_plane_stride;
   const int tid = threadIdx.x;
   if (pic_w == 0 || pic_h == 0) {
     for (long i = tid; i < (long)plane_w*plane_h; i += kPadThreads) {
@@ -60,7 +77,7 @@ __global__ __launch_bounds__(kPadThreads) void k_img_pad(uint8_t *dst, int dst_s
         const int c = buf[cur][y];
         const int u = buf[cur][y > 0 ? y - 1 : y];
         const int dn = buf[cur][y + 1 < pic_h ? y + 1 : y];
-        const uint8_t v = (uint8_t)((2*c + u + dn + 2) >> 2);
+        const S v = (S)((2*c + u + dn + 2) >> 2);
         buf[cur ^ 1][y] = v;
         d[(long)y*dst_stride + x] = v;
         if (y == pic_h - 1) last_row[x - pic_w] = v;
@@ -81,7 +98,7 @@ __global__ __launch_bounds__(kPadThreads) void k_img_pad(uint8_t *dst, int dst_s
         const int c = buf[cur][x];
         const int l = buf[cur][x - (x > 0)];
         const int r = buf[cur][x + (x + 1 < plane_w)];
-        const uint8_t v = (uint8_t)((2*c + l + r + 2) >> 2);
+        const S v = (S)((2*c + l + r + 2) >> 2);
         buf[cur ^ 1][x] = v;
         d[(long)y*dst_stride + x] = v;
       }
@@ -112,7 +129,35 @@ extern "C" int odhip_image_planes_copy_pad(uint8_t *d_dst, int dst_stride, long 
      src_plane_stride, pic_w, pic_h);
   }
   if (pic_w == 0 || pic_h == 0 || pic_w < plane_w || pic_h < plane_h) {
-    k_img_pad<<<(unsigned)nplanes, kPadThreads, 0, s>>>(d_dst, dst_stride, dst_plane_stride, plane_w,
+    k_img_pad<uint8_t><<<(unsigned)nplanes, kPadThreads, 0, s>>>(d_dst, dst_stride, dst_plane_stride, plane_w,
+     plane_h, pic_w, pic_h);
+  }
+  return odhip_check_launch();
+}
+
+/* The same for full-precision references: d_dst holds uint16_t samples at 12 bits; the
+   source is `src_bitdepth` 8 (uint8_t samples) or 10 / 12 (int16_t samples).  Strides in
+   samples. */
+extern "C" int odhip_image_planes_copy_pad16(uint16_t *d_dst, int dst_stride, long dst_plane_stride,
+ int plane_w, int plane_h, const void *d_src, int src_bitdepth, int src_stride, long src_plane_stride,
+ int pic_w, int pic_h, int nplanes, odhip_stream stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (nplanes == 0) return ODHIP_SUCCESS;
+  if (!d_dst || nplanes < 0 || plane_w <= 0 || plane_h <= 0 || plane_w > kMaxDim || plane_h > kMaxDim
+   || pic_w < 0 || pic_h < 0 || pic_w > plane_w || pic_h > plane_h || dst_stride < plane_w
+   || (src_bitdepth != 8 && src_bitdepth != 10 && src_bitdepth != 12)) {
+    return ODHIP_EINVAL;
+  }
+  if (pic_w > 0 && pic_h > 0 && plane_w - pic_w > 64) return ODHIP_EINVAL;
+  if (pic_w > 0 && pic_h > 0) {
+    if (!d_src || src_stride < pic_w) return ODHIP_EINVAL;
+    const dim3 grid((unsigned)((pic_w + 255)/256), (unsigned)pic_h, (unsigned)nplanes);
+    if (grid.y > 65535u || grid.z > 65535u) return ODHIP_EINVAL;
+    k_img_copy16<<<grid, 256, 0, s>>>(d_dst, dst_stride, dst_plane_stride, d_src, src_bitdepth, src_stride,
+     src_plane_stride, pic_w, pic_h);
+  }
+  if (pic_w == 0 || pic_h == 0 || pic_w < plane_w || pic_h < plane_h) {
+    k_img_pad<uint16_t><<<(unsigned)nplanes, kPadThreads, 0, s>>>(d_dst, dst_stride, dst_plane_stride, plane_w,
      plane_h, pic_w, pic_h);
   }
   return odhip_check_launch();

@@ -68,7 +68,15 @@ struct PyramidArgs {
   int h;
   int pic_w;
   int pic_h;
+  /* full-precision references (odhip_ctx_set_fpr): px holds int16 samples at 12 bits,
+     strides in samples (the reference's xstride 2, src/state.c:1238-1254) */
+  int px16;
 };
+
+/* The plane's first sample. */
+__device__ __forceinline__ const uint8_t *pyr_plane(const PyramidArgs &a, int plane) {
+  return a.px + ((long)plane*a.px_plane_stride << a.px16);
+}
 
 /* 4-point filter across 4 LDS words a, a+step, a+2*step, a+3*step. */
 template <bool INV, typename E>
@@ -281,13 +289,23 @@ __device__ __forceinline__ void sb_load(short *t, const PyramidArgs &a, const ui
   constexpr int P = G::kPitch;
   const int w = a.w;
   const int h = a.h;
-  /* od_ref_buf_to_coeff, src/state.c:1231-1237: (p - 128) << OD_COEFF_SHIFT. */
+  /* od_ref_buf_to_coeff, src/state.c:1231-1237: (p - 128) << OD_COEFF_SHIFT; with
+     full-precision references :1245-1250: p - 2048. */
+  const bool px16 = a.px16 != 0;
+  const short *px_w = reinterpret_cast<const short *>(px);
   for (int i = tid; i < TILE*TILE/4; i += NT) {
     const int y = i/(TILE/4);
     const int x = (i % (TILE/4))*4;
-    const uchar4 v = *reinterpret_cast<const uchar4 *>(px + (long)(y0 + y)*a.px_stride + x0 + x);
-    *reinterpret_cast<short4 *>(t + y*P + x) =
-     make_short4((v.x - 128)*16, (v.y - 128)*16, (v.z - 128)*16, (v.w - 128)*16);
+    const long at = (long)(y0 + y)*a.px_stride + x0 + x;
+    if (px16) {
+      const short4 v = *reinterpret_cast<const short4 *>(px_w + at);
+      *reinterpret_cast<short4 *>(t + y*P + x) = make_short4(v.x - 2048, v.y - 2048, v.z - 2048, v.w - 2048);
+    }
+    else {
+      const uchar4 v = *reinterpret_cast<const uchar4 *>(px + at);
+      *reinterpret_cast<short4 *>(t + y*P + x) =
+       make_short4((v.x - 128)*16, (v.y - 128)*16, (v.z - 128)*16, (v.w - 128)*16);
+    }
   }
   /* Halo ring: 2 samples of each neighbouring superblock (where it exists). */
   for (int i = tid; i < 8*TILE + 16; i += NT) {
@@ -307,7 +325,8 @@ __device__ __forceinline__ void sb_load(short *t, const PyramidArgs &a, const ui
     const int gx = x0 + c;
     const int gy = y0 + r;
     if (gx >= 0 && gx < w && gy >= 0 && gy < h) {
-      t[G::map(r)*P + G::map(c)] = (short)((px[(long)gy*a.px_stride + gx] - 128)*16);
+      const long at = (long)gy*a.px_stride + gx;
+      t[G::map(r)*P + G::map(c)] = px16 ? (short)(px_w[at] - 2048) : (short)((px[at] - 128)*16);
     }
   }
 }
@@ -384,7 +403,7 @@ __global__ __launch_bounds__(NT) void k_forward_pyramid(PyramidArgs a) {
   const int tid = threadIdx.x;
   const int x0 = blockIdx.x*TILE;
   const int y0 = blockIdx.y*TILE;
-  const uint8_t *px = a.px + blockIdx.z*a.px_plane_stride;
+  const uint8_t *px = pyr_plane(a, blockIdx.z);
   const long plane_off = (long)blockIdx.z*a.w*a.h;
   sb_load<TILE, NT>(t, a, px, x0, y0, tid);
   od_lds_barrier();
@@ -416,7 +435,7 @@ __global__ __launch_bounds__(256) void k_forward_pyramid64x2(PyramidArgs a) {
   const int tid = threadIdx.x;
   const int xb = blockIdx.x*2*TILE;
   const int y0 = blockIdx.y*TILE;
-  const uint8_t *px = a.px + blockIdx.z*a.px_plane_stride;
+  const uint8_t *px = pyr_plane(a, blockIdx.z);
   const long plane_off = (long)blockIdx.z*a.w*a.h;
   for (int s = 0; s < 2; s++) sb_load<TILE, NT>(t[s], a, px, xb + s*TILE, y0, tid);
   od_lds_barrier();
@@ -653,7 +672,7 @@ __global__ __launch_bounds__(128) void k_forward_pyramid_halves(PyramidArgs a) {
   const int tid = threadIdx.x;
   const int x0 = blockIdx.x*TILE;
   const int y0 = blockIdx.y*TILE;
-  const uint8_t *px = a.px + blockIdx.z*a.px_plane_stride;
+  const uint8_t *px = pyr_plane(a, blockIdx.z);
   const long plane_off = (long)blockIdx.z*a.w*a.h;
   sb_load<TILE, NT>(t, a, px, x0, y0, tid);
   od_lds_barrier();
@@ -697,6 +716,7 @@ struct InverseArgs {
      the reference plane itself (skip-copy bands). */
   const int16_t *r16;
   const od_coeff *ref;
+  int px16;                 /* full-precision references: px holds int16 samples, see PyramidArgs */
 };
 
 /* Several partition levels of one plane set in ONE launch (blockIdx.z = level *
@@ -715,6 +735,14 @@ __device__ unsigned char gInvBandOf[OD_SCAN_LEN];
 /* od_coeff_to_ref_buf, src/state.c:1296-1304. */
 __device__ __forceinline__ unsigned char od_to_px(int c) {
   return (unsigned char)min(max(((c + 8) >> 4) + 128, 0), 255);
+}
+/* ... with full-precision references, :1313-1318: OD_CLAMPFPR(c + (128 << OD_COEFF_SHIFT)). */
+__device__ __forceinline__ short od_to_px16(int c) {
+  return (short)min(max(c + 2048, 0), 4095);
+}
+__device__ __forceinline__ void od_store_px(uint8_t *plane, long at, int c, bool px16) {
+  if (px16) reinterpret_cast<short *>(plane)[at] = od_to_px16(c);
+  else plane[at] = od_to_px(c);
 }
 
 template <int TILE, int LN>
@@ -862,17 +890,25 @@ __device__ __forceinline__ void inverse_store(const int *t, const InverseArgs &a
   constexpr int NT = Geo<TILE>::kNT;
   const int w = a.w;
   const int h = a.h;
-  uint8_t *px = a.px + plane*a.px_plane_stride;
+  const bool px16 = a.px16 != 0;
+  uint8_t *px = a.px + ((long)plane*a.px_plane_stride << a.px16);
   for (int i = tid; i < TILE*TILE/4; i += NT) {
     const int y = i/(TILE/4);
     const int x = (i % (TILE/4))*4;
     const int4 v = *reinterpret_cast<const int4 *>(t + y*P + x);
-    uchar4 o;
-    o.x = od_to_px(v.x);
-    o.y = od_to_px(v.y);
-    o.z = od_to_px(v.z);
-    o.w = od_to_px(v.w);
-    *reinterpret_cast<uchar4 *>(px + (long)(y0 + y)*a.px_stride + x0 + x) = o;
+    const long at = (long)(y0 + y)*a.px_stride + x0 + x;
+    if (px16) {
+      *reinterpret_cast<short4 *>(reinterpret_cast<short *>(px) + at) =
+       make_short4(od_to_px16(v.x), od_to_px16(v.y), od_to_px16(v.z), od_to_px16(v.w));
+    }
+    else {
+      uchar4 o;
+      o.x = od_to_px(v.x);
+      o.y = od_to_px(v.y);
+      o.z = od_to_px(v.z);
+      o.w = od_to_px(v.w);
+      *reinterpret_cast<uchar4 *>(px + at) = o;
+    }
   }
   const int nv = w/TILE - 1;
   const int nh = h/TILE - 1;
@@ -1156,6 +1192,7 @@ struct EdgeArgs {
   int w;
   int h;
   int tile;
+  int px16;
 };
 
 struct EdgeArgsMulti {
@@ -1191,11 +1228,13 @@ __global__ __launch_bounds__(256) void k_edge_rows(EdgeArgsMulti mm) {
     row[3] = t3;
   }
   else {
-    uint8_t *p = a.px + plane*a.px_plane_stride + (long)y*a.px_stride + x;
-    p[0] = od_to_px(t0);
-    p[1] = od_to_px(t1);
-    p[2] = od_to_px(t2);
-    p[3] = od_to_px(t3);
+    uint8_t *pl = a.px + ((long)plane*a.px_plane_stride << a.px16);
+    const long at = (long)y*a.px_stride + x;
+    const bool px16 = a.px16 != 0;
+    od_store_px(pl, at, t0, px16);
+    od_store_px(pl, at + 1, t1, px16);
+    od_store_px(pl, at + 2, t2, px16);
+    od_store_px(pl, at + 3, t3, px16);
   }
 }
 
@@ -1214,11 +1253,13 @@ __global__ __launch_bounds__(256) void k_edge_cols(EdgeArgsMulti mm) {
   int t2 = col[2*a.w];
   int t3 = col[3*a.w];
   od_post_filter4_dev(t0, t1, t2, t3);
-  uint8_t *p = a.px + plane*a.px_plane_stride + (long)((e + 1)*a.tile - 2)*a.px_stride + x;
-  p[0] = od_to_px(t0);
-  p[a.px_stride] = od_to_px(t1);
-  p[2*a.px_stride] = od_to_px(t2);
-  p[3*a.px_stride] = od_to_px(t3);
+  uint8_t *pl = a.px + ((long)plane*a.px_plane_stride << a.px16);
+  const long at = (long)((e + 1)*a.tile - 2)*a.px_stride + x;
+  const bool px16 = a.px16 != 0;
+  od_store_px(pl, at, t0, px16);
+  od_store_px(pl, at + a.px_stride, t1, px16);
+  od_store_px(pl, at + 2*a.px_stride, t2, px16);
+  od_store_px(pl, at + 3*a.px_stride, t3, px16);
 }
 
 /* Scratch for the edge strips between k_inverse_sb and k_edge_rows / k_edge_cols:
@@ -1253,6 +1294,11 @@ extern "C" int odhip_forward_pyramid(od_coeff *const d_levels[ODHIP_NBSIZES],
   a.h = h;
   a.pic_w = pic_w;
   a.pic_h = pic_h;
+  {
+    ODHIP_CTX_OR_RETURN(ctx);
+    a.px16 = ctx->fpr != 0;
+    if (a.px16 && ((uintptr_t)d_px & 7)) return ODHIP_EINVAL;     /* 8-byte sample groups */
+  }
   const dim3 grid(w/tile, h/tile, nplanes);
   hipStream_t s = (hipStream_t)stream;
   /* ODHIP_PYR_VARIANT selects the kernel shapes round 2 measured against each other
@@ -1316,6 +1362,9 @@ int inverse_launch(const InverseArgs *levels, int nlevels, int nplanes, int dec,
   for (int l = 0; l < nlevels; l++) {
     if (levels[l].w != w || levels[l].h != h) return ODHIP_EINVAL;
     im.a[l] = levels[l];
+    im.a[l].px16 = ctx->fpr != 0;
+    em.a[l].px16 = ctx->fpr != 0;
+    if (ctx->fpr && ((uintptr_t)levels[l].px & 7)) return ODHIP_EINVAL;
     im.a[l].vs = g_strips + (vs_words + hs_words)*l;
     im.a[l].hs = im.a[l].vs + vs_words;
     em.a[l].vs = im.a[l].vs;
@@ -1409,6 +1458,8 @@ extern "C" int odhip_inverse_partition(uint8_t *d_px, int px_stride, long px_pla
   pa.a.pic_h = pic_h;
   pa.a.vs = st.strips;
   pa.a.hs = st.strips + vs_words;
+  pa.a.px16 = ctx->fpr != 0;
+  if (ctx->fpr && ((uintptr_t)d_px & 7)) return ODHIP_EINVAL;
   pa.bsize = d_bsize;
   pa.bstride = bstride;
   pa.bsize_frame_stride = bsize_frame_stride;
@@ -1425,6 +1476,7 @@ extern "C" int odhip_inverse_partition(uint8_t *d_px, int px_stride, long px_pla
   em.a[0].w = w;
   em.a[0].h = h;
   em.a[0].tile = tile;
+  em.a[0].px16 = ctx->fpr != 0;
   const dim3 grid(w/tile, h/tile, nplanes);
   if (dec) k_inverse_part<32><<<grid, Geo<32>::kNT, 0, s>>>(pa);
   else k_inverse_part<64><<<grid, Geo<64>::kNT, 0, s>>>(pa);

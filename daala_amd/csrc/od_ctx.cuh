@@ -26,6 +26,7 @@ enum {
 struct odhip_ctx {
   int device;
   int serial;              /* odhip_ctx_set_serial: no internal side streams */
+  int fpr;                 /* odhip_ctx_set_fpr: picture planes hold int16 samples at 12 bits */
   void *slot[ODHIP_SLOT_COUNT];
   void (*drop[ODHIP_SLOT_COUNT])(void *);
 };

@@ -765,6 +765,28 @@ int odhip_image_planes_copy_pad(uint8_t *d_dst, int dst_stride, long dst_plane_s
  int plane_w, int plane_h, const uint8_t *d_src, int src_stride, long src_plane_stride,
  int pic_w, int pic_h, int nplanes, odhip_stream stream);
 
+/* ---- full-precision references ------------------------------------------------------
+   An encoder created with daala_info.full_precision_references keeps its picture buffers
+   as 16-bit samples at 8 + OD_COEFF_SHIFT = 12 bits (src/encode.c:212-213,
+   src/state.c:256-258: xstride 2), which is how 10- and 12-bit video is coded and how an
+   8-bit source keeps four more bits through prediction.  odhip_ctx_set_fpr(ctx, 1) puts a
+   context in that mode: every PICTURE plane its calls take or produce - the `px` arguments
+   of odhip_forward_pyramid, odhip_inverse_level(s), odhip_inverse_level(s)_pvq,
+   odhip_inverse_levels_pvq_ref and odhip_inverse_partition, typed uint8_t * like the
+   reference's daala_image_plane.data - then holds int16 samples, 8-byte aligned, with
+   strides in SAMPLES: coefficient = p - 2048 on the way in (od_ref_buf_to_coeff,
+   src/state.c:1238-1254), OD_CLAMPFPR(c + 2048) on the way out (od_coeff_to_ref_buf,
+   :1306-1321).  Everything between (filters, transforms, PVQ) is the same arithmetic.
+   odhip_image_planes_copy_pad16 is od_img_plane_copy_pad for such buffers: the copy step is
+   od_img_plane_copy's bit-depth conversion (src/state.c:93-213; src_bitdepth 8: uint8_t
+   samples, 10 / 12: int16_t samples, shifted up to 12 bits and clamped), the extension runs
+   on the 16-bit samples (src/encode.c:791-803, :821-832). */
+int odhip_ctx_set_fpr(odhip_ctx *ctx, int on);
+int odhip_ctx_get_fpr(const odhip_ctx *ctx);
+int odhip_image_planes_copy_pad16(uint16_t *d_dst, int dst_stride, long dst_plane_stride, int plane_w,
+ int plane_h, const void *d_src, int src_bitdepth, int src_stride, long src_plane_stride, int pic_w,
+ int pic_h, int nplanes, odhip_stream stream);
+
 /* ---- frame cache: one batched pyramid serving every per-block fdct_2d call ---
 
    The samples a block of level bs sees in the reference encoder depend only on

@@ -332,12 +332,52 @@ void odo_apply_postfilter_frame_sbs(odo_coeff *c0, int stride, int nhsb,
 /* Pixel <-> coefficient                                                     */
 /* ======================================================================== */
 
+/* Full-precision references (info.full_precision_references, src/encode.c:212-213,
+   src/state.c:256-258): the picture buffers hold 16-bit samples at 8 + OD_COEFF_SHIFT =
+   12 bits (xstride 2 in the reference).  odo_set_fpr(1) makes every px pointer of this
+   file's plane functions (typed uint8_t * as daala_image_plane.data is) an array of
+   uint16_t samples, strides in SAMPLES. */
+static int odo_fpr;
+void odo_set_fpr(int on) {
+  odo_fpr = on != 0;
+}
+
+/* od_ref_buf_to_coeff, src/state.c:1238-1254 (xstride 2, lossy: coeff_shift 0):
+   p - (1 << (8 + OD_COEFF_SHIFT) >> 1). */
+void odo_px16_to_coeff(odo_coeff *dst, int dst_stride, const uint16_t *src, int src_stride, int w,
+ int h) {
+  int x;
+  int y;
+  for (y = 0; y < h; y++) {
+    for (x = 0; x < w; x++) dst[y*dst_stride + x] = (int16_t)src[y*src_stride + x] - 2048;
+  }
+}
+
+/* od_coeff_to_ref_buf, src/state.c:1306-1321 (xstride 2, lossy): OD_CLAMPFPR(c + (128 <<
+   OD_COEFF_SHIFT)), src/odintrin.h:117-120. */
+void odo_coeff_to_px16(uint16_t *dst, int dst_stride, const odo_coeff *src, int src_stride, int w,
+ int h) {
+  int x;
+  int y;
+  for (y = 0; y < h; y++) {
+    for (x = 0; x < w; x++) {
+      int v;
+      v = src[y*src_stride + x] + 2048;
+      dst[y*dst_stride + x] = (uint16_t)(v < 0 ? 0 : v > 4095 ? 4095 : v);
+    }
+  }
+}
+
 /* od_ref_buf_to_coeff, src/state.c:1231-1237 with coeff_shift =
    OD_COEFF_SHIFT = 4 (src/internal.h:124). */
 void odo_px_to_coeff(odo_coeff *dst, int dst_stride, const uint8_t *src,
  int src_stride, int w, int h) {
   int x;
   int y;
+  if (odo_fpr) {
+    odo_px16_to_coeff(dst, dst_stride, (const uint16_t *)src, src_stride, w, h);
+    return;
+  }
   for (y = 0; y < h; y++) {
     for (x = 0; x < w; x++) dst[y*dst_stride + x] = (src[y*src_stride + x] - 128)*16;
   }
@@ -349,6 +389,10 @@ void odo_coeff_to_px(uint8_t *dst, int dst_stride, const odo_coeff *src,
  int src_stride, int w, int h) {
   int x;
   int y;
+  if (odo_fpr) {
+    odo_coeff_to_px16((uint16_t *)dst, dst_stride, src, src_stride, w, h);
+    return;
+  }
   for (y = 0; y < h; y++) {
     for (x = 0; x < w; x++) {
       int v;
@@ -499,6 +543,54 @@ void odo_img_plane_copy_pad(uint8_t *dst, int dstride, int plane_w, int plane_h,
       l = up[x - (x > 0)];
       r = up[x + (x + 1 < plane_w)];
       dst[y*dstride + x] = (uint8_t)((2*c + l + r + 2) >> 2);
+    }
+  }
+}
+
+/* The same for a full-precision-references encoder: the padded plane holds 16-bit samples
+   at 12 bits.  Step 1 is od_img_plane_copy's bit-depth conversion (src/state.c:93-213): an
+   8-bit source (src_bitdepth 8, uint8_t samples) or a 10 / 12-bit one (uint16_t samples) is
+   shifted up into 12 bits and clamped to [0, 4095]; step 2 the [1 2 1]/4 extension on
+   uint16_t (src/encode.c:791-803, :821-832). */
+void odo_img_plane_copy_pad16(uint16_t *dst, int dstride, int plane_w, int plane_h, const void *src,
+ int src_bitdepth, int sstride, int pic_w, int pic_h) {
+  int x;
+  int y;
+  if (pic_w == 0 || pic_h == 0) {
+    for (y = 0; y < plane_h; y++) memset(dst + y*dstride, 0, plane_w*sizeof(*dst));
+    return;
+  }
+  for (y = 0; y < pic_h; y++) {
+    for (x = 0; x < pic_w; x++) {
+      int v;
+      if (src_bitdepth > 8) v = ((const int16_t *)src)[y*sstride + x] << (12 - src_bitdepth);
+      else v = ((const uint8_t *)src)[y*sstride + x] << 4;
+      /* the reference stores through an int16_t pointer: OD_CLAMPI(0, v, 4095) */
+      dst[y*dstride + x] = (uint16_t)(v < 0 ? 0 : v > 4095 ? 4095 : v);
+    }
+  }
+  for (x = pic_w; x < plane_w; x++) {
+    for (y = 0; y < pic_h; y++) {
+      int c;
+      int u;
+      int d;
+      c = dst[y*dstride + x - 1];
+      u = dst[(y > 0 ? y - 1 : y)*dstride + x - 1];
+      d = dst[(y + 1 < pic_h ? y + 1 : y)*dstride + x - 1];
+      dst[y*dstride + x] = (uint16_t)((2*c + u + d + 2) >> 2);
+    }
+  }
+  for (y = pic_h; y < plane_h; y++) {
+    const uint16_t *up;
+    up = dst + (y - 1)*dstride;
+    for (x = 0; x < plane_w; x++) {
+      int c;
+      int l;
+      int r;
+      c = up[x];
+      l = up[x - (x > 0)];
+      r = up[x + (x + 1 < plane_w)];
+      dst[y*dstride + x] = (uint16_t)((2*c + l + r + 2) >> 2);
     }
   }
 }

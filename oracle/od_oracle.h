@@ -44,6 +44,11 @@ void odo_apply_prefilter_frame_sbs(odo_coeff *c0, int stride, int nhsb, int nvsb
 void odo_apply_postfilter_frame_sbs(odo_coeff *c0, int stride, int nhsb, int nvsb, int xdec, int ydec);
 
 /* ---- pixel <-> coefficient: src/state.c:1216-1323 (8-bit, lossy) ---------- */
+void odo_set_fpr(int on);
+void odo_px16_to_coeff(odo_coeff *dst, int dst_stride, const uint16_t *src, int src_stride, int w, int h);
+void odo_coeff_to_px16(uint16_t *dst, int dst_stride, const odo_coeff *src, int src_stride, int w, int h);
+void odo_img_plane_copy_pad16(uint16_t *dst, int dstride, int plane_w, int plane_h, const void *src,
+ int src_bitdepth, int sstride, int pic_w, int pic_h);
 void odo_px_to_coeff(odo_coeff *dst, int dst_stride, const uint8_t *src, int src_stride, int w, int h);
 void odo_coeff_to_px(uint8_t *dst, int dst_stride, const odo_coeff *src, int src_stride, int w, int h);
 

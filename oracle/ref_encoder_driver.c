@@ -494,6 +494,80 @@ REF_EXPORT int ref_image_copy_pad(const unsigned char *frame, int w, int h,
   return 0;
 }
 
+/* The same for an encoder with full_precision_references = 1 (16-bit picture buffers at
+   12 bits, src/encode.c:212-213): the source is 4:2:0 at `bitdepth` 8 (uint8_t samples) or
+   10 / 12 (uint16_t samples, little endian in memory); planes[pli] receives uint16_t
+   samples, tightly packed. */
+REF_EXPORT int ref_image_copy_pad_fpr(const unsigned char *frame, int w, int h, int bitdepth,
+ uint16_t *const planes[3], int *dims) {
+  daala_info di;
+  daala_enc_ctx *enc;
+  daala_image img;
+  daala_image *pad;
+  int pli;
+  int ret;
+  int bytes;
+  bytes = bitdepth > 8 ? 2 : 1;
+  daala_info_init(&di);
+  di.pic_width = w;
+  di.pic_height = h;
+  di.bitdepth_mode = bitdepth == 12 ? OD_BITDEPTH_MODE_12 : bitdepth == 10 ? OD_BITDEPTH_MODE_10
+   : OD_BITDEPTH_MODE_8;
+  di.full_precision_references = 1;
+  di.timebase_numerator = 30;
+  di.timebase_denominator = 1;
+  di.frame_duration = 1;
+  di.pixel_aspect_numerator = 1;
+  di.pixel_aspect_denominator = 1;
+  di.nplanes = 3;
+  di.plane_info[1].xdec = di.plane_info[1].ydec = 1;
+  di.plane_info[2].xdec = di.plane_info[2].ydec = 1;
+  di.keyframe_rate = 1;
+  enc = daala_encode_create(&di);
+  if (enc == NULL) return -1;
+  memset(&img, 0, sizeof(img));
+  img.nplanes = 3;
+  img.width = w;
+  img.height = h;
+  img.planes[0].data = (unsigned char *)frame;
+  img.planes[0].xstride = bytes;
+  img.planes[0].ystride = w*bytes;
+  img.planes[0].bitdepth = bitdepth;
+  for (pli = 1; pli < 3; pli++) {
+    img.planes[pli].data = (unsigned char *)frame + ((long)w*h
+     + (pli - 1)*(long)((w + 1) >> 1)*((h + 1) >> 1))*bytes;
+    img.planes[pli].xdec = 1;
+    img.planes[pli].ydec = 1;
+    img.planes[pli].xstride = bytes;
+    img.planes[pli].ystride = ((w + 1) >> 1)*bytes;
+    img.planes[pli].bitdepth = bitdepth;
+  }
+  ret = daala_encode_img_in(enc, &img, 0);
+  if (ret < 0) {
+    daala_encode_free(enc);
+    return ret;
+  }
+  pad = &enc->input_queue.images[enc->input_queue.input_head];
+  for (pli = 0; pli < 3; pli++) {
+    int pw;
+    int ph;
+    int y;
+    if (pad->planes[pli].xstride != 2) {
+      daala_encode_free(enc);
+      return -2;
+    }
+    pw = pad->width >> pad->planes[pli].xdec;
+    ph = pad->height >> pad->planes[pli].ydec;
+    dims[2*pli] = pw;
+    dims[2*pli + 1] = ph;
+    for (y = 0; y < ph; y++) {
+      memcpy(planes[pli] + (long)y*pw, pad->planes[pli].data + (long)y*pad->planes[pli].ystride, pw*2);
+    }
+  }
+  daala_encode_free(enc);
+  return 0;
+}
+
 /* ---- decoder side ------------------------------------------------------------------
    ref_roundtrip_yuv420: encodes like ref_encode_yuv420 but keeps the three header
    packets, then feeds headers and data packets to the REAL reference decoder

@@ -170,15 +170,23 @@ REF_EXPORT void ref_apply_postfilter_frame_sbs(od_coeff *c, int stride,
   od_apply_postfilter_frame_sbs(c, stride, nhsb, nvsb, xdec, ydec, 0, NULL, 0);
 }
 
-/* ---- pixel <-> coefficient (src/state.c:1216-1323, 8-bit lossy path) ---- */
+/* ---- pixel <-> coefficient (src/state.c:1216-1323, lossy path) ----------------
+   ref_set_fpr(1): full-precision references - every px pointer of this file's plane
+   functions is an array of 16-bit samples at 12 bits (the reference's xstride 2), strides
+   in SAMPLES; the reference's own conversion branches for xstride 2 do the work. */
+static int ref_fpr;
+REF_EXPORT void ref_set_fpr(int on) {
+  ref_fpr = on != 0;
+}
+
 REF_EXPORT void ref_px_to_coeff(od_coeff *dst, int dst_stride,
  unsigned char *src, int src_stride, int w, int h) {
-  od_ref_buf_to_coeff(NULL, dst, dst_stride, 0, src, 1, src_stride, w, h);
+  od_ref_buf_to_coeff(NULL, dst, dst_stride, 0, src, ref_fpr ? 2 : 1, src_stride << ref_fpr, w, h);
 }
 
 REF_EXPORT void ref_coeff_to_px(unsigned char *dst, int dst_stride,
  od_coeff *src, int src_stride, int w, int h) {
-  od_coeff_to_ref_buf(NULL, dst, 1, dst_stride, src, src_stride, 0, w, h);
+  od_coeff_to_ref_buf(NULL, dst, ref_fpr ? 2 : 1, dst_stride << ref_fpr, src, src_stride, 0, w, h);
 }
 
 /* ---- forward lapped-transform pyramid of one plane ----------------------
@@ -223,7 +231,7 @@ REF_EXPORT void ref_forward_pyramid_plane(od_coeff **levels, od_coeff *c,
   top = OD_NBSIZES - 1 - dec;
   nhsb = w >> (OD_LOG_BSIZE_MAX - dec);
   nvsb = h >> (OD_LOG_BSIZE_MAX - dec);
-  od_ref_buf_to_coeff(NULL, c, w, 0, px, 1, px_stride, w, h);
+  od_ref_buf_to_coeff(NULL, c, w, 0, px, ref_fpr ? 2 : 1, px_stride << ref_fpr, w, h);
   od_apply_prefilter_frame_sbs(c, w, nhsb, nvsb, dec, dec);
   for (sby = 0; sby < nvsb; sby++) {
     for (sbx = 0; sbx < nhsb; sbx++) {
@@ -281,7 +289,7 @@ REF_EXPORT void ref_inverse_level_plane(unsigned char *px, int px_stride,
     }
   }
   od_apply_postfilter_frame_sbs(c, w, nhsb, nvsb, dec, dec, 0, NULL, 0);
-  od_coeff_to_ref_buf(NULL, px, 1, px_stride, c, w, 0, w, h);
+  od_coeff_to_ref_buf(NULL, px, ref_fpr ? 2 : 1, px_stride << ref_fpr, c, w, 0, w, h);
 }
 
 /* ---- coefficient scan (src/partition.c:144-194) ------------------------- */

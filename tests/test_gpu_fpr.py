@@ -1,0 +1,100 @@
+"""Full-precision references on the GPU (odhip_ctx_set_fpr, odhip_image_planes_copy_pad16):
+16-bit picture planes at 12 bits through the input padding, the forward pyramid and the
+inverse, bit-exact against the oracle in FPR mode (itself pinned to the reference's xstride-2
+branches and to a real FPR encoder's padded input, tests/test_oracle_fpr.py)."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from _libs import P, oracle
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    import torch
+    import daala_amd
+    assert torch.cuda.is_available()
+    daala_amd.init(0)
+    return daala_amd
+
+
+def _cuda(a):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+@pytest.mark.parametrize("bitdepth", [8, 10, 12])
+def test_image_pad16_matches_oracle(hip, bitdepth):
+    o = oracle()
+    rng = np.random.RandomState(bitdepth)
+    for (pw, ph, plane_w, plane_h) in ((70, 50, 128, 64), (64, 64, 64, 64), (1, 1, 64, 64), (1920, 1080, 1920, 1088),
+                                       (0, 0, 64, 64), (100, 64, 128, 64), (128, 37, 128, 64)):
+        if bitdepth == 8:
+            src = rng.randint(0, 256, size=(3, ph, pw)).astype(np.uint8)
+        else:
+            src = rng.randint(0, 1 << bitdepth, size=(3, ph, pw)).astype(np.int16)
+        got = hip.image_planes_copy_pad16(_cuda(src), plane_w, plane_h, bitdepth).cpu().numpy().view(np.uint16)
+        for p in range(3):
+            want = np.zeros((plane_h, plane_w), np.uint16)
+            o.odo_img_plane_copy_pad16(P(want), plane_w, plane_w, plane_h,
+                                       P(np.ascontiguousarray(src[p])) if src[p].size else None, bitdepth,
+                                       pw, pw, ph)
+            assert np.array_equal(got[p], want), (bitdepth, pw, ph, p)
+
+
+@pytest.mark.parametrize("dec,shape", [(0, (2, 192, 320)), (1, (4, 96, 160)), (0, (1, 64, 64))])
+def test_fpr_pyramid_and_inverse_match_oracle(hip, dec, shape):
+    o = oracle()
+    rng = np.random.RandomState(31 + dec)
+    nplanes, h, w = shape
+    px = rng.randint(0, 4096, size=shape).astype(np.int16)
+    px[:, :8, :8] = 4095
+    px[:, 8:16, :8] = 0
+    pic_w, pic_h = (w << dec) - 20, (h << dec) - 12      # the split filters are gated by the picture size
+    top = 4 - dec
+    ctx = hip.Context(0).set_fpr(True)
+    try:
+        with ctx:
+            levels = hip.forward_pyramid(_cuda(px), dec, pic_w, pic_h)
+            assert hip.px_dtype().itemsize == 2
+            d = [np.ascontiguousarray(levels[bs].cpu().numpy() + rng.randint(-700, 701, size=shape).astype(np.int32))
+                 for bs in range(top + 1)]
+            recon = hip.inverse_levels([_cuda(a) for a in d], dec, list(range(top + 1)), pic_w, pic_h)
+            recon = [t.cpu().numpy().view(np.uint16) for t in recon]
+        o.odo_set_fpr(1)
+        for p in range(nplanes):
+            want = [np.zeros((h, w), np.int32) for _ in range(5)]
+            c = np.zeros((h, w), np.int32)
+            o.odo_forward_pyramid_plane((ctypes.c_void_p * 5)(*[a.ctypes.data for a in want]), P(c),
+                                        P(np.ascontiguousarray(px[p])), w, w, h, dec, pic_w, pic_h)
+            for bs in range(top + 1):
+                assert np.array_equal(levels[bs][p].cpu().numpy(), want[bs]), (dec, p, bs)
+                rec = np.zeros((h, w), np.uint16)
+                cc = np.zeros((h, w), np.int32)
+                o.odo_inverse_level_plane(P(rec), w, P(cc), P(np.ascontiguousarray(d[bs][p])), w, h, dec, bs,
+                                          pic_w, pic_h)
+                assert np.array_equal(recon[bs][p], rec), (dec, p, bs)
+                assert int(rec.max()) <= 4095
+    finally:
+        o.odo_set_fpr(0)
+        ctx.destroy()
+
+
+def test_fpr_of_an_8bit_source_is_the_8bit_pyramid(hip):
+    """A 12-bit plane that is an 8-bit picture shifted up by OD_COEFF_SHIFT gives the very
+    coefficients of the 8-bit path ((p << 4) - 2048 == (p - 128) << 4)."""
+    rng = np.random.RandomState(2)
+    p8 = rng.randint(0, 256, size=(2, 128, 192)).astype(np.uint8)
+    a = hip.forward_pyramid(_cuda(p8), 0, 192, 128)
+    ctx = hip.Context(0).set_fpr(True)
+    try:
+        with ctx:
+            b = hip.forward_pyramid(_cuda((p8.astype(np.int16) << 4)), 0, 192, 128)
+    finally:
+        ctx.destroy()
+    import torch
+    for bs in range(5):
+        assert torch.equal(a[bs], b[bs]), bs
