@@ -135,13 +135,17 @@ int setup_set(odhip_pipe *p, PlaneSet &s, int dec, int pli, int nplanes) {
   s.pw = (p->pic_w + dec) >> dec;
   s.ph = (p->pic_h + dec) >> dec;
   s.nlev = ODHIP_NBSIZES - dec;
-  PIPE_ALLOC(p, s.pic, (size_t)nplanes*s.pw*s.ph, true);
-  PIPE_ALLOC(p, s.px, (size_t)nplanes*s.w*s.h, true);
+  /* full-precision references: the coded planes and the reconstructions hold int16
+     samples; the resident source pictures keep their own depth */
+  const size_t px_bytes = p->cfg.fpr_bits ? 2 : 1;
+  const size_t pic_bytes = p->cfg.fpr_bits > 8 ? 2 : 1;
+  PIPE_ALLOC(p, s.pic, (size_t)nplanes*s.pw*s.ph*pic_bytes, true);
+  PIPE_ALLOC(p, s.px, (size_t)nplanes*s.w*s.h*px_bytes, true);
   for (int bs = 0; bs < s.nlev; bs++) {
     const int n = 4 << bs;
     const int len = n*n < OD_SCAN_LEN ? n*n : OD_SCAN_LEN;
     PIPE_ALLOC(p, s.levels[bs], sizeof(od_coeff)*(size_t)nplanes*s.w*s.h, true);
-    PIPE_ALLOC(p, s.recon[bs], (size_t)nplanes*s.w*s.h, true);
+    PIPE_ALLOC(p, s.recon[bs], (size_t)nplanes*s.w*s.h*px_bytes, true);
     PIPE_ALLOC(p, s.qm[bs], sizeof(int16_t)*len, false);
     PIPE_ALLOC(p, s.qm_inv[bs], sizeof(int16_t)*len, false);
     const int off = odhip_qm_offset(bs, dec);
@@ -227,6 +231,7 @@ int pipe_init(odhip_pipe *p) {
     p->ctx[i] = odhip_create(c.device);
     if (!p->ctx[i]) return ODHIP_EFAULT;
     odhip_ctx_set_serial(p->ctx[i], p->serial);
+    odhip_ctx_set_fpr(p->ctx[i], c.fpr_bits != 0);
   }
   ODHIP_TRY(hipStreamCreateWithFlags(&p->stream[0], hipStreamNonBlocking));
   if (p->serial) p->stream[1] = p->stream[0];
@@ -279,6 +284,10 @@ struct Current {
 int stage_pad(odhip_pipe *p, int si, hipStream_t s) {
   PlaneSet &t = p->set[si];
   Timed tm(p, si ? ODHIP_PIPE_PAD_CHROMA : ODHIP_PIPE_PAD_LUMA, s);
+  if (p->cfg.fpr_bits) {
+    return odhip_image_planes_copy_pad16(reinterpret_cast<uint16_t *>(t.px), t.w, (long)t.w*t.h, t.w, t.h, t.pic,
+     p->cfg.fpr_bits, t.pw, (long)t.pw*t.ph, t.pw, t.ph, t.nplanes, s);
+  }
   return odhip_image_planes_copy_pad(t.px, t.w, (long)t.w*t.h, t.w, t.h, t.pic, t.pw, (long)t.pw*t.ph,
    t.pw, t.ph, t.nplanes, s);
 }
@@ -441,7 +450,8 @@ int step_cfl(odhip_pipe *p) {
 
 extern "C" odhip_pipe *odhip_pipe_create(const odhip_pipe_config *cfg) {
   if (!cfg || !cfg->quant || cfg->frames <= 0 || cfg->pic_w <= 0 || cfg->pic_h <= 0
-   || (cfg->pic_w & 1) || (cfg->pic_h & 1)) {
+   || (cfg->pic_w & 1) || (cfg->pic_h & 1)
+   || (cfg->fpr_bits != 0 && cfg->fpr_bits != 8 && cfg->fpr_bits != 10 && cfg->fpr_bits != 12)) {
     return nullptr;
   }
   odhip_pipe *p = new odhip_pipe();
@@ -494,8 +504,9 @@ extern "C" int odhip_pipe_set_pictures(odhip_pipe *p, const uint8_t *luma, const
   const hipMemcpyKind kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
   const PlaneSet &l = p->set[0];
   const PlaneSet &c = p->set[1];
-  ODHIP_TRY(hipMemcpyAsync(l.pic, luma, (size_t)l.nplanes*l.pw*l.ph, kind, p->stream[0]));
-  ODHIP_TRY(hipMemcpyAsync(c.pic, chroma, (size_t)c.nplanes*c.pw*c.ph, kind, p->stream[0]));
+  const size_t pic_bytes = p->cfg.fpr_bits > 8 ? 2 : 1;
+  ODHIP_TRY(hipMemcpyAsync(l.pic, luma, (size_t)l.nplanes*l.pw*l.ph*pic_bytes, kind, p->stream[0]));
+  ODHIP_TRY(hipMemcpyAsync(c.pic, chroma, (size_t)c.nplanes*c.pw*c.ph*pic_bytes, kind, p->stream[0]));
   ODHIP_TRY(hipStreamSynchronize(p->stream[0]));
   return ODHIP_SUCCESS;
 }
@@ -598,10 +609,10 @@ extern "C" int odhip_pipe_buffer(odhip_pipe *p, int what, int set, int level, in
   void *ptr = nullptr;
   size_t n = 0;
   switch (what) {
-    case ODHIP_PIPE_BUF_PIC: ptr = t.pic; n = (size_t)t.nplanes*t.pw*t.ph; break;
-    case ODHIP_PIPE_BUF_PX: ptr = t.px; n = (size_t)t.nplanes*t.w*t.h; break;
+    case ODHIP_PIPE_BUF_PIC: ptr = t.pic; n = (size_t)t.nplanes*t.pw*t.ph*(p->cfg.fpr_bits > 8 ? 2 : 1); break;
+    case ODHIP_PIPE_BUF_PX: ptr = t.px; n = (size_t)t.nplanes*t.w*t.h*(p->cfg.fpr_bits ? 2 : 1); break;
     case ODHIP_PIPE_BUF_LEVEL: ptr = t.levels[level]; n = sizeof(od_coeff)*(size_t)t.nplanes*t.w*t.h; break;
-    case ODHIP_PIPE_BUF_RECON: ptr = t.recon[level]; n = (size_t)t.nplanes*t.w*t.h; break;
+    case ODHIP_PIPE_BUF_RECON: ptr = t.recon[level]; n = (size_t)t.nplanes*t.w*t.h*(p->cfg.fpr_bits ? 2 : 1); break;
     case ODHIP_PIPE_BUF_BAND:
       ptr = j ? (void *)j->cands.band : (void *)r->band;
       n = (size_t)64*B*nb;

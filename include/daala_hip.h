@@ -960,7 +960,11 @@ typedef struct {
   int price;                    /* 1: the choice prices every candidate with od_pvq_rate's
                                    closed form on the device (odhip_pvq_*choose_priced_*);
                                    0: on distortion alone, or with rate tables             */
-  int reserved;
+  int fpr_bits;                 /* 0: 8-bit picture buffers.  8 / 10 / 12: full-precision
+                                   references - the coded planes and the reconstructions are
+                                   int16 samples at 12 bits (odhip_ctx_set_fpr on both
+                                   contexts), the resident pictures are uint8_t (8) or int16
+                                   (10, 12) samples of that depth */
   double pvq_norm_lambda;       /* OD_PVQ_LAMBDA, src/pvq.h:49 */
   const odhip_quant *quant;
 } odhip_pipe_config;

@@ -38,11 +38,24 @@ def _tables(qt, p):
     return qm_off, qb, bb
 
 
-def cpu_frame(qt, pics, pic_w, pic_h, chroma_cfl=True, lam=0.147, lib=None):
+def cpu_frame(qt, pics, pic_w, pic_h, chroma_cfl=True, lam=0.147, lib=None, fpr_bits=0):
     """pics: [Y, Cb, Cr] uint8 pictures.  Returns (recon, blocks, seconds): recon[pli][bs]
     = uint8 plane of the coded size, reconstructed at uniform partition level bs.  lib:
-    another build of the reference (the x86-intrinsics one) instead of oracle/_ref's default."""
+    another build of the reference (the x86-intrinsics one) instead of oracle/_ref's default.
+    fpr_bits = 8 / 10 / 12: full-precision references - pictures of that depth, planes of
+    int16 samples at 12 bits, the reference's xstride-2 conversions (recon is uint16)."""
     r = lib if lib is not None else ref()
+    if fpr_bits:
+        r.ref_set_fpr(1)
+        try:
+            return _cpu_frame(r, qt, pics, pic_w, pic_h, chroma_cfl, lam, fpr_bits)
+        finally:
+            r.ref_set_fpr(0)
+    return _cpu_frame(r, qt, pics, pic_w, pic_h, chroma_cfl, lam, 0)
+
+
+def _cpu_frame(r, qt, pics, pic_w, pic_h, chroma_cfl, lam, fpr_bits):
+    pdt = np.uint16 if fpr_bits else np.uint8
     assert r is not None, "oracle/_ref/libdaalaref.so not built"
     r.ref_stage_plane_levels.restype = ctypes.c_long
     W, H = (pic_w + 63) & ~63, (pic_h + 63) & ~63
@@ -58,15 +71,19 @@ def cpu_frame(qt, pics, pic_w, pic_h, chroma_cfl=True, lam=0.147, lib=None):
         h, w = H >> dec, W >> dec
         qm_off, qb, bb = _tables(qt, p)
         pic = np.ascontiguousarray(pics[pli])
-        px = np.zeros((h, w), np.uint8)
+        px = np.zeros((h, w), pdt)
         nlev = 5 - dec
-        rec = [np.zeros((h, w), np.uint8) for _ in range(nlev)]
+        rec = [np.zeros((h, w), pdt) for _ in range(nlev)]
         rec_arr = (ctypes.c_void_p * 5)(*([a.ctypes.data for a in rec] + [None] * (5 - nlev)))
         t0 = time.perf_counter()
         # od_img_plane_copy_pad is file-static in the reference's encode.c: the restatement
         # (pinned to the encoder's own padded input, tests/test_oracle_golden.py)
-        oracle().odo_img_plane_copy_pad(P(px), w, w, h, P(pic), pic.shape[1], pic.shape[1],
-                                        pic.shape[0])
+        if fpr_bits:
+            oracle().odo_img_plane_copy_pad16(P(px), w, w, h, P(pic), fpr_bits, pic.shape[1], pic.shape[1],
+                                              pic.shape[0])
+        else:
+            oracle().odo_img_plane_copy_pad(P(px), w, w, h, P(pic), pic.shape[1], pic.shape[1],
+                                            pic.shape[0])
         if pli == 0:
             dq = (ctypes.c_void_p * 5)(*[a.ctypes.data for a in ldq])
             blocks += r.ref_stage_plane_levels(P(px), w, w, h, 0, pic_w, pic_h, 0, P(qm), P(qmi), qm_off,
@@ -160,7 +177,7 @@ def gpu_priced_frame(D, qt, pics, pic_w, pic_h, chroma_cfl=True, lam=0.147, fram
 
 
 def gpu_device_priced(D, qt, pics, pic_w, pic_h, chroma_cfl=True, lam=0.147, frames=None, serial=False,
-                      steps=None):
+                      steps=None, fpr_bits=0):
     """The F pictures through `steps` odhip_pipe_step calls (each codes all F) of a price=1
     pipe.  Returns (recon like gpu_priced_frame(), bands the host libm re-decided)."""
     F = frames or 1
@@ -168,7 +185,8 @@ def gpu_device_priced(D, qt, pics, pic_w, pic_h, chroma_cfl=True, lam=0.147, fra
     chroma = np.concatenate([np.ascontiguousarray(pics[1]).reshape(F, pic_h // 2, pic_w // 2),
                              np.ascontiguousarray(pics[2]).reshape(F, pic_h // 2, pic_w // 2)])
     pipe = D.Pipe(qt, F, pic_w, pic_h, chroma_cfl=chroma_cfl, serial=serial, pvq_norm_lambda=lam,
-                  price=True)
+                  price=True, fpr_bits=fpr_bits)
+    rdt = np.uint16 if fpr_bits else np.uint8
     try:
         pipe.set_pictures(luma, chroma)
         for _ in range(steps or 2):
@@ -176,8 +194,8 @@ def gpu_device_priced(D, qt, pics, pic_w, pic_h, chroma_cfl=True, lam=0.147, fra
         pipe.flush()
         pipe.sync()
         W, H = pipe.W, pipe.H
-        out = [[pipe.read(D.BUF_RECON, 0, bs).reshape(F, H, W) for bs in range(5)],
-               [pipe.read(D.BUF_RECON, 1, bs).reshape(2 * F, H // 2, W // 2) for bs in range(4)]]
+        out = [[pipe.read(D.BUF_RECON, 0, bs, dtype=rdt).reshape(F, H, W) for bs in range(5)],
+               [pipe.read(D.BUF_RECON, 1, bs, dtype=rdt).reshape(2 * F, H // 2, W // 2) for bs in range(4)]]
         reruns = pipe.price_reruns()
     finally:
         pipe.destroy()

@@ -98,3 +98,36 @@ def test_fpr_of_an_8bit_source_is_the_8bit_pyramid(hip):
     import torch
     for bs in range(5):
         assert torch.equal(a[bs], b[bs]), bs
+
+
+@pytest.mark.parametrize("bits", [8, 10, 12])
+def test_fpr_whole_frame_step_equals_compiled_reference(hip, bits):
+    """The frame-batch step in full-precision-references mode (odhip_pipe_config.fpr_bits):
+    pictures of 8 / 10 / 12 bits, the choice priced on the device, every reconstructed
+    12-bit sample of every level of Y, Cb, Cr against the reference's own C functions in
+    FPR mode."""
+    from _libs import ref
+    if ref() is None:
+        pytest.skip("oracle/_ref not present")
+    import sys
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    import _pipeline_check as C
+    qt = hip.QuantTables.for_quality(40)
+    full = bench.natural_like_frame_np(4, 77)
+    pw, ph = 312, 180
+    rng = np.random.RandomState(bits)
+    pics = []
+    for pl, (w_, h_) in zip(full, ((pw, ph), (pw // 2, ph // 2), (pw // 2, ph // 2))):
+        p8 = pl[:h_, :w_].astype(np.int32)
+        if bits == 8:
+            pics.append(p8.astype(np.uint8))
+        else:
+            lo = rng.randint(0, 1 << (bits - 8), size=p8.shape)      # use the extra bits
+            pics.append(((p8 << (bits - 8)) + lo).astype(np.int16))
+    for cfl in (True, False):
+        cpu, _, _ = C.cpu_frame(qt, pics, pw, ph, chroma_cfl=cfl, fpr_bits=bits)
+        gpu, _ = C.gpu_device_priced(hip, qt, pics, pw, ph, chroma_cfl=cfl, fpr_bits=bits)
+        assert C.compare_frame(gpu, cpu) == [], (bits, cfl)
+        assert int(cpu[0][0].max()) > 255          # really 12-bit samples
