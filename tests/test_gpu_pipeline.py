@@ -142,6 +142,44 @@ def test_device_priced_host_libm_path_forced():
 
 
 @pytest.mark.skipif(ref() is None, reason="oracle/_ref (the compiled reference) not present")
+def test_theta_margin_rerun_inside_priced_steps():
+    """The other deferred host path of a step: bands whose theta the device cannot be trusted
+    with (margin forced wide, device theta deliberately off by one) are re-run with the
+    host's acos one step late, and - the band stage having made the priced choice of the
+    per-lane bands itself - every band is then decided again from the candidate records.
+    Same pixels as the compiled reference, pipelined and serial."""
+    import daala_amd as D
+    import _pipeline_check as C
+    D.init(0)
+    b = _bench()
+    qt = D.QuantTables.for_quality(40)
+    full = b.natural_like_frame_np(6, 5)
+    pw, ph = 312, 180
+    pics = [full[0][:ph, :pw], full[1][:ph // 2, :pw // 2], full[2][:ph // 2, :pw // 2]]
+    cpu, _, _ = C.cpu_frame(qt, pics, pw, ph, chroma_cfl=True)
+    D.pvq_ref_set_theta_margin(0.25, True)
+    try:
+        for serial in (False, True):
+            luma = np.ascontiguousarray(pics[0])[None]
+            chroma = np.stack([pics[1], pics[2]])
+            pipe = D.Pipe(qt, 1, pw, ph, chroma_cfl=True, serial=serial, price=True)
+            try:
+                pipe.set_pictures(luma, chroma)
+                for _ in range(3):
+                    pipe.step()
+                pipe.flush()
+                pipe.sync()
+                assert pipe.theta_reruns() > 100, pipe.theta_reruns()
+                gpu = [[pipe.read(D.BUF_RECON, 0, bs).reshape(1, pipe.H, pipe.W) for bs in range(5)],
+                       [pipe.read(D.BUF_RECON, 1, bs).reshape(2, pipe.H // 2, pipe.W // 2) for bs in range(4)]]
+            finally:
+                pipe.destroy()
+            assert C.compare_frame(gpu, cpu) == [], serial
+    finally:
+        D.pvq_ref_set_theta_margin(0, False)
+
+
+@pytest.mark.skipif(ref() is None, reason="oracle/_ref (the compiled reference) not present")
 def test_whole_frame_noref_chroma_and_ragged_size():
     """Chroma through the no-reference stage, and a picture whose size is not a
     multiple of the superblock (padding + gated split filters), whole frame."""
