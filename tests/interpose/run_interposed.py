@@ -22,7 +22,9 @@ if interpose:
     assert hip.odhip_init(0) == 0
     ipo = ctypes.CDLL(os.path.join(ROOT, "tests", "interpose", "libinterpose.so"),
                       mode=ctypes.RTLD_GLOBAL)
-r = ctypes.CDLL(os.path.join(ROOT, "oracle", "_ref", "libdaalaref.so"))
+# REF_LIB=libdaalaref_4x4.so: the reference built with block sizes limited to 4x4 (BASELINE
+# configs[0]; oracle/Makefile)
+r = ctypes.CDLL(os.path.join(ROOT, "oracle", "_ref", os.environ.get("REF_LIB", "libdaalaref.so")))
 if ipo is not None:
     # pass-through mode (ODHIP_INTERPOSE_PASSTHROUGH=1) calls the reference's own definitions
     ipo.odhip_interpose_set_reference(ctypes.c_void_p(r._handle))

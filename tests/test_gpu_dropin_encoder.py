@@ -5,6 +5,7 @@ its od_state_opt_vtbl.fdct_2d/idct_2d slots produces byte-identical packets.
 Skipped when oracle/_ref is not present on the box (it is a prebuilt file that
 travels with the snapshot; /root/reference itself is never read here)."""
 import ctypes
+import os
 
 import numpy as np
 import pytest
@@ -195,3 +196,36 @@ def test_dering_level_search_from_batched_passes_is_byte_identical():
         # one launch per (plane, threshold) pair per frame, at most 5 + 2 * 5
         assert launches <= 15 * nframes, cached["dering"]
         assert served == cached["calls"][5], (cached["dering"], cached["calls"])
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "oracle",
+                                                    "_ref", "libdaalaref_4x4.so")),
+                    reason="oracle/_ref/libdaalaref_4x4.so not present")
+def test_configs0_reference_built_for_4x4_blocks_only():
+    """BASELINE configs[0]: 64x64 4:2:0, two frames, the reference BUILT with block sizes limited
+    to 4x4 (src/internal.h:100-101; oracle/_ref/libdaalaref_4x4.so).  With the HIP surfaces bound -
+    the transforms through the vtbl slots, the filter drivers and the PVQ search by symbol - its
+    packets are byte-identical to its own plain-C packets, and differ from the default build's
+    (the limit really changes what is coded)."""
+    import json
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+
+    def run(mode, **env):
+        e = dict(os.environ)
+        e.update({k: str(v) for k, v in env.items()})
+        p = subprocess.run([sys.executable, os.path.join(here, "interpose", "run_interposed.py"), str(mode)],
+                           capture_output=True, text=True, timeout=900, env=e)
+        assert p.returncode == 0, p.stderr[-3000:]
+        return json.loads(p.stdout.strip().splitlines()[-1])
+
+    default = run(0)
+    plain = run(0, REF_LIB="libdaalaref_4x4.so")
+    bound = run(1, REF_LIB="libdaalaref_4x4.so", ODHIP_INTERPOSE_VTBL=1)
+    assert plain["sizes"] != default["sizes"]
+    assert bound["sizes"] == plain["sizes"]
+    assert bound["packets"] == plain["packets"], "4x4-only build: packets differ with the HIP surfaces bound"
+    # every superblock is split all the way down (the split filters of all four levels run),
+    # only 4x4 blocks are coded
+    assert all(c > 0 for c in bound["calls"]), bound["calls"]
