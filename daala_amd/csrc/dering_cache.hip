@@ -104,6 +104,8 @@ int load_plane(odhip_dering_cache *c, odhip_dering_cache::Plane &p, const int16_
   }
   ODHIP_TRY(hipMemcpyAsync(p.d_x, base, xbytes, hipMemcpyHostToDevice, c->stream));
   ODHIP_TRY(hipMemcpyAsync(p.d_skip, skip_base, sbytes, hipMemcpyHostToDevice, c->stream));
+  /* the encoder owns the source: it must not be read after this call returns */
+  ODHIP_TRY(hipStreamSynchronize(c->stream));
   p.base = base;
   p.skip_base = skip_base;
   p.xstride = xstride;
