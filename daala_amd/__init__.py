@@ -24,5 +24,6 @@ from .api import (DaalaHipError, lib, lib_path, init, fdct2d_batch, idct2d_batch
                   pvq_ref_choose_multi, inverse_levels_pvq_ref, Context, Pipe, PIPE_STAGES,
                   BUF_PIC, BUF_PX, BUF_LEVEL, BUF_RECON, BUF_BAND, BUF_Y, BUF_CHOICE, BUF_ITEMS,
                   BUF_REF, BUF_RATE, compute_dist, set_price_tol_scale, px_dtype,
-                  image_planes_copy_pad16)
+                  image_planes_copy_pad16, pvq_choose_priced_multi,
+                  pvq_ref_choose_priced_multi)
 from .quant import QuantTables, OD_PVQ_LAMBDA  # noqa: F401

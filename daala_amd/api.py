@@ -454,6 +454,30 @@ def pvq_choose_multi(jobs, pvq_norm_lambda):
            "odhip_pvq_choose_multi")
 
 
+def _resolved(n, what):
+    if n < 0:
+        raise DaalaHipError("%s failed with code %d" % (what, n))
+    return n
+
+
+def pvq_choose_priced_multi(jobs, pvq_norm_lambda, fused_bands=False):
+    """The choice priced with od_pvq_rate's closed form on the device.  fused_bands=False:
+    after pvq_noref_bands_multi, a choice kernel reads the records
+    (odhip_pvq_choose_priced_multi); True: band stage AND choice in one pass
+    (odhip_pvq_noref_bands_priced_multi).  Either way followed by the host-libm resolve;
+    returns the number of bands it re-decided."""
+    arr = _jobs_array(jobs)
+    lam = ctypes.c_double(pvq_norm_lambda)
+    if fused_bands:
+        _check(lib().odhip_pvq_noref_bands_priced_multi(arr, len(jobs), lam, _stream()),
+               "odhip_pvq_noref_bands_priced_multi")
+    else:
+        _check(lib().odhip_pvq_choose_priced_multi(arr, len(jobs), lam, _stream()),
+               "odhip_pvq_choose_priced_multi")
+    return _resolved(lib().odhip_pvq_choose_priced_resolve(arr, len(jobs), lam, _stream()),
+                     "odhip_pvq_choose_priced_resolve")
+
+
 def inverse_level_pvq(job, dec, pic_w, pic_h, out=None):
     """Inverse stage fed by the band stage: dequantise-on-load from the chosen
     pulse vectors of `job` (no dequantised plane in HBM)."""
@@ -756,6 +780,32 @@ def pvq_ref_choose_multi(jobs, pvq_norm_lambda):
     _check(lib().odhip_pvq_ref_choose_multi(_refjobs_array(jobs), len(jobs),
                                             ctypes.c_double(pvq_norm_lambda), _stream()),
            "odhip_pvq_ref_choose_multi")
+
+
+def pvq_ref_choose_priced_multi(jobs, pvq_norm_lambda, fused_bands=False):
+    """The with-reference stage's choice priced on the device.  fused_bands=False: after
+    pvq_ref_bands_multi, every band decided from its candidate records
+    (odhip_pvq_ref_choose_priced_multi); True: band stage with the per-lane bands decided
+    inside their searches, then the rest (odhip_pvq_ref_bands_priced_multi +
+    odhip_pvq_ref_resolve + odhip_pvq_ref_choose_priced_rest_multi).  Followed by the host-libm
+    resolve; returns the number of bands it re-decided."""
+    arr = _refjobs_array(jobs)
+    lam = ctypes.c_double(pvq_norm_lambda)
+    L = lib()
+    if fused_bands:
+        _check(L.odhip_pvq_ref_bands_priced_multi(arr, len(jobs), lam, _stream()), "odhip_pvq_ref_bands_priced_multi")
+        if _resolved(L.odhip_pvq_ref_resolve(arr, len(jobs), lam, _stream()), "odhip_pvq_ref_resolve"):
+            # bands were re-run with the host's theta: everything is decided from the records
+            _check(L.odhip_pvq_ref_choose_priced_multi(arr, len(jobs), lam, _stream()),
+                   "odhip_pvq_ref_choose_priced_multi")
+        else:
+            _check(L.odhip_pvq_ref_choose_priced_rest_multi(arr, len(jobs), lam, _stream()),
+                   "odhip_pvq_ref_choose_priced_rest_multi")
+    else:
+        _check(L.odhip_pvq_ref_choose_priced_multi(arr, len(jobs), lam, _stream()),
+               "odhip_pvq_ref_choose_priced_multi")
+    return _resolved(L.odhip_pvq_ref_choose_priced_resolve(arr, len(jobs), lam, _stream()),
+                     "odhip_pvq_ref_choose_priced_resolve")
 
 
 def inverse_levels_pvq_ref(jobs, dec, pic_w, pic_h, outs=None):

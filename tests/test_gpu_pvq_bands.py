@@ -209,6 +209,57 @@ def test_inverse_levels_in_one_launch_equal_level_by_level(hip, dec):
     assert torch.equal(got2[0], want[2]) and torch.equal(got2[1], want[0])
 
 
+@pytest.mark.parametrize("dec", [0, 1])
+def test_priced_choice_inside_the_search_equals_the_choice_kernel(hip, dec):
+    """odhip_pvq_noref_bands_priced_multi (the search kernels decide from their registers) and
+    odhip_pvq_noref_bands_multi + odhip_pvq_choose_priced_multi (a choice kernel reads the
+    records) leave identical choice records, candidate records and pulse vectors; and with the
+    decision margin forced wide the host-libm resolve re-decides bands to the same result."""
+    import torch
+    W, H = 256, 192
+    planes = synth_frame(W, H, seed=29)
+    rng = np.random.RandomState(6)
+    src = planes[0] if dec == 0 else planes[1]
+    src = np.clip(src.astype(int) + rng.randint(-70, 71, size=src.shape), 0, 255).astype(np.uint8)
+    px = _cuda(np.stack([src, src[::-1].copy()]))
+    pli = 0 if dec == 0 else 1
+    levels = hip.forward_pyramid(px, dec, W, H)
+    qt = hip.QuantTables.load()
+    lam = hip.OD_PVQ_LAMBDA
+
+    def jobs():
+        out = []
+        for bs in range(5 - dec):
+            qm, qmi = qt.qm_slices(pli, bs)
+            out.append(hip.PvqJob(levels[bs], bs, _cuda(qm), _cuda(qmi), qt.q_band(pli, bs),
+                                  qt.beta_band(pli, bs)))
+        return out
+
+    a, b, c = jobs(), jobs(), jobs()
+    hip.pvq_noref_bands_multi(a, lam)
+    assert hip.pvq_choose_priced_multi(a, lam) == 0
+    assert hip.pvq_choose_priced_multi(b, lam, fused_bands=True) == 0
+    hip.set_price_tol_scale(1e12)
+    try:
+        redone = hip.pvq_choose_priced_multi(c, lam, fused_bands=True)
+    finally:
+        hip.set_price_tol_scale(1.)
+    assert redone > 100
+    torch.cuda.synchronize()
+    nonzero = 0
+    for ja, jb, jc in zip(a, b, c):
+        for key in ("choice", "band", "y"):
+            assert torch.equal(ja.cands[key], jb.cands[key]), (ja.bs, key)
+            assert torch.equal(ja.cands[key], jc.cands[key]), (ja.bs, key, "resolved")
+        nonzero += int((ja.cands["choice"].view(-1, 4)[:, 1] != 0).sum())
+    assert nonzero > 1000
+    # pricing really changes decisions: the distortion-only choice differs somewhere
+    d = jobs()
+    hip.pvq_noref_bands_multi(d, lam)
+    hip.pvq_choose_multi(d, lam)
+    assert any(not torch.equal(ja.cands["choice"], jd.cands["choice"]) for ja, jd in zip(a, d))
+
+
 def test_pair_search_sequential_combine_equals_exact_combine(hip, monkeypatch):
     """The 128-coefficient band is searched by two lanes per band; the halves of
     the greedy argmax are combined by an exact-arithmetic argument, with a

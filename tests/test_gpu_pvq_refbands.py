@@ -140,6 +140,67 @@ def test_uncertain_theta_is_settled_by_the_host(hip):
     assert mm.total() == 0, mm.summary()
 
 
+@pytest.mark.parametrize("is_keyframe,pli", MODES)
+def test_priced_choice_on_the_device_equals_host_priced_choice(hip, is_keyframe, pli):
+    """od_pvq_rate's closed form on the device - keyframe chroma, inter luma / chroma (theta
+    cost, the `qg == icgr` term, the skip rules of inter frames) and keyframe luma with a
+    reference - three ways: (a) the host prices every candidate with the oracle's od_pvq_rate
+    and the choice kernel takes its rate table (checked against the oracle's pvq_theta),
+    (b) the choice kernels price on the device, (c) the per-lane searches decide inside the
+    band stage.  All three leave identical choice records."""
+    import torch
+    lam = hip.OD_PVQ_LAMBDA
+    rng = np.random.RandomState(91 + 2 * is_keyframe + pli)
+    top = 3 if pli else 4
+    sets = []
+    planes = [make_planes(rng, 2, 64, 128, bs) for bs in range(top + 1)]
+    for _ in range(3):
+        jobs = []
+        for bs in range(top + 1):
+            qt = hip.QuantTables.load()
+            dec = 1 if pli else 0
+            qm, qmi = qt.qm_slices(dec, bs)
+            x, r = planes[bs]
+            jobs.append((hip.PvqRefJob(_cuda(x), _cuda(r), bs, _cuda(qm), _cuda(qmi), qt.q_band(pli, bs),
+                                       qt.beta_band(pli, bs), is_keyframe, pli), x, r, qm, qmi,
+                         qt.q_band(pli, bs), qt.beta_band(pli, bs)))
+        sets.append(jobs)
+    # (a) host-priced, validated against the oracle
+    ja = [j[0] for j in sets[0]]
+    hip.pvq_ref_bands_multi(ja, lam)
+    torch.cuda.synchronize()
+    mm = Mismatch()
+    for (job, x, r, qm, qmi, qb, bb) in sets[0]:
+        traces, _ = oracle_traces(x, r, job.bs, qm, qmi, qb, bb, is_keyframe, pli, lam)
+        job.rate = _cuda(host_rates(job, traces, is_keyframe, pli))
+    hip.pvq_ref_select_synth_multi(ja, lam)
+    torch.cuda.synchronize()
+    for (job, x, r, qm, qmi, qb, bb) in sets[0]:
+        traces, _ = oracle_traces(x, r, job.bs, qm, qmi, qb, bb, is_keyframe, pli, lam)
+        compare_choice(job, traces, mm)
+    assert mm.total() == 0, mm.summary()
+    # (b) choice kernels price on the device, (c) decided inside the band stage
+    jb = [j[0] for j in sets[1]]
+    jc = [j[0] for j in sets[2]]
+    hip.pvq_ref_bands_multi(jb, lam)
+    assert hip.pvq_ref_choose_priced_multi(jb, lam) == 0
+    assert hip.pvq_ref_choose_priced_multi(jc, lam, fused_bands=True) == 0
+    torch.cuda.synchronize()
+    for a, b, c in zip(ja, jb, jc):
+        assert torch.equal(a.choice, b.choice), (is_keyframe, pli, a.bs, "device-priced")
+        assert torch.equal(a.choice, c.choice), (is_keyframe, pli, a.bs, "decided in the search")
+    # with the margin forced wide the host libm re-decides bands, to the same records
+    hip.set_price_tol_scale(1e12)
+    try:
+        jd = [j[0] for j in sets[1]]
+        assert hip.pvq_ref_choose_priced_multi(jd, lam, fused_bands=True) > 50
+    finally:
+        hip.set_price_tol_scale(1.)
+    torch.cuda.synchronize()
+    for a, d in zip(ja, jd):
+        assert torch.equal(a.choice, d.choice), (is_keyframe, pli, a.bs, "host-libm resolve")
+
+
 def test_ref_jobs_argument_validation(hip):
     import ctypes
     L = hip.lib()
