@@ -466,6 +466,8 @@ def main():
     ap.add_argument("--no-cpu-allcores", action="store_true")
     ap.add_argument("--no-replay", action="store_true",
                     help="skip the serial replay after the timed region (profiling runs: no extra launches)")
+    ap.add_argument("--no-streaming", action="store_true",
+                    help="skip the auxiliary run that feeds every step's pictures from pinned host memory")
     ap.add_argument("--no-price", action="store_true",
                     help="choose on distortion alone inside the step (no od_pvq_rate)")
     ap.add_argument("--no-shard-check", action="store_true",
@@ -547,6 +549,40 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    # what the timed steps left in the reconstruction buffers (for `verified`), before
+    # anything else runs on the pipe
+    timed_recon = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and price:
+        F = args.frames
+        timed_recon = [[pipe.read(D.BUF_RECON, 0, bs).reshape(F, H, W) for bs in range(5)],
+                       [pipe.read(D.BUF_RECON, 1, bs).reshape(2 * F, H // 2, W // 2) for bs in range(4)]]
+    # A stream of pictures instead of resident ones (auxiliary, never `value`): every step
+    # codes pictures that arrive from pinned host memory through odhip_pipe_feed, on the
+    # pipe's copy stream, while the previous step computes.
+    streaming = None
+    if rank == 0 and not args.no_streaming:
+        hl = torch.from_numpy(luma_pic).pin_memory()
+        hc = torch.from_numpy(chroma_pic).pin_memory()
+        for _ in range(2):
+            pipe.feed(hl, hc)
+            pipe.step()
+        pipe.flush()
+        pipe.sync()
+        s0 = time.perf_counter()
+        for _ in range(args.steps):
+            pipe.feed(hl, hc)
+            pipe.step()
+        pipe.flush()
+        pipe.sync()
+        sdt = time.perf_counter() - s0
+        h2d = hl.numel() + hc.numel()
+        streaming = {"value": args.frames * args.steps * blocks_per_frame() / sdt, "unit": "blocks/s",
+                     "ms_per_step": sdt / args.steps * 1e3, "h2d_bytes_per_step": int(h2d),
+                     "h2d_GBs": h2d * args.steps / sdt / 1e9,
+                     "note": "the same steps with the pictures of every step copied from pinned host memory "
+                             "(odhip_pipe_feed: own copy stream, double-buffered, overlapped with the previous "
+                             "step) - the input side of the PCIe-inclusive rate; this rank only; the outputs "
+                             "stay on the device (DESIGN.md section 5b for what exporting candidates costs)"}
     shard_check = None
     if dist is not None and not args.no_shard_check:
         shard_check = sharded_encode_check(rank, world, local_rank, dist, torch)
@@ -690,18 +726,13 @@ def main():
             "pipelined_equals_serial": None if digest is None else digest == serial_digest,
             "theta_margin_reruns": pipe.theta_reruns(),
             "price_margin_reruns": pipe.price_reruns() if price else None,
+            "streaming_input": streaming,
             "kernels": kernels,
         }
         if shard_check is not None:
             line["sharded_encode_check"] = shard_check
         if world == 1 and not args.no_cpu_baseline:
             frame0 = [luma_pic[0], chroma_pic[0], chroma_pic[args.frames]]
-            timed_recon = None
-            if price:
-                F = args.frames
-                timed_recon = [[pipe.read(D.BUF_RECON, 0, bs).reshape(F, H, W) for bs in range(5)],
-                               [pipe.read(D.BUF_RECON, 1, bs).reshape(2 * F, H // 2, W // 2)
-                                for bs in range(4)]]
             base, host, ver = cpu_baseline(D, qt, cfl, args, frame0, timed_recon)
             if base is not None:
                 line["cpu_baseline"] = base

@@ -919,6 +919,22 @@ class Pipe:
         _check(lib().odhip_pipe_set_pictures(self._p(), ctypes.c_void_p(pl), ctypes.c_void_p(pc),
                                              int(dev)), "odhip_pipe_set_pictures")
 
+    def feed(self, luma, chroma):
+        """The pictures of the NEXT step from host memory, copied while the enqueued steps
+        compute (odhip_pipe_feed).  luma / chroma: pinned CPU torch tensors (asynchronous) or
+        numpy arrays, same shapes as set_pictures; the caller keeps them alive and untouched
+        until sync()."""
+        dt = np.int16 if self.fpr_bits > 8 else np.uint8
+        if hasattr(luma, "data_ptr"):
+            assert not luma.is_cuda and luma.is_contiguous() and chroma.is_contiguous()
+            pl, pc = luma.data_ptr(), chroma.data_ptr()
+        else:
+            assert luma.dtype == dt and chroma.dtype == dt and luma.flags["C_CONTIGUOUS"]
+            pl, pc = luma.ctypes.data, chroma.ctypes.data
+        assert tuple(luma.shape) == (self.frames, self.pic_h, self.pic_w)
+        assert tuple(chroma.shape) == (2 * self.frames, self.pic_h // 2, self.pic_w // 2)
+        _check(lib().odhip_pipe_feed(self._p(), ctypes.c_void_p(pl), ctypes.c_void_p(pc)), "odhip_pipe_feed")
+
     def step(self):
         _check(lib().odhip_pipe_step(self._p()), "odhip_pipe_step")
 

@@ -43,7 +43,8 @@ struct PlaneSet {
   int w, h;          /* coded plane size */
   int pw, ph;        /* picture size in this plane */
   int nlev;
-  uint8_t *pic;
+  uint8_t *pic;      /* the pictures the next step reads: pic_buf[front] */
+  uint8_t *pic_buf[2];
   uint8_t *px;
   od_coeff *levels[ODHIP_NBSIZES];
   uint8_t *recon[ODHIP_NBSIZES];
@@ -76,6 +77,13 @@ struct odhip_pipe {
   long price_reruns;              /* priced choices re-decided with the host libm so far */
   double wait_ms;                 /* host time spent waiting for the margin count */
   bool record;
+  /* odhip_pipe_feed: the pictures of the NEXT step arrive in the back buffers on their
+     own stream while the current step computes */
+  hipStream_t copy_stream;
+  hipEvent_t ev_fed;              /* the back buffers hold the fed pictures */
+  hipEvent_t ev_pad[2];           /* the padding kernel of a chain has read its pictures */
+  int front;
+  bool fed;
   std::vector<hipEvent_t> timed[kStages];    /* pairs */
   std::vector<void *> owned;
 };
@@ -139,7 +147,9 @@ int setup_set(odhip_pipe *p, PlaneSet &s, int dec, int pli, int nplanes) {
      samples; the resident source pictures keep their own depth */
   const size_t px_bytes = p->cfg.fpr_bits ? 2 : 1;
   const size_t pic_bytes = p->cfg.fpr_bits > 8 ? 2 : 1;
-  PIPE_ALLOC(p, s.pic, (size_t)nplanes*s.pw*s.ph*pic_bytes, true);
+  PIPE_ALLOC(p, s.pic_buf[0], (size_t)nplanes*s.pw*s.ph*pic_bytes, true);
+  PIPE_ALLOC(p, s.pic_buf[1], (size_t)nplanes*s.pw*s.ph*pic_bytes, true);
+  s.pic = s.pic_buf[0];
   PIPE_ALLOC(p, s.px, (size_t)nplanes*s.w*s.h*px_bytes, true);
   for (int bs = 0; bs < s.nlev; bs++) {
     const int n = 4 << bs;
@@ -266,6 +276,10 @@ int pipe_init(odhip_pipe *p) {
     }
   }
   p->pending = -1;
+  ODHIP_TRY(hipStreamCreateWithFlags(&p->copy_stream, hipStreamNonBlocking));
+  ODHIP_TRY(hipEventCreateWithFlags(&p->ev_fed, hipEventDisableTiming));
+  ODHIP_TRY(hipEventCreateWithFlags(&p->ev_pad[0], hipEventDisableTiming));
+  ODHIP_TRY(hipEventCreateWithFlags(&p->ev_pad[1], hipEventDisableTiming));
   ODHIP_TRY(hipDeviceSynchronize());
   return ODHIP_SUCCESS;
 }
@@ -281,7 +295,18 @@ struct Current {
   }
 };
 
+int stage_pad_run(odhip_pipe *p, int si, hipStream_t s);
+
+/* Padding is the only reader of the resident pictures: its completion frees them for the
+   next feed. */
 int stage_pad(odhip_pipe *p, int si, hipStream_t s) {
+  const int rc = stage_pad_run(p, si, s);
+  if (rc) return rc;
+  ODHIP_TRY(hipEventRecord(p->ev_pad[si], s));
+  return ODHIP_SUCCESS;
+}
+
+int stage_pad_run(odhip_pipe *p, int si, hipStream_t s) {
   PlaneSet &t = p->set[si];
   Timed tm(p, si ? ODHIP_PIPE_PAD_CHROMA : ODHIP_PIPE_PAD_LUMA, s);
   if (p->cfg.fpr_bits) {
@@ -468,6 +493,11 @@ extern "C" odhip_pipe *odhip_pipe_create(const odhip_pipe_config *cfg) {
   memset(p->refs, 0, sizeof(p->refs));
   memset(p->ev_refs, 0, sizeof(p->ev_refs));
   memset(p->ev_used, 0, sizeof(p->ev_used));
+  p->copy_stream = nullptr;
+  p->ev_fed = nullptr;
+  p->ev_pad[0] = p->ev_pad[1] = nullptr;
+  p->front = 0;
+  p->fed = false;
   if (pipe_init(p) != ODHIP_SUCCESS) {
     odhip_pipe_destroy(p);
     return nullptr;
@@ -485,7 +515,10 @@ extern "C" void odhip_pipe_destroy(odhip_pipe *p) {
     if (p->ctx[i]) odhip_destroy(p->ctx[i]);
     if (p->ev_refs[i]) (void)hipEventDestroy(p->ev_refs[i]);
     if (p->ev_used[i]) (void)hipEventDestroy(p->ev_used[i]);
+    if (p->ev_pad[i]) (void)hipEventDestroy(p->ev_pad[i]);
   }
+  if (p->ev_fed) (void)hipEventDestroy(p->ev_fed);
+  if (p->copy_stream) (void)hipStreamDestroy(p->copy_stream);
   if (p->stream[1] && p->stream[1] != p->stream[0]) (void)hipStreamDestroy(p->stream[1]);
   if (p->stream[0]) (void)hipStreamDestroy(p->stream[0]);
   for (int i = 0; i < kStages; i++) {
@@ -508,12 +541,48 @@ extern "C" int odhip_pipe_set_pictures(odhip_pipe *p, const uint8_t *luma, const
   ODHIP_TRY(hipMemcpyAsync(l.pic, luma, (size_t)l.nplanes*l.pw*l.ph*pic_bytes, kind, p->stream[0]));
   ODHIP_TRY(hipMemcpyAsync(c.pic, chroma, (size_t)c.nplanes*c.pw*c.ph*pic_bytes, kind, p->stream[0]));
   ODHIP_TRY(hipStreamSynchronize(p->stream[0]));
+  /* a feed that no step has taken yet is dropped: these are the pictures of the next step */
+  ODHIP_TRY(hipStreamSynchronize(p->copy_stream));
+  p->fed = false;
+  return ODHIP_SUCCESS;
+}
+
+/* The pictures of the NEXT step, from host memory, while the steps already enqueued
+   compute: copied on the pipe's own copy stream into the back buffers (after the padding
+   kernels that may still read them), taken by the next odhip_pipe_step.  Pinned host
+   memory (hipHostMalloc / hipHostRegister) makes the copy asynchronous; the buffers must
+   stay valid until that step has been enqueued AND the copy has completed
+   (odhip_pipe_sync waits for it too). */
+extern "C" int odhip_pipe_feed(odhip_pipe *p, const uint8_t *luma, const uint8_t *chroma) {
+  if (!p || !luma || !chroma) return ODHIP_EINVAL;
+  ODHIP_TRY(hipSetDevice(p->cfg.device));
+  const int back = p->front ^ 1;
+  const PlaneSet &l = p->set[0];
+  const PlaneSet &c = p->set[1];
+  const size_t pic_bytes = p->cfg.fpr_bits > 8 ? 2 : 1;
+  ODHIP_TRY(hipStreamWaitEvent(p->copy_stream, p->ev_pad[0], 0));
+  ODHIP_TRY(hipStreamWaitEvent(p->copy_stream, p->ev_pad[1], 0));
+  ODHIP_TRY(hipMemcpyAsync(l.pic_buf[back], luma, (size_t)l.nplanes*l.pw*l.ph*pic_bytes, hipMemcpyHostToDevice,
+   p->copy_stream));
+  ODHIP_TRY(hipMemcpyAsync(c.pic_buf[back], chroma, (size_t)c.nplanes*c.pw*c.ph*pic_bytes, hipMemcpyHostToDevice,
+   p->copy_stream));
+  ODHIP_TRY(hipEventRecord(p->ev_fed, p->copy_stream));
+  p->fed = true;
   return ODHIP_SUCCESS;
 }
 
 extern "C" int odhip_pipe_step(odhip_pipe *p) {
   if (!p) return ODHIP_EINVAL;
   ODHIP_TRY(hipSetDevice(p->cfg.device));
+  if (p->fed) {
+    /* odhip_pipe_feed: this step codes the fed pictures */
+    p->front ^= 1;
+    p->set[0].pic = p->set[0].pic_buf[p->front];
+    p->set[1].pic = p->set[1].pic_buf[p->front];
+    ODHIP_TRY(hipStreamWaitEvent(p->stream[0], p->ev_fed, 0));
+    if (p->stream[1] != p->stream[0]) ODHIP_TRY(hipStreamWaitEvent(p->stream[1], p->ev_fed, 0));
+    p->fed = false;
+  }
   const int rc = p->cfg.chroma_cfl ? step_cfl(p) : step_noref(p);
   p->nstep++;
   return rc;
@@ -528,6 +597,7 @@ extern "C" int odhip_pipe_sync(odhip_pipe *p) {
   if (!p) return ODHIP_EINVAL;
   ODHIP_TRY(hipStreamSynchronize(p->stream[0]));
   if (p->stream[1] != p->stream[0]) ODHIP_TRY(hipStreamSynchronize(p->stream[1]));
+  ODHIP_TRY(hipStreamSynchronize(p->copy_stream));
   return ODHIP_SUCCESS;
 }
 

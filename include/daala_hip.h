@@ -989,6 +989,14 @@ enum {
 odhip_pipe *odhip_pipe_create(const odhip_pipe_config *cfg);
 void odhip_pipe_destroy(odhip_pipe *p);
 int odhip_pipe_set_pictures(odhip_pipe *p, const uint8_t *luma, const uint8_t *chroma, int on_device);
+/* A stream of pictures instead of resident ones: odhip_pipe_feed copies the pictures of
+   the NEXT step from host memory (same layouts as odhip_pipe_set_pictures) into the pipe's
+   back buffers on its own copy stream - behind the padding kernels that may still read
+   them, beside the steps already enqueued - and the next odhip_pipe_step codes them.
+   Asynchronous for pinned host memory; the host buffers must stay untouched until
+   odhip_pipe_sync (or any later odhip_pipe_feed of the same pipe followed by a sync).
+     for (;;) { odhip_pipe_feed(p, next_luma, next_chroma); odhip_pipe_step(p); ... } */
+int odhip_pipe_feed(odhip_pipe *p, const uint8_t *luma, const uint8_t *chroma);
 int odhip_pipe_step(odhip_pipe *p);
 int odhip_pipe_flush(odhip_pipe *p);
 int odhip_pipe_sync(odhip_pipe *p);

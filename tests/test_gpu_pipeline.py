@@ -197,6 +197,70 @@ def test_whole_frame_noref_chroma_and_ragged_size():
         assert C.compare_frame(gpu, cpu) == [], cfl
 
 
+def test_fed_pictures_equal_resident_pictures():
+    """odhip_pipe_feed: a different set of pictures for every step, copied from pinned host
+    memory into the back buffers while the previous steps compute.  After each of six steps
+    the pipe must hold exactly what a pipe with those pictures resident (set_pictures) holds -
+    reconstructions, choice records, band records (pulse-vector slots of pruned candidates keep
+    whatever an earlier step left there, so those buffers depend on the history) - i.e. no copy
+    ever lands in a buffer a padding kernel is still reading and no step starts before its
+    pictures arrived."""
+    import torch
+    import daala_amd as D
+    D.init(0)
+    b = _bench()
+    qt = D.QuantTables.load()
+    F = 2
+    pw, ph = 640, 360
+    gens = (b.synth_frame_np, b.natural_like_frame_np)
+
+    def pictures(k):
+        fr = [b.picture_planes(gens[(k + i) % 2](10 * k + i, 7 + k)) for i in range(F)]
+        luma = np.stack([f[0][:ph, :pw] for f in fr])
+        chroma = np.concatenate([np.stack([f[1][:ph // 2, :pw // 2] for f in fr]),
+                                 np.stack([f[2][:ph // 2, :pw // 2] for f in fr])])
+        return np.ascontiguousarray(luma), np.ascontiguousarray(chroma)
+
+    sets = [pictures(k) for k in range(6)]
+    pinned = [(torch.from_numpy(l).pin_memory(), torch.from_numpy(c).pin_memory()) for l, c in sets]
+    fed = D.Pipe(qt, F, pw, ph, chroma_cfl=True, price=True)
+    resident = D.Pipe(qt, F, pw, ph, chroma_cfl=True, price=True, serial=True)
+    try:
+        # all six steps in flight, then the last state; and step by step
+        for l, c in pinned:
+            fed.feed(l, c)
+            fed.step()
+        fed.flush()
+        fed.sync()
+        resident.set_pictures(*sets[5])
+        resident.step()
+        resident.flush()
+        resident.sync()
+        want = _dump(D, resident, True)
+        got = _dump(D, fed, True)
+        for key in want:
+            if key[0] in ("recon", "choice", "band"):
+                assert np.array_equal(got[key], want[key]), ("in flight", key)
+        assert np.array_equal(fed.read(D.BUF_PIC, 0), sets[5][0].ravel())
+        for k in (1, 4, 2):
+            fed.feed(*pinned[k])
+            fed.step()
+            fed.flush()
+            fed.sync()
+            resident.set_pictures(*sets[k])
+            resident.step()
+            resident.flush()
+            resident.sync()
+            want = _dump(D, resident, True)
+            got = _dump(D, fed, True)
+            for key in want:
+                if key[0] in ("recon", "choice", "band"):
+                    assert np.array_equal(got[key], want[key]), (k, key)
+    finally:
+        fed.destroy()
+        resident.destroy()
+
+
 def test_two_contexts_keep_their_own_scratch():
     """Two inverse calls in flight on two streams with one context each reproduce the
     serial results (the API-level form of (i))."""
