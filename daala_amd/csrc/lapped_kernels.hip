@@ -717,6 +717,7 @@ struct InverseArgs {
   const int16_t *r16;
   const od_coeff *ref;
   int px16;                 /* full-precision references: px holds int16 samples, see PyramidArgs */
+  int inter;                /* with-reference source of an inter frame (is_keyframe == 0) */
 };
 
 /* Several partition levels of one plane set in ONE launch (blockIdx.z = level *
@@ -784,8 +785,20 @@ __device__ __forceinline__ void inverse_load_ref(int *t, const InverseArgs &a, i
   const int nbsb = nbw*nbw;
   const int bw = a.w >> sh;
   const int bh = a.h >> sh;
-  if ((a.len >> sh) < (1 << sh)) {            /* 32x32 / 64x64: uncoded positions are zero */
-    for (int i = tid; i < TILE*P/4; i += NT) reinterpret_cast<int4 *>(t)[i] = make_int4(0, 0, 0, 0);
+  if ((a.len >> sh) < (1 << sh)) {
+    /* 32x32 / 64x64: the positions PVQ never codes are what od_init_skipped_coeffs leaves
+       (src/state.c:1347-1366): zero on a keyframe, the prediction's coefficients otherwise */
+    if (a.inter) {
+      for (int i = tid; i < TILE*TILE/4; i += NT) {
+        const int y = i/(TILE/4);
+        const int x = (i % (TILE/4))*4;
+        *reinterpret_cast<int4 *>(t + y*P + x) =
+         *reinterpret_cast<const int4 *>(a.ref + plane_off + (long)(y0 + y)*a.w + x0 + x);
+      }
+    }
+    else {
+      for (int i = tid; i < TILE*P/4; i += NT) reinterpret_cast<int4 *>(t)[i] = make_int4(0, 0, 0, 0);
+    }
     __syncthreads();
   }
   const int cpb = a.len >> 3;
@@ -1647,6 +1660,7 @@ extern "C" int odhip_inverse_levels_pvq_ref(uint8_t *const *d_px, int px_stride,
     ia[i].nb_bands = OD_NBANDS[bs];
     ia[i].r16 = j.r16;
     ia[i].ref = j.d_ref;
+    ia[i].inter = j.is_keyframe == 0;
   }
   const int rc = upload_inv_tables();
   if (rc) return rc;

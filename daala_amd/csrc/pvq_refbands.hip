@@ -2232,10 +2232,13 @@ int ref_select(const odhip_pvq_refjob *jobs, int njobs, double pvq_norm_lambda, 
   int rc = stage_jobs(st, jobs, njobs, synth ? 1 : 2, host, s);
   if (rc) return rc;
   for (int j = 0; synth && j < njobs; j++) {
-    /* 32x32 and 64x64 blocks code their lowest 512 coefficients only */
+    /* 32x32 and 64x64 blocks code their lowest 512 coefficients only; the rest is what
+       od_init_skipped_coeffs leaves (src/state.c:1347-1366): zero on a keyframe, the
+       prediction's coefficients on an inter frame */
     if (host[j].bs >= 3) {
-      ODHIP_TRY(hipMemsetAsync(host[j].dq, 0, sizeof(od_coeff)*(size_t)host[j].nplanes*host[j].w
-       *host[j].h, s));
+      const size_t bytes = sizeof(od_coeff)*(size_t)host[j].nplanes*host[j].w*host[j].h;
+      if (host[j].is_keyframe) ODHIP_TRY(hipMemsetAsync(host[j].dq, 0, bytes, s));
+      else ODHIP_TRY(hipMemcpyAsync(host[j].dq, host[j].ref, bytes, hipMemcpyDeviceToDevice, s));
     }
   }
   /* rest_only: the per-lane bands were decided (and their close calls listed) inside

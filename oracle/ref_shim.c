@@ -447,6 +447,15 @@ REF_EXPORT double ref_now(void) {
    tables for this plane's decimation, one slice per bs at qm_off[bs].
    Returns the number of transform blocks processed. */
 static unsigned char *const *g_recon_levels;   /* ref_stage_plane_levels: one recon per level */
+/* ref_stage_set_inter(1): the stage functions below run pvq_theta as an INTER frame does
+   (is_keyframe = 0, src/encode.c:1326-1360): ref_levels then holds the transformed
+   motion-compensated prediction of every block at every level (mctmp / mdtmp in the
+   encoder, od_encode_compute_pred :880-886), used as it is - no chroma-from-luma flip. */
+static int ref_stage_inter;
+REF_EXPORT void ref_stage_set_inter(int on) {
+  ref_stage_inter = on != 0;
+}
+
 static long stage_plane_core(unsigned char *px, int px_stride, int w, int h,
  int dec, int pic_w, int pic_h, int pli, const int16_t *qm, const int16_t *qm_inv,
  const int *qm_off, const int *q_band, const int *beta_band,
@@ -487,7 +496,10 @@ static long stage_plane_core(unsigned char *px, int px_stride, int w, int h,
         int bo;
         bo = by*n*w + bx*n;
         od_raster_to_coding_order(in, n, levels[bs] + bo, w);
-        if (ref_levels != NULL) {
+        if (ref_levels != NULL && ref_stage_inter) {
+          od_raster_to_coding_order(ref0, n, ref_levels[bs] + bo, w);
+        }
+        else if (ref_levels != NULL) {
           /* keyframe chroma: the chroma-from-luma prediction and its sign, as
              od_pvq_encode applies it before the band loop
              (src/pvq_encoder.c:846-872; that block is not callable on its own,
@@ -515,7 +527,7 @@ static long stage_plane_core(unsigned char *px, int px_stride, int w, int h,
           int k;
           pvq_theta(out + off[i], in + off[i], ref0 + off[i], off[i + 1] - off[i],
            q_band[bs*12 + i], y + off[i], &itheta, &max_theta, &k,
-           (od_val16)beta_band[bs*12 + i], &skip_diff, 1, 1, pli, adapt,
+           (od_val16)beta_band[bs*12 + i], &skip_diff, 1, !ref_stage_inter, pli, adapt,
            qm + qm_off[bs] + off[i], qm_inv + qm_off[bs] + off[i],
            pvq_norm_lambda, 1);
         }
