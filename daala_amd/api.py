@@ -867,7 +867,8 @@ PIPE_STAGES = ("image_copy_pad_luma", "forward_pyramid_luma", "pvq_noref_bands",
 class _PipeConfig(ctypes.Structure):
     _fields_ = [("device", ctypes.c_int), ("frames", ctypes.c_int), ("pic_w", ctypes.c_int),
                 ("pic_h", ctypes.c_int), ("chroma_cfl", ctypes.c_int), ("serial", ctypes.c_int),
-                ("price", ctypes.c_int), ("fpr_bits", ctypes.c_int),
+                ("price", ctypes.c_int), ("fpr_bits", ctypes.c_int), ("inter", ctypes.c_int),
+                ("reserved", ctypes.c_int),
                 ("pvq_norm_lambda", ctypes.c_double), ("quant", ctypes.c_void_p)]
 
 
@@ -876,7 +877,7 @@ class Pipe:
     one C call per step.  Buffers are read / written as numpy arrays."""
 
     def __init__(self, quant, frames, pic_w, pic_h, chroma_cfl=True, serial=False, device=0,
-                 pvq_norm_lambda=0.147, price=False, fpr_bits=0):
+                 pvq_norm_lambda=0.147, price=False, fpr_bits=0, inter=False):
         """price=True: the choices price every candidate with od_pvq_rate's closed form on
         the device (odhip_pvq_*choose_priced_*), nothing for the host to do in a step.
         fpr_bits = 8 / 10 / 12: full-precision references, pictures of that bit depth (uint8 /
@@ -886,7 +887,8 @@ class Pipe:
         L.odhip_pipe_theta_reruns.restype = ctypes.c_long
         L.odhip_pipe_price_reruns.restype = ctypes.c_long
         cfg = _PipeConfig(int(device), int(frames), int(pic_w), int(pic_h), int(bool(chroma_cfl)),
-                          int(bool(serial)), int(bool(price)), int(fpr_bits), float(pvq_norm_lambda),
+                          int(bool(serial)), int(bool(price)), int(fpr_bits), int(bool(inter)), 0,
+                          float(pvq_norm_lambda),
                           ctypes.cast(ctypes.byref(quant.c), ctypes.c_void_p))
         self.h = L.odhip_pipe_create(ctypes.byref(cfg))
         if not self.h:
@@ -895,6 +897,7 @@ class Pipe:
         self.W, self.H = (pic_w + 63) & ~63, (pic_h + 63) & ~63
         self.chroma_cfl = bool(chroma_cfl)
         self.fpr_bits = int(fpr_bits)
+        self.inter = bool(inter)
 
     def _p(self):
         return ctypes.c_void_p(self.h)
@@ -918,6 +921,18 @@ class Pipe:
         assert tuple(chroma.shape) == (2 * self.frames, self.pic_h // 2, self.pic_w // 2)
         _check(lib().odhip_pipe_set_pictures(self._p(), ctypes.c_void_p(pl), ctypes.c_void_p(pc),
                                              int(dev)), "odhip_pipe_set_pictures")
+
+    def set_reference_pictures(self, luma, chroma):
+        """Inter mode: the prediction pictures of the batch (numpy, same shapes and depth as
+        set_pictures)."""
+        dt = np.int16 if self.fpr_bits > 8 else np.uint8
+        luma = np.ascontiguousarray(luma, dt)
+        chroma = np.ascontiguousarray(chroma, dt)
+        assert tuple(luma.shape) == (self.frames, self.pic_h, self.pic_w)
+        assert tuple(chroma.shape) == (2 * self.frames, self.pic_h // 2, self.pic_w // 2)
+        _check(lib().odhip_pipe_set_reference_pictures(self._p(), ctypes.c_void_p(luma.ctypes.data),
+                                                       ctypes.c_void_p(chroma.ctypes.data), 0),
+               "odhip_pipe_set_reference_pictures")
 
     def feed(self, luma, chroma):
         """The pictures of the NEXT step from host memory, copied while the enqueued steps

@@ -46,6 +46,11 @@ struct PlaneSet {
   uint8_t *pic;      /* the pictures the next step reads: pic_buf[front] */
   uint8_t *pic_buf[2];
   uint8_t *px;
+  /* inter mode: the motion-compensated prediction of every picture, its padded plane and
+     its pyramid (the reference of every block at every level, mdtmp in the encoder) */
+  uint8_t *pred_pic;
+  uint8_t *pred_px;
+  od_coeff *pred_levels[ODHIP_NBSIZES];
   od_coeff *levels[ODHIP_NBSIZES];
   uint8_t *recon[ODHIP_NBSIZES];
   int16_t *qm[ODHIP_NBSIZES];
@@ -68,6 +73,8 @@ struct odhip_pipe {
   int njobs;
   od_coeff *refs[2][ODHIP_NBSIZES];          /* [parity][chroma level] */
   odhip_pvq_refjob refjobs[2][ODHIP_NBSIZES];
+  odhip_pvq_refjob interjobs[2][ODHIP_NBSIZES];   /* inter mode: [plane set][level] */
+  bool inter_pending[2];
   double *rate[2][ODHIP_NBSIZES];
   hipEvent_t ev_refs[2];
   hipEvent_t ev_used[2];
@@ -151,10 +158,17 @@ int setup_set(odhip_pipe *p, PlaneSet &s, int dec, int pli, int nplanes) {
   PIPE_ALLOC(p, s.pic_buf[1], (size_t)nplanes*s.pw*s.ph*pic_bytes, true);
   s.pic = s.pic_buf[0];
   PIPE_ALLOC(p, s.px, (size_t)nplanes*s.w*s.h*px_bytes, true);
+  s.pred_pic = s.pred_px = nullptr;
+  if (p->cfg.inter) {
+    PIPE_ALLOC(p, s.pred_pic, (size_t)nplanes*s.pw*s.ph*pic_bytes, true);
+    PIPE_ALLOC(p, s.pred_px, (size_t)nplanes*s.w*s.h*px_bytes, true);
+  }
   for (int bs = 0; bs < s.nlev; bs++) {
     const int n = 4 << bs;
     const int len = n*n < OD_SCAN_LEN ? n*n : OD_SCAN_LEN;
     PIPE_ALLOC(p, s.levels[bs], sizeof(od_coeff)*(size_t)nplanes*s.w*s.h, true);
+    s.pred_levels[bs] = nullptr;
+    if (p->cfg.inter) PIPE_ALLOC(p, s.pred_levels[bs], sizeof(od_coeff)*(size_t)nplanes*s.w*s.h, true);
     PIPE_ALLOC(p, s.recon[bs], (size_t)nplanes*s.w*s.h*px_bytes, true);
     PIPE_ALLOC(p, s.qm[bs], sizeof(int16_t)*len, false);
     PIPE_ALLOC(p, s.qm_inv[bs], sizeof(int16_t)*len, false);
@@ -250,6 +264,25 @@ int pipe_init(odhip_pipe *p) {
   if (rc) return rc;
   rc = setup_set(p, p->set[1], 1, 1, 2*c.frames);
   if (rc) return rc;
+  p->inter_pending[0] = p->inter_pending[1] = false;
+  if (c.inter) {
+    /* every plane through the with-reference stage against its own prediction pyramid */
+    for (int si = 0; si < 2; si++) {
+      for (int bs = 0; bs < p->set[si].nlev; bs++) {
+        rc = setup_refjob(p, p->interjobs[si][bs], p->set[si], bs, p->set[si].pred_levels[bs], nullptr);
+        if (rc) return rc;
+        p->interjobs[si][bs].is_keyframe = 0;
+      }
+    }
+    p->njobs = 0;
+    p->pending = -1;
+    ODHIP_TRY(hipStreamCreateWithFlags(&p->copy_stream, hipStreamNonBlocking));
+    ODHIP_TRY(hipEventCreateWithFlags(&p->ev_fed, hipEventDisableTiming));
+    ODHIP_TRY(hipEventCreateWithFlags(&p->ev_pad[0], hipEventDisableTiming));
+    ODHIP_TRY(hipEventCreateWithFlags(&p->ev_pad[1], hipEventDisableTiming));
+    ODHIP_TRY(hipDeviceSynchronize());
+    return ODHIP_SUCCESS;
+  }
   for (int bs = 0; bs < 5; bs++) {
     rc = setup_job(p, p->jobs[bs], p->set[0], bs);
     if (rc) return rc;
@@ -434,6 +467,94 @@ int chroma_bands(odhip_pipe *p, int par, hipStream_t s) {
   return odhip_pvq_ref_resolve_begin(s);
 }
 
+/* ---- inter mode: both plane sets through the with-reference stage against the pyramid of
+   their prediction pictures (pvq_theta with is_keyframe = 0, src/encode.c:1326-1360); the two
+   chains are independent, each in its own context on its own stream. */
+int inter_tail(odhip_pipe *p, int si, hipStream_t s, bool rerun) {
+  PlaneSet &t = p->set[si];
+  const double lam = p->cfg.pvq_norm_lambda;
+  odhip_pvq_refjob *jobs = p->interjobs[si];
+  {
+    Timed tm(p, si ? ODHIP_PIPE_CHOOSE_CHROMA : ODHIP_PIPE_CHOOSE_LUMA, s);
+    STEP_TRY(!p->cfg.price ? odhip_pvq_ref_choose_multi(jobs, t.nlev, lam, s)
+     : rerun ? odhip_pvq_ref_choose_priced_multi(jobs, t.nlev, lam, s)
+     : odhip_pvq_ref_choose_priced_rest_multi(jobs, t.nlev, lam, s));
+  }
+  Timed tm(p, si ? ODHIP_PIPE_INVERSE_CHROMA : ODHIP_PIPE_INVERSE_LUMA, s);
+  return odhip_inverse_levels_pvq_ref(t.recon, t.w, (long)t.w*t.h, jobs, t.nlev, t.dec, p->pic_w, p->pic_h, s);
+}
+
+/* the counts of the previous step's chain si (theta margin, price margin), one step late */
+int inter_finish(odhip_pipe *p, int si) {
+  if (!p->inter_pending[si]) return ODHIP_SUCCESS;
+  p->inter_pending[si] = false;
+  PlaneSet &t = p->set[si];
+  hipStream_t s = p->stream[si];
+  const double lam = p->cfg.pvq_norm_lambda;
+  Current cur(p->ctx[si]);
+  const auto t0 = std::chrono::steady_clock::now();
+  const int n = odhip_pvq_ref_resolve_finish(p->interjobs[si], t.nlev, lam, s);
+  if (n < 0) return n;
+  if (n > 0) {
+    p->reruns += n;
+    STEP_TRY(inter_tail(p, si, s, true));
+  }
+  if (p->cfg.price) {
+    const int m = odhip_pvq_ref_choose_priced_resolve(p->interjobs[si], t.nlev, lam, s);
+    if (m < 0) return m;
+    if (m > 0) {
+      p->price_reruns += m;
+      STEP_TRY(odhip_inverse_levels_pvq_ref(t.recon, t.w, (long)t.w*t.h, p->interjobs[si], t.nlev, t.dec,
+       p->pic_w, p->pic_h, s));
+    }
+  }
+  p->wait_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  return ODHIP_SUCCESS;
+}
+
+int inter_chain(odhip_pipe *p, int si) {
+  PlaneSet &t = p->set[si];
+  hipStream_t s = p->stream[si];
+  const double lam = p->cfg.pvq_norm_lambda;
+  Current cur(p->ctx[si]);
+  STEP_TRY(stage_pad(p, si, s));
+  STEP_TRY(stage_pyramid(p, si, s));
+  {
+    /* the prediction pictures: same padding, same pyramid */
+    Timed tm(p, si ? ODHIP_PIPE_PAD_CHROMA : ODHIP_PIPE_PAD_LUMA, s);
+    if (p->cfg.fpr_bits) {
+      STEP_TRY(odhip_image_planes_copy_pad16(reinterpret_cast<uint16_t *>(t.pred_px), t.w, (long)t.w*t.h, t.w,
+       t.h, t.pred_pic, p->cfg.fpr_bits, t.pw, (long)t.pw*t.ph, t.pw, t.ph, t.nplanes, s));
+    }
+    else {
+      STEP_TRY(odhip_image_planes_copy_pad(t.pred_px, t.w, (long)t.w*t.h, t.w, t.h, t.pred_pic, t.pw,
+       (long)t.pw*t.ph, t.pw, t.ph, t.nplanes, s));
+    }
+  }
+  {
+    Timed tm(p, si ? ODHIP_PIPE_PYRAMID_CHROMA : ODHIP_PIPE_PYRAMID_LUMA, s);
+    STEP_TRY(odhip_forward_pyramid(t.pred_levels, t.pred_px, t.w, (long)t.w*t.h, t.nplanes, t.w, t.h, t.dec,
+     p->pic_w, p->pic_h, s));
+  }
+  {
+    Timed tm(p, si ? ODHIP_PIPE_BANDS_CHROMA : ODHIP_PIPE_BANDS_LUMA, s);
+    STEP_TRY(p->cfg.price ? odhip_pvq_ref_bands_priced_multi(p->interjobs[si], t.nlev, lam, s)
+     : odhip_pvq_ref_bands_multi(p->interjobs[si], t.nlev, lam, s));
+    STEP_TRY(odhip_pvq_ref_resolve_begin(s));
+  }
+  STEP_TRY(inter_tail(p, si, s, false));
+  p->inter_pending[si] = true;
+  return ODHIP_SUCCESS;
+}
+
+int step_inter(odhip_pipe *p) {
+  for (int si = 0; si < 2; si++) {
+    STEP_TRY(inter_finish(p, si));
+    STEP_TRY(inter_chain(p, si));
+  }
+  return ODHIP_SUCCESS;
+}
+
 int step_noref(odhip_pipe *p) {
   hipStream_t s = p->stream[0];
   Current cur(p->ctx[0]);
@@ -583,14 +704,35 @@ extern "C" int odhip_pipe_step(odhip_pipe *p) {
     if (p->stream[1] != p->stream[0]) ODHIP_TRY(hipStreamWaitEvent(p->stream[1], p->ev_fed, 0));
     p->fed = false;
   }
-  const int rc = p->cfg.chroma_cfl ? step_cfl(p) : step_noref(p);
+  const int rc = p->cfg.inter ? step_inter(p) : p->cfg.chroma_cfl ? step_cfl(p) : step_noref(p);
   p->nstep++;
   return rc;
 }
 
 extern "C" int odhip_pipe_flush(odhip_pipe *p) {
   if (!p) return ODHIP_EINVAL;
+  if (p->cfg.inter) {
+    STEP_TRY(inter_finish(p, 0));
+    return inter_finish(p, 1);
+  }
   return finish_pending(p);
+}
+
+/* Inter mode: the prediction pictures (what motion compensation produced for each picture
+   of the batch), same layouts and depth as odhip_pipe_set_pictures. */
+extern "C" int odhip_pipe_set_reference_pictures(odhip_pipe *p, const uint8_t *luma, const uint8_t *chroma,
+ int on_device) {
+  if (!p || !luma || !chroma || !p->cfg.inter) return ODHIP_EINVAL;
+  const int rc = odhip_pipe_sync(p);
+  if (rc) return rc;
+  const hipMemcpyKind kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+  const PlaneSet &l = p->set[0];
+  const PlaneSet &c = p->set[1];
+  const size_t pic_bytes = p->cfg.fpr_bits > 8 ? 2 : 1;
+  ODHIP_TRY(hipMemcpyAsync(l.pred_pic, luma, (size_t)l.nplanes*l.pw*l.ph*pic_bytes, kind, p->stream[0]));
+  ODHIP_TRY(hipMemcpyAsync(c.pred_pic, chroma, (size_t)c.nplanes*c.pw*c.ph*pic_bytes, kind, p->stream[0]));
+  ODHIP_TRY(hipStreamSynchronize(p->stream[0]));
+  return ODHIP_SUCCESS;
 }
 
 extern "C" int odhip_pipe_sync(odhip_pipe *p) {
@@ -606,6 +748,7 @@ extern "C" int odhip_pipe_sync(odhip_pipe *p) {
    stage and the choice).  parity selects the reference buffer. */
 extern "C" int odhip_pipe_stage(odhip_pipe *p, int stage, int parity) {
   if (!p || stage < 0 || stage >= kStages || (parity != 0 && parity != 1)) return ODHIP_EINVAL;
+  if (p->cfg.inter) return ODHIP_EINVAL;       /* inter mode runs whole steps only */
   ODHIP_TRY(hipSetDevice(p->cfg.device));
   hipStream_t s = p->stream[0];
   const bool cfl = p->cfg.chroma_cfl != 0;
@@ -673,9 +816,10 @@ extern "C" int odhip_pipe_buffer(odhip_pipe *p, int what, int set, int level, in
   int len = 0;
   if (level >= 0 && level < ODHIP_NBSIZES) odhip_pvq_band_layout(level, &nb, nullptr, &len);
   const long B = level >= 0 && level < ODHIP_NBSIZES ? t.nblocks[level] : 0;
-  const bool ref = set == 1 && p->cfg.chroma_cfl;
-  const odhip_pvq_job *j = set == 0 ? &p->jobs[level] : (!ref ? &p->jobs[5 + level] : nullptr);
-  const odhip_pvq_refjob *r = ref ? &p->refjobs[parity][level] : nullptr;
+  const bool inter = p->cfg.inter != 0;
+  const bool ref = inter || (set == 1 && p->cfg.chroma_cfl);
+  const odhip_pvq_job *j = ref ? nullptr : set == 0 ? &p->jobs[level] : &p->jobs[5 + level];
+  const odhip_pvq_refjob *r = inter ? &p->interjobs[set][level] : ref ? &p->refjobs[parity][level] : nullptr;
   void *ptr = nullptr;
   size_t n = 0;
   switch (what) {

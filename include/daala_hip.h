@@ -965,6 +965,12 @@ typedef struct {
                                    int16 samples at 12 bits (odhip_ctx_set_fpr on both
                                    contexts), the resident pictures are uint8_t (8) or int16
                                    (10, 12) samples of that depth */
+  int inter;                    /* 1: an INTER frame - every plane goes through the with-reference
+                                   stage (pvq_theta with is_keyframe = 0) against the pyramid of
+                                   its prediction picture (odhip_pipe_set_reference_pictures: what
+                                   motion compensation produced; the encoder's mctmp / mdtmp,
+                                   src/encode.c:880-886, :1326-1360); chroma_cfl is ignored */
+  int reserved;
   double pvq_norm_lambda;       /* OD_PVQ_LAMBDA, src/pvq.h:49 */
   const odhip_quant *quant;
 } odhip_pipe_config;
@@ -997,6 +1003,10 @@ int odhip_pipe_set_pictures(odhip_pipe *p, const uint8_t *luma, const uint8_t *c
    odhip_pipe_sync (or any later odhip_pipe_feed of the same pipe followed by a sync).
      for (;;) { odhip_pipe_feed(p, next_luma, next_chroma); odhip_pipe_step(p); ... } */
 int odhip_pipe_feed(odhip_pipe *p, const uint8_t *luma, const uint8_t *chroma);
+/* Inter mode (odhip_pipe_config.inter): the prediction pictures of the batch, same layouts
+   and depth as odhip_pipe_set_pictures. */
+int odhip_pipe_set_reference_pictures(odhip_pipe *p, const uint8_t *luma, const uint8_t *chroma,
+ int on_device);
 int odhip_pipe_step(odhip_pipe *p);
 int odhip_pipe_flush(odhip_pipe *p);
 int odhip_pipe_sync(odhip_pipe *p);

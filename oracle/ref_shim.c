@@ -532,7 +532,15 @@ static long stage_plane_core(unsigned char *px, int px_stride, int w, int h,
            pvq_norm_lambda, 1);
         }
         out[0] = in[0];
-        od_init_skipped_coeffs(dq, NULL, 1, bo, n, w);
+        /* src/encode.c:1388: what PVQ never codes is zero on a keyframe, the prediction's
+           own coefficients on an inter frame (src/state.c:1347-1366) */
+        if (ref_levels != NULL && ref_stage_inter) {
+          od_coeff predblk[OD_BSIZE_MAX*OD_BSIZE_MAX];
+          int r;
+          for (r = 0; r < n; r++) memcpy(predblk + r*n, ref_levels[bs] + bo + r*w, sizeof(od_coeff)*n);
+          od_init_skipped_coeffs(dq, predblk, 0, bo, n, w);
+        }
+        else od_init_skipped_coeffs(dq, NULL, 1, bo, n, w);
         od_coding_order_to_raster(dq + bo, w, out, n);
         nblocks++;
       }

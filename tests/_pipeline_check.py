@@ -38,23 +38,34 @@ def _tables(qt, p):
     return qm_off, qb, bb
 
 
-def cpu_frame(qt, pics, pic_w, pic_h, chroma_cfl=True, lam=0.147, lib=None, fpr_bits=0):
+def cpu_frame(qt, pics, pic_w, pic_h, chroma_cfl=True, lam=0.147, lib=None, fpr_bits=0, inter_pred=None):
     """pics: [Y, Cb, Cr] uint8 pictures.  Returns (recon, blocks, seconds): recon[pli][bs]
     = uint8 plane of the coded size, reconstructed at uniform partition level bs.  lib:
     another build of the reference (the x86-intrinsics one) instead of oracle/_ref's default.
     fpr_bits = 8 / 10 / 12: full-precision references - pictures of that depth, planes of
-    int16 samples at 12 bits, the reference's xstride-2 conversions (recon is uint16)."""
+    int16 samples at 12 bits, the reference's xstride-2 conversions (recon is uint16).
+    inter_pred = [Y, Cb, Cr] prediction pictures: an INTER frame - every plane through
+    pvq_theta with is_keyframe = 0 against the pyramid of its prediction."""
     r = lib if lib is not None else ref()
+    r.ref_set_fpr(1 if fpr_bits else 0)
+    r.ref_stage_set_inter(1 if inter_pred is not None else 0)
+    try:
+        return _cpu_frame(r, qt, pics, pic_w, pic_h, chroma_cfl, lam, fpr_bits, inter_pred)
+    finally:
+        r.ref_set_fpr(0)
+        r.ref_stage_set_inter(0)
+
+
+def _pad(px, pic, fpr_bits):
+    h, w = px.shape
     if fpr_bits:
-        r.ref_set_fpr(1)
-        try:
-            return _cpu_frame(r, qt, pics, pic_w, pic_h, chroma_cfl, lam, fpr_bits)
-        finally:
-            r.ref_set_fpr(0)
-    return _cpu_frame(r, qt, pics, pic_w, pic_h, chroma_cfl, lam, 0)
+        oracle().odo_img_plane_copy_pad16(P(px), w, w, h, P(pic), fpr_bits, pic.shape[1], pic.shape[1],
+                                          pic.shape[0])
+    else:
+        oracle().odo_img_plane_copy_pad(P(px), w, w, h, P(pic), pic.shape[1], pic.shape[1], pic.shape[0])
 
 
-def _cpu_frame(r, qt, pics, pic_w, pic_h, chroma_cfl, lam, fpr_bits):
+def _cpu_frame(r, qt, pics, pic_w, pic_h, chroma_cfl, lam, fpr_bits, inter_pred):
     pdt = np.uint16 if fpr_bits else np.uint8
     assert r is not None, "oracle/_ref/libdaalaref.so not built"
     r.ref_stage_plane_levels.restype = ctypes.c_long
@@ -78,13 +89,17 @@ def _cpu_frame(r, qt, pics, pic_w, pic_h, chroma_cfl, lam, fpr_bits):
         t0 = time.perf_counter()
         # od_img_plane_copy_pad is file-static in the reference's encode.c: the restatement
         # (pinned to the encoder's own padded input, tests/test_oracle_golden.py)
-        if fpr_bits:
-            oracle().odo_img_plane_copy_pad16(P(px), w, w, h, P(pic), fpr_bits, pic.shape[1], pic.shape[1],
-                                              pic.shape[0])
-        else:
-            oracle().odo_img_plane_copy_pad(P(px), w, w, h, P(pic), pic.shape[1], pic.shape[1],
-                                            pic.shape[0])
-        if pli == 0:
+        _pad(px, pic, fpr_bits)
+        if inter_pred is not None:
+            ppx = np.zeros((h, w), pdt)
+            _pad(ppx, np.ascontiguousarray(inter_pred[pli]), fpr_bits)
+            plev = [np.zeros((h, w), np.int32) for _ in range(5)]
+            r.ref_forward_pyramid_plane((ctypes.c_void_p * 5)(*[a.ctypes.data for a in plev]),
+                                        P(np.zeros((h, w), np.int32)), P(ppx), w, w, h, dec, pic_w, pic_h)
+            arr = (ctypes.c_void_p * 5)(*[a.ctypes.data for a in plev])
+            blocks += r.ref_stage_plane_levels(P(px), w, w, h, dec, pic_w, pic_h, p, P(qm), P(qmi), qm_off,
+                                               qb, bb, ctypes.c_double(lam), rec_arr, None, arr)
+        elif pli == 0:
             dq = (ctypes.c_void_p * 5)(*[a.ctypes.data for a in ldq])
             blocks += r.ref_stage_plane_levels(P(px), w, w, h, 0, pic_w, pic_h, 0, P(qm), P(qmi), qm_off,
                                                qb, bb, ctypes.c_double(lam), rec_arr, dq, None)
@@ -177,7 +192,7 @@ def gpu_priced_frame(D, qt, pics, pic_w, pic_h, chroma_cfl=True, lam=0.147, fram
 
 
 def gpu_device_priced(D, qt, pics, pic_w, pic_h, chroma_cfl=True, lam=0.147, frames=None, serial=False,
-                      steps=None, fpr_bits=0):
+                      steps=None, fpr_bits=0, inter_pred=None):
     """The F pictures through `steps` odhip_pipe_step calls (each codes all F) of a price=1
     pipe.  Returns (recon like gpu_priced_frame(), bands the host libm re-decided)."""
     F = frames or 1
@@ -185,10 +200,15 @@ def gpu_device_priced(D, qt, pics, pic_w, pic_h, chroma_cfl=True, lam=0.147, fra
     chroma = np.concatenate([np.ascontiguousarray(pics[1]).reshape(F, pic_h // 2, pic_w // 2),
                              np.ascontiguousarray(pics[2]).reshape(F, pic_h // 2, pic_w // 2)])
     pipe = D.Pipe(qt, F, pic_w, pic_h, chroma_cfl=chroma_cfl, serial=serial, pvq_norm_lambda=lam,
-                  price=True, fpr_bits=fpr_bits)
+                  price=True, fpr_bits=fpr_bits, inter=inter_pred is not None)
     rdt = np.uint16 if fpr_bits else np.uint8
     try:
         pipe.set_pictures(luma, chroma)
+        if inter_pred is not None:
+            pipe.set_reference_pictures(
+                np.ascontiguousarray(inter_pred[0]).reshape(F, pic_h, pic_w),
+                np.concatenate([np.ascontiguousarray(inter_pred[1]).reshape(F, pic_h // 2, pic_w // 2),
+                                np.ascontiguousarray(inter_pred[2]).reshape(F, pic_h // 2, pic_w // 2)]))
         for _ in range(steps or 2):
             pipe.step()
         pipe.flush()

@@ -197,6 +197,37 @@ def test_whole_frame_noref_chroma_and_ragged_size():
         assert C.compare_frame(gpu, cpu) == [], cfl
 
 
+@pytest.mark.skipif(ref() is None, reason="oracle/_ref (the compiled reference) not present")
+@pytest.mark.parametrize("size", [(312, 180, 40), (1920, 1080, 20)])
+def test_inter_frame_step_equals_compiled_reference(size):
+    """odhip_pipe_config.inter: an INTER frame - luma and chroma through pvq_theta with
+    is_keyframe = 0 against the pyramid of a prediction picture (here: the same scene half a
+    phase later, a plausible motion-compensated prediction), the choice priced on the device,
+    positions PVQ never codes taken from the prediction.  Every reconstructed pixel of every
+    level of Y, Cb, Cr against the reference's own C functions run the same way."""
+    import daala_amd as D
+    import _pipeline_check as C
+    D.init(0)
+    b = _bench()
+    pw, ph, quality = size
+    qt = D.QuantTables.for_quality(quality)
+    cur = b.natural_like_frame_np(8, 3)
+    prev = b.natural_like_frame_np(8, 3)
+    rng = np.random.RandomState(4)
+    pics, pred = [], []
+    for pl, pp, (w_, h_) in zip(cur, prev, ((pw, ph), (pw // 2, ph // 2), (pw // 2, ph // 2))):
+        pics.append(np.ascontiguousarray(pl[:h_, :w_]))
+        # the prediction: the picture shifted by one sample with a little noise
+        q = np.roll(pp[:h_, :w_].astype(np.int32), 1, axis=1) + rng.randint(-6, 7, size=(h_, w_))
+        pred.append(np.clip(q, 0, 255).astype(np.uint8))
+    cpu, blocks, _ = C.cpu_frame(qt, pics, pw, ph, inter_pred=pred)
+    gpu, _ = C.gpu_device_priced(D, qt, pics, pw, ph, inter_pred=pred, steps=3)
+    assert C.compare_frame(gpu, cpu) == [], size
+    # the prediction matters: coding the same picture as a keyframe gives other pixels
+    key, _, _ = C.cpu_frame(qt, pics, pw, ph)
+    assert not np.array_equal(key[0][2], cpu[0][2])
+
+
 def test_fed_pictures_equal_resident_pictures():
     """odhip_pipe_feed: a different set of pictures for every step, copied from pinned host
     memory into the back buffers while the previous steps compute.  After each of six steps
