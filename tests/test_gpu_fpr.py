@@ -131,3 +131,11 @@ def test_fpr_whole_frame_step_equals_compiled_reference(hip, bits):
         gpu, _ = C.gpu_device_priced(hip, qt, pics, pw, ph, chroma_cfl=cfl, fpr_bits=bits)
         assert C.compare_frame(gpu, cpu) == [], (bits, cfl)
         assert int(cpu[0][0].max()) > 255          # really 12-bit samples
+    # and as an inter frame against a prediction of the same depth
+    pred = []
+    for p_ in pics:
+        q = np.roll(p_.astype(np.int32), 1, axis=1) + rng.randint(-3, 4, size=p_.shape) * (1 << (bits - 8))
+        pred.append(np.clip(q, 0, (1 << bits) - 1).astype(p_.dtype))
+    cpu, _, _ = C.cpu_frame(qt, pics, pw, ph, fpr_bits=bits, inter_pred=pred)
+    gpu, _ = C.gpu_device_priced(hip, qt, pics, pw, ph, fpr_bits=bits, inter_pred=pred)
+    assert C.compare_frame(gpu, cpu) == [], (bits, "inter")
