@@ -254,10 +254,12 @@ int pipe_init(odhip_pipe *p) {
   for (int i = 0; i < 2; i++) {
     p->ctx[i] = odhip_create(c.device);
     if (!p->ctx[i]) return ODHIP_EFAULT;
-    /* the band stages do not fork their searches onto side streams here: with the two
-       chains side by side more concurrency only interleaves the searches of one chain
-       (measured: 5.80 -> 5.68 ms per step; ODHIP_PIPE_FORK=1 restores the forks) */
-    odhip_ctx_set_serial(p->ctx[i], p->serial || getenv("ODHIP_PIPE_FORK") == nullptr);
+    /* with two chains side by side (chroma from luma, inter) the band stages do not fork
+       their searches onto side streams: more concurrency only interleaves the searches of
+       one chain (measured: 5.72 -> 5.58 ms per step; ODHIP_PIPE_FORK=1 restores the forks).
+       The single chain of the chroma-without-reference mode keeps them (3.56 vs 3.45 ms). */
+    const bool two_chains = c.chroma_cfl || c.inter;
+    odhip_ctx_set_serial(p->ctx[i], p->serial || (two_chains && getenv("ODHIP_PIPE_FORK") == nullptr));
     odhip_ctx_set_fpr(p->ctx[i], c.fpr_bits != 0);
   }
   ODHIP_TRY(hipStreamCreateWithFlags(&p->stream[0], hipStreamNonBlocking));
