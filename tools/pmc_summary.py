@@ -83,8 +83,8 @@ def main():
                     ctr[(n, r["Grid_Size"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
         except FileNotFoundError:
             pass
-    print("# kernel trace (rocprofv3 --kernel-trace --stats) of the default bench command: the band-stage")
-    print("# kernels overlap on forked streams, durations include the time they share the GPU")
+    print("# kernel trace (rocprofv3 --kernel-trace --stats) of the default bench command: the luma and the")
+    print("# chroma chain overlap on their two streams, durations include the time kernels share the GPU")
     print("%-28s %-18s %5s %6s %5s %6s %10s %10s" % ("kernel", "grid", "wg", "lds", "vgpr", "calls", "avg_us", "min_us"))
     tot = sum(sum(v) for v in dur.values())
     for k, v in sorted(dur.items(), key=lambda kv: -sum(kv[1])):

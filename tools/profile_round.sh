@@ -10,7 +10,7 @@ TAG=${1:-r2}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-B="python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-replay"
+B="python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-replay --no-streaming"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- $B > $OUT/bench_trace.json 2> $OUT/trace.err
 export ODHIP_PVQ_SERIAL=1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_serial -o t -- $B > $OUT/bench_trace_serial.json 2> $OUT/trace_serial.err
