@@ -139,3 +139,66 @@ def test_fpr_whole_frame_step_equals_compiled_reference(hip, bits):
     cpu, _, _ = C.cpu_frame(qt, pics, pw, ph, fpr_bits=bits, inter_pred=pred)
     gpu, _ = C.gpu_device_priced(hip, qt, pics, pw, ph, fpr_bits=bits, inter_pred=pred)
     assert C.compare_frame(gpu, cpu) == [], (bits, "inter")
+
+
+@pytest.mark.parametrize("fpr", [False, True])
+def test_inverse_partition_uniform_map_equals_inverse_level(hip, fpr):
+    """odhip_inverse_partition with a block-size map that says `level L everywhere` is
+    odhip_inverse_levels at level L - luma, and chroma (one size down, 4x4 for 8x8 and 4x4
+    luma) - for 8-bit planes and for the int16 planes of a full-precision-references
+    context; plus a mixed map: every superblock at its own level."""
+    import torch
+    L_ = hip.lib()
+    rng = np.random.RandomState(12)
+    F, h, w = 2, 128, 256
+    ctx = hip.Context(0).set_fpr(fpr)
+    try:
+        with ctx:
+            dt = hip.px_dtype()
+            for dec in (0, 1):
+                hh, ww = h >> dec, w >> dec
+                nplanes = F * (2 if dec else 1)
+                top = 4 - dec
+                coefs = [_cuda((rng.randint(-200, 201, size=(nplanes, hh, ww)) * 8).astype(np.int32))
+                         for _ in range(top + 1)]
+                want = hip.inverse_levels(coefs, dec, list(range(top + 1)), w, h)
+                bstride = (w // 64) * 8
+                rows = (h // 64) * 8
+                for lum in range(5):
+                    lvl = max(lum - dec, 0)                       # the chroma block of a luma block
+                    bsize = _cuda(np.full((F, rows, bstride), lum, np.uint8))
+                    out = torch.empty((nplanes, hh, ww), dtype=dt, device="cuda")
+                    rc = L_.odhip_inverse_partition(ctypes.c_void_p(out.data_ptr()), ww, ctypes.c_long(hh * ww),
+                                                    ctypes.c_void_p(coefs[lvl].data_ptr()), nplanes, ww, hh, dec,
+                                                    ctypes.c_void_p(bsize.data_ptr()), bstride,
+                                                    ctypes.c_long(rows * bstride), 2 if dec else 1, w, h, None)
+                    assert rc == 0
+                    torch.cuda.synchronize()
+                    assert torch.equal(out, want[lvl]), (fpr, dec, lum)
+                if dec == 0:
+                    # superblock (sx, sy) coded at level (sx + sy) % 5: every superblock must equal
+                    # the uniform reconstruction of its own level, given coefficients that agree
+                    mix = np.zeros((F, rows, bstride), np.uint8)
+                    coef_mix = torch.empty_like(coefs[0])
+                    for sy in range(h // 64):
+                        for sx in range(w // 64):
+                            lv = (sx + sy) % 5
+                            mix[:, sy * 8:(sy + 1) * 8, sx * 8:(sx + 1) * 8] = lv
+                            coef_mix[:, sy * 64:(sy + 1) * 64, sx * 64:(sx + 1) * 64] = \
+                                coefs[lv][:, sy * 64:(sy + 1) * 64, sx * 64:(sx + 1) * 64]
+                    out = torch.empty((nplanes, hh, ww), dtype=dt, device="cuda")
+                    rc = L_.odhip_inverse_partition(ctypes.c_void_p(out.data_ptr()), ww, ctypes.c_long(hh * ww),
+                                                    ctypes.c_void_p(coef_mix.data_ptr()), nplanes, ww, hh, 0,
+                                                    ctypes.c_void_p(_cuda(mix).data_ptr()), bstride,
+                                                    ctypes.c_long(rows * bstride), 1, w, h, None)
+                    assert rc == 0
+                    torch.cuda.synchronize()
+                    # inside a superblock - away from the 2 samples the superblock-edge post-filter
+                    # mixes with the neighbours - the samples are those of the uniform level
+                    for sy in range(h // 64):
+                        for sx in range(w // 64):
+                            lv = (sx + sy) % 5
+                            ys, xs = slice(sy * 64 + 2, sy * 64 + 62), slice(sx * 64 + 2, sx * 64 + 62)
+                            assert torch.equal(out[:, ys, xs], want[lv][:, ys, xs]), (fpr, sx, sy, lv)
+    finally:
+        ctx.destroy()
