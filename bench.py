@@ -374,7 +374,8 @@ def sharded_encode_check(rank, world, local_rank, dist, torch):
         err = err or "gather: %r" % (e,)
     torch.cuda.synchronize()
     t_gather = time.perf_counter() - t0
-    tt = torch.tensor([t_enc, t_gather], dtype=torch.float64, device="cuda")
+    tt = torch.tensor([t_enc, t_gather], dtype=torch.float64,
+                      device="cuda" if dist.get_backend() == "nccl" else "cpu")
     dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     if rank == 0 and (err or got is None):
         return {"ran": False, "why": err or "gather returned nothing"}
@@ -495,12 +496,21 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback exists)")
+    # ODHIP_BENCH_ONE_GPU=1 / ODHIP_BENCH_BACKEND=gloo: test hooks - every rank on cuda:0 and the
+    # control plane over gloo, so that the N > 1 flow can be exercised on a one-GPU box
+    # (tests/test_gpu_bench_multi.py); the driver's runs use one GPU per rank and RCCL
+    if os.environ.get("ODHIP_BENCH_ONE_GPU") == "1":
+        local_rank = 0
+    backend = os.environ.get("ODHIP_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     D.init(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend)
     device = torch.device("cuda", local_rank)
 
     cfl = not args.chroma_noref
@@ -546,7 +556,7 @@ def main():
     fd_alone = pipe.time_pyramid(10)
     copy_gbs = copy_ceiling_gbs(device)
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        t = torch.tensor([dt], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     # what the timed steps left in the reconstruction buffers (for `verified`), before
