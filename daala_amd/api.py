@@ -271,7 +271,8 @@ class _Job(ctypes.Structure):
                 ("d_qm_inv", ctypes.c_void_p), ("q_band", ctypes.POINTER(ctypes.c_int32)),
                 ("beta_band", ctypes.POINTER(ctypes.c_int32)), ("cands", _Cands),
                 ("d_dq", ctypes.c_void_p), ("d_rate", ctypes.c_void_p),
-                ("d_qg", ctypes.c_void_p)]
+                ("d_qg", ctypes.c_void_p), ("q_band2", ctypes.POINTER(ctypes.c_int32)),
+                ("plane_split", ctypes.c_int)]
 
 
 # ---- with-reference (theta / Householder) building blocks -------------------------
@@ -394,7 +395,9 @@ class PvqJob:
     tensor and host array it points to alive."""
 
     def __init__(self, coef, bs, qm, qm_inv, q_band, beta_band, cands=None, dq=None,
-                 rate=None, qg=None):
+                 rate=None, qg=None, q_band2=None, plane_split=0):
+        """q_band2 / plane_split: the planes from plane_split on (the Cr half of a chroma
+        plane set) take q_band2 - pvq_qm_q4[pli] is per plane in the reference."""
         import torch
         _need(coef, torch.int32, "coef")
         self.coef, self.bs, self.qm, self.qm_inv = coef, int(bs), qm, qm_inv
@@ -405,6 +408,8 @@ class PvqJob:
         assert len(q_band) == nb and len(beta_band) == nb
         self.q_band = (ctypes.c_int32 * 12)(*[int(v) for v in q_band])
         self.beta_band = (ctypes.c_int32 * 12)(*[int(v) for v in beta_band])
+        self.q_band2 = (ctypes.c_int32 * 12)(*[int(v) for v in q_band2]) if q_band2 is not None else None
+        self.plane_split = int(plane_split) if q_band2 is not None else 0
         self.cands = cands if cands is not None else alloc_pvq_cands(self.nblocks, bs,
                                                                      coef.device)
         self.dq, self.rate, self.qg = dq, rate, qg
@@ -420,7 +425,8 @@ class PvqJob:
         c = _Cands(*[ctypes.c_void_p(self.cands[n].data_ptr() if self.cands.get(n) is not None
                                      else None) for n in _CAND_FIELDS])
         return _Job(_p(self.coef), nplanes, w, h, self.bs, opt(self.qm), opt(self.qm_inv),
-                    self.q_band, self.beta_band, c, opt(self.dq), opt(self.rate), opt(self.qg))
+                    self.q_band, self.beta_band, c, opt(self.dq), opt(self.rate), opt(self.qg),
+                    self.q_band2, self.plane_split)
 
 
 def _jobs_array(jobs):
@@ -553,7 +559,8 @@ class _RefJob(ctypes.Structure):
                 ("beta_band", ctypes.POINTER(ctypes.c_int32)), ("band", ctypes.c_void_p),
                 ("items", ctypes.c_void_p), ("y", ctypes.c_void_p), ("r16", ctypes.c_void_p),
                 ("x16", ctypes.c_void_p), ("xr", ctypes.c_void_p), ("d_rate", ctypes.c_void_p),
-                ("choice", ctypes.c_void_p), ("d_dq", ctypes.c_void_p)]
+                ("choice", ctypes.c_void_p), ("d_dq", ctypes.c_void_p),
+                ("q_band2", ctypes.POINTER(ctypes.c_int32)), ("plane_split", ctypes.c_int)]
 
 
 class PvqRefJob:
@@ -561,7 +568,7 @@ class PvqRefJob:
     band stage (odhip_pvq_refjob); owns its output and work buffers."""
 
     def __init__(self, coef, ref, bs, qm, qm_inv, q_band, beta_band, is_keyframe, pli, rate=None,
-                 share=None):
+                 share=None, q_band2=None, plane_split=0):
         """share: another PvqRefJob of the same shape whose output and work buffers this
         one uses too (same planes, another reference buffer: double-buffered references)."""
         import torch
@@ -577,6 +584,8 @@ class PvqRefJob:
         assert len(q_band) == self.nb and len(beta_band) == self.nb
         self.q_band = (ctypes.c_int32 * 12)(*[int(v) for v in q_band])
         self.beta_band = (ctypes.c_int32 * 12)(*[int(v) for v in beta_band])
+        self.q_band2 = (ctypes.c_int32 * 12)(*[int(v) for v in q_band2]) if q_band2 is not None else None
+        self.plane_split = int(plane_split) if q_band2 is not None else 0
         dev = coef.device
         if share is not None:
             assert share.coef.shape == coef.shape and share.bs == self.bs
@@ -602,7 +611,8 @@ class PvqRefJob:
         return _RefJob(_p(self.coef), _p(self.ref), nplanes, w, h, self.bs, self.is_keyframe,
                        self.pli, opt(self.qm), opt(self.qm_inv), self.q_band, self.beta_band,
                        _p(self.band), _p(self.items), _p(self.y), _p(self.r16), _p(self.x16),
-                       _p(self.xr), opt(self.rate), _p(self.choice), _p(self.dq))
+                       _p(self.xr), opt(self.rate), _p(self.choice), _p(self.dq), self.q_band2,
+                       self.plane_split)
 
     def unpack(self):
         """Host copies: record fields [B][nb], item fields [B][nb][REF_SLOTS], y, choice."""

@@ -166,12 +166,17 @@ int run_pass(odhip_dering_cache *c, int pli, odhip_dering_cache::Result &r) {
 }  // namespace
 
 extern "C" odhip_dering_cache *odhip_dering_cache_create(void) {
-  odhip_ctx *ctx = odhip_ctx_current();
+  /* the cache OWNS its context (as the frame cache does): it may be used from another
+     thread than its creator, and outlive that thread's default context */
+  odhip_ctx *cur = odhip_ctx_current();
+  if (!cur) return nullptr;
+  odhip_ctx *ctx = odhip_create(cur->device);
   if (!ctx) return nullptr;
   odhip_dering_cache *c = new odhip_dering_cache();
   c->ctx = ctx;
   if (hipSetDevice(ctx->device) != hipSuccess
    || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+    odhip_destroy(ctx);
     delete c;
     return nullptr;
   }
@@ -195,6 +200,10 @@ extern "C" void odhip_dering_cache_destroy(odhip_dering_cache *c) {
   if (c->d_dirs) (void)hipFree(c->d_dirs);
   if (c->h_dirs) (void)hipHostFree(c->h_dirs);
   if (c->d_thr) (void)hipFree(c->d_thr);
+  if (c->ctx) {
+    if (odhip_get_current() == c->ctx) (void)odhip_make_current(nullptr);
+    odhip_destroy(c->ctx);
+  }
   delete c;
 }
 

@@ -69,7 +69,7 @@ struct odhip_frame_cache {
     od_coeff *h_levels[ODHIP_NBSIZES];
     od_coeff *d_levels[ODHIP_NBSIZES];
     size_t cap;
-    unsigned long long px_hash;   /* FNV-1a of the pixels the cached pyramid was made from */
+    int pic_w, pic_h;        /* the picture size the cached pyramid was made for */
     BandLevel *bands;        /* [ODHIP_NBSIZES], allocated by odhip_cache_load_bands */
     int bands_valid;
     int bands_quantizer;     /* the set-up the cached band stage was run with */
@@ -208,7 +208,8 @@ int odhip_cache_load_plane(odhip_frame_cache *c, int pli, const od_coeff *coef, 
     return ODHIP_EINVAL;
   }
   odhip_frame_cache::Plane &p = c->planes[pli];
-  const bool same_shape = p.valid && p.w == w && p.h == h && p.dec == dec && p.base == coef;
+  const bool same_shape = p.valid && p.w == w && p.h == h && p.dec == dec && p.base == coef
+   && p.pic_w == c->pic_w && p.pic_h == c->pic_h;
   const int was_bands = p.bands_valid;
   p.valid = 0;
   p.bands_valid = 0;
@@ -216,24 +217,27 @@ int odhip_cache_load_plane(odhip_frame_cache *c, int pli, const od_coeff *coef, 
   if (rc) return rc;
   /* od_ref_buf_to_coeff wrote (p - 128) << 4 (src/state.c:1233): recover p. */
   const size_t n = (size_t)w*h;
-  unsigned long long hash = 1469598103934665603ULL;
+  /* the exact test for "the same pixels again" (below): compared while h_px still holds
+     the previous load's */
+  bool same_px = same_shape;
   for (size_t i = 0; i < n; i++) {
     const int v = coef[i];
     const int px = (v >> 4) + 128;
     if ((v & 15) || px < 0 || px > 255) return ODHIP_EINVAL;  /* not a fresh 8-bit plane */
+    same_px = same_px && p.h_px[i] == (uint8_t)px;
     p.h_px[i] = (uint8_t)px;
-    hash = (hash ^ (unsigned)px)*1099511628211ULL;
   }
   /* The encoder converts and laps the same input once per RDO pass (src/encode.c:
      2560-2572 runs for OD_ENCODE_RDO and for OD_ENCODE_REAL): the second load of
      identical pixels keeps the pyramid (and the band stage) it already has. */
-  if (same_shape && hash == p.px_hash && !c->check) {
+  if (same_px && !c->check) {
     p.valid = 1;
     p.bands_valid = was_bands;
     c->reloads_skipped++;
     return ODHIP_SUCCESS;
   }
-  p.px_hash = hash;
+  p.pic_w = c->pic_w;
+  p.pic_h = c->pic_h;
   ODHIP_TRY(hipMemcpyAsync(p.d_px, p.h_px, n, hipMemcpyHostToDevice, c->stream));
   od_coeff *levels[ODHIP_NBSIZES];
   for (int i = 0; i < ODHIP_NBSIZES; i++) levels[i] = p.d_levels[i];

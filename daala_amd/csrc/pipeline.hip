@@ -56,6 +56,10 @@ struct PlaneSet {
   int16_t *qm[ODHIP_NBSIZES];
   int16_t *qm_inv[ODHIP_NBSIZES];
   int32_t q[ODHIP_NBSIZES][ODHIP_MAX_BANDS];
+  /* the chroma set holds F Cb planes, then F Cr planes: per-band steps of the second
+     half (pvq_qm_q4[2], src/encode.c:3052-3072) */
+  int32_t q2[ODHIP_NBSIZES][ODHIP_MAX_BANDS];
+  int plane_split;   /* 0: one table */
   int32_t beta[ODHIP_NBSIZES][ODHIP_MAX_BANDS];
   long nblocks[ODHIP_NBSIZES];
 };
@@ -150,6 +154,7 @@ int setup_set(odhip_pipe *p, PlaneSet &s, int dec, int pli, int nplanes) {
   s.pw = (p->pic_w + dec) >> dec;
   s.ph = (p->pic_h + dec) >> dec;
   s.nlev = ODHIP_NBSIZES - dec;
+  s.plane_split = pli == 1 ? nplanes/2 : 0;
   /* full-precision references: the coded planes and the reconstructions hold int16
      samples; the resident source pictures keep their own depth */
   const size_t px_bytes = p->cfg.fpr_bits ? 2 : 1;
@@ -176,6 +181,7 @@ int setup_set(odhip_pipe *p, PlaneSet &s, int dec, int pli, int nplanes) {
     ODHIP_TRY(hipMemcpy(s.qm[bs], qt->qm + off, sizeof(int16_t)*len, hipMemcpyHostToDevice));
     ODHIP_TRY(hipMemcpy(s.qm_inv[bs], qt->qm_inv + off, sizeof(int16_t)*len, hipMemcpyHostToDevice));
     if (odhip_quant_bands(qt, pli, bs, s.q[bs], s.beta[bs]) < 0) return ODHIP_EINVAL;
+    if (pli == 1 && odhip_quant_bands(qt, 2, bs, s.q2[bs], nullptr) < 0) return ODHIP_EINVAL;
     s.nblocks[bs] = (long)nplanes*(s.w/n)*(s.h/n);
   }
   return ODHIP_SUCCESS;
@@ -195,6 +201,10 @@ int setup_job(odhip_pipe *p, odhip_pvq_job &j, PlaneSet &s, int bs) {
   j.d_qm_inv = s.qm_inv[bs];
   j.q_band = s.q[bs];
   j.beta_band = s.beta[bs];
+  if (s.plane_split) {
+    j.q_band2 = s.q2[bs];
+    j.plane_split = s.plane_split;
+  }
   const long B = s.nblocks[bs];
   PIPE_ALLOC(p, j.cands.band, sizeof(odhip_pvq_band)*(size_t)B*nb, true);
   PIPE_ALLOC(p, j.cands.y, sizeof(int16_t)*(size_t)2*B*len, true);
@@ -220,6 +230,10 @@ int setup_refjob(odhip_pipe *p, odhip_pvq_refjob &j, PlaneSet &s, int bs, const 
   j.d_qm_inv = s.qm_inv[bs];
   j.q_band = s.q[bs];
   j.beta_band = s.beta[bs];
+  if (s.plane_split) {
+    j.q_band2 = s.q2[bs];
+    j.plane_split = s.plane_split;
+  }
   if (share) {
     /* same planes, the other reference buffer: outputs and work vectors are shared
        (the chroma chains of consecutive steps run in order on one stream) */
@@ -262,9 +276,29 @@ int pipe_init(odhip_pipe *p) {
     odhip_ctx_set_serial(p->ctx[i], p->serial || (two_chains && getenv("ODHIP_PIPE_FORK") == nullptr));
     odhip_ctx_set_fpr(p->ctx[i], c.fpr_bits != 0);
   }
-  ODHIP_TRY(hipStreamCreateWithFlags(&p->stream[0], hipStreamNonBlocking));
-  if (p->serial) p->stream[1] = p->stream[0];
-  else ODHIP_TRY(hipStreamCreateWithFlags(&p->stream[1], hipStreamNonBlocking));
+  /* Experiment knob: ODHIP_PIPE_CUSPLIT=n (1..7) gives the luma chain n of every 8 compute
+     units and the chroma chain the other 8 - n (hipExtStreamCreateWithCUMask) instead of
+     letting the two chains share every CU. */
+  const char *split_env = getenv("ODHIP_PIPE_CUSPLIT");
+  const int split = split_env ? atoi(split_env) : 0;
+  if (!p->serial && split >= 1 && split <= 7) {
+    hipDeviceProp_t prop;
+    ODHIP_TRY(hipGetDeviceProperties(&prop, c.device));
+    const int words = (prop.multiProcessorCount + 31)/32;
+    std::vector<uint32_t> ma(words), mb(words);
+    const uint32_t byte_a = (1u << split) - 1u;
+    for (int i = 0; i < words; i++) {
+      ma[i] = byte_a*0x01010101u;
+      mb[i] = ~ma[i];
+    }
+    ODHIP_TRY(hipExtStreamCreateWithCUMask(&p->stream[0], (uint32_t)words, ma.data()));
+    ODHIP_TRY(hipExtStreamCreateWithCUMask(&p->stream[1], (uint32_t)words, mb.data()));
+  }
+  else {
+    ODHIP_TRY(hipStreamCreateWithFlags(&p->stream[0], hipStreamNonBlocking));
+    if (p->serial) p->stream[1] = p->stream[0];
+    else ODHIP_TRY(hipStreamCreateWithFlags(&p->stream[1], hipStreamNonBlocking));
+  }
   int rc = setup_set(p, p->set[0], 0, 0, c.frames);
   if (rc) return rc;
   rc = setup_set(p, p->set[1], 1, 1, 2*c.frames);
@@ -404,6 +438,8 @@ int finish_pending(odhip_pipe *p) {
   if (n > 0) {
     p->reruns += n;
     STEP_TRY(chroma_tail(p, par, p->stream[1], true));
+    /* the re-run reads refs[par] again: the luma chain must not overwrite it before */
+    ODHIP_TRY(hipEventRecord(p->ev_used[par], p->stream[1]));
   }
   if (p->cfg.price) {
     /* the chroma choices of that step: listed bands are re-decided with the host libm and
@@ -419,6 +455,7 @@ int finish_pending(odhip_pipe *p) {
       PlaneSet &ch = p->set[1];
       STEP_TRY(odhip_inverse_levels_pvq_ref(ch.recon, ch.w, (long)ch.w*ch.h, p->refjobs[par], 4, 1, p->pic_w,
        p->pic_h, p->stream[1]));
+      ODHIP_TRY(hipEventRecord(p->ev_used[par], p->stream[1]));
     }
   }
   return ODHIP_SUCCESS;
@@ -851,7 +888,8 @@ extern "C" int odhip_pipe_buffer(odhip_pipe *p, int what, int set, int level, in
       break;
     case ODHIP_PIPE_BUF_REF:
       if (!r) return ODHIP_EINVAL;
-      ptr = p->refs[parity][level];
+      /* inter mode: the reference of every block is the pyramid of its prediction picture */
+      ptr = inter ? t.pred_levels[level] : p->refs[parity][level];
       n = sizeof(od_coeff)*(size_t)t.nplanes*t.w*t.h;
       break;
     case ODHIP_PIPE_BUF_RATE: {
@@ -863,6 +901,7 @@ extern "C" int odhip_pipe_buffer(odhip_pipe *p, int what, int set, int level, in
         ODHIP_TRY(hipSetDevice(p->cfg.device));
         PIPE_ALLOC(p, p->rate[set][level], n, true);
         if (j) p->jobs[set ? 5 + level : level].d_rate = p->rate[set][level];
+        else if (inter) p->interjobs[set][level].d_rate = p->rate[set][level];
         else {
           p->refjobs[0][level].d_rate = p->rate[set][level];
           p->refjobs[1][level].d_rate = p->rate[set][level];

@@ -74,6 +74,10 @@ struct DJob {
   int q[ODHIP_MAX_BANDS];
   int beta[ODHIP_MAX_BANDS];
   int off[ODHIP_MAX_BANDS + 1];
+  /* planes from plane_split on (blocks from split_blk on) take q2: the Cr half of a
+     chroma plane set - pvq_qm_q4[pli] is per plane, src/encode.c:3052-3072 */
+  long split_blk;
+  int q2[ODHIP_MAX_BANDS];
 };
 
 /* A band whose priced choice the host (re)decides: candidate rates from the host libm. */
@@ -199,8 +203,15 @@ struct PrepCtx {
   int len;
   int nb_bands;
   int q;
+  int q2;
+  long split_blk;
   int beta;
 };
+
+/* The band's quantiser step for block blk. */
+__device__ __forceinline__ int prep_q(const PrepCtx &cx, long blk) {
+  return blk >= cx.split_blk ? cx.q2 : cx.q;
+}
 
 __device__ __forceinline__ PrepCtx prep_ctx(const DJob &jb, int band, int off, int pad) {
   PrepCtx c;
@@ -212,6 +223,8 @@ __device__ __forceinline__ PrepCtx prep_ctx(const DJob &jb, int band, int off, i
   c.len = jb.len;
   c.nb_bands = jb.nb_bands;
   c.q = jb.q[band];
+  c.q2 = jb.q2[band];
+  c.split_blk = jb.split_blk;
   c.beta = jb.beta[band];
   return c;
 }
@@ -298,7 +311,7 @@ __device__ __forceinline__ void od_prep_lane(const DJob &jb, int band, int off, 
   }
   if (!bp.live) return;
   int32_t g;
-  const int32_t cg = odq_gain_from_acc(acc, cx.q, cx.beta, xshift, &g);
+  const int32_t cg = odq_gain_from_acc(acc, prep_q(cx, bp.blk), cx.beta, xshift, &g);
   od_band_candidates(cx, N, bp.blk, cg);
 }
 
@@ -384,7 +397,7 @@ __global__ __launch_bounds__(kWave) void k_prep_corner(Items it) {
     });
     if (bp.live) {
       int32_t g;
-      const int32_t cg = odq_gain_from_acc(acc, cx[b].q, cx[b].beta, xshift, &g);
+      const int32_t cg = odq_gain_from_acc(acc, prep_q(cx[b], bp.blk), cx[b].beta, xshift, &g);
       od_band_candidates(cx[b], n, bp.blk, cg);
     }
   });
@@ -448,7 +461,7 @@ __global__ __launch_bounds__(kWave) void k_prep_wide(Items it) {
   acc = row_sum(acc);
   if (!bp.live || l != 0) return;
   int32_t g;
-  const int32_t cg = odq_gain_from_acc(acc, cx.q, cx.beta, xshift, &g);
+  const int32_t cg = odq_gain_from_acc(acc, prep_q(cx, bp.blk), cx.beta, xshift, &g);
   od_band_candidates(cx, n, bp.blk, cg);
 }
 
@@ -762,7 +775,7 @@ template <int PRICE>
 __device__ __forceinline__ void choose_core(const Items &it, int job, const DJob &jb, long sb, int band,
  const RecHead &hd, double best_cost, int yy0, int yy1, int mom0, int mom1, double dist0, double dist1,
  const double *given) {
-  const int qb = jb.q[band];
+  const int qb = sb/jb.nb_bands >= jb.split_blk ? jb.q2[band] : jb.q[band];
   const int betab = jb.beta[band];
   const double *const rate = jb.rate;
   int4 *const choice = reinterpret_cast<int4 *>(jb.choice);
@@ -1197,7 +1210,14 @@ int fill_job(DJob &d, const odhip_pvq_job &j, int mode) {
   for (int i = 0; i < d.nb_bands; i++) {
     if (j.q_band[i] < 1) return ODHIP_EINVAL;
     d.q[i] = j.q_band[i];
+    d.q2[i] = j.q_band2 ? j.q_band2[i] : j.q_band[i];
+    if (d.q2[i] < 1) return ODHIP_EINVAL;
     d.beta[i] = j.beta_band[i];
+  }
+  d.split_blk = d.nblocks;
+  if (j.q_band2) {
+    if (j.plane_split <= 0 || j.plane_split >= j.nplanes) return ODHIP_EINVAL;
+    d.split_blk = (long)j.plane_split*d.bw*d.bh;
   }
   return ODHIP_SUCCESS;
 }

@@ -91,7 +91,16 @@ struct RJob {
   int q[ODHIP_MAX_BANDS];
   int beta[ODHIP_MAX_BANDS];
   int off[ODHIP_MAX_BANDS + 1];
+  /* planes from plane_split on (blocks from split_blk on) take q2: the Cr half of a
+     chroma plane set - pvq_qm_q4[pli] is per plane, src/encode.c:3052-3072 */
+  long split_blk;
+  int q2[ODHIP_MAX_BANDS];
 };
+
+/* The band's quantiser step for block blk. */
+__device__ __forceinline__ int job_q(const RJob &jb, int band, long blk) {
+  return blk >= jb.split_blk ? jb.q2[band] : jb.q[band];
+}
 
 struct Unc;
 /* A band whose priced choice the host (re)decides: rate[0] = the initial candidate,
@@ -299,7 +308,7 @@ __global__ __launch_bounds__(kWave) void k_refb_prep_lane(RItems it) {
   const int w = jb.w;
   const int len = jb.len;
   const int nb_bands = jb.nb_bands;
-  const int q0 = jb.q[band];
+  const int q0 = job_q(jb, band, blk);
   const int beta = jb.beta[band];
   const int is_keyframe = jb.is_keyframe;
   const int cfl_enabled = is_keyframe && jb.pli != 0;
@@ -529,7 +538,7 @@ __global__ __launch_bounds__(kWave) void k_refb_prep_row(RItems it) {
   const int w = jb.w;
   const int len = jb.len;
   const int nb_bands = jb.nb_bands;
-  const int q0 = jb.q[band];
+  const int q0 = job_q(jb, band, blk);
   const int beta = jb.beta[band];
   const int is_keyframe = jb.is_keyframe;
   const int cfl_enabled = is_keyframe && jb.pli != 0;
@@ -1135,7 +1144,7 @@ struct RowVector {
 };
 
 template <int E, int G>
-__global__ __launch_bounds__(kWave) void k_refb_search_row(RItems it) {
+__global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_refb_search_row(RItems it) {
   od_rsqrt_init(threadIdx.x);
   const int item = find_item(it, blockIdx.x);
   const RJob &jb = it.jobs[it.job[item]];
@@ -1413,7 +1422,7 @@ __device__ __forceinline__ void refb_finish(const RItems &it, int job, const RJo
   /* od_gain_expand + od_pvq_synthesis_partial (band-wide part), :623-633,
      src/pvq.c:1037-1115 */
   const int32_t g = odq_gain_expand(odq_shl32(qg, ODQ_CGAIN_SHIFT) + (noref ? 0 : r.gain_offset),
-   jb.q[band], jb.beta[band]);
+   job_q(jb, band, blk), jb.beta[band]);
   const int nn = N - (!noref);
   int yy = 0;
 #pragma unroll
@@ -1739,7 +1748,17 @@ int fill_job(RJob &d, const odhip_pvq_refjob &j, int mode) {
   for (int i = 0; i < d.nb_bands; i++) {
     if (j.q_band[i] < 1) return ODHIP_EINVAL;
     d.q[i] = j.q_band[i];
+    d.q2[i] = j.q_band[i];
     d.beta[i] = j.beta_band[i];
+  }
+  d.split_blk = d.nblocks;
+  if (j.q_band2) {
+    if (j.plane_split <= 0 || j.plane_split >= j.nplanes) return ODHIP_EINVAL;
+    d.split_blk = (long)j.plane_split*d.bw*d.bh;
+    for (int i = 0; i < d.nb_bands; i++) {
+      if (j.q_band2[i] < 1) return ODHIP_EINVAL;
+      d.q2[i] = j.q_band2[i];
+    }
   }
   return ODHIP_SUCCESS;
 }

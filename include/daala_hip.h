@@ -355,6 +355,12 @@ typedef struct {
   od_coeff *d_dq;
   const double *d_rate;
   int32_t *d_qg;
+  /* optional: planes plane_split .. nplanes-1 use q_band2 instead of q_band (HOST
+     [nb_bands]): a chroma plane set holding the Cb planes first and the Cr planes
+     after them - the per-band step comes from pvq_qm_q4[pli], which differs between
+     Cb and Cr (OD_DEFAULT_QMS, src/encode.c:118-131, :3052-3072).  NULL = one table. */
+  const int32_t *q_band2;
+  int plane_split;
 } odhip_pvq_job;
 
 /* All jobs (at most 16) in one set of launches, so that small levels (510
@@ -615,6 +621,8 @@ typedef struct {
   int32_t *choice;           /* select_synth out [B][nb][16], 16-byte aligned  */
   od_coeff *d_dq;            /* select_synth out: dequantised planes, layout of
                                 d_coef; DC passed through; uncoded positions 0 */
+  const int32_t *q_band2;    /* optional, HOST [nb]: as odhip_pvq_job.q_band2 - */
+  int plane_split;           /* planes plane_split.. (the Cr half) use q_band2  */
 } odhip_pvq_refjob;
 
 /* At most 8 jobs per call, all on one stream.  The stage keeps per-call state

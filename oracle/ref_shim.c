@@ -456,6 +456,19 @@ REF_EXPORT void ref_stage_set_inter(int on) {
   ref_stage_inter = on != 0;
 }
 
+/* ref_stage_set_dump: the stage functions below also hand back what pvq_theta decided for
+   every band of every block - what north_star calls "coefficients and PVQ pulse vectors":
+   y_levels[bs] int32 [blocks][len] = the pulse vector y[] of each block in coding order
+   (len = min(N*N, 512); zero where pvq_theta wrote nothing, i.e. DC and bands whose gain 0 /
+   skip won), band_levels[bs] int32 [blocks][nb][4] = {return value (the coded gain
+   index), itheta, max_theta, k}.  Blocks in raster order of the plane.  NULL, NULL = off. */
+static int32_t *const *g_dump_y;
+static int32_t *const *g_dump_band;
+REF_EXPORT void ref_stage_set_dump(int32_t *const *y_levels, int32_t *const *band_levels) {
+  g_dump_y = y_levels;
+  g_dump_band = band_levels;
+}
+
 static long stage_plane_core(unsigned char *px, int px_stride, int w, int h,
  int dec, int pic_w, int pic_h, int pli, const int16_t *qm, const int16_t *qm_inv,
  const int *qm_off, const int *q_band, const int *beta_band,
@@ -482,9 +495,11 @@ static long stage_plane_core(unsigned char *px, int px_stride, int w, int h,
     int by;
     int nb;
     const int *off;
+    long nblocks_level;
     n = 4 << bs;
     nb = OD_BAND_OFFSETS[bs][0];
     off = &OD_BAND_OFFSETS[bs][1];
+    nblocks_level = 0;
     for (by = 0; by < h/n; by++) {
       for (bx = 0; bx < w/n; bx++) {
         od_coeff in[OD_BSIZE_MAX*OD_BSIZE_MAX];
@@ -521,16 +536,32 @@ static long stage_plane_core(unsigned char *px, int px_stride, int w, int h,
         }
         else memset(ref0, 0, sizeof(*ref0)*n*n);
         skip_diff = 0;
+        if (g_dump_y != NULL) memset(y, 0, sizeof(*y)*off[nb]);
         for (i = 0; i < nb; i++) {
           int itheta;
           int max_theta;
           int k;
-          pvq_theta(out + off[i], in + off[i], ref0 + off[i], off[i + 1] - off[i],
+          int qg;
+          qg = pvq_theta(out + off[i], in + off[i], ref0 + off[i], off[i + 1] - off[i],
            q_band[bs*12 + i], y + off[i], &itheta, &max_theta, &k,
            (od_val16)beta_band[bs*12 + i], &skip_diff, 1, !ref_stage_inter, pli, adapt,
            qm + qm_off[bs] + off[i], qm_inv + qm_off[bs] + off[i],
            pvq_norm_lambda, 1);
+          if (g_dump_band != NULL && g_dump_band[bs] != NULL) {
+            int32_t *rec;
+            rec = g_dump_band[bs] + ((size_t)nblocks_level*nb + i)*4;
+            rec[0] = qg;
+            rec[1] = itheta;
+            rec[2] = max_theta;
+            rec[3] = k;
+          }
         }
+        if (g_dump_y != NULL && g_dump_y[bs] != NULL) {
+          int32_t *dst;
+          dst = g_dump_y[bs] + (size_t)nblocks_level*off[nb];
+          for (i = 0; i < off[nb]; i++) dst[i] = y[i];
+        }
+        nblocks_level++;
         out[0] = in[0];
         /* src/encode.c:1388: what PVQ never codes is zero on a keyframe, the prediction's
            own coefficients on an inter frame (src/state.c:1347-1366) */

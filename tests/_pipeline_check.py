@@ -27,7 +27,9 @@ NBANDS = [1, 4, 7, 9, 9]
 
 
 def _tables(qt, p):
-    qm_off = (ctypes.c_int * 5)(*[int(qt.qm_offset[bs][p]) for bs in range(5)])
+    """p = plane index: the QM depends on the decimation only, the per-band steps on the plane
+    (pvq_qm_q4[pli])."""
+    qm_off = (ctypes.c_int * 5)(*[int(qt.qm_offset[bs][1 if p else 0]) for bs in range(5)])
     qb = (ctypes.c_int * 60)()
     bb = (ctypes.c_int * 60)()
     for bs in range(5):
@@ -38,22 +40,29 @@ def _tables(qt, p):
     return qm_off, qb, bb
 
 
-def cpu_frame(qt, pics, pic_w, pic_h, chroma_cfl=True, lam=0.147, lib=None, fpr_bits=0, inter_pred=None):
+def cpu_frame(qt, pics, pic_w, pic_h, chroma_cfl=True, lam=0.147, lib=None, fpr_bits=0, inter_pred=None,
+              decisions=None):
     """pics: [Y, Cb, Cr] uint8 pictures.  Returns (recon, blocks, seconds): recon[pli][bs]
     = uint8 plane of the coded size, reconstructed at uniform partition level bs.  lib:
     another build of the reference (the x86-intrinsics one) instead of oracle/_ref's default.
     fpr_bits = 8 / 10 / 12: full-precision references - pictures of that depth, planes of
     int16 samples at 12 bits, the reference's xstride-2 conversions (recon is uint16).
     inter_pred = [Y, Cb, Cr] prediction pictures: an INTER frame - every plane through
-    pvq_theta with is_keyframe = 0 against the pyramid of its prediction."""
+    pvq_theta with is_keyframe = 0 against the pyramid of its prediction.
+    decisions: a list that receives, per plane, [(y, band)] per level - what pvq_theta decided
+    for every band of every block (ref_stage_set_dump: y int32 [blocks][len] = the pulse
+    vectors in coding order, band int32 [blocks][nb][4] = {coded gain index (the return
+    value), itheta, max_theta, k}), blocks in raster order."""
     r = lib if lib is not None else ref()
     r.ref_set_fpr(1 if fpr_bits else 0)
     r.ref_stage_set_inter(1 if inter_pred is not None else 0)
     try:
-        return _cpu_frame(r, qt, pics, pic_w, pic_h, chroma_cfl, lam, fpr_bits, inter_pred)
+        return _cpu_frame(r, qt, pics, pic_w, pic_h, chroma_cfl, lam, fpr_bits, inter_pred, decisions)
     finally:
         r.ref_set_fpr(0)
         r.ref_stage_set_inter(0)
+        if decisions is not None:
+            r.ref_stage_set_dump(None, None)
 
 
 def _pad(px, pic, fpr_bits):
@@ -65,7 +74,7 @@ def _pad(px, pic, fpr_bits):
         oracle().odo_img_plane_copy_pad(P(px), w, w, h, P(pic), pic.shape[1], pic.shape[1], pic.shape[0])
 
 
-def _cpu_frame(r, qt, pics, pic_w, pic_h, chroma_cfl, lam, fpr_bits, inter_pred):
+def _cpu_frame(r, qt, pics, pic_w, pic_h, chroma_cfl, lam, fpr_bits, inter_pred, decisions=None):
     pdt = np.uint16 if fpr_bits else np.uint8
     assert r is not None, "oracle/_ref/libdaalaref.so not built"
     r.ref_stage_plane_levels.restype = ctypes.c_long
@@ -80,12 +89,24 @@ def _cpu_frame(r, qt, pics, pic_w, pic_h, chroma_cfl, lam, fpr_bits, inter_pred)
     for pli, dec in ((0, 0), (1, 1), (2, 1)):
         p = 1 if pli else 0
         h, w = H >> dec, W >> dec
-        qm_off, qb, bb = _tables(qt, p)
+        # the per-band steps are per PLANE: pvq_qm_q4[pli], Cb != Cr (src/encode.c:3052-3072)
+        qm_off, qb, bb = _tables(qt, pli)
         pic = np.ascontiguousarray(pics[pli])
         px = np.zeros((h, w), pdt)
         nlev = 5 - dec
         rec = [np.zeros((h, w), pdt) for _ in range(nlev)]
         rec_arr = (ctypes.c_void_p * 5)(*([a.ctypes.data for a in rec] + [None] * (5 - nlev)))
+        if decisions is not None:
+            dump = []
+            for bs in range(nlev):
+                n = 4 << bs
+                nblk = (h // n) * (w // n)
+                dump.append((np.zeros((nblk, min(n * n, 512)), np.int32), np.zeros((nblk, NBANDS[bs], 4), np.int32)))
+            # the shim keeps these two pointer tables until ref_stage_set_dump(NULL, NULL)
+            ytab = (ctypes.c_void_p * 5)(*([d[0].ctypes.data for d in dump] + [None] * (5 - nlev)))
+            btab = (ctypes.c_void_p * 5)(*([d[1].ctypes.data for d in dump] + [None] * (5 - nlev)))
+            r.ref_stage_set_dump(ytab, btab)
+            decisions.append(dump)
         t0 = time.perf_counter()
         # od_img_plane_copy_pad is file-static in the reference's encode.c: the restatement
         # (pinned to the encoder's own padded input, tests/test_oracle_golden.py)
@@ -111,6 +132,8 @@ def _cpu_frame(r, qt, pics, pic_w, pic_h, chroma_cfl, lam, fpr_bits, inter_pred)
             blocks += r.ref_stage_plane_levels(P(px), w, w, h, 1, pic_w, pic_h, 1, P(qm), P(qmi), qm_off,
                                                qb, bb, ctypes.c_double(lam), rec_arr, None, None)
         busy += time.perf_counter() - t0
+        if decisions is not None:
+            r.ref_stage_set_dump(None, None)
         if pli == 0 and chroma_cfl:
             # od_resample_luma_coeffs for luma blocks one size up (src/intra.c:97-108: the
             # upper-left quarter of the decoded block), timed like the GPU's kernel
@@ -192,9 +215,10 @@ def gpu_priced_frame(D, qt, pics, pic_w, pic_h, chroma_cfl=True, lam=0.147, fram
 
 
 def gpu_device_priced(D, qt, pics, pic_w, pic_h, chroma_cfl=True, lam=0.147, frames=None, serial=False,
-                      steps=None, fpr_bits=0, inter_pred=None):
+                      steps=None, fpr_bits=0, inter_pred=None, decisions=False):
     """The F pictures through `steps` odhip_pipe_step calls (each codes all F) of a price=1
-    pipe.  Returns (recon like gpu_priced_frame(), bands the host libm re-decided)."""
+    pipe.  Returns (recon like gpu_priced_frame(), bands the host libm re-decided) and, with
+    decisions=True, gpu_decisions() of the last step as a third element."""
     F = frames or 1
     luma = np.ascontiguousarray(pics[0]).reshape(F, pic_h, pic_w)
     chroma = np.concatenate([np.ascontiguousarray(pics[1]).reshape(F, pic_h // 2, pic_w // 2),
@@ -217,9 +241,10 @@ def gpu_device_priced(D, qt, pics, pic_w, pic_h, chroma_cfl=True, lam=0.147, fra
         out = [[pipe.read(D.BUF_RECON, 0, bs, dtype=rdt).reshape(F, H, W) for bs in range(5)],
                [pipe.read(D.BUF_RECON, 1, bs, dtype=rdt).reshape(2 * F, H // 2, W // 2) for bs in range(4)]]
         reruns = pipe.price_reruns()
+        dec = gpu_decisions(D, pipe) if decisions else None
     finally:
         pipe.destroy()
-    return out, reruns
+    return (out, reruns, dec) if decisions else (out, reruns)
 
 
 def compare_frame(gpu, cpu, frame=0, frames=1):
@@ -234,3 +259,89 @@ def compare_frame(gpu, cpu, frame=0, frames=1):
             if d:
                 bad.append((pli, bs, d))
     return bad
+
+
+def gpu_decisions(D, pipe):
+    """What the pipe's last step decided for every band of every block, in the form
+    cpu_frame(decisions=...) hands back: {(set, level): (y int32 [B][len], band int32
+    [B][nb][4] = {coded gain index, itheta, max_theta, k}, coded bool [B][nb])}; `coded` =
+    the band's pulses are defined (not skipped).  Read from the choice records and the pulse
+    slot they name - the same fields the inverse stage consumes."""
+    out = {}
+    cfl = pipe.chroma_cfl
+    for set_ in (0, 1):
+        for bs in range(5 - set_):
+            nb, offs, ln = D.pvq_band_layout(bs)
+            B = pipe.nblocks(set_, bs)
+            with_ref = bool(set_ and cfl)
+            ych = np.zeros((B, ln), np.int32)
+            band = np.zeros((B, nb, 4), np.int32)
+            coded = np.zeros((B, nb), bool)
+            yall = pipe.read(D.BUF_Y, set_, bs, dtype=np.int16)
+            if with_ref:
+                ch = pipe.read(D.BUF_CHOICE, set_, bs, dtype=np.int32).reshape(B, nb, 16)
+                y = yall.reshape(-1, B, ln)
+                for i in range(nb):
+                    a, b = offs[i], offs[i + 1]
+                    noref = ch[:, i, 2]
+                    skip = ch[:, i, 6]
+                    slot = ch[:, i, 9]
+                    band[:, i, 0] = ch[:, i, 7]
+                    band[:, i, 1] = ch[:, i, 3]
+                    band[:, i, 2] = ch[:, i, 4]
+                    band[:, i, 3] = ch[:, i, 5]
+                    on = (skip == 0) & (slot >= 0)
+                    idx = np.nonzero(on)[0]
+                    v = y[slot[idx], idx, a:b].astype(np.int32)
+                    v[noref[idx] == 0, -1] = 0       # a theta winner holds n - 1 pulses
+                    ych[idx, a:b] = v
+                    coded[:, i] = skip == 0
+            else:
+                ch = pipe.read(D.BUF_CHOICE, set_, bs, dtype=np.int32).reshape(B, nb, 4)
+                rec = pipe.read(D.BUF_BAND, set_, bs).view(D.BAND_RECORD).reshape(B, nb)
+                y = yall.reshape(2, B, ln)
+                for i in range(nb):
+                    a, b = offs[i], offs[i + 1]
+                    sel = ch[:, i, 0]
+                    qg = ch[:, i, 1]
+                    band[:, i, 0] = qg            # keyframe, no reference: the gain index itself
+                    band[:, i, 1] = -1
+                    band[:, i, 2] = 0
+                    k = np.where(sel == 1, rec["k"][:, i, 1], rec["k"][:, i, 0]).astype(np.int32)
+                    band[:, i, 3] = np.where(qg != 0, k, 0)
+                    idx = np.nonzero(qg != 0)[0]
+                    ych[idx, a:b] = y[sel[idx], idx, a:b]
+                    coded[:, i] = True
+            out[(set_, bs)] = (ych, band, coded)
+    return out
+
+
+def compare_decisions(gpu, cpu, frame=0, frames=1):
+    """gpu: gpu_decisions(); cpu: the `decisions` list of cpu_frame() for picture `frame`.
+    Returns a list of (plane, level, what, count) mismatches; empty = every gain index,
+    theta, K and pulse vector equals the reference's."""
+    bad = []
+    for pli in range(3):
+        set_ = 1 if pli else 0
+        plane = frame if pli == 0 else (pli - 1) * frames + frame
+        for bs, (yc, bc) in enumerate(cpu[pli]):
+            yg, bg, coded = gpu[(set_, bs)]
+            per = yc.shape[0]
+            sl = slice(plane * per, (plane + 1) * per)
+            yg, bg, coded = yg[sl], bg[sl], coded[sl]
+            d = int(np.count_nonzero((bg != bc).any(axis=2)))
+            if d:
+                bad.append((pli, bs, "band", d))
+            nb, offs, _ = _layout(bs)
+            for i in range(nb):
+                a, b = offs[i], offs[i + 1]
+                on = coded[:, i]
+                d = int(np.count_nonzero((yg[on, a:b] != yc[on, a:b]).any(axis=1)))
+                if d:
+                    bad.append((pli, bs, "y[band %d]" % i, d))
+    return bad
+
+
+def _layout(bs):
+    import daala_amd as D
+    return D.pvq_band_layout(bs)

@@ -57,11 +57,24 @@ def test_1080p_pyramid_random_blocks_match_oracle(hip):
         assert np.array_equal(got[bs][0].cpu().numpy(), want[bs]), bs
 
 
-@pytest.mark.parametrize("n,k", [(16, 1), (16, 4), (16, 16), (15, 1), (8, 1), (128, 24)])
-def test_pvq_search_1m_bands_properties(hip, n, k):
-    """configs[3]: 1M random bands.  Properties of a PVQ codeword: sum |y| = k,
-    y_i*x_i >= 0 (a pulse may sit on a zero coefficient), 0 <= cos <= 1 (+rounding); and the
-    first 4096 bands bit-exact against the oracle."""
+def _oracle_search(xs, ks, gs, lam=0.147):
+    """pvq_search_rdo_double (src/pvq_encoder.c:93-224) band by band in the CPU oracle."""
+    m, n = xs.shape
+    yo = np.zeros((m, n), np.int32)
+    co = np.zeros(m)
+    oracle().odo_pvq_search_batch(P(np.ascontiguousarray(xs)), n, P(np.ascontiguousarray(ks)), P(yo),
+                                  P(np.ascontiguousarray(gs)), ctypes.c_double(lam), None, P(co),
+                                  ctypes.c_long(m))
+    return yo, co
+
+
+@pytest.mark.parametrize("n,k", [(16, 1), (16, 2), (16, 4), (16, 8), (16, 16), (15, 1), (8, 1), (128, 24)])
+def test_pvq_search_1m_bands_all_match_oracle(hip, n, k):
+    """configs[3]: 1M random bands (n = 16, x ~ U[-1000, 1000], k in
+    {1, 2, 4, 8, 16}, g2 = 1, lambda = 0.147, prev_k = 0; plus the two lengths
+    pvq_search_rdo_double special-cases at k = 1 and the longest band).  EVERY band: the
+    pulse vector exactly and the returned cosine as int64 bits, against the oracle; and the
+    properties of a PVQ codeword (sum |y| = k, no pulse opposes its coefficient)."""
     import torch
     nb = 1 << 20 if n <= 16 else 1 << 17
     g = torch.Generator(device="cuda").manual_seed(n * 131 + k)
@@ -73,16 +86,37 @@ def test_pvq_search_1m_bands_properties(hip, n, k):
     assert torch.equal(y.abs().sum(1)[nz], kk[nz].long() if y.dtype == torch.int64 else kk[nz])
     assert bool((y.long()*x.long() >= 0).all()), "a pulse never opposes the sign of its coefficient"
     assert float(cos.min()) >= 0.0 and float(cos.max()) <= 1.0 + 1e-12
-    m = 4096
-    xs = x[:m].cpu().numpy()
-    ks = kk[:m].cpu().numpy()
-    gs = g2[:m].cpu().numpy()
-    yo = np.zeros((m, n), np.int32)
-    co = np.zeros(m)
-    oracle().odo_pvq_search_batch(P(xs), n, P(ks), P(yo), P(gs), ctypes.c_double(0.147), None,
-                                  P(co), ctypes.c_long(m))
-    assert np.array_equal(y[:m].cpu().numpy(), yo)
-    assert np.array_equal(cos[:m].cpu().numpy().view(np.int64), co.view(np.int64))
+    yo, co = _oracle_search(x.cpu().numpy(), kk.cpu().numpy(), g2.cpu().numpy())
+    assert np.array_equal(y.cpu().numpy(), yo)
+    assert np.array_equal(cos.cpu().numpy().view(np.int64), co.view(np.int64))
+
+
+def test_pvq_search_1m_laplacian_bands_empirical_k_all_match_oracle(hip):
+    """SURVEY 8(d) C4's second set: 1M bands, n = 16, Laplacian x (scale 200), K drawn from
+    the pulse counts the encoder really asks for (tests/golden/k_hist.npz: the histogram of K
+    over every search of the configs[1] frame, dumped by tools/k_hist.py; geometric fallback
+    with a similar mean when the fixture is absent), g2 from the band's own energy.  Every
+    band: pulses exact, cosine bit for bit."""
+    import os
+    import torch
+    nb, n = 1 << 20, 16
+    rng = np.random.RandomState(77)
+    x = np.clip(np.rint(rng.laplace(scale=200.0, size=(nb, n))), -32000, 32000).astype(np.int16)
+    x[::4097] = 0                                   # all-zero bands take the early return
+    fix = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "k_hist.npz")
+    if os.path.exists(fix):
+        h = np.load(fix)["hist"].astype(np.float64)
+        ks = rng.choice(len(h), size=nb, p=h / h.sum()).astype(np.int32)
+    else:
+        ks = np.minimum(rng.geometric(1.0 / 6.0, size=nb), 350).astype(np.int32)
+    ks[:64] = np.arange(64, dtype=np.int32)         # k = 0 .. 63 each at least once
+    g2 = (x.astype(np.float64) ** 2).sum(1) / 4096.0 + 1e-3
+    y, cos = hip.pvq_search_batch(torch.from_numpy(x).cuda(), torch.from_numpy(ks).cuda(),
+                                  torch.from_numpy(g2).cuda(), 0.147)
+    yo, co = _oracle_search(x, ks, g2)
+    assert np.array_equal(y.cpu().numpy(), yo)
+    got = cos.cpu().numpy().view(np.int64)
+    assert np.array_equal(got, co.view(np.int64))
 
 
 def test_ragged_and_minimum_sizes(hip):

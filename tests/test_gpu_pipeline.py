@@ -108,10 +108,16 @@ def test_device_priced_steps_equal_compiled_reference_1080p(content):
     F = 2
     fr = [b.picture_planes(b.CONTENT[content](3 + i, 4321)) for i in range(F)]
     pics = [np.stack([f[p] for f in fr]) for p in range(3)]
-    gpu, reruns = C.gpu_device_priced(D, qt, pics, PIC_W, PIC_H, chroma_cfl=True, frames=F, steps=3)
+    gpu, reruns, dec = C.gpu_device_priced(D, qt, pics, PIC_W, PIC_H, chroma_cfl=True, frames=F, steps=3,
+                                           decisions=True)
     for i in range(F):
-        cpu, _, _ = C.cpu_frame(qt, fr[i], PIC_W, PIC_H, chroma_cfl=True)
+        want = []
+        cpu, _, _ = C.cpu_frame(qt, fr[i], PIC_W, PIC_H, chroma_cfl=True, decisions=want)
         assert C.compare_frame(gpu, cpu, frame=i, frames=F) == [], (content, i)
+        # north_star's "coefficients and PVQ pulse vectors": the coded gain index, itheta,
+        # max_theta, K and the pulse vector of EVERY band of every block of every level of the
+        # whole frame (Y, Cb, Cr) against the reference's pvq_theta (src/pvq_encoder.c:333-641)
+        assert C.compare_decisions(dec, want, frame=i, frames=F) == [], (content, i)
     print("%s: %d priced decisions left to the host libm in 3 steps of %d frames" % (content, reruns, F))
 
 
