@@ -818,6 +818,22 @@ def pvq_ref_choose_priced_multi(jobs, pvq_norm_lambda, fused_bands=False):
                      "odhip_pvq_ref_choose_priced_resolve")
 
 
+def pvq_ref_bands_decided_multi(jobs, pvq_norm_lambda):
+    """The with-reference band stage with the priced choice of every band made inside its
+    search (odhip_pvq_ref_bands_decided_multi), followed by the two resolves.  Leaves the
+    choice records and, in slot 0 of each job's y, the winners' pulse vectors.  Returns
+    (bands re-run with the host's theta, bands re-decided with the host libm)."""
+    arr = _refjobs_array(jobs)
+    lam = ctypes.c_double(pvq_norm_lambda)
+    L = lib()
+    _check(L.odhip_pvq_ref_bands_decided_multi(arr, len(jobs), lam, _stream()),
+           "odhip_pvq_ref_bands_decided_multi")
+    n = _resolved(L.odhip_pvq_ref_resolve_finish(arr, len(jobs), lam, _stream()), "odhip_pvq_ref_resolve_finish")
+    m = _resolved(L.odhip_pvq_ref_choose_priced_resolve(arr, len(jobs), lam, _stream()),
+                  "odhip_pvq_ref_choose_priced_resolve")
+    return n, m
+
+
 def inverse_levels_pvq_ref(jobs, dec, pic_w, pic_h, outs=None):
     """Inverse of several partition levels of one plane set fed by the with-reference
     band stage: dequantise-on-load from the chosen candidates (no dequantised plane)."""

@@ -238,30 +238,58 @@ __device__ __forceinline__ int odq_compute_k_ref(int itheta, int n) {
    choice kernels and the HOST libm's log where flagged bands are re-decided - the two
    may differ in the last place, which is why a choice whose costs come within
    ODQ_RATE_TOL of each other is never taken from the device (see k_choose). */
-#define ODQ_RATE_BODY(LOGFN, DIV) \
-  double rate; \
-  if (k == 0) rate = 0; \
-  else { \
-    const double f = DIV((double)sum, (double)(k*n)); \
-    const double a = DIV(LOGFN(((double)(n*2))*(f + .025))*k, (double)n); \
-    rate = ((1 + .4*f)*n)*(1.4426950408889634073599246810019*LOGFN(1 + (0 > a ? 0 : a))) + 3; \
-  } \
-  if (qg > 0 && theta >= 0) { \
-    rate += .9*(1.4426950408889634073599246810019*LOGFN((double)ts)); \
-    if (is_keyframe && pli == 0) rate += 6; \
-    if (qg == icgr) rate -= .5; \
-  } \
+/* Two halves: the part that depends on the pulses alone (one value per SEARCH: candidates
+   that share a pulse vector share it) and the theta terms of the candidate; the sum is
+   formed in the reference's order, so pricing a candidate from a cached pulse part gives
+   the very double odq_pvq_rate_fast returns. */
+#define ODQ_RATE_PULSES_BODY(LOGFN, DIV) \
+  if (k == 0) return 0; \
+  const double f = DIV((double)sum, (double)(k*n)); \
+  const double a = DIV(LOGFN(((double)(n*2))*(f + .025))*k, (double)n); \
+  return ((1 + .4*f)*n)*(1.4426950408889634073599246810019*LOGFN(1 + (0 > a ? 0 : a))) + 3;
+
+/* .9*log2(ts), :278 */
+#define ODQ_RATE_TS_BODY(LOGFN) \
+  return .9*(1.4426950408889634073599246810019*LOGFN((double)ts));
+
+__device__ __forceinline__ double odq_pvq_rate_pulses(int sum, int k, int n) {
+  ODQ_RATE_PULSES_BODY(log, __ddiv_rn)
+}
+
+__device__ __forceinline__ double odq_pvq_rate_ts(int ts) {
+  ODQ_RATE_TS_BODY(log)
+}
+
+/* rate of a candidate from its two halves (ts_term is read only for a theta candidate
+   with qg > 0) */
+__host__ __device__ static inline double odq_pvq_rate_join(double pulses, double ts_term, int qg, int icgr,
+ int theta, int is_keyframe, int pli) {
+  double rate = pulses;
+  if (qg > 0 && theta >= 0) {
+    rate += ts_term;
+    if (is_keyframe && pli == 0) rate += 6;
+    if (qg == icgr) rate -= .5;
+  }
   return rate;
+}
 
 __device__ __forceinline__ double odq_pvq_rate_fast(int sum, int k, int n, int qg, int icgr, int theta,
  int ts, int is_keyframe, int pli) {
-  ODQ_RATE_BODY(log, __ddiv_rn)
+  return odq_pvq_rate_join(odq_pvq_rate_pulses(sum, k, n), qg > 0 && theta >= 0 ? odq_pvq_rate_ts(ts) : 0.,
+   qg, icgr, theta, is_keyframe, pli);
 }
 
 static inline double odq_host_div(double a, double b) { return a/b; }
+static inline double odq_pvq_rate_pulses_host(int sum, int k, int n) {
+  ODQ_RATE_PULSES_BODY(log, odq_host_div)
+}
+static inline double odq_pvq_rate_ts_host(int ts) {
+  ODQ_RATE_TS_BODY(log)
+}
 static inline double odq_pvq_rate_fast_host(int sum, int k, int n, int qg, int icgr, int theta, int ts,
  int is_keyframe, int pli) {
-  ODQ_RATE_BODY(log, odq_host_div)
+  return odq_pvq_rate_join(odq_pvq_rate_pulses_host(sum, k, n),
+   qg > 0 && theta >= 0 ? odq_pvq_rate_ts_host(ts) : 0., qg, icgr, theta, is_keyframe, pli);
 }
 
 /* |cost_a - cost_b| at or below this is "too close to call on the device". */

@@ -27,6 +27,15 @@ __device__ __forceinline__ void od_inc(int &j) {
   asm("v_add_u32 %0, 1, %0" : "+v"(j));
 }
 
+/* (double)v for a non-negative int, spelled so that the compiler cannot hoist it out of a
+   loop: the searches convert |x_j| where they use it - a double copy of the band kept across
+   the pulse loops costs two VGPRs per coefficient and an occupancy step. */
+__device__ __forceinline__ double od_cvt_u(int v) {
+  double d;
+  asm volatile("v_cvt_f64_u32_e32 %0, %1" : "=v"(d) : "v"(v));
+  return d;
+}
+
 __device__ __forceinline__ double od_sel(unsigned long long m, double t, double f) {
   const int lo = od_sel(m, __double2loint(t), __double2loint(f));
   const int hi = od_sel(m, __double2hiint(t), __double2hiint(f));

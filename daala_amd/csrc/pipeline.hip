@@ -403,20 +403,15 @@ int stage_inverse_noref(odhip_pipe *p, int si, hipStream_t s) {
    p->pic_w, p->pic_h, s);
 }
 
-/* rerun: the band stage of some bands was repeated with the host's theta - every band is
-   decided again from the candidate records; otherwise, with pricing, only the bands the band
-   stage did not decide itself (odhip_pvq_ref_bands_priced_multi). */
-int chroma_tail(odhip_pipe *p, int par, hipStream_t s, bool rerun = false) {
+/* Choice (only when the host prices or nobody does: with cfg.price the band stage decided
+   every band itself, odhip_pvq_ref_bands_decided_multi) and the inverse. */
+int chroma_tail(odhip_pipe *p, int par, hipStream_t s) {
   PlaneSet &ch = p->set[1];
   const double lam = p->cfg.pvq_norm_lambda;
-  int rc;
-  {
+  if (!p->cfg.price) {
     Timed tm(p, ODHIP_PIPE_CHOOSE_CHROMA, s);
-    rc = !p->cfg.price ? odhip_pvq_ref_choose_multi(p->refjobs[par], 4, lam, s)
-     : rerun ? odhip_pvq_ref_choose_priced_multi(p->refjobs[par], 4, lam, s)
-     : odhip_pvq_ref_choose_priced_rest_multi(p->refjobs[par], 4, lam, s);
+    STEP_TRY(odhip_pvq_ref_choose_multi(p->refjobs[par], 4, lam, s));
   }
-  if (rc) return rc;
   Timed tm(p, ODHIP_PIPE_INVERSE_CHROMA, s);
   return odhip_inverse_levels_pvq_ref(ch.recon, ch.w, (long)ch.w*ch.h, p->refjobs[par], 4, 1, p->pic_w,
    p->pic_h, s);
@@ -432,31 +427,26 @@ int finish_pending(odhip_pipe *p) {
   p->pending = -1;
   Current cur(p->ctx[1]);
   const auto t0 = std::chrono::steady_clock::now();
+  /* with cfg.price a band re-run with the host's theta is also decided again by the resolve */
   const int n = odhip_pvq_ref_resolve_finish(p->refjobs[par], 4, p->cfg.pvq_norm_lambda, p->stream[1]);
   p->wait_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   if (n < 0) return n;
-  if (n > 0) {
-    p->reruns += n;
-    STEP_TRY(chroma_tail(p, par, p->stream[1], true));
-    /* the re-run reads refs[par] again: the luma chain must not overwrite it before */
-    ODHIP_TRY(hipEventRecord(p->ev_used[par], p->stream[1]));
-  }
+  int m = 0;
   if (p->cfg.price) {
-    /* the chroma choices of that step: listed bands are re-decided with the host libm and
-       the inverse that consumed them runs again (the buffers are intact until the next
-       chroma chain is enqueued, below) */
+    /* the chroma choices of that step: listed bands are re-decided with the host libm */
     const auto t1 = std::chrono::steady_clock::now();
-    const int m = odhip_pvq_ref_choose_priced_resolve(p->refjobs[par], 4, p->cfg.pvq_norm_lambda,
-     p->stream[1]);
+    m = odhip_pvq_ref_choose_priced_resolve(p->refjobs[par], 4, p->cfg.pvq_norm_lambda, p->stream[1]);
     p->wait_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count();
     if (m < 0) return m;
-    if (m > 0) {
-      p->price_reruns += m;
-      PlaneSet &ch = p->set[1];
-      STEP_TRY(odhip_inverse_levels_pvq_ref(ch.recon, ch.w, (long)ch.w*ch.h, p->refjobs[par], 4, 1, p->pic_w,
-       p->pic_h, p->stream[1]));
-      ODHIP_TRY(hipEventRecord(p->ev_used[par], p->stream[1]));
-    }
+  }
+  p->reruns += n;
+  p->price_reruns += m;
+  if (n > 0 || m > 0) {
+    /* what consumed the choices runs again (the buffers are intact until the next chroma
+       chain is enqueued, below); it reads refs[par] again: the luma chain must not overwrite
+       that buffer before */
+    STEP_TRY(chroma_tail(p, par, p->stream[1]));
+    ODHIP_TRY(hipEventRecord(p->ev_used[par], p->stream[1]));
   }
   return ODHIP_SUCCESS;
 }
@@ -499,28 +489,28 @@ int luma_choose(odhip_pipe *p, hipStream_t s) {
 
 int luma_refs(odhip_pipe *p, int par, hipStream_t s) {
   Timed tm(p, ODHIP_PIPE_CFL_REFS, s);
-  return odhip_cfl_refs_from_luma(p->jobs + 1, 4, p->refs[par], 2, s);
+  /* (the reference buffers were cleared when the pipe was made and have no other writer) */
+  return odhip_cfl_refs_from_luma_ex(p->jobs + 1, 4, p->refs[par], 2, 1, s);
 }
 
 int chroma_bands(odhip_pipe *p, int par, hipStream_t s) {
   Timed tm(p, ODHIP_PIPE_BANDS_CHROMA, s);
-  STEP_TRY(p->cfg.price ? odhip_pvq_ref_bands_priced_multi(p->refjobs[par], 4, p->cfg.pvq_norm_lambda, s)
-   : odhip_pvq_ref_bands_multi(p->refjobs[par], 4, p->cfg.pvq_norm_lambda, s));
+  /* (the decided stage sends its two counts itself) */
+  if (p->cfg.price) return odhip_pvq_ref_bands_decided_multi(p->refjobs[par], 4, p->cfg.pvq_norm_lambda, s);
+  STEP_TRY(odhip_pvq_ref_bands_multi(p->refjobs[par], 4, p->cfg.pvq_norm_lambda, s));
   return odhip_pvq_ref_resolve_begin(s);
 }
 
 /* ---- inter mode: both plane sets through the with-reference stage against the pyramid of
    their prediction pictures (pvq_theta with is_keyframe = 0, src/encode.c:1326-1360); the two
    chains are independent, each in its own context on its own stream. */
-int inter_tail(odhip_pipe *p, int si, hipStream_t s, bool rerun) {
+int inter_tail(odhip_pipe *p, int si, hipStream_t s) {
   PlaneSet &t = p->set[si];
   const double lam = p->cfg.pvq_norm_lambda;
   odhip_pvq_refjob *jobs = p->interjobs[si];
-  {
+  if (!p->cfg.price) {
     Timed tm(p, si ? ODHIP_PIPE_CHOOSE_CHROMA : ODHIP_PIPE_CHOOSE_LUMA, s);
-    STEP_TRY(!p->cfg.price ? odhip_pvq_ref_choose_multi(jobs, t.nlev, lam, s)
-     : rerun ? odhip_pvq_ref_choose_priced_multi(jobs, t.nlev, lam, s)
-     : odhip_pvq_ref_choose_priced_rest_multi(jobs, t.nlev, lam, s));
+    STEP_TRY(odhip_pvq_ref_choose_multi(jobs, t.nlev, lam, s));
   }
   Timed tm(p, si ? ODHIP_PIPE_INVERSE_CHROMA : ODHIP_PIPE_INVERSE_LUMA, s);
   return odhip_inverse_levels_pvq_ref(t.recon, t.w, (long)t.w*t.h, jobs, t.nlev, t.dec, p->pic_w, p->pic_h, s);
@@ -537,19 +527,14 @@ int inter_finish(odhip_pipe *p, int si) {
   const auto t0 = std::chrono::steady_clock::now();
   const int n = odhip_pvq_ref_resolve_finish(p->interjobs[si], t.nlev, lam, s);
   if (n < 0) return n;
-  if (n > 0) {
-    p->reruns += n;
-    STEP_TRY(inter_tail(p, si, s, true));
-  }
+  int m = 0;
   if (p->cfg.price) {
-    const int m = odhip_pvq_ref_choose_priced_resolve(p->interjobs[si], t.nlev, lam, s);
+    m = odhip_pvq_ref_choose_priced_resolve(p->interjobs[si], t.nlev, lam, s);
     if (m < 0) return m;
-    if (m > 0) {
-      p->price_reruns += m;
-      STEP_TRY(odhip_inverse_levels_pvq_ref(t.recon, t.w, (long)t.w*t.h, p->interjobs[si], t.nlev, t.dec,
-       p->pic_w, p->pic_h, s));
-    }
   }
+  p->reruns += n;
+  p->price_reruns += m;
+  if (n > 0 || m > 0) STEP_TRY(inter_tail(p, si, s));
   p->wait_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   return ODHIP_SUCCESS;
 }
@@ -580,11 +565,13 @@ int inter_chain(odhip_pipe *p, int si) {
   }
   {
     Timed tm(p, si ? ODHIP_PIPE_BANDS_CHROMA : ODHIP_PIPE_BANDS_LUMA, s);
-    STEP_TRY(p->cfg.price ? odhip_pvq_ref_bands_priced_multi(p->interjobs[si], t.nlev, lam, s)
-     : odhip_pvq_ref_bands_multi(p->interjobs[si], t.nlev, lam, s));
-    STEP_TRY(odhip_pvq_ref_resolve_begin(s));
+    if (p->cfg.price) STEP_TRY(odhip_pvq_ref_bands_decided_multi(p->interjobs[si], t.nlev, lam, s));
+    else {
+      STEP_TRY(odhip_pvq_ref_bands_multi(p->interjobs[si], t.nlev, lam, s));
+      STEP_TRY(odhip_pvq_ref_resolve_begin(s));
+    }
   }
-  STEP_TRY(inter_tail(p, si, s, false));
+  STEP_TRY(inter_tail(p, si, s));
   p->inter_pending[si] = true;
   return ODHIP_SUCCESS;
 }
@@ -822,17 +809,15 @@ extern "C" int odhip_pipe_stage(odhip_pipe *p, int stage, int parity) {
     }
     case ODHIP_PIPE_CHOOSE_CHROMA: {
       if (!cfl) return ODHIP_SUCCESS;
-      {
-        Timed tm(p, stage, s);
-        STEP_TRY(p->cfg.price ? odhip_pvq_ref_choose_priced_multi(p->refjobs[parity], 4, lam, s)
-         : odhip_pvq_ref_choose_multi(p->refjobs[parity], 4, lam, s));
-      }
       if (p->cfg.price) {
+        /* the band stage decided; what is left is the host-libm resolve of listed bands */
         const int m = odhip_pvq_ref_choose_priced_resolve(p->refjobs[parity], 4, lam, s);
         if (m < 0) return m;
         p->price_reruns += m;
+        return ODHIP_SUCCESS;
       }
-      return ODHIP_SUCCESS;
+      Timed tm(p, stage, s);
+      return odhip_pvq_ref_choose_multi(p->refjobs[parity], 4, lam, s);
     }
     case ODHIP_PIPE_INVERSE_CHROMA: {
       if (!cfl) return stage_inverse_noref(p, 1, s);

@@ -1126,6 +1126,7 @@ struct BandState {
   hipEvent_t fork = nullptr;
   hipEvent_t join[2] = {nullptr, nullptr};
   bool serial = false;             /* the context's setting, refreshed per call    */
+  bool sort_dirty = false;         /* the sort histograms may hold counts of a failed call */
   bool prof_on = false;            /* odhip_pvq_profile                            */
   bool prof_made = false;
   int prof_n = 0;
@@ -1492,13 +1493,16 @@ int noref_bands(const odhip_pvq_job *jobs, int njobs, double pvq_norm_lambda, od
       items_add(all, j, b, 1);
     }
   }
-  {
-    /* the histograms are consumed and cleared by k_prefix; clear them here as
-       well so that a call that failed half way cannot poison the next sort */
+  /* the histograms are consumed and cleared by k_prefix; only a call that failed between
+     the two leaves them dirty */
+  if (st.sort_dirty) {
     ODHIP_TRY(hipMemsetAsync(st.d_sort, 0, sizeof(unsigned)*kMaxItems*kKeyBins, s));
+    st.sort_dirty = false;
   }
+  st.sort_dirty = true;
   k_hist<<<it.wg_start[it.nitems], 256, 0, s>>>(it);
   k_prefix<<<all.nitems, 256, 0, s>>>(all);
+  st.sort_dirty = odhip_check_launch() != ODHIP_SUCCESS;
   k_scatter<<<it.wg_start[it.nitems], 256, 0, s>>>(it);
   /* search: the band sizes are independent launches on forked streams */
   if (fork_streams(st, s, side) != ODHIP_SUCCESS) return ODHIP_EFAULT;
@@ -1678,6 +1682,11 @@ extern "C" void odhip_pvq_price_set_tol_scale(double scale) {
 
 extern "C" int odhip_cfl_refs_from_luma(const odhip_pvq_job *luma_jobs, int njobs,
  od_coeff *const *d_ref, int copies, odhip_stream stream) {
+  return odhip_cfl_refs_from_luma_ex(luma_jobs, njobs, d_ref, copies, 0, stream);
+}
+
+extern "C" int odhip_cfl_refs_from_luma_ex(const odhip_pvq_job *luma_jobs, int njobs,
+ od_coeff *const *d_ref, int copies, int prezeroed, odhip_stream stream) {
   BandState *stp;
   {
     const int rc0 = band_state(&stp);
@@ -1703,7 +1712,7 @@ extern "C" int odhip_cfl_refs_from_luma(const odhip_pvq_job *luma_jobs, int njob
       const int n = 2 << host[j].bs;
       const int ncode = n*n < host[j].len ? n*n : host[j].len;
       items_add(it, j, 0, (host[j].nblocks*(ncode >> 3) + 255)/256);
-      if (n*n > ncode) {
+      if (n*n > ncode && !prezeroed) {
         /* 64x64 luma blocks: half of the 32x32 corner is not coded */
         ODHIP_TRY(hipMemsetAsync(d_ref[j], 0, sizeof(od_coeff)*(size_t)copies*host[j].nplanes
          *(host[j].w >> 1)*(host[j].h >> 1), s));

@@ -246,6 +246,75 @@ __device__ __forceinline__ void householder_consts(int32_t l2r, int32_t proj, in
   *outshift = os > 30 ? 30 : os;
 }
 
+
+/* ---- sorting the bands of an item by work -----------------------------------------
+   The cost of a band is the number of pulses its chains place, which spans
+   0..hundreds within one level, and a wavefront (64 bands, or 4 rows) runs as
+   long as its slowest member.  Every band is classified (kSortBins classes, heavy
+   first); a counting sort per (job, band) item - LDS histogram per chunk of blocks,
+   one global atomic per non-empty class per chunk - yields the block order the
+   searches walk. */
+constexpr int kSortBins = 256;
+constexpr int kSortChunk = 2048;
+
+__device__ __forceinline__ int od_work_bin(int pulses) {   /* 0..kSortBins-1, monotone */
+  if (pulses < 96) return pulses;
+  const int b = 96 + ((pulses - 96) >> 3);
+  return b < kSortBins ? b : kSortBins - 1;
+}
+
+/* The candidates of a band in the reference's ENUMERATION order (src/pvq_encoder.c:466-504,
+   then :571-581), handed to a sink:
+     sink.gain(gi, i, ts, lower)   gain index i = gain_bound - 1 + gi (gi = 0..2) is about to
+                                   be enumerated: its angular resolution and first angle
+     sink.theta(gi, i, j, ts, k)   one (gain, theta) candidate with its pulse count
+     sink.noref(c, i, k)           no-reference candidate c = 0 / 1
+   At most kSlots - 2 theta candidates, as refb_candidates keeps. */
+template <class Sink>
+__device__ __forceinline__ void refb_enumerate(const RJob &jb, int band, int32_t cg, int32_t gain_offset,
+ int32_t theta, int flags, double corr, Sink &sink) {
+  const int n = jb.off[band + 1] - jb.off[band];
+  const int beta = jb.beta[band];
+  if (flags & ODHIP_REFBAND_THETA) {
+    int nth = 0;
+    const int gain_bound = (cg - gain_offset) >> ODQ_CGAIN_SHIFT;
+    const double scale_1 = __ddiv_rn(1., kThetaScale);   /* OD_THETA_SCALE_1 */
+    for (int i = gain_bound - 1 > 1 ? gain_bound - 1 : 1; i <= gain_bound + 1; i++) {
+      const int32_t qcg = odq_shl32(i, ODQ_CGAIN_SHIFT) + gain_offset;
+      const int ts = odq_pvq_compute_max_theta(qcg, beta);
+      /* same left-to-right products as src/pvq_encoder.c:482-484 */
+      const double t = __ddiv_rn(((theta*scale_1)*2), kPi)*ts;
+      int lower = (int)floor(.5 + t) - 2;
+      if (lower < 0) lower = 0;
+      int upper = (int)ceil(t);
+      if (upper > ts - 1) upper = ts - 1;
+      const int gi = i - (gain_bound - 1);
+      sink.gain(gi, i, ts, lower);
+      for (int j = lower; j <= upper && nth < ODHIP_PVQ_REF_SLOTS - 2; j++) {
+        sink.theta(gi, i, j, ts, odq_compute_k_ref(j, n));
+        nth++;
+      }
+    }
+  }
+  /* src/pvq_encoder.c:571-581 */
+  if ((jb.is_keyframe && jb.pli == 0) || corr < .5 || cg < odq_shl32(2, ODQ_CGAIN_SHIFT)) {
+    const int gain_bound = cg >> ODQ_CGAIN_SHIFT;
+    int c = 0;
+    for (int i = gain_bound > 1 ? gain_bound : 1; i <= gain_bound + 1; i++) {
+      sink.noref(c++, i, odq_compute_k_noref(odq_shl32(i, ODQ_CGAIN_SHIFT), n, beta));
+    }
+  }
+}
+
+/* The work class of a band: its chains place about kmax pulses. */
+struct KeySink {
+  int kt = 0;
+  int kn = 0;
+  __device__ __forceinline__ void gain(int, int, int, int) {}
+  __device__ __forceinline__ void theta(int, int, int, int, int k) { kt = k > kt ? k : kt; }
+  __device__ __forceinline__ void noref(int, int, int k) { kn = k > kn ? k : kn; }
+};
+
 /* Record of the band, theta with the device acos and the uncertainty list
    (one lane per band). */
 __device__ __forceinline__ void prep_write(const RItems &it, odhip_pvq_refband *rec, int job, int band,
@@ -289,6 +358,13 @@ __device__ __forceinline__ void prep_write(const RItems &it, odhip_pvq_refband *
   o.corr = p.corr;
   o.dist0 = p.dist0;
   *rec = o;
+  if (it.fuse == 2) {
+    /* the decided stage has no candidate kernel: the work class comes from here */
+    const RJob &jb = it.jobs[job];
+    KeySink ks;
+    refb_enumerate(jb, band, o.cg, o.gain_offset, o.theta, flags, o.corr, ks);
+    jb.keys[(long)band*jb.nblocks + blk] = (unsigned short)(kSortBins - 1 - od_work_bin(ks.kt + ks.kn));
+  }
 }
 
 __device__ __forceinline__ uint32_t pack16(int lo, int hi) {
@@ -701,22 +777,6 @@ __device__ __forceinline__ ItemPtr item_ptr(const RJob &jb, int band, long blk) 
   p.res = p.tail + plane;
   p.stride = jb.nblocks;
   return p;
-}
-
-/* ---- sorting the bands of an item by work -----------------------------------------
-   The cost of a band is the number of pulses its chains place, which spans
-   0..hundreds within one level, and a wavefront (64 bands, or 4 rows) runs as
-   long as its slowest member.  The candidate kernel classifies every band
-   (kSortBins classes, heavy first); a counting sort per (job, band) item - LDS
-   histogram per chunk of blocks, one global atomic per non-empty class per
-   chunk - yields the block order the searches walk. */
-constexpr int kSortBins = 256;
-constexpr int kSortChunk = 2048;
-
-__device__ __forceinline__ int od_work_bin(int pulses) {   /* 0..kSortBins-1, monotone */
-  if (pulses < 96) return pulses;
-  const int b = 96 + ((pulses - 96) >> 3);
-  return b < kSortBins ? b : kSortBins - 1;
 }
 
 
@@ -1557,6 +1617,474 @@ __global__ __launch_bounds__(kWave) void k_refb_search_regs(RItems it) {
   }
 }
 
+
+/* ==== the DECIDED band stage (odhip_pvq_ref_bands_decided_multi) =========================
+   With od_pvq_rate's closed form the choice of a band needs nothing but the band itself, so
+   the searches make it and NOTHING per candidate ever reaches HBM: no candidate heads (the
+   lists are rebuilt in LDS by the kernel that walks them - round 2's candidate kernel wrote
+   0.33 GB of them per 16-frame step and the searches read them back one exposed latency per
+   candidate), no tail / result vectors, no pulse vector per searched candidate (1.76 GB per
+   launch of the 15-coefficient bands alone).  A band costs one 64-byte record and two
+   16/32-byte vectors in, one 64-byte choice record and the winner's pulses (slot 0 of the
+   job's pulse buffer) out.  The resolve paths (theta inside the acos margin, a priced
+   comparison inside the log margin: a handful of bands per 10^9) re-run their bands through
+   the exporting kernels above.
+
+   The pulse part of a candidate's rate is computed once per SEARCH (candidates that reuse a
+   pulse vector, :539-544, share it) and .9*log2(ts) once per gain index; both are the very
+   doubles odq_pvq_rate_fast forms, joined in its order. */
+constexpr int kLeanAux = 12;            /* per band: ts[3], lower[3], .9*log2(ts)[3] (two words each) */
+constexpr int kLeanWords = kSlots + kLeanAux;
+
+/* A band's candidate list in LDS: word s of the band at col[s*stride].  Theta candidate:
+   gi | min(k, 65535) << 2 | (j - lower[gi]) << 18 - the low 18 bits order by (k, gain) as
+   items_compare does (src/pvq_encoder.c:301-305); no-reference candidate: c | k << 2. */
+struct CandList {
+  uint32_t *col;
+  int stride;
+  int ntheta;
+  int nitems;
+  int gb1;       /* gain index of gi = 0 */
+  int gbn;       /* gain index of no-reference candidate 0 */
+};
+
+struct ListSink {
+  uint32_t *col;
+  int stride;
+  bool writer;
+  int n = 0;
+  int lower_cur = 0;
+  __device__ __forceinline__ void gain(int gi, int, int ts, int lower) {
+    lower_cur = lower;
+    if (!writer) return;
+    const double l = odq_pvq_rate_ts(ts);
+    col[(kSlots + gi)*stride] = (uint32_t)ts;
+    col[(kSlots + 3 + gi)*stride] = (uint32_t)lower;
+    col[(kSlots + 6 + 2*gi)*stride] = (uint32_t)__double2loint(l);
+    col[(kSlots + 7 + 2*gi)*stride] = (uint32_t)__double2hiint(l);
+  }
+  __device__ __forceinline__ void theta(int gi, int, int j, int, int k) {
+    const uint32_t c = (uint32_t)gi | (uint32_t)(k < 65535 ? k : 65535) << 2 | (uint32_t)(j - lower_cur) << 18;
+    /* stable insertion by (k, gain): glibc's qsort is a stable merge sort at this size */
+    int pos = n;
+    while (pos > 0) {
+      const uint32_t q = col[(pos - 1)*stride];
+      if ((q & 0x3ffffu) <= (c & 0x3ffffu)) break;
+      if (writer) col[pos*stride] = q;
+      pos--;
+    }
+    if (writer) col[pos*stride] = c;
+    n++;
+  }
+  __device__ __forceinline__ void noref(int c, int, int k) {
+    if (writer) col[n*stride] = (uint32_t)c | (uint32_t)(k < 65535 ? k : 65535) << 2;
+    n++;
+  }
+};
+
+/* Every lane that calls this computes the list (uniformly over a group that shares the
+   band); `writer` lanes store it. */
+__device__ __forceinline__ CandList refb_build_list(const RJob &jb, int band, const odhip_pvq_refband &r,
+ uint32_t *col, int stride, bool writer) {
+  ListSink sink;
+  sink.col = col;
+  sink.stride = stride;
+  sink.writer = writer;
+  CandList cl;
+  cl.col = col;
+  cl.stride = stride;
+  cl.gb1 = ((r.cg - r.gain_offset) >> ODQ_CGAIN_SHIFT) - 1;
+  const int gbn = r.cg >> ODQ_CGAIN_SHIFT;
+  cl.gbn = gbn > 1 ? gbn : 1;
+  /* the theta candidates first: ListSink::n is their count when the no-reference ones start */
+  struct Split {
+    ListSink &s;
+    int ntheta = -1;
+    __device__ __forceinline__ void gain(int gi, int i, int ts, int lower) { s.gain(gi, i, ts, lower); }
+    __device__ __forceinline__ void theta(int gi, int i, int j, int ts, int k) { s.theta(gi, i, j, ts, k); }
+    __device__ __forceinline__ void noref(int c, int i, int k) {
+      if (ntheta < 0) ntheta = s.n;
+      s.noref(c, i, k);
+    }
+  } split{sink};
+  refb_enumerate(jb, band, r.cg, r.gain_offset, r.theta, r.flags, r.corr, split);
+  cl.nitems = sink.n;
+  cl.ntheta = split.ntheta < 0 ? sink.n : split.ntheta;
+  return cl;
+}
+
+/* refb_loops without a single store: candidates from the LDS list, every searched
+   candidate offered to the decider with its rate halves. */
+template <class V, class D>
+__device__ __forceinline__ void refb_loops_lean(const RJob &jb, int band, long blk,
+ const odhip_pvq_refband &r, const CandList &cl, int nrate, double lambda, V &v, D &dec) {
+  const int off = jb.off[band];
+  const int n = jb.off[band + 1] - off;
+  const int len = jb.len;
+  const double s2 = (1./256)*(1./256);   /* OD_CGAIN_SCALE_2 */
+  const double t1 = 1./32768;            /* OD_TRIG_SCALE_1 */
+  const int32_t cg = r.cg;
+  const double dist0 = r.dist0;
+  if (cl.ntheta > 0) {
+    v.load(jb.xr + blk*len + off, true);
+    int prev_k = 0;
+    bool has = false;
+    double cos_dist = 0;
+    double prate = 0;
+    const int32_t theta = r.theta;
+    for (int idx = 0; idx < cl.ntheta; idx++) {
+      const uint32_t w = cl.col[idx*cl.stride];
+      const int gi = (int)(w & 3u);
+      const int k = (int)(w >> 2 & 0xffffu);
+      const int i = cl.gb1 + gi;
+      const int ts = (int)cl.col[(kSlots + gi)*cl.stride];
+      const int j = (int)cl.col[(kSlots + 3 + gi)*cl.stride] + (int)(w >> 18);
+      const int32_t qcg = odq_shl32(i, ODQ_CGAIN_SHIFT) + r.gain_offset;
+      const int32_t qtheta = odq_pvq_compute_theta(j, ts);
+      /* :526-531 */
+      double dist_theta = 2 - (2.*odq_pvq_cos(theta - qtheta))*t1;
+      double dist = (1.4*(qcg - cg))*(qcg - cg) + (qcg*(double)cg)*dist_theta;
+      dist *= s2;
+      if (dist > dist0 + 1.0*lambda && k != 0) continue;
+      /* pulses are kept in 16 bits: never searched or chosen (sorted by K: every later
+         candidate is skipped as well) */
+      if (k > ODHIP_PVQ_MAX_K) continue;
+      const double sin_prod = ((odq_pvq_sin(theta)*t1)*odq_pvq_sin(qtheta))*t1;
+      if (k == 0) {
+        cos_dist = 0;
+        has = false;
+        prate = 0;
+      }
+      else if (k != prev_k) {
+        cos_dist = v.search(n - 1, k, prev_k, ((qcg*(double)cg)*sin_prod)*s2, lambda);
+        has = true;
+        prate = odq_pvq_rate_pulses(v.moment(), k, nrate);
+      }
+      prev_k = k;
+      /* :548-552 */
+      dist_theta = 2 - (2.*odq_pvq_cos(theta - qtheta))*t1 + sin_prod*(2 - 2*cos_dist);
+      dist = (1.4*(qcg - cg))*(qcg - cg) + (qcg*(double)cg)*dist_theta;
+      dist *= s2;
+      const double lts = __hiloint2double((int)cl.col[(kSlots + 7 + 2*gi)*cl.stride],
+       (int)cl.col[(kSlots + 6 + 2*gi)*cl.stride]);
+      dec.offer(idx, true, i, j, ts, k, qtheta, dist, prate, lts, has, v);
+    }
+  }
+  if (cl.nitems > cl.ntheta) {
+    v.load(jb.x16 + blk*len + off, false);
+    int prev_k = 0;
+    for (int idx = cl.ntheta; idx < cl.nitems; idx++) {
+      const uint32_t w = cl.col[idx*cl.stride];
+      const int i = cl.gbn + (int)(w & 3u);
+      const int k = (int)(w >> 2 & 0xffffu);
+      const int32_t qcg = odq_shl32(i, ODQ_CGAIN_SHIFT);
+      /* :585-595 */
+      double dist = (1.4*(qcg - cg))*(qcg - cg);
+      dist *= s2;
+      if (dist > dist0 && k != 0) continue;
+      if (k > ODHIP_PVQ_MAX_K) continue;
+      const double cos_dist = v.search(n, k, prev_k, (qcg*(double)cg)*s2, lambda);
+      prev_k = k;
+      const double prate = odq_pvq_rate_pulses(v.moment(), k, nrate);
+      dist = (1.4*(qcg - cg))*(qcg - cg) + (qcg*(double)cg)*(2 - 2*cos_dist);
+      dist *= s2;
+      dec.offer(idx, false, i, -1, 0, k, 0, dist, prate, 0., true, v);
+    }
+  }
+}
+
+/* The running choice over NY pulses held by this lane (the whole band, or its E positions
+   of a band spread over a group): the reference's comparisons (`<` theta candidates, :559;
+   `<=` no-reference ones, :601) on cost = dist + lambda*rate.  Only the cost, the winner's
+   list index and its pulses are carried through the chain; everything else about the winner
+   is read back from the list at the end (lean_best). */
+template <int NY>
+struct LeanDecide {
+  double best_cost;
+  int chosen;              /* list index, -1 = the initial candidate */
+  bool close;              /* a comparison too close for the device's log */
+  int y[NY];
+  unsigned sg;
+  double lambda;
+  double tol_scale;
+  int icgr;
+  int is_keyframe;
+  int pli;
+  __device__ __forceinline__ void init(const odhip_pvq_refband &r, const RJob &jb, double lam, double tol) {
+    best_cost = r.dist0;       /* the initial candidate places no pulse: its rate is 0 */
+    chosen = -1;
+    close = false;
+    lambda = lam;
+    tol_scale = tol;
+    icgr = r.icgr;
+    is_keyframe = jb.is_keyframe;
+    pli = jb.pli;
+    sg = 0;
+#pragma unroll
+    for (int i = 0; i < NY; i++) y[i] = 0;
+  }
+  template <class V>
+  __device__ __forceinline__ void offer(int idx, bool with_ref, int i, int j, int ts, int k, int32_t qtheta,
+   double dist, double prate, double lts, bool has, const V &v) {
+    const double rate = odq_pvq_rate_join(prate, lts, i, with_ref ? icgr : 0, with_ref ? j : -1, is_keyframe,
+     pli);
+    const double cost = dist + lambda*rate;
+    const double d = cost - best_cost;
+    if ((d < 0 ? -d : d) <= tol_scale*odq_rate_tol(cost, best_cost)) close = true;
+    if (with_ref ? cost < best_cost : cost <= best_cost) {
+      best_cost = cost;
+      chosen = idx;
+      sg = v.sg;
+#pragma unroll
+      for (int e = 0; e < NY; e++) y[e] = has ? v.y[e] : 0;
+    }
+    (void)ts;
+    (void)k;
+    (void)qtheta;
+  }
+  __device__ __forceinline__ int signed_y(int e) const {
+    return (sg >> e) & 1 ? -y[e] : y[e];
+  }
+};
+
+/* RefBest of the winner, decoded from the list. */
+template <int NY>
+__device__ __forceinline__ RefBest lean_best(const LeanDecide<NY> &dec, const CandList &cl, int is_keyframe) {
+  RefBest b;
+  b.best_cost = dec.best_cost;
+  b.chosen = dec.chosen;
+  b.yslot = -1;
+  b.noref = is_keyframe ? 1 : 0;
+  b.qtheta = 0;
+  b.gain = b.theta = b.ts = b.k = 0;
+  b.close = dec.close;
+  if (dec.chosen >= 0) {
+    const uint32_t w = cl.col[dec.chosen*cl.stride];
+    b.k = (int)(w >> 2 & 0xffffu);
+    b.yslot = b.k > 0 ? 0 : -1;     /* the winner's pulses go to slot 0 */
+    if (dec.chosen < cl.ntheta) {
+      const int gi = (int)(w & 3u);
+      b.noref = 0;
+      b.gain = cl.gb1 + gi;
+      b.ts = (int)cl.col[(kSlots + gi)*cl.stride];
+      b.theta = (int)cl.col[(kSlots + 3 + gi)*cl.stride] + (int)(w >> 18);
+      b.qtheta = odq_pvq_compute_theta(b.theta, b.ts);
+    }
+    else {
+      b.noref = 1;
+      b.gain = cl.gbn + (int)(w & 3u);
+    }
+  }
+  return b;
+}
+
+template <int N>
+__global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(3))) void k_refb_lean_lane(RItems it) {
+  constexpr int SH = N == 15 ? 1 : 0;
+  __shared__ uint32_t s_list[kLeanWords*kWave];
+  od_rsqrt_init(threadIdx.x);
+  const int item = find_item(it, blockIdx.x);
+  const int job = it.job[item];
+  const RJob &jb = it.jobs[job];
+  const long pos = (long)(blockIdx.x - it.wg_start[item])*kWave + threadIdx.x;
+  if (pos >= jb.nblocks) return;
+  const int band = it.band[item];
+  const long blk = jb.ids[(long)band*jb.nblocks + pos];
+  const odhip_pvq_refband r = jb.rec[blk*jb.nb_bands + band];
+  const CandList cl = refb_build_list(jb, band, r, s_list + threadIdx.x, kWave, true);
+  RegVector<N> v;
+  LeanDecide<N> dec;
+  dec.init(r, jb, it.lambda, it.tol_scale);
+  refb_loops_lean(jb, band, blk, r, cl, N, it.lambda, v, dec);
+  const RefBest best = lean_best(dec, cl, jb.is_keyframe);
+  if (best.yslot >= 0) {
+    uint4 *p = reinterpret_cast<uint4 *>(jb.y + blk*jb.len + jb.off[band] - SH);
+    int t[N + SH];
+    if (SH) t[0] = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) t[i + SH] = dec.signed_y(i);
+#pragma unroll
+    for (int q = 0; q < (N + SH)/8; q++) {
+      p[q] = make_uint4(pack16(t[8*q], t[8*q + 1]), pack16(t[8*q + 2], t[8*q + 3]),
+       pack16(t[8*q + 4], t[8*q + 5]), pack16(t[8*q + 6], t[8*q + 7]));
+    }
+  }
+  refb_finish<N>(it, job, jb, band, blk, r, best, [&](int i) -> int { return dec.signed_y(i); });
+}
+
+/* One lane to the left within the group (0 into the group's first lane). */
+template <int G>
+__device__ __forceinline__ int grp_from_prev(int v, int l) {
+  if (G == 16) return __builtin_amdgcn_update_dpp(0, v, 0x111 /* row_shr:1 */, 0xf, 0xf, true);
+  const int t = row_mov<0x90>(v);     /* quad_perm [0,0,1,2] */
+  return l == 0 ? 0 : t;
+}
+
+/* refb_finish for a band spread over a group of G lanes (lane l holds the winner's pulses
+   l*E .. l*E+E-1): the decisions are uniform over the group, the band-wide sums are group
+   reductions, lane 0 writes the record. */
+template <int E, int G>
+__device__ __forceinline__ void refb_finish_row(const RItems &it, int job, const RJob &jb, int band, long blk,
+ const odhip_pvq_refband &r, const LeanDecide<E> &dec, const RefBest &best, int l, bool live) {
+  constexpr int n = G*E;
+  const long bi = blk*jb.nb_bands + band;
+  const int off = jb.off[band];
+  const int cfl_enabled = jb.is_keyframe && jb.pli != 0;
+  const bool writer = live && l == 0;
+  const int chosen = best.chosen;
+  const int yslot = best.yslot;
+  const int noref = best.noref;
+  int qg = 0;
+  int itheta = jb.is_keyframe ? -1 : 0;
+  int max_theta = 0;
+  int best_k = 0;
+  if (best.close && writer) {
+    const unsigned slot = atomicAdd(it.pcount, 1u);
+    if (slot < (unsigned)kPUncCap) {
+      PUncR *e = it.plist + slot;
+      e->job = job;
+      e->band = band;
+      e->blk = (unsigned)blk;
+    }
+  }
+  if (chosen >= 0) {
+    qg = best.gain;
+    best_k = best.k;
+    if (!noref) {
+      itheta = best.theta;
+      max_theta = best.ts;
+    }
+    else {
+      itheta = -1;
+      max_theta = 0;
+    }
+  }
+  /* :611-622 */
+  int skip = 0;
+  if (noref) {
+    if (qg == 0) skip = 1;
+  }
+  else {
+    if (!jb.is_keyframe && qg == 0) skip = r.icgr ? 1 : 2;
+    if (qg == r.icgr && itheta == 0 && !cfl_enabled) skip = 2;
+  }
+  int4 *ch = reinterpret_cast<int4 *>(jb.choice + bi*16);
+  if (writer) {
+    ch[0] = make_int4(chosen, qg, noref, itheta);
+    ch[1] = make_int4(max_theta, best_k, skip, jb.is_keyframe ? (noref ? qg : neg_interleave(qg, r.icgr))
+     : (noref ? qg - 1 : neg_interleave(qg + 1, r.icgr + 1)));
+  }
+  if (skip) {
+    if (writer) {
+      const int flip = (r.flags & ODHIP_REFBAND_FLIP) != 0;
+      ch[2] = make_int4(skip == 2 ? (flip ? 4 : 1) : 0, -1, 0, 0);
+      ch[3] = make_int4(0, 0, 0, 0);
+    }
+    return;
+  }
+  int wy[E];
+#pragma unroll
+  for (int e = 0; e < E; e++) wy[e] = dec.signed_y(e);
+  /* the winner's pulses: slot 0 of the job's pulse buffer */
+  if (live && yslot >= 0) {
+    int16_t *p = jb.y + blk*jb.len + off + l*E;
+    static_assert(E == 8, "one 16-byte piece per lane");
+    *reinterpret_cast<uint4 *>(p) = make_uint4(pack16(wy[0], wy[1]), pack16(wy[2], wy[3]), pack16(wy[4], wy[5]),
+     pack16(wy[6], wy[7]));
+  }
+  const int32_t g = odq_gain_expand(odq_shl32(qg, ODQ_CGAIN_SHIFT) + (noref ? 0 : r.gain_offset),
+   job_q(jb, band, blk), jb.beta[band]);
+  int yy = 0;
+#pragma unroll
+  for (int e = 0; e < E; e++) yy += wy[e]*wy[e];    /* the pad of a theta winner holds 0 */
+  yy = grp_sum<G>(yy);
+  int gshift = odq_ilog(g) - 14;
+  gshift = gshift > 0 ? gshift : 0;
+  int32_t scale = 0;
+  if (yy != 0) {
+    int rsqrt_shift;
+    const int16_t rsqrt = odq_rsqrt(yy, &rsqrt_shift);
+    scale = odq_vshr_round(rsqrt*(int64_t)g, rsqrt_shift + gshift - 16);
+  }
+  const int qshift = ODQ_QM_INV_SHIFT - gshift;
+  if (noref) {
+    if (writer) {
+      ch[2] = make_int4(2, yslot, scale, qshift);
+      ch[3] = make_int4(0, 0, 0, 0);
+    }
+    return;
+  }
+  const int m = r.m;
+  const int s = r.s;
+  /* src/pvq.c:1094-1114: the two double products by 2^-15 are exact */
+  scale = (int32_t)floor(.5 + (scale*(1./32768))*odq_pvq_sin(best.qtheta));
+  const int16_t xm = (int16_t)floor(.5 + ((-s*odq_shr_round(g, gshift))*(1./32768))*odq_pvq_cos(best.qtheta));
+  const uint4 r4 = *reinterpret_cast<const uint4 *>(jb.r16 + blk*jb.len + off + l*E);
+  const uint32_t rw[4] = {r4.x, r4.y, r4.z, r4.w};
+  /* position i of the band takes pulse i below the Householder pivot m and pulse i - 1 above */
+  const int yprev = grp_from_prev<G>(wy[E - 1], l);
+  int32_t l2r = 0;
+  int32_t proj = 0;
+#pragma unroll
+  for (int e = 0; e < E; e++) {
+    const int i = l*E + e;
+    const int ri = (int16_t)(rw[e >> 1] >> (16*(e & 1)));
+    const int ysrc = i < m ? wy[e] : (e == 0 ? yprev : wy[e > 0 ? e - 1 : 0]);
+    const int16_t xi = i == m ? xm : (int16_t)odq_mult16_32_q16(ysrc, scale);
+    l2r += odq_mult16_16(ri, ri);
+    proj += odq_mult16_16(ri, xi);
+  }
+  l2r = grp_sum<G>(l2r);
+  proj = grp_sum<G>(proj);
+  int16_t proj_1;
+  int outshift;
+  householder_consts(l2r, proj, &proj_1, &outshift);
+  if (writer) {
+    ch[2] = make_int4(3, yslot, scale, qshift);
+    ch[3] = make_int4(xm, m, proj_1, outshift);
+  }
+  (void)n;
+}
+
+template <int E, int G>
+__global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(3))) void k_refb_lean_row(RItems it) {
+  constexpr int C = kWave/G;            /* bands per wavefront */
+  __shared__ uint32_t s_list[kLeanWords*C];
+  od_rsqrt_init(threadIdx.x);
+  const int item = find_item(it, blockIdx.x);
+  const int job = it.job[item];
+  const RJob &jb = it.jobs[job];
+  const int band = it.band[item];
+  const int lane = threadIdx.x;
+  RowVector<E, G> v;
+  v.row = lane/G;
+  v.l = lane%G;
+  v.force = it.perturb >> 1;
+  const long nblocks = jb.nblocks;
+  const long pos = (long)(blockIdx.x - it.wg_start[item])*C + v.row;
+  const bool live = pos < nblocks;
+  /* rows beyond the end redo the last band without storing anything */
+  const long blk = jb.ids[(long)band*nblocks + (live ? pos : nblocks - 1)];
+  const odhip_pvq_refband r = jb.rec[blk*jb.nb_bands + band];
+  const CandList cl = refb_build_list(jb, band, r, s_list + v.row, C, v.l == 0);
+  LeanDecide<E> dec;
+  dec.init(r, jb, it.lambda, it.tol_scale);
+  refb_loops_lean(jb, band, blk, r, cl, G*E, it.lambda, v, dec);
+  refb_finish_row<E, G>(it, job, jb, band, blk, r, dec, lean_best(dec, cl, jb.is_keyframe), v.l, live);
+}
+
+/* The bands a theta-margin re-run rebuilt (records, candidates and pulses of every slot, by
+   the exporting kernels) decided from those records, as k_refb_choose<N, 1> does. */
+template <int N>
+__global__ __launch_bounds__(kWave) void k_refb_choose_unc_list(RItems it, const Unc *list, int count) {
+  const int i = blockIdx.x*kWave + threadIdx.x;
+  if (i >= count) return;
+  const Unc e = list[i];
+  const RJob &jb = it.jobs[e.job];
+  if (jb.off[e.band + 1] - jb.off[e.band] != N) return;
+  refb_choose_band<N, 1>(it, e.job, jb, e.band, e.blk, nullptr);
+}
+
 template <int N, int PRICE>
 __global__ __launch_bounds__(kWave) void k_refb_choose(RItems it) {
   const int item = find_item(it, blockIdx.x);
@@ -1793,13 +2321,16 @@ struct RefState {
   unsigned *unc_host = nullptr;      /* pinned mirror of the counter                */
   hipEvent_t unc_event = nullptr;
   bool serial = false;               /* the context's setting, refreshed per call   */
+  bool sort_dirty = false;           /* the sort histogram may hold counts of a failed call */
+  bool lean = false;                 /* the last band stage was the decided one: no
+                                        candidate records exist unless a resolve re-ran
+                                        the band                                    */
   bool prof_on = false;              /* odhip_pvq_ref_profile                       */
   bool prof_made = false;
   int prof_n = 0;
   hipEvent_t prof_ev[kProfSlots][2];
   ~RefState() {
     if (d_jobs) (void)hipFree(d_jobs);
-    if (d_pcount) (void)hipFree(d_pcount);
     if (d_plist) (void)hipFree(d_plist);
     if (pcount_host) (void)hipHostFree(pcount_host);
     if (pcount_event) (void)hipEventDestroy(pcount_event);
@@ -1829,11 +2360,12 @@ int ref_state(RefState **out) {
   RefState *st = odhip_ctx_state<RefState>(ctx, ODHIP_SLOT_REFBANDS);
   if (!st->d_jobs) {
     ODHIP_TRY(hipMalloc((void **)&st->d_jobs, sizeof(RJob)*kMaxJobs*kTableSlots));
-    ODHIP_TRY(hipMalloc((void **)&st->d_unc_count, sizeof(unsigned)));
+    /* the two counters are adjacent (unc_count, pcount): one clear per band stage */
+    ODHIP_TRY(hipMalloc((void **)&st->d_unc_count, 2*sizeof(unsigned)));
     ODHIP_TRY(hipMalloc((void **)&st->d_unc, sizeof(Unc)*kUncCap));
     ODHIP_TRY(hipMalloc((void **)&st->d_sort, sizeof(unsigned)*2*kMaxItems*kSortBins));
-    ODHIP_TRY(hipMemset(st->d_unc_count, 0, sizeof(unsigned)));
-    ODHIP_TRY(hipMalloc((void **)&st->d_pcount, sizeof(unsigned)));
+    ODHIP_TRY(hipMemset(st->d_unc_count, 0, 2*sizeof(unsigned)));
+    st->d_pcount = st->d_unc_count + 1;
     ODHIP_TRY(hipMalloc((void **)&st->d_plist, sizeof(PUncR)*kPUncCap));
     ODHIP_TRY(hipMemset(st->d_pcount, 0, sizeof(unsigned)));
     ODHIP_TRY(hipMemset(st->d_sort, 0, sizeof(unsigned)*2*kMaxItems*kSortBins));
@@ -2005,12 +2537,12 @@ extern "C" int odhip_pvq_ref_theta_probe(const double *d_corr, double *d_t, long
 }
 
 namespace {
-int ref_bands(const odhip_pvq_refjob *jobs, int njobs, double pvq_norm_lambda, odhip_stream stream, bool fuse);
+int ref_bands(const odhip_pvq_refjob *jobs, int njobs, double pvq_norm_lambda, odhip_stream stream, int fuse);
 }
 
 extern "C" int odhip_pvq_ref_bands_multi(const odhip_pvq_refjob *jobs, int njobs,
  double pvq_norm_lambda, odhip_stream stream) {
-  return ref_bands(jobs, njobs, pvq_norm_lambda, stream, false);
+  return ref_bands(jobs, njobs, pvq_norm_lambda, stream, 0);
 }
 
 /* The band stage with the priced choice of the bands searched one per lane (the 15- and
@@ -2022,21 +2554,51 @@ extern "C" int odhip_pvq_ref_bands_priced_multi(const odhip_pvq_refjob *jobs, in
   for (int j = 0; jobs && j < njobs; j++) {
     if (!jobs[j].choice) return ODHIP_EINVAL;
   }
-  return ref_bands(jobs, njobs, pvq_norm_lambda, stream, true);
+  return ref_bands(jobs, njobs, pvq_norm_lambda, stream, 1);
+}
+
+/* The whole band stage with the priced choice of EVERY band made inside its search (see
+   "the DECIDED band stage" above): choice records and the winners' pulse vectors (slot 0 of
+   each job's y) are the only outputs; the candidate arrays of the jobs (items, the other
+   slots of y) are scratch of the resolve paths.  The counts of bands inside the theta margin
+   and inside the price margin are on their way to the host when this returns; follow with
+   odhip_pvq_ref_resolve_finish and odhip_pvq_ref_choose_priced_resolve (both normally find
+   nothing and return 0; a band they re-run is decided again by them), then consume the
+   choices.  A job must carry its choice buffer. */
+extern "C" int odhip_pvq_ref_bands_decided_multi(const odhip_pvq_refjob *jobs, int njobs,
+ double pvq_norm_lambda, odhip_stream stream) {
+  for (int j = 0; jobs && j < njobs; j++) {
+    if (!jobs[j].choice) return ODHIP_EINVAL;
+  }
+  return ref_bands(jobs, njobs, pvq_norm_lambda, stream, 2);
 }
 
 namespace {
-int ref_bands(const odhip_pvq_refjob *jobs, int njobs, double pvq_norm_lambda, odhip_stream stream, bool fuse) {
+int send_pcount(RefState &st, hipStream_t s) {
+  if (!st.pcount_host) {
+    ODHIP_TRY(hipHostMalloc((void **)&st.pcount_host, sizeof(unsigned), hipHostMallocDefault));
+    ODHIP_TRY(hipEventCreateWithFlags(&st.pcount_event, hipEventDisableTiming));
+  }
+  *st.pcount_host = 0xffffffffu;
+  ODHIP_TRY(hipMemcpyAsync(st.pcount_host, st.d_pcount, sizeof(unsigned), hipMemcpyDeviceToHost, s));
+  ODHIP_TRY(hipEventRecord(st.pcount_event, s));
+  return ODHIP_SUCCESS;
+}
+
+int ref_bands(const odhip_pvq_refjob *jobs, int njobs, double pvq_norm_lambda, odhip_stream stream, int fuse) {
   hipStream_t s = (hipStream_t)stream;
   REF_STATE_OR_RETURN(st);
   RJob host[kMaxJobs];
   int rc = stage_jobs(st, jobs, njobs, 0, host, s);
   if (rc) return rc;
-  if (fuse) ODHIP_TRY(hipMemsetAsync(st.d_pcount, 0, sizeof(unsigned), s));
-  ODHIP_TRY(hipMemsetAsync(st.d_unc_count, 0, sizeof(unsigned), s));
-  /* the histogram is consumed and cleared by k_refb_prefix; cleared here as well so
-     that a call that failed half way cannot poison the next sort */
-  ODHIP_TRY(hipMemsetAsync(st.d_sort, 0, sizeof(unsigned)*kMaxItems*kSortBins, s));
+  ODHIP_TRY(hipMemsetAsync(st.d_unc_count, 0, (fuse ? 2 : 1)*sizeof(unsigned), s));
+  /* the histogram is consumed and cleared by k_refb_prefix; only a call that failed
+     between the two leaves it dirty */
+  if (st.sort_dirty) {
+    ODHIP_TRY(hipMemsetAsync(st.d_sort, 0, sizeof(unsigned)*kMaxItems*kSortBins, s));
+    st.sort_dirty = false;
+  }
+  st.lean = fuse == 2;
   RItems it;
   items_all(it, st, host, njobs, pvq_norm_lambda, 0);
   if (!it.nitems) return ODHIP_SUCCESS;
@@ -2046,9 +2608,11 @@ int ref_bands(const odhip_pvq_refjob *jobs, int njobs, double pvq_norm_lambda, o
   {
     RItems pi;
     items_begin(pi, st, pvq_norm_lambda);
+    pi.fuse = fuse;
     for (int j = 0; j < njobs; j++) items_add(pi, j, 0, (host[j].nblocks + kWave - 1)/kWave);
     k_refb_prep_lane<15><<<pi.wg_start[pi.nitems], kWave, 0, s>>>(pi);
     items_begin(pi, st, pvq_norm_lambda);
+    pi.fuse = fuse;
     for (int j = 0; j < njobs; j++) {
       for (int b = 1; b < host[j].nb_bands; b++) {
         if (host[j].off[b + 1] - host[j].off[b] == 8) items_add(pi, j, b, (host[j].nblocks + kWave - 1)/kWave);
@@ -2057,6 +2621,7 @@ int ref_bands(const odhip_pvq_refjob *jobs, int njobs, double pvq_norm_lambda, o
     if (pi.nitems) k_refb_prep_lane<8><<<pi.wg_start[pi.nitems], kWave, 0, s>>>(pi);
     for (int sz = 32; sz <= 128; sz *= 4) {
       items_begin(pi, st, pvq_norm_lambda);
+      pi.fuse = fuse;
       for (int j = 0; j < njobs; j++) {
         for (int b = 1; b < host[j].nb_bands; b++) {
           if (host[j].off[b + 1] - host[j].off[b] == sz) {
@@ -2069,7 +2634,8 @@ int ref_bands(const odhip_pvq_refjob *jobs, int njobs, double pvq_norm_lambda, o
       else k_refb_prep_row<8, 16><<<pi.wg_start[pi.nitems], kWave, 0, s>>>(pi);
     }
   }
-  k_refb_cands<<<it.wg_start[it.nitems], kWave, 0, s>>>(it);
+  /* (the decided stage has no candidate kernel: the work classes came from the preparation) */
+  if (fuse != 2) k_refb_cands<<<it.wg_start[it.nitems], kWave, 0, s>>>(it);
   /* counting sort of every item's blocks by work class */
   {
     RItems chunks;
@@ -2082,12 +2648,14 @@ int ref_bands(const odhip_pvq_refjob *jobs, int njobs, double pvq_norm_lambda, o
         items_add(all, j, b, 1);
       }
     }
+    st.sort_dirty = true;
     k_refb_hist<<<chunks.wg_start[chunks.nitems], 256, 0, s>>>(chunks);
     k_refb_prefix<<<all.nitems, 256, 0, s>>>(all);
+    st.sort_dirty = odhip_check_launch() != ODHIP_SUCCESS;
     k_refb_scatter<<<chunks.wg_start[chunks.nitems], 256, 0, s>>>(chunks);
   }
   /* 128- and 32-coefficient bands: one band per 16-lane row; 15 and 8: per lane */
-  const bool lane_only = getenv("ODHIP_PVQ_REF_LANE") != nullptr;
+  const bool lane_only = fuse != 2 && getenv("ODHIP_PVQ_REF_LANE") != nullptr;
   static const int sizes[4] = {128, 32, 15, 8};
   hipStream_t side[2] = {s, s};
   if (rfork(st, s, side) != ODHIP_SUCCESS) return ODHIP_EFAULT;
@@ -2110,9 +2678,11 @@ int ref_bands(const odhip_pvq_refjob *jobs, int njobs, double pvq_norm_lambda, o
       if (sizes[i] == 128) {
         const bool prof = st.prof_on && st.prof_n < kProfSlots;
         if (prof) (void)hipEventRecord(st.prof_ev[st.prof_n][0], s);
-        k_refb_search_row<8, 16><<<it.wg_start[it.nitems], kWave, 0, s>>>(it);
+        if (fuse == 2) k_refb_lean_row<8, 16><<<it.wg_start[it.nitems], kWave, 0, s>>>(it);
+        else k_refb_search_row<8, 16><<<it.wg_start[it.nitems], kWave, 0, s>>>(it);
         if (prof) (void)hipEventRecord(st.prof_ev[st.prof_n++][1], s);
       }
+      else if (fuse == 2) k_refb_lean_row<8, 4><<<it.wg_start[it.nitems], kWave, 0, s>>>(it);
       else k_refb_search_row<8, 4><<<it.wg_start[it.nitems], kWave, 0, s>>>(it);
       continue;
     }
@@ -2120,7 +2690,11 @@ int ref_bands(const odhip_pvq_refjob *jobs, int njobs, double pvq_norm_lambda, o
     if (!it.nitems) continue;
     if (sizes[i] < 32 && !lane_only) {
       const int wgs = it.wg_start[it.nitems];
-      if (fuse) {
+      if (fuse == 2) {
+        if (sizes[i] == 15) k_refb_lean_lane<15><<<wgs, kWave, 0, s>>>(it);
+        else k_refb_lean_lane<8><<<wgs, kWave, 0, s>>>(it);
+      }
+      else if (fuse) {
         if (sizes[i] == 15) k_refb_search_regs<15, true><<<wgs, kWave, 0, s>>>(it);
         else k_refb_search_regs<8, true><<<wgs, kWave, 0, s>>>(it);
       }
@@ -2133,6 +2707,13 @@ int ref_bands(const odhip_pvq_refjob *jobs, int njobs, double pvq_norm_lambda, o
   }
   s = main_stream;
   if (rjoin(st, s, side) != ODHIP_SUCCESS) return ODHIP_EFAULT;
+  if (fuse == 2) {
+    /* both counts of listed bands on their way to the host */
+    const int rc2 = odhip_pvq_ref_resolve_begin(s);
+    if (rc2) return rc2;
+    const int rc3 = send_pcount(st, s);
+    if (rc3) return rc3;
+  }
   return odhip_check_launch();
 }
 }  // namespace
@@ -2219,6 +2800,19 @@ extern "C" int odhip_pvq_ref_resolve(const odhip_pvq_refjob *jobs, int njobs,
   k_refb_cands_list<<<(nfix + kWave - 1)/kWave, kWave, 0, s>>>(st.cur, d_list, (int)nfix);
   k_refb_search_list<<<nfix, kWave, (size_t)2*128*kWave*sizeof(unsigned short), s>>>(st.cur,
    d_list, (int)nfix, pvq_norm_lambda);
+  if (st.lean) {
+    /* the decided stage: nobody else will choose for these bands - decided here from the
+       records the re-run just wrote (a close call joins the price list, whose count is
+       sent again) */
+    RItems it;
+    items_begin(it, st, pvq_norm_lambda);
+    const unsigned grid = (nfix + kWave - 1)/kWave;
+    k_refb_choose_unc_list<128><<<grid, kWave, 0, s>>>(it, d_list, (int)nfix);
+    k_refb_choose_unc_list<32><<<grid, kWave, 0, s>>>(it, d_list, (int)nfix);
+    k_refb_choose_unc_list<15><<<grid, kWave, 0, s>>>(it, d_list, (int)nfix);
+    k_refb_choose_unc_list<8><<<grid, kWave, 0, s>>>(it, d_list, (int)nfix);
+    (void)send_pcount(st, s);
+  }
   rc = odhip_check_launch();
   hipError_t e = hipStreamSynchronize(s);
   free(list);
@@ -2281,13 +2875,8 @@ int ref_select(const odhip_pvq_refjob *jobs, int njobs, double pvq_norm_lambda, 
     else k_refb_choose<8, 0><<<grid, kWave, 0, s>>>(it);
   }
   if (price) {
-    if (!st.pcount_host) {
-      ODHIP_TRY(hipHostMalloc((void **)&st.pcount_host, sizeof(unsigned), hipHostMallocDefault));
-      ODHIP_TRY(hipEventCreateWithFlags(&st.pcount_event, hipEventDisableTiming));
-    }
-    *st.pcount_host = 0xffffffffu;
-    ODHIP_TRY(hipMemcpyAsync(st.pcount_host, st.d_pcount, sizeof(unsigned), hipMemcpyDeviceToHost, s));
-    ODHIP_TRY(hipEventRecord(st.pcount_event, s));
+    const int rcp = send_pcount(st, s);
+    if (rcp) return rcp;
   }
   if (!synth) return odhip_check_launch();
   items_begin(it, st, pvq_norm_lambda);
@@ -2337,11 +2926,42 @@ extern "C" int odhip_pvq_ref_choose_priced_resolve(const odhip_pvq_refjob *jobs,
   if (!list) return ODHIP_EFAULT;
   if (hipMemcpy(list, st.d_plist, sizeof(PUncR)*count, hipMemcpyDeviceToHost) != hipSuccess) rc = ODHIP_EFAULT;
   for (unsigned i = 0; i < count && !rc; i++) {
-    PUncR &e = list[i];
-    if (e.job < 0 || e.job >= njobs) {
-      rc = ODHIP_EINVAL;
-      break;
+    if (list[i].job < 0 || list[i].job >= njobs) rc = ODHIP_EINVAL;
+  }
+  if (!rc && st.lean) {
+    /* the decided stage kept no candidate records: the listed bands are searched again by
+       the exporting kernels (their theta as the record holds it) */
+    Unc *ul = (Unc *)malloc(sizeof(Unc)*count);
+    Unc *d_ul = nullptr;
+    if (!ul) rc = ODHIP_EFAULT;
+    for (unsigned i = 0; i < count && !rc; i++) {
+      ul[i].job = list[i].job;
+      ul[i].band = list[i].band;
+      ul[i].blk = list[i].blk;
+      ul[i].theta = -1;
+      ul[i].corr = 0;
     }
+    if (!rc && (hipMalloc((void **)&d_ul, sizeof(Unc)*count) != hipSuccess
+     || hipMemcpy(d_ul, ul, sizeof(Unc)*count, hipMemcpyHostToDevice) != hipSuccess)) {
+      rc = ODHIP_EFAULT;
+    }
+    /* the band-stage form of the job table (sort scratch, work vectors) for the re-run, then
+       the choice form again */
+    RJob host0[kMaxJobs];
+    if (!rc) rc = stage_jobs(st, jobs, njobs, 0, host0, s);
+    if (!rc) {
+      k_refb_cands_list<<<(count + kWave - 1)/kWave, kWave, 0, s>>>(st.cur, d_ul, (int)count);
+      k_refb_search_list<<<count, kWave, (size_t)2*128*kWave*sizeof(unsigned short), s>>>(st.cur, d_ul,
+       (int)count, pvq_norm_lambda);
+      rc = odhip_check_launch();
+      if (hipStreamSynchronize(s) != hipSuccess) rc = ODHIP_EFAULT;
+    }
+    if (!rc) rc = stage_jobs(st, jobs, njobs, 2, host, s);
+    free(ul);
+    if (d_ul) (void)hipFree(d_ul);
+  }
+  for (unsigned i = 0; i < count && !rc; i++) {
+    PUncR &e = list[i];
     const RJob &jb = host[e.job];
     const int n = jb.off[e.band + 1] - jb.off[e.band];
     const long B = jb.nblocks;

@@ -13,6 +13,7 @@
 
    Requires pvq_search.cuh (od_rsqrt_table) before it and -ffp-contract=off. */
 #pragma once
+#include <type_traits>
 #include "od_sel.cuh"
 
 namespace {
@@ -34,7 +35,7 @@ __device__ __forceinline__ double od_pvq_search_regs(const int (&ax)[N], int (&y
   const bool padded = n != N;
   /* |x_j| is converted where it is used: a second, double copy of the band costs 2N
      VGPRs and an occupancy step */
-#define OD_XD(j) ((double)ax[j])
+#define OD_XD(j) od_cvt_u(ax[j])
   const double lambda = __ddiv_rn(pvq_norm_lambda, 1e-30 + g2);
   double xy = 0;
   double yy = 0;
@@ -127,23 +128,32 @@ __device__ __forceinline__ double od_pvq_search_regs(const int (&ax)[N], int (&y
   const double norm2 = 2*norm_1;
   for (; i < k; i++) {
     /* od_rsqrt_table(yy + 2*y_j + 1) for every candidate straight from the LDS
-       table (the reference's four-entry cache :199-200 holds the same values) */
+       table (the reference's four-entry cache :199-200 holds the same values).  No y_j
+       exceeds the i pulses placed so far: when yy + 2*i + 1 is inside the table - every
+       pulse of every band of the frames measured - the lookups are unconditional; round 2
+       tested each of them against the table size, a saveexec / branch pair and an
+       if-converted sqrt + division per candidate position. */
     const int yyi = (int)yy;
     int pos = 0;
     double best_cost = -1e5;
+    auto scan = [&](auto fast) {
 #pragma unroll
-    for (int j = 0; j < N; j++) {
-      double tmp_xy = xy + OD_XD(j);
-      const double tmp_yy = od_rsqrt_table(yyi + 2*y[j] + 1);
-      tmp_xy = (tmp_xy*norm2)*tmp_yy - pen[j];
-      if (j == N - 1 && padded) tmp_xy = -1.7976931348623157e308;   /* PAD */
-      if (j == 0) best_cost = tmp_xy;
-      else {
-        const unsigned long long take = od_cmp_gt(tmp_xy, best_cost);
-        best_cost = od_sel(take, tmp_xy, best_cost);
-        pos = od_sel(take, j, pos);
+      for (int j = 0; j < N; j++) {
+        double tmp_xy = xy + OD_XD(j);
+        const int idx = yyi + 2*y[j] + 1;
+        const double tmp_yy = decltype(fast)::value ? od_rsq_lds[idx - 1] : od_rsqrt_table(idx);
+        tmp_xy = (tmp_xy*norm2)*tmp_yy - pen[j];
+        if (j == N - 1 && padded) tmp_xy = -1.7976931348623157e308;   /* PAD */
+        if (j == 0) best_cost = tmp_xy;
+        else {
+          const unsigned long long take = od_cmp_gt(tmp_xy, best_cost);
+          best_cost = od_sel(take, tmp_xy, best_cost);
+          pos = od_sel(take, j, pos);
+        }
       }
-    }
+    };
+    if (yyi + 2*i + 1 <= OD_RSQ_TABLE_N) scan(std::true_type());
+    else scan(std::false_type());
     int xp = 0;
     int yp = 0;
 #pragma unroll

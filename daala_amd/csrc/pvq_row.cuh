@@ -41,6 +41,8 @@
    cases of :154-163 are not implemented here; those bands are searched one
    per lane). */
 #pragma once
+#include <type_traits>
+#include "od_sel.cuh"
 
 namespace {
 
@@ -192,7 +194,7 @@ __device__ __forceinline__ double od_pvq_search_row(const int (&ax)[E], int (&y)
     const int yyp1 = (int)yy + 1;
 #pragma unroll
     for (int e = 0; e < E; e++) {
-      const double t = xy + (double)ax[e];
+      const double t = xy + od_cvt_u(ax[e]);
       a[e] = t*t;
       b[e] = (double)(yyp1 + 2*y[e]);
       if (e == E - 1 && pad_lane) a[e] = -1;   /* PAD: loses every comparison */
@@ -279,18 +281,27 @@ __device__ __forceinline__ double od_pvq_search_row(const int (&ax)[E], int (&y)
     const int yyi = (int)yy;
     double bc = 0;
     int bi = 0;
+    /* no y_j exceeds the i pulses placed so far: when yy + 2*i + 1 is inside the table in
+       every row still searching, the lookups are unconditional (an index of a finished row
+       is clamped, its result unused); otherwise each is tested (od_rsqrt_table) */
+    auto scan = [&](auto fast) {
 #pragma unroll
-    for (int e = 0; e < E; e++) {
-      const int j = l*E + e;
-      double tmp_xy = xy + (double)ax[e];
-      const double r = od_rsqrt_table(yyi + 2*y[e] + 1);
-      tmp_xy = (tmp_xy*norm2)*r - pen[e];
-      if (e == E - 1 && pad_lane) tmp_xy = -1.7976931348623157e308;   /* PAD */
-      if (e == 0 || tmp_xy > bc) {
-        bc = tmp_xy;
-        bi = j;
+      for (int e = 0; e < E; e++) {
+        const int j = l*E + e;
+        double tmp_xy = xy + od_cvt_u(ax[e]);
+        const int idx = yyi + 2*y[e] + 1;
+        const double r = decltype(fast)::value ? od_rsq_lds[(idx < OD_RSQ_TABLE_N ? idx : OD_RSQ_TABLE_N) - 1]
+         : od_rsqrt_table(idx);
+        tmp_xy = (tmp_xy*norm2)*r - pen[e];
+        if (e == E - 1 && pad_lane) tmp_xy = -1.7976931348623157e308;   /* PAD */
+        if (e == 0 || tmp_xy > bc) {
+          bc = tmp_xy;
+          bi = j;
+        }
       }
-    }
+    };
+    if (!__any(on && yyi + 2*i + 1 > OD_RSQ_TABLE_N)) scan(std::true_type());
+    else scan(std::false_type());
     /* (max cost, lowest index): butterfly over the row, both fields moved by DPP */
 #define OD_RDO_STEP(CTRL) \
     { \

@@ -403,6 +403,12 @@ int odhip_inverse_level_pvq(uint8_t *d_px, int px_stride, long px_plane_stride,
    level 0 when the luma partition there is 4x4. */
 int odhip_cfl_refs_from_luma(const odhip_pvq_job *luma_jobs, int njobs, od_coeff *const *d_ref,
  int copies, odhip_stream stream);
+/* prezeroed != 0: the caller guarantees that the positions a 64x64 luma level never codes
+   (half of each 32x32 chroma reference block) are already zero in d_ref - buffers that were
+   cleared once and are only ever written by this function - and the per-call clear of that
+   plane set is skipped. */
+int odhip_cfl_refs_from_luma_ex(const odhip_pvq_job *luma_jobs, int njobs, od_coeff *const *d_ref,
+ int copies, int prezeroed, odhip_stream stream);
 
 /* Profiling aid (bench.py): while enabled, odhip_pvq_noref_bands_multi brackets
    its dominant kernel - the search of the 128-coefficient bands,
@@ -673,6 +679,18 @@ int odhip_pvq_ref_choose_multi(const odhip_pvq_refjob *jobs, int njobs,
  double pvq_norm_lambda, odhip_stream stream);
 int odhip_inverse_levels_pvq_ref(uint8_t *const *d_px, int px_stride, long px_plane_stride,
  const odhip_pvq_refjob *jobs, int njobs, int dec, int pic_w, int pic_h, odhip_stream stream);
+/* The whole band stage with the priced choice (od_pvq_rate's closed form, speed > 0,
+   src/pvq_encoder.c:250-264) of EVERY band made inside its search: nothing per candidate
+   reaches memory.  Outputs: choice[] of every job and the winner's pulse vector of every
+   coded band in slot 0 of the job's y (choice word 9 names the slot: 0, or -1 when the
+   winner places no pulse); items and the other slots of y are scratch of the resolve
+   paths.  The counts of bands inside the theta margin and inside the price margin are on
+   their way to the host when this returns: follow with odhip_pvq_ref_resolve_finish and
+   odhip_pvq_ref_choose_priced_resolve (same jobs and stream; both normally return 0; a band
+   they re-run through the exporting kernels is decided again by them), then consume the
+   choices (odhip_inverse_levels_pvq_ref).  A job must carry its choice buffer. */
+int odhip_pvq_ref_bands_decided_multi(const odhip_pvq_refjob *jobs, int njobs,
+ double pvq_norm_lambda, odhip_stream stream);
 /* Test hooks: the uncertainty margin (default 1e-9; <= 0 restores it) and, when
    perturb != 0, a deliberately wrong device theta (+1) for the listed bands, so
    that tests exercise the host-libm path on real data. */

@@ -199,6 +199,39 @@ def test_priced_choice_on_the_device_equals_host_priced_choice(hip, is_keyframe,
     torch.cuda.synchronize()
     for a, d in zip(ja, jd):
         assert torch.equal(a.choice, d.choice), (is_keyframe, pli, a.bs, "host-libm resolve")
+    # (e) the DECIDED stage: every band chosen inside its search, nothing per candidate
+    # exported - same choice records (word 9 names the pulse slot: 0 there) and the same
+    # winner's pulses; then with the margin forced wide (listed bands re-run by the exporting
+    # kernels and re-decided from host rates)
+    for scale in (1., 1e12):
+        hip.set_price_tol_scale(scale)
+        try:
+            je = [hip.PvqRefJob(j.coef, j.ref, j.bs, j.qm, j.qm_inv, list(j.q_band)[:j.nb],
+                                list(j.beta_band)[:j.nb], is_keyframe, pli) for j in ja]
+            nt, npz = hip.pvq_ref_bands_decided_multi(je, lam)
+            assert nt == 0 and (npz == 0 if scale == 1. else npz > 50)
+        finally:
+            hip.set_price_tol_scale(1.)
+        torch.cuda.synchronize()
+        for a, e in zip(ja, je):
+            ca = a.choice.cpu().numpy()
+            ce = e.choice.cpu().numpy()
+            keep = [i for i in range(16) if i != 9]
+            assert np.array_equal(ca[..., keep], ce[..., keep]), (is_keyframe, pli, a.bs, "decided", scale)
+            ya = a.y.cpu().numpy()
+            ye = e.y.cpu().numpy()
+            for band in range(a.nb):
+                lo, hi = a.offsets[band], a.offsets[band + 1]
+                sa = ca[:, band, 9]
+                se = ce[:, band, 9]
+                assert np.array_equal(sa >= 0, se >= 0)
+                idx = np.nonzero(sa >= 0)[0]
+                # a theta winner holds n - 1 pulses (the last position is a pad)
+                last = hi - 1 - (ca[idx, band, 2] == 0)
+                for w in range(lo, hi):
+                    m = w <= last
+                    assert np.array_equal(ya[sa[idx], idx, w][m], ye[se[idx], idx, w][m]), \
+                        (is_keyframe, pli, a.bs, band, w, scale)
 
 
 def test_ref_jobs_argument_validation(hip):
