@@ -560,7 +560,8 @@ class _RefJob(ctypes.Structure):
                 ("items", ctypes.c_void_p), ("y", ctypes.c_void_p), ("r16", ctypes.c_void_p),
                 ("x16", ctypes.c_void_p), ("xr", ctypes.c_void_p), ("d_rate", ctypes.c_void_p),
                 ("choice", ctypes.c_void_p), ("d_dq", ctypes.c_void_p),
-                ("q_band2", ctypes.POINTER(ctypes.c_int32)), ("plane_split", ctypes.c_int)]
+                ("q_band2", ctypes.POINTER(ctypes.c_int32)), ("plane_split", ctypes.c_int),
+                ("luma", ctypes.c_void_p)]
 
 
 class PvqRefJob:
@@ -612,7 +613,7 @@ class PvqRefJob:
                        self.pli, opt(self.qm), opt(self.qm_inv), self.q_band, self.beta_band,
                        _p(self.band), _p(self.items), _p(self.y), _p(self.r16), _p(self.x16),
                        _p(self.xr), opt(self.rate), _p(self.choice), _p(self.dq), self.q_band2,
-                       self.plane_split)
+                       self.plane_split, None)
 
     def unpack(self):
         """Host copies: record fields [B][nb], item fields [B][nb][REF_SLOTS], y, choice."""
@@ -989,21 +990,22 @@ class Pipe:
         _check(lib().odhip_pipe_stage(self._p(), PIPE_STAGES.index(name), int(parity)),
                "odhip_pipe_stage(%s)" % name)
 
-    def buffer(self, what, set_, level=0, parity=0):
+    def buffer(self, what, set_, level=0, parity=-1):
         ptr = ctypes.c_void_p()
         n = ctypes.c_size_t()
         _check(lib().odhip_pipe_buffer(self._p(), int(what), int(set_), int(level), int(parity),
                                        ctypes.byref(ptr), ctypes.byref(n)), "odhip_pipe_buffer")
         return ptr.value, n.value
 
-    def read(self, what, set_, level=0, parity=0, dtype=np.uint8):
+    def read(self, what, set_, level=0, parity=-1, dtype=np.uint8):
+        """parity -1: the buffers of the last step() (0 when the pipe is driven stage by stage)."""
         ptr, n = self.buffer(what, set_, level, parity)
         out = np.empty(n, np.uint8)
         _check(lib().odhip_pipe_read(self._p(), out.ctypes.data_as(ctypes.c_void_p),
                                      ctypes.c_void_p(ptr), ctypes.c_size_t(n)), "odhip_pipe_read")
         return out.view(dtype)
 
-    def write(self, what, set_, level, data, parity=0):
+    def write(self, what, set_, level, data, parity=-1):
         ptr, n = self.buffer(what, set_, level, parity)
         data = np.ascontiguousarray(data)
         assert data.nbytes == n, (data.nbytes, n)

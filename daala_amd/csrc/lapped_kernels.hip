@@ -1630,7 +1630,11 @@ extern "C" int odhip_inverse_levels_pvq_ref(uint8_t *const *d_px, int px_stride,
   memset(ia, 0, sizeof(ia));
   for (int i = 0; i < njobs; i++) {
     const odhip_pvq_refjob &j = jobs[i];
-    if (!d_px[i] || !j.d_coef || !j.d_ref || !j.y || !j.r16 || !j.choice || !j.d_qm_inv || j.nplanes <= 0
+    /* a job whose reference is read in place from the luma stage (keyframe chroma from luma)
+       has no reference plane, and none of its bands can be a skip-copy
+       (src/pvq_encoder.c:620: not with CfL) */
+    const bool lref = j.luma != nullptr && j.is_keyframe && j.pli != 0;
+    if (!d_px[i] || !j.d_coef || (!j.d_ref && !lref) || !j.y || !j.r16 || !j.choice || !j.d_qm_inv || j.nplanes <= 0
      || j.nplanes != jobs[0].nplanes || j.w != jobs[0].w || j.h != jobs[0].h) {
       return ODHIP_EINVAL;
     }

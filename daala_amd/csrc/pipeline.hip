@@ -73,9 +73,12 @@ struct odhip_pipe {
   hipStream_t stream[2];
   bool serial;
   PlaneSet set[2];
-  odhip_pvq_job jobs[2*ODHIP_NBSIZES];       /* luma 0..4, chroma (no-reference mode) 5..8 */
+  /* [parity]: luma 0..4, chroma (no-reference mode) 5..8.  With chroma from luma the
+     chroma chain of step i reads the luma CHOICES of step i (pulses and choice records,
+     odhip_pvq_refjob.luma) while the luma chain of step i + 1 already writes the next ones:
+     two sets that share everything but those two buffers; otherwise only [0] is used */
+  odhip_pvq_job jobs[2][2*ODHIP_NBSIZES];
   int njobs;
-  od_coeff *refs[2][ODHIP_NBSIZES];          /* [parity][chroma level] */
   odhip_pvq_refjob refjobs[2][ODHIP_NBSIZES];
   odhip_pvq_refjob interjobs[2][ODHIP_NBSIZES];   /* inter mode: [plane set][level] */
   bool inter_pending[2];
@@ -187,7 +190,7 @@ int setup_set(odhip_pipe *p, PlaneSet &s, int dec, int pli, int nplanes) {
   return ODHIP_SUCCESS;
 }
 
-int setup_job(odhip_pipe *p, odhip_pvq_job &j, PlaneSet &s, int bs) {
+int setup_job(odhip_pipe *p, odhip_pvq_job &j, PlaneSet &s, int bs, const odhip_pvq_job *share = nullptr) {
   int nb = 0;
   int len = 0;
   odhip_pvq_band_layout(bs, &nb, nullptr, &len);
@@ -206,20 +209,22 @@ int setup_job(odhip_pipe *p, odhip_pvq_job &j, PlaneSet &s, int bs) {
     j.plane_split = s.plane_split;
   }
   const long B = s.nblocks[bs];
-  PIPE_ALLOC(p, j.cands.band, sizeof(odhip_pvq_band)*(size_t)B*nb, true);
+  if (share) j.cands.band = share->cands.band;       /* the other parity's set: own pulses and choices */
+  else PIPE_ALLOC(p, j.cands.band, sizeof(odhip_pvq_band)*(size_t)B*nb, true);
   PIPE_ALLOC(p, j.cands.y, sizeof(int16_t)*(size_t)2*B*len, true);
   PIPE_ALLOC(p, j.cands.choice, sizeof(int32_t)*(size_t)B*nb*4, true);
   return ODHIP_SUCCESS;
 }
 
 int setup_refjob(odhip_pipe *p, odhip_pvq_refjob &j, PlaneSet &s, int bs, const od_coeff *ref,
- const odhip_pvq_refjob *share) {
+ const odhip_pvq_refjob *share, const odhip_pvq_job *luma = nullptr) {
   int nb = 0;
   int len = 0;
   odhip_pvq_band_layout(bs, &nb, nullptr, &len);
   memset(&j, 0, sizeof(j));
   j.d_coef = s.levels[bs];
   j.d_ref = ref;
+  j.luma = luma;
   j.nplanes = s.nplanes;
   j.w = s.w;
   j.h = s.h;
@@ -323,24 +328,29 @@ int pipe_init(odhip_pipe *p) {
     return ODHIP_SUCCESS;
   }
   for (int bs = 0; bs < 5; bs++) {
-    rc = setup_job(p, p->jobs[bs], p->set[0], bs);
+    rc = setup_job(p, p->jobs[0][bs], p->set[0], bs);
     if (rc) return rc;
   }
   p->njobs = 5;
   if (!c.chroma_cfl) {
     for (int bs = 0; bs < 4; bs++) {
-      rc = setup_job(p, p->jobs[5 + bs], p->set[1], bs);
+      rc = setup_job(p, p->jobs[0][5 + bs], p->set[1], bs);
       if (rc) return rc;
     }
     p->njobs = 9;
   }
   else {
     PlaneSet &ch = p->set[1];
+    for (int bs = 0; bs < 5; bs++) {
+      rc = setup_job(p, p->jobs[1][bs], p->set[0], bs, &p->jobs[0][bs]);
+      if (rc) return rc;
+    }
     for (int par = 0; par < 2; par++) {
       for (int bs = 0; bs < 4; bs++) {
-        PIPE_ALLOC(p, p->refs[par][bs], sizeof(od_coeff)*(size_t)ch.nplanes*ch.w*ch.h, true);
-        rc = setup_refjob(p, p->refjobs[par][bs], ch, bs, p->refs[par][bs],
-         par ? &p->refjobs[0][bs] : nullptr);
+        /* the chroma-from-luma reference of chroma level bs: the choices of luma level
+           bs + 1 of the same step, read in place (no reference planes) */
+        rc = setup_refjob(p, p->refjobs[par][bs], ch, bs, nullptr, par ? &p->refjobs[0][bs] : nullptr,
+         &p->jobs[par][bs + 1]);
         if (rc) return rc;
       }
       ODHIP_TRY(hipEventCreateWithFlags(&p->ev_refs[par], hipEventDisableTiming));
@@ -396,10 +406,10 @@ int stage_pyramid(odhip_pipe *p, int si, hipStream_t s) {
    p->pic_w, p->pic_h, s);
 }
 
-int stage_inverse_noref(odhip_pipe *p, int si, hipStream_t s) {
+int stage_inverse_noref(odhip_pipe *p, int si, hipStream_t s, int jpar) {
   PlaneSet &t = p->set[si];
   Timed tm(p, si ? ODHIP_PIPE_INVERSE_CHROMA : ODHIP_PIPE_INVERSE_LUMA, s);
-  return odhip_inverse_levels_pvq(t.recon, t.w, (long)t.w*t.h, p->jobs + (si ? 5 : 0), t.nlev, t.dec,
+  return odhip_inverse_levels_pvq(t.recon, t.w, (long)t.w*t.h, p->jobs[jpar] + (si ? 5 : 0), t.nlev, t.dec,
    p->pic_w, p->pic_h, s);
 }
 
@@ -443,36 +453,39 @@ int finish_pending(odhip_pipe *p) {
   p->price_reruns += m;
   if (n > 0 || m > 0) {
     /* what consumed the choices runs again (the buffers are intact until the next chroma
-       chain is enqueued, below); it reads refs[par] again: the luma chain must not overwrite
-       that buffer before */
+       chain is enqueued, below) */
     STEP_TRY(chroma_tail(p, par, p->stream[1]));
-    ODHIP_TRY(hipEventRecord(p->ev_used[par], p->stream[1]));
   }
   return ODHIP_SUCCESS;
 }
 
-int luma_front(odhip_pipe *p, hipStream_t s) {
+int luma_bands(odhip_pipe *p, hipStream_t s, int jpar) {
   const double lam = p->cfg.pvq_norm_lambda;
+  /* with pricing the searches make the choice themselves (no separate choice kernel) */
+  Timed tm(p, ODHIP_PIPE_BANDS_LUMA, s);
+  return p->cfg.price ? odhip_pvq_noref_bands_priced_multi(p->jobs[jpar], p->njobs, lam, s)
+   : odhip_pvq_noref_bands_multi(p->jobs[jpar], p->njobs, lam, s);
+}
+
+int luma_front(odhip_pipe *p, hipStream_t s, int jpar) {
   STEP_TRY(stage_pad(p, 0, s));
   STEP_TRY(stage_pyramid(p, 0, s));
   if (!p->cfg.chroma_cfl) {
     STEP_TRY(stage_pad(p, 1, s));
     STEP_TRY(stage_pyramid(p, 1, s));
   }
-  {
-    /* with pricing the searches make the choice themselves (no separate choice kernel) */
-    Timed tm(p, ODHIP_PIPE_BANDS_LUMA, s);
-    STEP_TRY(p->cfg.price ? odhip_pvq_noref_bands_priced_multi(p->jobs, p->njobs, lam, s)
-     : odhip_pvq_noref_bands_multi(p->jobs, p->njobs, lam, s));
+  else {
+    /* the chroma chain of step i - 2 has read the choices this band stage overwrites */
+    ODHIP_TRY(hipStreamWaitEvent(s, p->ev_used[jpar], 0));
   }
-  return ODHIP_SUCCESS;
+  return luma_bands(p, s, jpar);
 }
 
-int luma_choose(odhip_pipe *p, hipStream_t s) {
+int luma_choose(odhip_pipe *p, hipStream_t s, int jpar) {
   const double lam = p->cfg.pvq_norm_lambda;
   if (!p->cfg.price) {
     Timed tm(p, ODHIP_PIPE_CHOOSE_LUMA, s);
-    return odhip_pvq_choose_multi(p->jobs, p->njobs, lam, s);
+    return odhip_pvq_choose_multi(p->jobs[jpar], p->njobs, lam, s);
   }
   /* (the choice was made inside the band stage: odhip_pvq_noref_bands_priced_multi) */
   /* The luma choices feed this step's chroma references and inverse: a band whose priced
@@ -480,17 +493,11 @@ int luma_choose(odhip_pipe *p, hipStream_t s) {
      enqueued.  The host waits here for the luma front of this step while the chroma chain
      of the previous step keeps the GPU busy. */
   const auto t0 = std::chrono::steady_clock::now();
-  const int n = odhip_pvq_choose_priced_resolve(p->jobs, p->njobs, lam, s);
+  const int n = odhip_pvq_choose_priced_resolve(p->jobs[jpar], p->njobs, lam, s);
   p->wait_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   if (n < 0) return n;
   p->price_reruns += n;
   return ODHIP_SUCCESS;
-}
-
-int luma_refs(odhip_pipe *p, int par, hipStream_t s) {
-  Timed tm(p, ODHIP_PIPE_CFL_REFS, s);
-  /* (the reference buffers were cleared when the pipe was made and have no other writer) */
-  return odhip_cfl_refs_from_luma_ex(p->jobs + 1, 4, p->refs[par], 2, 1, s);
 }
 
 int chroma_bands(odhip_pipe *p, int par, hipStream_t s) {
@@ -587,10 +594,10 @@ int step_inter(odhip_pipe *p) {
 int step_noref(odhip_pipe *p) {
   hipStream_t s = p->stream[0];
   Current cur(p->ctx[0]);
-  STEP_TRY(luma_front(p, s));
-  STEP_TRY(luma_choose(p, s));
-  STEP_TRY(stage_inverse_noref(p, 0, s));
-  return stage_inverse_noref(p, 1, s);
+  STEP_TRY(luma_front(p, s, 0));
+  STEP_TRY(luma_choose(p, s, 0));
+  STEP_TRY(stage_inverse_noref(p, 0, s, 0));
+  return stage_inverse_noref(p, 1, s, 0);
 }
 
 int step_cfl(odhip_pipe *p) {
@@ -599,13 +606,12 @@ int step_cfl(odhip_pipe *p) {
   const int par = (int)(p->nstep & 1);
   {
     Current cur(p->ctx[0]);
-    STEP_TRY(luma_front(p, main));
-    STEP_TRY(luma_choose(p, main));
-    /* step i-2 no longer reads this reference buffer */
-    ODHIP_TRY(hipStreamWaitEvent(main, p->ev_used[par], 0));
-    STEP_TRY(luma_refs(p, par, main));
+    STEP_TRY(luma_front(p, main, par));
+    STEP_TRY(luma_choose(p, main, par));
+    /* the luma choices of this step are final: the chroma chain takes its references from
+       them (odhip_pvq_refjob.luma) */
     ODHIP_TRY(hipEventRecord(p->ev_refs[par], main));
-    STEP_TRY(stage_inverse_noref(p, 0, main));
+    STEP_TRY(stage_inverse_noref(p, 0, main, par));
   }
   STEP_TRY(finish_pending(p));
   {
@@ -614,8 +620,9 @@ int step_cfl(odhip_pipe *p) {
     STEP_TRY(stage_pyramid(p, 1, side));
     ODHIP_TRY(hipStreamWaitEvent(side, p->ev_refs[par], 0));
     STEP_TRY(chroma_bands(p, par, side));
-    STEP_TRY(chroma_tail(p, par, side));
+    /* only the preparation kernels of the band stage read the luma choices */
     ODHIP_TRY(hipEventRecord(p->ev_used[par], side));
+    STEP_TRY(chroma_tail(p, par, side));
   }
   p->pending = par;
   return ODHIP_SUCCESS;
@@ -640,7 +647,6 @@ extern "C" odhip_pipe *odhip_pipe_create(const odhip_pipe_config *cfg) {
   p->wait_ms = 0;
   p->record = false;
   memset(p->rate, 0, sizeof(p->rate));
-  memset(p->refs, 0, sizeof(p->refs));
   memset(p->ev_refs, 0, sizeof(p->ev_refs));
   memset(p->ev_used, 0, sizeof(p->ev_used));
   p->copy_stream = nullptr;
@@ -786,19 +792,18 @@ extern "C" int odhip_pipe_stage(odhip_pipe *p, int stage, int parity) {
    || stage == ODHIP_PIPE_BANDS_CHROMA || stage == ODHIP_PIPE_CHOOSE_CHROMA
    || stage == ODHIP_PIPE_INVERSE_CHROMA;
   Current cur(p->ctx[chroma_stage && cfl ? 1 : 0]);
+  const int jpar = cfl ? parity : 0;     /* the luma set of that parity */
+  (void)lam;
   switch (stage) {
     case ODHIP_PIPE_PAD_LUMA: return stage_pad(p, 0, s);
     case ODHIP_PIPE_PYRAMID_LUMA: return stage_pyramid(p, 0, s);
     case ODHIP_PIPE_PAD_CHROMA: return stage_pad(p, 1, s);
     case ODHIP_PIPE_PYRAMID_CHROMA: return stage_pyramid(p, 1, s);
-    case ODHIP_PIPE_BANDS_LUMA: {
-      Timed tm(p, stage, s);
-      return p->cfg.price ? odhip_pvq_noref_bands_priced_multi(p->jobs, p->njobs, lam, s)
-       : odhip_pvq_noref_bands_multi(p->jobs, p->njobs, lam, s);
-    }
-    case ODHIP_PIPE_CHOOSE_LUMA: return luma_choose(p, s);
-    case ODHIP_PIPE_CFL_REFS: return cfl ? luma_refs(p, parity, s) : ODHIP_EINVAL;
-    case ODHIP_PIPE_INVERSE_LUMA: return stage_inverse_noref(p, 0, s);
+    case ODHIP_PIPE_BANDS_LUMA: return luma_bands(p, s, jpar);
+    case ODHIP_PIPE_CHOOSE_LUMA: return luma_choose(p, s, jpar);
+    /* (the references are read in place from the luma choices: nothing to run) */
+    case ODHIP_PIPE_CFL_REFS: return cfl ? ODHIP_SUCCESS : ODHIP_EINVAL;
+    case ODHIP_PIPE_INVERSE_LUMA: return stage_inverse_noref(p, 0, s, jpar);
     case ODHIP_PIPE_BANDS_CHROMA: {
       if (!cfl) return ODHIP_SUCCESS;      /* part of ODHIP_PIPE_BANDS_LUMA */
       STEP_TRY(chroma_bands(p, parity, s));
@@ -820,7 +825,7 @@ extern "C" int odhip_pipe_stage(odhip_pipe *p, int stage, int parity) {
       return odhip_pvq_ref_choose_multi(p->refjobs[parity], 4, lam, s);
     }
     case ODHIP_PIPE_INVERSE_CHROMA: {
-      if (!cfl) return stage_inverse_noref(p, 1, s);
+      if (!cfl) return stage_inverse_noref(p, 1, s, 0);
       PlaneSet &ch = p->set[1];
       Timed tm(p, stage, s);
       return odhip_inverse_levels_pvq_ref(ch.recon, ch.w, (long)ch.w*ch.h, p->refjobs[parity], 4, 1,
@@ -832,9 +837,12 @@ extern "C" int odhip_pipe_stage(odhip_pipe *p, int stage, int parity) {
 
 extern "C" int odhip_pipe_buffer(odhip_pipe *p, int what, int set, int level, int parity, void **d_ptr,
  size_t *bytes) {
-  if (!p || !d_ptr || !bytes || (set != 0 && set != 1) || (parity != 0 && parity != 1)) {
+  if (!p || !d_ptr || !bytes || (set != 0 && set != 1) || parity < -1 || parity > 1) {
     return ODHIP_EINVAL;
   }
+  /* -1: the buffers of the LAST odhip_pipe_step (the luma choices and the chroma references
+     alternate between two sets from step to step) */
+  if (parity < 0) parity = p->nstep > 0 ? (int)((p->nstep - 1) & 1) : 0;
   PlaneSet &t = p->set[set];
   if (what != ODHIP_PIPE_BUF_PIC && what != ODHIP_PIPE_BUF_PX && (level < 0 || level >= t.nlev)) {
     return ODHIP_EINVAL;
@@ -845,7 +853,8 @@ extern "C" int odhip_pipe_buffer(odhip_pipe *p, int what, int set, int level, in
   const long B = level >= 0 && level < ODHIP_NBSIZES ? t.nblocks[level] : 0;
   const bool inter = p->cfg.inter != 0;
   const bool ref = inter || (set == 1 && p->cfg.chroma_cfl);
-  const odhip_pvq_job *j = ref ? nullptr : set == 0 ? &p->jobs[level] : &p->jobs[5 + level];
+  const int jpar = p->cfg.chroma_cfl && !inter ? parity : 0;
+  const odhip_pvq_job *j = ref ? nullptr : set == 0 ? &p->jobs[jpar][level] : &p->jobs[0][5 + level];
   const odhip_pvq_refjob *r = inter ? &p->interjobs[set][level] : ref ? &p->refjobs[parity][level] : nullptr;
   void *ptr = nullptr;
   size_t n = 0;
@@ -873,8 +882,10 @@ extern "C" int odhip_pipe_buffer(odhip_pipe *p, int what, int set, int level, in
       break;
     case ODHIP_PIPE_BUF_REF:
       if (!r) return ODHIP_EINVAL;
-      /* inter mode: the reference of every block is the pyramid of its prediction picture */
-      ptr = inter ? t.pred_levels[level] : p->refs[parity][level];
+      /* inter mode: the reference of every block is the pyramid of its prediction picture;
+         keyframe chroma takes its reference from the luma choices in place: no plane exists */
+      if (!inter) return ODHIP_EINVAL;
+      ptr = t.pred_levels[level];
       n = sizeof(od_coeff)*(size_t)t.nplanes*t.w*t.h;
       break;
     case ODHIP_PIPE_BUF_RATE: {
@@ -885,7 +896,10 @@ extern "C" int odhip_pipe_buffer(odhip_pipe *p, int what, int set, int level, in
       if (!p->rate[set][level]) {
         ODHIP_TRY(hipSetDevice(p->cfg.device));
         PIPE_ALLOC(p, p->rate[set][level], n, true);
-        if (j) p->jobs[set ? 5 + level : level].d_rate = p->rate[set][level];
+        if (j) {
+          p->jobs[0][set ? 5 + level : level].d_rate = p->rate[set][level];
+          p->jobs[1][set ? 5 + level : level].d_rate = p->rate[set][level];
+        }
         else if (inter) p->interjobs[set][level].d_rate = p->rate[set][level];
         else {
           p->refjobs[0][level].d_rate = p->rate[set][level];

@@ -95,11 +95,44 @@ struct RJob {
      chroma plane set - pvq_qm_q4[pli] is per plane, src/encode.c:3052-3072 */
   long split_blk;
   int q2[ODHIP_MAX_BANDS];
+  /* chroma-from-luma reference taken straight from the luma band stage (odhip_pvq_refjob.luma):
+     the chosen pulses / choice records / inverse QM of the luma level one size up; the
+     reference plane itself never exists */
+  const int16_t *ly;
+  const int32_t *lchoice;
+  const int16_t *lqmi;
+  long lnblocks;
+  long lsplit;      /* blocks of one luma plane set: chroma plane p uses luma plane p mod planes */
+  int llen;
+  int lnb;
 };
 
 /* The band's quantiser step for block blk. */
 __device__ __forceinline__ int job_q(const RJob &jb, int band, long blk) {
   return blk >= jb.split_blk ? jb.q2[band] : jb.q[band];
+}
+
+/* od_resample_luma_coeffs for luma blocks of 8x8 and larger (src/intra.c:97-108: the
+   upper-left quarter of the decoded luma block) for the eight coding positions c0 .. c0 + 7
+   of chroma block blk, band `band`: the scan is nested (the first n*n coding positions of a
+   2n x 2n block are its n x n corner, and the band offsets coincide), so they are coding
+   positions c0 .. c0 + 7 of the same band of the co-located luma block, dequantised from its
+   chosen pulses exactly as od_pvq_synthesis_partial without reference writes them
+   (src/pvq.c:1081-1092).  Position 0 (the DC slot, never used by PVQ) comes out as 0. */
+__device__ __forceinline__ void lref_piece(const RJob &jb, int band, long blk, int c0, int (&rv)[8]) {
+  const long lblk = blk >= jb.lsplit ? blk - jb.lsplit : blk;
+  const int4 ch = reinterpret_cast<const int4 *>(jb.lchoice)[lblk*jb.lnb + band];   /* sel, qg, scale, qshift */
+  uint4 y4 = make_uint4(0, 0, 0, 0);
+  if (ch.y != 0) y4 = *reinterpret_cast<const uint4 *>(jb.ly + ((long)ch.x*jb.lnblocks + lblk)*jb.llen + c0);
+  const uint4 q4 = *reinterpret_cast<const uint4 *>(jb.lqmi + c0);
+  const unsigned yw[4] = {y4.x, y4.y, y4.z, y4.w};
+  const unsigned qw[4] = {q4.x, q4.y, q4.z, q4.w};
+#pragma unroll
+  for (int e = 0; e < 8; e++) {
+    const int yv = (int16_t)(yw[e >> 1] >> (16*(e & 1)));
+    const int qmi = (int16_t)(qw[e >> 1] >> (16*(e & 1)));
+    rv[e] = odq_shr_round(odq_mult16_32_q16(yv, ch.z)*qmi, ch.w);
+  }
 }
 
 struct Unc;
@@ -390,7 +423,10 @@ __global__ __launch_bounds__(kWave) void k_refb_prep_lane(RItems it) {
   const int cfl_enabled = is_keyframe && jb.pli != 0;
   const long base = block_base(jb, blk);
   const od_coeff *x0 = jb.coef + base;
-  const od_coeff *r0 = jb.ref + base;
+  /* the reference: a plane of the job's layout, or (keyframe chroma) taken straight from
+     the luma band stage - lref_piece */
+  const bool lref = jb.ly != nullptr;
+  const od_coeff *r0 = lref ? jb.coef + base : jb.ref + base;
   const int16_t *qmp = jb.qm + off;
   odhip_pvq_refband *rec = jb.rec + blk*nb_bands;
   int16_t *x16o = jb.x16 + blk*len;
@@ -408,7 +444,7 @@ __global__ __launch_bounds__(kWave) void k_refb_prep_lane(RItems it) {
 #pragma unroll
     for (int y = 0; y < 4; y++) {
       xr4[y] = *reinterpret_cast<const int4 *>(x0 + (long)y*w);
-      rr4[y] = *reinterpret_cast<const int4 *>(r0 + (long)y*w);
+      rr4[y] = lref ? make_int4(0, 0, 0, 0) : *reinterpret_cast<const int4 *>(r0 + (long)y*w);
     }
 #pragma unroll
     for (int i = 0; i < N; i++) {
@@ -428,7 +464,7 @@ __global__ __launch_bounds__(kWave) void k_refb_prep_lane(RItems it) {
 #pragma unroll
     for (int y = 0; y < 2; y++) {
       xr4[y] = *reinterpret_cast<const int4 *>(x0 + (long)y*w + 4);
-      rr4[y] = *reinterpret_cast<const int4 *>(r0 + (long)y*w + 4);
+      rr4[y] = lref ? make_int4(0, 0, 0, 0) : *reinterpret_cast<const int4 *>(r0 + (long)y*w + 4);
     }
 #pragma unroll
     for (int i = 0; i < N; i++) {
@@ -448,7 +484,7 @@ __global__ __launch_bounds__(kWave) void k_refb_prep_lane(RItems it) {
 #pragma unroll
     for (int y = 0; y < 4; y++) {
       xr2[y] = *reinterpret_cast<const int2 *>(x0 + (long)(4 + y)*w);
-      rr2[y] = *reinterpret_cast<const int2 *>(r0 + (long)(4 + y)*w);
+      rr2[y] = lref ? make_int2(0, 0) : *reinterpret_cast<const int2 *>(r0 + (long)(4 + y)*w);
     }
 #pragma unroll
     for (int i = 0; i < N; i++) {
@@ -466,8 +502,25 @@ __global__ __launch_bounds__(kWave) void k_refb_prep_lane(RItems it) {
     for (int i = 0; i < N; i++) {
       const long p = (long)kRScanXY[off + i][1]*w + kRScanXY[off + i][0];
       xv[i] = x0[p];
-      rv[i] = r0[p];
+      rv[i] = lref ? 0 : r0[p];
       qm[i] = qmp[i];
+    }
+  }
+  if (lref) {
+    /* coding order is what the luma stage keeps: whole 16-byte pieces */
+    if constexpr (N == 15) {
+      int lo[8];
+      int hi[8];
+      lref_piece(jb, band, blk, 0, lo);
+      lref_piece(jb, band, blk, 8, hi);
+#pragma unroll
+      for (int i = 0; i < N; i++) rv[i] = i + 1 < 8 ? lo[(i + 1) & 7] : hi[(i + 1) & 7];
+    }
+    else {
+      int pc[8];
+      lref_piece(jb, band, blk, off, pc);
+#pragma unroll
+      for (int i = 0; i < N; i++) rv[i] = pc[i & 7];
     }
   }
   int flip = 0;
@@ -620,7 +673,8 @@ __global__ __launch_bounds__(kWave) void k_refb_prep_row(RItems it) {
   const int cfl_enabled = is_keyframe && jb.pli != 0;
   const long base = block_base(jb, blk);
   const od_coeff *x0 = jb.coef + base;
-  const od_coeff *r0 = jb.ref + base;
+  const bool lref = jb.ly != nullptr;
+  const od_coeff *r0 = lref ? jb.coef + base : jb.ref + base;
   const int16_t *qmp = jb.qm + off + l*E;
   odhip_pvq_refband *rec = jb.rec + blk*nb_bands;
   int16_t *x16o = jb.x16 + blk*len + off;
@@ -638,9 +692,16 @@ __global__ __launch_bounds__(kWave) void k_refb_prep_row(RItems it) {
     const int pk = s_scan[l*E + e];
     const long p = (long)(pk >> 8)*w + (pk & 255);
     xv[e] = x0[p];
-    const int r = r0[p];
+    const int r = lref ? 0 : r0[p];
     rv[e] = flip ? -r : r;
     qm[e] = qmp[e];
+  }
+  if (lref) {
+    static_assert(E == 8, "one 16-byte piece of the luma stage's pulses per lane");
+    int pc[8];
+    lref_piece(jb, band, blk, off + l*E, pc);
+#pragma unroll
+    for (int e = 0; e < E; e++) rv[e] = flip ? -pc[e] : pc[e];
   }
 #pragma unroll
   for (int e = 0; e < E; e++) {
@@ -1634,6 +1695,52 @@ __global__ __launch_bounds__(kWave) void k_refb_search_regs(RItems it) {
    pulse vector, :539-544, share it) and .9*log2(ts) once per gain index; both are the very
    doubles odq_pvq_rate_fast forms, joined in its order. */
 constexpr int kLeanAux = 12;            /* per band: ts[3], lower[3], .9*log2(ts)[3] (two words each) */
+
+/* od_pvq_rate's pulse part is a function of (sum, k, n) alone and .9*log2(ts) of ts: for the
+   small pulse counts nearly every search ends with they are read from tables filled ONCE per
+   device by the very functions they replace (k_rate_fill: same code, same device log - the
+   values are identical, two logs and two divisions per search become one load).  NR = band
+   size; entries [k][sum], k = 1..kRateK, sum = 0..(NR - 1)*kRateK. */
+constexpr int kRateK = 32;
+constexpr int kRateTs = 64;
+template <int NR> struct RateTab { static constexpr int W = (NR - 1)*kRateK + 1; };
+__device__ double gRate8[(kRateK + 1)*RateTab<8>::W];
+__device__ double gRate15[(kRateK + 1)*RateTab<15>::W];
+__device__ double gRate32[(kRateK + 1)*RateTab<32>::W];
+__device__ double gRateTs[kRateTs];
+
+template <int NR>
+__device__ __forceinline__ double *rate_tab(void) {
+  return NR == 8 ? gRate8 : NR == 15 ? gRate15 : gRate32;
+}
+
+template <int NR>
+__global__ void k_rate_fill(void) {
+  constexpr int W = RateTab<NR>::W;
+  const int i = blockIdx.x*blockDim.x + threadIdx.x;
+  if (i >= (kRateK + 1)*W) return;
+  const int k = i/W;
+  const int sum = i - k*W;
+  rate_tab<NR>()[i] = k == 0 ? 0. : odq_pvq_rate_pulses(sum, k, NR);
+}
+
+__global__ void k_rate_ts_fill(void) {
+  const int ts = threadIdx.x;
+  if (ts < kRateTs) gRateTs[ts] = ts > 0 ? odq_pvq_rate_ts(ts) : 0.;
+}
+
+template <int NR>
+__device__ __forceinline__ double lean_rate_pulses(int sum, int k) {
+  if constexpr (NR == 8 || NR == 15 || NR == 32) {
+    if (k <= kRateK) return rate_tab<NR>()[k*RateTab<NR>::W + sum];
+  }
+  return odq_pvq_rate_pulses(sum, k, NR);
+}
+
+__device__ __forceinline__ double lean_rate_ts(int ts) {
+  if (ts > 0 && ts < kRateTs) return gRateTs[ts];
+  return odq_pvq_rate_ts(ts);
+}
 constexpr int kLeanWords = kSlots + kLeanAux;
 
 /* A band's candidate list in LDS: word s of the band at col[s*stride].  Theta candidate:
@@ -1657,7 +1764,7 @@ struct ListSink {
   __device__ __forceinline__ void gain(int gi, int, int ts, int lower) {
     lower_cur = lower;
     if (!writer) return;
-    const double l = odq_pvq_rate_ts(ts);
+    const double l = lean_rate_ts(ts);
     col[(kSlots + gi)*stride] = (uint32_t)ts;
     col[(kSlots + 3 + gi)*stride] = (uint32_t)lower;
     col[(kSlots + 6 + 2*gi)*stride] = (uint32_t)__double2loint(l);
@@ -1715,9 +1822,9 @@ __device__ __forceinline__ CandList refb_build_list(const RJob &jb, int band, co
 
 /* refb_loops without a single store: candidates from the LDS list, every searched
    candidate offered to the decider with its rate halves. */
-template <class V, class D>
+template <int NR, class V, class D>
 __device__ __forceinline__ void refb_loops_lean(const RJob &jb, int band, long blk,
- const odhip_pvq_refband &r, const CandList &cl, int nrate, double lambda, V &v, D &dec) {
+ const odhip_pvq_refband &r, const CandList &cl, double lambda, V &v, D &dec) {
   const int off = jb.off[band];
   const int n = jb.off[band + 1] - off;
   const int len = jb.len;
@@ -1758,7 +1865,7 @@ __device__ __forceinline__ void refb_loops_lean(const RJob &jb, int band, long b
       else if (k != prev_k) {
         cos_dist = v.search(n - 1, k, prev_k, ((qcg*(double)cg)*sin_prod)*s2, lambda);
         has = true;
-        prate = odq_pvq_rate_pulses(v.moment(), k, nrate);
+        prate = lean_rate_pulses<NR>(v.moment(), k);
       }
       prev_k = k;
       /* :548-552 */
@@ -1785,7 +1892,7 @@ __device__ __forceinline__ void refb_loops_lean(const RJob &jb, int band, long b
       if (k > ODHIP_PVQ_MAX_K) continue;
       const double cos_dist = v.search(n, k, prev_k, (qcg*(double)cg)*s2, lambda);
       prev_k = k;
-      const double prate = odq_pvq_rate_pulses(v.moment(), k, nrate);
+      const double prate = lean_rate_pulses<NR>(v.moment(), k);
       dist = (1.4*(qcg - cg))*(qcg - cg) + (qcg*(double)cg)*(2 - 2*cos_dist);
       dist *= s2;
       dec.offer(idx, false, i, -1, 0, k, 0, dist, prate, 0., true, v);
@@ -1895,7 +2002,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(3))) void
   RegVector<N> v;
   LeanDecide<N> dec;
   dec.init(r, jb, it.lambda, it.tol_scale);
-  refb_loops_lean(jb, band, blk, r, cl, N, it.lambda, v, dec);
+  refb_loops_lean<N>(jb, band, blk, r, cl, it.lambda, v, dec);
   const RefBest best = lean_best(dec, cl, jb.is_keyframe);
   if (best.yslot >= 0) {
     uint4 *p = reinterpret_cast<uint4 *>(jb.y + blk*jb.len + jb.off[band] - SH);
@@ -2069,7 +2176,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(3))) void
   const CandList cl = refb_build_list(jb, band, r, s_list + v.row, C, v.l == 0);
   LeanDecide<E> dec;
   dec.init(r, jb, it.lambda, it.tol_scale);
-  refb_loops_lean(jb, band, blk, r, cl, G*E, it.lambda, v, dec);
+  refb_loops_lean<G*E>(jb, band, blk, r, cl, it.lambda, v, dec);
   refb_finish_row<E, G>(it, job, jb, band, blk, r, dec, lean_best(dec, cl, jb.is_keyframe), v.l, live);
 }
 
@@ -2218,6 +2325,10 @@ int upload_tables_now(void) {
   }
   ODHIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(gRBandOf), band_of, sizeof(band_of)));
   od_rsqrt_fill_launch();
+  k_rate_fill<8><<<((kRateK + 1)*RateTab<8>::W + 255)/256, 256, 0, 0>>>();
+  k_rate_fill<15><<<((kRateK + 1)*RateTab<15>::W + 255)/256, 256, 0, 0>>>();
+  k_rate_fill<32><<<((kRateK + 1)*RateTab<32>::W + 255)/256, 256, 0, 0>>>();
+  k_rate_ts_fill<<<1, kRateTs, 0, 0>>>();
   ODHIP_TRY(hipDeviceSynchronize());
   return ODHIP_SUCCESS;
 }
@@ -2228,7 +2339,7 @@ int upload_tables(void) {
 
 /* mode 0: band stage; 1: choice + synthesis */
 int fill_job(RJob &d, const odhip_pvq_refjob &j, int mode) {
-  if (!j.d_coef || !j.d_ref || !j.q_band || !j.beta_band || j.bs < 0 || j.bs >= ODHIP_NBSIZES
+  if (!j.d_coef || (!j.d_ref && !j.luma) || !j.q_band || !j.beta_band || j.bs < 0 || j.bs >= ODHIP_NBSIZES
    || j.nplanes <= 0 || !j.band || !j.items || !j.y || !j.r16) {
     return ODHIP_EINVAL;
   }
@@ -2246,6 +2357,7 @@ int fill_job(RJob &d, const odhip_pvq_refjob &j, int mode) {
   if (j.w <= 0 || j.h <= 0 || j.w % n || j.h % n) return ODHIP_EINVAL;
   /* 16-byte row loads of the coefficient and reference planes */
   if (mode == 0 && (((uintptr_t)j.d_coef & 15) || ((uintptr_t)j.d_ref & 15))) return ODHIP_EINVAL;
+  if (j.luma && !j.d_ref && mode == 1) return ODHIP_EINVAL;   /* the synthesis into planes may copy the reference */
   memset(&d, 0, sizeof(d));
   d.coef = j.d_coef;
   d.ref = j.d_ref;
@@ -2287,6 +2399,24 @@ int fill_job(RJob &d, const odhip_pvq_refjob &j, int mode) {
       if (j.q_band2[i] < 1) return ODHIP_EINVAL;
       d.q2[i] = j.q_band2[i];
     }
+  }
+  if (j.luma) {
+    /* the luma level one size up over the same grid of blocks, nplanes or nplanes / 2 planes
+       (Cb and Cr share the prediction) */
+    const odhip_pvq_job &l = *j.luma;
+    if (l.bs != j.bs + 1 || l.w != 2*j.w || l.h != 2*j.h || !l.cands.y || !l.cands.choice || !l.d_qm_inv
+     || (l.nplanes != j.nplanes && 2*l.nplanes != j.nplanes) || !j.is_keyframe || j.pli == 0
+     || ((uintptr_t)l.cands.y & 15) || ((uintptr_t)l.cands.choice & 15) || ((uintptr_t)l.d_qm_inv & 15)) {
+      return ODHIP_EINVAL;
+    }
+    const int ln = 4 << l.bs;
+    d.ly = l.cands.y;
+    d.lchoice = l.cands.choice;
+    d.lqmi = l.d_qm_inv;
+    d.lsplit = (long)l.nplanes*d.bw*d.bh;
+    d.lnblocks = d.lsplit;
+    d.llen = ln*ln < OD_SCAN_LEN ? ln*ln : OD_SCAN_LEN;
+    d.lnb = OD_NBANDS[l.bs];
   }
   return ODHIP_SUCCESS;
 }

@@ -341,7 +341,7 @@ typedef struct {
    q_band / beta_band are HOST arrays [nb_bands]; everything prefixed d_ and the
    arrays inside `cands` are device memory.  d_qm is needed by the band stage,
    d_qm_inv and d_dq by select_synth; d_rate and d_qg are optional (NULL). */
-typedef struct {
+typedef struct odhip_pvq_job_s {
   const od_coeff *d_coef;
   int nplanes;
   int w;
@@ -629,6 +629,21 @@ typedef struct {
                                 d_coef; DC passed through; uncoded positions 0 */
   const int32_t *q_band2;    /* optional, HOST [nb]: as odhip_pvq_job.q_band2 - */
   int plane_split;           /* planes plane_split.. (the Cr half) use q_band2  */
+  const struct odhip_pvq_job_s *luma; /* optional (keyframe chroma): the chroma-from-luma reference
+                                taken STRAIGHT from the luma band stage instead of a
+                                reference plane - od_resample_luma_coeffs for luma blocks
+                                of 8x8 and larger, src/intra.c:97-108.  `luma` is the
+                                job of the luma level bs + 1 over the same picture(s)
+                                (planes 2w x 2h, nplanes or nplanes / 2 of them: Cb and
+                                Cr share the prediction) after its choice
+                                (odhip_pvq_choose_multi / the priced band stage): its
+                                cands.y, cands.choice and d_qm_inv are read by the
+                                preparation kernels, which dequantise the co-located
+                                coefficients on the fly.  d_ref may then be NULL (the
+                                synthesis into planes, odhip_pvq_ref_select_synth_multi,
+                                still needs it).  What odhip_cfl_refs_from_luma would
+                                have written, without the planes: 0.8 GB of traffic per
+                                16-frame step and a kernel less.                     */
 } odhip_pvq_refjob;
 
 /* At most 8 jobs per call, all on one stream.  The stage keeps per-call state
@@ -1015,7 +1030,9 @@ enum {
   ODHIP_PIPE_BUF_Y,         /* pulse vectors                                           */
   ODHIP_PIPE_BUF_CHOICE,    /* choice records                                          */
   ODHIP_PIPE_BUF_ITEMS,     /* with-reference candidates (3 planes of 16-byte vectors) */
-  ODHIP_PIPE_BUF_REF,       /* chroma-from-luma reference planes [parity][level]       */
+  ODHIP_PIPE_BUF_REF,       /* inter mode: the prediction pyramid.  (Keyframe chroma takes
+                               its chroma-from-luma reference in place from the luma
+                               choices, odhip_pvq_refjob.luma: no plane exists)        */
   ODHIP_PIPE_BUF_RATE       /* rate table (allocated on first request)                 */
 };
 odhip_pipe *odhip_pipe_create(const odhip_pipe_config *cfg);
@@ -1037,6 +1054,9 @@ int odhip_pipe_step(odhip_pipe *p);
 int odhip_pipe_flush(odhip_pipe *p);
 int odhip_pipe_sync(odhip_pipe *p);
 int odhip_pipe_stage(odhip_pipe *p, int stage, int parity);
+/* parity: with chroma from luma the luma pulse vectors / choice records alternate between
+   two sets from step to step (the chroma chain of step i reads them while the luma chain of
+   step i + 1 writes the next); 0 / 1 selects one, -1 the set of the last odhip_pipe_step. */
 int odhip_pipe_buffer(odhip_pipe *p, int what, int set, int level, int parity, void **d_ptr,
  size_t *bytes);
 int odhip_pipe_read(odhip_pipe *p, void *host, const void *d_ptr, size_t bytes);
