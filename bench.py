@@ -140,11 +140,12 @@ def copy_ceiling_gbs(device, n=10):
 
 
 def ref128_bytes(D, pipe):
-    """Algorithmic bytes and band count of one k_refb_search_row<8,16> launch, counted
-    from the records and candidate vectors the last step left: per band the 64 B record,
-    the 254 B reflected vector (+ 256 B x16 when the no-reference candidates run), per
-    candidate 16 B in + 16 B out (+ 16 B result when searched), and 256 B of pulses per
-    search that stored its vector."""
+    """Algorithmic bytes and band count of one k_refb_lean_row<8,16> launch (the decided
+    with-reference stage: nothing per candidate reaches memory), counted from the choice
+    records the last step left: per 128-coefficient band the 64 B preparation record, the
+    254 B reflected vector and the 256 B QM-scaled vector in (an upper bound: a band reads
+    one or both), 4 B of sort index, the 64 B choice record out, and 256 B of pulses when the
+    winner places any."""
     total = 0
     bands = 0
     for bs in range(4):
@@ -153,18 +154,10 @@ def ref128_bytes(D, pipe):
         if not which:
             continue
         B = pipe.nblocks(1, bs)
-        rec = pipe.read(D.BUF_BAND, 1, bs, dtype=np.int32).reshape(B, nb, 16)
-        items = pipe.read(D.BUF_ITEMS, 1, bs, dtype=np.int32).reshape(3, nb, D.REF_SLOTS, B, 4)
-        slot = np.arange(D.REF_SLOTS).reshape(-1, 1)
+        ch = pipe.read(D.BUF_CHOICE, 1, bs, dtype=np.int32).reshape(B, nb, 16)
         for b in which:
-            nitems = rec[:, b, 10].astype(np.int64)
-            ntheta = rec[:, b, 11].astype(np.int64)
-            tail = items[1, b]                               # [slot][B][4]
-            valid = slot < nitems.reshape(1, -1)
-            searched = valid & ((tail[:, :, 2] & 1) != 0)
-            stored = searched & (tail[:, :, 3] == slot)
-            total += int((64 + 254 * (ntheta > 0) + 256 * (nitems > ntheta) + 32 * nitems).sum())
-            total += int(16 * searched.sum() + 256 * stored.sum())
+            stored = (ch[:, b, 6] == 0) & (ch[:, b, 9] >= 0)
+            total += B * (64 + 254 + 256 + 4 + 64) + 256 * int(stored.sum())
             bands += B
     return total, bands
 
@@ -248,7 +241,7 @@ def cpu_worker(args):
     print(json.dumps({"blocks": blocks * len(rates), "seconds": busy}))
 
 
-def cpu_baseline(D, qt, chroma_cfl, args, gpu_frame0, timed_recon=None):
+def cpu_baseline(D, qt, chroma_cfl, args, gpu_frame0, timed_recon=None, timed_dec=None):
     """cpu_baseline (one pinned core, median of >= 5 pictures), the all-cores figure
     (one pinned process per core, independent pictures - all-intra frames are
     independent), and the whole-frame verification of the GPU path against it."""
@@ -335,6 +328,42 @@ def cpu_baseline(D, qt, chroma_cfl, args, gpu_frame0, timed_recon=None):
                 "level of Y, Cb, Cr from the GPU stages (host-priced choice) == the reference C "
                 "functions' (cpu_baseline leg)")
     ver = {"verified": not bad, "what": what, "planes_levels_compared": 13, "mismatches": bad}
+    if timed_dec is not None:
+        # north_star's "coefficients and PVQ pulse vectors": the coded gain index, itheta,
+        # max_theta, K and the pulse vector of EVERY band of every block of every level of
+        # frame 0 as the TIMED pipeline left them, against the reference's pvq_theta
+        want = []
+        C.cpu_frame(qt, gpu_frame0, PIC_W, PIC_H, chroma_cfl=chroma_cfl, decisions=want)
+        dbad = C.compare_decisions(timed_dec, want, frame=0, frames=args.frames)
+        nbands = int(sum(b.shape[0] * b.shape[1] for plane in want for (_, b) in plane))
+        ver["decisions"] = {"verified": not dbad, "bands_compared": nbands, "mismatches": dbad,
+                            "what": "gain index, itheta, max_theta, K and pulse vector of every band of frame 0 "
+                                    "(timed pipeline) == the reference's pvq_theta (ref_stage_set_dump)"}
+        ver["verified"] = bool(ver["verified"] and not dbad)
+    # the partition the reference encoder really codes for this picture (report
+    # the coded blocks beside the evaluated ones): the whole encoder, -v 20, complexity 7
+    coded = None
+    try:
+        r = ref()
+        frame = np.concatenate([np.ascontiguousarray(p).ravel() for p in gpu_frame0])
+        out = np.zeros(4 << 20, np.uint8)
+        pk = np.zeros(8, np.int64)
+        t0 = time.perf_counter()
+        n = r.ref_encode_yuv420(frame.ctypes.data_as(ctypes.c_void_p), PIC_W, PIC_H, 1, 20, 7, 0,
+                                out.ctypes.data_as(ctypes.c_void_p), ctypes.c_long(out.size),
+                                pk.ctypes.data_as(ctypes.c_void_p))
+        dt = time.perf_counter() - t0
+        cb = (ctypes.c_long * 2)()
+        r.ref_last_coded_blocks(cb)
+        if n == 1:
+            coded = {"luma": int(cb[0]), "chroma_per_plane": int(cb[1]), "total": int(cb[0] + 2 * cb[1]),
+                     "packet_bytes": int(pk[0]), "encoder_seconds": dt,
+                     "note": "final partition of the unmodified reference encoder (state.bsize after the "
+                             "block-size RDO) on frame 0 of the batch; the metric counts EVALUATED blocks "
+                             "(every block of every level, what the RDO prices), of which these are coded"}
+    except Exception as e:      # noqa: BLE001 - an auxiliary figure must not take the line down
+        coded = {"error": repr(e)}
+    ver["coded_blocks_frame0"] = coded
     if simd is not None:
         base["simd_build"] = simd
     return base, host, ver
@@ -407,21 +436,58 @@ def pipeline_digest(D, pipe):
     return h.hexdigest()
 
 
-def load_pmc(tag_order=("r2", "r1")):
+def source_hash():
+    """SHA-256 over the kernel sources (daala_amd/csrc, sorted): the committed PMC counters
+    are properties of THESE sources - tools/pmc_summary.py stores the hash beside them and
+    the counters are dropped when it differs."""
+    import hashlib
+    h = hashlib.sha256()
+    root = os.path.join(ROOT, "daala_amd", "csrc")
+    for dirpath, _, files in sorted(os.walk(root)):
+        for f in sorted(files):
+            if f.endswith((".hip", ".cuh", ".h")):
+                h.update(f.encode())
+                with open(os.path.join(dirpath, f), "rb") as fh:
+                    h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def load_pmc(tag_order=("r3",)):
+    """(per-kernel counters, source file, stale?) of the committed rocprofv3 --pmc passes."""
     for tag in tag_order:
         path = os.path.join(ROOT, "profiles", "%s_pmc_traffic.json" % tag)
         try:
             with open(path) as f:
-                return json.load(f)["kernels"], "profiles/%s_pmc_traffic.json" % tag
-        except (OSError, ValueError, KeyError):
+                doc = json.load(f)
+        except (OSError, ValueError):
             continue
-    return {}, None
+        if doc.get("source_hash") != source_hash():
+            return {}, "profiles/%s_pmc_traffic.json" % tag, True
+        return doc["kernels"], "profiles/%s_pmc_traffic.json" % tag, False
+    return {}, None, False
 
 
 # gfx950: 256 CUs x 4 SIMDs; one fp64 VALU wave-instruction issues in about 4 cycles per
 # SIMD at the 2.4 GHz peak clock (tools/ubench/fp64_rate.hip measures 4.9-5.2 for
 # v_add/mul/fma_f64, DESIGN.md) -> the issue-rate roof used for the search kernels
 VALU_PEAK_GINSTR = 1024 * 2.4 / 4.0
+
+
+def step_counters(pmc, src, stale, step_ms):
+    """Whole-step figures from the committed counter passes: VALU issue utilisation = SUM
+    SQ_INSTS_VALU x 4 cycles / 1024 SIMDs / 2.4 GHz / step, and the HBM bytes a step moves."""
+    if stale:
+        return {"stale": True, "why": "%s was collected from other kernel sources (source_hash differs): "
+                                      "dropped" % src}
+    if not pmc:
+        return None
+    valu = sum(e.get("valu_wave_instructions") or 0 for e in pmc.values())
+    hbm = sum(e.get("hbm_bytes_per_launch") or 0 for e in pmc.values())
+    return {"valu_wave_instructions_per_step": valu,
+            "valu_issue_utilisation": round(valu / (VALU_PEAK_GINSTR * 1e9) / (step_ms * 1e-3), 4),
+            "hbm_bytes_per_step": hbm,
+            "hbm_GBs_average": round(hbm / (step_ms * 1e-3) / 1e9, 1),
+            "source": "%s (every kernel of a step is launched once; per-launch counters summed)" % src}
 
 
 def search_roofline(name, kernel_prefix, ms_excl, ms_in_step, launches, alg_bytes, bands, step_ms, pmc, src):
@@ -457,6 +523,174 @@ def search_roofline(name, kernel_prefix, ms_excl, ms_in_step, launches, alg_byte
     return out
 
 
+
+def write_y4m(path, nframes, w=PIC_W, h=PIC_H):
+    """The bench generator's frames 0 .. nframes-1 as a YUV4MPEG2 file (what
+    encoder_example is fed, examples/encoder_example.c:89-160)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import _shard_encode as S
+    with open(path, "wb") as f:
+        f.write(("YUV4MPEG2 W%d H%d F30:1 Ip A1:1 C420jpeg\n" % (w, h)).encode())
+        for i in range(nframes):
+            f.write(b"FRAME\n")
+            f.write(S.frame_yuv(i, w, h).tobytes())
+
+
+def read_y4m_owned(D, path, rank, world, limit):
+    """Frames rank, rank + world, ... (< limit) of a Y4M file through the library's reader
+    (odhip_y4m_open / _read / _skip): ({global index: planar 4:2:0 bytes}, w, h)."""
+    L = D.lib()
+    L.odhip_y4m_open.restype = ctypes.c_void_p
+    w, h, fn, fd, err = (ctypes.c_int() for _ in range(5))
+    y = L.odhip_y4m_open(path.encode(), ctypes.byref(w), ctypes.byref(h), ctypes.byref(fn), ctypes.byref(fd),
+                         ctypes.byref(err))
+    if not y:
+        raise SystemExit("cannot read %s as progressive 8-bit 4:2:0 YUV4MPEG2 (code %d)" % (path, err.value))
+    w, h = w.value, h.value
+    cw, chh = (w + 1) >> 1, (h + 1) >> 1
+    out = {}
+    i = 0
+    while i < limit:
+        if i % world == rank:
+            fr = np.empty(w * h + 2 * cw * chh, np.uint8)
+            rc = L.odhip_y4m_read(ctypes.c_void_p(y), fr[:w * h].ctypes.data_as(ctypes.c_void_p),
+                                  fr[w * h:w * h + cw * chh].ctypes.data_as(ctypes.c_void_p),
+                                  fr[w * h + cw * chh:].ctypes.data_as(ctypes.c_void_p))
+            if rc == 1:
+                out[i] = fr
+        else:
+            rc = L.odhip_y4m_skip(ctypes.c_void_p(y))
+        if rc == 0:
+            break
+        if rc < 0:
+            raise SystemExit("%s: loss of framing at frame %d (code %d)" % (path, i, rc))
+        i += 1
+    L.odhip_y4m_close(ctypes.c_void_p(y))
+    return out, w, h, i
+
+
+def seq_encode_worker(args):
+    """Child process of encode_mode: the plain C reference encoder (nothing bound) on the
+    first N frames of the Y4M file, sequentially; prints the packet digest."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import _shard_encode as S
+    import daala_amd as D
+    path, n = args.seq_encode[0], int(args.seq_encode[1])
+    frames, w, h, got = read_y4m_owned(D, path, 0, 1, n)
+    r = ctypes.CDLL(os.path.join(ROOT, "oracle", "_ref", "libdaalaref.so"))
+    t0 = time.perf_counter()
+    packets = S.encode_frames(r, list(range(got)), [frames[i] for i in range(got)], w, h)
+    dt = time.perf_counter() - t0
+    print(json.dumps({"digest": S.digest([packets[i] for i in range(got)]), "frames": got, "seconds": dt}))
+    return 0
+
+
+def encode_mode(args, D, torch, dist, rank, world, local_rank):
+    """BASELINE configs[4]: an N-frame 1080p all-intra encode, frames sharded over the ranks
+    (frame i -> rank i mod world; all-intra frames are independent, src/encode.c:303-308,
+    :3029, :3080), every rank the reference encoder (its own host C: entropy coding, pricing,
+    block-size RDO - test infrastructure here, oracle/_ref) with the batched GPU stage bound
+    behind it (one batched pyramid per plane, the PVQ band stage of keyframe luma, the deringing
+    level search), input through the library's Y4M reader, coded packets gathered to rank 0
+    (all_gather of sizes + padded all_gather of bytes over RCCL).  Rank 0 checks a prefix
+    against the plain C encoder run sequentially and prints one JSON line: frames per second
+    of the whole job.  No 1 -> 8 curve exists until a multi-GPU box runs this."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import _shard_encode as S
+    from daala_amd.shard import gather_packets
+    if not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libdaalaref.so")):
+        raise SystemExit("--encode-frames needs the reference encoder (oracle/_ref, built by build())")
+    nframes = args.encode_frames
+    path = args.y4m
+    made = False
+    if path is None:
+        path = "/tmp/odhip_bench_%d.y4m" % nframes
+        if rank == 0:
+            write_y4m(path, nframes)
+        made = True
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    frames, w, h, total = read_y4m_owned(D, path, rank, world, nframes)
+    t_read = time.perf_counter() - t0
+    nframes = min(nframes, total)
+    owned = sorted(frames)
+    # the deringing level search from batched passes as well (odhip_dering_cache)
+    os.environ["ODHIP_INTERPOSE_DERING_CACHE"] = "1"
+    r, ipo = S.load_batched_encoder(w, h, device=local_rank)
+    # one frame first (allocations, first-use tables), outside the timed region
+    if owned:
+        S.encode_frames(r, owned[:1], [frames[owned[0]]], w, h)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    local = S.encode_frames(r, owned, [frames[i] for i in owned], w, h)
+    torch.cuda.synchronize()
+    t_enc = time.perf_counter() - t0
+    if dist is not None:
+        dist.barrier()
+    t_all = time.perf_counter() - t0
+    t1 = time.perf_counter()
+    packets = gather_packets(local, nframes) if dist is not None else [local[i] for i in range(nframes)]
+    torch.cuda.synchronize()
+    t_gather = time.perf_counter() - t1
+    tt = torch.tensor([t_all, t_enc, t_gather, t_read], dtype=torch.float64,
+                      device="cuda" if dist is not None and dist.get_backend() == "nccl" else "cpu")
+    if dist is not None:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    if rank != 0:
+        return 0
+    st = S.band_stats(ipo)
+    load_ms = ctypes.c_double.in_dll(ipo, "odhip_interposed_load_ms").value
+    nprefix = min(nframes, args.encode_check)
+    check = None
+    if nprefix > 0:
+        import subprocess
+        e = dict(os.environ)
+        for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "ODHIP_INTERPOSE_PASSTHROUGH"):
+            e.pop(k, None)
+        pr = subprocess.run([sys.executable, os.path.abspath(__file__), "--seq-encode", path, str(nprefix)],
+                            capture_output=True, text=True, timeout=3600, env=e)
+        if pr.returncode == 0:
+            ref_out = json.loads(pr.stdout.strip().splitlines()[-1])
+            check = {"frames": ref_out["frames"],
+                     "packets_equal_sequential_c_encoder": ref_out["digest"] == S.digest(packets[:ref_out["frames"]]),
+                     "c_encoder_frames_per_s_one_core": ref_out["frames"] / ref_out["seconds"]}
+        else:
+            check = {"error": pr.stderr[-500:]}
+    t_job = float(tt[0].item())
+    line = {
+        "metric": "1080p all-intra encode frames/s (frame-sharded over the GPUs of one node)",
+        "value": nframes / t_job, "unit": "frames/s", "n_gpus": world, "frames": nframes,
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "data": "synthetic",
+        "dtype": "int32 (lifting DCT/filters) + f64 (PVQ search)",
+        "config": {"workload": "configs[4]: %d-frame %dx%d all-intra encode (-v 20, complexity 7), frame i -> "
+                               "rank i mod %d, Y4M in (odhip_y4m_*), packets gathered to rank 0" % (nframes, w, h, world),
+                   "encoder": "the reference's own encoder (host C: entropy coding, od_pvq_rate on the live "
+                              "adaptive state, block-size RDO) with the batched GPU stage bound behind it: "
+                              "pyramids of all planes, the PVQ band stage of keyframe luma, the deringing "
+                              "level search (tests/interpose; INTEGRATION.md section 7)"},
+        "seconds": {"job_max_over_ranks": t_job, "encode_max_over_ranks": float(tt[1].item()),
+                    "gather": float(tt[2].item()), "y4m_read_max_over_ranks": float(tt[3].item())},
+        "packet_bytes": int(sum(len(p) for p in packets)),
+        "rank0": {"frames": len(owned), "bands_from_batch": st[0], "bands_left_to_reference": st[1] + st[2],
+                  "searches_saved": st[3], "batched_gpu_pass_ms_per_frame": load_ms / max(1, len(owned) + 1),
+                  "stage_blocks_per_s": blocks_per_frame() * (len(owned) + 1) / max(load_ms * 1e-3, 1e-9)},
+        "prefix_check": check,
+        "note": "frames/s of the whole job (barrier to barrier, max over ranks); the host half of every rank is "
+                "the reference's sequential entropy coder, which bounds a rank at ~1 frame/s - the GPU stage "
+                "takes %.0f ms of each frame (rank0.batched_gpu_pass_ms_per_frame)" % (load_ms / max(1, len(owned) + 1)),
+    }
+    print(json.dumps(line))
+    if made:
+        try:
+            os.remove(path)
+        except OSError:
+            pass
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -474,6 +708,16 @@ def main():
     ap.add_argument("--no-shard-check", action="store_true",
                     help="N > 1: skip the sharded real-encoder check (frames over ranks, RCCL gather)")
     ap.add_argument("--cpu-worker", type=int, default=None, help=argparse.SUPPRESS)
+    ap.add_argument("--encode-frames", type=int, default=0,
+                    help="BASELINE configs[4] instead of the stage benchmark: encode this many 1080p frames "
+                         "(300 in the config), frame-sharded over the ranks, with the batched GPU stage behind "
+                         "the reference encoder; prints frames/s of the whole job")
+    ap.add_argument("--y4m", default=None, help="--encode-frames: a YUV4MPEG2 file to encode (default: the "
+                                                "bench generator's frames, written to /tmp)")
+    ap.add_argument("--encode-check", type=int, default=2,
+                    help="--encode-frames: how many leading frames rank 0 re-encodes with the plain C encoder "
+                         "(sequentially, one core) to compare the gathered packets with")
+    ap.add_argument("--seq-encode", nargs=2, default=None, help=argparse.SUPPRESS)
     ap.add_argument("--content", choices=sorted(CONTENT), default="checker",
                     help="synthetic picture generator: 'checker' (smooth texture + 32-pixel checker "
                          "edges + uniform noise, independent chroma) or 'natural' (cosines + AR(1) "
@@ -485,6 +729,8 @@ def main():
     args = ap.parse_args()
     if args.cpu_worker is not None:
         return cpu_worker(args)
+    if args.seq_encode is not None:
+        return seq_encode_worker(args)
 
     import torch
     import daala_amd as D
@@ -512,6 +758,11 @@ def main():
         else:
             dist.init_process_group(backend=backend)
     device = torch.device("cuda", local_rank)
+    if args.encode_frames > 0:
+        rc = encode_mode(args, D, torch, dist, rank, world, local_rank)
+        if dist is not None:
+            dist.destroy_process_group()
+        return rc
 
     cfl = not args.chroma_noref
     qt = D.QuantTables.load()
@@ -562,10 +813,43 @@ def main():
     # what the timed steps left in the reconstruction buffers (for `verified`), before
     # anything else runs on the pipe
     timed_recon = None
+    timed_dec = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and price:
         F = args.frames
         timed_recon = [[pipe.read(D.BUF_RECON, 0, bs).reshape(F, H, W) for bs in range(5)],
                        [pipe.read(D.BUF_RECON, 1, bs).reshape(2 * F, H // 2, W // 2) for bs in range(4)]]
+        # ... and what it decided: gain index, theta, K and pulse vector of every band
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import _pipeline_check as C0
+        timed_dec = C0.gpu_decisions(D, pipe)
+    # configs[1] says "single 1920x1080 frame": the same step with ONE picture per step
+    # (latency-bound) - throughput of pipelined one-picture steps and the
+    # latency of one step from enqueue to pixels
+    single = None
+    if rank == 0 and not args.no_streaming:
+        p1 = D.Pipe(qt, 1, PIC_W, PIC_H, chroma_cfl=cfl, device=local_rank, price=price)
+        p1.set_pictures(luma_pic[:1], np.ascontiguousarray(chroma_pic[[0, args.frames]]))
+        for _ in range(3):
+            p1.step()
+        p1.flush()
+        p1.sync()
+        s0 = time.perf_counter()
+        for _ in range(20):
+            p1.step()
+        p1.flush()
+        p1.sync()
+        thr = (time.perf_counter() - s0) / 20
+        s0 = time.perf_counter()
+        for _ in range(10):
+            p1.step()
+            p1.flush()
+            p1.sync()
+        lat = (time.perf_counter() - s0) / 10
+        p1.destroy()
+        single = {"frames_per_step": 1, "ms_per_step_pipelined": thr * 1e3, "blocks_per_s": blocks_per_frame() / thr,
+                  "latency_ms_enqueue_to_pixels": lat * 1e3,
+                  "note": "one 1920x1080 picture per step: ~60 kernel launches over 260 610 blocks - launch / "
+                          "latency bound, which is why the metric batches frames"}
     # A stream of pictures instead of resident ones (auxiliary, never `value`): every step
     # codes pictures that arrive from pinned host memory through odhip_pipe_feed, on the
     # pipe's copy stream, while the previous step computes.
@@ -637,8 +921,8 @@ def main():
                 ent["achieved_GBs"] = round(ab[key] / (ms * 1e-3) / 1e9, 1)
                 ent["frac_of_hbm_peak"] = round(ent["achieved_GBs"] / HBM_PEAK_GBS, 4)
             kernels[key] = ent
-        pmc, pmc_src = load_pmc()
-        if args.frames != DEFAULT_FRAMES or not cfl or args.content != "checker":
+        pmc, pmc_src, pmc_stale = load_pmc()
+        if args.frames != DEFAULT_FRAMES or not cfl or args.content != "checker" or not price:
             pmc, pmc_src = {}, None       # the committed counters are of the default command
         # roofline = the single kernel with the largest EXCLUSIVE time among the kernels
         # the library brackets: the two K-pulse searches of the 128-coefficient bands.
@@ -658,8 +942,9 @@ def main():
         roof_ref = None
         if cfl and ref_search_ms:
             roof_ref = search_roofline(
-                "k_refb_search_row<8,16> (with-reference candidate chains of the 128-coefficient "
-                "chroma bands, one band per 16-lane row)", "k_refb_search_row<8, 16>",
+                "k_refb_lean_row<8,16> (with-reference candidate chains of the 128-coefficient chroma "
+                "bands, one band per 16-lane row, the band decided inside the search)",
+                "k_refb_lean_row<8, 16>" if price else "k_refb_search_row<8, 16>",
                 float(np.mean(ref_search_excl)), float(np.mean(ref_search_ms)), len(ref_search_ms),
                 r_bytes, r_bands, step_ms, pmc, pmc_src)
             if roof_ref["avg_ms_per_launch"] >= roof_noref["avg_ms_per_launch"]:
@@ -737,13 +1022,15 @@ def main():
             "theta_margin_reruns": pipe.theta_reruns(),
             "price_margin_reruns": pipe.price_reruns() if price else None,
             "streaming_input": streaming,
+            "single_frame_step": single,
+            "step_counters": step_counters(pmc, pmc_src, pmc_stale, step_ms),
             "kernels": kernels,
         }
         if shard_check is not None:
             line["sharded_encode_check"] = shard_check
         if world == 1 and not args.no_cpu_baseline:
             frame0 = [luma_pic[0], chroma_pic[0], chroma_pic[args.frames]]
-            base, host, ver = cpu_baseline(D, qt, cfl, args, frame0, timed_recon)
+            base, host, ver = cpu_baseline(D, qt, cfl, args, frame0, timed_recon, timed_dec)
             if base is not None:
                 line["cpu_baseline"] = base
                 line["speedup_vs_cpu_baseline"] = line["value"] / base["value"]
@@ -752,6 +1039,7 @@ def main():
                 line["speedup_vs_all_host_cores"] = line["value"] / host["value"]
             line["verified"] = ver["verified"]
             line["verification"] = ver
+            line["coded_blocks_per_frame"] = ver.pop("coded_blocks_frame0", None)
         print(json.dumps(line))
     pipe.destroy()
     if dist is not None:

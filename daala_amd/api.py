@@ -681,10 +681,32 @@ def pvq_ref_select_synth_multi(jobs, pvq_norm_lambda):
            "odhip_pvq_ref_select_synth_multi")
 
 
+# Test hooks live in the library's contexts (odhip_ctx_set_test_hooks); this module keeps the
+# values the tests asked for and applies them to the calling thread's current context and to
+# every live Pipe (and to Pipes made later).
+_hooks = {"margin": 0.0, "perturb": 0, "tol": 1.0}
+_pipes = None
+
+
+def _apply_hooks():
+    global _pipes
+    import weakref
+    if _pipes is None:
+        _pipes = weakref.WeakSet()
+    L = lib()
+    args = (ctypes.c_double(_hooks["margin"]), int(_hooks["perturb"]), ctypes.c_double(_hooks["tol"]))
+    _check(L.odhip_ctx_set_test_hooks(None, *args), "odhip_ctx_set_test_hooks")
+    for p in list(_pipes):
+        if p.h:
+            _check(L.odhip_pipe_set_test_hooks(p._p(), *args), "odhip_pipe_set_test_hooks")
+
+
 def pvq_ref_set_theta_margin(margin, perturb=False):
-    f = lib().odhip_pvq_ref_set_theta_margin
-    f.restype = None
-    f(ctypes.c_double(margin), int(bool(perturb)))
+    """Test hook (per context in the library): the device-acos uncertainty margin (<= 0: the
+    default) and a deliberately wrong device theta for the listed bands."""
+    _hooks["margin"] = float(margin)
+    _hooks["perturb"] = int(bool(perturb))
+    _apply_hooks()
 
 
 def pvq_ref_theta_probe(corr):
@@ -925,6 +947,16 @@ class Pipe:
         self.chroma_cfl = bool(chroma_cfl)
         self.fpr_bits = int(fpr_bits)
         self.inter = bool(inter)
+        # test hooks the tests asked for (module state above) reach this pipe's contexts too
+        global _pipes
+        if _pipes is None:
+            import weakref
+            _pipes = weakref.WeakSet()
+        _pipes.add(self)
+        if _hooks["margin"] > 0 or _hooks["perturb"] or _hooks["tol"] != 1.0:
+            _check(L.odhip_pipe_set_test_hooks(self._p(), ctypes.c_double(_hooks["margin"]),
+                                               int(_hooks["perturb"]), ctypes.c_double(_hooks["tol"])),
+                   "odhip_pipe_set_test_hooks")
 
     def _p(self):
         return ctypes.c_void_p(self.h)
@@ -1080,7 +1112,6 @@ def compute_dist(x, y, bs, use_masking=1, flat_qm=0, coded_quantizer=40):
 
 def set_price_tol_scale(scale):
     """Test hook: multiplies the margin inside which a priced choice is left to the host
-    libm (odhip_pvq_price_set_tol_scale / odhip_pvq_ref_price_set_tol_scale); 1 restores it."""
-    L = lib()
-    L.odhip_pvq_price_set_tol_scale(ctypes.c_double(float(scale)))
-    L.odhip_pvq_ref_price_set_tol_scale(ctypes.c_double(float(scale)))
+    libm (odhip_ctx_set_test_hooks on the current context and every live Pipe); 1 restores it."""
+    _hooks["tol"] = float(scale)
+    _apply_hooks()

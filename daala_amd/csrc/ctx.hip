@@ -103,6 +103,17 @@ extern "C" int odhip_ctx_set_fpr(odhip_ctx *ctx, int on) {
   return ODHIP_SUCCESS;
 }
 
+/* Test hooks of one context (NULL: the calling thread's current context). */
+extern "C" int odhip_ctx_set_test_hooks(odhip_ctx *ctx, double theta_margin, int theta_perturb,
+ double price_tol_scale) {
+  if (!ctx) ctx = odhip_ctx_current();
+  if (!ctx) return ODHIP_EINVAL;
+  ctx->theta_margin = theta_margin;
+  ctx->theta_perturb = theta_perturb != 0;
+  ctx->price_tol_scale = price_tol_scale;
+  return ODHIP_SUCCESS;
+}
+
 extern "C" int odhip_ctx_get_fpr(const odhip_ctx *ctx) {
   return ctx ? ctx->fpr : ODHIP_EINVAL;
 }

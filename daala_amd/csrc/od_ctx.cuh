@@ -27,6 +27,10 @@ struct odhip_ctx {
   int device;
   int serial;              /* odhip_ctx_set_serial: no internal side streams */
   int fpr;                 /* odhip_ctx_set_fpr: picture planes hold int16 samples at 12 bits */
+  /* odhip_ctx_set_test_hooks (tests only; per context, nothing process-wide) */
+  double theta_margin;     /* <= 0: the default margin of the device acos */
+  int theta_perturb;       /* a deliberately wrong device theta for listed bands */
+  double price_tol_scale;  /* <= 0: 1; multiplies the priced choice's decision margin */
   void *slot[ODHIP_SLOT_COUNT];
   void (*drop[ODHIP_SLOT_COUNT])(void *);
 };

@@ -1016,6 +1016,16 @@ extern "C" double odhip_pipe_host_wait_ms(const odhip_pipe *p) {
   return p ? p->wait_ms : 0;
 }
 
+extern "C" int odhip_pipe_set_test_hooks(odhip_pipe *p, double theta_margin, int theta_perturb,
+ double price_tol_scale) {
+  if (!p) return ODHIP_EINVAL;
+  for (int i = 0; i < 2; i++) {
+    const int rc = odhip_ctx_set_test_hooks(p->ctx[i], theta_margin, theta_perturb, price_tol_scale);
+    if (rc) return rc;
+  }
+  return ODHIP_SUCCESS;
+}
+
 extern "C" long odhip_pipe_price_reruns(const odhip_pipe *p) {
   return p ? p->price_reruns : 0;
 }

@@ -1066,7 +1066,6 @@ __global__ __launch_bounds__(256) void k_cfl_ref_tf(Items it, CflOut out) {
 
 /* ---- host side ----------------------------------------------------------------- */
 odhip_device_once g_tables_once;
-double g_price_tol_scale = 1.;   /* test hook (odhip_pvq_price_set_tol_scale): process-wide */
 
 int upload_tables_now(void) {
   short inv[32*32];
@@ -1127,6 +1126,7 @@ struct BandState {
   hipEvent_t join[2] = {nullptr, nullptr};
   bool serial = false;             /* the context's setting, refreshed per call    */
   bool sort_dirty = false;         /* the sort histograms may hold counts of a failed call */
+  double tol_scale = 1.;           /* odhip_ctx_set_test_hooks */
   bool prof_on = false;            /* odhip_pvq_profile                            */
   bool prof_made = false;
   int prof_n = 0;
@@ -1167,6 +1167,7 @@ int band_state(BandState **out) {
     ODHIP_TRY(hipMemset(st->d_pcount, 0, sizeof(unsigned)));
   }
   st->serial = ctx->serial != 0;
+  st->tol_scale = ctx->price_tol_scale > 0 ? ctx->price_tol_scale : 1.;   /* test hook of the context */
   *out = st;
   return ODHIP_SUCCESS;
 }
@@ -1322,7 +1323,7 @@ void items_begin(Items &it, const BandState &st, double lambda) {
   it.sort = st.d_sort;
   it.pcount = st.d_pcount;
   it.plist = st.d_plist;
-  it.tol_scale = g_price_tol_scale;
+  it.tol_scale = st.tol_scale;
   const char *e = getenv("ODHIP_PVQ_FORCE_SEQ");
   it.reserved = e && e[0] == '1';   /* pair-mode search: always take the sequential combine */
 }
@@ -1676,9 +1677,6 @@ extern "C" int odhip_pvq_choose_priced_resolve(const odhip_pvq_job *jobs, int nj
 }
 
 /* Test hook: scales the decision margin of the priced choices (1 restores it). */
-extern "C" void odhip_pvq_price_set_tol_scale(double scale) {
-  g_price_tol_scale = scale > 0 ? scale : 1.;
-}
 
 extern "C" int odhip_cfl_refs_from_luma(const odhip_pvq_job *luma_jobs, int njobs,
  od_coeff *const *d_ref, int copies, odhip_stream stream) {

@@ -2307,10 +2307,6 @@ __global__ __launch_bounds__(256) void k_refb_synth(RItems it) {
 
 /* ---- host side --------------------------------------------------------------------- */
 odhip_device_once g_tables_once;
-/* test hooks (odhip_pvq_ref_set_theta_margin): process-wide, set before any call */
-double g_margin = kDefaultMargin;
-int g_perturb = 0;
-double g_price_tol_scale = 1.;   /* odhip_pvq_ref_price_set_tol_scale */
 
 int upload_tables_now(void) {
   ODHIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(kRScanXY), OD_SCAN_XY, sizeof(OD_SCAN_XY)));
@@ -2452,6 +2448,9 @@ struct RefState {
   hipEvent_t unc_event = nullptr;
   bool serial = false;               /* the context's setting, refreshed per call   */
   bool sort_dirty = false;           /* the sort histogram may hold counts of a failed call */
+  double margin = kDefaultMargin;    /* test hooks of the context */
+  int perturb = 0;
+  double tol_scale = 1.;
   bool lean = false;                 /* the last band stage was the decided one: no
                                         candidate records exist unless a resolve re-ran
                                         the band                                    */
@@ -2501,6 +2500,10 @@ int ref_state(RefState **out) {
     ODHIP_TRY(hipMemset(st->d_sort, 0, sizeof(unsigned)*2*kMaxItems*kSortBins));
   }
   st->serial = ctx->serial != 0;
+  /* the context's test hooks (odhip_ctx_set_test_hooks), refreshed per call like `serial` */
+  st->margin = ctx->theta_margin > 0 ? ctx->theta_margin : kDefaultMargin;
+  st->perturb = ctx->theta_perturb != 0;
+  st->tol_scale = ctx->price_tol_scale > 0 ? ctx->price_tol_scale : 1.;
   *out = st;
   return ODHIP_SUCCESS;
 }
@@ -2564,8 +2567,8 @@ int stage_jobs(RefState &st, const odhip_pvq_refjob *jobs, int njobs, int mode, 
 void items_begin(RItems &it, const RefState &st, double lambda) {
   memset(&it, 0, sizeof(it));
   it.lambda = lambda;
-  it.margin = g_margin;
-  it.perturb = g_perturb;
+  it.margin = st.margin;
+  it.perturb = st.perturb;
   it.jobs = st.cur;
   it.unc_count = st.d_unc_count;
   it.unc = st.d_unc;
@@ -2573,7 +2576,7 @@ void items_begin(RItems &it, const RefState &st, double lambda) {
   it.rcursor = st.d_sort + kMaxItems*kSortBins;
   it.pcount = st.d_pcount;
   it.plist = st.d_plist;
-  it.tol_scale = g_price_tol_scale;
+  it.tol_scale = st.tol_scale;
 }
 
 void items_add(RItems &it, int job, int band, long wgs) {
@@ -2651,11 +2654,6 @@ extern "C" int odhip_pvq_ref_profile_read(float *ms, int max_n) {
   }
   st.prof_n = 0;
   return n;
-}
-
-extern "C" void odhip_pvq_ref_set_theta_margin(double margin, int perturb) {
-  g_margin = margin > 0 ? margin : kDefaultMargin;
-  g_perturb = perturb != 0;
 }
 
 extern "C" int odhip_pvq_ref_theta_probe(const double *d_corr, double *d_t, long n,
@@ -3140,6 +3138,3 @@ extern "C" int odhip_pvq_ref_choose_priced_resolve(const odhip_pvq_refjob *jobs,
   return rc ? rc : (int)count;
 }
 
-extern "C" void odhip_pvq_ref_price_set_tol_scale(double scale) {
-  g_price_tol_scale = scale > 0 ? scale : 1.;
-}

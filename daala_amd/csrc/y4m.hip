@@ -99,6 +99,27 @@ extern "C" int odhip_y4m_read(odhip_y4m *y, uint8_t *luma, uint8_t *cb, uint8_t 
   return 1;
 }
 
+/* Steps over one FRAME without reading its samples (a rank of a frame-sharded encode reads
+   only the frames it owns): 1, 0 at the end of the stream, negative on loss of framing. */
+extern "C" int odhip_y4m_skip(odhip_y4m *y) {
+  if (!y) return ODHIP_EINVAL;
+  char frame[6];
+  const size_t got = fread(frame, 1, 6, y->f);
+  if (got == 0) return 0;
+  if (got != 6 || memcmp(frame, "FRAME", 5) != 0) return ODHIP_EFAULT;
+  if (frame[5] != '\n') {
+    int c;
+    int k = 0;
+    while ((c = fgetc(y->f)) != EOF && c != '\n' && k < 121) k++;
+    if (c != '\n') return ODHIP_EFAULT;
+  }
+  const size_t ny = (size_t)y->w*y->h;
+  const size_t nc = (size_t)((y->w + 1) >> 1)*((y->h + 1) >> 1);
+  if (fseek(y->f, (long)(ny + 2*nc), SEEK_CUR) != 0) return ODHIP_EFAULT;
+  /* a short file shows at the next read */
+  return 1;
+}
+
 extern "C" void odhip_y4m_close(odhip_y4m *y) {
   if (!y) return;
   fclose(y->f);

@@ -706,10 +706,8 @@ int odhip_inverse_levels_pvq_ref(uint8_t *const *d_px, int px_stride, long px_pl
    choices (odhip_inverse_levels_pvq_ref).  A job must carry its choice buffer. */
 int odhip_pvq_ref_bands_decided_multi(const odhip_pvq_refjob *jobs, int njobs,
  double pvq_norm_lambda, odhip_stream stream);
-/* Test hooks: the uncertainty margin (default 1e-9; <= 0 restores it) and, when
-   perturb != 0, a deliberately wrong device theta (+1) for the listed bands, so
-   that tests exercise the host-libm path on real data. */
-void odhip_pvq_ref_set_theta_margin(double margin, int perturb);
+/* (Test hooks - the uncertainty margin, a deliberately wrong device theta for listed bands,
+   the scale of the priced choice's margin - are per context: odhip_ctx_set_test_hooks.) */
 /* S*acos(corr) + .5 as the device evaluates it (parity check of the margin). */
 int odhip_pvq_ref_theta_probe(const double *d_corr, double *d_t, long n, odhip_stream stream);
 
@@ -824,6 +822,15 @@ int odhip_image_planes_copy_pad(uint8_t *d_dst, int dst_stride, long dst_plane_s
    on the 16-bit samples (src/encode.c:791-803, :821-832). */
 int odhip_ctx_set_fpr(odhip_ctx *ctx, int on);
 int odhip_ctx_get_fpr(const odhip_ctx *ctx);
+/* TEST HOOKS, per context (ctx == NULL: the calling thread's current context; nothing here
+   is process-wide).  theta_margin: the distance from an integer inside which
+   OD_THETA_SCALE*acos(corr) + .5 is not trusted to the device acos (default 1e-9; <= 0
+   restores it); theta_perturb != 0: the device theta of a listed band is deliberately wrong
+   (+1), so that tests exercise the host-libm re-run on real data; price_tol_scale multiplies
+   the margin inside which a priced choice is left to the host libm (<= 0: 1).  A production
+   caller never touches these. */
+int odhip_ctx_set_test_hooks(odhip_ctx *ctx, double theta_margin, int theta_perturb,
+ double price_tol_scale);
 int odhip_image_planes_copy_pad16(uint16_t *d_dst, int dst_stride, long dst_plane_stride, int plane_w,
  int plane_h, const void *d_src, int src_bitdepth, int src_stride, long src_plane_stride, int pic_w,
  int pic_h, int nplanes, odhip_stream stream);
@@ -877,7 +884,7 @@ void odhip_install_cached_dct_vtbl(odhip_dct_func_2d fdct_2d[ODHIP_NBSIZES],
    normally 0 - and otherwise recomputes those bands' rates with the HOST libm, the
    function the reference calls, and decides them again.  It returns the number of
    bands re-decided; consumers of the choice records enqueued before it must then be
-   repeated.  *_price_set_tol_scale multiplies the margin (test hook). */
+   repeated.  (odhip_ctx_set_test_hooks can widen the margin to force this path.) */
 int odhip_pvq_choose_priced_multi(const odhip_pvq_job *jobs, int njobs, double pvq_norm_lambda,
  odhip_stream stream);
 int odhip_pvq_choose_priced_resolve(const odhip_pvq_job *jobs, int njobs, double pvq_norm_lambda,
@@ -888,7 +895,6 @@ int odhip_pvq_choose_priced_resolve(const odhip_pvq_job *jobs, int njobs, double
    host that wants the candidates read them).  Follow with odhip_pvq_choose_priced_resolve. */
 int odhip_pvq_noref_bands_priced_multi(const odhip_pvq_job *jobs, int njobs, double pvq_norm_lambda,
  odhip_stream stream);
-void odhip_pvq_price_set_tol_scale(double scale);
 int odhip_pvq_ref_choose_priced_multi(const odhip_pvq_refjob *jobs, int njobs, double pvq_norm_lambda,
  odhip_stream stream);
 int odhip_pvq_ref_choose_priced_resolve(const odhip_pvq_refjob *jobs, int njobs, double pvq_norm_lambda,
@@ -904,7 +910,6 @@ int odhip_pvq_ref_bands_priced_multi(const odhip_pvq_refjob *jobs, int njobs, do
  odhip_stream stream);
 int odhip_pvq_ref_choose_priced_rest_multi(const odhip_pvq_refjob *jobs, int njobs, double pvq_norm_lambda,
  odhip_stream stream);
-void odhip_pvq_ref_price_set_tol_scale(double scale);
 
 /* ---- frame cache, second half: the batched band stage behind pvq_theta ------------
 
@@ -960,6 +965,9 @@ void odhip_cache_band_stats(const odhip_frame_cache *c, long *hits, long *misses
 typedef struct odhip_y4m odhip_y4m;
 odhip_y4m *odhip_y4m_open(const char *path, int *pic_w, int *pic_h, int *fps_n, int *fps_d, int *err);
 int odhip_y4m_read(odhip_y4m *y, uint8_t *luma, uint8_t *cb, uint8_t *cr);
+/* Steps over one FRAME without reading it (frame-sharded input: a rank reads only the
+   frames it owns); 1, 0 at the end of the stream, negative on loss of framing. */
+int odhip_y4m_skip(odhip_y4m *y);
 void odhip_y4m_close(odhip_y4m *y);
 
 /* ---- odhip_pipe: the frame-batch step as one C call ------------------------------
@@ -1068,6 +1076,8 @@ int odhip_pipe_time_pyramid(odhip_pipe *p, int n, double *avg_ms);
 long odhip_pipe_theta_reruns(const odhip_pipe *p);
 long odhip_pipe_price_reruns(const odhip_pipe *p);
 double odhip_pipe_host_wait_ms(const odhip_pipe *p);
+/* odhip_ctx_set_test_hooks on both contexts of the pipe. */
+int odhip_pipe_set_test_hooks(odhip_pipe *p, double theta_margin, int theta_perturb, double price_tol_scale);
 
 #ifdef __cplusplus
 }

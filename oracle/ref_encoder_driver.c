@@ -15,6 +15,7 @@
 #include "daala/daalaenc.h"
 #include "state.h"
 #include "encint.h"
+#include "block_size.h"
 
 #define REF_EXPORT __attribute__((visibility("default")))
 
@@ -23,6 +24,8 @@
    ref_encode_yuv420 after daala_encode_create (the vtbl lives in od_state,
    src/state.h:112-131; daala_enc_ctx starts with its od_state,
    src/encint.h). */
+static long ref_last_luma_blocks;
+static long ref_last_chroma_blocks;
 static long ref_fdct_calls[OD_NBSIZES];
 static long ref_idct_calls[OD_NBSIZES];
 static od_dct_func_2d ref_fdct_real[OD_NBSIZES];
@@ -227,9 +230,40 @@ static int ref_encode_core(const unsigned char *frames, int w, int h,
       if (ret < 0) return ret;
     }
   }
+  {
+    /* the final partition of the last frame coded (state.bsize, src/state.h:250-259: one
+       entry per 8x8, the size of the block that covers it; 0 = four 4x4 luma blocks over
+       ONE 4x4 chroma block): how many transform blocks the bitstream really carries */
+    od_state *st;
+    int bx;
+    int by;
+    st = (od_state *)enc;
+    ref_last_luma_blocks = ref_last_chroma_blocks = 0;
+    for (by = 0; by < st->nvsb*OD_BSIZE_GRID; by++) {
+      for (bx = 0; bx < st->nhsb*OD_BSIZE_GRID; bx++) {
+        int v;
+        v = OD_BLOCK_SIZE8x8(st->bsize, st->bstride, bx, by);
+        if (v == 0) {
+          ref_last_luma_blocks += 4;
+          ref_last_chroma_blocks++;
+        }
+        else if ((bx & ((1 << (v - 1)) - 1)) == 0 && (by & ((1 << (v - 1)) - 1)) == 0) {
+          ref_last_luma_blocks++;
+          ref_last_chroma_blocks++;
+        }
+      }
+    }
+  }
   daala_comment_clear(&dc);
   daala_encode_free(enc);
   return npackets;
+}
+
+/* Transform blocks of the final partition of the last frame the drivers above coded:
+   out[0] luma, out[1] one chroma plane of a 4:2:0 picture. */
+REF_EXPORT void ref_last_coded_blocks(long out[2]) {
+  out[0] = ref_last_luma_blocks;
+  out[1] = ref_last_chroma_blocks;
 }
 
 /* What the batched band stage needs to know about a live encoder when a frame's

@@ -62,10 +62,16 @@ def frame_yuv(index, w, h):
 
 
 def encode_owned(r, indices, w, h, quality=20, complexity=7):
-    """{global frame index: packet bytes} of the frames in `indices`."""
+    """{global frame index: packet bytes} of the frames in `indices` (bench generator)."""
+    return encode_frames(r, indices, [frame_yuv(i, w, h) for i in indices], w, h, quality, complexity)
+
+
+def encode_frames(r, indices, yuv, w, h, quality=20, complexity=7):
+    """{global frame index: packet bytes}: yuv[j] (planar 4:2:0 bytes) is frame indices[j] of
+    the whole sequence."""
     if not indices:
         return {}
-    frames = np.concatenate([frame_yuv(i, w, h) for i in indices])
+    frames = np.concatenate([np.ascontiguousarray(f, np.uint8).ravel() for f in yuv])
     idx = (ctypes.c_int * len(indices))(*indices)
     out = np.zeros(max(8 << 20, len(indices) * (w * h)), np.uint8)
     sizes = (ctypes.c_long * len(indices))()

@@ -347,6 +347,19 @@ int daala_encode_img_in(void *enc, void *img, int duration) {
   return next(enc, img, duration);
 }
 
+/* daala_encode_free (include/daala/daalaenc.h): the planes of this encoder are gone - the
+   next encoder's planes take the cache slots from the start (a second encoder in one
+   process used to find the four slots taken by the first one's buffers). */
+void daala_encode_free(void *enc) {
+  typedef void (*fn)(void *);
+  static fn next;
+  if (!next) next = NEXT(fn, "daala_encode_free");
+  if (enc == g_enc) g_enc = NULL;
+  g_nbases = 0;
+  g_bands_frame = 0;
+  next(enc);
+}
+
 /* od_pvq_encode (src/pvq_encoder.h:46-49, the boundary symbol of BASELINE.json): the
    reference's own definition runs; this wrapper only notes WHICH block its pvq_theta
    calls belong to (bx, by in 4x4 units as src/encode.c:1264-1265 passes them). */

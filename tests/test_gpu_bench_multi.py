@@ -36,3 +36,26 @@ def test_bench_two_ranks_one_gpu():
         assert chk and chk["ran"], chk
         assert chk["packets_equal_sequential_c_encoder"] is True
         assert chk["frames"] == 2
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libdaalaref.so")),
+                    reason="oracle/_ref (the reference encoder: the host half) not present")
+def test_configs4_encode_mode_two_ranks_one_gpu(tmp_path):
+    """BASELINE configs[4] as a command, in miniature: `bench.py --gpus 2 --encode-frames 5` -
+    a Y4M file in through odhip_y4m_*, frame i -> rank i mod 2, every rank the reference
+    encoder with the batched GPU stage behind it, packets gathered to rank 0, the first three
+    compared with the plain C encoder run sequentially; one JSON line with frames/s."""
+    env = dict(os.environ)
+    env.update(ODHIP_BENCH_ONE_GPU="1", ODHIP_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", "29633", os.path.join(ROOT, "bench.py"),
+           "--gpus", "2", "--encode-frames", "5", "--encode-check", "3"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["frames"] == 5 and d["unit"] == "frames/s" and d["value"] > 0
+    assert d["rank0"]["frames"] == 3 and d["rank0"]["bands_from_batch"] > 100000
+    assert d["prefix_check"]["frames"] == 3
+    assert d["prefix_check"]["packets_equal_sequential_c_encoder"] is True

@@ -81,3 +81,34 @@ def test_refuses_what_the_batched_path_cannot_take(tmp_path):
     planes = [np.zeros(256, np.uint8), np.zeros(64, np.uint8), np.zeros(64, np.uint8)]
     assert L.odhip_y4m_read(ctypes.c_void_p(y), *[p.ctypes.data_as(ctypes.c_void_p) for p in planes]) == -1
     L.odhip_y4m_close(ctypes.c_void_p(y))
+
+
+def test_skip_reads_only_the_frames_a_rank_owns(tmp_path):
+    """odhip_y4m_skip: rank r of a world of 3 reads frames r, r + 3, ... of a 7-frame file
+    (with frame parameters on some FRAME lines) and steps over the rest."""
+    w, h, n = 48, 32, 7
+    rng = np.random.RandomState(9)
+    fsz = w * h + 2 * (w // 2) * (h // 2)
+    frames = [rng.randint(0, 256, size=fsz).astype(np.uint8) for _ in range(n)]
+    path = tmp_path / "shard.y4m"
+    with open(path, "wb") as f:
+        f.write(b"YUV4MPEG2 W48 H32 F30:1 Ip C420jpeg\n")
+        for i, fr in enumerate(frames):
+            f.write(b"FRAME Ip\n" if i % 2 else b"FRAME\n")
+            f.write(fr.tobytes())
+    for rank in range(3):
+        L, y, gw, gh, fps, err = _open(path)
+        assert y and (gw, gh) == (w, h)
+        planes = [np.zeros(w * h, np.uint8), np.zeros(w * h // 4, np.uint8), np.zeros(w * h // 4, np.uint8)]
+        got = []
+        for i in range(n + 1):
+            if i % 3 == rank:
+                rc = L.odhip_y4m_read(ctypes.c_void_p(y), *[p.ctypes.data_as(ctypes.c_void_p) for p in planes])
+                if rc == 1:
+                    got.append((i, np.concatenate(planes)))
+            else:
+                rc = L.odhip_y4m_skip(ctypes.c_void_p(y))
+            assert rc == (1 if i < n else 0), (rank, i, rc)
+        L.odhip_y4m_close(ctypes.c_void_p(y))
+        assert [i for i, _ in got] == list(range(rank, n, 3))
+        assert all(np.array_equal(a, frames[i]) for i, a in got)

@@ -112,8 +112,12 @@ def main():
         print("%-28s %-10s " % (k[0], k[1]) + " ".join("%14.0f" % v for v in vals) + " %12.1f %9.2f" % (hbm, bc))
     if len(sys.argv) > 2:
         import json
+        import os
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        import bench
         with open(sys.argv[2], "w") as f:
-            json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), "
+            json.dump({"source_hash": bench.source_hash(),
+                       "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), "
                                  "HBM bytes = (2*FETCH_SIZE + WRITE_SIZE) KiB, MI355X_MICROARCH.md gfx950 correction",
                        "kernels": traffic}, f, indent=1)
 
