@@ -25,5 +25,6 @@ from .api import (DaalaHipError, lib, lib_path, init, fdct2d_batch, idct2d_batch
                   BUF_PIC, BUF_PX, BUF_LEVEL, BUF_RECON, BUF_BAND, BUF_Y, BUF_CHOICE, BUF_ITEMS,
                   BUF_REF, BUF_RATE, compute_dist, set_price_tol_scale, px_dtype,
                   image_planes_copy_pad16, pvq_choose_priced_multi,
-                  pvq_ref_choose_priced_multi, pvq_ref_bands_decided_multi, BAND_RECORD)
+                  pvq_ref_choose_priced_multi, pvq_ref_bands_decided_multi, BAND_RECORD,
+                  pvq_decode_bands)
 from .quant import QuantTables, OD_PVQ_LAMBDA  # noqa: F401

@@ -841,6 +841,26 @@ def pvq_ref_choose_priced_multi(jobs, pvq_norm_lambda, fused_bands=False):
                      "odhip_pvq_ref_choose_priced_resolve")
 
 
+def pvq_decode_bands(ref, y, sym, qm, qm_inv, q0, beta, is_keyframe, pli):
+    """The decoder's arithmetic for a batch of bands (odhip_pvq_decode_bands): ref, y int32
+    [nbands, n] CUDA, sym int32 [nbands, 4] = {gain symbol as read, itheta, noref, 0}, qm /
+    qm_inv int16 [n].  Returns (out int32 [nbands, n], info int32 [nbands, 2] = {K, skip})."""
+    import torch
+    _need(ref, torch.int32, "ref")
+    _need(y, torch.int32, "y")
+    _need(sym, torch.int32, "sym")
+    _need(qm, torch.int16, "qm")
+    _need(qm_inv, torch.int16, "qm_inv")
+    nbands, n = ref.shape
+    assert y.shape == ref.shape and sym.shape == (nbands, 4)
+    out = torch.empty_like(ref)
+    info = torch.empty((nbands, 2), dtype=torch.int32, device=ref.device)
+    _check(lib().odhip_pvq_decode_bands(_p(out), _p(ref), _p(y), int(n), ctypes.c_long(nbands), _p(sym),
+                                        _p(qm), _p(qm_inv), int(q0), int(beta), int(is_keyframe), int(pli),
+                                        _p(info), _stream()), "odhip_pvq_decode_bands")
+    return out, info
+
+
 def pvq_ref_bands_decided_multi(jobs, pvq_norm_lambda):
     """The with-reference band stage with the priced choice of every band made inside its
     search (odhip_pvq_ref_bands_decided_multi), followed by the two resolves.  Leaves the

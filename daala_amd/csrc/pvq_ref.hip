@@ -244,7 +244,160 @@ __global__ __launch_bounds__(64) void k_synthesis(od_coeff *out, const od_coeff 
   }
 }
 
+
+/* neg_deinterleave, src/pvq_decoder.c:53-59. */
+__device__ __forceinline__ int odq_neg_deinterleave(int x, int ref) {
+  if (x < 2*ref - 1) return x & 1 ? ref - 1 - (x >> 1) : ref + (x >> 1);
+  return x + 1;
+}
+
+/* od_pvq_compute_k, nodesync (src/pvq.c:902-953): what the decoder derives the pulse count
+   from under OD_ROBUST_STREAM - nothing that depends on the reference. */
+__device__ __forceinline__ int odq_compute_k_dec(int32_t qcg, int itheta, int noref, int n, int beta) {
+  return noref ? odq_compute_k_noref(qcg, n, beta) : odq_compute_k_ref(itheta, n);
+}
+
+/* pvq_decode_partition (src/pvq_decoder.c:122-298) after its entropy-decoder reads, one band
+   per lane: sym[b] = {the gain symbol as read (before deinterleaving), itheta, noref, -}.
+   The QM-scaled reference is recomputed where it is used (a lane cannot hold 128 values):
+   ref16[i] = SHR_ROUND(ref[i]*qm[i], OD_QM_SHIFT + rshift), and after od_compute_householder
+   element m carries + SHR_ROUND(gr*s, rshift) (src/pvq.c:498-521). */
+__global__ __launch_bounds__(64) void k_pvq_decode(od_coeff *out, const od_coeff *refa, const od_coeff *ya,
+ int n, long nbands, const int4 *sym, const int16_t *qm, const int16_t *qm_inv, int q0, int beta,
+ int is_keyframe, int pli, int2 *info) {
+  const long b = (long)blockIdx.x*64 + threadIdx.x;
+  if (b >= nbands) return;
+  const od_coeff *ref = refa + b*n;
+  const od_coeff *yp = ya + b*n;
+  od_coeff *xo = out + b*n;
+  const int4 sy = sym[b];
+  int qg = sy.x;
+  int itheta = sy.y;
+  const int noref = sy.z;
+  /* :213-224 */
+  int sr = 0;
+  for (int i = 0; i < n; i++) {
+    const int tr = (int16_t)(ref[i] >> 8);
+    sr += tr*tr;
+  }
+  int rshift = 8 + 1 + odq_ilog(n + sr)/2 - 14;
+  rshift = rshift > 0 ? rshift : 0;
+#define OD_REF16(i) ((int16_t)odq_shr_round((int32_t)((uint32_t)ref[i]*(uint32_t)(int32_t)qm[i]), ODQ_QM_SHIFT + rshift))
+  int32_t theta = 0;
+  int32_t gr = 0;
+  int32_t qcg;
+  int skip = 0;
+  int m = 0;
+  int sgn = 0;
+  int rm = 0;          /* ref16[m] after od_compute_householder */
+  if (!noref) {
+    /* :225-255 */
+    int accr = 0;
+    int maxr = 0;
+    for (int i = 0; i < n; i++) {
+      const int rv = OD_REF16(i);
+      accr += rv*rv;
+      const int a = abs(rv);
+      if (a > maxr) {
+        maxr = a;
+        m = i;
+        rm = rv;
+      }
+    }
+    if (maxr == 0) rm = OD_REF16(0);
+    int32_t cgr = odq_gain_from_acc(accr, q0, beta, rshift, &gr);
+    const int cfl_enabled = pli != 0 && is_keyframe;
+    if (cfl_enabled) cgr = 256;
+    const int icgr = odq_shr_round(cgr, ODQ_CGAIN_SHIFT);
+    if (is_keyframe) qg = odq_neg_deinterleave(qg, icgr);
+    else {
+      qg = odq_neg_deinterleave(qg, icgr + 1) - 1;
+      if (qg == 0) skip = icgr ? 1 : 2;
+    }
+    if (qg == icgr && itheta == 0 && !cfl_enabled) skip = 2;
+    const int32_t gain_offset = cgr - odq_shl32(icgr, ODQ_CGAIN_SHIFT);
+    qcg = odq_shl32(qg, ODQ_CGAIN_SHIFT) + gain_offset;
+    theta = odq_pvq_compute_theta(itheta, odq_pvq_compute_max_theta(qcg, beta));
+    /* od_compute_householder, src/pvq.c:498-521 */
+    sgn = rm > 0 ? 1 : -1;
+    rm = (int16_t)(rm + odq_shr_round(gr*sgn, rshift));
+  }
+  else {
+    itheta = 0;
+    if (!is_keyframe) qg++;
+    qcg = odq_shl32(qg, ODQ_CGAIN_SHIFT);
+    if (qg == 0) skip = 1;
+  }
+  if (info) info[b] = make_int2(odq_compute_k_dec(qcg, itheta, noref, n, beta), skip);
+  if (skip) {
+    for (int i = 0; i < n; i++) xo[i] = skip == 2 ? ref[i] : 0;
+    return;
+  }
+  /* od_gain_expand + od_pvq_synthesis_partial, src/pvq.c:766-811, :1037-1115 */
+  const int32_t g = odq_gain_expand(qcg, q0, beta);
+  const int nn = n - (!noref);
+  int yy = 0;
+  for (int i = 0; i < nn; i++) yy += yp[i]*(int32_t)yp[i];
+  int gshift = odq_ilog(g) - 14;
+  gshift = gshift > 0 ? gshift : 0;
+  int32_t scale = 0;
+  if (yy != 0) {
+    int rsqrt_shift;
+    const int16_t rsqrt = odq_rsqrt(yy, &rsqrt_shift);
+    scale = odq_vshr_round(rsqrt*(int64_t)g, rsqrt_shift + gshift - 16);
+  }
+  const int qshift = ODQ_QM_INV_SHIFT - gshift;
+  if (noref) {
+    for (int i = 0; i < n; i++) {
+      const int32_t x = (int32_t)odq_mult16_32_q16(yp[i], scale);
+      xo[i] = odq_shr_round(x*qm_inv[i], qshift);
+    }
+    return;
+  }
+  scale = (int32_t)floor(.5 + (scale*(1./32768))*odq_pvq_sin(theta));
+  const int16_t xm = (int16_t)floor(.5 + ((-sgn*odq_shr_round(g, gshift))*(1./32768))*odq_pvq_cos(theta));
+  int32_t l2r = 0;
+  int32_t proj = 0;
+  for (int i = 0; i < n; i++) {
+    const int ri = i == m ? rm : OD_REF16(i);
+    const int16_t xi = i == m ? xm : (int16_t)odq_mult16_32_q16(yp[i < m ? i : i - 1], scale);
+    l2r += odq_mult16_16(ri, ri);
+    proj += odq_mult16_16(ri, xi);
+  }
+  const int l2r_shift = (odq_ilog(l2r) - 1) - 14;
+  const int16_t l2r_norm = (int16_t)odq_vshr_round(l2r, l2r_shift);
+  const int16_t rcp = odq_rcp(l2r_norm);
+  const int proj_shift = (odq_ilog(abs(proj)) - 1) - 14;
+  const int16_t proj_norm = (int16_t)odq_vshr_round(proj, proj_shift);
+  const int16_t proj_1 = (int16_t)odq_mult16_16_q15(proj_norm, rcp);
+  int outshift = 14 - proj_shift - 1 + l2r_shift;
+  if (outshift > 30) outshift = 30;
+  for (int i = 0; i < n; i++) {
+    const int ri = i == m ? rm : OD_REF16(i);
+    const int16_t xi = i == m ? xm : (int16_t)odq_mult16_32_q16(yp[i < m ? i : i - 1], scale);
+    int32_t tmp = odq_mult16_16(ri, proj_1);
+    tmp = outshift >= 0 ? odq_shr_round(tmp, outshift) : odq_shl32(tmp, -outshift);
+    const int16_t v = (int16_t)(xi - tmp);
+    xo[i] = odq_shr_round(v*qm_inv[i], qshift);
+  }
+#undef OD_REF16
+}
+
 }  // namespace
+
+extern "C" int odhip_pvq_decode_bands(od_coeff *d_out, const od_coeff *d_ref, const od_coeff *d_y, int n,
+ long nbands, const int32_t *d_sym, const int16_t *d_qm, const int16_t *d_qm_inv, int q0, int beta,
+ int is_keyframe, int pli, int32_t *d_info, odhip_stream stream) {
+  if (nbands == 0) return ODHIP_SUCCESS;
+  if (!d_out || !d_ref || !d_y || !d_sym || !d_qm || !d_qm_inv || n < 2 || n > kMaxN || nbands < 0 || q0 < 1
+   || ((uintptr_t)d_sym & 15) || ((uintptr_t)d_info & 7)) {
+    return ODHIP_EINVAL;
+  }
+  k_pvq_decode<<<(unsigned)((nbands + 63)/64), 64, 0, (hipStream_t)stream>>>(d_out, d_ref, d_y, n, nbands,
+   reinterpret_cast<const int4 *>(d_sym), d_qm, d_qm_inv, q0, beta, is_keyframe != 0, pli,
+   reinterpret_cast<int2 *>(d_info));
+  return odhip_check_launch();
+}
 
 extern "C" int odhip_pvq_ref_prepare(const od_coeff *d_x0, const od_coeff *d_r0, int n, long nbands,
  const int16_t *d_qm, int q0, int beta, int cfl_enabled, int16_t *d_x16, int16_t *d_r16,

@@ -506,6 +506,28 @@ int odhip_pvq_ref_candidates(const odhip_pvq_refprep *d_prep, const int32_t *d_t
 int odhip_pvq_synthesis(od_coeff *d_out, const od_coeff *d_y, const int16_t *d_r16, int n,
  long nbands, const int32_t *d_params, const int16_t *d_qm_inv, odhip_stream stream);
 
+/* ---- decoder side: a PVQ band from its decoded symbols ------------------------------
+
+   pvq_decode_partition (src/pvq_decoder.c:122-298; od_pvq_decode :300-376 calls it per band)
+   AFTER its entropy-decoder reads, for a batch of band vectors [band][n] in coding order
+   (device memory): d_sym[band] = {the gain symbol as read - id & 1, or 1 + the
+   generic_decode value, before deinterleaving (:190-208) -, itheta after the theta decode
+   (:248-254), noref, unused}; d_y the decoded pulses (n - !noref of them, :262-266), d_ref
+   the reference band (the prediction, after the chroma-from-luma flip where one was read).
+   Computes what the function computes from them: the reference's scaling and gain, the
+   deinterleaved gain, gain_offset, theta (:213-255), the skip rules, od_gain_expand and
+   pvq_synthesis = od_compute_householder + od_pvq_synthesis_partial (:78-89, :268-279) into
+   d_out; d_info (optional) [band][2] = {K as the decoder derives it under OD_ROBUST_STREAM
+   (od_pvq_compute_k, nodesync), skip code 0 / OD_PVQ_SKIP_ZERO 1 / OD_PVQ_SKIP_COPY 2}.
+   The entropy decoding itself (od_decode_cdf_adapt, generic_decode,
+   od_decode_pvq_codeword) is sequential host state and stays the reference's; under
+   OD_ROBUST_STREAM (nodesync = 1, src/encode.c:1354) none of its reads depends on a value
+   computed here, so a decoder can parse a whole frame first and reconstruct its bands in
+   batches.  q0 / beta: the band's quantiser step and OD_PVQ_BETA entry. */
+int odhip_pvq_decode_bands(od_coeff *d_out, const od_coeff *d_ref, const od_coeff *d_y, int n,
+ long nbands, const int32_t *d_sym, const int16_t *d_qm, const int16_t *d_qm_inv, int q0, int beta,
+ int is_keyframe, int pli, int32_t *d_info, odhip_stream stream);
+
 /* ---- with-reference band stage on whole planes ---------------------------------
 
    pvq_theta (src/pvq_encoder.c:333-641) for every block of side N = 4 << bs of a

@@ -1030,6 +1030,90 @@ void odo_pvq_synthesis_partial(odo_coeff *xcoeff, const odo_coeff *ypulse,
   }
 }
 
+/* neg_deinterleave, src/pvq_decoder.c:53-59. */
+static int odo_neg_deinterleave(int x, int ref) {
+  if (x < 2*ref - 1) {
+    if (x & 1) return ref - 1 - (x >> 1);
+    return ref + (x >> 1);
+  }
+  return x + 1;
+}
+
+/* pvq_decode_partition (src/pvq_decoder.c:122-298) WITHOUT its entropy-decoder reads:
+   given what it read - qg_coded = the gain symbol before deinterleaving (id & 1, or 1 + the
+   generic_decode value, :190-208), itheta after the theta decode (:248-254), noref, and the
+   pulses y (n - !noref of them, :262-266) - and the reference band: rshift / ref16 (:213-224),
+   the reference's gain and the deinterleaved gain (:225-241), gain_offset, qcg, max_theta,
+   theta (:242-255), the skip rules, K (:261; nodesync, OD_ROBUST_STREAM), od_gain_expand and
+   pvq_synthesis = od_compute_householder + od_pvq_synthesis_partial (:78-89, :275-279).
+   Returns the skip code (0, 1 = OD_PVQ_SKIP_ZERO, 2 = OD_PVQ_SKIP_COPY); *k_out = K. */
+int odo_pvq_decode_band(odo_coeff *out, const odo_coeff *ref, const odo_coeff *y, int n, int q0,
+ int beta, int qg_coded, int itheta, int noref, int is_keyframe, int pli, const int16_t *qm,
+ const int16_t *qm_inv, int *k_out) {
+  int16_t ref16[ODO_MAX_PVQ_SIZE];
+  int32_t theta;
+  int32_t gr;
+  int32_t gain_offset;
+  int32_t qcg;
+  int qg;
+  int skip;
+  int rshift;
+  int k;
+  int i;
+  theta = 0;
+  gr = 0;
+  gain_offset = 0;
+  qg = qg_coded;
+  skip = 0;
+  rshift = odo_vector_log_mag(ref, n) - 14;
+  if (rshift < 0) rshift = 0;
+  for (i = 0; i < n; i++) {
+    ref16[i] = (int16_t)shr_round((int32_t)((uint32_t)ref[i]*(uint32_t)(int32_t)qm[i]), Q_QM_SHIFT + rshift);
+  }
+  if (!noref) {
+    int32_t cgr;
+    int icgr;
+    int cfl_enabled;
+    int max_theta;
+    cfl_enabled = pli != 0 && is_keyframe;
+    cgr = odo_pvq_compute_gain(ref16, n, q0, &gr, beta, rshift);
+    if (cfl_enabled) cgr = 256;
+    icgr = shr_round(cgr, Q_CGAIN_SHIFT);
+    if (is_keyframe) qg = odo_neg_deinterleave(qg, icgr);
+    else {
+      qg = odo_neg_deinterleave(qg, icgr + 1) - 1;
+      if (qg == 0) skip = icgr ? 1 : 2;
+    }
+    if (qg == icgr && itheta == 0 && !cfl_enabled) skip = 2;
+    gain_offset = cgr - shl32(icgr, Q_CGAIN_SHIFT);
+    qcg = shl32(qg, Q_CGAIN_SHIFT) + gain_offset;
+    max_theta = odo_pvq_compute_max_theta(qcg, beta);
+    theta = odo_pvq_compute_theta(itheta, max_theta);
+  }
+  else {
+    itheta = 0;
+    if (!is_keyframe) qg++;
+    qcg = shl32(qg, Q_CGAIN_SHIFT);
+    if (qg == 0) skip = 1;
+  }
+  k = odo_pvq_compute_k(qcg, itheta, theta, noref, n, beta, 1);
+  if (k_out) *k_out = k;
+  if (skip) {
+    if (skip == 2) for (i = 0; i < n; i++) out[i] = ref[i];
+    else for (i = 0; i < n; i++) out[i] = 0;
+  }
+  else {
+    int32_t g;
+    int s;
+    int m;
+    g = odo_gain_expand(qcg, q0, beta);
+    s = 0;
+    m = noref ? 0 : odo_compute_householder(ref16, n, gr, &s, rshift);
+    odo_pvq_synthesis_partial(out, y, ref16, n, noref, g, theta, m, s, qm_inv);
+  }
+  return skip;
+}
+
 /* ======================================================================== */
 /* PVQ search                                                                */
 /* ======================================================================== */

@@ -126,6 +126,13 @@ int odo_pvq_theta(odo_coeff *out, const odo_coeff *x0, const odo_coeff *r0, int 
  int is_keyframe, int pli, const int16_t *qm, const int16_t *qm_inv, double pvq_norm_lambda,
  int speed, odo_pvq_band_trace *trace);
 
+/* pvq_decode_partition (src/pvq_decoder.c:122-298) after its entropy-decoder reads: the
+   reconstructed band from the decoded gain symbol, itheta, noref, the pulses and the
+   reference band; returns the skip code, *k_out = the pulse count the decoder derives. */
+int odo_pvq_decode_band(odo_coeff *out, const odo_coeff *ref, const odo_coeff *y, int n, int q0,
+ int beta, int qg_coded, int itheta, int noref, int is_keyframe, int pli, const int16_t *qm,
+ const int16_t *qm_inv, int *k_out);
+
 /* The whole stage on one plane (forward pyramid, PVQ noref bands of every block
    at every level, dequantisation, inverse at every level): the CPU "port" that
    bench.py times when oracle/_ref is absent.  rate_mode 0 = distortion-only

@@ -41,7 +41,7 @@ def _tables(qt, p):
 
 
 def cpu_frame(qt, pics, pic_w, pic_h, chroma_cfl=True, lam=0.147, lib=None, fpr_bits=0, inter_pred=None,
-              decisions=None):
+              decisions=None, planes_out=None):
     """pics: [Y, Cb, Cr] uint8 pictures.  Returns (recon, blocks, seconds): recon[pli][bs]
     = uint8 plane of the coded size, reconstructed at uniform partition level bs.  lib:
     another build of the reference (the x86-intrinsics one) instead of oracle/_ref's default.
@@ -57,7 +57,8 @@ def cpu_frame(qt, pics, pic_w, pic_h, chroma_cfl=True, lam=0.147, lib=None, fpr_
     r.ref_set_fpr(1 if fpr_bits else 0)
     r.ref_stage_set_inter(1 if inter_pred is not None else 0)
     try:
-        return _cpu_frame(r, qt, pics, pic_w, pic_h, chroma_cfl, lam, fpr_bits, inter_pred, decisions)
+        return _cpu_frame(r, qt, pics, pic_w, pic_h, chroma_cfl, lam, fpr_bits, inter_pred, decisions,
+                          planes_out)
     finally:
         r.ref_set_fpr(0)
         r.ref_stage_set_inter(0)
@@ -74,7 +75,11 @@ def _pad(px, pic, fpr_bits):
         oracle().odo_img_plane_copy_pad(P(px), w, w, h, P(pic), pic.shape[1], pic.shape[1], pic.shape[0])
 
 
-def _cpu_frame(r, qt, pics, pic_w, pic_h, chroma_cfl, lam, fpr_bits, inter_pred, decisions=None):
+def _cpu_frame(r, qt, pics, pic_w, pic_h, chroma_cfl, lam, fpr_bits, inter_pred, decisions=None,
+               planes_out=None):
+    """planes_out: a list that receives, per plane, {"dq": the dequantised coefficient plane of
+    every level (what pvq_theta synthesised "like the decoder would"), "ref": the reference
+    plane of every level (chroma from luma; None for luma)} - keyframes only."""
     pdt = np.uint16 if fpr_bits else np.uint8
     assert r is not None, "oracle/_ref/libdaalaref.so not built"
     r.ref_stage_plane_levels.restype = ctypes.c_long
@@ -126,14 +131,20 @@ def _cpu_frame(r, qt, pics, pic_w, pic_h, chroma_cfl, lam, fpr_bits, inter_pred,
                                                qb, bb, ctypes.c_double(lam), rec_arr, dq, None)
         elif chroma_cfl:
             arr = (ctypes.c_void_p * 5)(*([a.ctypes.data for a in refs] + [None]))
+            cdq = [np.zeros((h, w), np.int32) for _ in range(4)] if planes_out is not None else None
+            dqa = (ctypes.c_void_p * 5)(*([a.ctypes.data for a in cdq] + [None])) if cdq else None
             blocks += r.ref_stage_plane_levels(P(px), w, w, h, 1, pic_w, pic_h, 1, P(qm), P(qmi), qm_off,
-                                               qb, bb, ctypes.c_double(lam), rec_arr, None, arr)
+                                               qb, bb, ctypes.c_double(lam), rec_arr, dqa, arr)
+            if planes_out is not None:
+                planes_out.append({"dq": cdq, "ref": [a.copy() for a in refs]})
         else:
             blocks += r.ref_stage_plane_levels(P(px), w, w, h, 1, pic_w, pic_h, 1, P(qm), P(qmi), qm_off,
                                                qb, bb, ctypes.c_double(lam), rec_arr, None, None)
         busy += time.perf_counter() - t0
         if decisions is not None:
             r.ref_stage_set_dump(None, None)
+        if pli == 0 and planes_out is not None:
+            planes_out.append({"dq": [a.copy() for a in ldq], "ref": None})
         if pli == 0 and chroma_cfl:
             # od_resample_luma_coeffs for luma blocks one size up (src/intra.c:97-108: the
             # upper-left quarter of the decoded block), timed like the GPU's kernel
