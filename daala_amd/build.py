@@ -15,7 +15,7 @@ LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libdaalahip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 SOURCES = ["dct_kernels.hip", "lapped_kernels.hip", "pvq_kernels.hip", "pvq_bands.hip", "pvq_ref.hip", "pvq_refbands.hip", "image_kernels.hip", "dering_kernels.hip", "dering_cache.hip", "frame_cache.hip",
-           "odhip_host.hip", "ctx.hip", "quant.hip", "pipeline.hip", "y4m.hip", "dist_kernels.hip"]
+           "odhip_host.hip", "ctx.hip", "quant.hip", "pipeline.hip", "y4m.hip", "dist_kernels.hip", "rate_host.hip"]
 # -ffp-contract=off is MANDATORY for the fp64 PVQ search (bit-exactness with
 # gcc -O2 on x86-64, which emits no FMA); harmless for the integer kernels.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",

@@ -933,6 +933,35 @@ int odhip_pvq_ref_bands_priced_multi(const odhip_pvq_refjob *jobs, int njobs, do
 int odhip_pvq_ref_choose_priced_rest_multi(const odhip_pvq_refjob *jobs, int njobs, double pvq_norm_lambda,
  odhip_stream stream);
 
+/* ---- od_pvq_rate at the default complexity (speed == 0), batched on the host ----------
+
+   At speed == 0 od_pvq_rate (src/pvq_encoder.c:247-287) prices a candidate by running
+   od_encode_pvq_codeword on a scratch range coder against a COPY of the live adaptive
+   od_pvq_codeword_ctx (:265-275): the price depends on every symbol coded before, which is
+   sequential host state (SURVEY hard part 1) - but not on most of what that call moves.
+   odhip_pvq_rate_batch prices all `ncand` candidates of one band against one snapshot of
+   the live context with a rate-only range coder (range + bit count: all od_ec_enc_tell_frac
+   reads) and copy-on-touch CDF rows: no allocation, no context copy, no output bytes; the
+   doubles are the reference's bit for bit.  ctx: the live context itself (the layout below
+   is the reference's struct, src/pvq.h:125-132; &adapt->pvq.pvq_codeword_ctx sits at offset
+   0 of od_adapt_ctx); it is only read.  Candidate c: pulses y[c][0 .. n - (theta[c] != -1))
+   (NULL allowed when k[c] == 0), k[c], gain index qg[c], theta[c] (-1: no reference),
+   ts[c] = max_theta; n = band size, icgr, is_keyframe, pli as od_pvq_rate takes them.
+   _batch16: the pulses as int16 (what the band stages export). */
+typedef struct {
+  int32_t pvq_adapt[2*ODHIP_NBSIZES*4];
+  int32_t pvq_k1_increment;
+  uint16_t pvq_k1_cdf[12][16];
+  uint16_t pvq_split_cdf[14*7][8];
+  int32_t pvq_split_increment;
+} odhip_pvq_codeword_ctx;
+int odhip_pvq_rate_batch(double *rate, const odhip_pvq_codeword_ctx *ctx, int ncand,
+ const od_coeff *const *y, const int *k, const int *qg, const int *theta, const int *ts, int n, int icgr,
+ int is_keyframe, int pli);
+int odhip_pvq_rate_batch16(double *rate, const odhip_pvq_codeword_ctx *ctx, int ncand,
+ const int16_t *const *y, const int *k, const int *qg, const int *theta, const int *ts, int n, int icgr,
+ int is_keyframe, int pli);
+
 /* ---- frame cache, second half: the batched band stage behind pvq_theta ------------
 
    odhip_cache_load_bands (after odhip_cache_load_plane(pli), same frame): the

@@ -430,6 +430,38 @@ void od_encode_rollback(daala_enc_ctx *enc, const od_rollback_buffer *rbuf) {
 }
 #endif
 
+/* ---- od_pvq_rate at speed == 0 on a LIVE, adapted context (tests/test_rate_host.py) -----
+   ref_adapt_new: a freshly reset adaptation context; ref_adapt_code: codes one codeword into a
+   scratch range coder with the LIVE codeword context, i.e. adapts it as the encoder's real
+   coding does; ref_pvq_rate0: the reference's own pricing of a candidate against it
+   (src/pvq_encoder.c:247-287, speed = 0: the context is copied, never changed). */
+REF_EXPORT void *ref_adapt_new(int is_keyframe) {
+  od_adapt_ctx *a;
+  a = (od_adapt_ctx *)calloc(1, sizeof(*a));
+  od_adapt_pvq_ctx_reset(&a->pvq, is_keyframe);
+  return a;
+}
+
+REF_EXPORT void ref_adapt_free(void *a) {
+  free(a);
+}
+
+REF_EXPORT void ref_adapt_code(void *a, const od_coeff *y, int n, int k) {
+  od_ec_enc ec;
+  od_ec_enc_init(&ec, 1000);
+  od_encode_pvq_codeword(&ec, &((od_adapt_ctx *)a)->pvq.pvq_codeword_ctx, y, n, k);
+  od_ec_enc_clear(&ec);
+}
+
+REF_EXPORT double ref_pvq_rate0(void *a, int qg, int icgr, int theta, int ts, const od_coeff *y, int k,
+ int n, int is_keyframe, int pli) {
+  return od_pvq_rate(qg, icgr, theta, ts, (od_adapt_ctx *)a, y, k, n, is_keyframe, pli, 0);
+}
+
+REF_EXPORT int ref_codeword_ctx_size(void) {
+  return (int)sizeof(od_pvq_codeword_ctx);
+}
+
 REF_EXPORT double ref_now(void) {
   struct timespec ts;
   clock_gettime(CLOCK_MONOTONIC, &ts);

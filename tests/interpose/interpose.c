@@ -13,6 +13,7 @@
 #include <dlfcn.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <string.h>
 #include "../../include/daala_hip.h"
 
 /* ODHIP_INTERPOSE_PASSTHROUGH=1: forward to the reference's own definition
@@ -444,20 +445,67 @@ int pvq_theta(od_coeff *out, const od_coeff *x0, const od_coeff *r0, int n, int 
       *max_theta = 0;
       for (i = 0; i < n; i++) y[i] = 0;
       skip_dist = c.dist0;        /* :439: the same expression as :417 on a keyframe */
-      /* :578-609: the (at most two) no-reference candidates, in gain order */
-      for (s = 0; s < 2; s++) {
-        double cost;
-        if (c.flags[s] != 1) continue;
-        odhip_interposed_theta[3]++;
-        for (i = 0; i < n; i++) y_tmp[i] = c.y[s][i];
-        cost = c.dist[s] + pvq_norm_lambda*rate(c.gain[s], 0, -1, 0, adapt, y_tmp, c.k[s], n,
-         is_keyframe, pli, speed);
-        if (cost <= best_cost) {
-          best_cost = cost;
-          best_dist = c.dist[s];
-          qg = c.gain[s];
-          best_k = c.k[s];
-          for (i = 0; i < n; i++) y[i] = y_tmp[i];
+      /* :578-609: the (at most two) no-reference candidates, in gain order.  At the default
+         complexity (speed == 0) od_pvq_rate runs the codeword coder on a copy of the live
+         context per candidate: both candidates are priced in one call of the library's
+         batched routine instead (odhip_pvq_rate_batch16: rate-only range coder,
+         copy-on-touch CDF rows, the same doubles - tests/test_rate_host.py) */
+      {
+        double rates[2];
+        rates[0] = rates[1] = 0;
+        if (speed == 0) {
+          const int16_t *ys[2];
+          int ks[2];
+          int qgs[2];
+          int thetas[2];
+          int tss[2];
+          int nc;
+          int map[2];
+          nc = 0;
+          for (s = 0; s < 2; s++) {
+            if (c.flags[s] != 1) continue;
+            ys[nc] = c.y[s];
+            ks[nc] = c.k[s];
+            qgs[nc] = c.gain[s];
+            thetas[nc] = -1;
+            tss[nc] = 0;
+            map[nc++] = s;
+          }
+          if (nc) {
+            double out[2];
+            /* &adapt->pvq.pvq_codeword_ctx is at offset 0 of od_adapt_ctx (src/state.h:141-143) */
+            if (odhip_pvq_rate_batch16(out, (const odhip_pvq_codeword_ctx *)adapt, nc, ys, ks, qgs, thetas, tss, n, 0,
+             is_keyframe, pli) != 0) {
+              fprintf(stderr, "interpose: odhip_pvq_rate_batch16 failed\n");
+              abort();
+            }
+            for (i = 0; i < nc; i++) rates[map[i]] = out[i];
+          }
+        }
+        for (s = 0; s < 2; s++) {
+          double cost;
+          if (c.flags[s] != 1) continue;
+          odhip_interposed_theta[3]++;
+          for (i = 0; i < n; i++) y_tmp[i] = c.y[s][i];
+          if (speed != 0) {
+            rates[s] = rate(c.gain[s], 0, -1, 0, adapt, y_tmp, c.k[s], n, is_keyframe, pli, speed);
+          }
+          else if (getenv("ODHIP_RATE_CHECK")) {
+            /* every batched price against the reference's own od_pvq_rate */
+            const double want = rate(c.gain[s], 0, -1, 0, adapt, y_tmp, c.k[s], n, is_keyframe, pli, speed);
+            if (memcmp(&want, &rates[s], sizeof(want)) != 0) {
+              fprintf(stderr, "interpose: batched rate %.17g != od_pvq_rate %.17g\n", rates[s], want);
+              abort();
+            }
+          }
+          cost = c.dist[s] + pvq_norm_lambda*rates[s];
+          if (cost <= best_cost) {
+            best_cost = cost;
+            best_dist = c.dist[s];
+            qg = c.gain[s];
+            best_k = c.k[s];
+            for (i = 0; i < n; i++) y[i] = y_tmp[i];
+          }
         }
       }
       /* :611-633: skip rule and the decoder's synthesis */

@@ -127,7 +127,10 @@ def test_batched_band_stage_behind_the_real_encoder_is_byte_identical():
         env = dict(NFRAMES=nframes, QUALITY=quality, COMPLEXITY=complexity,
                    ODHIP_INTERPOSE_PASSTHROUGH=1)
         plain = run(0, w, h, **env)
-        batch = run(3, w, h, ODHIP_CACHE_CHECK=1, **env)
+        # ODHIP_RATE_CHECK: at the default complexity the served bands are priced by the
+        # library's batched host routine (odhip_pvq_rate_batch16); every price is compared
+        # with the reference's own od_pvq_rate on the live context inside the encoder
+        batch = run(3, w, h, ODHIP_CACHE_CHECK=1, ODHIP_RATE_CHECK=1, **env)
         assert batch["sizes"] == plain["sizes"], (w, h)
         assert batch["packets"] == plain["packets"], (w, h, quality, complexity)
         served, with_ref, other, searches = batch["theta"]
