@@ -280,6 +280,39 @@ void od_apply_postfilter_frame_sbs_hip(od_coeff *c, int stride, int nhsb, int nv
   });
 }
 
+/* od_compute_dist (src/encode.c:1170-1226; file-static there, call sites :1418-1421,
+   :1797-1798) for ONE block, host pointers, synchronous: x (source) and y (reconstruction)
+   are compact n x n blocks (stride n) as the encoder's c_orig / split / nosplit buffers
+   hold them; the device computes every 8x8 block's three doubles up to the pow
+   (odhip_dist_parts), the host finishes with its libm (odhip_dist_finish).  The arguments
+   the reference reads from enc are passed: enc->use_activity_masking, enc->qm ==
+   OD_FLAT_QM, enc->state.coded_quantizer. */
+double od_compute_dist_hip(const od_coeff *x, const od_coeff *y, int n, int use_masking, int flat_qm,
+ int coded_quantizer) {
+  int bs = 0;
+  while (bs < ODHIP_NBSIZES && (4 << bs) != n) bs++;
+  if (bs < 1 || bs >= ODHIP_NBSIZES) {
+    fprintf(stderr, "libdaalahip: fatal: od_compute_dist_hip n=%d (8, 16, 32 or 64)\n", n);
+    abort();
+  }
+  Scratch &s = g_scratch;
+  const size_t blk = (size_t)n*n*sizeof(od_coeff);
+  const size_t nparts = (size_t)(n/8)*(n/8)*3;
+  char *d = (char *)s.get(0, 2*blk + nparts*sizeof(double));
+  HIP_OR_DIE(hipMemcpyAsync(d, x, blk, hipMemcpyHostToDevice, s.stream));
+  HIP_OR_DIE(hipMemcpyAsync(d + blk, y, blk, hipMemcpyHostToDevice, s.stream));
+  double *d_parts = (double *)(d + 2*blk);
+  ok_or_die(odhip_dist_parts(d_parts, (const od_coeff *)d, (const od_coeff *)(d + blk), 1, n, n, bs,
+   use_masking, flat_qm, s.stream), "odhip_dist_parts");
+  double parts[8*8*3];
+  HIP_OR_DIE(hipMemcpyAsync(parts, d_parts, nparts*sizeof(double), hipMemcpyDeviceToHost, s.stream));
+  HIP_OR_DIE(hipStreamSynchronize(s.stream));
+  double dist = 0;
+  ok_or_die(odhip_dist_finish(&dist, parts, 1, n, n, bs, use_masking, flat_qm, coded_quantizer),
+   "odhip_dist_finish");
+  return dist;
+}
+
 double od_pvq_search_rdo_double_hip(const int16_t *xcoeff, int n, int k,
  od_coeff *ypulse, double g2, double pvq_norm_lambda, int prev_k) {
   if (n < 1 || n > 128) {

@@ -806,6 +806,12 @@ void odhip_dering_cache_stats(const odhip_dering_cache *c, long *launches, long 
                         coded-quantiser factor: dist [plane][h/n][w/n].
    use_masking = enc->use_activity_masking, flat_qm = (enc->qm == OD_FLAT_QM: plain
    squared error), coded_quantizer = state.coded_quantizer. */
+/* Per-call form with od_compute_dist's arguments (host pointers, compact n x n blocks,
+   synchronous; enc's three fields passed): a reference build binds it at the top of its
+   file-static od_compute_dist (oracle/Makefile builds that variant,
+   _ref/libdaalaref_disthip.so, for tests/test_gpu_dropin_encoder.py). */
+double od_compute_dist_hip(const od_coeff *x, const od_coeff *y, int n, int use_masking, int flat_qm,
+ int coded_quantizer);
 int odhip_dist_parts(double *d_parts, const od_coeff *d_x, const od_coeff *d_y, int nplanes, int w,
  int h, int bs, int use_masking, int flat_qm, odhip_stream stream);
 int odhip_dist_finish(double *dist, const double *parts, int nplanes, int w, int h, int bs,

@@ -85,6 +85,12 @@ if ipo is not None and os.environ.get("ODHIP_INTERPOSE_DERING_CACHE") == "1":
     ipo.odhip_interpose_dering_stats()
     arr = (ctypes.c_long * 2).in_dll(ipo, "odhip_interposed_dering")
     dering = [arr[0], arr[1]]      # batched launches, od_dering calls served from them
+dist_calls = None
+try:
+    # the build with od_compute_dist bound to od_compute_dist_hip counts its calls
+    dist_calls = ctypes.c_long.in_dll(r, "ref_dist_hip_calls").value
+except ValueError:
+    pass
 import hashlib
 pkt_digest = None
 if os.environ.get("PACKET_DIGEST") == "1":
@@ -98,5 +104,5 @@ if os.environ.get("PACKET_DIGEST") == "1":
     pkt_digest = hh.hexdigest()
 print(json.dumps({"digest": pkt_digest, "packets": hashlib.sha256(bytes(out[:total])).hexdigest(),
                   "sizes": [sizes[i] for i in range(n)], "calls": calls, "cache": stats, "theta": theta, "dering": dering,
-                  "gpu_batch_ms": gpu_ms,
+                  "gpu_batch_ms": gpu_ms, "dist_hip_calls": dist_calls,
                   "encode_seconds": seconds}))

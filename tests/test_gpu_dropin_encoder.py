@@ -232,3 +232,34 @@ def test_configs0_reference_built_for_4x4_blocks_only():
     # every superblock is split all the way down (the split filters of all four levels run),
     # only 4x4 blocks are coded
     assert all(c > 0 for c in bound["calls"]), bound["calls"]
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                                    "oracle", "_ref", "libdaalaref_disthip.so")),
+                    reason="oracle/_ref/libdaalaref_disthip.so not present")
+def test_od_compute_dist_bound_behind_the_block_size_rdo_is_byte_identical():
+    """SURVEY.md 8(f) rank 2 bound where the reference calls it: a build of the reference whose
+    file-static od_compute_dist (src/encode.c:1170; call sites :1418-1421, :1797-1798: every
+    split / no-split decision of the block-size RDO) forwards to the library's per-call surface
+    od_compute_dist_hip - device parts + host pow.  Its doubles feed `dist + lambda*rate`
+    comparisons, so the packets are byte-identical to plain C only if every one of them is the
+    reference's bit for bit."""
+    import json
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    res = {}
+    for lib in ("libdaalaref.so", "libdaalaref_disthip.so"):
+        e = dict(os.environ)
+        e.update(NFRAMES="2", QUALITY="20", COMPLEXITY="7", REF_LIB=lib)
+        p = subprocess.run([sys.executable, os.path.join(here, "interpose", "run_interposed.py"), "0", "192", "128"],
+                           capture_output=True, text=True, timeout=1500, env=e)
+        assert p.returncode == 0, p.stderr[-3000:]
+        res[lib] = json.loads(p.stdout.strip().splitlines()[-1])
+    a, b = res["libdaalaref.so"], res["libdaalaref_disthip.so"]
+    assert b["dist_hip_calls"] and b["dist_hip_calls"] > 500 and a["dist_hip_calls"] is None
+    assert b["sizes"] == a["sizes"] and b["packets"] == a["packets"]
+    print("od_compute_dist bound: %d calls through od_compute_dist_hip, %.1f us per call incl. PCIe both ways "
+          "(encode %.2f s vs %.2f s plain C)"
+          % (b["dist_hip_calls"], 1e6 * (b["encode_seconds"] - a["encode_seconds"]) / b["dist_hip_calls"],
+             b["encode_seconds"], a["encode_seconds"]))
