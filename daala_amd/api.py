@@ -18,7 +18,8 @@ class DaalaHipError(RuntimeError):
 
 
 def lib_path():
-    return os.path.join(_HERE, "lib", "libdaalahip.so")
+    # ODHIP_LIB: another build of the same library (kernel A/B experiments, tools/)
+    return os.environ.get("ODHIP_LIB") or os.path.join(_HERE, "lib", "libdaalahip.so")
 
 
 def lib():
@@ -172,9 +173,17 @@ def forward_pyramid(px, dec, pic_w, pic_h, levels=None, want=None):
     nplanes, h, w = px.shape
     top = 4 - dec
     if levels is None:
-        levels = [torch.empty((nplanes, h, w), dtype=torch.int32, device=px.device)
-                  if (want is None or bs in want) else None
-                  for bs in range(top + 1)]
+        # ONE allocation, the planes a non-power-of-two distance apart: separate torch allocations
+        # of 127.5 MiB (16 frames of 1080p) land exactly 128 MiB apart, and five streams written
+        # concurrently at addresses equal modulo 2^27 share HBM channels and banks - 216 us per
+        # launch instead of 173 (tools/pyr_skew.py, DESIGN.md par. 4)
+        n = nplanes * h * w
+        stride = ((n + 1023) & ~1023) + (68 << 10)          # int32 elements; +272 KiB
+        ks = [bs for bs in range(top + 1) if (want is None or bs in want)]
+        big = torch.empty((max(len(ks), 1) * stride,), dtype=torch.int32, device=px.device)
+        levels = [None] * (top + 1)
+        for i, bs in enumerate(ks):
+            levels[bs] = big[i * stride: i * stride + n].view(nplanes, h, w)
     arr = (ctypes.c_void_p * 5)()
     for bs in range(5):
         t = levels[bs] if bs <= top else None

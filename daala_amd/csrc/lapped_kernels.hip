@@ -42,6 +42,17 @@ __device__ __forceinline__ void od_lds_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+/* 16-byte store of coefficients to a level plane.  OD_PYR_STORE_NT (experiment): non-temporal. */
+typedef int od_v4i __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void od_store_coef4(od_coeff *p, int4 v) {
+#ifdef OD_PYR_STORE_NT
+  od_v4i w = {v.x, v.y, v.z, v.w};
+  __builtin_nontemporal_store(w, reinterpret_cast<od_v4i *>(p));
+#else
+  *reinterpret_cast<int4 *>(p) = v;
+#endif
+}
+
 template <int TILE>
 struct Geo {
 #ifndef OD_PYR_NT64
@@ -122,15 +133,33 @@ __device__ __forceinline__ void split_filter_rows(E *t, int tid, int y0, int pic
   }
 }
 
+/* Tile -> raster plane.  Every lane's LDS reads are issued before its first store: one exposed
+   LDS latency per tile instead of one per 16 bytes (the rolled loop was a chain of
+   ds_read -> s_waitcnt -> global_store, ~150 cycles each, 160 times per wave and superblock pair). */
 template <int TILE, int NT = Geo<TILE>::kNT>
 __device__ __forceinline__ void store_tile(od_coeff *plane, int w, int x0, int y0,
  const int *z, int tid) {
   constexpr int P = Geo<TILE>::kPitch;
-  for (int i = tid; i < TILE*TILE/4; i += NT) {
-    const int y = i/(TILE/4);
-    const int x = (i % (TILE/4))*4;
-    *reinterpret_cast<int4 *>(plane + (long)(y0 + y)*w + x0 + x) =
-     *reinterpret_cast<const int4 *>(z + y*P + x);
+  if constexpr ((TILE*TILE/4) % NT == 0) {
+    constexpr int K = TILE*TILE/4/NT;
+    int4 v[K];
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+      const int i = tid + k*NT;
+      v[k] = *reinterpret_cast<const int4 *>(z + (i/(TILE/4))*P + (i % (TILE/4))*4);
+    }
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+      const int i = tid + k*NT;
+      od_store_coef4(plane + (long)(y0 + i/(TILE/4))*w + x0 + (i % (TILE/4))*4, v[k]);
+    }
+  }
+  else {
+    for (int i = tid; i < TILE*TILE/4; i += NT) {
+      const int y = i/(TILE/4);
+      const int x = (i % (TILE/4))*4;
+      od_store_coef4(plane + (long)(y0 + y)*w + x0 + x, *reinterpret_cast<const int4 *>(z + y*P + x));
+    }
   }
 }
 
@@ -193,19 +222,26 @@ __device__ __forceinline__ void pyramid_level_split64(short *t, int *z, const Py
   od_lds_barrier();
   if (a.levels[LN]) {
     od_coeff *plane = a.levels[LN] + plane_off;
-    for (int i = tid; i < TILE*TILE/4; i += NT) {
+    static_assert((TILE*TILE/4) % NT == 0, "whole trips");
+    constexpr int K = TILE*TILE/4/NT;
+    int o[K][4];
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+      const int i = tid + k*NT;
       const int y = i/(TILE/4);
       const int x = (i % (TILE/4))*4;
       const int v = y & (N - 1);
       const int col = (y - v) + (v & 1)*H + (v >> 1);
-      int o[4];
 #pragma unroll
       for (int j = 0; j < 4; j++) {
         const int u = (x + j) & (N - 1);
-        o[j] = z[((x + j - u) + (u & 1)*H + (u >> 1))*PZ + col];
+        o[k][j] = z[((x + j - u) + (u & 1)*H + (u >> 1))*PZ + col];
       }
-      *reinterpret_cast<int4 *>(plane + (long)(y0 + y)*a.w + x0 + x) =
-       make_int4(o[0], o[1], o[2], o[3]);
+    }
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+      const int i = tid + k*NT;
+      od_store_coef4(plane + (long)(y0 + i/(TILE/4))*a.w + x0 + (i % (TILE/4))*4, make_int4(o[k][0], o[k][1], o[k][2], o[k][3]));
     }
   }
   split_filter_rows<TILE, LN, false, NT>(t, tid, y0, a.pic_h);
@@ -249,8 +285,7 @@ __device__ __forceinline__ void pyramid_level4(const short *t, const PyramidArgs
   for (int r = 0; r < 4; r++) {
     T out[4];
     od_fdct4_lift(out, m[r]);
-    *reinterpret_cast<int4 *>(plane + (long)(y0 + by*4 + r)*a.w + x0 + bx*4) =
-     make_int4(out[0], out[1], out[2], out[3]);
+    od_store_coef4(plane + (long)(y0 + by*4 + r)*a.w + x0 + bx*4, make_int4(out[0], out[1], out[2], out[3]));
   }
   }
 }
@@ -283,51 +318,110 @@ __device__ __forceinline__ void pyramid_level(short *t, int *z, const PyramidArg
 /* The three steps that bring a superblock tile (with its 2-sample halo) into
    LDS and lap it across the superblock edges; a barrier separates them. */
 template <int TILE, int NT>
-__device__ __forceinline__ void sb_load(short *t, const PyramidArgs &a, const uint8_t *px,
+__device__ __forceinline__ void sb_halo_pos(int i, int &r, int &c) {
+  if (i < 4*(TILE + 4)) {
+    const int k = i/(TILE + 4);
+    r = k < 2 ? k - 2 : TILE + k - 2;
+    c = i % (TILE + 4) - 2;
+  }
+  else {
+    const int j = i - 4*(TILE + 4);
+    const int k = j & 3;
+    r = j >> 2;
+    c = k < 2 ? k - 2 : TILE + k - 2;
+  }
+}
+
+/* One lane's share of an 8-bit superblock tile and its halo ring (2 samples of each
+   neighbouring superblock, where it exists).  issue() puts every global load in flight,
+   commit() converts (od_ref_buf_to_coeff, src/state.c:1231-1237: (p - 128) << OD_COEFF_SHIFT)
+   and writes the tile: a workgroup pays ONE memory latency for its pictures, not one per
+   256 samples (the rolled loops were load -> s_waitcnt vmcnt(0) -> ds_write, 7 times per tile). */
+template <int TILE, int NT>
+struct SbFetch {
+  using G = Geo<TILE>;
+  static_assert((TILE*TILE/4) % NT == 0, "whole trips");
+  static constexpr int kMain = TILE*TILE/4/NT;
+  static constexpr int kHalo = (8*TILE + 16 + NT - 1)/NT;
+  uint32_t m[kMain];
+  int hv[kHalo];
+  __device__ __forceinline__ void issue(const PyramidArgs &a, const uint8_t *px, int x0, int y0, int tid) {
+#pragma unroll
+    for (int k = 0; k < kMain; k++) {
+      const int i = tid + k*NT;
+      m[k] = *reinterpret_cast<const uint32_t *>(px + (long)(y0 + i/(TILE/4))*a.px_stride + x0
+       + (i % (TILE/4))*4);
+    }
+#pragma unroll
+    for (int k = 0; k < kHalo; k++) {
+      const int i = tid + k*NT;
+      int r;
+      int c;
+      sb_halo_pos<TILE, NT>(i, r, c);
+      const int gx = x0 + c;
+      const int gy = y0 + r;
+      hv[k] = -1;
+      if (i < 8*TILE + 16 && gx >= 0 && gx < a.w && gy >= 0 && gy < a.h) hv[k] = px[(long)gy*a.px_stride + gx];
+    }
+  }
+  __device__ __forceinline__ void commit(short *t, int tid) const {
+    constexpr int P = G::kPitch;
+#pragma unroll
+    for (int k = 0; k < kMain; k++) {
+      const int i = tid + k*NT;
+      const uint32_t v = m[k];
+      *reinterpret_cast<short4 *>(t + (i/(TILE/4))*P + (i % (TILE/4))*4) =
+       make_short4(((int)(v & 255) - 128)*16, ((int)((v >> 8) & 255) - 128)*16,
+       ((int)((v >> 16) & 255) - 128)*16, ((int)(v >> 24) - 128)*16);
+    }
+#pragma unroll
+    for (int k = 0; k < kHalo; k++) {
+      int r;
+      int c;
+      sb_halo_pos<TILE, NT>(tid + k*NT, r, c);
+      if (hv[k] >= 0) t[G::map(r)*P + G::map(c)] = (short)((hv[k] - 128)*16);
+    }
+  }
+};
+
+/* Full-precision references (src/state.c:1245-1250: p - 2048): int16 samples, the plain loops. */
+template <int TILE, int NT>
+__device__ __forceinline__ void sb_load16(short *t, const PyramidArgs &a, const uint8_t *px,
  int x0, int y0, int tid) {
   using G = Geo<TILE>;
   constexpr int P = G::kPitch;
-  const int w = a.w;
-  const int h = a.h;
-  /* od_ref_buf_to_coeff, src/state.c:1231-1237: (p - 128) << OD_COEFF_SHIFT; with
-     full-precision references :1245-1250: p - 2048. */
-  const bool px16 = a.px16 != 0;
   const short *px_w = reinterpret_cast<const short *>(px);
   for (int i = tid; i < TILE*TILE/4; i += NT) {
     const int y = i/(TILE/4);
     const int x = (i % (TILE/4))*4;
-    const long at = (long)(y0 + y)*a.px_stride + x0 + x;
-    if (px16) {
-      const short4 v = *reinterpret_cast<const short4 *>(px_w + at);
-      *reinterpret_cast<short4 *>(t + y*P + x) = make_short4(v.x - 2048, v.y - 2048, v.z - 2048, v.w - 2048);
-    }
-    else {
-      const uchar4 v = *reinterpret_cast<const uchar4 *>(px + at);
-      *reinterpret_cast<short4 *>(t + y*P + x) =
-       make_short4((v.x - 128)*16, (v.y - 128)*16, (v.z - 128)*16, (v.w - 128)*16);
-    }
+    const short4 v = *reinterpret_cast<const short4 *>(px_w + (long)(y0 + y)*a.px_stride + x0 + x);
+    *reinterpret_cast<short4 *>(t + y*P + x) = make_short4(v.x - 2048, v.y - 2048, v.z - 2048, v.w - 2048);
   }
-  /* Halo ring: 2 samples of each neighbouring superblock (where it exists). */
   for (int i = tid; i < 8*TILE + 16; i += NT) {
     int r;
     int c;
-    if (i < 4*(TILE + 4)) {
-      const int k = i/(TILE + 4);
-      r = k < 2 ? k - 2 : TILE + k - 2;
-      c = i % (TILE + 4) - 2;
-    }
-    else {
-      const int j = i - 4*(TILE + 4);
-      const int k = j & 3;
-      r = j >> 2;
-      c = k < 2 ? k - 2 : TILE + k - 2;
-    }
+    sb_halo_pos<TILE, NT>(i, r, c);
     const int gx = x0 + c;
     const int gy = y0 + r;
-    if (gx >= 0 && gx < w && gy >= 0 && gy < h) {
-      const long at = (long)gy*a.px_stride + gx;
-      t[G::map(r)*P + G::map(c)] = px16 ? (short)(px_w[at] - 2048) : (short)((px[at] - 128)*16);
+    if (gx >= 0 && gx < a.w && gy >= 0 && gy < a.h) {
+      t[G::map(r)*P + G::map(c)] = (short)(px_w[(long)gy*a.px_stride + gx] - 2048);
     }
+  }
+}
+
+/* NS horizontally adjacent tiles starting at x0. */
+template <int TILE, int NT, int NS = 1>
+__device__ __forceinline__ void sb_load(short (*t)[Geo<TILE>::kHaloWords], const PyramidArgs &a,
+ const uint8_t *px, int x0, int y0, int tid) {
+  if (a.px16) {
+    for (int s = 0; s < NS; s++) sb_load16<TILE, NT>(t[s], a, px, x0 + s*TILE, y0, tid);
+  }
+  else {
+    SbFetch<TILE, NT> f[NS];
+#pragma unroll
+    for (int s = 0; s < NS; s++) f[s].issue(a, px, x0 + s*TILE, y0, tid);
+#pragma unroll
+    for (int s = 0; s < NS; s++) f[s].commit(t[s], tid);
   }
 }
 
@@ -405,7 +499,7 @@ __global__ __launch_bounds__(NT) void k_forward_pyramid(PyramidArgs a) {
   const int y0 = blockIdx.y*TILE;
   const uint8_t *px = pyr_plane(a, blockIdx.z);
   const long plane_off = (long)blockIdx.z*a.w*a.h;
-  sb_load<TILE, NT>(t, a, px, x0, y0, tid);
+  sb_load<TILE, NT>(&t, a, px, x0, y0, tid);
   od_lds_barrier();
   sb_edge_cols<TILE, NT>(t, a, x0, y0, tid);
   od_lds_barrier();
@@ -437,7 +531,7 @@ __global__ __launch_bounds__(256) void k_forward_pyramid64x2(PyramidArgs a) {
   const int y0 = blockIdx.y*TILE;
   const uint8_t *px = pyr_plane(a, blockIdx.z);
   const long plane_off = (long)blockIdx.z*a.w*a.h;
-  for (int s = 0; s < 2; s++) sb_load<TILE, NT>(t[s], a, px, xb + s*TILE, y0, tid);
+  sb_load<TILE, NT, 2>(t, a, px, xb, y0, tid);
   od_lds_barrier();
   for (int s = 0; s < 2; s++) sb_edge_cols<TILE, NT>(t[s], a, xb + s*TILE, y0, tid);
   od_lds_barrier();
@@ -478,18 +572,28 @@ __global__ __launch_bounds__(256) void k_forward_pyramid64x2(PyramidArgs a) {
     }
     od_lds_barrier();
     if (a.levels[4]) {
+      /* copy-out: every lane reads its 8 x 16 bytes of both tiles, then stores them */
       od_coeff *plane = a.levels[4] + plane_off;
-      for (int i = tid; i < 2*TILE*TILE/4; i += NT) {
+      constexpr int K = 2*TILE*TILE/4/NT;
+      int o[K][4];
+#pragma unroll
+      for (int k = 0; k < K; k++) {
+        const int i = tid + k*NT;
         const int s = i/(TILE*TILE/4);
         const int j = i - s*(TILE*TILE/4);
         const int y = j/(TILE/4);
         const int x = (j % (TILE/4))*4;
         const int col = (y & 1)*H + (y >> 1);
-        int o[4];
 #pragma unroll
-        for (int q = 0; q < 4; q++) o[q] = z[s][(((x + q) & 1)*H + ((x + q) >> 1))*PZ + col];
-        *reinterpret_cast<int4 *>(plane + (long)(y0 + y)*a.w + xb + s*TILE + x) =
-         make_int4(o[0], o[1], o[2], o[3]);
+        for (int q = 0; q < 4; q++) o[k][q] = z[s][(((x + q) & 1)*H + ((x + q) >> 1))*PZ + col];
+      }
+#pragma unroll
+      for (int k = 0; k < K; k++) {
+        const int i = tid + k*NT;
+        const int s = i/(TILE*TILE/4);
+        const int j = i - s*(TILE*TILE/4);
+        od_store_coef4(plane + (long)(y0 + j/(TILE/4))*a.w + xb + s*TILE + (j % (TILE/4))*4,
+         make_int4(o[k][0], o[k][1], o[k][2], o[k][3]));
       }
     }
     for (int s = 0; s < 2; s++) split_filter_rows<TILE, 4, false>(t[s], tid, y0, a.pic_h);
@@ -590,8 +694,7 @@ __device__ __forceinline__ void half_level(short *t, int *z, const PyramidArgs &
       for (int r = 0; r < 4; r++) {
         T out[4];
         od_fdct4_lift(out, m[r]);
-        *reinterpret_cast<int4 *>(plane + (long)(y0 + r0 + by*4 + r)*a.w + x0 + bx*4) =
-         make_int4(out[0], out[1], out[2], out[3]);
+        od_store_coef4(plane + (long)(y0 + r0 + by*4 + r)*a.w + x0 + bx*4, make_int4(out[0], out[1], out[2], out[3]));
       }
     }
   }
@@ -645,8 +748,7 @@ __device__ __forceinline__ void half_level(short *t, int *z, const PyramidArgs &
       for (int i = lane; i < ROWS*TILE/4; i += 64) {
         const int y = r0 + i/(TILE/4);
         const int x = (i % (TILE/4))*4;
-        *reinterpret_cast<int4 *>(plane + (long)(y0 + y)*a.w + x0 + x) =
-         *reinterpret_cast<const int4 *>(z + y*P + x);
+        od_store_coef4(plane + (long)(y0 + y)*a.w + x0 + x, *reinterpret_cast<const int4 *>(z + y*P + x));
       }
     }
     /* ... and row taps */
@@ -674,7 +776,7 @@ __global__ __launch_bounds__(128) void k_forward_pyramid_halves(PyramidArgs a) {
   const int y0 = blockIdx.y*TILE;
   const uint8_t *px = pyr_plane(a, blockIdx.z);
   const long plane_off = (long)blockIdx.z*a.w*a.h;
-  sb_load<TILE, NT>(t, a, px, x0, y0, tid);
+  sb_load<TILE, NT>(&t, a, px, x0, y0, tid);
   od_lds_barrier();
   sb_edge_cols<TILE, NT>(t, a, x0, y0, tid);
   od_lds_barrier();
@@ -1321,6 +1423,9 @@ extern "C" int odhip_forward_pyramid(od_coeff *const d_levels[ODHIP_NBSIZES],
      64 points (k_forward_pyramid_halves).  16 frames of 1080p: 2 -> 239 us,
      0 -> 243, 6 -> 245, 3 -> 253, 4 -> 258, 1 -> 259. */
   static const int variant = getenv("ODHIP_PYR_VARIANT") ? atoi(getenv("ODHIP_PYR_VARIANT")) : 2;
+  /* ODHIP_PYR_LDS_PAD: extra dynamic LDS bytes per workgroup of the luma kernel, to measure how the
+     time follows occupancy (tools/pyr_stalls.py); 0 outside that experiment. */
+  static const unsigned lds_pad = getenv("ODHIP_PYR_LDS_PAD") ? (unsigned)atoi(getenv("ODHIP_PYR_LDS_PAD")) : 0;
   if (dec) {
     if (variant & 2) k_forward_pyramid<32, OdMul24S><<<grid, Geo<32>::kNT, 0, s>>>(a);
     else k_forward_pyramid<32><<<grid, Geo<32>::kNT, 0, s>>>(a);
@@ -1334,7 +1439,7 @@ extern "C" int odhip_forward_pyramid(od_coeff *const d_levels[ODHIP_NBSIZES],
     else k_forward_pyramid<64, OdMul24, 128><<<grid, 128, 0, s>>>(a);
   }
   else if ((w/tile) % 2 == 0 && !getenv("ODHIP_PYRAMID_X1")) {
-    if (variant & 2) k_forward_pyramid64x2<OdMul24S><<<dim3(w/(2*tile), h/tile, nplanes), 256, 0, s>>>(a);
+    if (variant & 2) k_forward_pyramid64x2<OdMul24S><<<dim3(w/(2*tile), h/tile, nplanes), 256, lds_pad, s>>>(a);
     else k_forward_pyramid64x2<OdMul24><<<dim3(w/(2*tile), h/tile, nplanes), 256, 0, s>>>(a);
   }
   else k_forward_pyramid<64><<<grid, Geo<64>::kNT, 0, s>>>(a);
