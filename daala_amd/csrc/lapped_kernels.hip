@@ -848,6 +848,26 @@ __device__ __forceinline__ void od_store_px(uint8_t *plane, long at, int c, bool
   else plane[at] = od_to_px(c);
 }
 
+/* Raster plane -> tile, every lane's global loads in flight before its first LDS write. */
+template <int TILE>
+__device__ __forceinline__ void load_plane_tile(int *t, const od_coeff *plane, int w, int x0, int y0, int tid) {
+  constexpr int P = Geo<TILE>::kPitch;
+  constexpr int NT = Geo<TILE>::kNT;
+  static_assert((TILE*TILE/4) % NT == 0, "whole trips");
+  constexpr int K = TILE*TILE/4/NT;
+  int4 v[K];
+#pragma unroll
+  for (int k = 0; k < K; k++) {
+    const int i = tid + k*NT;
+    v[k] = *reinterpret_cast<const int4 *>(plane + (long)(y0 + i/(TILE/4))*w + x0 + (i % (TILE/4))*4);
+  }
+#pragma unroll
+  for (int k = 0; k < K; k++) {
+    const int i = tid + k*NT;
+    *reinterpret_cast<int4 *>(t + (i/(TILE/4))*P + (i % (TILE/4))*4) = v[k];
+  }
+}
+
 template <int TILE, int LN>
 __device__ __forceinline__ void inverse_split_levels(int *t, const InverseArgs &a,
  int x0, int y0, int tid) {
@@ -891,12 +911,7 @@ __device__ __forceinline__ void inverse_load_ref(int *t, const InverseArgs &a, i
     /* 32x32 / 64x64: the positions PVQ never codes are what od_init_skipped_coeffs leaves
        (src/state.c:1347-1366): zero on a keyframe, the prediction's coefficients otherwise */
     if (a.inter) {
-      for (int i = tid; i < TILE*TILE/4; i += NT) {
-        const int y = i/(TILE/4);
-        const int x = (i % (TILE/4))*4;
-        *reinterpret_cast<int4 *>(t + y*P + x) =
-         *reinterpret_cast<const int4 *>(a.ref + plane_off + (long)(y0 + y)*a.w + x0 + x);
-      }
+      load_plane_tile<TILE>(t, a.ref + plane_off, a.w, x0, y0, tid);
     }
     else {
       for (int i = tid; i < TILE*P/4; i += NT) reinterpret_cast<int4 *>(t)[i] = make_int4(0, 0, 0, 0);
@@ -1007,10 +1022,20 @@ __device__ __forceinline__ void inverse_store(const int *t, const InverseArgs &a
   const int h = a.h;
   const bool px16 = a.px16 != 0;
   uint8_t *px = a.px + ((long)plane*a.px_plane_stride << a.px16);
-  for (int i = tid; i < TILE*TILE/4; i += NT) {
+  static_assert((TILE*TILE/4) % NT == 0, "whole trips");
+  constexpr int K = TILE*TILE/4/NT;
+  int4 tv[K];
+#pragma unroll
+  for (int k = 0; k < K; k++) {               /* all LDS reads in flight before the first store */
+    const int i = tid + k*NT;
+    tv[k] = *reinterpret_cast<const int4 *>(t + (i/(TILE/4))*P + (i % (TILE/4))*4);
+  }
+#pragma unroll
+  for (int k = 0; k < K; k++) {
+    const int i = tid + k*NT;
     const int y = i/(TILE/4);
     const int x = (i % (TILE/4))*4;
-    const int4 v = *reinterpret_cast<const int4 *>(t + y*P + x);
+    const int4 v = tv[k];
     const long at = (long)(y0 + y)*a.px_stride + x0 + x;
     if (px16) {
       *reinterpret_cast<short4 *>(reinterpret_cast<short *>(px) + at) =
@@ -1164,18 +1189,16 @@ __global__ __launch_bounds__(Geo<TILE>::kNT) void k_inverse_part(InversePartArgs
     if (DEC) v = (v > 1 ? v : 1) - 1;      /* the chroma block of that luma block */
     map[tid] = (unsigned char)v;
   }
-  for (int i = tid; i < TILE*TILE/4; i += NT) {
-    const int y = i/(TILE/4);
-    const int x = (i % (TILE/4))*4;
-    *reinterpret_cast<int4 *>(t + y*P + x) =
-     *reinterpret_cast<const int4 *>(a.coef + plane_off + (long)(y0 + y)*a.w + x0 + x);
-  }
+  load_plane_tile<TILE>(t, a.coef + plane_off, a.w, x0, y0, tid);
   __syncthreads();
   inverse_part_levels<TILE, 0>(t, map, a, x0, y0, tid);
   inverse_store<TILE>(t, a, plane, x0, y0, tid);
 }
 
-template <int TILE, bool REF = false>
+/* MINLEAF..MAXLEAF: the leaf levels this instance is launched for.  The 64- and 32-point networks
+   need ~120 VGPRs (4 waves per SIMD), the 16-point and smaller ones about half of that: the luma
+   levels go out as two launches so that three of the five run at twice the occupancy. */
+template <int TILE, bool REF = false, int MINLEAF = 0, int MAXLEAF = (TILE == 64 ? 4 : 3)>
 __global__ __launch_bounds__(Geo<TILE>::kNT) void k_inverse_sb(InverseArgsMulti mm) {
   using G = Geo<TILE>;
   constexpr int P = G::kPitch;
@@ -1196,67 +1219,66 @@ __global__ __launch_bounds__(Geo<TILE>::kNT) void k_inverse_sb(InverseArgsMulti 
        scattered to raster inside LDS (od_coding_order_to_raster,
        src/partition.c:176-194).  The pulse vectors are read as contiguous
        len-word rows; the dequantised plane never exists in HBM. */
-    __shared__ __attribute__((aligned(16))) unsigned short s_scan[OD_SCAN_LEN];
-    __shared__ unsigned char s_band[OD_SCAN_LEN];
-    __shared__ int4 s_choice[256];
-    __shared__ __attribute__((aligned(16))) short s_qmi[OD_SCAN_LEN];
     const int sh = a.leaf_bs + 2;
     const int nbw = TILE >> sh;                 /* blocks per tile row */
     const int nbsb = nbw*nbw;
     const int bw = a.w >> sh;
     const int bh = a.h >> sh;
-    for (int i = tid; i < a.len; i += NT) {
-      s_scan[i] = gInvScanXY[i];
-      s_band[i] = gInvBandOf[i];
-      s_qmi[i] = a.qm_inv[i];
-    }
-    for (int i = tid; i < nbsb*a.nb_bands; i += NT) {
-      const int b = i/a.nb_bands;
-      const int band = i - b*a.nb_bands;
-      const long blk = ((long)plane*bh + (y0 >> sh) + b/nbw)*bw + (x0 >> sh) + b % nbw;
-      s_choice[i] = a.choice[blk*a.nb_bands + band];
-    }
-    if ((a.len >> sh) < (1 << sh)) {            /* 32x32 / 64x64: uncoded positions are zero */
-      for (int i = tid; i < TILE*P/4; i += NT) reinterpret_cast<int4 *>(t)[i] = make_int4(0, 0, 0, 0);
-    }
-    __syncthreads();
-    /* One CHUNK of 16 consecutive coding indices of one block per thread
-       (len/16 chunks per block, at most one chunk per thread): two 16-byte
-       loads of pulses, two of inverse-QM entries and two of scan positions per
-       chunk, one exposed memory latency per workgroup.  A chunk touches at
-       most two bands (coding indices 16..31 hold two bands of 8): one choice
-       per half. */
+    /* One CHUNK of 16 consecutive coding indices of one block per thread (len/16 chunks per
+       block; nbsb*len/16 <= NT for every level, so a thread has at most one chunk).  Everything
+       the chunk needs comes straight from global memory into registers - band of its two halves
+       (gInvBandOf: 1 KB, cache-resident), their choice records, two 16-byte loads of pulses, of
+       inverse-QM entries and of scan positions - in one dependent chain band -> choice -> pulses
+       with the table loads beside it: the workgroup pays that chain ONCE.  (Staging the tables
+       and the choices in LDS first cost a load -> wait -> LDS store per 256 entries, up to 12
+       serial memory latencies per workgroup, and 9 KB of LDS: 6 instead of 9 workgroups per CU.)
+       A chunk touches at most two bands (coding indices 16..31 hold two bands of 8). */
     const int lsh = 31 - __clz(a.len);          /* len is a power of two */
     const int csh = lsh - 4;                    /* chunks per block = len/16 */
     const int lnb = 31 - __clz(nbw);            /* so is the block count per tile row */
     const long blk0 = ((long)plane*bh + (y0 >> sh))*bw + (x0 >> sh);
-    for (int c = tid; c < nbsb << csh; c += NT) {
-      const int b = c >> csh;
-      const int j0 = (c & ((1 << csh) - 1)) << 4;
-      const int lby = b >> lnb;
-      const int lbx = b & (nbw - 1);
-      const unsigned blk = (unsigned)blk0 + lby*bw + lbx;   /* < 2^31/len, checked by the host */
-      const int4 chs[2] = {s_choice[b*a.nb_bands + s_band[j0 ? j0 : 1]],
-       s_choice[b*a.nb_bands + s_band[j0 + 8]]};
-      int4 yq[2];
+    const int c = tid;
+    const bool act = c < (nbsb << csh);
+    const int b = c >> csh;
+    const int j0 = (c & ((1 << csh) - 1)) << 4;
+    const int lby = b >> lnb;
+    const int lbx = b & (nbw - 1);
+    const unsigned blk = (unsigned)blk0 + lby*bw + lbx;   /* < 2^31/len, checked by the host */
+    int4 chs[2] = {make_int4(0, 0, 0, 0), make_int4(0, 0, 0, 0)};
+    int4 yq[2] = {make_int4(0, 0, 0, 0), make_int4(0, 0, 0, 0)};
+    int4 qm4[2];
+    int4 sc4[2];
+    int dc = 0;
+    if (act) {
+      const int bnd0 = gInvBandOf[j0 ? j0 : 1];
+      const int bnd1 = gInvBandOf[j0 + 8];
 #pragma unroll
       for (int hf = 0; hf < 2; hf++) {
-        yq[hf] = make_int4(0, 0, 0, 0);
+        qm4[hf] = *reinterpret_cast<const int4 *>(a.qm_inv + j0 + 8*hf);
+        sc4[hf] = *reinterpret_cast<const int4 *>(gInvScanXY + j0 + 8*hf);
+      }
+      if (j0 == 0) dc = a.coef[plane_off + (long)(y0 + (lby << sh))*a.w + x0 + (lbx << sh)];
+      chs[0] = a.choice[(long)blk*a.nb_bands + bnd0];
+      chs[1] = a.choice[(long)blk*a.nb_bands + bnd1];
+#pragma unroll
+      for (int hf = 0; hf < 2; hf++) {
         if (chs[hf].y != 0) {
           yq[hf] = *reinterpret_cast<const int4 *>(a.y
            + (((unsigned)chs[hf].x*(unsigned)a.nblocks + blk) << lsh) + j0 + 8*hf);
         }
       }
-      int dc = 0;
-      if (j0 == 0) dc = a.coef[plane_off + (long)(y0 + (lby << sh))*a.w + x0 + (lbx << sh)];
+    }
+    if ((a.len >> sh) < (1 << sh)) {            /* 32x32 / 64x64: uncoded positions are zero */
+      for (int i = tid; i < TILE*P/4; i += NT) reinterpret_cast<int4 *>(t)[i] = make_int4(0, 0, 0, 0);
+      __syncthreads();
+    }
+    if (act) {
       const int base = (lby << sh)*P + (lbx << sh);
 #pragma unroll
       for (int hf = 0; hf < 2; hf++) {
-        const int4 qm4 = *reinterpret_cast<const int4 *>(s_qmi + j0 + 8*hf);
-        const int4 sc4 = *reinterpret_cast<const int4 *>(s_scan + j0 + 8*hf);
         const int yd[4] = {yq[hf].x, yq[hf].y, yq[hf].z, yq[hf].w};
-        const int qd[4] = {qm4.x, qm4.y, qm4.z, qm4.w};
-        const int sd[4] = {sc4.x, sc4.y, sc4.z, sc4.w};
+        const int qd[4] = {qm4[hf].x, qm4[hf].y, qm4[hf].z, qm4[hf].w};
+        const int sd[4] = {sc4[hf].x, sc4[hf].y, sc4[hf].z, sc4[hf].w};
         const int4 ch = chs[hf];
         const int rnd = (1 << ch.w) >> 1;
 #pragma unroll
@@ -1277,21 +1299,16 @@ __global__ __launch_bounds__(Geo<TILE>::kNT) void k_inverse_sb(InverseArgsMulti 
     }
   }
   else {
-    for (int i = tid; i < TILE*TILE/4; i += NT) {
-      const int y = i/(TILE/4);
-      const int x = (i % (TILE/4))*4;
-      *reinterpret_cast<int4 *>(t + y*P + x) =
-       *reinterpret_cast<const int4 *>(a.coef + plane_off + (long)(y0 + y)*a.w + x0 + x);
-    }
+    load_plane_tile<TILE>(t, a.coef + plane_off, a.w, x0, y0, tid);
   }
   __syncthreads();
   switch (a.leaf_bs) {
-    case 0: inverse_leaf<TILE, 0>(t, tid); break;
-    case 1: inverse_leaf<TILE, 1>(t, tid); break;
-    case 2: inverse_leaf<TILE, 2>(t, tid); break;
-    case 3: inverse_leaf<TILE, 3>(t, tid); break;
+    case 0: if constexpr (MINLEAF <= 0 && MAXLEAF >= 0) inverse_leaf<TILE, 0>(t, tid); break;
+    case 1: if constexpr (MINLEAF <= 1 && MAXLEAF >= 1) inverse_leaf<TILE, 1>(t, tid); break;
+    case 2: if constexpr (MINLEAF <= 2 && MAXLEAF >= 2) inverse_leaf<TILE, 2>(t, tid); break;
+    case 3: if constexpr (MINLEAF <= 3 && MAXLEAF >= 3) inverse_leaf<TILE, 3>(t, tid); break;
     default:
-      if constexpr (TILE == 64) inverse_leaf<TILE, 4>(t, tid);
+      if constexpr (TILE == 64 && MAXLEAF >= 4) inverse_leaf<TILE, 4>(t, tid);
       break;
   }
   inverse_split_levels<TILE, 1>(t, a, x0, y0, tid);
@@ -1500,7 +1517,23 @@ int inverse_launch(const InverseArgs *levels, int nlevels, int nplanes, int dec,
     else k_inverse_sb<64, true><<<grid, Geo<64>::kNT, 0, s>>>(im);
   }
   else if (dec) k_inverse_sb<32><<<grid, Geo<32>::kNT, 0, s>>>(im);
-  else k_inverse_sb<64><<<grid, Geo<64>::kNT, 0, s>>>(im);
+  else {
+    /* leaf levels up to 16x16 and the 32x32 / 64x64 ones as separate launches (see k_inverse_sb) */
+    InverseArgsMulti lo;
+    InverseArgsMulti hi;
+    memset(&lo, 0, sizeof(lo));
+    memset(&hi, 0, sizeof(hi));
+    lo.nplanes = nplanes;
+    hi.nplanes = nplanes;
+    int nlo = 0;
+    int nhi = 0;
+    for (int l = 0; l < nlevels; l++) {
+      if (im.a[l].leaf_bs <= 2) lo.a[nlo++] = im.a[l];
+      else hi.a[nhi++] = im.a[l];
+    }
+    if (nhi) k_inverse_sb<64, false, 3, 4><<<dim3(w/tile, h/tile, nplanes*nhi), Geo<64>::kNT, 0, s>>>(hi);
+    if (nlo) k_inverse_sb<64, false, 0, 2><<<dim3(w/tile, h/tile, nplanes*nlo), Geo<64>::kNT, 0, s>>>(lo);
+  }
   if (nv > 0) k_edge_rows<<<dim3((h + 255)/256, nv, nplanes*nlevels), 256, 0, s>>>(em);
   if (nh > 0) k_edge_cols<<<dim3((w + 255)/256, nh, nplanes*nlevels), 256, 0, s>>>(em);
   return odhip_check_launch();
@@ -1669,7 +1702,8 @@ int pvq_inverse_args(InverseArgs &ia, uint8_t *d_px, int px_stride, long px_plan
   const int h = job->h;
   const int bs = job->bs;
   if (w <= 0 || h <= 0 || w % tile || h % tile || (px_stride & 3) || (px_plane_stride & 3)
-   || bs < 0 || bs > 4 - dec || ((uintptr_t)job->cands.y & 15) || ((uintptr_t)job->cands.choice & 15)) {
+   || bs < 0 || bs > 4 - dec || ((uintptr_t)job->cands.y & 15) || ((uintptr_t)job->cands.choice & 15)
+   || ((uintptr_t)job->d_qm_inv & 15)) {        /* 16-byte vector loads of all three */
     return ODHIP_EINVAL;
   }
   const int n = 4 << bs;
