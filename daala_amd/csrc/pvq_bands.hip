@@ -580,7 +580,7 @@ struct BandFetch {
 };
 
 template <int PRICE>
-__device__ __forceinline__ void choose_core(const Items &it, int job, const DJob &jb, long sb, int band,
+__device__ __forceinline__ int choose_core(const Items &it, int job, const DJob &jb, long sb, int band,
  const RecHead &hd, double best_cost, int yy0, int yy1, int mom0, int mom1, double dist0, double dist1,
  const double *given);
 
@@ -682,6 +682,32 @@ __global__ __launch_bounds__(kWave, (S == 2 ? 2 : 1)) void k_search(Items it) {
     int mom1 = 0;
     double dist0 = 0;
     double dist1 = 0;
+    /* the candidate in LDS -> signed int16 pulses, 16 bytes at a time into `sink`; returns the moment */
+    auto pack = [&](bool on, auto &&sink) {
+      int mom = 0;
+      const int4 *xp = reinterpret_cast<const int4 *>(x16 + blk*len);
+#pragma unroll
+      for (int v = 0; v < NV; v++) {
+        /* signs: from the registers for the short bands, re-read (L2) for the
+           128-coefficient band, whose registers are better spent on the
+           pipelined search loops */
+        const int4 q = N > 32 ? xp[v] : cur.x[v];
+        const int d[4] = {q.x, q.y, q.z, q.w};
+        int o[4];
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+          const int j0 = v*8 + 2*t - PAD;
+          const int y0 = j0 >= 0 && on ? (int)(pk[j0*kWave + lane] >> 1 & 0x7fffu) : 0;
+          const int y1 = on ? (int)(pk[(j0 + 1)*kWave + lane] >> 1 & 0x7fffu) : 0;
+          const int s0 = (int)(short)d[t] >> 31;
+          const int s1 = d[t] >> 31;
+          o[t] = (((y0 ^ s0) - s0) & 0xffff) | ((y1 ^ s1) - s1) << 16;
+          mom += (half*NL + j0)*y0 + (half*NL + j0 + 1)*y1;     /* y0 = 0 where j0 < 0 */
+        }
+        sink(v, make_int4(o[0], o[1], o[2], o[3]));
+      }
+      return mom;
+    };
 #pragma unroll 1
     for (int c = 0; c < 2; c++) {
       /* selects, not hd.x[c]: a dynamically indexed local array lives in scratch */
@@ -711,47 +737,52 @@ __global__ __launch_bounds__(kWave, (S == 2 ? 2 : 1)) void k_search(Items it) {
       }
       /* od_pvq_rate's centre-of-mass sum SUM i*|y_i| (src/pvq_encoder.c:258-259), taken
          while the pulses pass through on their way out: the priced choice then never
-         reads the vectors again */
+         reads the vectors again.  With the fused choice the second candidate's pulses stay
+         in LDS until the decision (below). */
       int mom = 0;
       if (live) {
         if (cosd && half == 0) cosd[2*(blk*nb_bands + band) + c] = on ? cos_dist : 0.;
-        int4 *yo = reinterpret_cast<int4 *>(yout + ((long)c*nblocks + blk)*len);
-        const int4 *xp = reinterpret_cast<const int4 *>(x16 + blk*len);
-#pragma unroll
-        for (int v = 0; v < NV; v++) {
-          /* signs: from the registers for the short bands, re-read (L2) for the
-             128-coefficient band, whose registers are better spent on the
-             pipelined search loops */
-          const int4 q = N > 32 ? xp[v] : cur.x[v];
-          const int d[4] = {q.x, q.y, q.z, q.w};
-          int o[4];
-#pragma unroll
-          for (int t = 0; t < 4; t++) {
-            const int j0 = v*8 + 2*t - PAD;
-            const int y0 = j0 >= 0 && on ? (int)(pk[j0*kWave + lane] >> 1 & 0x7fffu) : 0;
-            const int y1 = on ? (int)(pk[(j0 + 1)*kWave + lane] >> 1 & 0x7fffu) : 0;
-            const int s0 = (int)(short)d[t] >> 31;
-            const int s1 = d[t] >> 31;
-            o[t] = (((y0 ^ s0) - s0) & 0xffff) | ((y1 ^ s1) - s1) << 16;
-            mom += (half*NL + j0)*y0 + (half*NL + j0 + 1)*y1;     /* y0 = 0 where j0 < 0 */
-          }
-          yo[v] = make_int4(o[0], o[1], o[2], o[3]);
+        if (!(c && it.fuse)) {
+          int4 *yo = reinterpret_cast<int4 *>(yout + ((long)c*nblocks + blk)*len);
+          mom = pack(on, [&](int v, int4 q) { yo[v] = q; });
         }
       }
       if (S == 2) mom += row_mov<OD_DPP_XOR1>(mom);    /* the two halves of the band */
       if (c) mom1 = mom;
       else mom0 = mom;
     }
-    if (live && half == 0) {
+    int4 ysec[NV];
+    if (it.fuse) {
+      int mom = 0;
+      if (live) mom = pack(hd.flags[1] == 1, [&](int v, int4 q) { ysec[v] = q; });
+      if (S == 2) mom += row_mov<OD_DPP_XOR1>(mom);
+      mom1 = mom;
+    }
+    /* The priced choice right here, from the registers (odhip_pvq_noref_bands_priced_multi).  What nobody
+       reads is not written: the second candidate's pulses go out only when it was chosen, and - like the
+       second half of the record (sums, distortions, moments) - when the decision was a close call, which
+       the host-libm resolve decides again from the record and may turn over.  (The first candidate's
+       pulses left before the second search overwrote them.) */
+    int res = 3;
+    if (it.fuse) {
+      if (live && half == 0) {
+        res = choose_core<1>(it, it.job[item], jb, blk*nb_bands + band, band, hd,
+         __hiloint2double(cur.head[1].w, cur.head[1].z), yy0, yy1, mom0, mom1, dist0, dist1, nullptr);
+      }
+      if (S == 2) {
+        const int other = row_mov<OD_DPP_XOR1>(res);
+        if (half) res = other;
+      }
+      if (live && res) {
+        int4 *yo = reinterpret_cast<int4 *>(yout + (nblocks + blk)*len);
+#pragma unroll
+        for (int v = 0; v < NV; v++) yo[v] = ysec[v];
+      }
+    }
+    if (live && half == 0 && (res & 2)) {
       int4 *out = reinterpret_cast<int4 *>(recs + blk*nb_bands) + 2;
       out[0] = make_int4(yy0, yy1, __double2loint(dist0), __double2hiint(dist0));
       out[1] = make_int4(__double2loint(dist1), __double2hiint(dist1), mom0, mom1);
-      /* the priced choice right here, from the registers (odhip_pvq_noref_bands_priced_multi):
-         the record is still written - the host-libm resolve of a listed band reads it */
-      if (it.fuse) {
-        choose_core<1>(it, it.job[item], jb, blk*nb_bands + band, band, hd,
-         __hiloint2double(cur.head[1].w, cur.head[1].z), yy0, yy1, mom0, mom1, dist0, dist1, nullptr);
-      }
     }
   }
 }
@@ -771,8 +802,9 @@ __global__ __launch_bounds__(kWave, (S == 2 ? 2 : 1)) void k_search(Items it) {
    it again; PRICE = 2 is that second decision (rates given per band). */
 /* The decision itself, on values: from the record (k_choose) or straight from the
    registers of the search that produced them (k_search with Items::fuse). */
+/* Returns sel | close << 1. */
 template <int PRICE>
-__device__ __forceinline__ void choose_core(const Items &it, int job, const DJob &jb, long sb, int band,
+__device__ __forceinline__ int choose_core(const Items &it, int job, const DJob &jb, long sb, int band,
  const RecHead &hd, double best_cost, int yy0, int yy1, int mom0, int mom1, double dist0, double dist1,
  const double *given) {
   const int qb = sb/jb.nb_bands >= jb.split_blk ? jb.q2[band] : jb.q[band];
@@ -832,6 +864,7 @@ __device__ __forceinline__ void choose_core(const Items &it, int job, const DJob
   }
   choice[sb] = make_int4(sel, qg, scale, qshift);
   if (qg_out) qg_out[sb] = qg;
+  return sel | (close ? 2 : 0);
 }
 
 template <int PRICE>

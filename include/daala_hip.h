@@ -919,8 +919,13 @@ int odhip_pvq_choose_priced_resolve(const odhip_pvq_job *jobs, int njobs, double
  odhip_stream stream);
 /* odhip_pvq_noref_bands_multi AND odhip_pvq_choose_priced_multi in one pass: the search
    kernels decide each band from the values they hold in registers, so no choice kernel
-   reads the records back (they are still written: the resolve of a listed band and any
-   host that wants the candidates read them).  Follow with odhip_pvq_choose_priced_resolve. */
+   reads the records back.  What leaves the stage is what its consumers read: the choice
+   record, the first 32 bytes of every band record (what the preparation wrote), the FIRST
+   candidate's pulses, and the second candidate's pulses where it was chosen.  The second
+   half of a record (sums, distortions, moments) and a losing second candidate are written
+   only for a band listed as a close call - the resolve decides it again from exactly those.
+   A host that wants both candidates of every band uses odhip_pvq_noref_bands_multi.
+   Follow with odhip_pvq_choose_priced_resolve. */
 int odhip_pvq_noref_bands_priced_multi(const odhip_pvq_job *jobs, int njobs, double pvq_norm_lambda,
  odhip_stream stream);
 int odhip_pvq_ref_choose_priced_multi(const odhip_pvq_refjob *jobs, int njobs, double pvq_norm_lambda,
