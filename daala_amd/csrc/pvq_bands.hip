@@ -1541,7 +1541,7 @@ int noref_bands(const odhip_pvq_job *jobs, int njobs, double pvq_norm_lambda, od
   /* search: the band sizes are independent launches on forked streams */
   if (fork_streams(st, s, side) != ODHIP_SUCCESS) return ODHIP_EFAULT;
   launch_search<128, 2, 1>(st, host, njobs, lambda, s, fuse);
-  launch_search<32, 1, 1>(st, host, njobs, lambda, side[0], fuse);
+  launch_search<32, 2, 1>(st, host, njobs, lambda, side[0], fuse);
   launch_search<15, 1, 1>(st, host, njobs, lambda, side[1], fuse);
   launch_search<8, 1, 1>(st, host, njobs, lambda, side[1], fuse);
   if (join_streams(st, s, side) != ODHIP_SUCCESS) return ODHIP_EFAULT;
