@@ -456,6 +456,9 @@ int finish_pending(odhip_pipe *p) {
        chain is enqueued, below) */
     STEP_TRY(chroma_tail(p, par, p->stream[1]));
   }
+  /* the resolves and the re-run read that step's luma pulses and choices (the chroma-from-luma
+     references, in place): the luma chain of step + 2 reuses those buffers and waits for this */
+  if (n > 0 || m > 0) ODHIP_TRY(hipEventRecord(p->ev_used[par], p->stream[1]));
   return ODHIP_SUCCESS;
 }
 
