@@ -232,7 +232,13 @@ __device__ __forceinline__ PrepCtx prep_ctx(const DJob &jb, int band, int off, i
 /* Everything of a band that precedes the search, from cg on: the two gain
    candidates (src/pvq_encoder.c:578-592), the first half of the record and the
    sort key.  Heavy bands get SMALL keys so that they are dispatched first. */
-__device__ __forceinline__ void od_band_candidates(const PrepCtx &cx, int n, long blk, int32_t cg) {
+struct BandHead {
+  int4 h0;                 /* cg, gain[2], k[0] | k[1] << 16                  */
+  int4 h1;                 /* flags[0] | flags[1] << 8, 0, dist0 (lo, hi)     */
+  unsigned short key;
+};
+
+__device__ __forceinline__ BandHead od_band_head(int beta, int n, int32_t cg) {
   const double s2 = (1./256)*(1./256);  /* OD_CGAIN_SCALE_2 */
   const double dist0 = ((1.4*cg)*cg)*s2;
   const int gain_bound = cg >> ODQ_CGAIN_SHIFT;
@@ -246,22 +252,31 @@ __device__ __forceinline__ void od_band_candidates(const PrepCtx &cx, int n, lon
     if (i <= gain_bound + 1) {
       const int32_t qcg = odq_shl32(i, ODQ_CGAIN_SHIFT);
       gain[c] = i;
-      kk[c] = odq_compute_k_noref(qcg, n, cx.beta);
+      kk[c] = odq_compute_k_noref(qcg, n, beta);
       const double dist = ((1.4*(qcg - cg))*(qcg - cg))*s2;
       fl[c] = !(dist > dist0 && kk[c] != 0);
       if (fl[c] && kk[c] > kMaxK) fl[c] = 2;   /* not representable: reported, not searched */
       if (kk[c] > kMaxK) kk[c] = kMaxK;
     }
   }
-  int4 *out = reinterpret_cast<int4 *>(cx.rec + blk*cx.nb_bands);
-  out[0] = make_int4(cg, gain[0], gain[1], (kk[0] & 0xffff) | kk[1] << 16);
-  out[1] = make_int4(fl[0] | fl[1] << 8, 0, __double2loint(dist0), __double2hiint(dist0));
+  BandHead bh;
+  bh.h0 = make_int4(cg, gain[0], gain[1], (kk[0] & 0xffff) | kk[1] << 16);
+  bh.h1 = make_int4(fl[0] | fl[1] << 8, 0, __double2loint(dist0), __double2hiint(dist0));
   const bool s0 = fl[0] == 1;
   const bool s1 = fl[1] == 1;
   const int p0 = s0 ? kk[0] : 0;
   int p1 = 0;
   if (s1) p1 = s0 && kk[0] > 0 && kk[0] <= kk[1] ? kk[1] - kk[0] : kk[1];
-  cx.keys[blk] = (unsigned short)(kKeyBins - 1 - (od_pulse_bin(p0) << 4 | od_extra_bin(p1)));
+  bh.key = (unsigned short)(kKeyBins - 1 - (od_pulse_bin(p0) << 4 | od_extra_bin(p1)));
+  return bh;
+}
+
+__device__ __forceinline__ void od_band_candidates(const PrepCtx &cx, int n, long blk, int32_t cg) {
+  const BandHead bh = od_band_head(cx.beta, n, cg);
+  int4 *out = reinterpret_cast<int4 *>(cx.rec + blk*cx.nb_bands);
+  out[0] = bh.h0;
+  out[1] = bh.h1;
+  cx.keys[blk] = bh.key;
 }
 
 /* ---- prep, bands of up to 32 coefficients: one band per lane ------------------
@@ -784,6 +799,228 @@ __global__ __launch_bounds__(kWave, (S == 2 ? 2 : 1)) void k_search(Items it) {
       out[0] = make_int4(yy0, yy1, __double2loint(dist0), __double2hiint(dist0));
       out[1] = make_int4(__double2loint(dist1), __double2hiint(dist1), mom0, mom1);
     }
+  }
+}
+
+/* ---- corner bands decided where they are prepared ---------------------------------
+   odhip_pvq_noref_bands_priced_multi: band 0 of every block (15 coefficients) and bands 1, 2
+   of every block of 8x8 and up (8 each) - 4.2 of the 5.5 M bands of a 16-frame step - never
+   leave the lane that prepared them.  The block's corner is in registers (k_prep_corner);
+   the lane scales it, forms the band's record head in registers, runs both K-pulse searches
+   (od_lane_search, |x| and pulses in its LDS column as in k_search), makes the priced choice
+   and writes the choice record and the pulses that are read: no x16, no band record, no sort
+   key, no sorted index for these bands - the two-pass stage wrote and re-read ~300 bytes per
+   band for them, 16 bytes at a time in sorted order.  Natural block order instead of the
+   sort by pulse class costs these short bands 3-12 % (measured with the sort keys forced
+   equal); the records of a band listed as a close call are written whole, for the resolve.
+   Band 3 of the larger blocks (32 coefficients) stays with the sorted two-pass stage. */
+template <int N>
+__device__ __forceinline__ void od_decide_band(const Items &it, int job, const DJob &jb, int band, long blk,
+ bool live, const BandHead &bh, const int *xs, uint32_t *pk, const double *rsq, int lane) {
+  constexpr int PAD = N == 15 ? 1 : 0;
+  constexpr int NV = (N + PAD)/8;
+  RecHead hd;
+  hd.cg = bh.h0.x;
+  hd.gain[0] = bh.h0.y;
+  hd.gain[1] = bh.h0.z;
+  hd.k[0] = (int16_t)(bh.h0.w & 0xffff);
+  hd.k[1] = bh.h0.w >> 16;
+  hd.flags[0] = live ? bh.h1.x & 0xff : 0;
+  hd.flags[1] = live ? bh.h1.x >> 8 & 0xff : 0;
+#pragma unroll
+  for (int j = 0; j < N; j++) pk[j*kWave + lane] = (uint32_t)abs(xs[j]) << 16;
+  LaneSearch st;
+  od_lane_prepare<N, 1>(st, pk, lane);
+  const int32_t cg = hd.cg;
+  const double s2 = (1./256)*(1./256);
+  const int off = jb.off[band] - PAD;
+  const long nblocks = jb.nblocks;
+  const int len = jb.len;
+  int prev_k = 0;
+  int yyv[2] = {0, 0};
+  int momv[2] = {0, 0};
+  double distv[2] = {0, 0};
+  int4 yq[2][NV];
+#pragma unroll 1
+  for (int c = 0; c < 2; c++) {
+    const bool on = (c ? hd.flags[1] : hd.flags[0]) == 1;
+    const int k = c ? hd.k[1] : hd.k[0];
+    const int gain = c ? hd.gain[1] : hd.gain[0];
+    const int32_t qcg = odq_shl32(gain, ODQ_CGAIN_SHIFT);
+    const double g2 = (qcg*(double)cg)*s2;
+    const bool fresh = !(prev_k > 0 && prev_k <= k);
+    const double cos_dist = od_lane_search<N, 1>(st, pk, rsq, lane, 0, on, fresh, k, g2, it.lambda,
+     it.reserved != 0);
+    /* src/pvq_encoder.c:586,:593-595; a slot that is not in use has distortion 0 */
+    int yyc = 0;
+    double distc = gain ? ((1.4*(qcg - cg))*(qcg - cg))*s2 : 0.;
+    if (on) {
+      prev_k = k;
+      yyc = (int)st.yy;
+      distc = ((1.4*(qcg - cg))*(qcg - cg) + (qcg*(double)cg)*(2 - 2*cos_dist))*s2;
+    }
+    if (live && jb.cos_dist) jb.cos_dist[2*(blk*jb.nb_bands + band) + c] = on ? cos_dist : 0.;
+    int mom = 0;
+    int4 q[NV];
+#pragma unroll
+    for (int v = 0; v < NV; v++) {
+      int o[4];
+#pragma unroll
+      for (int t = 0; t < 4; t++) {
+        const int j0 = v*8 + 2*t - PAD;
+        const int y0 = j0 >= 0 && on ? (int)(pk[(j0 < 0 ? 0 : j0)*kWave + lane] >> 1 & 0x7fffu) : 0;
+        const int y1 = on ? (int)(pk[(j0 + 1)*kWave + lane] >> 1 & 0x7fffu) : 0;
+        const int s0 = j0 >= 0 ? xs[j0 < 0 ? 0 : j0] >> 31 : 0;
+        const int s1 = xs[j0 + 1] >> 31;
+        o[t] = (((y0 ^ s0) - s0) & 0xffff) | ((y1 ^ s1) - s1) << 16;
+        mom += j0*y0 + (j0 + 1)*y1;          /* y0 = 0 where j0 < 0 */
+      }
+      q[v] = make_int4(o[0], o[1], o[2], o[3]);
+    }
+    /* selects, not [c]: dynamically indexed locals live in scratch */
+    if (c) {
+      yyv[1] = yyc;
+      distv[1] = distc;
+      momv[1] = mom;
+#pragma unroll
+      for (int v = 0; v < NV; v++) yq[1][v] = q[v];
+    }
+    else {
+      yyv[0] = yyc;
+      distv[0] = distc;
+      momv[0] = mom;
+#pragma unroll
+      for (int v = 0; v < NV; v++) yq[0][v] = q[v];
+    }
+  }
+  if (!live) return;
+  const double dist0 = __hiloint2double(bh.h1.w, bh.h1.z);
+  const int res = choose_core<1>(it, job, jb, blk*jb.nb_bands + band, band, hd, dist0, yyv[0], yyv[1], momv[0],
+   momv[1], distv[0], distv[1], nullptr);
+  /* sel | close << 1: the chosen candidate's pulses; both, and the whole record, for a close call */
+  if (!(res & 1) || (res & 2)) {
+    int4 *yo = reinterpret_cast<int4 *>(jb.y + off + blk*len);
+#pragma unroll
+    for (int v = 0; v < NV; v++) yo[v] = yq[0][v];
+  }
+  if (res) {
+    int4 *yo = reinterpret_cast<int4 *>(jb.y + off + (nblocks + blk)*len);
+#pragma unroll
+    for (int v = 0; v < NV; v++) yo[v] = yq[1][v];
+  }
+  if (res & 2) {
+    int4 *out = reinterpret_cast<int4 *>(jb.rec + blk*jb.nb_bands + band);
+    out[0] = bh.h0;
+    out[1] = bh.h1;
+    out[2] = make_int4(yyv[0], yyv[1], __double2loint(distv[0]), __double2hiint(distv[0]));
+    out[3] = make_int4(__double2loint(distv[1]), __double2hiint(distv[1]), momv[0], momv[1]);
+  }
+}
+
+/* PART 0: band 0 of every block of every size (the 4x4 corner); PART 1: bands 1 and 2 of the blocks
+   of 8x8 and up (x 4..7 of rows 0..1 and x 0..1 of rows 4..7, gen/od_scan_tables.h).  Two kernels
+   rather than one per block: searched in one kernel the three bands hold 150 VGPRs (three waves
+   per SIMD), apart 121 and ~100 (four and five). */
+template <int PART>
+__global__ __launch_bounds__(kWave) void k_decide_corner(Items it) {
+  extern __shared__ __attribute__((aligned(16))) double lds_d[];
+  double *rsq = lds_d;                                   /* [kRsqN]  */
+  uint32_t *pk = (uint32_t *)(rsq + kRsqN);              /* [15][64] */
+  const int lane = threadIdx.x;
+  {
+    double r[kRsqN/kWave];
+#pragma unroll
+    for (int i = 0; i < kRsqN/kWave; i++) r[i] = gRsqTable[i*kWave + lane];
+#pragma unroll
+    for (int i = 0; i < kRsqN/kWave; i++) rsq[i*kWave + lane] = r[i];
+  }
+  const int item = find_item(it, blockIdx.x);
+  const int job = it.job[item];
+  const DJob &jb = it.jobs[job];
+  const BlockPos bp = locate(jb, (long)(blockIdx.x - it.wg_start[item])*kWave + threadIdx.x);
+  const int16_t *const qmp = jb.qm;
+  const int w = jb.w;
+  constexpr int C = 8;
+  int r[C*C];       /* raster, row-major; only what the part's bands cover is loaded */
+  if constexpr (PART == 0) {
+#pragma unroll
+    for (int y = 0; y < 4; y++) {
+      const int4 q = *reinterpret_cast<const int4 *>(bp.src + y*w);
+      r[y*C] = q.x;
+      r[y*C + 1] = q.y;
+      r[y*C + 2] = q.z;
+      r[y*C + 3] = q.w;
+    }
+  }
+  else {
+#pragma unroll
+    for (int y = 0; y < 2; y++) {
+      const int4 q = *reinterpret_cast<const int4 *>(bp.src + y*w + 4);
+      r[y*C + 4] = q.x;
+      r[y*C + 5] = q.y;
+      r[y*C + 6] = q.z;
+      r[y*C + 7] = q.w;
+    }
+#pragma unroll
+    for (int y = 4; y < 8; y++) {
+      const int2 q = *reinterpret_cast<const int2 *>(bp.src + y*w);
+      r[y*C] = q.x;
+      r[y*C + 1] = q.y;
+    }
+  }
+  __syncthreads();   /* the 1/sqrt table */
+  int x16[32];
+  int32_t cgs[3] = {0, 0, 0};
+  auto scale_band = [&](auto bc) {
+    constexpr int b = decltype(bc)::value;
+    constexpr int kOff[4] = {1, 16, 24, 32};
+    constexpr int off = kOff[b];
+    constexpr int n = kOff[b + 1] - off;
+    /* od_vector_log_mag, src/pvq.c:472-484 */
+    int sum = 0;
+    od_static_for<off, off + n>([&](auto jc) {
+      constexpr int j = decltype(jc)::value;
+      const int t = (int16_t)(r[OD_SCAN_XY[j][1]*C + OD_SCAN_XY[j][0]] >> 8);
+      sum += t*t;
+    });
+    int xshift = 8 + 1 + odq_ilog(n + sum)/2 - 15;
+    xshift = xshift > 0 ? xshift : 0;
+    int acc = 0;
+    od_static_for<off, off + n>([&](auto jc) {
+      constexpr int j = decltype(jc)::value;
+      x16[j] = (int16_t)odq_shr_round(r[OD_SCAN_XY[j][1]*C + OD_SCAN_XY[j][0]]*qmp[j],
+       ODQ_QM_SHIFT + xshift);
+      acc += x16[j]*x16[j];
+    });
+    const int qb = bp.blk >= jb.split_blk ? jb.q2[b] : jb.q[b];
+    int32_t g;
+    cgs[b] = odq_gain_from_acc(acc, qb, jb.beta[b], xshift, &g);
+  };
+  if constexpr (PART == 0) {
+    scale_band(std::integral_constant<int, 0>{});
+    od_decide_band<15>(it, job, jb, 0, bp.blk, bp.live, od_band_head(jb.beta[0], 15, cgs[0]), x16 + 1, pk, rsq,
+     lane);
+  }
+  else {
+    /* band 2 waits as packed int16 pairs and its gain while band 1 is searched */
+    scale_band(std::integral_constant<int, 2>{});
+    int packed[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      packed[i] = (x16[24 + 2*i] & 0xffff) | x16[25 + 2*i] << 16;
+      /* materialise here: sunk below the search, the raster values it is made of would stay live */
+      asm volatile("" : "+v"(packed[i]));
+    }
+    asm volatile("" : "+v"(cgs[2]));
+    scale_band(std::integral_constant<int, 1>{});
+    od_decide_band<8>(it, job, jb, 1, bp.blk, bp.live, od_band_head(jb.beta[1], 8, cgs[1]), x16 + 16, pk, rsq, lane);
+    int xs[8];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      xs[2*i] = (int)(short)packed[i];
+      xs[2*i + 1] = packed[i] >> 16;
+    }
+    od_decide_band<8>(it, job, jb, 2, bp.blk, bp.live, od_band_head(jb.beta[2], 8, cgs[2]), xs, pk, rsq, lane);
   }
 }
 
@@ -1488,27 +1725,34 @@ int noref_bands(const odhip_pvq_job *jobs, int njobs, double pvq_norm_lambda, od
   hipStream_t side[2] = {s, s};
   if (fork_streams(st, s, side) != ODHIP_SUCCESS) return ODHIP_EFAULT;
   Items it;
-  /* prep: the low-frequency corner of every block one block per lane (bands
-     0..3), the remaining 32-coefficient bands one band per lane, the
-     128-coefficient bands one per 16-lane row */
-  items_begin(it, st, lambda);
-  for (int j = 0; j < njobs; j++) {
-    if (host[j].bs == 0) items_add(it, j, 0, (host[j].nblocks + kWave - 1)/kWave);
+  /* With the priced choice (fuse) the corner bands 0..2 are decided by the lanes that prepare
+     them (k_decide_corner: nothing of them enters the sort or the searches below); the first
+     band of the two-pass stage is then band 3. */
+  const int first_band = fuse ? 3 : 0;
+  constexpr size_t corner_lds = kRsqN*sizeof(double) + (size_t)15*kPitch*4;
+  if (!fuse) {
+    /* prep: the low-frequency corner of every block one block per lane (bands
+       0..3), the remaining 32-coefficient bands one band per lane, the
+       128-coefficient bands one per 16-lane row */
+    items_begin(it, st, lambda);
+    for (int j = 0; j < njobs; j++) {
+      if (host[j].bs == 0) items_add(it, j, 0, (host[j].nblocks + kWave - 1)/kWave);
+    }
+    if (it.nitems) k_prep_corner<4><<<it.wg_start[it.nitems], kWave, 0, s>>>(it);
+    items_begin(it, st, lambda);
+    for (int j = 0; j < njobs; j++) {
+      if (host[j].bs > 0) items_add(it, j, 0, (host[j].nblocks + kWave - 1)/kWave);
+    }
+    if (it.nitems) k_prep_corner<8><<<it.wg_start[it.nitems], kWave, 0, s>>>(it);
   }
-  if (it.nitems) k_prep_corner<4><<<it.wg_start[it.nitems], kWave, 0, s>>>(it);
   items_begin(it, st, lambda);
   for (int j = 0; j < njobs; j++) {
-    if (host[j].bs > 0) items_add(it, j, 0, (host[j].nblocks + kWave - 1)/kWave);
-  }
-  if (it.nitems) k_prep_corner<8><<<it.wg_start[it.nitems], kWave, 0, s>>>(it);
-  items_begin(it, st, lambda);
-  for (int j = 0; j < njobs; j++) {
-    for (int b = 4; b < host[j].nb_bands; b++) {
+    for (int b = fuse ? 3 : 4; b < host[j].nb_bands; b++) {
       const int n = host[j].off[b + 1] - host[j].off[b];
       if (n <= 32) items_add(it, j, b, (host[j].nblocks + kWave - 1)/kWave);
     }
   }
-  if (it.nitems) k_prep_lane<<<it.wg_start[it.nitems], kWave, 0, side[1]>>>(it);
+  if (it.nitems) k_prep_lane<<<it.wg_start[it.nitems], kWave, 0, fuse ? s : side[1]>>>(it);
   items_begin(it, st, lambda);
   for (int j = 0; j < njobs; j++) {
     for (int b = 0; b < host[j].nb_bands; b++) {
@@ -1522,7 +1766,7 @@ int noref_bands(const odhip_pvq_job *jobs, int njobs, double pvq_norm_lambda, od
   items_begin(all, st, lambda);
   items_begin(it, st, lambda);
   for (int j = 0; j < njobs; j++) {
-    for (int b = 0; b < host[j].nb_bands; b++) {
+    for (int b = first_band; b < host[j].nb_bands; b++) {
       items_add(it, j, b, (host[j].nblocks + kSortChunk - 1)/kSortChunk);
       items_add(all, j, b, 1);
     }
@@ -1534,16 +1778,32 @@ int noref_bands(const odhip_pvq_job *jobs, int njobs, double pvq_norm_lambda, od
     st.sort_dirty = false;
   }
   st.sort_dirty = true;
-  k_hist<<<it.wg_start[it.nitems], 256, 0, s>>>(it);
-  k_prefix<<<all.nitems, 256, 0, s>>>(all);
+  if (it.nitems) {
+    k_hist<<<it.wg_start[it.nitems], 256, 0, s>>>(it);
+    k_prefix<<<all.nitems, 256, 0, s>>>(all);
+  }
   st.sort_dirty = odhip_check_launch() != ODHIP_SUCCESS;
-  k_scatter<<<it.wg_start[it.nitems], 256, 0, s>>>(it);
+  if (it.nitems) k_scatter<<<it.wg_start[it.nitems], 256, 0, s>>>(it);
   /* search: the band sizes are independent launches on forked streams */
   if (fork_streams(st, s, side) != ODHIP_SUCCESS) return ODHIP_EFAULT;
   launch_search<128, 2, 1>(st, host, njobs, lambda, s, fuse);
   launch_search<32, 2, 1>(st, host, njobs, lambda, side[0], fuse);
-  launch_search<15, 1, 1>(st, host, njobs, lambda, side[1], fuse);
-  launch_search<8, 1, 1>(st, host, njobs, lambda, side[1], fuse);
+  if (fuse) {
+    items_begin(it, st, lambda);
+    it.fuse = 1;
+    for (int j = 0; j < njobs; j++) items_add(it, j, 0, (host[j].nblocks + kWave - 1)/kWave);
+    if (it.nitems) k_decide_corner<0><<<it.wg_start[it.nitems], kWave, corner_lds, side[1]>>>(it);
+    items_begin(it, st, lambda);
+    it.fuse = 1;
+    for (int j = 0; j < njobs; j++) {
+      if (host[j].bs > 0) items_add(it, j, 1, (host[j].nblocks + kWave - 1)/kWave);
+    }
+    if (it.nitems) k_decide_corner<1><<<it.wg_start[it.nitems], kWave, corner_lds, side[1]>>>(it);
+  }
+  else {
+    launch_search<15, 1, 1>(st, host, njobs, lambda, side[1], fuse);
+    launch_search<8, 1, 1>(st, host, njobs, lambda, side[1], fuse);
+  }
   if (join_streams(st, s, side) != ODHIP_SUCCESS) return ODHIP_EFAULT;
   if (fuse) {
     const int rc2 = price_count_begin(st, s);

@@ -917,15 +917,17 @@ int odhip_pvq_choose_priced_multi(const odhip_pvq_job *jobs, int njobs, double p
  odhip_stream stream);
 int odhip_pvq_choose_priced_resolve(const odhip_pvq_job *jobs, int njobs, double pvq_norm_lambda,
  odhip_stream stream);
-/* odhip_pvq_noref_bands_multi AND odhip_pvq_choose_priced_multi in one pass: the search
-   kernels decide each band from the values they hold in registers, so no choice kernel
-   reads the records back.  What leaves the stage is what its consumers read: the choice
-   record, the first 32 bytes of every band record (what the preparation wrote), the FIRST
-   candidate's pulses, and the second candidate's pulses where it was chosen.  The second
-   half of a record (sums, distortions, moments) and a losing second candidate are written
-   only for a band listed as a close call - the resolve decides it again from exactly those.
-   A host that wants both candidates of every band uses odhip_pvq_noref_bands_multi.
-   Follow with odhip_pvq_choose_priced_resolve. */
+/* odhip_pvq_noref_bands_multi AND odhip_pvq_choose_priced_multi in one pass: every band is
+   decided where its search ends, from the values held in registers; no choice kernel reads the
+   records back.  What leaves the stage is what its consumers read: the choice record and the
+   CHOSEN candidate's pulses (slot = choice[0]).  Bands 0..2 of a block (the 15-, 8- and
+   8-coefficient bands of its low-frequency corner) are prepared, searched and decided by one
+   lane without ever existing as records or scaled vectors in memory; the other bands go
+   through the two-pass stage (preparation, sort, search) and keep the first half of their
+   record.  A losing candidate's pulses and the second half of a record (sums, distortions,
+   moments) are written only for a band listed as a close call - the resolve decides it again
+   from exactly those.  A host that wants both candidates of every band uses
+   odhip_pvq_noref_bands_multi.  Follow with odhip_pvq_choose_priced_resolve. */
 int odhip_pvq_noref_bands_priced_multi(const odhip_pvq_job *jobs, int njobs, double pvq_norm_lambda,
  odhip_stream stream);
 int odhip_pvq_ref_choose_priced_multi(const odhip_pvq_refjob *jobs, int njobs, double pvq_norm_lambda,

@@ -309,7 +309,6 @@ def gpu_decisions(D, pipe):
                     coded[:, i] = skip == 0
             else:
                 ch = pipe.read(D.BUF_CHOICE, set_, bs, dtype=np.int32).reshape(B, nb, 4)
-                rec = pipe.read(D.BUF_BAND, set_, bs).view(D.BAND_RECORD).reshape(B, nb)
                 y = yall.reshape(2, B, ln)
                 for i in range(nb):
                     a, b = offs[i], offs[i + 1]
@@ -318,10 +317,11 @@ def gpu_decisions(D, pipe):
                     band[:, i, 0] = qg            # keyframe, no reference: the gain index itself
                     band[:, i, 1] = -1
                     band[:, i, 2] = 0
-                    k = np.where(sel == 1, rec["k"][:, i, 1], rec["k"][:, i, 0]).astype(np.int32)
-                    band[:, i, 3] = np.where(qg != 0, k, 0)
                     idx = np.nonzero(qg != 0)[0]
                     ych[idx, a:b] = y[sel[idx], idx, a:b]
+                    # K of a no-reference winner = its pulse count (the band records of the
+                    # corner bands are not written by the stage that decides inside the search)
+                    band[:, i, 3] = np.abs(ych[:, a:b]).sum(axis=1)
                     coded[:, i] = True
             out[(set_, bs)] = (ych, band, coded)
     return out
