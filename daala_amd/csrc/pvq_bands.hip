@@ -814,11 +814,15 @@ __global__ __launch_bounds__(kWave, (S == 2 ? 2 : 1)) void k_search(Items it) {
    sort by pulse class costs these short bands 3-12 % (measured with the sort keys forced
    equal); the records of a band listed as a close call are written whole, for the resolve.
    Band 3 of the larger blocks (32 coefficients) stays with the sorted two-pass stage. */
-template <int N>
+/* N = band size, S = lanes per band (2: the lane pair of pvq_lane.cuh, `half` = lane & 1, each lane
+   holding NL = N/S coefficients in xs). */
+template <int N, int S = 1>
 __device__ __forceinline__ void od_decide_band(const Items &it, int job, const DJob &jb, int band, long blk,
- bool live, const BandHead &bh, const int *xs, uint32_t *pk, const double *rsq, int lane) {
+ bool live, const BandHead &bh, const int *xs, uint32_t *pk, const double *rsq, int lane, int half = 0) {
+  constexpr int NL = N/S;
   constexpr int PAD = N == 15 ? 1 : 0;
-  constexpr int NV = (N + PAD)/8;
+  constexpr int NV = (NL + PAD)/8;
+  static_assert(S == 1 || PAD == 0, "pair mode has no padded band");
   RecHead hd;
   hd.cg = bh.h0.x;
   hd.gain[0] = bh.h0.y;
@@ -828,12 +832,12 @@ __device__ __forceinline__ void od_decide_band(const Items &it, int job, const D
   hd.flags[0] = live ? bh.h1.x & 0xff : 0;
   hd.flags[1] = live ? bh.h1.x >> 8 & 0xff : 0;
 #pragma unroll
-  for (int j = 0; j < N; j++) pk[j*kWave + lane] = (uint32_t)abs(xs[j]) << 16;
+  for (int j = 0; j < NL; j++) pk[j*kWave + lane] = (uint32_t)abs(xs[j]) << 16;
   LaneSearch st;
-  od_lane_prepare<N, 1>(st, pk, lane);
+  od_lane_prepare<NL, S>(st, pk, lane);
   const int32_t cg = hd.cg;
   const double s2 = (1./256)*(1./256);
-  const int off = jb.off[band] - PAD;
+  const int off = jb.off[band] - PAD + half*NL;
   const long nblocks = jb.nblocks;
   const int len = jb.len;
   int prev_k = 0;
@@ -849,7 +853,7 @@ __device__ __forceinline__ void od_decide_band(const Items &it, int job, const D
     const int32_t qcg = odq_shl32(gain, ODQ_CGAIN_SHIFT);
     const double g2 = (qcg*(double)cg)*s2;
     const bool fresh = !(prev_k > 0 && prev_k <= k);
-    const double cos_dist = od_lane_search<N, 1>(st, pk, rsq, lane, 0, on, fresh, k, g2, it.lambda,
+    const double cos_dist = od_lane_search<NL, S>(st, pk, rsq, lane, half, on, fresh, k, g2, it.lambda,
      it.reserved != 0);
     /* src/pvq_encoder.c:586,:593-595; a slot that is not in use has distortion 0 */
     int yyc = 0;
@@ -859,7 +863,7 @@ __device__ __forceinline__ void od_decide_band(const Items &it, int job, const D
       yyc = (int)st.yy;
       distc = ((1.4*(qcg - cg))*(qcg - cg) + (qcg*(double)cg)*(2 - 2*cos_dist))*s2;
     }
-    if (live && jb.cos_dist) jb.cos_dist[2*(blk*jb.nb_bands + band) + c] = on ? cos_dist : 0.;
+    if (live && half == 0 && jb.cos_dist) jb.cos_dist[2*(blk*jb.nb_bands + band) + c] = on ? cos_dist : 0.;
     int mom = 0;
     int4 q[NV];
 #pragma unroll
@@ -873,10 +877,11 @@ __device__ __forceinline__ void od_decide_band(const Items &it, int job, const D
         const int s0 = j0 >= 0 ? xs[j0 < 0 ? 0 : j0] >> 31 : 0;
         const int s1 = xs[j0 + 1] >> 31;
         o[t] = (((y0 ^ s0) - s0) & 0xffff) | ((y1 ^ s1) - s1) << 16;
-        mom += j0*y0 + (j0 + 1)*y1;          /* y0 = 0 where j0 < 0 */
+        mom += (half*NL + j0)*y0 + (half*NL + j0 + 1)*y1;          /* y0 = 0 where j0 < 0 */
       }
       q[v] = make_int4(o[0], o[1], o[2], o[3]);
     }
+    if (S == 2) mom += od_pair_swap(mom);    /* the two halves of the band */
     /* selects, not [c]: dynamically indexed locals live in scratch */
     if (c) {
       yyv[1] = yyc;
@@ -893,10 +898,17 @@ __device__ __forceinline__ void od_decide_band(const Items &it, int job, const D
       for (int v = 0; v < NV; v++) yq[0][v] = q[v];
     }
   }
+  int res = 0;
+  if (live && half == 0) {
+    const double dist0 = __hiloint2double(bh.h1.w, bh.h1.z);
+    res = choose_core<1>(it, job, jb, blk*jb.nb_bands + band, band, hd, dist0, yyv[0], yyv[1], momv[0],
+     momv[1], distv[0], distv[1], nullptr);
+  }
+  if (S == 2) {
+    const int other = od_pair_swap(res);
+    if (half) res = other;
+  }
   if (!live) return;
-  const double dist0 = __hiloint2double(bh.h1.w, bh.h1.z);
-  const int res = choose_core<1>(it, job, jb, blk*jb.nb_bands + band, band, hd, dist0, yyv[0], yyv[1], momv[0],
-   momv[1], distv[0], distv[1], nullptr);
   /* sel | close << 1: the chosen candidate's pulses; both, and the whole record, for a close call */
   if (!(res & 1) || (res & 2)) {
     int4 *yo = reinterpret_cast<int4 *>(jb.y + off + blk*len);
@@ -908,7 +920,7 @@ __device__ __forceinline__ void od_decide_band(const Items &it, int job, const D
 #pragma unroll
     for (int v = 0; v < NV; v++) yo[v] = yq[1][v];
   }
-  if (res & 2) {
+  if ((res & 2) && half == 0) {
     int4 *out = reinterpret_cast<int4 *>(jb.rec + blk*jb.nb_bands + band);
     out[0] = bh.h0;
     out[1] = bh.h1;
@@ -1022,6 +1034,68 @@ __global__ __launch_bounds__(kWave) void k_decide_corner(Items it) {
     }
     od_decide_band<8>(it, job, jb, 2, bp.blk, bp.live, od_band_head(jb.beta[2], 8, cgs[2]), xs, pk, rsq, lane);
   }
+}
+
+/* The 32-coefficient bands the same way (band 3 of every block of 8x8 and up, bands 4 and 5 of 16x16 and
+   up), two lanes per band as in k_search<32, 2, 1>: each lane gathers its 16 coding positions, the
+   pair shares the sums by DPP.  Natural order costs these bands 1 % (measured). */
+__global__ __launch_bounds__(kWave) void k_decide_lane32(Items it) {
+  constexpr int NL = 16;
+  extern __shared__ __attribute__((aligned(16))) double lds_d[];
+  double *rsq = lds_d;                                   /* [kRsqN]  */
+  uint32_t *pk = (uint32_t *)(rsq + kRsqN);              /* [16][64] */
+  const int lane = threadIdx.x;
+  {
+    double r[kRsqN/kWave];
+#pragma unroll
+    for (int i = 0; i < kRsqN/kWave; i++) r[i] = gRsqTable[i*kWave + lane];
+#pragma unroll
+    for (int i = 0; i < kRsqN/kWave; i++) rsq[i*kWave + lane] = r[i];
+  }
+  const int item = find_item(it, blockIdx.x);
+  const int job = it.job[item];
+  const DJob &jb = it.jobs[job];
+  const int band = it.band[item];
+  const int half = lane & 1;
+  const int off = jb.off[band];
+  const BlockPos bp = locate(jb, (long)(blockIdx.x - it.wg_start[item])*(kWave/2) + (lane >> 1));
+  const int w = jb.w;
+  const int16_t *const qmp = jb.qm + off + half*NL;
+  int v[NL];
+  int qm[NL];
+#pragma unroll
+  for (int j = 0; j < NL; j++) {
+    /* the scan positions of both halves are wave-uniform (scalar loads), the lane takes its own */
+    const int x0 = kScanXY[off + j][0];
+    const int y0 = kScanXY[off + j][1];
+    const int x1 = kScanXY[off + NL + j][0];
+    const int y1 = kScanXY[off + NL + j][1];
+    v[j] = bp.src[(half ? y1 : y0)*w + (half ? x1 : x0)];
+    qm[j] = qmp[j];
+  }
+  __syncthreads();   /* the 1/sqrt table */
+  int sum = 0;
+#pragma unroll
+  for (int j = 0; j < NL; j++) {
+    const int t = (int16_t)(v[j] >> 8);
+    sum += t*t;
+  }
+  sum += od_pair_swap(sum);
+  int xshift = 8 + 1 + odq_ilog(2*NL + sum)/2 - 15;
+  xshift = xshift > 0 ? xshift : 0;
+  int xs[NL];
+  int acc = 0;
+#pragma unroll
+  for (int j = 0; j < NL; j++) {
+    xs[j] = (int16_t)odq_shr_round(v[j]*qm[j], ODQ_QM_SHIFT + xshift);
+    acc += xs[j]*xs[j];
+  }
+  acc += od_pair_swap(acc);
+  const int qb = bp.blk >= jb.split_blk ? jb.q2[band] : jb.q[band];
+  int32_t g;
+  const int32_t cg = odq_gain_from_acc(acc, qb, jb.beta[band], xshift, &g);
+  od_decide_band<32, 2>(it, job, jb, band, bp.blk, bp.live, od_band_head(jb.beta[band], 32, cg), xs, pk, rsq, lane,
+   half);
 }
 
 /* ---- choice: one (block, band) per lane --------------------------------------
@@ -1725,11 +1799,10 @@ int noref_bands(const odhip_pvq_job *jobs, int njobs, double pvq_norm_lambda, od
   hipStream_t side[2] = {s, s};
   if (fork_streams(st, s, side) != ODHIP_SUCCESS) return ODHIP_EFAULT;
   Items it;
-  /* With the priced choice (fuse) the corner bands 0..2 are decided by the lanes that prepare
-     them (k_decide_corner: nothing of them enters the sort or the searches below); the first
-     band of the two-pass stage is then band 3. */
-  const int first_band = fuse ? 3 : 0;
-  constexpr size_t corner_lds = kRsqN*sizeof(double) + (size_t)15*kPitch*4;
+  /* With the priced choice (fuse) every band of up to 32 coefficients is decided by the lanes that
+     prepare it (k_decide_corner, k_decide_lane32: nothing of them enters the sort or the searches
+     below); the two-pass stage keeps the 128-coefficient bands. */
+  constexpr size_t corner_lds = kRsqN*sizeof(double) + (size_t)16*kPitch*4;
   if (!fuse) {
     /* prep: the low-frequency corner of every block one block per lane (bands
        0..3), the remaining 32-coefficient bands one band per lane, the
@@ -1745,14 +1818,16 @@ int noref_bands(const odhip_pvq_job *jobs, int njobs, double pvq_norm_lambda, od
     }
     if (it.nitems) k_prep_corner<8><<<it.wg_start[it.nitems], kWave, 0, s>>>(it);
   }
-  items_begin(it, st, lambda);
-  for (int j = 0; j < njobs; j++) {
-    for (int b = fuse ? 3 : 4; b < host[j].nb_bands; b++) {
-      const int n = host[j].off[b + 1] - host[j].off[b];
-      if (n <= 32) items_add(it, j, b, (host[j].nblocks + kWave - 1)/kWave);
+  if (!fuse) {
+    items_begin(it, st, lambda);
+    for (int j = 0; j < njobs; j++) {
+      for (int b = 4; b < host[j].nb_bands; b++) {
+        const int n = host[j].off[b + 1] - host[j].off[b];
+        if (n <= 32) items_add(it, j, b, (host[j].nblocks + kWave - 1)/kWave);
+      }
     }
+    if (it.nitems) k_prep_lane<<<it.wg_start[it.nitems], kWave, 0, side[1]>>>(it);
   }
-  if (it.nitems) k_prep_lane<<<it.wg_start[it.nitems], kWave, 0, fuse ? s : side[1]>>>(it);
   items_begin(it, st, lambda);
   for (int j = 0; j < njobs; j++) {
     for (int b = 0; b < host[j].nb_bands; b++) {
@@ -1766,7 +1841,9 @@ int noref_bands(const odhip_pvq_job *jobs, int njobs, double pvq_norm_lambda, od
   items_begin(all, st, lambda);
   items_begin(it, st, lambda);
   for (int j = 0; j < njobs; j++) {
-    for (int b = first_band; b < host[j].nb_bands; b++) {
+    for (int b = 0; b < host[j].nb_bands; b++) {
+      /* with the choice inside, only the 128-coefficient bands go through the two-pass stage */
+      if (fuse && host[j].off[b + 1] - host[j].off[b] != 128) continue;
       items_add(it, j, b, (host[j].nblocks + kSortChunk - 1)/kSortChunk);
       items_add(all, j, b, 1);
     }
@@ -1787,7 +1864,17 @@ int noref_bands(const odhip_pvq_job *jobs, int njobs, double pvq_norm_lambda, od
   /* search: the band sizes are independent launches on forked streams */
   if (fork_streams(st, s, side) != ODHIP_SUCCESS) return ODHIP_EFAULT;
   launch_search<128, 2, 1>(st, host, njobs, lambda, s, fuse);
-  launch_search<32, 2, 1>(st, host, njobs, lambda, side[0], fuse);
+  if (fuse) {
+    items_begin(it, st, lambda);
+    it.fuse = 1;
+    for (int j = 0; j < njobs; j++) {
+      for (int b = 0; b < host[j].nb_bands; b++) {
+        if (host[j].off[b + 1] - host[j].off[b] == 32) items_add(it, j, b, (host[j].nblocks + kWave/2 - 1)/(kWave/2));
+      }
+    }
+    if (it.nitems) k_decide_lane32<<<it.wg_start[it.nitems], kWave, corner_lds, side[0]>>>(it);
+  }
+  else launch_search<32, 2, 1>(st, host, njobs, lambda, side[0], fuse);
   if (fuse) {
     items_begin(it, st, lambda);
     it.fuse = 1;

@@ -255,8 +255,8 @@ def test_priced_choice_inside_the_search_equals_the_choice_kernel(hip, dec):
         for key in ("choice", "band", "y"):
             assert torch.equal(ja.cands[key], jc.cands[key]), (ja.bs, key, "resolved")
         # decided in the search (b): the choice and the chosen candidate's pulses; what nobody
-        # reads (a losing candidate, the second half of a record, the whole record of a corner
-        # band decided by the lane that prepared it) is not written
+        # reads (a losing candidate, the second half of a record, the whole record of a band of up
+        # to 32 coefficients, decided by the lanes that prepared it) is not written
         assert torch.equal(ja.cands["choice"], jb.cands["choice"]), (ja.bs, "choice")
         nb, offs, ln = hip.pvq_band_layout(ja.bs)
         band_of = torch.zeros(ln, dtype=torch.long, device="cuda")
@@ -270,9 +270,10 @@ def test_priced_choice_inside_the_search_equals_the_choice_kernel(hip, dec):
             assert torch.equal(ja.cands["y"][slot][per_coef], jb.cands["y"][slot][per_coef]), (ja.bs, slot)
             if slot:
                 second += int(picked.sum())
-        # bands that go through the two-pass stage (band 3 on) keep the first half of their record
-        if nb > 3:
-            assert torch.equal(ja.cands["band"][:, 3:, :32], jb.cands["band"][:, 3:, :32]), (ja.bs, "band head")
+        # the 128-coefficient bands (band 6 on) go through the two-pass stage and keep the first
+        # half of their record
+        if nb > 6:
+            assert torch.equal(ja.cands["band"][:, 6:, :32], jb.cands["band"][:, 6:, :32]), (ja.bs, "band head")
         nonzero += int((ch.view(-1, 4)[:, 1] != 0).sum())
     assert nonzero > 1000 and second > 100
     # pricing really changes decisions: the distortion-only choice differs somewhere
