@@ -275,10 +275,12 @@ int pipe_init(odhip_pipe *p) {
     if (!p->ctx[i]) return ODHIP_EFAULT;
     /* with two chains side by side (chroma from luma, inter) the band stages do not fork
        their searches onto side streams: more concurrency only interleaves the searches of
-       one chain (measured: 5.72 -> 5.58 ms per step; ODHIP_PIPE_FORK=1 restores the forks).
+       one chain (measured: 5.72 -> 5.58 ms per step; ODHIP_PIPE_FORK=3 restores the forks).
        The single chain of the chroma-without-reference mode keeps them (3.56 vs 3.45 ms). */
     const bool two_chains = c.chroma_cfl || c.inter;
-    odhip_ctx_set_serial(p->ctx[i], p->serial || (two_chains && getenv("ODHIP_PIPE_FORK") == nullptr));
+    /* ODHIP_PIPE_FORK: bit 0 = the luma chain forks, bit 1 = the chroma chain forks */
+    const int forkmask = getenv("ODHIP_PIPE_FORK") ? atoi(getenv("ODHIP_PIPE_FORK")) : 0;
+    odhip_ctx_set_serial(p->ctx[i], p->serial || (two_chains && !(forkmask >> i & 1)));
     odhip_ctx_set_fpr(p->ctx[i], c.fpr_bits != 0);
   }
   /* Experiment knob: ODHIP_PIPE_CUSPLIT=n (1..7) gives the luma chain n of every 8 compute
