@@ -209,8 +209,8 @@ def test_inverse_levels_in_one_launch_equal_level_by_level(hip, dec):
     assert torch.equal(got2[0], want[2]) and torch.equal(got2[1], want[0])
 
 
-@pytest.mark.parametrize("dec", [0, 1])
-def test_priced_choice_inside_the_search_equals_the_choice_kernel(hip, dec):
+@pytest.mark.parametrize("dec,size", [(0, (256, 192)), (1, (256, 192)), (0, (64, 128)), (1, (128, 64))])
+def test_priced_choice_inside_the_search_equals_the_choice_kernel(hip, dec, size):
     """odhip_pvq_noref_bands_priced_multi (the search kernels decide from their registers) and
     odhip_pvq_noref_bands_multi + odhip_pvq_choose_priced_multi (a choice kernel reads the
     records) leave identical choice records and identical pulses of every chosen candidate (the
@@ -218,7 +218,8 @@ def test_priced_choice_inside_the_search_equals_the_choice_kernel(hip, dec):
     the decision was a close call); and with the decision margin forced wide - every band a
     close call - the host-libm resolve re-decides bands to the same result, byte for byte."""
     import torch
-    W, H = 256, 192
+    W, H = size              # the small ones: fewer blocks than a wavefront has lanes at the upper levels
+    big = W*H > 20000
     planes = synth_frame(W, H, seed=29)
     rng = np.random.RandomState(6)
     src = planes[0] if dec == 0 else planes[1]
@@ -246,7 +247,7 @@ def test_priced_choice_inside_the_search_equals_the_choice_kernel(hip, dec):
         redone = hip.pvq_choose_priced_multi(c, lam, fused_bands=True)
     finally:
         hip.set_price_tol_scale(1.)
-    assert redone > 100
+    assert redone > (100 if big else 10)
     torch.cuda.synchronize()
     nonzero = 0
     second = 0
@@ -275,7 +276,7 @@ def test_priced_choice_inside_the_search_equals_the_choice_kernel(hip, dec):
         if nb > 6:
             assert torch.equal(ja.cands["band"][:, 6:, :32], jb.cands["band"][:, 6:, :32]), (ja.bs, "band head")
         nonzero += int((ch.view(-1, 4)[:, 1] != 0).sum())
-    assert nonzero > 1000 and second > 100
+    assert nonzero > (1000 if big else 100) and second > (100 if big else 0)
     # pricing really changes decisions: the distortion-only choice differs somewhere
     d = jobs()
     hip.pvq_noref_bands_multi(d, lam)
