@@ -816,12 +816,18 @@ __global__ __launch_bounds__(kWave, (S == 2 ? 2 : 1)) void k_search(Items it) {
    Band 3 of the larger blocks (32 coefficients) stays with the sorted two-pass stage. */
 /* N = band size, S = lanes per band (2: the lane pair of pvq_lane.cuh, `half` = lane & 1, each lane
    holding NL = N/S coefficients in xs). */
-template <int N, int S = 1>
+/* MASK: the lane's LDS column already holds |x| << 16 and the signs come as one bit per coefficient in
+   `sg` (a band too long to keep signed in registers across the searches); xs is not read. */
+template <int N, int S = 1, bool MASK = false>
 __device__ __forceinline__ void od_decide_band(const Items &it, int job, const DJob &jb, int band, long blk,
- bool live, const BandHead &bh, const int *xs, uint32_t *pk, const double *rsq, int lane, int half = 0) {
+ bool live, const BandHead &bh, const int *xs, uint32_t *pk, const double *rsq, int lane, int half = 0,
+ unsigned long long sg = 0) {
   constexpr int NL = N/S;
   constexpr int PAD = N == 15 ? 1 : 0;
   constexpr int NV = (NL + PAD)/8;
+  /* a long band's first candidate leaves as it is packed (32 registers not held across the second
+     search); a short one waits for the decision */
+  constexpr bool EARLY0 = NL >= 64;
   static_assert(S == 1 || PAD == 0, "pair mode has no padded band");
   RecHead hd;
   hd.cg = bh.h0.x;
@@ -831,8 +837,10 @@ __device__ __forceinline__ void od_decide_band(const Items &it, int job, const D
   hd.k[1] = bh.h0.w >> 16;
   hd.flags[0] = live ? bh.h1.x & 0xff : 0;
   hd.flags[1] = live ? bh.h1.x >> 8 & 0xff : 0;
+  if constexpr (!MASK) {
 #pragma unroll
-  for (int j = 0; j < NL; j++) pk[j*kWave + lane] = (uint32_t)abs(xs[j]) << 16;
+    for (int j = 0; j < NL; j++) pk[j*kWave + lane] = (uint32_t)abs(xs[j]) << 16;
+  }
   LaneSearch st;
   od_lane_prepare<NL, S>(st, pk, lane);
   const int32_t cg = hd.cg;
@@ -844,7 +852,8 @@ __device__ __forceinline__ void od_decide_band(const Items &it, int job, const D
   int yyv[2] = {0, 0};
   int momv[2] = {0, 0};
   double distv[2] = {0, 0};
-  int4 yq[2][NV];
+  int4 yq[2][EARLY0 ? 1 : NV];
+  int4 ylate[EARLY0 ? NV : 1];
 #pragma unroll 1
   for (int c = 0; c < 2; c++) {
     const bool on = (c ? hd.flags[1] : hd.flags[0]) == 1;
@@ -874,8 +883,16 @@ __device__ __forceinline__ void od_decide_band(const Items &it, int job, const D
         const int j0 = v*8 + 2*t - PAD;
         const int y0 = j0 >= 0 && on ? (int)(pk[(j0 < 0 ? 0 : j0)*kWave + lane] >> 1 & 0x7fffu) : 0;
         const int y1 = on ? (int)(pk[(j0 + 1)*kWave + lane] >> 1 & 0x7fffu) : 0;
-        const int s0 = j0 >= 0 ? xs[j0 < 0 ? 0 : j0] >> 31 : 0;
-        const int s1 = xs[j0 + 1] >> 31;
+        int s0;
+        int s1;
+        if constexpr (MASK) {
+          s0 = -(int)(sg >> (j0 < 0 ? 0 : j0) & 1u);
+          s1 = -(int)(sg >> (j0 + 1) & 1u);
+        }
+        else {
+          s0 = j0 >= 0 ? xs[j0 < 0 ? 0 : j0] >> 31 : 0;
+          s1 = xs[j0 + 1] >> 31;
+        }
         o[t] = (((y0 ^ s0) - s0) & 0xffff) | ((y1 ^ s1) - s1) << 16;
         mom += (half*NL + j0)*y0 + (half*NL + j0 + 1)*y1;          /* y0 = 0 where j0 < 0 */
       }
@@ -888,14 +905,26 @@ __device__ __forceinline__ void od_decide_band(const Items &it, int job, const D
       distv[1] = distc;
       momv[1] = mom;
 #pragma unroll
-      for (int v = 0; v < NV; v++) yq[1][v] = q[v];
+      for (int v = 0; v < NV; v++) {
+        if constexpr (EARLY0) ylate[v] = q[v];
+        else yq[1][v] = q[v];
+      }
     }
     else {
       yyv[0] = yyc;
       distv[0] = distc;
       momv[0] = mom;
+      if constexpr (EARLY0) {
+        if (live) {
+          int4 *yo = reinterpret_cast<int4 *>(jb.y + off + blk*len);
 #pragma unroll
-      for (int v = 0; v < NV; v++) yq[0][v] = q[v];
+          for (int v = 0; v < NV; v++) yo[v] = q[v];
+        }
+      }
+      else {
+#pragma unroll
+        for (int v = 0; v < NV; v++) yq[0][v] = q[v];
+      }
     }
   }
   int res = 0;
@@ -910,15 +939,17 @@ __device__ __forceinline__ void od_decide_band(const Items &it, int job, const D
   }
   if (!live) return;
   /* sel | close << 1: the chosen candidate's pulses; both, and the whole record, for a close call */
-  if (!(res & 1) || (res & 2)) {
-    int4 *yo = reinterpret_cast<int4 *>(jb.y + off + blk*len);
+  if constexpr (!EARLY0) {
+    if (!(res & 1) || (res & 2)) {
+      int4 *yo = reinterpret_cast<int4 *>(jb.y + off + blk*len);
 #pragma unroll
-    for (int v = 0; v < NV; v++) yo[v] = yq[0][v];
+      for (int v = 0; v < NV; v++) yo[v] = yq[0][v];
+    }
   }
   if (res) {
     int4 *yo = reinterpret_cast<int4 *>(jb.y + off + (nblocks + blk)*len);
 #pragma unroll
-    for (int v = 0; v < NV; v++) yo[v] = yq[1][v];
+    for (int v = 0; v < NV; v++) yo[v] = EARLY0 ? ylate[v] : yq[1][v];
   }
   if ((res & 2) && half == 0) {
     int4 *out = reinterpret_cast<int4 *>(jb.rec + blk*jb.nb_bands + band);
@@ -1096,6 +1127,70 @@ __global__ __launch_bounds__(kWave) void k_decide_lane32(Items it) {
   const int32_t cg = odq_gain_from_acc(acc, qb, jb.beta[band], xshift, &g);
   od_decide_band<32, 2>(it, job, jb, band, bp.blk, bp.live, od_band_head(jb.beta[band], 32, cg), xs, pk, rsq, lane,
    half);
+}
+
+/* ... and the 128-coefficient bands: a lane pair per band as k_search<128, 2, 1>, each lane gathering its
+   64 coding positions straight into its LDS column (the raw coefficients wait in registers only until the
+   band's scaling shift is known; the signs as 64 bits).  The sort by pulse class buys these bands -2 % on
+   the default content and +8 % on the natural one (measured with the keys forced equal) against 130 us of
+   preparation and sort and a 600 MB round trip of scaled vectors. */
+__global__ __launch_bounds__(kWave, 2) void k_decide_pair128(Items it) {
+  constexpr int NL = 64;
+  extern __shared__ __attribute__((aligned(16))) double lds_d[];
+  double *rsq = lds_d;                                   /* [kRsqN]  */
+  uint32_t *pk = (uint32_t *)(rsq + kRsqN);              /* [64][64] */
+  const int lane = threadIdx.x;
+  {
+    double r[kRsqN/kWave];
+#pragma unroll
+    for (int i = 0; i < kRsqN/kWave; i++) r[i] = gRsqTable[i*kWave + lane];
+#pragma unroll
+    for (int i = 0; i < kRsqN/kWave; i++) rsq[i*kWave + lane] = r[i];
+  }
+  const int item = find_item(it, blockIdx.x);
+  const int job = it.job[item];
+  const DJob &jb = it.jobs[job];
+  const int band = it.band[item];
+  const int half = lane & 1;
+  const int off = jb.off[band];
+  const BlockPos bp = locate(jb, (long)(blockIdx.x - it.wg_start[item])*(kWave/2) + (lane >> 1));
+  const int w = jb.w;
+  const int16_t *const qmp = jb.qm + off + half*NL;
+  int v[NL];
+  int sum = 0;
+#pragma unroll
+  for (int j = 0; j < NL; j++) {
+    /* the scan positions of both halves are wave-uniform (scalar loads), the lane takes its own */
+    const int x0 = kScanXY[off + j][0];
+    const int y0 = kScanXY[off + j][1];
+    const int x1 = kScanXY[off + NL + j][0];
+    const int y1 = kScanXY[off + NL + j][1];
+    v[j] = bp.src[(half ? y1 : y0)*w + (half ? x1 : x0)];
+  }
+  __syncthreads();   /* the 1/sqrt table */
+#pragma unroll
+  for (int j = 0; j < NL; j++) {
+    const int t = (int16_t)(v[j] >> 8);
+    sum += t*t;
+  }
+  sum += od_pair_swap(sum);
+  int xshift = 8 + 1 + odq_ilog(2*NL + sum)/2 - 15;
+  xshift = xshift > 0 ? xshift : 0;
+  unsigned long long sg = 0;
+  int acc = 0;
+#pragma unroll
+  for (int j = 0; j < NL; j++) {
+    const int x = (int16_t)odq_shr_round(v[j]*qmp[j], ODQ_QM_SHIFT + xshift);
+    acc += x*x;
+    sg |= (unsigned long long)(x < 0) << j;
+    pk[j*kWave + lane] = (uint32_t)abs(x) << 16;
+  }
+  acc += od_pair_swap(acc);
+  const int qb = bp.blk >= jb.split_blk ? jb.q2[band] : jb.q[band];
+  int32_t g;
+  const int32_t cg = odq_gain_from_acc(acc, qb, jb.beta[band], xshift, &g);
+  od_decide_band<128, 2, true>(it, job, jb, band, bp.blk, bp.live, od_band_head(jb.beta[band], 128, cg), nullptr, pk,
+   rsq, lane, half, sg);
 }
 
 /* ---- choice: one (block, band) per lane --------------------------------------
@@ -1783,51 +1878,87 @@ int noref_bands(const odhip_pvq_job *jobs, int njobs, double pvq_norm_lambda, od
       if (n != 8 && n != 15 && n != 32 && n != 128) return ODHIP_EINVAL;
     }
   }
-  rc = scratch_reserve(st, x16_elems, band_elems, s);
-  if (rc) return rc;
-  x16_elems = 0;
-  band_elems = 0;
-  for (int j = 0; j < njobs; j++) {
-    host[j].x16 = st.scr.x16 + x16_elems;
-    host[j].keys = st.scr.keys + band_elems;
-    host[j].ids = st.scr.ids + band_elems;
-    x16_elems += (size_t)host[j].nblocks*host[j].len;
-    band_elems += (size_t)host[j].nblocks*host[j].nb_bands;
+  if (!fuse) {
+    /* scaled vectors, sort keys and sorted indices of the two-pass stage (the stage that decides in place
+       keeps none of them) */
+    rc = scratch_reserve(st, x16_elems, band_elems, s);
+    if (rc) return rc;
+    x16_elems = 0;
+    band_elems = 0;
+    for (int j = 0; j < njobs; j++) {
+      host[j].x16 = st.scr.x16 + x16_elems;
+      host[j].keys = st.scr.keys + band_elems;
+      host[j].ids = st.scr.ids + band_elems;
+      x16_elems += (size_t)host[j].nblocks*host[j].len;
+      band_elems += (size_t)host[j].nblocks*host[j].nb_bands;
+    }
   }
   rc = upload_jobs(st, host, njobs, s);
   if (rc) return rc;
   hipStream_t side[2] = {s, s};
   if (fork_streams(st, s, side) != ODHIP_SUCCESS) return ODHIP_EFAULT;
   Items it;
-  /* With the priced choice (fuse) every band of up to 32 coefficients is decided by the lanes that
-     prepare it (k_decide_corner, k_decide_lane32: nothing of them enters the sort or the searches
-     below); the two-pass stage keeps the 128-coefficient bands. */
-  constexpr size_t corner_lds = kRsqN*sizeof(double) + (size_t)16*kPitch*4;
-  if (!fuse) {
-    /* prep: the low-frequency corner of every block one block per lane (bands
-       0..3), the remaining 32-coefficient bands one band per lane, the
-       128-coefficient bands one per 16-lane row */
+  if (fuse) {
+    /* With the priced choice every band is prepared, searched and decided by the lanes that load it
+       (k_decide_corner, k_decide_lane32, k_decide_pair128): no preparation pass, no sort, no scaled
+       vectors or records in memory.  Four independent launches. */
+    constexpr size_t lane_lds = kRsqN*sizeof(double) + (size_t)16*kPitch*4;
+    constexpr size_t pair_lds = kRsqN*sizeof(double) + (size_t)64*kPitch*4;
     items_begin(it, st, lambda);
+    it.fuse = 1;
     for (int j = 0; j < njobs; j++) {
-      if (host[j].bs == 0) items_add(it, j, 0, (host[j].nblocks + kWave - 1)/kWave);
-    }
-    if (it.nitems) k_prep_corner<4><<<it.wg_start[it.nitems], kWave, 0, s>>>(it);
-    items_begin(it, st, lambda);
-    for (int j = 0; j < njobs; j++) {
-      if (host[j].bs > 0) items_add(it, j, 0, (host[j].nblocks + kWave - 1)/kWave);
-    }
-    if (it.nitems) k_prep_corner<8><<<it.wg_start[it.nitems], kWave, 0, s>>>(it);
-  }
-  if (!fuse) {
-    items_begin(it, st, lambda);
-    for (int j = 0; j < njobs; j++) {
-      for (int b = 4; b < host[j].nb_bands; b++) {
-        const int n = host[j].off[b + 1] - host[j].off[b];
-        if (n <= 32) items_add(it, j, b, (host[j].nblocks + kWave - 1)/kWave);
+      for (int b = 0; b < host[j].nb_bands; b++) {
+        if (host[j].off[b + 1] - host[j].off[b] == 128) items_add(it, j, b, (host[j].nblocks + kWave/2 - 1)/(kWave/2));
       }
     }
-    if (it.nitems) k_prep_lane<<<it.wg_start[it.nitems], kWave, 0, side[1]>>>(it);
+    const bool prof = st.prof_on && st.prof_n < kProfSlots;
+    if (prof) (void)hipEventRecord(st.prof_ev[st.prof_n][0], s);
+    if (it.nitems) k_decide_pair128<<<it.wg_start[it.nitems], kWave, pair_lds, s>>>(it);
+    if (prof) (void)hipEventRecord(st.prof_ev[st.prof_n++][1], s);
+    items_begin(it, st, lambda);
+    it.fuse = 1;
+    for (int j = 0; j < njobs; j++) {
+      for (int b = 0; b < host[j].nb_bands; b++) {
+        if (host[j].off[b + 1] - host[j].off[b] == 32) items_add(it, j, b, (host[j].nblocks + kWave/2 - 1)/(kWave/2));
+      }
+    }
+    if (it.nitems) k_decide_lane32<<<it.wg_start[it.nitems], kWave, lane_lds, side[0]>>>(it);
+    items_begin(it, st, lambda);
+    it.fuse = 1;
+    for (int j = 0; j < njobs; j++) items_add(it, j, 0, (host[j].nblocks + kWave - 1)/kWave);
+    if (it.nitems) k_decide_corner<0><<<it.wg_start[it.nitems], kWave, lane_lds, side[1]>>>(it);
+    items_begin(it, st, lambda);
+    it.fuse = 1;
+    for (int j = 0; j < njobs; j++) {
+      if (host[j].bs > 0) items_add(it, j, 1, (host[j].nblocks + kWave - 1)/kWave);
+    }
+    if (it.nitems) k_decide_corner<1><<<it.wg_start[it.nitems], kWave, lane_lds, side[1]>>>(it);
+    if (join_streams(st, s, side) != ODHIP_SUCCESS) return ODHIP_EFAULT;
+    const int rc2 = price_count_begin(st, s);
+    if (rc2) return rc2;
+    return odhip_check_launch();
   }
+  /* prep: the low-frequency corner of every block one block per lane (bands
+     0..3), the remaining 32-coefficient bands one band per lane, the
+     128-coefficient bands one per 16-lane row */
+  items_begin(it, st, lambda);
+  for (int j = 0; j < njobs; j++) {
+    if (host[j].bs == 0) items_add(it, j, 0, (host[j].nblocks + kWave - 1)/kWave);
+  }
+  if (it.nitems) k_prep_corner<4><<<it.wg_start[it.nitems], kWave, 0, s>>>(it);
+  items_begin(it, st, lambda);
+  for (int j = 0; j < njobs; j++) {
+    if (host[j].bs > 0) items_add(it, j, 0, (host[j].nblocks + kWave - 1)/kWave);
+  }
+  if (it.nitems) k_prep_corner<8><<<it.wg_start[it.nitems], kWave, 0, s>>>(it);
+  items_begin(it, st, lambda);
+  for (int j = 0; j < njobs; j++) {
+    for (int b = 4; b < host[j].nb_bands; b++) {
+      const int n = host[j].off[b + 1] - host[j].off[b];
+      if (n <= 32) items_add(it, j, b, (host[j].nblocks + kWave - 1)/kWave);
+    }
+  }
+  if (it.nitems) k_prep_lane<<<it.wg_start[it.nitems], kWave, 0, side[1]>>>(it);
   items_begin(it, st, lambda);
   for (int j = 0; j < njobs; j++) {
     for (int b = 0; b < host[j].nb_bands; b++) {
@@ -1842,8 +1973,6 @@ int noref_bands(const odhip_pvq_job *jobs, int njobs, double pvq_norm_lambda, od
   items_begin(it, st, lambda);
   for (int j = 0; j < njobs; j++) {
     for (int b = 0; b < host[j].nb_bands; b++) {
-      /* with the choice inside, only the 128-coefficient bands go through the two-pass stage */
-      if (fuse && host[j].off[b + 1] - host[j].off[b] != 128) continue;
       items_add(it, j, b, (host[j].nblocks + kSortChunk - 1)/kSortChunk);
       items_add(all, j, b, 1);
     }
@@ -1855,47 +1984,17 @@ int noref_bands(const odhip_pvq_job *jobs, int njobs, double pvq_norm_lambda, od
     st.sort_dirty = false;
   }
   st.sort_dirty = true;
-  if (it.nitems) {
-    k_hist<<<it.wg_start[it.nitems], 256, 0, s>>>(it);
-    k_prefix<<<all.nitems, 256, 0, s>>>(all);
-  }
+  k_hist<<<it.wg_start[it.nitems], 256, 0, s>>>(it);
+  k_prefix<<<all.nitems, 256, 0, s>>>(all);
   st.sort_dirty = odhip_check_launch() != ODHIP_SUCCESS;
-  if (it.nitems) k_scatter<<<it.wg_start[it.nitems], 256, 0, s>>>(it);
+  k_scatter<<<it.wg_start[it.nitems], 256, 0, s>>>(it);
   /* search: the band sizes are independent launches on forked streams */
   if (fork_streams(st, s, side) != ODHIP_SUCCESS) return ODHIP_EFAULT;
-  launch_search<128, 2, 1>(st, host, njobs, lambda, s, fuse);
-  if (fuse) {
-    items_begin(it, st, lambda);
-    it.fuse = 1;
-    for (int j = 0; j < njobs; j++) {
-      for (int b = 0; b < host[j].nb_bands; b++) {
-        if (host[j].off[b + 1] - host[j].off[b] == 32) items_add(it, j, b, (host[j].nblocks + kWave/2 - 1)/(kWave/2));
-      }
-    }
-    if (it.nitems) k_decide_lane32<<<it.wg_start[it.nitems], kWave, corner_lds, side[0]>>>(it);
-  }
-  else launch_search<32, 2, 1>(st, host, njobs, lambda, side[0], fuse);
-  if (fuse) {
-    items_begin(it, st, lambda);
-    it.fuse = 1;
-    for (int j = 0; j < njobs; j++) items_add(it, j, 0, (host[j].nblocks + kWave - 1)/kWave);
-    if (it.nitems) k_decide_corner<0><<<it.wg_start[it.nitems], kWave, corner_lds, side[1]>>>(it);
-    items_begin(it, st, lambda);
-    it.fuse = 1;
-    for (int j = 0; j < njobs; j++) {
-      if (host[j].bs > 0) items_add(it, j, 1, (host[j].nblocks + kWave - 1)/kWave);
-    }
-    if (it.nitems) k_decide_corner<1><<<it.wg_start[it.nitems], kWave, corner_lds, side[1]>>>(it);
-  }
-  else {
-    launch_search<15, 1, 1>(st, host, njobs, lambda, side[1], fuse);
-    launch_search<8, 1, 1>(st, host, njobs, lambda, side[1], fuse);
-  }
+  launch_search<128, 2, 1>(st, host, njobs, lambda, s, false);
+  launch_search<32, 2, 1>(st, host, njobs, lambda, side[0], false);
+  launch_search<15, 1, 1>(st, host, njobs, lambda, side[1], false);
+  launch_search<8, 1, 1>(st, host, njobs, lambda, side[1], false);
   if (join_streams(st, s, side) != ODHIP_SUCCESS) return ODHIP_EFAULT;
-  if (fuse) {
-    const int rc2 = price_count_begin(st, s);
-    if (rc2) return rc2;
-  }
   return odhip_check_launch();
 }
 

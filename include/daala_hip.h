@@ -920,12 +920,12 @@ int odhip_pvq_choose_priced_resolve(const odhip_pvq_job *jobs, int njobs, double
 /* odhip_pvq_noref_bands_multi AND odhip_pvq_choose_priced_multi in one pass: every band is
    decided where its search ends, from the values held in registers; no choice kernel reads the
    records back.  What leaves the stage is what its consumers read: the choice record and the
-   CHOSEN candidate's pulses (slot = choice[0]).  Bands of up to 32 coefficients are
-   prepared, searched and decided by one lane (a lane pair for 32) without ever existing as
-   records or scaled vectors in memory; the 128-coefficient bands go through the two-pass
-   stage (preparation, sort, search) and keep the first half of their record.  A losing candidate's pulses and the second half of a record (sums, distortions,
-   moments) are written only for a band listed as a close call - the resolve decides it again
-   from exactly those.  A host that wants both candidates of every band uses
+   CHOSEN candidate's pulses (slot = choice[0]).  Every band is prepared, searched and
+   decided by the lane (or lane pair) that loads its coefficients, in natural block order: no
+   scaled vector, band record, sort key or sorted index exists in memory for it.  A losing
+   candidate's pulses and the band record (gains, pulse counts, sums, distortions, moments) are
+   written only for a band listed as a close call - the resolve decides it again from exactly
+   those.  A host that wants both candidates of every band uses
    odhip_pvq_noref_bands_multi.  Follow with odhip_pvq_choose_priced_resolve. */
 int odhip_pvq_noref_bands_priced_multi(const odhip_pvq_job *jobs, int njobs, double pvq_norm_lambda,
  odhip_stream stream);
