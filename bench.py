@@ -932,12 +932,21 @@ def main():
                 continue     # chroma goes through the with-reference stage
             for bs in range(top + 1):
                 n128 += planes * (w // (4 << bs)) * (h // (4 << bs)) * [0, 0, 1, 3, 3][bs]
-        # k_search<128,2,1>: per band 2n B x16 in + 32 B record head in, 2 x 2n B pulses +
-        # 32 B record tail out = 6n + 64 = 832 B
-        roof_noref = search_roofline(
-            "k_search<128,2,1> (PVQ search of the 128-coefficient luma bands, no reference)",
-            "k_search<128", float(np.mean(search_excl)), float(np.mean(search_ms)), len(search_ms),
-            n128 * (6 * 128 + 64), n128, step_ms, pmc, pmc_src)
+        # priced step: k_decide_pair128 (the band prepared, searched and decided by a lane pair):
+        # per band 4n B coefficients in, 2n B pulses (chosen candidate) + 16 B choice out = 784 B;
+        # --no-price: k_search<128,2,1>: 2n B x16 + 32 B record head in, 2 x 2n B pulses + 32 B
+        # record tail out = 6n + 64 = 832 B
+        if price:
+            roof_noref = search_roofline(
+                "k_decide_pair128 (the 128-coefficient luma bands, no reference: prepared, searched and "
+                "decided by a lane pair)",
+                "k_decide_pair128", float(np.mean(search_excl)), float(np.mean(search_ms)), len(search_ms),
+                n128 * (6 * 128 + 16), n128, step_ms, pmc, pmc_src)
+        else:
+            roof_noref = search_roofline(
+                "k_search<128,2,1> (PVQ search of the 128-coefficient luma bands, no reference)",
+                "k_search<128", float(np.mean(search_excl)), float(np.mean(search_ms)), len(search_ms),
+                n128 * (6 * 128 + 64), n128, step_ms, pmc, pmc_src)
         roof = roof_noref
         roof_ref = None
         if cfl and ref_search_ms:
