@@ -322,3 +322,27 @@ def test_two_contexts_keep_their_own_scratch():
         assert torch.equal(outs[i], want[i])
     for c in ctxs:
         c.destroy()
+
+
+@pytest.mark.skipif(ref() is None, reason="oracle/_ref (the compiled reference) not present")
+@pytest.mark.parametrize("quality,masking,hvs", [(1, 1, 1), (5, 1, 1), (40, 1, 1), (100, 1, 1), (20, 0, 1), (20, 1, 0),
+                                                 (511, 1, 1)])
+def test_device_priced_step_across_quantisers(quality, masking, hvs):
+    """The priced step (every band decided inside its search, the no-reference bands in place) against the
+    compiled reference's pvq_theta at other operating points than -v 20: fine and coarse quantisers (K from 1 to
+    hundreds of pulses), activity masking off (beta = 1 everywhere), the flat quantisation matrices - pixels of
+    every level and gain / theta / K / pulses of every band, a 640x360 picture of each content type."""
+    import daala_amd as D
+    import _pipeline_check as C
+    D.init(0)
+    b = _bench()
+    qt = D.QuantTables.for_quality(quality, use_masking=masking, hvs_qm=hvs)
+    pw, ph = 640, 360
+    for gen in (b.synth_frame_np, b.natural_like_frame_np):
+        full = b.picture_planes(gen(2, 1717))
+        pics = [full[0][:ph, :pw], full[1][:ph // 2, :pw // 2], full[2][:ph // 2, :pw // 2]]
+        gpu, _, dec = C.gpu_device_priced(D, qt, pics, pw, ph, chroma_cfl=True, decisions=True)
+        want = []
+        cpu, _, _ = C.cpu_frame(qt, pics, pw, ph, chroma_cfl=True, decisions=want)
+        assert C.compare_frame(gpu, cpu) == [], (quality, masking, hvs, gen.__name__)
+        assert C.compare_decisions(dec, want) == [], (quality, masking, hvs, gen.__name__)
