@@ -1015,7 +1015,7 @@ __device__ __forceinline__ void inverse_load_ref(int *t, const InverseArgs &a, i
    the whole plane. */
 template <int TILE>
 __device__ __forceinline__ void inverse_store(const int *t, const InverseArgs &a, int plane, int x0,
- int y0, int tid) {
+ int y0, int tid, int sbx, int sby) {
   constexpr int P = Geo<TILE>::kPitch;
   constexpr int NT = Geo<TILE>::kNT;
   const int w = a.w;
@@ -1052,8 +1052,6 @@ __device__ __forceinline__ void inverse_store(const int *t, const InverseArgs &a
   }
   const int nv = w/TILE - 1;
   const int nh = h/TILE - 1;
-  const int sbx = blockIdx.x;
-  const int sby = blockIdx.y;
   od_coeff *vs = a.vs + (long)plane*nv*h*4;
   od_coeff *hs = a.hs + (long)plane*nh*4*w;
   for (int i = tid; i < 2*TILE; i += NT) {
@@ -1192,7 +1190,7 @@ __global__ __launch_bounds__(Geo<TILE>::kNT) void k_inverse_part(InversePartArgs
   load_plane_tile<TILE>(t, a.coef + plane_off, a.w, x0, y0, tid);
   __syncthreads();
   inverse_part_levels<TILE, 0>(t, map, a, x0, y0, tid);
-  inverse_store<TILE>(t, a, plane, x0, y0, tid);
+  inverse_store<TILE>(t, a, plane, x0, y0, tid, blockIdx.x, blockIdx.y);
 }
 
 /* MINLEAF..MAXLEAF: the leaf levels this instance is launched for.  The 64- and 32-point networks
@@ -1312,7 +1310,124 @@ __global__ __launch_bounds__(Geo<TILE>::kNT) void k_inverse_sb(InverseArgsMulti 
       break;
   }
   inverse_split_levels<TILE, 1>(t, a, x0, y0, tid);
-  inverse_store<TILE>(t, a, plane, x0, y0, tid);
+  inverse_store<TILE>(t, a, plane, x0, y0, tid, blockIdx.x, blockIdx.y);
+}
+
+/* The 32x32 and 64x64 leaf levels of luma, TWO horizontally adjacent superblocks per 256-thread
+   workgroup: a 64-point pass has 64 columns (rows) per tile and a 32-point pass 128, so one tile keeps one /
+   two of a workgroup's four waves busy while the others wait at the barriers; with two tiles the 32-point
+   passes use every lane and the 64-point ones half.  Pulse-fed source only (odhip_inverse_levels_pvq). */
+__global__ __launch_bounds__(256) void k_inverse_sb_top2(InverseArgsMulti mm) {
+  constexpr int TILE = 64;
+  using G = Geo<TILE>;
+  using T = OdMul24;
+  constexpr int P = G::kPitch;
+  constexpr int NT = 256;
+  __shared__ __attribute__((aligned(16))) int t[2][TILE*P];
+  const int tid = threadIdx.x;
+  const int xb = blockIdx.x*2*TILE;
+  const int y0 = blockIdx.y*TILE;
+  const int plane = blockIdx.z % mm.nplanes;
+  const InverseArgs &a = mm.a[blockIdx.z / mm.nplanes];
+  const long plane_off = (long)plane*a.w*a.h;
+  const int sh = a.leaf_bs + 2;               /* 5 or 6 */
+  const int nbw = TILE >> sh;                 /* 2 or 1 blocks per tile row */
+  const int nbsb = nbw*nbw;
+  const int bw = a.w >> sh;
+  const int bh = a.h >> sh;
+  const int lsh = 31 - __clz(a.len);
+  const int csh = lsh - 4;
+  const int lnb = 31 - __clz(nbw);
+  const int nchunks = nbsb << csh;            /* per tile: 128 (32x32 leaves: 4 blocks x 512 coded) or 32 (64x64) */
+  /* thread tid takes chunk tid % nchunks of tile tid / nchunks: both tiles' chunks in one trip */
+  const int st = tid/nchunks;
+  const int c = tid - st*nchunks;
+  const bool act = st < 2;
+  const int x0 = xb + st*TILE;
+  const int b = c >> csh;
+  const int j0 = (c & ((1 << csh) - 1)) << 4;
+  const int lby = b >> lnb;
+  const int lbx = b & (nbw - 1);
+  int4 chs[2] = {make_int4(0, 0, 0, 0), make_int4(0, 0, 0, 0)};
+  int4 yq[2] = {make_int4(0, 0, 0, 0), make_int4(0, 0, 0, 0)};
+  int4 qm4[2];
+  int4 sc4[2];
+  int dc = 0;
+  if (act) {
+    const unsigned blk = (unsigned)(((long)plane*bh + (y0 >> sh))*bw + (x0 >> sh)) + lby*bw + lbx;
+    const int bnd0 = gInvBandOf[j0 ? j0 : 1];
+    const int bnd1 = gInvBandOf[j0 + 8];
+#pragma unroll
+    for (int hf = 0; hf < 2; hf++) {
+      qm4[hf] = *reinterpret_cast<const int4 *>(a.qm_inv + j0 + 8*hf);
+      sc4[hf] = *reinterpret_cast<const int4 *>(gInvScanXY + j0 + 8*hf);
+    }
+    if (j0 == 0) dc = a.coef[plane_off + (long)(y0 + (lby << sh))*a.w + x0 + (lbx << sh)];
+    chs[0] = a.choice[(long)blk*a.nb_bands + bnd0];
+    chs[1] = a.choice[(long)blk*a.nb_bands + bnd1];
+#pragma unroll
+    for (int hf = 0; hf < 2; hf++) {
+      if (chs[hf].y != 0) {
+        yq[hf] = *reinterpret_cast<const int4 *>(a.y
+         + (((unsigned)chs[hf].x*(unsigned)a.nblocks + blk) << lsh) + j0 + 8*hf);
+      }
+    }
+  }
+  /* uncoded positions of these levels are zero */
+  for (int i = tid; i < 2*TILE*P/4; i += NT) reinterpret_cast<int4 *>(&t[0][0])[i] = make_int4(0, 0, 0, 0);
+  __syncthreads();
+  if (act) {
+    const int base = (lby << sh)*P + (lbx << sh);
+    int *tt = t[st];
+#pragma unroll
+    for (int hf = 0; hf < 2; hf++) {
+      const int yd[4] = {yq[hf].x, yq[hf].y, yq[hf].z, yq[hf].w};
+      const int qd[4] = {qm4[hf].x, qm4[hf].y, qm4[hf].z, qm4[hf].w};
+      const int sd[4] = {sc4[hf].x, sc4[hf].y, sc4[hf].z, sc4[hf].w};
+      const int4 ch = chs[hf];
+      const int rnd = (1 << ch.w) >> 1;
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+          /* OD_MULT16_32_Q16: (int16)y * (int32)scale >> 16 == mulhi(y << 16, scale) */
+          const int yhi = u ? (yd[e] & (int)0xffff0000) : yd[e] << 16;
+          const int qmi = u ? qd[e] >> 16 : (int)(short)qd[e];
+          const int xy = u ? (unsigned)sd[e] >> 16 : sd[e] & 0xffff;
+          int v = (__mulhi(yhi, ch.z)*qmi + rnd) >> ch.w;
+          if (ch.y == 0) v = 0;
+          if (hf == 0 && e == 0 && u == 0 && j0 == 0) v = dc;
+          tt[base + (xy >> 8)*P + (xy & 255)] = v;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (a.leaf_bs == 3) {
+    /* 32-point: 128 rows (columns) per tile, tile = tid >> 7 */
+    const int s2 = tid >> 7;
+    const int lt = tid & 127;
+    od_tile_rows<TILE, 3, true, T, 128>(t[s2], t[s2], lt, OdAllBlocks());
+    __syncthreads();
+    od_tile_cols<TILE, 3, true, T, 128>(t[s2], t[s2], lt, OdAllBlocks());
+    __syncthreads();
+  }
+  else {
+    /* 64-point: 64 per tile, waves 0 and 1 */
+    const int g = tid >> 6;
+    if (g < 2) od_tile_rows<TILE, 4, true, T, 64>(t[g], t[g], tid & 63, OdAllBlocks());
+    __syncthreads();
+    if (g < 2) od_tile_cols<TILE, 4, true, T, 64>(t[g], t[g], tid & 63, OdAllBlocks());
+    __syncthreads();
+  }
+  if (a.leaf_bs == 3) {
+    /* od_postfilter_split of the 64x64 node above (src/filter.c:1510-1525: rows first, then columns) */
+    for (int s = 0; s < 2; s++) split_filter_rows<TILE, 4, true>(t[s], tid, y0, a.pic_h);
+    __syncthreads();
+    for (int s = 0; s < 2; s++) split_filter_cols<TILE, 4, true>(t[s], tid, xb + s*TILE, a.pic_w);
+    __syncthreads();
+  }
+  for (int s = 0; s < 2; s++) inverse_store<TILE>(t[s], a, plane, xb + s*TILE, y0, tid, 2*blockIdx.x + s, blockIdx.y);
 }
 
 struct EdgeArgs {
@@ -1531,7 +1646,14 @@ int inverse_launch(const InverseArgs *levels, int nlevels, int nplanes, int dec,
       if (im.a[l].leaf_bs <= 2) lo.a[nlo++] = im.a[l];
       else hi.a[nhi++] = im.a[l];
     }
-    if (nhi) k_inverse_sb<64, false, 3, 4><<<dim3(w/tile, h/tile, nplanes*nhi), Geo<64>::kNT, 0, s>>>(hi);
+    if (nhi) {
+      bool pulse_fed = true;
+      for (int l = 0; l < nhi; l++) pulse_fed = pulse_fed && hi.a[l].y != nullptr;
+      if (pulse_fed && (w/tile) % 2 == 0 && !getenv("ODHIP_INVERSE_X1")) {
+        k_inverse_sb_top2<<<dim3(w/(2*tile), h/tile, nplanes*nhi), 256, 0, s>>>(hi);
+      }
+      else k_inverse_sb<64, false, 3, 4><<<dim3(w/tile, h/tile, nplanes*nhi), Geo<64>::kNT, 0, s>>>(hi);
+    }
     if (nlo) k_inverse_sb<64, false, 0, 2><<<dim3(w/tile, h/tile, nplanes*nlo), Geo<64>::kNT, 0, s>>>(lo);
   }
   if (nv > 0) k_edge_rows<<<dim3((h + 255)/256, nv, nplanes*nlevels), 256, 0, s>>>(em);
