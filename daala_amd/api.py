@@ -1097,6 +1097,13 @@ class Pipe:
                "odhip_pipe_time_pyramid")
         return ms.value
 
+    def time_stage(self, stage, n=10, parity=-1):
+        """Average ms per launch group of one filter + DCT stage (a PIPE_STAGES name) run alone."""
+        ms = ctypes.c_double()
+        _check(lib().odhip_pipe_time_stage(self._p(), PIPE_STAGES.index(stage), int(parity), int(n),
+                                           ctypes.byref(ms)), "odhip_pipe_time_stage")
+        return ms.value
+
     def host_wait_ms(self):
         lib().odhip_pipe_host_wait_ms.restype = ctypes.c_double
         return float(lib().odhip_pipe_host_wait_ms(self._p()))

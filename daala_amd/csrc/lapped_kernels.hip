@@ -23,6 +23,7 @@
    Pixels are bounded, so every lifting multiply uses the full-rate 24-bit
    multiplier (OdMul24, see od_lift.cuh). */
 #include "../../include/daala_hip.h"
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include "od_ctx.cuh"
@@ -1430,6 +1431,539 @@ __global__ __launch_bounds__(256) void k_inverse_sb_top2(InverseArgsMulti mm) {
   for (int s = 0; s < 2; s++) inverse_store<TILE>(t[s], a, plane, xb + s*TILE, y0, tid, 2*blockIdx.x + s, blockIdx.y);
 }
 
+/* ---- inverse, workgroups that WALK along a superblock row --------------------------------
+   One workgroup reconstructs a SEGMENT of horizontally adjacent superblocks of one (level, plane,
+   superblock row), group after group (a group = G adjacent tiles that are in LDS together).  What
+   that buys over one workgroup per superblock (k_inverse_sb above):
+
+   * the post-filter across the VERTICAL superblock edges inside a segment
+     (od_apply_postfilter_frame_sbs, first half, src/filter.c:1600-1606) runs in LDS: the last four
+     columns of a group stay behind in the pad columns of the tile ("keep": pitch = TILE + 4, the
+     four spare words of every row), the next group filters keep[2..3] | its own columns 0..1, and
+     the pixel rows go out in a window shifted four samples to the left.  No 2-sample strips, no
+     second kernel touching 4 bytes of every 64-byte line of the plane (k_edge_rows wrote 170 MB
+     for 12 MB of pixels and took 127 us per step); only the JOINTS between segments still go
+     through the strips and k_edge_rows;
+   * the leaf level is a compile-time constant per body (one kernel, a wave-uniform switch):
+     block / chunk indices are shifts, no runtime divisions in the dequantise-on-load;
+   * 4:2:0 chroma takes its 32x32 superblocks in PAIRS: a 32-point pass has 32 rows per tile, a
+     wavefront 64 lanes;
+   * LDS-only barriers between the phases (the stores of a group drain under the next group).
+
+   The horizontal edges still go through the hs strips (written after the vertical-edge filter,
+   which is the reference's order) and k_edge_cols. */
+#ifndef OD_WALK_WAVES
+#define OD_WALK_WAVES 1
+#endif
+struct InverseWalkArgs {
+  InverseArgs a[kMaxInvLevels];
+  int nplanes;
+  int seg_len;                   /* groups per workgroup */
+};
+
+/* One pass (rows, then columns: od_bin_idctNxN, src/dct.c:158-163 ...) of the leaf transforms of
+   the G tiles at t. */
+template <int TILE, int G, int NT, int LN, bool ROWS>
+__device__ __forceinline__ void walk_idct_pass(int *t, unsigned tid) {
+  using T = OdMul24;
+  constexpr int N = 4 << LN;
+  constexpr int P = TILE + 4;
+  constexpr int kTasks = TILE*(TILE/N);
+  for (unsigned k = tid; k < G*kTasks; k += NT) {
+    int *ts = t + (k/kTasks)*(TILE*P);
+    const unsigned kk = k % kTasks;
+    T in[N];
+    T out[N];
+    if constexpr (ROWS) {
+      const unsigned base = (kk % TILE)*P + (kk/TILE)*N;
+#pragma unroll
+      for (int c = 0; c < N; c += 4) {
+        const int4 v = *reinterpret_cast<const int4 *>(ts + base + c);
+        in[c] = T(v.x);
+        in[c + 1] = T(v.y);
+        in[c + 2] = T(v.z);
+        in[c + 3] = T(v.w);
+      }
+      od_idct_lift<LN>(out, in);
+#pragma unroll
+      for (int c = 0; c < N; c += 4) {
+        *reinterpret_cast<int4 *>(ts + base + c) = make_int4(out[c], out[c + 1], out[c + 2], out[c + 3]);
+      }
+    }
+    else {
+      const unsigned base = (kk/TILE)*N*P + kk % TILE;
+#pragma unroll
+      for (int r = 0; r < N; r++) in[r] = T(ts[base + r*P]);
+      od_idct_lift<LN>(out, in);
+#pragma unroll
+      for (int r = 0; r < N; r++) ts[base + r*P] = out[r];
+    }
+  }
+}
+
+/* 4-point post-filter across p[0], p[step], p[2 step], p[3 step] (bounded values, see od_lift.cuh). */
+__device__ __forceinline__ void walk_post4(int *p, int step) {
+  int t0 = p[0];
+  int t1 = p[step];
+  int t2 = p[2*step];
+  int t3 = p[3*step];
+  od_post_filter4_dev24(t0, t1, t2, t3);
+  p[0] = t0;
+  p[step] = t1;
+  p[2*step] = t2;
+  p[3*step] = t3;
+}
+
+/* One half of od_postfilter_split (src/filter.c:1510-1525: rows first, then columns) of every
+   level-LN node of the G tiles. */
+template <int TILE, int G, int NT, int LN, bool ROWS>
+__device__ __forceinline__ void walk_split_pass(int *t, unsigned tid, int xg, int y0, int pic_w, int pic_h) {
+  constexpr int N = 4 << LN;
+  constexpr int P = TILE + 4;
+  constexpr int kTasks = TILE*(TILE/N);
+  for (unsigned k = tid; k < G*kTasks; k += NT) {
+    const unsigned s = k/kTasks;
+    const unsigned kk = k % kTasks;
+    int *ts = t + s*(TILE*P);
+    if constexpr (ROWS) {
+      const unsigned y = kk % TILE;
+      const unsigned bx = kk/TILE;
+      if (((y0 + y)/N + 1)*N <= pic_h) walk_post4(ts + y*P + bx*N + N/2 - 2, 1);
+    }
+    else {
+      const unsigned x = kk % TILE;
+      const unsigned by = kk/TILE;
+      if (((xg + s*TILE + x)/N + 1)*N <= pic_w) walk_post4(ts + (by*N + N/2 - 2)*P + x, P);
+    }
+  }
+}
+
+template <int TILE, int G, int NT, int LEAF, int LN>
+__device__ __forceinline__ void walk_split_levels(int *t, unsigned tid, int xg, int y0, int pic_w, int pic_h) {
+  constexpr int TOP = TILE == 64 ? 4 : 3;
+  if constexpr (LN > LEAF) {
+    walk_split_pass<TILE, G, NT, LN, true>(t, tid, xg, y0, pic_w, pic_h);
+    od_lds_barrier();
+    walk_split_pass<TILE, G, NT, LN, false>(t, tid, xg, y0, pic_w, pic_h);
+    od_lds_barrier();
+  }
+  if constexpr (LN < TOP) walk_split_levels<TILE, G, NT, LEAF, LN + 1>(t, tid, xg, y0, pic_w, pic_h);
+}
+
+/* Band of coding index j (OD_BAND_OFFSETS, src/partition.c:77-91) and its first index, for a block
+   of level LEAF. */
+template <int LEAF>
+__device__ __forceinline__ int walk_band_of(int j, int &off) {
+  int b = 0;
+  off = 1;
+  if constexpr (LEAF >= 1) {
+    if (j >= 16) { b = 1; off = 16; }
+    if (j >= 24) { b = 2; off = 24; }
+    if (j >= 32) { b = 3; off = 32; }
+  }
+  if constexpr (LEAF >= 2) {
+    if (j >= 64) { b = 4; off = 64; }
+    if (j >= 96) { b = 5; off = 96; }
+    if (j >= 128) { b = 6; off = 128; }
+  }
+  if constexpr (LEAF >= 3) {
+    if (j >= 256) { b = 7; off = 256; }
+    if (j >= 384) { b = 8; off = 384; }
+  }
+  return b;
+}
+
+/* Columns 0..TILE-1 of the G tiles <- 0 (the pad columns hold the keep). */
+template <int TILE, int G, int NT>
+__device__ __forceinline__ void walk_zero(int *t, unsigned tid) {
+  constexpr int P = TILE + 4;
+  for (unsigned i = tid; i < G*TILE*(TILE/4); i += NT) {
+    const unsigned s = i/(TILE*(TILE/4));
+    const unsigned j = i % (TILE*(TILE/4));
+    *reinterpret_cast<int4 *>(t + s*(TILE*P) + (j/(TILE/4))*P + (j % (TILE/4))*4) = make_int4(0, 0, 0, 0);
+  }
+}
+
+/* Source 0: dequantised coefficient planes. */
+template <int TILE, int G, int NT>
+__device__ __forceinline__ void walk_load_plane(int *t, const od_coeff *plane, int w, int xg, int y0, unsigned tid) {
+  constexpr int P = TILE + 4;
+  constexpr int Q = TILE/4;
+  static_assert((G*TILE*Q) % NT == 0, "whole trips");
+  constexpr int K = G*TILE*Q/NT;
+  int4 v[K];
+#pragma unroll
+  for (int k = 0; k < K; k++) {
+    const unsigned i = tid + k*NT;
+    const unsigned s = i/(TILE*Q);
+    const unsigned j = i % (TILE*Q);
+    v[k] = *reinterpret_cast<const int4 *>(plane + (long)(y0 + j/Q)*w + xg + s*TILE + (j % Q)*4);
+  }
+#pragma unroll
+  for (int k = 0; k < K; k++) {
+    const unsigned i = tid + k*NT;
+    const unsigned s = i/(TILE*Q);
+    const unsigned j = i % (TILE*Q);
+    *reinterpret_cast<int4 *>(t + s*(TILE*P) + (j/Q)*P + (j % Q)*4) = v[k];
+  }
+}
+
+/* Source 1: the no-reference band stage's choices, dequantised on load (od_pvq_synthesis_partial
+   noref, src/pvq.c:1081-1092; od_coding_order_to_raster, src/partition.c:176-194): one chunk of 16
+   consecutive coding indices of one block per thread and trip, as in k_inverse_sb. */
+template <int TILE, int G, int NT, int LEAF>
+__device__ __forceinline__ void walk_load_pvq(int *t, const InverseArgs &a, int plane, long plane_off, int xg,
+ int y0, unsigned tid) {
+  constexpr int P = TILE + 4;
+  constexpr int sh = LEAF + 2;
+  constexpr int n = 4 << LEAF;
+  constexpr int len = n*n < OD_SCAN_LEN ? n*n : OD_SCAN_LEN;
+  constexpr int lsh = LEAF >= 3 ? 9 : 2*LEAF + 4;           /* log2(len) */
+  static_assert((1 << lsh) == len, "len is a power of two");
+  constexpr int nbw = TILE >> sh;
+  constexpr int cpb = len/16;                                /* chunks per block */
+  constexpr int nch = nbw*nbw*cpb;                           /* chunks per tile */
+  const int bw = a.w >> sh;
+  const int bh = a.h >> sh;
+  if constexpr (len < n*n) {                                 /* 32x32 / 64x64: uncoded positions are zero */
+    walk_zero<TILE, G, NT>(t, tid);
+    od_lds_barrier();
+  }
+  for (unsigned c = tid; c < G*nch; c += NT) {
+    const unsigned s = c/nch;
+    const unsigned cc = c % nch;
+    const unsigned b = cc/cpb;
+    const unsigned j0 = (cc % cpb) << 4;
+    const unsigned lby = b/nbw;
+    const unsigned lbx = b % nbw;
+    const int x0 = xg + s*TILE;
+    const unsigned blk = (unsigned)(((long)plane*bh + (y0 >> sh) + lby)*bw + (x0 >> sh) + lbx);
+    int o0;
+    int o1;
+    const int bnd0 = walk_band_of<LEAF>(j0 ? j0 : 1, o0);
+    const int bnd1 = walk_band_of<LEAF>(j0 + 8, o1);
+    int4 chs[2];
+    int4 yq[2] = {make_int4(0, 0, 0, 0), make_int4(0, 0, 0, 0)};
+    int4 qm4[2];
+    int4 sc4[2];
+#pragma unroll
+    for (int hf = 0; hf < 2; hf++) {
+      qm4[hf] = *reinterpret_cast<const int4 *>(a.qm_inv + j0 + 8*hf);
+      sc4[hf] = *reinterpret_cast<const int4 *>(gInvScanXY + j0 + 8*hf);
+    }
+    int dc = 0;
+    if (j0 == 0) dc = a.coef[plane_off + (long)(y0 + (lby << sh))*a.w + x0 + (lbx << sh)];
+    chs[0] = a.choice[(long)blk*a.nb_bands + bnd0];
+    chs[1] = a.choice[(long)blk*a.nb_bands + bnd1];
+#pragma unroll
+    for (int hf = 0; hf < 2; hf++) {
+      if (chs[hf].y != 0) {
+        yq[hf] = *reinterpret_cast<const int4 *>(a.y
+         + (((unsigned)chs[hf].x*(unsigned)a.nblocks + blk) << lsh) + j0 + 8*hf);
+      }
+    }
+    int *ts = t + s*(TILE*P) + (lby << sh)*P + (lbx << sh);
+#pragma unroll
+    for (int hf = 0; hf < 2; hf++) {
+      const int yd[4] = {yq[hf].x, yq[hf].y, yq[hf].z, yq[hf].w};
+      const int qd[4] = {qm4[hf].x, qm4[hf].y, qm4[hf].z, qm4[hf].w};
+      const int sd[4] = {sc4[hf].x, sc4[hf].y, sc4[hf].z, sc4[hf].w};
+      const int4 ch = chs[hf];
+      const int rnd = (1 << ch.w) >> 1;
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+          /* OD_MULT16_32_Q16: (int16)y * (int32)scale >> 16 == mulhi(y << 16, scale) */
+          const int yhi = u ? (yd[e] & (int)0xffff0000) : yd[e] << 16;
+          const int qmi = u ? qd[e] >> 16 : (int)(short)qd[e];
+          const int xy = u ? (unsigned)sd[e] >> 16 : sd[e] & 0xffff;
+          int v = (__mulhi(yhi, ch.z)*qmi + rnd) >> ch.w;
+          if (ch.y == 0) v = 0;
+          if (hf == 0 && e == 0 && u == 0 && j0 == 0) v = dc;
+          ts[(xy >> 8)*P + (xy & 255)] = v;
+        }
+      }
+    }
+  }
+}
+
+/* Source 2: the with-reference band stage's choices (the per-coefficient part of
+   od_pvq_synthesis_partial, src/pvq.c:1081-1114, with or without reference, skip-copy and skip-zero
+   bands; inverse_load_ref above): eight consecutive coding positions of one block per thread and
+   trip; a chunk never straddles a band. */
+template <int TILE, int G, int NT, int LEAF>
+__device__ __forceinline__ void walk_load_ref(int *t, const InverseArgs &a, int plane, long plane_off, int xg,
+ int y0, unsigned tid) {
+  constexpr int P = TILE + 4;
+  constexpr int sh = LEAF + 2;
+  constexpr int n = 4 << LEAF;
+  constexpr int len = n*n < OD_SCAN_LEN ? n*n : OD_SCAN_LEN;
+  constexpr int nbw = TILE >> sh;
+  constexpr int cpb = len/8;
+  constexpr int nch = nbw*nbw*cpb;
+  const int bw = a.w >> sh;
+  const int bh = a.h >> sh;
+  if constexpr (len < n*n) {
+    /* the positions PVQ never codes are what od_init_skipped_coeffs leaves (src/state.c:1347-1366):
+       zero on a keyframe, the prediction's coefficients otherwise */
+    if (a.inter) walk_load_plane<TILE, G, NT>(t, a.ref + plane_off, a.w, xg, y0, tid);
+    else walk_zero<TILE, G, NT>(t, tid);
+    od_lds_barrier();
+  }
+  const int4 *choice4 = a.choice;
+  for (unsigned c = tid; c < G*nch; c += NT) {
+    const unsigned s = c/nch;
+    const unsigned cc = c % nch;
+    const unsigned b = cc/cpb;
+    const unsigned c0 = (cc % cpb) << 3;
+    const unsigned lby = b/nbw;
+    const unsigned lbx = b % nbw;
+    const int x0 = xg + s*TILE;
+    const long blk = ((long)plane*bh + (y0 >> sh) + lby)*bw + (x0 >> sh) + lbx;
+    int off;
+    const int band = walk_band_of<LEAF>(c0 ? c0 : 1, off);
+    const int4 ca = choice4[(blk*a.nb_bands + band)*4 + 2];   /* mode, slot, scale, qshift */
+    const int mode = ca.x;
+    int *ts = t + s*(TILE*P) + (lby << sh)*P + (lbx << sh);
+    const long gbase = plane_off + (long)(y0 + (lby << sh))*a.w + x0 + (lbx << sh);
+    const uint4 sc4 = *reinterpret_cast<const uint4 *>(gInvScanXY + c0);
+    const unsigned scw[4] = {sc4.x, sc4.y, sc4.z, sc4.w};
+    int py[8];
+    int px_[8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+      const unsigned pk = (scw[e >> 1] >> (16*(e & 1))) & 0xffffu;
+      py[e] = (int)(pk >> 8);
+      px_[e] = (int)(pk & 255);
+    }
+    const bool first = c0 == 0;
+    if (first) ts[0] = a.coef[gbase];       /* the DC sits at (0, 0) */
+    if (mode == 0) {
+#pragma unroll
+      for (int e = 0; e < 8; e++) if (!(first && e == 0)) ts[py[e]*P + px_[e]] = 0;
+      continue;
+    }
+    if (mode == 1 || mode == 4) {
+#pragma unroll
+      for (int e = 0; e < 8; e++) {
+        if (first && e == 0) continue;
+        const od_coeff rv = a.ref[gbase + (long)py[e]*a.w + px_[e]];
+        ts[py[e]*P + px_[e]] = mode == 4 ? -rv : rv;
+      }
+      continue;
+    }
+    const int yslot = ca.y;
+    const int32_t scale = ca.z;
+    const int qshift = ca.w;
+    const int rnd = (1 << qshift) >> 1;
+    const uint4 q4 = *reinterpret_cast<const uint4 *>(a.qm_inv + c0);
+    const unsigned qw[4] = {q4.x, q4.y, q4.z, q4.w};
+    unsigned yw[4] = {0, 0, 0, 0};
+    int yprev = 0;
+    if (yslot >= 0) {
+      const int16_t *yp = a.y + ((long)yslot*a.nblocks + blk)*len + c0;
+      const uint4 y4 = *reinterpret_cast<const uint4 *>(yp);
+      yw[0] = y4.x;
+      yw[1] = y4.y;
+      yw[2] = y4.z;
+      yw[3] = y4.w;
+      if (mode == 3 && c0 > off) yprev = yp[-1];
+    }
+    if (mode == 2) {
+#pragma unroll
+      for (int e = 0; e < 8; e++) {
+        if (first && e == 0) continue;
+        /* OD_MULT16_32_Q16 as mulhi(y << 16, scale); OD_SHR_ROUND in the reference's 32 bits */
+        const int yhi = (e & 1) ? (int)(yw[e >> 1] & 0xffff0000u) : (int)(yw[e >> 1] << 16);
+        const int qmi = (int16_t)(qw[e >> 1] >> (16*(e & 1)));
+        ts[py[e]*P + px_[e]] = (__mulhi(yhi, scale)*qmi + rnd) >> qshift;
+      }
+      continue;
+    }
+    const int4 cb = choice4[(blk*a.nb_bands + band)*4 + 3];   /* xm, m, proj_1, outshift */
+    const int m = cb.y;
+    const uint4 r4 = *reinterpret_cast<const uint4 *>(a.r16 + blk*len + c0);
+    const unsigned rw[4] = {r4.x, r4.y, r4.z, r4.w};
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+      if (first && e == 0) continue;
+      const int i = c0 + e - off;
+      const int yhi = (e & 1) ? (int)(yw[e >> 1] & 0xffff0000u) : (int)(yw[e >> 1] << 16);
+      const int ym1hi = e == 0 ? yprev << 16
+       : ((e - 1) & 1) ? (int)(yw[(e - 1) >> 1] & 0xffff0000u) : (int)(yw[(e - 1) >> 1] << 16);
+      const int qmi = (int16_t)(qw[e >> 1] >> (16*(e & 1)));
+      const int ri = (int16_t)(rw[e >> 1] >> (16*(e & 1)));
+      const int16_t xi = i == m ? (int16_t)cb.x : (int16_t)__mulhi(i < m ? yhi : ym1hi, scale);
+      int32_t tmp = ri*(int)(int16_t)cb.z;                    /* OD_MULT16_16(r[i], proj_1) */
+      tmp = cb.w >= 0 ? (tmp + ((1 << cb.w) >> 1)) >> cb.w : (int32_t)((uint32_t)tmp << -cb.w);
+      const int16_t v = (int16_t)(xi - tmp);
+      ts[py[e]*P + px_[e]] = (v*qmi + rnd) >> qshift;
+    }
+  }
+}
+
+/* The group's pixel rows and horizontal-edge strips, in a window shifted four samples to the
+   left: [xg - 4, xg + G*TILE - 4) - the keep columns first (not for the first group of a segment),
+   the last four columns only when the segment ends with this group - and the keep renewed. */
+template <int TILE, int G, int NT>
+__device__ __forceinline__ void walk_store(int *t, const InverseArgs &a, int plane, int xg, int y0, int sby,
+ bool first, bool last, unsigned tid) {
+  constexpr int P = TILE + 4;
+  constexpr int VG = G*TILE/4;
+  static_assert((TILE*VG) % NT == 0, "whole trips");
+  constexpr int K = TILE*VG/NT;
+  const bool px16 = a.px16 != 0;
+  uint8_t *px = a.px + ((long)plane*a.px_plane_stride << a.px16);
+  const int nh = a.h/TILE - 1;
+  od_coeff *hs = a.hs + (long)plane*nh*4*a.w;
+  auto put = [&](int r, int x, int4 v) {
+    const long at = (long)(y0 + r)*a.px_stride + x;
+    if (px16) {
+      *reinterpret_cast<short4 *>(reinterpret_cast<short *>(px) + at) =
+       make_short4(od_to_px16(v.x), od_to_px16(v.y), od_to_px16(v.z), od_to_px16(v.w));
+    }
+    else {
+      uchar4 o;
+      o.x = od_to_px(v.x);
+      o.y = od_to_px(v.y);
+      o.z = od_to_px(v.z);
+      o.w = od_to_px(v.w);
+      *reinterpret_cast<uchar4 *>(px + at) = o;
+    }
+    /* rows 0, 1 / TILE-2, TILE-1 also feed the post-filter across the horizontal superblock edge
+       above / below (k_edge_cols) */
+    if (r < 2) {
+      if (sby > 0) *reinterpret_cast<int4 *>(hs + ((long)(sby - 1)*4 + r + 2)*a.w + x) = v;
+    }
+    else if (r >= TILE - 2) {
+      if (sby < nh) *reinterpret_cast<int4 *>(hs + ((long)sby*4 + r - (TILE - 2))*a.w + x) = v;
+    }
+  };
+  /* in batches of four 16-byte pieces per lane: every LDS read of a batch in flight before its
+     first store */
+  constexpr int KB = K < 4 ? K : 4;
+  static_assert(K % KB == 0, "whole batches");
+#pragma unroll 1
+  for (int k0 = 0; k0 < K; k0 += KB) {
+    int4 tv[KB];
+#pragma unroll
+    for (int k = 0; k < KB; k++) {
+      const unsigned i = tid + (k0 + k)*NT;
+      const unsigned r = i/VG;
+      const unsigned vg = i % VG;
+      const unsigned c = 4*vg - 4;
+      const int *src = vg == 0 ? t + r*P + TILE : t + (c/TILE)*(TILE*P) + r*P + c % TILE;
+      tv[k] = *reinterpret_cast<const int4 *>(src);
+    }
+#pragma unroll
+    for (int k = 0; k < KB; k++) {
+      const unsigned i = tid + (k0 + k)*NT;
+      const unsigned r = i/VG;
+      if (i % VG == 0) {                      /* this lane read the old keep of row r: renew it */
+        *reinterpret_cast<int4 *>(t + r*P + TILE) =
+         *reinterpret_cast<const int4 *>(t + (G - 1)*(TILE*P) + r*P + TILE - 4);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < KB; k++) {
+      const unsigned i = tid + (k0 + k)*NT;
+      const unsigned r = i/VG;
+      const unsigned vg = i % VG;
+      if (vg == 0 && first) continue;
+      put(r, xg - 4 + 4*vg, tv[k]);
+    }
+  }
+  if (last) {
+    for (unsigned r = tid; r < TILE; r += NT) {
+      put(r, xg + G*TILE - 4, *reinterpret_cast<const int4 *>(t + (G - 1)*(TILE*P) + r*P + TILE - 4));
+    }
+  }
+}
+
+template <int TILE, int G, int NT, int SRC, int LEAF>
+__device__ __forceinline__ void inverse_walk(int *t, const InverseArgs &a, int plane, int seg_len, unsigned tid_in) {
+  unsigned tid = tid_in;
+  constexpr int P = TILE + 4;
+  const int ng = a.w/(TILE*G);
+  const int g0 = blockIdx.x*seg_len;
+  const int g1 = min(g0 + seg_len, ng);
+  const int sby = blockIdx.y;
+  const int y0 = sby*TILE;
+  const long plane_off = (long)plane*a.w*a.h;
+  const int nv = a.w/TILE - 1;
+  od_coeff *vs = a.vs + (long)plane*nv*a.h*4;
+  for (int g = g0; g < g1; g++) {
+    const int xg = g*G*TILE;
+    /* per-lane index arithmetic is redone for every group (as one workgroup per superblock did):
+       hoisted out of this loop it occupies ~50 VGPRs and halves the occupancy */
+    asm volatile("" : "+v"(tid));
+    if constexpr (SRC == 0) walk_load_plane<TILE, G, NT>(t, a.coef + plane_off, a.w, xg, y0, tid);
+    else if constexpr (SRC == 1) walk_load_pvq<TILE, G, NT, LEAF>(t, a, plane, plane_off, xg, y0, tid);
+    else walk_load_ref<TILE, G, NT, LEAF>(t, a, plane, plane_off, xg, y0, tid);
+    od_lds_barrier();
+    walk_idct_pass<TILE, G, NT, LEAF, true>(t, tid);
+    od_lds_barrier();
+    walk_idct_pass<TILE, G, NT, LEAF, false>(t, tid);
+    od_lds_barrier();
+    walk_split_levels<TILE, G, NT, LEAF, 1>(t, tid, xg, y0, a.pic_w, a.pic_h);
+    /* the vertical superblock edges of the group: left of every tile (against the keep for the
+       first tile; a segment's first group hands its columns 0..1 to the strips instead) and, at a
+       segment's end inside the plane, columns TILE-2..TILE-1 of the last tile to the strips */
+    for (unsigned k = tid; k < G*TILE; k += NT) {
+      const unsigned s = k/TILE;
+      const unsigned r = k % TILE;
+      int *row = t + s*(TILE*P) + r*P;
+      if (s == 0 && g == g0) {
+        if (xg > 0) {
+          *reinterpret_cast<int2 *>(vs + ((long)(g*G - 1)*a.h + y0 + r)*4 + 2) = make_int2(row[0], row[1]);
+        }
+        continue;
+      }
+      int *left = s == 0 ? row + TILE + 2 : row - TILE*P + TILE - 2;
+      int t0 = left[0];
+      int t1 = left[1];
+      int t2 = row[0];
+      int t3 = row[1];
+      od_post_filter4_dev24(t0, t1, t2, t3);
+      left[0] = t0;
+      left[1] = t1;
+      row[0] = t2;
+      row[1] = t3;
+    }
+    if (g == g1 - 1 && g1 < ng) {
+      for (unsigned r = tid; r < TILE; r += NT) {
+        const int *row = t + (G - 1)*(TILE*P) + r*P;
+        *reinterpret_cast<int2 *>(vs + ((long)(g1*G - 1)*a.h + y0 + r)*4) = make_int2(row[TILE - 2], row[TILE - 1]);
+      }
+    }
+    od_lds_barrier();
+    walk_store<TILE, G, NT>(t, a, plane, xg, y0, sby, g == g0, g == g1 - 1, tid);
+    od_lds_barrier();
+  }
+}
+
+/* SRC: 0 = coefficient planes, 1 = no-reference band stage (odhip_inverse_levels_pvq), 2 =
+   with-reference band stage (odhip_inverse_levels_pvq_ref).  MINLEAF..MAXLEAF: the leaf levels this
+   instance is launched for (the register budget is that of its largest network). */
+template <int TILE, int G, int NT, int SRC, int MINLEAF, int MAXLEAF>
+__global__ __launch_bounds__(NT, OD_WALK_WAVES) void k_inverse_walk(InverseWalkArgs mm) {
+  constexpr int P = TILE + 4;
+  __shared__ __attribute__((aligned(16))) int t[G*TILE*P];
+  const unsigned tid = threadIdx.x;
+  const int plane = blockIdx.z % mm.nplanes;
+  const InverseArgs &a = mm.a[blockIdx.z / mm.nplanes];
+  switch (a.leaf_bs) {
+    case 0: if constexpr (MINLEAF <= 0 && MAXLEAF >= 0) inverse_walk<TILE, G, NT, SRC, 0>(t, a, plane, mm.seg_len, tid); break;
+    case 1: if constexpr (MINLEAF <= 1 && MAXLEAF >= 1) inverse_walk<TILE, G, NT, SRC, 1>(t, a, plane, mm.seg_len, tid); break;
+    case 2: if constexpr (MINLEAF <= 2 && MAXLEAF >= 2) inverse_walk<TILE, G, NT, SRC, 2>(t, a, plane, mm.seg_len, tid); break;
+    case 3: if constexpr (MINLEAF <= 3 && MAXLEAF >= 3) inverse_walk<TILE, G, NT, SRC, 3>(t, a, plane, mm.seg_len, tid); break;
+    default:
+      if constexpr (TILE == 64 && MAXLEAF >= 4) inverse_walk<TILE, G, NT, SRC, 4>(t, a, plane, mm.seg_len, tid);
+      break;
+  }
+}
+
 struct EdgeArgs {
   od_coeff *vs;
   od_coeff *hs;
@@ -1440,6 +1974,11 @@ struct EdgeArgs {
   int h;
   int tile;
   int px16;
+  /* the vertical edges k_edge_rows finishes: edge0 + i*edge_step, i < nedges (all of them behind
+     k_inverse_sb / k_inverse_part, the joints between segments behind k_inverse_walk) */
+  int edge0;
+  int edge_step;
+  int nedges;
 };
 
 struct EdgeArgsMulti {
@@ -1454,8 +1993,8 @@ __global__ __launch_bounds__(256) void k_edge_rows(EdgeArgsMulti mm) {
   const EdgeArgs &a = mm.a[blockIdx.z / mm.nplanes];
   const int plane = blockIdx.z % mm.nplanes;
   const int y = blockIdx.x*256 + threadIdx.x;
-  if (y >= a.h) return;
-  const int e = blockIdx.y;
+  if (y >= a.h || (int)blockIdx.y >= a.nedges) return;
+  const int e = a.edge0 + blockIdx.y*a.edge_step;
   const int nv = a.w/a.tile - 1;
   const int nh = a.h/a.tile - 1;
   const int4 v = *reinterpret_cast<const int4 *>(a.vs + (((long)plane*nv + e)*a.h + y)*4);
@@ -1626,6 +2165,100 @@ int inverse_launch(const InverseArgs *levels, int nlevels, int nplanes, int dec,
     em.a[l].h = h;
     em.a[l].tile = tile;
   }
+  for (int l = 0; l < nlevels; l++) {
+    em.a[l].edge0 = 0;
+    em.a[l].edge_step = 1;
+    em.a[l].nedges = nv;
+  }
+  /* Walking workgroups (k_inverse_walk) wherever the plane width is a whole number of groups:
+     every level of 4:2:0 chroma (pairs of 32x32 superblocks, one wavefront per pair), the leaf
+     levels up to 16x16 of luma.  The 32x32 / 64x64 leaf levels of luma keep one workgroup per
+     superblock pair (k_inverse_sb_top2): a 64x64 tile per wavefront bounds them at four
+     workgroups per CU, where segments long enough to matter leave a partially filled last round.
+     ODHIP_INVERSE_OLD=1: one workgroup per superblock for everything (the A/B baseline);
+     ODHIP_INVERSE_SEG=n: groups per workgroup. */
+  static const bool old_kernels = getenv("ODHIP_INVERSE_OLD") != nullptr;
+  const int src = ref ? 2 : (levels[0].y ? 1 : 0);
+  bool same_src = true;
+  for (int l = 0; l < nlevels; l++) same_src = same_src && ((levels[l].y != nullptr) == (levels[0].y != nullptr));
+  const int G = dec ? 2 : 1;
+  const int ng = w/(tile*G);
+  const bool walk = !old_kernels && same_src && (w/tile) % G == 0;
+  /* groups per workgroup, chosen so that one launch is ONE round of resident workgroups (walkers
+     are long: a partially filled second round would cost a whole segment's time): luma leaf
+     levels up to 16x16: 3 levels x 16 planes x 17 rows x 2 segments of 15 superblocks = 1632
+     workgroups of 256 threads for 7 x 256 slots; chroma likewise 2 segments of 8 / 7 pairs (3264
+     workgroups of 128 threads), its 32x32 level 5 segments of 3 pairs (2720).
+     ODHIP_INVERSE_SEG="luma,chroma_lo,chroma_hi" overrides. */
+  static int seg_cfg[3] = {15, 8, 3};
+  static const bool seg_parsed = [] {
+    const char *e = getenv("ODHIP_INVERSE_SEG");
+    if (e) (void)sscanf(e, "%d,%d,%d", &seg_cfg[0], &seg_cfg[1], &seg_cfg[2]);
+    for (int i = 0; i < 3; i++) if (seg_cfg[i] < 1) seg_cfg[i] = 1;
+    return true;
+  }();
+  (void)seg_parsed;
+  const int seg_lo = dec ? seg_cfg[1] : seg_cfg[0];
+  const int seg_hi = dec ? seg_cfg[2] : seg_cfg[0];
+  InverseWalkArgs lo;
+  InverseWalkArgs hi;
+  memset(&lo, 0, sizeof(lo));
+  memset(&hi, 0, sizeof(hi));
+  lo.nplanes = hi.nplanes = nplanes;
+  lo.seg_len = seg_lo;
+  hi.seg_len = seg_hi;
+  InverseArgsMulti top;
+  memset(&top, 0, sizeof(top));
+  top.nplanes = nplanes;
+  int nlo = 0;
+  int nhi = 0;
+  int ntop = 0;
+  if (walk) {
+    for (int l = 0; l < nlevels; l++) {
+      const int leaf = im.a[l].leaf_bs;
+      const bool walks = dec || leaf <= 2;
+      if (walks) {
+        (leaf <= 2 ? lo.a[nlo++] : hi.a[nhi++]) = im.a[l];
+        const int seg_len = leaf <= 2 ? seg_lo : seg_hi;
+        em.a[l].edge0 = seg_len*G - 1;
+        em.a[l].edge_step = seg_len*G;
+        em.a[l].nedges = (ng + seg_len - 1)/seg_len - 1;
+      }
+      else top.a[ntop++] = im.a[l];
+    }
+  }
+  if (walk) {
+    const dim3 glo((ng + seg_lo - 1)/seg_lo, h/tile, nplanes*nlo);
+    const dim3 ghi((ng + seg_hi - 1)/seg_hi, h/tile, nplanes*nhi);
+    if (dec) {
+      if (nhi) {
+        if (src == 2) k_inverse_walk<32, 2, 128, 2, 3, 3><<<ghi, 128, 0, s>>>(hi);
+        else if (src == 1) k_inverse_walk<32, 2, 128, 1, 3, 3><<<ghi, 128, 0, s>>>(hi);
+        else k_inverse_walk<32, 2, 128, 0, 3, 3><<<ghi, 128, 0, s>>>(hi);
+      }
+      if (nlo) {
+        if (src == 2) k_inverse_walk<32, 2, 128, 2, 0, 2><<<glo, 128, 0, s>>>(lo);
+        else if (src == 1) k_inverse_walk<32, 2, 128, 1, 0, 2><<<glo, 128, 0, s>>>(lo);
+        else k_inverse_walk<32, 2, 128, 0, 0, 2><<<glo, 128, 0, s>>>(lo);
+      }
+    }
+    else {
+      if (ntop) {
+        bool pulse_fed = src == 1;
+        if (src == 2) k_inverse_sb<64, true><<<dim3(w/tile, h/tile, nplanes*ntop), Geo<64>::kNT, 0, s>>>(top);
+        else if (pulse_fed && (w/tile) % 2 == 0 && !getenv("ODHIP_INVERSE_X1")) {
+          k_inverse_sb_top2<<<dim3(w/(2*tile), h/tile, nplanes*ntop), 256, 0, s>>>(top);
+        }
+        else k_inverse_sb<64, false, 3, 4><<<dim3(w/tile, h/tile, nplanes*ntop), Geo<64>::kNT, 0, s>>>(top);
+      }
+      if (nlo) {
+        if (src == 2) k_inverse_walk<64, 1, 256, 2, 0, 2><<<glo, 256, 0, s>>>(lo);
+        else if (src == 1) k_inverse_walk<64, 1, 256, 1, 0, 2><<<glo, 256, 0, s>>>(lo);
+        else k_inverse_walk<64, 1, 256, 0, 0, 2><<<glo, 256, 0, s>>>(lo);
+      }
+    }
+  }
+  else {
   const dim3 grid(w/tile, h/tile, nplanes*nlevels);
   if (ref) {
     if (dec) k_inverse_sb<32, true><<<grid, Geo<32>::kNT, 0, s>>>(im);
@@ -1656,7 +2289,10 @@ int inverse_launch(const InverseArgs *levels, int nlevels, int nplanes, int dec,
     }
     if (nlo) k_inverse_sb<64, false, 0, 2><<<dim3(w/tile, h/tile, nplanes*nlo), Geo<64>::kNT, 0, s>>>(lo);
   }
-  if (nv > 0) k_edge_rows<<<dim3((h + 255)/256, nv, nplanes*nlevels), 256, 0, s>>>(em);
+  }
+  int max_edges = 0;
+  for (int l = 0; l < nlevels; l++) max_edges = em.a[l].nedges > max_edges ? em.a[l].nedges : max_edges;
+  if (max_edges > 0) k_edge_rows<<<dim3((h + 255)/256, max_edges, nplanes*nlevels), 256, 0, s>>>(em);
   if (nh > 0) k_edge_cols<<<dim3((w + 255)/256, nh, nplanes*nlevels), 256, 0, s>>>(em);
   return odhip_check_launch();
 }
@@ -1750,6 +2386,9 @@ extern "C" int odhip_inverse_partition(uint8_t *d_px, int px_stride, long px_pla
   em.a[0].h = h;
   em.a[0].tile = tile;
   em.a[0].px16 = ctx->fpr != 0;
+  em.a[0].edge0 = 0;
+  em.a[0].edge_step = 1;
+  em.a[0].nedges = nv;
   const dim3 grid(w/tile, h/tile, nplanes);
   if (dec) k_inverse_part<32><<<grid, Geo<32>::kNT, 0, s>>>(pa);
   else k_inverse_part<64><<<grid, Geo<64>::kNT, 0, s>>>(pa);

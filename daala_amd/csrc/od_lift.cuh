@@ -167,3 +167,23 @@ __device__ __forceinline__ void od_post_filter4_dev(int &t0, int &t1, int &t2, i
   t2 = s1 - d21;
   t3 = s0 - d30;
 }
+
+/* od_post_filter4 on values that fit 24 bits (the frame pipeline, see OdMul24): the two lifting
+   multiplies through the 24-bit multiplier - written as plain C they compile to a 64-bit
+   v_mad_u64_u32 each. */
+__device__ __forceinline__ void od_post_filter4_dev24(int &t0, int &t1, int &t2, int &t3) {
+  int d30 = t0 - t3;
+  int d21 = t1 - t2;
+  int s1 = t1 - (d21 >> 1);
+  int s0 = t0 - (d30 >> 1);
+  d21 -= (__mul24(d30, 33) + 32) >> 6;
+  d30 -= (__mul24(d21, -15) + 32) >> 6;
+  d30 = d30*64/75;
+  d21 = d21*64/85;
+  s0 += d30 >> 1;
+  s1 += d21 >> 1;
+  t0 = s0;
+  t1 = s1;
+  t2 = s1 - d21;
+  t3 = s0 - d30;
+}

@@ -1015,6 +1015,42 @@ extern "C" int odhip_pipe_time_pyramid(odhip_pipe *p, int n, double *avg_ms) {
   return rc;
 }
 
+/* One filter + DCT stage (padding, forward pyramid or dequantise + inverse of one plane set)
+   launched n times on an otherwise idle GPU, on the buffers the last step left: average
+   milliseconds per launch group.  parity as for odhip_pipe_stage (-1: the last step's). */
+extern "C" int odhip_pipe_time_stage(odhip_pipe *p, int stage, int parity, int n, double *avg_ms) {
+  if (!p || n <= 0 || !avg_ms || parity < -1 || parity > 1) return ODHIP_EINVAL;
+  if (stage != ODHIP_PIPE_PAD_LUMA && stage != ODHIP_PIPE_PAD_CHROMA && stage != ODHIP_PIPE_PYRAMID_LUMA
+   && stage != ODHIP_PIPE_PYRAMID_CHROMA && stage != ODHIP_PIPE_INVERSE_LUMA && stage != ODHIP_PIPE_INVERSE_CHROMA) {
+    return ODHIP_EINVAL;     /* the other stages are not idempotent on their own buffers */
+  }
+  if (parity < 0) parity = p->nstep > 0 ? (int)((p->nstep - 1) & 1) : 0;
+  int rc = odhip_pipe_flush(p);
+  if (rc) return rc;
+  rc = odhip_pipe_sync(p);
+  if (rc) return rc;
+  const bool rec = p->record;
+  p->record = false;
+  hipStream_t s = p->stream[0];
+  hipEvent_t a = nullptr;
+  hipEvent_t b = nullptr;
+  ODHIP_TRY(hipEventCreate(&a));
+  ODHIP_TRY(hipEventCreate(&b));
+  rc = odhip_pipe_stage(p, stage, parity);
+  (void)hipEventRecord(a, s);
+  for (int i = 0; i < n && !rc; i++) rc = odhip_pipe_stage(p, stage, parity);
+  (void)hipEventRecord(b, s);
+  float ms = 0;
+  if (!rc && (hipEventSynchronize(b) != hipSuccess || hipEventElapsedTime(&ms, a, b) != hipSuccess)) {
+    rc = ODHIP_EFAULT;
+  }
+  (void)hipEventDestroy(a);
+  (void)hipEventDestroy(b);
+  p->record = rec;
+  *avg_ms = ms/n;
+  return rc;
+}
+
 /* Host milliseconds spent so far waiting for the margin counts (the only host waits
    of a step; everything else in odhip_pipe_step is launch work). */
 extern "C" double odhip_pipe_host_wait_ms(const odhip_pipe *p) {

@@ -1136,6 +1136,10 @@ int odhip_pipe_record(odhip_pipe *p, int enable);
 int odhip_pipe_timings(odhip_pipe *p, double avg_ms[ODHIP_PIPE_NSTAGES], int count[ODHIP_PIPE_NSTAGES]);
 int odhip_pipe_search_timings(odhip_pipe *p, int chroma, float *ms, int max_n);
 int odhip_pipe_time_pyramid(odhip_pipe *p, int n, double *avg_ms);
+/* One stage of the filter + DCT path (ODHIP_PIPE_PAD_*, _PYRAMID_*, _INVERSE_*) launched n times on
+   the idle GPU over the buffers the last step left: average milliseconds per launch group (the
+   roofline_* entries of bench.py).  parity as for odhip_pipe_stage, -1 = the last step's. */
+int odhip_pipe_time_stage(odhip_pipe *p, int stage, int parity, int n, double *avg_ms);
 long odhip_pipe_theta_reruns(const odhip_pipe *p);
 long odhip_pipe_price_reruns(const odhip_pipe *p);
 double odhip_pipe_host_wait_ms(const odhip_pipe *p);
