@@ -196,6 +196,26 @@ def algorithmic_bytes(F):
     }
 
 
+FILTER_DCT_STAGES = ("image_copy_pad_luma", "image_copy_pad_chroma", "forward_pyramid_luma",
+                     "forward_pyramid_chroma", "dequant_inverse_luma", "dequant_inverse_chroma")
+
+
+def stage_roofline(name, kernels_note, ab_bytes, ms_alone, in_step, pmc, pmc_keys):
+    """roofline object of one filter + DCT stage against HBM: SURVEY 8(d) bytes / the stage timed alone."""
+    gbs = ab_bytes / (ms_alone * 1e-3) / 1e9
+    out = {"kernel": kernels_note, "stage": name, "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
+           "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
+           "avg_ms_per_launch": round(ms_alone, 4), "launches": 10, "algorithmic_bytes_per_launch": ab_bytes}
+    if in_step is not None:
+        out["in_step"] = {"avg_ms_per_launch": in_step["avg_ms_per_launch"],
+                          "frac": in_step.get("frac_of_hbm_peak")}
+    tr = [pmc[k]["hbm_bytes_per_launch"] for k in pmc if any(k.startswith(q) for q in pmc_keys)
+          and pmc[k].get("hbm_bytes_per_launch")]
+    if tr:
+        out["traffic"] = int(sum(tr))
+    return out
+
+
 def _pin(core):
     try:
         os.sched_setaffinity(0, {core})
@@ -204,28 +224,35 @@ def _pin(core):
         return False
 
 
-def cpu_leg(qt, chroma_cfl, first_pictures, min_frames=5, min_seconds=10.0, max_frames=24, lib=None):
+def cpu_leg(qt, chroma_cfl, first_pictures, min_frames=5, min_seconds=10.0, max_frames=24, lib=None,
+            more_pictures=()):
     """The same per-block work on ONE pinned host core with the reference's own C
     functions (oracle/_ref): whole pictures of the bench generator, one timing per
     picture, until >= min_frames pictures and >= min_seconds of CPU work.  The first
-    picture is the GPU batch's frame 0 (its reconstruction is what `verified` compares).
-    Returns (per-picture rates, blocks per picture, recon of the first picture)."""
+    picture is the GPU batch's frame 0 (its reconstruction is what `verified` compares);
+    `more_pictures` (other frames of the GPU batch) come next and their reconstructions are
+    kept too.  Returns (per-picture rates, blocks per picture, recon of the first picture,
+    seconds, recons of more_pictures)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import _pipeline_check as C
     rates = []
     busy = 0.0
     first = None
+    more = []
     blocks = 0
     n = 0
-    while n < max_frames and (n < min_frames or busy < min_seconds):
-        pics = first_pictures if n == 0 else picture_planes(GENERATOR(1000 + n, 1234))
+    while n < max_frames and (n < min_frames or busy < min_seconds or n <= len(more_pictures)):
+        pics = first_pictures if n == 0 else more_pictures[n - 1] if n <= len(more_pictures) \
+            else picture_planes(GENERATOR(1000 + n, 1234))
         recon, blocks, dt = C.cpu_frame(qt, pics, PIC_W, PIC_H, chroma_cfl=chroma_cfl, lib=lib)
         if n == 0:
             first = recon
+        elif n <= len(more_pictures):
+            more.append(recon)
         rates.append(blocks / dt)
         busy += dt
         n += 1
-    return rates, blocks, first, busy
+    return rates, blocks, first, busy, more
 
 
 def cpu_worker(args):
@@ -236,12 +263,12 @@ def cpu_worker(args):
     _pin(args.cpu_worker)
     qt = D.QuantTables.load()
     first = picture_planes(GENERATOR(2000 + args.cpu_worker, 1234))
-    rates, blocks, _, busy = cpu_leg(qt, not args.chroma_noref, first, min_frames=2, min_seconds=0.0,
-                                     max_frames=2)
+    rates, blocks, _, busy, _ = cpu_leg(qt, not args.chroma_noref, first, min_frames=2, min_seconds=0.0,
+                                        max_frames=2)
     print(json.dumps({"blocks": blocks * len(rates), "seconds": busy}))
 
 
-def cpu_baseline(D, qt, chroma_cfl, args, gpu_frame0, timed_recon=None, timed_dec=None):
+def cpu_baseline(D, qt, chroma_cfl, args, gpu_frame0, timed_recon=None, timed_dec=None, more_frames=()):
     """cpu_baseline (one pinned core, median of >= 5 pictures), the all-cores figure
     (one pinned process per core, independent pictures - all-intra frames are
     independent), and the whole-frame verification of the GPU path against it."""
@@ -253,14 +280,16 @@ def cpu_baseline(D, qt, chroma_cfl, args, gpu_frame0, timed_recon=None, timed_de
         return None, None, {"verified": None, "why": "oracle/_ref/libdaalaref.so absent"}
     prev = os.sched_getaffinity(0) if hasattr(os, "sched_getaffinity") else None
     pinned = _pin(0)
-    rates, blocks, recon0, busy = cpu_leg(qt, chroma_cfl, gpu_frame0)
+    # more_frames: [(index in the batch, pictures)] - further frames of the GPU batch, verified like frame 0
+    rates, blocks, recon0, busy, recon_more = cpu_leg(qt, chroma_cfl, gpu_frame0,
+                                                      more_pictures=[p_ for _, p_ in more_frames])
     # the x86-intrinsics build of the reference (BASELINE.md section 3 asks for both): same
     # pinned core, median of 5 pictures; its reconstruction of frame 0 must equal the C build's
     simd = None
     from _libs import ref_simd
     if ref_simd() is not None and ref_simd().ref_stage_simd() > 0:
-        srates, _, srecon0, sbusy = cpu_leg(qt, chroma_cfl, gpu_frame0, min_frames=5, min_seconds=0.0,
-                                            max_frames=5, lib=ref_simd())
+        srates, _, srecon0, sbusy, _ = cpu_leg(qt, chroma_cfl, gpu_frame0, min_frames=5, min_seconds=0.0,
+                                               max_frames=5, lib=ref_simd())
         same = all(np.array_equal(a, b) for pa, pb in zip(recon0, srecon0) for a, b in zip(pa, pb))
         simd = {"value": float(np.median(srates)), "unit": "blocks/s", "cores": 1, "kind": "reference",
                 "runs": len(srates), "min": float(min(srates)), "max": float(max(srates)),
@@ -318,16 +347,19 @@ def cpu_baseline(D, qt, chroma_cfl, args, gpu_frame0, timed_recon=None, timed_de
     if timed_recon is not None:
         # price = 1: what the TIMED pipeline left in its buffers after the last step
         bad = C.compare_frame(timed_recon, recon0, frame=0, frames=args.frames)
-        what = ("frame 0 of the batch as the timed pipeline reconstructed it in its last step (device-"
-                "priced choice), whole frame: every reconstructed pixel of every partition level of Y, "
-                "Cb, Cr == the reference C functions' (cpu_baseline leg)")
+        for (fi, _), rec in zip(more_frames, recon_more):
+            bad += [(fi,) + b for b in C.compare_frame(timed_recon, rec, frame=fi, frames=args.frames)]
+        what = ("frames %s of the batch as the timed pipeline reconstructed them in its last step (device-"
+                "priced choice), whole frames: every reconstructed pixel of every partition level of Y, "
+                "Cb, Cr == the reference C functions' (cpu_baseline leg)" % ([0] + [fi for fi, _ in more_frames]))
     else:
         gpu = C.gpu_priced_frame(D, qt, gpu_frame0, PIC_W, PIC_H, chroma_cfl=chroma_cfl)
         bad = C.compare_frame(gpu, recon0)
         what = ("frame 0 of the batch, whole frame: every reconstructed pixel of every partition "
                 "level of Y, Cb, Cr from the GPU stages (host-priced choice) == the reference C "
                 "functions' (cpu_baseline leg)")
-    ver = {"verified": not bad, "what": what, "planes_levels_compared": 13, "mismatches": bad}
+    ver = {"verified": not bad, "what": what, "frames_compared": [0] + [fi for fi, _ in more_frames],
+           "planes_levels_compared": 13*(1 + len(more_frames) if timed_recon is not None else 1), "mismatches": bad}
     if timed_dec is not None:
         # north_star's "coefficients and PVQ pulse vectors": the coded gain index, itheta,
         # max_theta, K and the pulse vector of EVERY band of every block of every level of
@@ -336,8 +368,14 @@ def cpu_baseline(D, qt, chroma_cfl, args, gpu_frame0, timed_recon=None, timed_de
         C.cpu_frame(qt, gpu_frame0, PIC_W, PIC_H, chroma_cfl=chroma_cfl, decisions=want)
         dbad = C.compare_decisions(timed_dec, want, frame=0, frames=args.frames)
         nbands = int(sum(b.shape[0] * b.shape[1] for plane in want for (_, b) in plane))
+        for fi, pics in more_frames:
+            want = []
+            C.cpu_frame(qt, pics, PIC_W, PIC_H, chroma_cfl=chroma_cfl, decisions=want)
+            dbad += [(fi,) + b for b in C.compare_decisions(timed_dec, want, frame=fi, frames=args.frames)]
+            nbands += int(sum(b.shape[0] * b.shape[1] for plane in want for (_, b) in plane))
         ver["decisions"] = {"verified": not dbad, "bands_compared": nbands, "mismatches": dbad,
-                            "what": "gain index, itheta, max_theta, K and pulse vector of every band of frame 0 "
+                            "frames_compared": [0] + [fi for fi, _ in more_frames],
+                            "what": "gain index, itheta, max_theta, K and pulse vector of every band of those frames "
                                     "(timed pipeline) == the reference's pvq_theta (ref_stage_set_dump)"}
         ver["verified"] = bool(ver["verified"] and not dbad)
     # the partition the reference encoder really codes for this picture (report
@@ -805,6 +843,9 @@ def main():
     # The filter + DCT kernel on its own (after the timed steps): in the step it shares the
     # GPU with the other stream's kernels, which stretches its duration.
     fd_alone = pipe.time_pyramid(10)
+    # ... and every other stage of the filter + DCT path the same way (odhip_pipe_time_stage: the stage
+    # launched 10 times over the buffers the last step left, HIP events on its stream)
+    stage_alone = {st: pipe.time_stage(st, 10) for st in FILTER_DCT_STAGES}
     copy_gbs = copy_ceiling_gbs(device)
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
@@ -982,6 +1023,31 @@ def main():
         key = [k_ for k_ in pmc if k_.startswith("k_forward_pyramid64x2")]
         if key:
             roof_fd["traffic"] = pmc[key[0]]["hbm_bytes_per_launch"]
+        # the rest of the filter + DCT stage the north star prices (od_postfilter_split + iDCT,
+        # src/filter.c:1485-1527, src/dct.c:4890-4920; chroma; the padding in front)
+        roof_fd_chroma = stage_roofline(
+            "forward_pyramid_chroma", "k_forward_pyramid<32> (4:2:0 chroma, 4 levels)", ab["forward_pyramid_chroma"],
+            stage_alone["forward_pyramid_chroma"], kernels.get("forward_pyramid_chroma"), pmc, ("k_forward_pyramid<32",))
+        roof_inv_luma = stage_roofline(
+            "dequant_inverse_luma", "k_inverse_walk<64,1,256,1,0,2> + k_inverse_sb_top2 + k_edge_rows/cols "
+            "(dequantise on load + iDCT + od_postfilter_split + superblock edges + pixels, 5 levels)",
+            ab["dequant_inverse_luma"], stage_alone["dequant_inverse_luma"], kernels.get("dequant_inverse_luma"),
+            pmc, ("k_inverse_walk<64", "k_inverse_sb_top2", "k_inverse_sb<64", "k_edge_rows_luma", "k_edge_cols_luma"))
+        roof_inv_chroma = stage_roofline(
+            "dequant_inverse_chroma", "k_inverse_walk<32,2,128,...> + k_edge_rows/cols (4 levels, with-reference "
+            "synthesis on load)" if cfl else "k_inverse_walk<32,2,128,1,...> + k_edge_rows/cols (4 levels)",
+            ab["dequant_inverse_chroma"], stage_alone["dequant_inverse_chroma"], kernels.get("dequant_inverse_chroma"),
+            pmc, ("k_inverse_walk<32", "k_inverse_sb<32", "k_edge_rows_chroma", "k_edge_cols_chroma"))
+        st_bytes = sum(ab[st] for st in FILTER_DCT_STAGES)
+        st_ms = sum(stage_alone[st] for st in FILTER_DCT_STAGES)
+        roof_stage = {"stage": "padding + forward pyramids + dequantise / inverse / post-filter / edges, luma and "
+                               "chroma, every level", "bound": "hbm",
+                      "achieved": round(st_bytes / (st_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                      "frac": round(st_bytes / (st_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                      "algorithmic_bytes_per_step": st_bytes, "ms_per_step_alone": round(st_ms, 4),
+                      "ms": {st: round(stage_alone[st], 4) for st in FILTER_DCT_STAGES},
+                      "note": "SURVEY 8(d) bytes of the six stages / the sum of their durations, each timed alone "
+                              "(10 launch groups, HIP events on the stage's stream)"}
         line = {
             "metric": "1080p all-intra transform blocks/s (filter+DCT+PVQ)",
             "value": total_blocks / dt,
@@ -1025,6 +1091,10 @@ def main():
                        "sharding": "frames over ranks, no data-path collective"},
             "roofline": roof,
             "roofline_filter_dct": roof_fd,
+            "roofline_filter_dct_chroma": roof_fd_chroma,
+            "roofline_inverse_luma": roof_inv_luma,
+            "roofline_inverse_chroma": roof_inv_chroma,
+            "roofline_filter_dct_stage": roof_stage,
             "roofline_noref_search": roof_noref if roof is not roof_noref else None,
             "roofline_ref_search": roof_ref if (roof_ref is not None and roof is not roof_ref) else None,
             "pipelined_equals_serial": None if digest is None else digest == serial_digest,
@@ -1039,7 +1109,12 @@ def main():
             line["sharded_encode_check"] = shard_check
         if world == 1 and not args.no_cpu_baseline:
             frame0 = [luma_pic[0], chroma_pic[0], chroma_pic[args.frames]]
-            base, host, ver = cpu_baseline(D, qt, cfl, args, frame0, timed_recon, timed_dec)
+            # the middle and the last frame of the batch are verified like frame 0 (the
+            # other frames were only covered by the pipelined == serial self-comparison)
+            F = args.frames
+            more = [(fi, [luma_pic[fi], chroma_pic[fi], chroma_pic[F + fi]])
+                    for fi in sorted({F // 2 - (1 if F % 2 == 0 and F > 2 else 0), F - 1} - {0})] if price else []
+            base, host, ver = cpu_baseline(D, qt, cfl, args, frame0, timed_recon, timed_dec, more)
             if base is not None:
                 line["cpu_baseline"] = base
                 line["speedup_vs_cpu_baseline"] = line["value"] / base["value"]

@@ -821,6 +821,8 @@ struct InverseArgs {
   const od_coeff *ref;
   int px16;                 /* full-precision references: px holds int16 samples, see PyramidArgs */
   int inter;                /* with-reference source of an inter frame (is_keyframe == 0) */
+  int dbg;                  /* ODHIP_INVERSE_DBG (k_inverse_walk, timing experiments only): 1 = no pixel
+                               stores, 2 = no strip stores, 4 = no source loads (WRONG results) */
 };
 
 /* Several partition levels of one plane set in ONE launch (blockIdx.z = level *
@@ -1016,7 +1018,7 @@ __device__ __forceinline__ void inverse_load_ref(int *t, const InverseArgs &a, i
    the whole plane. */
 template <int TILE>
 __device__ __forceinline__ void inverse_store(const int *t, const InverseArgs &a, int plane, int x0,
- int y0, int tid, int sbx, int sby) {
+ int y0, int tid, int sbx, int sby, int done_edges = 0) {
   constexpr int P = Geo<TILE>::kPitch;
   constexpr int NT = Geo<TILE>::kNT;
   const int w = a.w;
@@ -1058,6 +1060,7 @@ __device__ __forceinline__ void inverse_store(const int *t, const InverseArgs &a
   for (int i = tid; i < 2*TILE; i += NT) {
     const int right = i/TILE;
     const int r = i % TILE;
+    if (done_edges & (right ? 1 : 2)) continue;     /* finished in LDS by the caller */
     if (right ? sbx < nv : sbx > 0) {
       const int e = right ? sbx : sbx - 1;
       const int c = right ? TILE - 2 : 0;
@@ -1414,9 +1417,30 @@ __global__ __launch_bounds__(256) void k_inverse_sb_top2(InverseArgsMulti mm) {
     __syncthreads();
   }
   else {
-    /* 64-point: 64 per tile, waves 0 and 1 */
+    /* 64-point: 64 per tile, waves 0 and 1.  Rows: only rows 0..31 of a 64x64 block hold coded
+       coefficients (the first 512 coding positions lie in its top-left 32x32 corner,
+       src/partition.c:144-194), and the network maps a zero row to a zero row: one wavefront
+       transforms the 32 live rows of both tiles */
     const int g = tid >> 6;
-    if (g < 2) od_tile_rows<TILE, 4, true, T, 64>(t[g], t[g], tid & 63, OdAllBlocks());
+    if (tid < 64) {
+      int *tt = t[tid >> 5];
+      const int base = (tid & 31)*P;
+      T in[64];
+      T out[64];
+#pragma unroll
+      for (int c = 0; c < 64; c += 4) {
+        const int4 v = *reinterpret_cast<const int4 *>(tt + base + c);
+        in[c] = T(v.x);
+        in[c + 1] = T(v.y);
+        in[c + 2] = T(v.z);
+        in[c + 3] = T(v.w);
+      }
+      od_idct_lift<4>(out, in);
+#pragma unroll
+      for (int c = 0; c < 64; c += 4) {
+        *reinterpret_cast<int4 *>(tt + base + c) = make_int4(out[c], out[c + 1], out[c + 2], out[c + 3]);
+      }
+    }
     __syncthreads();
     if (g < 2) od_tile_cols<TILE, 4, true, T, 64>(t[g], t[g], tid & 63, OdAllBlocks());
     __syncthreads();
@@ -1428,7 +1452,25 @@ __global__ __launch_bounds__(256) void k_inverse_sb_top2(InverseArgsMulti mm) {
     for (int s = 0; s < 2; s++) split_filter_cols<TILE, 4, true>(t[s], tid, xb + s*TILE, a.pic_w);
     __syncthreads();
   }
-  for (int s = 0; s < 2; s++) inverse_store<TILE>(t[s], a, plane, xb + s*TILE, y0, tid, 2*blockIdx.x + s, blockIdx.y);
+  /* the vertical superblock edge between the two tiles (od_apply_postfilter_frame_sbs,
+     src/filter.c:1600-1606) is finished here; k_edge_rows takes the odd edges only */
+  if (tid < TILE) {
+    int *l = t[0] + tid*P + TILE - 2;
+    int *r = t[1] + tid*P;
+    int t0 = l[0];
+    int t1 = l[1];
+    int t2 = r[0];
+    int t3 = r[1];
+    od_post_filter4_dev24(t0, t1, t2, t3);
+    l[0] = t0;
+    l[1] = t1;
+    r[0] = t2;
+    r[1] = t3;
+  }
+  __syncthreads();
+  for (int s = 0; s < 2; s++) {
+    inverse_store<TILE>(t[s], a, plane, xb + s*TILE, y0, tid, 2*blockIdx.x + s, blockIdx.y, s == 0 ? 1 : 2);
+  }
 }
 
 /* ---- inverse, workgroups that WALK along a superblock row --------------------------------
@@ -1819,7 +1861,9 @@ __device__ __forceinline__ void walk_store(int *t, const InverseArgs &a, int pla
   od_coeff *hs = a.hs + (long)plane*nh*4*a.w;
   auto put = [&](int r, int x, int4 v) {
     const long at = (long)(y0 + r)*a.px_stride + x;
-    if (px16) {
+    if (a.dbg & 1) {
+    }
+    else if (px16) {
       *reinterpret_cast<short4 *>(reinterpret_cast<short *>(px) + at) =
        make_short4(od_to_px16(v.x), od_to_px16(v.y), od_to_px16(v.z), od_to_px16(v.w));
     }
@@ -1833,7 +1877,9 @@ __device__ __forceinline__ void walk_store(int *t, const InverseArgs &a, int pla
     }
     /* rows 0, 1 / TILE-2, TILE-1 also feed the post-filter across the horizontal superblock edge
        above / below (k_edge_cols) */
-    if (r < 2) {
+    if (a.dbg & 2) {
+    }
+    else if (r < 2) {
       if (sby > 0) *reinterpret_cast<int4 *>(hs + ((long)(sby - 1)*4 + r + 2)*a.w + x) = v;
     }
     else if (r >= TILE - 2) {
@@ -1898,7 +1944,8 @@ __device__ __forceinline__ void inverse_walk(int *t, const InverseArgs &a, int p
     /* per-lane index arithmetic is redone for every group (as one workgroup per superblock did):
        hoisted out of this loop it occupies ~50 VGPRs and halves the occupancy */
     asm volatile("" : "+v"(tid));
-    if constexpr (SRC == 0) walk_load_plane<TILE, G, NT>(t, a.coef + plane_off, a.w, xg, y0, tid);
+    if (a.dbg & 4) walk_zero<TILE, G, NT>(t, tid);
+    else if constexpr (SRC == 0) walk_load_plane<TILE, G, NT>(t, a.coef + plane_off, a.w, xg, y0, tid);
     else if constexpr (SRC == 1) walk_load_pvq<TILE, G, NT, LEAF>(t, a, plane, plane_off, xg, y0, tid);
     else walk_load_ref<TILE, G, NT, LEAF>(t, a, plane, plane_off, xg, y0, tid);
     od_lds_barrier();
@@ -2151,6 +2198,8 @@ int inverse_launch(const InverseArgs *levels, int nlevels, int nplanes, int dec,
   for (int l = 0; l < nlevels; l++) {
     if (levels[l].w != w || levels[l].h != h) return ODHIP_EINVAL;
     im.a[l] = levels[l];
+    static const int dbg = getenv("ODHIP_INVERSE_DBG") ? atoi(getenv("ODHIP_INVERSE_DBG")) : 0;
+    im.a[l].dbg = dbg;
     im.a[l].px16 = ctx->fpr != 0;
     em.a[l].px16 = ctx->fpr != 0;
     if (ctx->fpr && ((uintptr_t)levels[l].px & 7)) return ODHIP_EINVAL;
@@ -2181,16 +2230,17 @@ int inverse_launch(const InverseArgs *levels, int nlevels, int nplanes, int dec,
   const int src = ref ? 2 : (levels[0].y ? 1 : 0);
   bool same_src = true;
   for (int l = 0; l < nlevels; l++) same_src = same_src && ((levels[l].y != nullptr) == (levels[0].y != nullptr));
+  const bool top2_ok = !dec && (w/tile) % 2 == 0 && !getenv("ODHIP_INVERSE_X1");
   const int G = dec ? 2 : 1;
   const int ng = w/(tile*G);
   const bool walk = !old_kernels && same_src && (w/tile) % G == 0;
-  /* groups per workgroup, chosen so that one launch is ONE round of resident workgroups (walkers
-     are long: a partially filled second round would cost a whole segment's time): luma leaf
-     levels up to 16x16: 3 levels x 16 planes x 17 rows x 2 segments of 15 superblocks = 1632
-     workgroups of 256 threads for 7 x 256 slots; chroma likewise 2 segments of 8 / 7 pairs (3264
-     workgroups of 128 threads), its 32x32 level 5 segments of 3 pairs (2720).
+  /* groups per workgroup (measured, profiles/r4_inverse_segments.txt: 16 frames of 1080p): short
+     segments win - many more workgroups than slots keep the phases of co-resident workgroups
+     staggered (walkers that start together load, compute and store together), and a long
+     segment's last, partially filled round costs a whole segment.  Luma 6 superblocks, chroma 3
+     pairs: 25 / 29 and 25 / 29 of the vertical edges never leave LDS.
      ODHIP_INVERSE_SEG="luma,chroma_lo,chroma_hi" overrides. */
-  static int seg_cfg[3] = {15, 8, 3};
+  static int seg_cfg[3] = {6, 3, 3};
   static const bool seg_parsed = [] {
     const char *e = getenv("ODHIP_INVERSE_SEG");
     if (e) (void)sscanf(e, "%d,%d,%d", &seg_cfg[0], &seg_cfg[1], &seg_cfg[2]);
@@ -2224,7 +2274,14 @@ int inverse_launch(const InverseArgs *levels, int nlevels, int nplanes, int dec,
         em.a[l].edge_step = seg_len*G;
         em.a[l].nedges = (ng + seg_len - 1)/seg_len - 1;
       }
-      else top.a[ntop++] = im.a[l];
+      else {
+        top.a[ntop++] = im.a[l];
+        if (top2_ok && src == 1) {       /* k_inverse_sb_top2 finishes the edge inside every pair */
+          em.a[l].edge0 = 1;
+          em.a[l].edge_step = 2;
+          em.a[l].nedges = nv/2;
+        }
+      }
     }
   }
   if (walk) {
@@ -2244,9 +2301,8 @@ int inverse_launch(const InverseArgs *levels, int nlevels, int nplanes, int dec,
     }
     else {
       if (ntop) {
-        bool pulse_fed = src == 1;
         if (src == 2) k_inverse_sb<64, true><<<dim3(w/tile, h/tile, nplanes*ntop), Geo<64>::kNT, 0, s>>>(top);
-        else if (pulse_fed && (w/tile) % 2 == 0 && !getenv("ODHIP_INVERSE_X1")) {
+        else if (src == 1 && top2_ok) {
           k_inverse_sb_top2<<<dim3(w/(2*tile), h/tile, nplanes*ntop), 256, 0, s>>>(top);
         }
         else k_inverse_sb<64, false, 3, 4><<<dim3(w/tile, h/tile, nplanes*ntop), Geo<64>::kNT, 0, s>>>(top);
@@ -2282,8 +2338,15 @@ int inverse_launch(const InverseArgs *levels, int nlevels, int nplanes, int dec,
     if (nhi) {
       bool pulse_fed = true;
       for (int l = 0; l < nhi; l++) pulse_fed = pulse_fed && hi.a[l].y != nullptr;
-      if (pulse_fed && (w/tile) % 2 == 0 && !getenv("ODHIP_INVERSE_X1")) {
+      if (pulse_fed && top2_ok) {
         k_inverse_sb_top2<<<dim3(w/(2*tile), h/tile, nplanes*nhi), 256, 0, s>>>(hi);
+        for (int l = 0; l < nlevels; l++) {
+          if (im.a[l].leaf_bs > 2) {
+            em.a[l].edge0 = 1;
+            em.a[l].edge_step = 2;
+            em.a[l].nedges = nv/2;
+          }
+        }
       }
       else k_inverse_sb<64, false, 3, 4><<<dim3(w/tile, h/tile, nplanes*nhi), Geo<64>::kNT, 0, s>>>(hi);
     }

@@ -52,3 +52,41 @@ except Exception as e:
 PY
   done
 fi
+if [ "${PMC:-0}" = "1" ]; then
+  # VALU / LDS counters of the filter + DCT kernels, new and old inverse kernels (one pass each)
+  for m in new old; do
+    if [ $m = old ]; then export ODHIP_INVERSE_OLD=1; else unset ODHIP_INVERSE_OLD; fi
+    PO=$OUT/pmc_$m; rm -rf $PO; mkdir -p $PO
+    ( cd /tmp && export TMPDIR=/tmp && rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVES --kernel-trace --output-format csv -d $PO -o t -- python $GRAFT_REPO_ROOT/tools/stage_times.py --n 2 > $PO/out.json 2> $PO/err.log )
+    python - $PO $m <<'PY'
+import csv, collections, glob, re, sys
+acc=collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob(sys.argv[1]+'/**/t_counter_collection.csv', recursive=True):
+    for r in csv.DictReader(open(f)):
+        n=r['Kernel_Name'].replace('(anonymous namespace)::','').replace('void ','')
+        n=re.sub(r'\(.*$','',n)
+        if re.search('inverse|edge|pyramid', n):
+            acc[(n, r.get('Grid_Size',''))][r['Counter_Name']].append(float(r['Counter_Value']))
+print('== pmc', sys.argv[2])
+for k,v in sorted(acc.items()):
+    print('  %-50s %-10s' % (k[0][:50], k[1]), ' '.join('%s=%.0f' % (c.replace('SQ_',''), sum(x)/len(x)) for c,x in sorted(v.items())))
+PY
+  done
+  unset ODHIP_INVERSE_OLD
+fi
+if [ "${FULLBENCH:-0}" = "1" ]; then
+  timeout 600 python bench.py > $OUT/bench_full.json 2> $OUT/bench_full.err; echo "bench rc=$?"
+  tail -3 $OUT/bench_full.err
+  python - $OUT/bench_full.json <<'PY'
+import json,sys
+try:
+    d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+    print({k:d.get(k) for k in ("value","ms_per_step","verified","pipelined_equals_serial","speedup_vs_cpu_baseline")})
+    print("verification", {k:d["verification"].get(k) for k in ("frames_compared","planes_levels_compared","mismatches")}, d["verification"].get("decisions",{}).get("bands_compared"), d["verification"].get("decisions",{}).get("mismatches"))
+    for k in ("roofline_filter_dct","roofline_filter_dct_chroma","roofline_inverse_luma","roofline_inverse_chroma","roofline_filter_dct_stage"):
+        print(k, d[k].get("frac"), d[k].get("avg_ms_per_launch", d[k].get("ms_per_step_alone")))
+    print("roofline", d["roofline"]["kernel"][:40], d["roofline"]["frac"], d["roofline"]["avg_ms_per_launch"])
+except Exception as e:
+    print("bench parse failed", repr(e))
+PY
+fi
