@@ -414,10 +414,9 @@ def sharded_encode_check(rank, world, local_rank, dist, torch):
     rank 0 over RCCL (daala_amd.shard.gather_packets) and compared with the plain C encoder
     run sequentially.  A CHECK outside the timed region (the encoder's host half is the
     reference's C, i.e. test infrastructure here), reported separately from `value`."""
-    if not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libdaalaref.so")):
-        return {"ran": False, "why": "oracle/_ref/libdaalaref.so absent"}
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import _shard_encode as S
+    import encode_job as S
+    if not S.reference_available():
+        return {"ran": False, "why": "the reference encoder (oracle/_ref/libdaalaref.so) or shim/libdaalahipglue.so absent"}
     from daala_amd.shard import frames_of_rank, gather_packets
     nframes = world
     err = None
@@ -449,7 +448,7 @@ def sharded_encode_check(rank, world, local_rank, dist, torch):
     if rank != 0:
         return None
     try:
-        want = S.sequential_digest(nframes, PIC_W, PIC_H)
+        want = sequential_digest(nframes)
     except Exception as e:      # noqa: BLE001
         return {"ran": False, "why": "sequential C encoder: %r" % (e,)}
     st = S.band_stats(ipo)
@@ -459,7 +458,7 @@ def sharded_encode_check(rank, world, local_rank, dist, torch):
             "encode_s_max_over_ranks": float(tt[0].item()), "gather_ms": float(tt[1].item()) * 1e3,
             "bands_from_batch_rank0": st[0], "bands_left_to_reference_rank0": st[1] + st[2],
             "note": "one 1920x1080 keyframe per rank, -v 20 -z 7, real reference encoder (host entropy "
-                    "coding / pricing) with the batched pyramid + luma PVQ band stage behind it; gather = "
+                    "coding / pricing) with the batched pyramid + luma PVQ band stage behind it (shim/); gather = "
                     "all_gather of sizes + padded all_gather of bytes over RCCL"}
 
 
@@ -565,8 +564,7 @@ def search_roofline(name, kernel_prefix, ms_excl, ms_in_step, launches, alg_byte
 def write_y4m(path, nframes, w=PIC_W, h=PIC_H):
     """The bench generator's frames 0 .. nframes-1 as a YUV4MPEG2 file (what
     encoder_example is fed, examples/encoder_example.c:89-160)."""
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import _shard_encode as S
+    import encode_job as S
     with open(path, "wb") as f:
         f.write(("YUV4MPEG2 W%d H%d F30:1 Ip A1:1 C420jpeg\n" % (w, h)).encode())
         for i in range(nframes):
@@ -574,48 +572,36 @@ def write_y4m(path, nframes, w=PIC_W, h=PIC_H):
             f.write(S.frame_yuv(i, w, h).tobytes())
 
 
-def read_y4m_owned(D, path, rank, world, limit):
-    """Frames rank, rank + world, ... (< limit) of a Y4M file through the library's reader
-    (odhip_y4m_open / _read / _skip): ({global index: planar 4:2:0 bytes}, w, h)."""
-    L = D.lib()
-    L.odhip_y4m_open.restype = ctypes.c_void_p
-    w, h, fn, fd, err = (ctypes.c_int() for _ in range(5))
-    y = L.odhip_y4m_open(path.encode(), ctypes.byref(w), ctypes.byref(h), ctypes.byref(fn), ctypes.byref(fd),
-                         ctypes.byref(err))
-    if not y:
-        raise SystemExit("cannot read %s as progressive 8-bit 4:2:0 YUV4MPEG2 (code %d)" % (path, err.value))
-    w, h = w.value, h.value
-    cw, chh = (w + 1) >> 1, (h + 1) >> 1
-    out = {}
-    i = 0
-    while i < limit:
-        if i % world == rank:
-            fr = np.empty(w * h + 2 * cw * chh, np.uint8)
-            rc = L.odhip_y4m_read(ctypes.c_void_p(y), fr[:w * h].ctypes.data_as(ctypes.c_void_p),
-                                  fr[w * h:w * h + cw * chh].ctypes.data_as(ctypes.c_void_p),
-                                  fr[w * h + cw * chh:].ctypes.data_as(ctypes.c_void_p))
-            if rc == 1:
-                out[i] = fr
-        else:
-            rc = L.odhip_y4m_skip(ctypes.c_void_p(y))
-        if rc == 0:
-            break
-        if rc < 0:
-            raise SystemExit("%s: loss of framing at frame %d (code %d)" % (path, i, rc))
-        i += 1
-    L.odhip_y4m_close(ctypes.c_void_p(y))
-    return out, w, h, i
+def sequential_digest(nframes):
+    """Packet digest of the plain C reference encoder run sequentially on the first frames of the
+    bench generator (a child process: this one has the shim bound)."""
+    import subprocess
+    path = "/tmp/odhip_seq_%d_%d.y4m" % (os.getpid(), nframes)
+    write_y4m(path, nframes)
+    e = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    try:
+        pr = subprocess.run([sys.executable, os.path.abspath(__file__), "--seq-encode", path, str(nframes)],
+                            capture_output=True, text=True, timeout=3600, env=e)
+    finally:
+        try:
+            os.remove(path)
+        except OSError:
+            pass
+    if pr.returncode != 0:
+        raise RuntimeError(pr.stderr[-500:])
+    return json.loads(pr.stdout.strip().splitlines()[-1])["digest"]
 
 
 def seq_encode_worker(args):
     """Child process of encode_mode: the plain C reference encoder (nothing bound) on the
     first N frames of the Y4M file, sequentially; prints the packet digest."""
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import _shard_encode as S
+    import encode_job as S
     import daala_amd as D
     path, n = args.seq_encode[0], int(args.seq_encode[1])
-    frames, w, h, got = read_y4m_owned(D, path, 0, 1, n)
-    r = ctypes.CDLL(os.path.join(ROOT, "oracle", "_ref", "libdaalaref.so"))
+    frames, w, h, got = S.read_y4m_frames(D, path, 0, 1, n)
+    r = ctypes.CDLL(S.REFERENCE_LIB)
     t0 = time.perf_counter()
     packets = S.encode_frames(r, list(range(got)), [frames[i] for i in range(got)], w, h)
     dt = time.perf_counter() - t0
@@ -624,21 +610,25 @@ def seq_encode_worker(args):
 
 
 def encode_mode(args, D, torch, dist, rank, world, local_rank):
-    """BASELINE configs[4]: an N-frame 1080p all-intra encode, frames sharded over the ranks
-    (frame i -> rank i mod world; all-intra frames are independent, src/encode.c:303-308,
-    :3029, :3080), every rank the reference encoder (its own host C: entropy coding, pricing,
-    block-size RDO - test infrastructure here, oracle/_ref) with the batched GPU stage bound
-    behind it (one batched pyramid per plane, the PVQ band stage of keyframe luma, the deringing
-    level search), input through the library's Y4M reader, coded packets gathered to rank 0
-    (all_gather of sizes + padded all_gather of bytes over RCCL).  Rank 0 checks a prefix
-    against the plain C encoder run sequentially and prints one JSON line: frames per second
-    of the whole job.  No 1 -> 8 curve exists until a multi-GPU box runs this."""
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import _shard_encode as S
+    """BASELINE configs[4]: an N-frame 1080p all-intra encode, frames sharded over the ranks and,
+    inside a rank, over P encoder processes that share the rank's GPU (frame i -> encoder
+    i mod (world * P); all-intra frames are independent, src/encode.c:303-308, :3029, :3080).
+    Every encoder process is the reference encoder (its own host C: entropy coding, pricing,
+    block-size RDO - the build of the reference's sources under oracle/_ref) with the batched GPU
+    stage bound behind it through the shim (shim/libdaalahipglue.so, explicit configuration: one
+    batched pyramid per plane, the PVQ band stage of keyframe luma, the deringing level search),
+    input through the library's Y4M reader, coded packets gathered to rank 0 (all_gather of sizes
+    + padded all_gather of bytes over RCCL).  Rank 0 checks a prefix against the plain C encoder
+    run sequentially and prints one JSON line: frames per second of the whole job.  No 1 -> 8
+    GPU curve exists until a multi-GPU box runs this."""
+    import subprocess
+    import encode_job as S
     from daala_amd.shard import gather_packets
-    if not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libdaalaref.so")):
-        raise SystemExit("--encode-frames needs the reference encoder (oracle/_ref, built by build())")
+    if not S.reference_available():
+        raise SystemExit("--encode-frames needs the reference encoder (oracle/_ref) and shim/libdaalahipglue.so, "
+                         "both built by build()")
     nframes = args.encode_frames
+    P = max(1, args.procs_per_gpu)
     path = args.y4m
     made = False
     if path is None:
@@ -648,45 +638,68 @@ def encode_mode(args, D, torch, dist, rank, world, local_rank):
         made = True
     if dist is not None:
         dist.barrier()
+    ncores = os.cpu_count() or 1
+    cores = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else list(range(ncores))
+    # P encoder processes of this rank: encoder e = rank * P + p takes frames e, e + world * P, ...
     t0 = time.perf_counter()
-    frames, w, h, total = read_y4m_owned(D, path, rank, world, nframes)
-    t_read = time.perf_counter() - t0
-    nframes = min(nframes, total)
-    owned = sorted(frames)
-    # the deringing level search from batched passes as well (odhip_dering_cache)
-    os.environ["ODHIP_INTERPOSE_DERING_CACHE"] = "1"
-    r, ipo = S.load_batched_encoder(w, h, device=local_rank)
-    # one frame first (allocations, first-use tables), outside the timed region
-    if owned:
-        S.encode_frames(r, owned[:1], [frames[owned[0]]], w, h)
+    outs = ["/tmp/odhip_job_%d_%d_%d.npz" % (os.getpid(), rank, p) for p in range(P)]
+    procs = []
+    for p in range(P):
+        e_idx = rank * P + p
+        cmd = [sys.executable, os.path.join(ROOT, "encode_job.py"), "--worker", "--y4m", path, "--frames", str(nframes),
+               "--stride", str(world * P), "--offset", str(e_idx), "--device", str(local_rank),
+               "--core", str(cores[e_idx % len(cores)]), "--out", outs[p]]
+        env = dict(os.environ)
+        for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+            env.pop(k, None)
+        procs.append(subprocess.Popen(cmd, stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                                      text=True, env=env))
+    for pr in procs:                      # every encoder has read its frames and coded one (untimed)
+        line = pr.stdout.readline()
+        if line.strip() != "READY":
+            raise SystemExit("encoder process failed to start: %s %s" % (line, pr.stderr.read()[-800:]))
+    t_start = time.perf_counter() - t0
     if dist is not None:
         dist.barrier()
-    torch.cuda.synchronize()
     t0 = time.perf_counter()
-    local = S.encode_frames(r, owned, [frames[i] for i in owned], w, h)
-    torch.cuda.synchronize()
+    for pr in procs:
+        pr.stdin.write("go\n")
+        pr.stdin.flush()
+    stats = []
+    for pr in procs:
+        out, err = pr.communicate()
+        if pr.returncode != 0:
+            raise SystemExit("encoder process failed: %s" % err[-800:])
+        stats.append(json.loads(out.strip().splitlines()[-1]))
     t_enc = time.perf_counter() - t0
     if dist is not None:
         dist.barrier()
     t_all = time.perf_counter() - t0
+    local = {}
+    for o in outs:
+        z = np.load(o)
+        pos = 0
+        for i, n in zip(z["indices"].tolist(), z["sizes"].tolist()):
+            local[int(i)] = bytes(z["bytes"][pos:pos + n])
+            pos += n
+        os.remove(o)
+    nframes = min(nframes, stats[0]["frames_in_file"])
+    w, h = stats[0]["w"], stats[0]["h"]
     t1 = time.perf_counter()
     packets = gather_packets(local, nframes) if dist is not None else [local[i] for i in range(nframes)]
     torch.cuda.synchronize()
     t_gather = time.perf_counter() - t1
-    tt = torch.tensor([t_all, t_enc, t_gather, t_read], dtype=torch.float64,
+    tt = torch.tensor([t_all, t_enc, t_gather, t_start], dtype=torch.float64,
                       device="cuda" if dist is not None and dist.get_backend() == "nccl" else "cpu")
     if dist is not None:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     if rank != 0:
         return 0
-    st = S.band_stats(ipo)
-    load_ms = ctypes.c_double.in_dll(ipo, "odhip_interposed_load_ms").value
     nprefix = min(nframes, args.encode_check)
     check = None
     if nprefix > 0:
-        import subprocess
         e = dict(os.environ)
-        for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "ODHIP_INTERPOSE_PASSTHROUGH"):
+        for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
             e.pop(k, None)
         pr = subprocess.run([sys.executable, os.path.abspath(__file__), "--seq-encode", path, str(nprefix)],
                             capture_output=True, text=True, timeout=3600, env=e)
@@ -698,27 +711,37 @@ def encode_mode(args, D, torch, dist, rank, world, local_rank):
         else:
             check = {"error": pr.stderr[-500:]}
     t_job = float(tt[0].item())
+    nf0 = sum(st["frames"] for st in stats)
+    batch_ms = sum(st["batch_ms"] for st in stats)
     line = {
         "metric": "1080p all-intra encode frames/s (frame-sharded over the GPUs of one node)",
         "value": nframes / t_job, "unit": "frames/s", "n_gpus": world, "frames": nframes,
+        "encoder_processes_per_gpu": P, "host_cores_available": len(cores),
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "data": "synthetic",
         "dtype": "int32 (lifting DCT/filters) + f64 (PVQ search)",
         "config": {"workload": "configs[4]: %d-frame %dx%d all-intra encode (-v 20, complexity 7), frame i -> "
-                               "rank i mod %d, Y4M in (odhip_y4m_*), packets gathered to rank 0" % (nframes, w, h, world),
+                               "encoder i mod %d (%d GPU(s) x %d encoder processes sharing each GPU), Y4M in "
+                               "(odhip_y4m_*), packets gathered to rank 0" % (nframes, w, h, world * P, world, P),
                    "encoder": "the reference's own encoder (host C: entropy coding, od_pvq_rate on the live "
-                              "adaptive state, block-size RDO) with the batched GPU stage bound behind it: "
-                              "pyramids of all planes, the PVQ band stage of keyframe luma, the deringing "
-                              "level search (tests/interpose; INTEGRATION.md section 7)"},
+                              "adaptive state, block-size RDO) with the batched GPU stage bound behind it "
+                              "through shim/libdaalahipglue.so: pyramids of all planes, the PVQ band stage of "
+                              "keyframe luma with batched speed-0 pricing, the deringing level search "
+                              "(INTEGRATION.md section 7)"},
         "seconds": {"job_max_over_ranks": t_job, "encode_max_over_ranks": float(tt[1].item()),
-                    "gather": float(tt[2].item()), "y4m_read_max_over_ranks": float(tt[3].item())},
+                    "gather": float(tt[2].item()), "start_up_untimed_max_over_ranks": float(tt[3].item())},
         "packet_bytes": int(sum(len(p) for p in packets)),
-        "rank0": {"frames": len(owned), "bands_from_batch": st[0], "bands_left_to_reference": st[1] + st[2],
-                  "searches_saved": st[3], "batched_gpu_pass_ms_per_frame": load_ms / max(1, len(owned) + 1),
-                  "stage_blocks_per_s": blocks_per_frame() * (len(owned) + 1) / max(load_ms * 1e-3, 1e-9)},
+        "rank0": {"frames": nf0, "bands_from_batch": sum(st["bands_from_batch"] for st in stats),
+                  "bands_left_to_reference": sum(st["bands_left_to_reference"] for st in stats),
+                  "searches_saved": sum(st["searches_saved"] for st in stats),
+                  "batched_gpu_pass_ms_per_frame": batch_ms / max(1, nf0),
+                  "encoder_seconds_per_process": [round(st["seconds"], 2) for st in stats],
+                  "stage_blocks_per_s": blocks_per_frame() * nf0 / max(batch_ms * 1e-3, 1e-9)},
         "prefix_check": check,
-        "note": "frames/s of the whole job (barrier to barrier, max over ranks); the host half of every rank is "
-                "the reference's sequential entropy coder, which bounds a rank at ~1 frame/s - the GPU stage "
-                "takes %.0f ms of each frame (rank0.batched_gpu_pass_ms_per_frame)" % (load_ms / max(1, len(owned) + 1)),
+        "note": "frames/s of the whole job (barrier to barrier, max over ranks); every encoder process is bound "
+                "by the reference's sequential entropy coder at ~1 frame/s, so a GPU serves several of them: the "
+                "batched GPU passes take %.0f ms of each frame (rank0.batched_gpu_pass_ms_per_frame); the job "
+                "scales with host cores until the GPU passes of P processes saturate the device"
+                % (batch_ms / max(1, nf0)),
     }
     print(json.dumps(line))
     if made:
@@ -752,6 +775,9 @@ def main():
                          "the reference encoder; prints frames/s of the whole job")
     ap.add_argument("--y4m", default=None, help="--encode-frames: a YUV4MPEG2 file to encode (default: the "
                                                 "bench generator's frames, written to /tmp)")
+    ap.add_argument("--procs-per-gpu", type=int, default=1,
+                    help="--encode-frames: encoder processes per GPU (they share the rank's device; the host "
+                         "chain of one encoder is sequential, ~1 frame/s, while its GPU passes take ~10 ms)")
     ap.add_argument("--encode-check", type=int, default=2,
                     help="--encode-frames: how many leading frames rank 0 re-encodes with the plain C encoder "
                          "(sequentially, one core) to compare the gathered packets with")
@@ -789,7 +815,9 @@ def main():
     torch.cuda.set_device(local_rank)
     D.init(local_rank)
     dist = None
-    if world > 1:
+    # ODHIP_BENCH_FORCE_DIST=1: a process group even for ONE rank, so that the RCCL branch of the
+    # gather (device tensors, backend "nccl") executes on a one-GPU box (tests/test_gpu_bench_multi.py)
+    if world > 1 or os.environ.get("ODHIP_BENCH_FORCE_DIST") == "1":
         import torch.distributed as dist
         if backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))

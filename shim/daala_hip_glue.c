@@ -1,0 +1,547 @@
+/* shim/daala_hip_glue.c - the reference-side binding of libdaalahip (see daala_hip_glue.h and
+   README.md in this directory).
+
+   Defines the reference's own symbol names for the surfaces of the block-transform path and
+   forwards them to libdaalahip; which surfaces are bound is what the host configured with
+   odhip_glue_configure().  Placed in front of libdaala in symbol search order (LD_PRELOAD, link
+   order, or RTLD_GLOBAL before a dlopen of the reference), the dynamic linker binds every call
+   inside the UNMODIFIED encoder / decoder to these definitions (src/encode.c:1489,1760,1789,
+   2571,2675,2787,2826; src/pvq_encoder.c:542,589; src/state.c:346) - the link-time form of the
+   glue INTEGRATION.md sections 1-3 and 7 spell out line by line; the shape of the backend
+   installation is od_state_opt_vtbl_init_x86's (src/x86/x86state.c:39-97).
+
+   Plain C, no HIP: everything device-side is behind include/daala_hip.h.  There is no CPU
+   fallback in here: a bound surface whose GPU call fails aborts. */
+#define _GNU_SOURCE
+#include <dlfcn.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdio.h>
+#include <time.h>
+#include "../include/daala_hip.h"
+#include "daala_hip_glue.h"
+
+/* ---- configuration ------------------------------------------------------------------- */
+static odhip_glue_config g_cfg;
+static int g_cfg_set;
+
+void odhip_glue_default_config(odhip_glue_config *cfg) {
+  memset(cfg, 0, sizeof(*cfg));
+  cfg->bind_filters = cfg->bind_search = cfg->bind_dering = cfg->bind_dct_vtbl = 1;
+}
+
+/* A host that embeds the glue in a library of its own (tests/interpose does) may define this
+   to supply the configuration in force until odhip_glue_configure() is called. */
+__attribute__((weak)) void odhip_glue_startup_config(odhip_glue_config *cfg);
+
+static odhip_glue_config *cfg(void) {
+  if (!g_cfg_set) {
+    odhip_glue_default_config(&g_cfg);
+    if (odhip_glue_startup_config) odhip_glue_startup_config(&g_cfg);
+    g_cfg_set = 1;
+  }
+  return &g_cfg;
+}
+
+int odhip_glue_configure(const odhip_glue_config *c) {
+  if (!c) return ODHIP_EINVAL;
+  g_cfg = *c;
+  g_cfg_set = 1;
+  if (c->frame_cache || c->band_cache) odhip_glue_enable_frame_cache(c->pic_w, c->pic_h);
+  return odhip_init(c->device);
+}
+
+void odhip_glue_get_config(odhip_glue_config *c) {
+  *c = *cfg();
+}
+
+/* dlopen handle of the reference library (dlsym(RTLD_NEXT) does not see
+   libraries outside a dlopen'ed object's own dependency scope). */
+static void *g_reference;
+void odhip_glue_set_reference(void *handle) {
+  g_reference = handle;
+}
+static void *next_sym(const char *name) {
+  /* dlopen'ed reference (python harness): its handle; a binary linked against
+     the reference with this library in LD_PRELOAD (encoder_example): the next
+     definition in load order. */
+  void *p = g_reference ? dlsym(g_reference, name) : dlsym(RTLD_NEXT, name);
+  if (!p) {
+    fprintf(stderr, "daala_hip_glue: no next definition of %s (%s)\n", name, dlerror());
+    abort();
+  }
+  return p;
+}
+#define NEXT(type, name) ((type)next_sym(name))
+
+/* Counters (odhip_glue_get_stats): proof that the calls really went through. */
+long odhip_glue_calls[6];
+
+/* od_state_opt_vtbl_init (src/state.c:346-352): the reference's backend
+   dispatch.  With bind_dct_vtbl this is the load-time form of the one
+   line of glue in INTEGRATION.md section 1: the reference's own initialisation
+   runs first, then libdaalahip's ten 2-D transforms are written into
+   opt_vtbl.fdct_2d / idct_2d - the shape of od_state_opt_vtbl_init_x86
+   (src/x86/x86state.c:39-97).  The slot offsets inside od_state are known to
+   ref_state_set_dct_vtbl (oracle/ref_encoder_driver.c, compiled with the
+   reference's headers), not to this file. */
+void od_state_opt_vtbl_init(void *state) {
+  typedef void (*init_fn)(void *);
+  typedef void (*set_fn)(void *, void **, void **);
+  static init_fn next;
+  if (!next) next = NEXT(init_fn, "od_state_opt_vtbl_init");
+  next(state);
+  if (cfg()->bind_dct_vtbl) {
+    odhip_dct_func_2d fd[5];
+    odhip_dct_func_2d id[5];
+    set_fn set;
+    if (odhip_init(cfg()->device) != 0) {
+      fprintf(stderr, "daala_hip_glue: odhip_init failed\n");
+      abort();
+    }
+    odhip_install_dct_vtbl(fd, id);
+    set = g_reference ? (set_fn)dlsym(g_reference, "ref_state_set_dct_vtbl")
+     : (set_fn)dlsym(RTLD_DEFAULT, "ref_state_set_dct_vtbl");
+    if (!set) {
+      fprintf(stderr, "daala_hip_glue: ref_state_set_dct_vtbl not found\n");
+      abort();
+    }
+    set(state, (void **)fd, (void **)id);
+  }
+}
+
+void od_prefilter_split(od_coeff *c0, int stride, int bs, int f, int hfilter, int vfilter) {
+  odhip_glue_calls[0]++;
+  if (!cfg()->bind_filters) {
+    typedef void (*fn)(od_coeff *, int, int, int, int, int);
+    static fn next;
+    if (!next) next = NEXT(fn, "od_prefilter_split");
+    next(c0, stride, bs, f, hfilter, vfilter);
+    return;
+  }
+  od_prefilter_split_hip(c0, stride, bs, f, hfilter, vfilter);
+}
+
+void od_postfilter_split(od_coeff *c0, int stride, int bs, int f, int q, unsigned char *skip,
+ int skip_stride, int hfilter, int vfilter) {
+  odhip_glue_calls[1]++;
+  if (!cfg()->bind_filters) {
+    typedef void (*fn)(od_coeff *, int, int, int, int, unsigned char *, int, int, int);
+    static fn next;
+    if (!next) next = NEXT(fn, "od_postfilter_split");
+    next(c0, stride, bs, f, q, skip, skip_stride, hfilter, vfilter);
+    return;
+  }
+  od_postfilter_split_hip(c0, stride, bs, f, q, skip, skip_stride, hfilter, vfilter);
+}
+
+static void glue_load_plane(const od_coeff *c, int stride, int nhsb, int nvsb, int xdec);
+
+void od_apply_prefilter_frame_sbs(od_coeff *c, int stride, int nhsb, int nvsb, int xdec,
+ int ydec) {
+  odhip_glue_calls[2]++;
+  glue_load_plane(c, stride, nhsb, nvsb, xdec);
+  if (!cfg()->bind_filters) {
+    typedef void (*fn)(od_coeff *, int, int, int, int, int);
+    static fn next;
+    if (!next) next = NEXT(fn, "od_apply_prefilter_frame_sbs");
+    next(c, stride, nhsb, nvsb, xdec, ydec);
+    return;
+  }
+  od_apply_prefilter_frame_sbs_hip(c, stride, nhsb, nvsb, xdec, ydec);
+}
+
+/* A host that embeds the glue may take over od_apply_postfilter_frame_sbs for a plane (returns
+   nonzero when it did): tests/interpose checks the decoder's reconstruction there. */
+typedef void (*odhip_glue_postfilter_fn)(od_coeff *, int, int, int, int, int, int, unsigned char *, int);
+__attribute__((weak)) int odhip_glue_hook_postfilter_frame(od_coeff *c, int stride, int nhsb, int nvsb, int xdec,
+ int ydec, int q, unsigned char *skip, int skip_stride, odhip_glue_postfilter_fn reference);
+
+/* ---- the deringing level search from batched passes (odhip_dering_cache) ------------
+   dering_cache: every od_dering call of the encoder's level search
+   (src/encode.c:2787,:2826) is served by odhip_dering_cache_call; the frame boundary is
+   the superblock-edge postfilter the encoder runs just before the search (:2670-2677) -
+   in a reference build that is one line at :2697. */
+static odhip_dering_cache *g_dering_cache;
+static int dering_cache_enabled(void) {
+  return cfg()->dering_cache;
+}
+
+void odhip_glue_enable_dering_cache(void) {
+  cfg()->dering_cache = 1;
+}
+
+void od_apply_postfilter_frame_sbs(od_coeff *c, int stride, int nhsb, int nvsb, int xdec,
+ int ydec, int q, unsigned char *skip, int skip_stride) {
+  odhip_glue_calls[3]++;
+  if (dering_cache_enabled() && g_dering_cache) odhip_dering_cache_begin(g_dering_cache);
+  if (odhip_glue_hook_postfilter_frame) {
+    static odhip_glue_postfilter_fn next;
+    if (!next) next = NEXT(odhip_glue_postfilter_fn, "od_apply_postfilter_frame_sbs");
+    if (odhip_glue_hook_postfilter_frame(c, stride, nhsb, nvsb, xdec, ydec, q, skip, skip_stride, next)) return;
+  }
+  if (!cfg()->bind_filters) {
+    typedef void (*fn)(od_coeff *, int, int, int, int, int, int, unsigned char *, int);
+    static fn next;
+    if (!next) next = NEXT(fn, "od_apply_postfilter_frame_sbs");
+    next(c, stride, nhsb, nvsb, xdec, ydec, q, skip, skip_stride);
+    return;
+  }
+  od_apply_postfilter_frame_sbs_hip(c, stride, nhsb, nvsb, xdec, ydec, q, skip, skip_stride);
+}
+
+double pvq_search_rdo_double(const int16_t *xcoeff, int n, int k, od_coeff *ypulse, double g2,
+ double pvq_norm_lambda, int prev_k) {
+  odhip_glue_calls[4]++;
+  if (!cfg()->bind_search) {
+    typedef double (*fn)(const int16_t *, int, int, od_coeff *, double, double, int);
+    static fn next;
+    if (!next) next = NEXT(fn, "pvq_search_rdo_double");
+    return next(xcoeff, n, k, ypulse, g2, pvq_norm_lambda, prev_k);
+  }
+  return od_pvq_search_rdo_double_hip(xcoeff, n, k, ypulse, g2, pvq_norm_lambda, prev_k);
+}
+
+/* ---- the frame cache ----------------------------------------------------------
+   When enabled (odhip_glue_enable_frame_cache), the interposed
+   od_apply_prefilter_frame_sbs - the moment the reference has just filled a
+   plane with (p - 128) << 4, src/encode.c:2568-2571 - first hands the plane to
+   odhip_cache_load_plane (one batched GPU pyramid), then laps it as before.
+   With odhip_install_cached_dct_vtbl bound into od_state.opt_vtbl, every later
+   fdct_2d call on that plane is served from the cache. */
+static odhip_frame_cache *g_cache;
+static const od_coeff *g_bases[4];
+static int g_nbases;
+#define g_bands_on (cfg()->band_cache)   /* the batched band stage behind pvq_theta */
+static void *g_enc;         /* the encoder whose frame is being coded */
+static int g_bands_frame;   /* the current frame's luma bands are loaded */
+long odhip_glue_theta[4];   /* served from the batch / left to the reference (r0 not null) /
+                               left to the reference (other reason) / searches the batch saved */
+
+void odhip_glue_enable_frame_cache(int pic_w, int pic_h) {
+  if (!g_cache) g_cache = odhip_cache_create();
+  odhip_cache_set_picture(g_cache, pic_w, pic_h);
+  odhip_cache_make_current(g_cache);
+  cfg()->frame_cache = 1;
+  cfg()->pic_w = pic_w;
+  cfg()->pic_h = pic_h;
+}
+
+/* The transforms to put into od_state.opt_vtbl when the frame cache is on: fdct_2d served from
+   the batched pyramid, idct_2d the per-call HIP ones (src/state.h:128-129).  A host that keeps
+   the reference's C idct_2d passes NULL for idct. */
+void odhip_glue_cached_dct_vtbl(odhip_dct_func_2d fdct[5], odhip_dct_func_2d idct[5]) {
+  odhip_install_cached_dct_vtbl(fdct, idct);
+}
+
+double odhip_glue_batch_ms;   /* wall time spent in the batched GPU pass (incl. PCIe both ways) */
+static void glue_load_plane_timed(const od_coeff *c, int stride, int nhsb, int nvsb, int xdec);
+static void glue_load_plane(const od_coeff *c, int stride, int nhsb, int nvsb, int xdec) {
+  struct timespec a;
+  struct timespec b;
+  clock_gettime(CLOCK_MONOTONIC, &a);
+  glue_load_plane_timed(c, stride, nhsb, nvsb, xdec);
+  clock_gettime(CLOCK_MONOTONIC, &b);
+  odhip_glue_batch_ms += (b.tv_sec - a.tv_sec)*1e3 + (b.tv_nsec - a.tv_nsec)*1e-6;
+}
+
+static void glue_load_plane_timed(const od_coeff *c, int stride, int nhsb, int nvsb, int xdec) {
+  int slot;
+  if (!g_cache) return;
+  for (slot = 0; slot < g_nbases; slot++) if (g_bases[slot] == c) break;
+  if (slot == g_nbases) {
+    if (g_nbases == 4) return;
+    g_bases[g_nbases++] = c;
+  }
+  odhip_cache_load_plane(g_cache, slot, c, stride, nhsb << 6 >> xdec, nvsb << 6 >> xdec, xdec);
+  if (g_bands_on && slot == 0 && xdec == 0) {
+    /* keyframe luma: the PVQ band stage of every block of every level, now, in one
+       batch, with the quantiser set-up this encoder uses for this frame */
+    typedef int (*setup_fn)(const void *, int *, int *, double *, unsigned char *, int16_t *, int16_t *);
+    static odhip_quant qt;
+    setup_fn setup;
+    double lambda;
+    g_bands_frame = 0;
+    setup = (setup_fn)(g_reference ? dlsym(g_reference, "ref_enc_band_setup")
+     : dlsym(RTLD_DEFAULT, "ref_enc_band_setup"));
+    if (!setup || !g_enc) {
+      fprintf(stderr, "daala_hip_glue: no encoder to take the quantiser set-up from\n");
+      abort();
+    }
+    if (setup(g_enc, &qt.quantizer, &qt.use_masking, &lambda, &qt.pvq_qm_q4[0][0], qt.qm, qt.qm_inv)) {
+      if (odhip_cache_load_bands(g_cache, 0, &qt, lambda) != 0) {
+        fprintf(stderr, "daala_hip_glue: odhip_cache_load_bands failed\n");
+        abort();
+      }
+      g_bands_frame = 1;
+    }
+  }
+}
+
+void odhip_glue_enable_band_cache(void) {
+  cfg()->band_cache = 1;
+}
+
+void odhip_glue_get_stats(odhip_glue_stats *st) {
+  int i;
+  memset(st, 0, sizeof(*st));
+  for (i = 0; i < 6; i++) st->calls[i] = odhip_glue_calls[i];
+  for (i = 0; i < 4; i++) st->theta[i] = odhip_glue_theta[i];
+  if (g_cache) {
+    odhip_cache_stats(g_cache, &st->fdct_hits, &st->fdct_misses);
+    odhip_cache_band_stats(g_cache, &st->band_hits, &st->band_misses);
+  }
+  if (g_dering_cache) odhip_dering_cache_stats(g_dering_cache, &st->dering_launches, &st->dering_served);
+  st->batch_ms = odhip_glue_batch_ms;
+}
+
+/* daala_encode_img_in (include/daala/daalaenc.h:118): remembers which encoder the
+   following plane loads and block encodes belong to. */
+int daala_encode_img_in(void *enc, void *img, int duration) {
+  typedef int (*fn)(void *, void *, int);
+  static fn next;
+  if (!next) next = NEXT(fn, "daala_encode_img_in");
+  g_enc = enc;
+  g_bands_frame = 0;
+  return next(enc, img, duration);
+}
+
+/* daala_encode_free (include/daala/daalaenc.h): the planes of this encoder are gone - the
+   next encoder's planes take the cache slots from the start (a second encoder in one
+   process used to find the four slots taken by the first one's buffers). */
+void daala_encode_free(void *enc) {
+  typedef void (*fn)(void *);
+  static fn next;
+  if (!next) next = NEXT(fn, "daala_encode_free");
+  if (enc == g_enc) g_enc = NULL;
+  g_nbases = 0;
+  g_bands_frame = 0;
+  next(enc);
+}
+
+/* od_pvq_encode (src/pvq_encoder.h:46-49, the boundary symbol of BASELINE.json): the
+   reference's own definition runs; this wrapper only notes WHICH block its pvq_theta
+   calls belong to (bx, by in 4x4 units as src/encode.c:1264-1265 passes them). */
+static __thread int t_pli, t_bs, t_bx, t_by, t_band;
+int od_pvq_encode(void *enc, od_coeff *ref, const od_coeff *in, od_coeff *out, int q0, int pli, int bs,
+ const int16_t *beta, int nodesync, int is_keyframe, int q_scaling, int bx, int by, const int16_t *qm,
+ const int16_t *qm_inv, int speed) {
+  typedef int (*fn)(void *, od_coeff *, const od_coeff *, od_coeff *, int, int, int, const int16_t *, int,
+   int, int, int, int, const int16_t *, const int16_t *, int);
+  static fn next;
+  if (!next) next = NEXT(fn, "od_pvq_encode");
+  t_pli = pli;
+  t_bs = bs;
+  t_bx = bx;
+  t_by = by;
+  t_band = 0;
+  return next(enc, ref, in, out, q0, pli, bs, beta, nodesync, is_keyframe, q_scaling, bx, by, qm, qm_inv,
+   speed);
+}
+
+/* pvq_theta (src/pvq_encoder.c:333-641; file-static in the reference, an ordinary
+   symbol of the test build).  This is the glue INTEGRATION.md section 7 puts at the
+   top of that function: a keyframe luma band whose reference vector is null takes
+   the no-reference path only (:452 fails, :571-609 runs), and every quantity of that
+   path that does not depend on the entropy coder's adaptive state was computed for
+   the whole frame in one batch (odhip_cache_load_bands).  What is left is what the
+   reference keeps on the host: price the candidates with od_pvq_rate on the LIVE
+   state, apply `cost <= best_cost`, the skip rule, and synthesise the winner with the
+   reference's own od_gain_expand / od_pvq_synthesis_partial.  Every other band goes
+   to the reference's pvq_theta untouched. */
+int pvq_theta(od_coeff *out, const od_coeff *x0, const od_coeff *r0, int n, int q0, od_coeff *y,
+ int *itheta, int *max_theta, int *vk, int16_t beta, double *skip_diff, int nodesync, int is_keyframe,
+ int pli, const void *adapt, const int16_t *qm, const int16_t *qm_inv, double pvq_norm_lambda,
+ int speed) {
+  typedef int (*fn)(od_coeff *, const od_coeff *, const od_coeff *, int, int, od_coeff *, int *, int *,
+   int *, int16_t, double *, int, int, int, const void *, const int16_t *, const int16_t *, double, int);
+  typedef double (*rate_fn)(int, int, int, int, const void *, const od_coeff *, int, int, int, int, int);
+  typedef int32_t (*expand_fn)(int32_t, int, int16_t);
+  typedef void (*synth_fn)(od_coeff *, const od_coeff *, const int16_t *, int, int, int32_t, int32_t,
+   int, int, const int16_t *);
+  static fn next;
+  static rate_fn rate;
+  static expand_fn gain_expand;
+  static synth_fn synthesis;
+  odhip_band_cands c;
+  const int band = t_band++;
+  int i;
+  if (!next) next = NEXT(fn, "pvq_theta");
+  if (g_bands_on && g_bands_frame && is_keyframe && pli == 0 && t_pli == 0 && n <= 128) {
+    int null_ref = 1;
+    for (i = 0; i < n; i++) {
+      if (r0[i]) {
+        null_ref = 0;
+        break;
+      }
+    }
+    if (!null_ref) odhip_glue_theta[1]++;
+    else if (!odhip_cache_band(g_cache, 0, t_bs, t_bx >> t_bs, t_by >> t_bs, band, x0, &c)
+     || c.n != n || c.q != q0 || c.beta != beta || c.flags[0] == 2 || c.flags[1] == 2) {
+      odhip_glue_theta[2]++;
+    }
+    else {
+      od_coeff y_tmp[128];
+      double best_cost;
+      double best_dist;
+      double skip_dist;
+      int qg;
+      int best_k;
+      int s;
+      if (!rate) {
+        rate = NEXT(rate_fn, "od_pvq_rate");
+        gain_expand = NEXT(expand_fn, "od_gain_expand");
+        synthesis = NEXT(synth_fn, "od_pvq_synthesis_partial");
+      }
+      odhip_glue_theta[0]++;
+      /* :415-421 with a null reference on a keyframe: the null candidate */
+      qg = 0;
+      best_dist = c.dist0;
+      best_cost = c.dist0 + pvq_norm_lambda*rate(0, 0, -1, 0, adapt, NULL, 0, n, is_keyframe, pli, speed);
+      best_k = 0;
+      *itheta = -1;
+      *max_theta = 0;
+      for (i = 0; i < n; i++) y[i] = 0;
+      skip_dist = c.dist0;        /* :439: the same expression as :417 on a keyframe */
+      /* :578-609: the (at most two) no-reference candidates, in gain order.  At the default
+         complexity (speed == 0) od_pvq_rate runs the codeword coder on a copy of the live
+         context per candidate: both candidates are priced in one call of the library's
+         batched routine instead (odhip_pvq_rate_batch16: rate-only range coder,
+         copy-on-touch CDF rows, the same doubles - tests/test_rate_host.py) */
+      {
+        double rates[2];
+        rates[0] = rates[1] = 0;
+        if (speed == 0) {
+          const int16_t *ys[2];
+          int ks[2];
+          int qgs[2];
+          int thetas[2];
+          int tss[2];
+          int nc;
+          int map[2];
+          nc = 0;
+          for (s = 0; s < 2; s++) {
+            if (c.flags[s] != 1) continue;
+            ys[nc] = c.y[s];
+            ks[nc] = c.k[s];
+            qgs[nc] = c.gain[s];
+            thetas[nc] = -1;
+            tss[nc] = 0;
+            map[nc++] = s;
+          }
+          if (nc) {
+            double out[2];
+            /* &adapt->pvq.pvq_codeword_ctx is at offset 0 of od_adapt_ctx (src/state.h:141-143) */
+            if (odhip_pvq_rate_batch16(out, (const odhip_pvq_codeword_ctx *)adapt, nc, ys, ks, qgs, thetas, tss, n, 0,
+             is_keyframe, pli) != 0) {
+              fprintf(stderr, "daala_hip_glue: odhip_pvq_rate_batch16 failed\n");
+              abort();
+            }
+            for (i = 0; i < nc; i++) rates[map[i]] = out[i];
+          }
+        }
+        for (s = 0; s < 2; s++) {
+          double cost;
+          if (c.flags[s] != 1) continue;
+          odhip_glue_theta[3]++;
+          for (i = 0; i < n; i++) y_tmp[i] = c.y[s][i];
+          if (speed != 0) {
+            rates[s] = rate(c.gain[s], 0, -1, 0, adapt, y_tmp, c.k[s], n, is_keyframe, pli, speed);
+          }
+          else if (cfg()->check_rates) {
+            /* every batched price against the reference's own od_pvq_rate */
+            const double want = rate(c.gain[s], 0, -1, 0, adapt, y_tmp, c.k[s], n, is_keyframe, pli, speed);
+            if (memcmp(&want, &rates[s], sizeof(want)) != 0) {
+              fprintf(stderr, "daala_hip_glue: batched rate %.17g != od_pvq_rate %.17g\n", rates[s], want);
+              abort();
+            }
+          }
+          cost = c.dist[s] + pvq_norm_lambda*rates[s];
+          if (cost <= best_cost) {
+            best_cost = cost;
+            best_dist = c.dist[s];
+            qg = c.gain[s];
+            best_k = c.k[s];
+            for (i = 0; i < n; i++) y[i] = y_tmp[i];
+          }
+        }
+      }
+      /* :611-633: skip rule and the decoder's synthesis */
+      if (qg == 0) for (i = 0; i < n; i++) out[i] = 0;
+      else {
+        int16_t r16[128];
+        for (i = 0; i < n; i++) r16[i] = 0;
+        synthesis(out, y, r16, n, 1, gain_expand(qg << 8, q0, beta), 0, 0, 1, qm_inv);
+      }
+      *vk = best_k;
+      *skip_diff += skip_dist - best_dist;
+      return qg;
+    }
+  }
+  return next(out, x0, r0, n, q0, y, itheta, max_theta, vk, beta, skip_diff, nodesync, is_keyframe, pli,
+   adapt, qm, qm_inv, pvq_norm_lambda, speed);
+}
+
+/* od_dering, src/dering.c:252 (call sites src/encode.c:2787,2826): the function
+   table argument is dropped, the HIP kernel implements what it would dispatch to. */
+void od_dering(const void *vtbl, int16_t *y, int ystride, const int16_t *x, int xstride, int nhb, int nvb,
+ int sbx, int sby, int nhsb, int nvsb, int xdec, int dir[8][8], int pli, unsigned char *bskip,
+ int skip_stride, int threshold, int overlap, int coeff_shift) {
+  odhip_glue_calls[5]++;
+  if (dering_cache_enabled()) {
+    if (!g_dering_cache) {
+      if (odhip_init(cfg()->device) != 0 || !(g_dering_cache = odhip_dering_cache_create())) {
+        fprintf(stderr, "daala_hip_glue: odhip_dering_cache_create failed\n");
+        abort();
+      }
+    }
+    if (odhip_dering_cache_call(g_dering_cache, y, ystride, x, xstride, nhb, nvb, sbx, sby, nhsb, nvsb, xdec,
+     dir, pli, bskip, skip_stride, threshold, overlap, coeff_shift) != 0) {
+      fprintf(stderr, "daala_hip_glue: odhip_dering_cache_call failed (no CPU fallback)\n");
+      abort();
+    }
+    if (cfg()->check_dering) {
+      /* every served superblock against the reference's own od_dering */
+      typedef void (*fn)(const void *, int16_t *, int, const int16_t *, int, int, int, int, int, int, int, int,
+       int (*)[8], int, unsigned char *, int, int, int, int);
+      static fn next;
+      int16_t want[64*64];
+      int wdir[8][8];
+      const int n = 64 >> xdec;
+      int i;
+      int j;
+      if (!next) next = NEXT(fn, "od_dering");
+      for (i = 0; i < 8; i++) for (j = 0; j < 8; j++) wdir[i][j] = dir[i][j];
+      next(vtbl, want, n, x, xstride, nhb, nvb, sbx, sby, nhsb, nvsb, xdec, wdir, pli, bskip, skip_stride,
+       threshold, overlap, coeff_shift);
+      for (i = 0; i < n; i++) {
+        for (j = 0; j < n; j++) {
+          if (want[i*n + j] != y[i*ystride + j]) {
+            fprintf(stderr, "daala_hip_glue: dering cache mismatch pli %d sb (%d, %d) thr %d at (%d, %d)\n", pli, sbx,
+             sby, threshold, i, j);
+            abort();
+          }
+        }
+      }
+      for (i = 0; i < 8; i++) for (j = 0; j < 8; j++) {
+        if (wdir[i][j] != dir[i][j]) {
+          fprintf(stderr, "daala_hip_glue: dering cache direction mismatch\n");
+          abort();
+        }
+      }
+    }
+    return;
+  }
+  if (!cfg()->bind_dering) {
+    typedef void (*fn)(const void *, int16_t *, int, const int16_t *, int, int, int, int, int, int, int, int,
+     int (*)[8], int, unsigned char *, int, int, int, int);
+    static fn next;
+    if (!next) next = NEXT(fn, "od_dering");
+    next(vtbl, y, ystride, x, xstride, nhb, nvb, sbx, sby, nhsb, nvsb, xdec, dir, pli, bskip, skip_stride,
+     threshold, overlap, coeff_shift);
+    return;
+  }
+  od_dering_hip(y, ystride, x, xstride, nhb, nvb, sbx, sby, nhsb, nvsb, xdec, dir, pli, bskip, skip_stride,
+   threshold, overlap, coeff_shift);
+}
