@@ -11,7 +11,7 @@ if [ "${SKIP_TESTS:-0}" != "1" ]; then
 timeout 1500 python -m pytest tests/test_gpu_dropin_encoder.py tests/test_gpu_shard_encode.py tests/test_gpu_bench_multi.py tests/test_gpu_decode_check.py tests/test_encoder_example.py -m gpu -x -q > $OUT/pytest.log 2>&1; echo "pytest rc=$?" | tee -a $OUT/pytest.log
 tail -15 $OUT/pytest.log
 fi
-N=${NFRAMES:-300}
+N=${JOB_FRAMES:-300}
 if [ "${PS:-}" != "" ]; then
   t0=$(date +%s)
   python -c "import bench; bench.write_y4m('/tmp/job.y4m', $N)"; echo "y4m written in $(( $(date +%s) - t0 )) s"
