@@ -43,7 +43,7 @@ class GlueConfig(ctypes.Structure):
     """odhip_glue_config, shim/daala_hip_glue.h."""
     _fields_ = [(n, ctypes.c_int) for n in (
         "device", "bind_filters", "bind_search", "bind_dering", "bind_dct_vtbl", "frame_cache", "band_cache",
-        "dering_cache", "pic_w", "pic_h", "check_rates", "check_dering")]
+        "dering_cache", "pic_w", "pic_h", "check_rates", "check_dering", "gpu_pass_lock")]
 
 
 class GlueStats(ctypes.Structure):
@@ -57,7 +57,7 @@ def reference_available():
     return os.path.exists(REFERENCE_LIB) and os.path.exists(GLUE_LIB)
 
 
-def load_batched_encoder(w, h, device=0, dering_cache=True, check_rates=False):
+def load_batched_encoder(w, h, device=0, dering_cache=True, check_rates=False, gpu_pass_lock=False):
     """(reference encoder library, glue library) with the batched GPU stage bound; once per
     process, and only in a process that has not loaded the reference library before."""
     if "r" in _state:
@@ -80,6 +80,7 @@ def load_batched_encoder(w, h, device=0, dering_cache=True, check_rates=False):
     cfg.dering_cache = int(bool(dering_cache))
     cfg.pic_w, cfg.pic_h = int(w), int(h)
     cfg.check_rates = int(bool(check_rates))
+    cfg.gpu_pass_lock = int(bool(gpu_pass_lock))
     rc = glue.odhip_glue_configure(ctypes.byref(cfg))
     if rc != 0:
         raise RuntimeError("odhip_glue_configure failed with code %d (no CPU fallback exists)" % rc)
@@ -192,7 +193,7 @@ def worker(args):
     import daala_amd as D
     frames, w, h, total = read_y4m_frames(D, args.y4m, args.offset, args.stride, args.frames)
     owned = sorted(frames)
-    r, glue = load_batched_encoder(w, h, device=args.device)
+    r, glue = load_batched_encoder(w, h, device=args.device, gpu_pass_lock=args.gpu_lock)
     if owned:
         encode_frames(r, owned[:1], [frames[owned[0]]], w, h)      # allocations, first-use tables
     st0 = glue_stats(glue)
@@ -224,6 +225,7 @@ def main():
     ap.add_argument("--device", type=int, default=0)
     ap.add_argument("--core", type=int, default=-1)
     ap.add_argument("--out")
+    ap.add_argument("--gpu-lock", type=int, default=0)
     args = ap.parse_args()
     if not args.worker:
         ap.error("encode_job.py is a module; as a program it only runs as --worker (see bench.py --encode-frames)")

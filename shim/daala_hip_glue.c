@@ -236,14 +236,37 @@ void odhip_glue_cached_dct_vtbl(odhip_dct_func_2d fdct[5], odhip_dct_func_2d idc
 }
 
 double odhip_glue_batch_ms;   /* wall time spent in the batched GPU pass (incl. PCIe both ways) */
-static void glue_load_plane_timed(const od_coeff *c, int stride, int nhsb, int nvsb, int xdec);
+static void glue_load_plane_locked(const od_coeff *c, int stride, int nhsb, int nvsb, int xdec);
 static void glue_load_plane(const od_coeff *c, int stride, int nhsb, int nvsb, int xdec) {
   struct timespec a;
   struct timespec b;
   clock_gettime(CLOCK_MONOTONIC, &a);
-  glue_load_plane_timed(c, stride, nhsb, nvsb, xdec);
+  glue_load_plane_locked(c, stride, nhsb, nvsb, xdec);
   clock_gettime(CLOCK_MONOTONIC, &b);
   odhip_glue_batch_ms += (b.tv_sec - a.tv_sec)*1e3 + (b.tv_nsec - a.tv_nsec)*1e-6;
+}
+
+/* Advisory lock around the batched GPU pass (odhip_glue_config.gpu_pass_lock). */
+#include <fcntl.h>
+#include <sys/file.h>
+#include <unistd.h>
+static int g_lock_fd = -1;
+static void gpu_pass_lock(int on) {
+  if (!cfg()->gpu_pass_lock) return;
+  if (g_lock_fd < 0) {
+    char path[64];
+    snprintf(path, sizeof(path), "/tmp/odhip_glue_gpu%d.lock", cfg()->device);
+    g_lock_fd = open(path, O_CREAT | O_RDWR, 0666);
+    if (g_lock_fd < 0) return;
+  }
+  (void)flock(g_lock_fd, on ? LOCK_EX : LOCK_UN);
+}
+
+static void glue_load_plane_timed(const od_coeff *c, int stride, int nhsb, int nvsb, int xdec);
+static void glue_load_plane_locked(const od_coeff *c, int stride, int nhsb, int nvsb, int xdec) {
+  gpu_pass_lock(1);
+  glue_load_plane_timed(c, stride, nhsb, nvsb, xdec);
+  gpu_pass_lock(0);
 }
 
 static void glue_load_plane_timed(const od_coeff *c, int stride, int nhsb, int nvsb, int xdec) {

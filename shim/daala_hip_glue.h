@@ -36,6 +36,12 @@ typedef struct odhip_glue_config {
      difference): for bring-up in a new host. */
   int check_rates;       /* every batched od_pvq_rate against od_pvq_rate */
   int check_dering;      /* every served od_dering superblock against od_dering */
+  /* Several encoder processes sharing one GPU (bench.py --procs-per-gpu): 1 = the batched GPU
+     pass of a frame (pyramids + band stage, ~5-10 ms alone) is taken under an advisory lock on
+     /tmp/odhip_glue_gpu<device>.lock, one process at a time.  Without it the passes of more than
+     ~16 processes time-slice against each other (profiles/r4_encode_mode_300frames.json: 12 ms
+     per frame with 8 processes, 216 ms with 32). */
+  int gpu_pass_lock;
 } odhip_glue_config;
 
 /* All per-call surfaces bound, no batched binding, no checks, device 0. */
