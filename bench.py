@@ -778,9 +778,10 @@ def main():
     ap.add_argument("--procs-per-gpu", type=int, default=1,
                     help="--encode-frames: encoder processes per GPU (they share the rank's device; the host "
                          "chain of one encoder is sequential, ~1 frame/s, while its GPU passes take ~10 ms)")
-    ap.add_argument("--gpu-lock", type=int, default=1,
+    ap.add_argument("--gpu-lock", type=int, default=0,
                     help="--encode-frames: the batched GPU pass of a frame under a cross-process lock "
-                         "(odhip_glue_config.gpu_pass_lock); 0 = off")
+                         "(odhip_glue_config.gpu_pass_lock); measured slower than letting the passes "
+                         "overlap (profiles/r4_encode_mode_300frames.json), default off")
     ap.add_argument("--encode-check", type=int, default=2,
                     help="--encode-frames: how many leading frames rank 0 re-encodes with the plain C encoder "
                          "(sequentially, one core) to compare the gathered packets with")
