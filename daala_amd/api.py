@@ -180,10 +180,15 @@ def forward_pyramid(px, dec, pic_w, pic_h, levels=None, want=None):
         n = nplanes * h * w
         stride = ((n + 1023) & ~1023) + (68 << 10)          # int32 elements; +272 KiB
         ks = [bs for bs in range(top + 1) if (want is None or bs in want)]
-        big = torch.empty((max(len(ks), 1) * stride,), dtype=torch.int32, device=px.device)
         levels = [None] * (top + 1)
-        for i, bs in enumerate(ks):
-            levels[bs] = big[i * stride: i * stride + n].view(nplanes, h, w)
+        if len(ks) == 1:
+            # a single level: its own allocation (a view of a shared block would pin the whole
+            # block for as long as the caller keeps that one level)
+            levels[ks[0]] = torch.empty((nplanes, h, w), dtype=torch.int32, device=px.device)
+        else:
+            big = torch.empty((max(len(ks), 1) * stride,), dtype=torch.int32, device=px.device)
+            for i, bs in enumerate(ks):
+                levels[bs] = big[i * stride: i * stride + n].view(nplanes, h, w)
     arr = (ctypes.c_void_p * 5)()
     for bs in range(5):
         t = levels[bs] if bs <= top else None
@@ -814,6 +819,10 @@ def pvq_ref_set_context(ctx):
     """Selects which of the two library contexts the following pvq_ref_* calls of this
     thread use (one call sequence may be in flight per context)."""
     _check(lib().odhip_pvq_ref_set_context(int(ctx)), "odhip_pvq_ref_set_context")
+    # the test hooks are per context: a test that set a margin / perturbation / tolerance scale and
+    # then switches context would silently run without them (ADVICE r3)
+    if any(_hooks[k] != v for k, v in (("margin", 0.0), ("perturb", 0), ("tol", 1.0))):
+        _apply_hooks()
 
 
 def pvq_ref_choose_multi(jobs, pvq_norm_lambda):
@@ -917,6 +926,8 @@ class Context:
         lib().odhip_get_current.restype = ctypes.c_void_p
         self._prev.append(lib().odhip_get_current())
         _check(lib().odhip_make_current(ctypes.c_void_p(self.handle)), "odhip_make_current")
+        if any(_hooks[k] != v for k, v in (("margin", 0.0), ("perturb", 0), ("tol", 1.0))):
+            _apply_hooks()      # per-context test hooks follow the selection
         return self
 
     def __exit__(self, *exc):

@@ -24,6 +24,7 @@
    choice is made on distortion alone.
 
    Host code only; the kernels are the batched entry points of daala_hip.h. */
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <chrono>
@@ -209,6 +210,14 @@ int setup_job(odhip_pipe *p, odhip_pvq_job &j, PlaneSet &s, int bs, const odhip_
     j.plane_split = s.plane_split;
   }
   const long B = s.nblocks[bs];
+  /* The two parities of the luma job set share ONE band-record buffer while the chroma chain of
+     step i runs beside the luma chain of step i + 1.  That is race-free only because (a) the
+     records are written by close-call bands alone and luma_choose resolves them on the host
+     BEFORE the next step is enqueued, (b) lref_piece and the inverse read the choice and pulse
+     buffers (which ARE per parity), never the records, (c) the unpriced choice kernel runs on the
+     luma stream itself.  A new consumer of luma band records on the side stream (e.g. a deferred
+     resolve, or a host dump through odhip_pipe_buffer(BUF_BAND) while a step is in flight) must
+     give parity 1 its own buffer here. */
   if (share) j.cands.band = share->cands.band;       /* the other parity's set: own pulses and choices */
   else PIPE_ALLOC(p, j.cands.band, sizeof(odhip_pvq_band)*(size_t)B*nb, true);
   PIPE_ALLOC(p, j.cands.y, sizeof(int16_t)*(size_t)2*B*len, true);
@@ -278,8 +287,21 @@ int pipe_init(odhip_pipe *p) {
        one chain (measured: 5.72 -> 5.58 ms per step; ODHIP_PIPE_FORK=3 restores the forks).
        The single chain of the chroma-without-reference mode keeps them (3.56 vs 3.45 ms). */
     const bool two_chains = c.chroma_cfl || c.inter;
-    /* ODHIP_PIPE_FORK: bit 0 = the luma chain forks, bit 1 = the chroma chain forks */
-    const int forkmask = getenv("ODHIP_PIPE_FORK") ? atoi(getenv("ODHIP_PIPE_FORK")) : 0;
+    /* ODHIP_PIPE_FORK: a bit mask - bit 0 = the luma chain forks, bit 1 = the chroma chain forks.
+       Rounds 1-2 read the variable as a flag ("set = both chains fork"): a value that is not a
+       number in 0..3 (e.g. "yes", "true") keeps that meaning; the parsed mask is logged once. */
+    int forkmask = 0;
+    if (const char *fe = getenv("ODHIP_PIPE_FORK")) {
+      char *end = nullptr;
+      const long v = strtol(fe, &end, 10);
+      forkmask = (end == fe || *end != '\0' || v < 0 || v > 3) ? 3 : (int)v;
+      static bool logged = false;
+      if (!logged) {
+        fprintf(stderr, "odhip_pipe: ODHIP_PIPE_FORK=%s -> fork mask %d (bit 0 luma chain, bit 1 chroma chain)\n",
+         fe, forkmask);
+        logged = true;
+      }
+    }
     odhip_ctx_set_serial(p->ctx[i], p->serial || (two_chains && !(forkmask >> i & 1)));
     odhip_ctx_set_fpr(p->ctx[i], c.fpr_bits != 0);
   }

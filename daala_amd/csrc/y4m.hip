@@ -115,8 +115,22 @@ extern "C" int odhip_y4m_skip(odhip_y4m *y) {
   }
   const size_t ny = (size_t)y->w*y->h;
   const size_t nc = (size_t)((y->w + 1) >> 1)*((y->h + 1) >> 1);
-  if (fseek(y->f, (long)(ny + 2*nc), SEEK_CUR) != 0) return ODHIP_EFAULT;
-  /* a short file shows at the next read */
+  const size_t nbytes = ny + 2*nc;
+  /* Every byte but the last is stepped over; the last one is READ, so that a truncated frame is
+     reported here, by the rank that skips it, exactly as the rank that owns it sees it from
+     odhip_y4m_read (a seek past the end of a file succeeds).  A stream that cannot seek (a pipe:
+     ESPIPE) is read and discarded. */
+  if (nbytes > 1 && fseek(y->f, (long)(nbytes - 1), SEEK_CUR) != 0) {
+    char buf[4096];
+    size_t left = nbytes - 1;
+    clearerr(y->f);
+    while (left > 0) {
+      const size_t n = left < sizeof(buf) ? left : sizeof(buf);
+      if (fread(buf, 1, n, y->f) != n) return ODHIP_EFAULT;
+      left -= n;
+    }
+  }
+  if (fgetc(y->f) == EOF) return ODHIP_EFAULT;
   return 1;
 }
 

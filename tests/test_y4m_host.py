@@ -112,3 +112,35 @@ def test_skip_reads_only_the_frames_a_rank_owns(tmp_path):
         L.odhip_y4m_close(ctypes.c_void_p(y))
         assert [i for i, _ in got] == list(range(rank, n, 3))
         assert all(np.array_equal(a, frames[i]) for i, a in got)
+
+
+def test_skip_reports_a_truncated_frame_like_read_does(tmp_path):
+    """A rank that SKIPS a truncated last frame must see the same error as the rank that reads it
+    (a seek past the end of a file succeeds, so skip used to count the frame and the
+    ranks of a sharded encode disagreed on the total)."""
+    w = h = 16
+    nbytes = w * h + 2 * 8 * 8
+    path = tmp_path / "trunc.y4m"
+    with open(path, "wb") as f:
+        f.write(b"YUV4MPEG2 W16 H16 F30:1 Ip C420\n")
+        f.write(b"FRAME\n" + bytes(nbytes))           # a whole frame
+        f.write(b"FRAME\n" + bytes(nbytes - 7))       # a truncated one
+    L, y, _, _, _, _ = _open(path)
+    assert L.odhip_y4m_skip(ctypes.c_void_p(y)) == 1
+    assert L.odhip_y4m_skip(ctypes.c_void_p(y)) < 0
+    L.odhip_y4m_close(ctypes.c_void_p(y))
+    L, y, _, _, _, _ = _open(path)
+    planes = [np.zeros((h, w), np.uint8), np.zeros((8, 8), np.uint8), np.zeros((8, 8), np.uint8)]
+    ptrs = [p.ctypes.data_as(ctypes.c_void_p) for p in planes]
+    assert L.odhip_y4m_read(ctypes.c_void_p(y), *ptrs) == 1
+    assert L.odhip_y4m_read(ctypes.c_void_p(y), *ptrs) < 0
+    L.odhip_y4m_close(ctypes.c_void_p(y))
+    # whole frames: skip, skip, end of stream
+    path = tmp_path / "whole.y4m"
+    with open(path, "wb") as f:
+        f.write(b"YUV4MPEG2 W16 H16 F30:1 Ip C420\n")
+        for _ in range(2):
+            f.write(b"FRAME\n" + bytes(nbytes))
+    L, y, _, _, _, _ = _open(path)
+    assert [L.odhip_y4m_skip(ctypes.c_void_p(y)) for _ in range(3)] == [1, 1, 0]
+    L.odhip_y4m_close(ctypes.c_void_p(y))
