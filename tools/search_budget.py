@@ -135,9 +135,11 @@ def main():
             # the tail loop reads the 1/sqrt table from LDS, the greedy loop does not
             tail = c["lds"] >= n // 2
             mn = MIN_TAIL if tail else MIN_GREEDY
+            if per < mn:
+                continue          # a partially unrolled piece of a pulse, not a whole pulse loop
             print("%-28s %-6d %-28s %.2f" % (pat.replace("ILi", "<").replace("ELi", ",").rstrip("E"), n,
                                              "%s: %.1f (f64 %.1f, select %.1f, other %.1f)" % (
-                                                 "tail  " if tail else "greedy", per, c["f64"] / n, c["sel"] / n,
+                                                 "reads LDS" if tail else "registers", per, c["f64"] / n, c["sel"] / n,
                                                  c["valu"] / n), mn / per))
         print("    %s" % what)
 
