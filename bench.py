@@ -489,7 +489,7 @@ def source_hash():
     return h.hexdigest()[:16]
 
 
-def load_pmc(tag_order=("r3",)):
+def load_pmc(tag_order=("r4", "r3")):
     """(per-kernel counters, source file, stale?) of the committed rocprofv3 --pmc passes."""
     for tag in tag_order:
         path = os.path.join(ROOT, "profiles", "%s_pmc_traffic.json" % tag)
@@ -877,7 +877,7 @@ def main():
     fd_alone = pipe.time_pyramid(10)
     # ... and every other stage of the filter + DCT path the same way (odhip_pipe_time_stage: the stage
     # launched 10 times over the buffers the last step left, HIP events on its stream)
-    stage_alone = {st: pipe.time_stage(st, 10) for st in FILTER_DCT_STAGES}
+    stage_alone = None if args.no_replay else {st: pipe.time_stage(st, 10) for st in FILTER_DCT_STAGES}
     copy_gbs = copy_ceiling_gbs(device)
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
@@ -979,6 +979,8 @@ def main():
             serial_digest = pipeline_digest(D, serial)
             serial.destroy()
 
+        if stage_alone is None:      # profiling runs (--no-replay): no extra launches, the in-step durations
+            stage_alone = {st: kms[st][0] for st in FILTER_DCT_STAGES}
         bpf = blocks_per_frame()
         total_blocks = world * args.frames * args.steps * bpf
         step_ms = dt / args.steps * 1e3
@@ -1064,12 +1066,14 @@ def main():
             "dequant_inverse_luma", "k_inverse_walk<64,1,256,1,0,2> + k_inverse_sb_top2 + k_edge_rows/cols "
             "(dequantise on load + iDCT + od_postfilter_split + superblock edges + pixels, 5 levels)",
             ab["dequant_inverse_luma"], stage_alone["dequant_inverse_luma"], kernels.get("dequant_inverse_luma"),
-            pmc, ("k_inverse_walk<64", "k_inverse_sb_top2", "k_inverse_sb<64", "k_edge_rows_luma", "k_edge_cols_luma"))
+            pmc, ("k_inverse_walk<64", "k_inverse_sb_top2", "k_inverse_sb<64",
+                  "k_edge_rows grid %d" % (1280 * 14 * 5 * args.frames), "k_edge_cols grid %d" % (2048 * 16 * 5 * args.frames)))
         roof_inv_chroma = stage_roofline(
             "dequant_inverse_chroma", "k_inverse_walk<32,2,128,...> + k_edge_rows/cols (4 levels, with-reference "
             "synthesis on load)" if cfl else "k_inverse_walk<32,2,128,1,...> + k_edge_rows/cols (4 levels)",
             ab["dequant_inverse_chroma"], stage_alone["dequant_inverse_chroma"], kernels.get("dequant_inverse_chroma"),
-            pmc, ("k_inverse_walk<32", "k_inverse_sb<32", "k_edge_rows_chroma", "k_edge_cols_chroma"))
+            pmc, ("k_inverse_walk<32", "k_inverse_sb<32",
+                  "k_edge_rows grid %d" % (768 * 4 * 8 * args.frames), "k_edge_cols grid %d" % (1024 * 16 * 8 * args.frames)))
         st_bytes = sum(ab[st] for st in FILTER_DCT_STAGES)
         st_ms = sum(stage_alone[st] for st in FILTER_DCT_STAGES)
         roof_stage = {"stage": "padding + forward pyramids + dequantise / inverse / post-filter / edges, luma and "

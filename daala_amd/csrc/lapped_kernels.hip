@@ -823,6 +823,8 @@ struct InverseArgs {
   int inter;                /* with-reference source of an inter frame (is_keyframe == 0) */
   int dbg;                  /* ODHIP_INVERSE_DBG (k_inverse_walk, timing experiments only): 1 = no pixel
                                stores, 2 = no strip stores, 4 = no source loads (WRONG results) */
+  int wide;                 /* k_inverse_walk: 8-bit samples in a 16-byte aligned plane - rows go out as
+                               whole lines, one group late (walk_store_prev) */
 };
 
 /* Several partition levels of one plane set in ONE launch (blockIdx.z = level *
@@ -1927,8 +1929,88 @@ __device__ __forceinline__ void walk_store(int *t, const InverseArgs &a, int pla
   }
 }
 
+/* ---- the same window, one group LATE and line by line ------------------------------------
+   With 8-bit samples a row of a 64-wide tile is exactly one 64-byte line of the plane: the window
+   shifted by four samples (walk_store) writes every line with TWO store instructions of
+   consecutive groups, which the memory system does not merge (26 us of the luma stage,
+   profiles/r4_inverse_segments.txt).  Instead the finished group is packed to 8-bit samples in
+   LDS (walk_pack), and its rows go out when the NEXT group has filtered the shared edge
+   (walk_store_prev): whole 16-byte pieces, every line written once, the last four samples of a
+   row converted from the keep.  Used when the pixel plane is 16-byte aligned and holds 8-bit
+   samples (InverseArgs::wide); full-precision references keep walk_store. */
+__device__ __forceinline__ uint32_t walk_pack4(int4 v) {
+  return (uint32_t)od_to_px(v.x) | (uint32_t)od_to_px(v.y) << 8 | (uint32_t)od_to_px(v.z) << 16
+   | (uint32_t)od_to_px(v.w) << 24;
+}
+
+/* The group at t -> packed samples in pxb ([tile][row][TILE/4] dwords), its strip rows (all but the
+   last four columns, which wait for the edge filter) -> hs, and the keep renewed. */
+template <int TILE, int G, int NT>
+__device__ __forceinline__ void walk_pack(int *t, uint32_t *pxb, const InverseArgs &a, int plane, int xg, int y0,
+ int sby, unsigned tid) {
+  constexpr int P = TILE + 4;
+  constexpr int Q = TILE/4;
+  const int nh = a.h/TILE - 1;
+  od_coeff *hs = a.hs + (long)plane*nh*4*a.w;
+  for (unsigned i = tid; i < G*TILE*Q; i += NT) {
+    const unsigned s = i/(TILE*Q);
+    const unsigned j = i % (TILE*Q);
+    const unsigned r = j/Q;
+    const unsigned q = j % Q;
+    const int4 v = *reinterpret_cast<const int4 *>(t + s*(TILE*P) + r*P + 4*q);
+    pxb[i] = walk_pack4(v);
+    if (!(a.dbg & 2) && !(s == G - 1 && q == Q - 1)) {
+      const int x = xg + s*TILE + 4*q;
+      if (r < 2) {
+        if (sby > 0) *reinterpret_cast<int4 *>(hs + ((long)(sby - 1)*4 + r + 2)*a.w + x) = v;
+      }
+      else if (r >= TILE - 2) {
+        if (sby < nh) *reinterpret_cast<int4 *>(hs + ((long)sby*4 + r - (TILE - 2))*a.w + x) = v;
+      }
+    }
+  }
+  for (unsigned r = tid; r < TILE; r += NT) {
+    *reinterpret_cast<int4 *>(t + r*P + TILE) = *reinterpret_cast<const int4 *>(t + (G - 1)*(TILE*P) + r*P + TILE - 4);
+  }
+}
+
+/* The rows of the group whose packed samples are in pxb and whose last four columns are in the
+   keep, at plane position (xp, y0): 16-byte pieces, whole lines. */
+template <int TILE, int G, int NT>
+__device__ __forceinline__ void walk_store_prev(const int *t, const uint32_t *pxb, const InverseArgs &a, int plane,
+ int xp, int y0, int sby, unsigned tid) {
+  constexpr int P = TILE + 4;
+  constexpr int Q = TILE/4;
+  constexpr int PR = G*TILE/16;            /* 16-byte pieces per row of the group */
+  const int nh = a.h/TILE - 1;
+  od_coeff *hs = a.hs + (long)plane*nh*4*a.w;
+  uint8_t *px = a.px + (long)plane*a.px_plane_stride;
+  for (unsigned i = tid; i < TILE*PR; i += NT) {
+    const unsigned r = i/PR;
+    const unsigned q = i % PR;
+    const unsigned d = 4*q;                /* first dword of the piece in the group's row */
+    const unsigned s = d/Q;
+    uint4 v = *reinterpret_cast<const uint4 *>(pxb + s*(TILE*Q) + r*Q + d % Q);
+    if (q == PR - 1) {
+      const int4 k = *reinterpret_cast<const int4 *>(t + r*P + TILE);
+      v.w = walk_pack4(k);
+      if (!(a.dbg & 2)) {
+        const int x = xp + G*TILE - 4;
+        if (r < 2) {
+          if (sby > 0) *reinterpret_cast<int4 *>(hs + ((long)(sby - 1)*4 + r + 2)*a.w + x) = k;
+        }
+        else if (r >= TILE - 2) {
+          if (sby < nh) *reinterpret_cast<int4 *>(hs + ((long)sby*4 + r - (TILE - 2))*a.w + x) = k;
+        }
+      }
+    }
+    if (!(a.dbg & 1)) *reinterpret_cast<uint4 *>(px + (long)(y0 + r)*a.px_stride + xp + 16*q) = v;
+  }
+}
+
 template <int TILE, int G, int NT, int SRC, int LEAF>
-__device__ __forceinline__ void inverse_walk(int *t, const InverseArgs &a, int plane, int seg_len, unsigned tid_in) {
+__device__ __forceinline__ void inverse_walk(int *t, uint32_t *pxb, const InverseArgs &a, int plane, int seg_len,
+ unsigned tid_in) {
   unsigned tid = tid_in;
   constexpr int P = TILE + 4;
   const int ng = a.w/(TILE*G);
@@ -1985,8 +2067,17 @@ __device__ __forceinline__ void inverse_walk(int *t, const InverseArgs &a, int p
       }
     }
     od_lds_barrier();
-    walk_store<TILE, G, NT>(t, a, plane, xg, y0, sby, g == g0, g == g1 - 1, tid);
-    od_lds_barrier();
+    if (a.wide) {
+      if (g != g0) walk_store_prev<TILE, G, NT>(t, pxb, a, plane, xg - G*TILE, y0, sby, tid);
+      od_lds_barrier();
+      walk_pack<TILE, G, NT>(t, pxb, a, plane, xg, y0, sby, tid);
+      od_lds_barrier();
+      if (g == g1 - 1) walk_store_prev<TILE, G, NT>(t, pxb, a, plane, xg, y0, sby, tid);
+    }
+    else {
+      walk_store<TILE, G, NT>(t, a, plane, xg, y0, sby, g == g0, g == g1 - 1, tid);
+      od_lds_barrier();
+    }
   }
 }
 
@@ -1997,16 +2088,17 @@ template <int TILE, int G, int NT, int SRC, int MINLEAF, int MAXLEAF>
 __global__ __launch_bounds__(NT, OD_WALK_WAVES) void k_inverse_walk(InverseWalkArgs mm) {
   constexpr int P = TILE + 4;
   __shared__ __attribute__((aligned(16))) int t[G*TILE*P];
+  __shared__ __attribute__((aligned(16))) uint32_t pxb[G*TILE*TILE/4];
   const unsigned tid = threadIdx.x;
   const int plane = blockIdx.z % mm.nplanes;
   const InverseArgs &a = mm.a[blockIdx.z / mm.nplanes];
   switch (a.leaf_bs) {
-    case 0: if constexpr (MINLEAF <= 0 && MAXLEAF >= 0) inverse_walk<TILE, G, NT, SRC, 0>(t, a, plane, mm.seg_len, tid); break;
-    case 1: if constexpr (MINLEAF <= 1 && MAXLEAF >= 1) inverse_walk<TILE, G, NT, SRC, 1>(t, a, plane, mm.seg_len, tid); break;
-    case 2: if constexpr (MINLEAF <= 2 && MAXLEAF >= 2) inverse_walk<TILE, G, NT, SRC, 2>(t, a, plane, mm.seg_len, tid); break;
-    case 3: if constexpr (MINLEAF <= 3 && MAXLEAF >= 3) inverse_walk<TILE, G, NT, SRC, 3>(t, a, plane, mm.seg_len, tid); break;
+    case 0: if constexpr (MINLEAF <= 0 && MAXLEAF >= 0) inverse_walk<TILE, G, NT, SRC, 0>(t, pxb, a, plane, mm.seg_len, tid); break;
+    case 1: if constexpr (MINLEAF <= 1 && MAXLEAF >= 1) inverse_walk<TILE, G, NT, SRC, 1>(t, pxb, a, plane, mm.seg_len, tid); break;
+    case 2: if constexpr (MINLEAF <= 2 && MAXLEAF >= 2) inverse_walk<TILE, G, NT, SRC, 2>(t, pxb, a, plane, mm.seg_len, tid); break;
+    case 3: if constexpr (MINLEAF <= 3 && MAXLEAF >= 3) inverse_walk<TILE, G, NT, SRC, 3>(t, pxb, a, plane, mm.seg_len, tid); break;
     default:
-      if constexpr (TILE == 64 && MAXLEAF >= 4) inverse_walk<TILE, G, NT, SRC, 4>(t, a, plane, mm.seg_len, tid);
+      if constexpr (TILE == 64 && MAXLEAF >= 4) inverse_walk<TILE, G, NT, SRC, 4>(t, pxb, a, plane, mm.seg_len, tid);
       break;
   }
 }
@@ -2200,6 +2292,9 @@ int inverse_launch(const InverseArgs *levels, int nlevels, int nplanes, int dec,
     im.a[l] = levels[l];
     static const int dbg = getenv("ODHIP_INVERSE_DBG") ? atoi(getenv("ODHIP_INVERSE_DBG")) : 0;
     im.a[l].dbg = dbg;
+    static const bool narrow = getenv("ODHIP_INVERSE_NARROW") != nullptr;     /* A/B: the shifted window */
+    im.a[l].wide = !narrow && !ctx->fpr && !(levels[l].px_stride & 15) && !(levels[l].px_plane_stride & 15)
+     && !((uintptr_t)levels[l].px & 15);
     im.a[l].px16 = ctx->fpr != 0;
     em.a[l].px16 = ctx->fpr != 0;
     if (ctx->fpr && ((uintptr_t)levels[l].px & 7)) return ODHIP_EINVAL;

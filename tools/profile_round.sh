@@ -6,7 +6,7 @@
 #   trace_serial  ODHIP_PVQ_SERIAL=1: one stream, exclusive per-kernel durations
 #   pmc_*         ODHIP_PVQ_SERIAL=1 as well (counters are per dispatch)
 set -u
-TAG=${1:-r3}
+TAG=${1:-r4}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
