@@ -106,17 +106,17 @@ __device__ __forceinline__ double od_pvq_search_regs(const int (&ax)[N], int (&y
       }
     }
     int xp = 0;
-    int yp = 0;
 #pragma unroll
     for (int j = 0; j < N; j++) {
       if (j == pos) {
         xp = ax[j];
-        yp = y[j];
-        y[j] = yp + 1;
+        y[j]++;
       }
     }
     xy = xy + (double)xp;
-    yy = yy + (double)(2*yp) + 1;
+    /* yy + 2*y[pos] + 1 is the winner's denominator, an exact integer either way: no need to read
+       y[pos] back */
+    yy = best_yy;
   }
   /* Last pulses with the rate term, :192-219. */
   /* rate penalty of each candidate, (lambda*j)*(delta_rate + j*accel_rate):

@@ -302,22 +302,21 @@ __device__ __forceinline__ double od_pvq_search_row(const int (&ax)[E], int (&y)
     };
     if (!__any(on && yyi + 2*i + 1 > OD_RSQ_TABLE_N)) scan(std::true_type());
     else scan(std::false_type());
-    /* (max cost, lowest index): butterfly over the row, both fields moved by DPP */
-#define OD_RDO_STEP(CTRL) \
-    { \
-      const double oc = row_mov<CTRL>(bc); \
-      const int oi = row_mov<CTRL>(bi); \
-      const bool take = oc > bc || (oc == bc && oi < bi); \
-      bc = take ? oc : bc; \
-      bi = take ? oi : bi; \
-    }
-    OD_RDO_STEP(OD_DPP_XOR1)
-    OD_RDO_STEP(OD_DPP_XOR2)
+    /* (max cost, lowest index) over the row.  Round 4: the maximum alone is reduced by DPP (v_max_f64
+       of finite doubles is exact), then the LOWEST lane whose own best equals it is found with one
+       ballot and its index broadcast - lanes hold consecutive index ranges and every lane's own scan
+       keeps its first maximum, so that is the lowest index attaining the maximum: the same total
+       order the (cost, index) butterfly of rounds 2-3 implemented with three moves, three compares
+       and three selects per step. */
+    double bm = bc;
+    bm = fmax(bm, row_mov<OD_DPP_XOR1>(bm));
+    bm = fmax(bm, row_mov<OD_DPP_XOR2>(bm));
     if (G == 16) {
-      OD_RDO_STEP(OD_DPP_HALF_MIRROR)
-      OD_RDO_STEP(OD_DPP_MIRROR)
+      bm = fmax(bm, row_mov<OD_DPP_HALF_MIRROR>(bm));
+      bm = fmax(bm, row_mov<OD_DPP_MIRROR>(bm));
     }
-#undef OD_RDO_STEP
+    const unsigned tmask = grp_ballot<G>(bc == bm, row);
+    bi = grp_bcast<G>(bi, row, tmask ? __ffs(tmask) - 1 : 0);
     const int pos = bi;
     int px = 0;
     int py = 0;
