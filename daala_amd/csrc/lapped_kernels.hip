@@ -641,6 +641,77 @@ __global__ __launch_bounds__(256) void k_forward_pyramid64x2(PyramidArgs a) {
   for (int s = 0; s < 2; s++) pyramid_level4<TILE, T>(t[s], a, plane_off, xb + s*TILE, y0, tid);
 }
 
+/* TWO horizontally adjacent 4:2:0 chroma superblocks per 128-thread workgroup (round 4).  A 32-point
+   pass has 32 columns (rows) per 32x32 tile and a wavefront 64 lanes: with one tile per wavefront
+   (k_forward_pyramid<32>) half of the lanes idle through the most expensive level - 55 % of the
+   kernel's network instructions.  Here wavefront 0 runs the 32-point passes of BOTH tiles (lane =
+   (tile, column), then (tile, row)), and below that level each wavefront takes its own tile through
+   the generic 64-lane code (the barriers are workgroup barriers that both wavefronts meet in the same
+   order). */
+template <typename T>
+__global__ __launch_bounds__(128) void k_forward_pyramid32x2(PyramidArgs a) {
+  constexpr int TILE = 32;
+  using G = Geo<TILE>;
+  constexpr int P = G::kPitch;
+  constexpr int NT = 128;
+  __shared__ __attribute__((aligned(16))) short t[2][G::kHaloWords];
+  __shared__ __attribute__((aligned(16))) int z[2][TILE*P];
+  const int tid = threadIdx.x;
+  const int wv = tid >> 6;
+  const int lane = tid & 63;
+  const int xb = blockIdx.x*2*TILE;
+  const int y0 = blockIdx.y*TILE;
+  const uint8_t *px = pyr_plane(a, blockIdx.z);
+  const long plane_off = (long)blockIdx.z*a.w*a.h;
+  sb_load<TILE, NT, 2>(t, a, px, xb, y0, tid);
+  od_lds_barrier();
+  for (int s = 0; s < 2; s++) sb_edge_cols<TILE, NT>(t[s], a, xb + s*TILE, y0, tid);
+  od_lds_barrier();
+  for (int s = 0; s < 2; s++) sb_edge_rows<TILE, NT>(t[s], a, xb + s*TILE, tid);
+  od_lds_barrier();
+  /* ---- 32-point level ------------------------------------------------------------------- */
+  {
+    const int s = lane >> 5;
+    const int c = lane & 31;
+    if (wv == 0) {
+      T in[TILE];
+      T out[TILE];
+#pragma unroll
+      for (int r = 0; r < TILE; r++) in[r] = T(t[s][r*P + c]);
+      od_fdct_lift<3>(out, in);
+#pragma unroll
+      for (int r = 0; r < TILE; r++) z[s][r*P + c] = out[r];
+    }
+    od_lds_barrier();
+    if (wv == 0) {
+      T in[TILE];
+      T out[TILE];
+      int *row = z[s] + c*P;
+#pragma unroll
+      for (int q = 0; q < TILE; q += 4) {
+        const int4 v = *reinterpret_cast<const int4 *>(row + q);
+        in[q] = T(v.x);
+        in[q + 1] = T(v.y);
+        in[q + 2] = T(v.z);
+        in[q + 3] = T(v.w);
+      }
+      od_fdct_lift<3>(out, in);
+#pragma unroll
+      for (int q = 0; q < TILE; q += 4) {
+        *reinterpret_cast<int4 *>(row + q) = make_int4(out[q], out[q + 1], out[q + 2], out[q + 3]);
+      }
+    }
+    /* the tiles are free: lapping of the next level overlaps the row pass */
+    split_filter_cols<TILE, 3, false, 64>(t[wv], lane, xb + wv*TILE, a.pic_w);
+    od_lds_barrier();
+    if (a.levels[3]) store_tile<TILE, 64>(a.levels[3] + plane_off, a.w, xb + wv*TILE, y0, z[wv], lane);
+    split_filter_rows<TILE, 3, false, 64>(t[wv], lane, y0, a.pic_h);
+    od_lds_barrier();
+  }
+  /* ---- 16-, 8- and 4-point levels: each wavefront its own tile -------------------------------- */
+  pyramid_level<TILE, 2, T, 64>(t[wv], z[wv], a, plane_off, xb + wv*TILE, y0, lane);
+}
+
 /* ONE luma superblock per 128-thread workgroup, and after the 64-point level NO
    workgroup barrier at all: blocks of 32x32 and smaller never straddle the
    horizontal mid-line of the superblock, so each of the two waves owns one half
@@ -2237,7 +2308,13 @@ extern "C" int odhip_forward_pyramid(od_coeff *const d_levels[ODHIP_NBSIZES],
      time follows occupancy (tools/pyr_stalls.py); 0 outside that experiment. */
   static const unsigned lds_pad = getenv("ODHIP_PYR_LDS_PAD") ? (unsigned)atoi(getenv("ODHIP_PYR_LDS_PAD")) : 0;
   if (dec) {
-    if (variant & 2) k_forward_pyramid<32, OdMul24S><<<grid, Geo<32>::kNT, 0, s>>>(a);
+    /* pairs of chroma superblocks (k_forward_pyramid32x2) whenever the plane is an even number of
+       them wide; ODHIP_PYRAMID_X1=1: one per wavefront (the A/B baseline) */
+    if ((w/tile) % 2 == 0 && !getenv("ODHIP_PYRAMID_X1")) {
+      if (variant & 2) k_forward_pyramid32x2<OdMul24S><<<dim3(w/(2*tile), h/tile, nplanes), 128, 0, s>>>(a);
+      else k_forward_pyramid32x2<OdMul24><<<dim3(w/(2*tile), h/tile, nplanes), 128, 0, s>>>(a);
+    }
+    else if (variant & 2) k_forward_pyramid<32, OdMul24S><<<grid, Geo<32>::kNT, 0, s>>>(a);
     else k_forward_pyramid<32><<<grid, Geo<32>::kNT, 0, s>>>(a);
   }
   else if (variant & 4) {
