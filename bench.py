@@ -648,7 +648,8 @@ def encode_mode(args, D, torch, dist, rank, world, local_rank):
         e_idx = rank * P + p
         cmd = [sys.executable, os.path.join(ROOT, "encode_job.py"), "--worker", "--y4m", path, "--frames", str(nframes),
                "--stride", str(world * P), "--offset", str(e_idx), "--device", str(local_rank),
-               "--core", str(cores[e_idx % len(cores)]), "--out", outs[p], "--gpu-lock", str(int(args.gpu_lock))]
+               "--core", "-1" if args.threads_per_proc > 1 else str(cores[e_idx % len(cores)]), "--out", outs[p],
+               "--gpu-lock", str(int(args.gpu_lock)), "--threads", str(max(1, args.threads_per_proc))]
         env = dict(os.environ)
         for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
             env.pop(k, None)
@@ -716,7 +717,9 @@ def encode_mode(args, D, torch, dist, rank, world, local_rank):
     line = {
         "metric": "1080p all-intra encode frames/s (frame-sharded over the GPUs of one node)",
         "value": nframes / t_job, "unit": "frames/s", "n_gpus": world, "frames": nframes,
-        "encoder_processes_per_gpu": P, "host_cores_available": len(cores), "gpu_pass_lock": bool(args.gpu_lock),
+        "encoder_processes_per_gpu": P, "encoder_threads_per_process": max(1, args.threads_per_proc),
+        "encoders_per_gpu": P * max(1, args.threads_per_proc),
+        "host_cores_available": len(cores), "gpu_pass_lock": bool(args.gpu_lock),
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "data": "synthetic",
         "dtype": "int32 (lifting DCT/filters) + f64 (PVQ search)",
         "config": {"workload": "configs[4]: %d-frame %dx%d all-intra encode (-v 20, complexity 7), frame i -> "
@@ -778,6 +781,9 @@ def main():
     ap.add_argument("--procs-per-gpu", type=int, default=1,
                     help="--encode-frames: encoder processes per GPU (they share the rank's device; the host "
                          "chain of one encoder is sequential, ~1 frame/s, while its GPU passes take ~10 ms)")
+    ap.add_argument("--threads-per-proc", type=int, default=1,
+                    help="--encode-frames: encoder contexts (host threads) per encoder process; they share the "
+                         "process's HIP context, so P x T encoders share a GPU with only P processes on it")
     ap.add_argument("--gpu-lock", type=int, default=0,
                     help="--encode-frames: the batched GPU pass of a frame under a cross-process lock "
                          "(odhip_glue_config.gpu_pass_lock); measured slower than letting the passes "

@@ -194,19 +194,53 @@ def worker(args):
     frames, w, h, total = read_y4m_frames(D, args.y4m, args.offset, args.stride, args.frames)
     owned = sorted(frames)
     r, glue = load_batched_encoder(w, h, device=args.device, gpu_pass_lock=args.gpu_lock)
-    if owned:
-        encode_frames(r, owned[:1], [frames[owned[0]]], w, h)      # allocations, first-use tables
+    # T encoder contexts in T host threads of this process (the C call releases the GIL; the shim's
+    # state is per thread, the HIP context is shared): thread t takes every T-th of the owned frames
+    T = max(1, args.threads)
+    parts = [owned[t::T] for t in range(T)]
+    import threading
+    go = threading.Event()
+    warmed = threading.Barrier(T + 1)
+    outs = [{} for _ in parts]
+    errors = []
+
+    def run(idx, out):
+        # the same thread codes its untimed first frame (allocations, first-use tables, its own frame /
+        # band / dering caches in the shim) and, after the start signal, its share of the job
+        try:
+            if idx:
+                encode_frames(r, idx[:1], [frames[idx[0]]], w, h)
+            warmed.wait()
+            go.wait()
+            out.update(encode_frames(r, idx, [frames[i] for i in idx], w, h))
+        except Exception as e:      # noqa: BLE001 - reported by the assertion below
+            errors.append(repr(e))
+            try:
+                warmed.abort()
+            except Exception:       # noqa: BLE001
+                pass
+
+    ths = [threading.Thread(target=run, args=(p_, o)) for p_, o in zip(parts, outs)]
+    for th in ths:
+        th.start()
+    warmed.wait()
     st0 = glue_stats(glue)
     print("READY", flush=True)
     sys.stdin.readline()
     t0 = time.perf_counter()
-    local = encode_frames(r, owned, [frames[i] for i in owned], w, h)
+    go.set()
+    for th in ths:
+        th.join()
+    local = {}
+    for o in outs:
+        local.update(o)
     dt = time.perf_counter() - t0
+    assert not errors and sorted(local) == owned, "an encoder thread failed: %s" % errors
     st = glue_stats(glue)
     sizes = np.array([len(local[i]) for i in owned], np.int64)
     blob = np.frombuffer(b"".join(local[i] for i in owned), np.uint8) if owned else np.zeros(0, np.uint8)
     np.savez(args.out, indices=np.array(owned, np.int64), sizes=sizes, bytes=blob)
-    print(json.dumps({"frames": len(owned), "seconds": dt, "frames_in_file": total, "w": w, "h": h,
+    print(json.dumps({"frames": len(owned), "seconds": dt, "frames_in_file": total, "w": w, "h": h, "threads": T,
                       "bands_from_batch": st.theta[0] - st0.theta[0],
                       "bands_left_to_reference": st.theta[1] + st.theta[2] - st0.theta[1] - st0.theta[2],
                       "searches_saved": st.theta[3] - st0.theta[3],
@@ -226,6 +260,7 @@ def main():
     ap.add_argument("--core", type=int, default=-1)
     ap.add_argument("--out")
     ap.add_argument("--gpu-lock", type=int, default=0)
+    ap.add_argument("--threads", type=int, default=1)
     args = ap.parse_args()
     if not args.worker:
         ap.error("encode_job.py is a module; as a program it only runs as --worker (see bench.py --encode-frames)")

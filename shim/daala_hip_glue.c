@@ -112,7 +112,7 @@ void od_state_opt_vtbl_init(void *state) {
 }
 
 void od_prefilter_split(od_coeff *c0, int stride, int bs, int f, int hfilter, int vfilter) {
-  odhip_glue_calls[0]++;
+  __atomic_fetch_add(&odhip_glue_calls[0], 1, __ATOMIC_RELAXED);
   if (!cfg()->bind_filters) {
     typedef void (*fn)(od_coeff *, int, int, int, int, int);
     static fn next;
@@ -125,7 +125,7 @@ void od_prefilter_split(od_coeff *c0, int stride, int bs, int f, int hfilter, in
 
 void od_postfilter_split(od_coeff *c0, int stride, int bs, int f, int q, unsigned char *skip,
  int skip_stride, int hfilter, int vfilter) {
-  odhip_glue_calls[1]++;
+  __atomic_fetch_add(&odhip_glue_calls[1], 1, __ATOMIC_RELAXED);
   if (!cfg()->bind_filters) {
     typedef void (*fn)(od_coeff *, int, int, int, int, unsigned char *, int, int, int);
     static fn next;
@@ -140,7 +140,7 @@ static void glue_load_plane(const od_coeff *c, int stride, int nhsb, int nvsb, i
 
 void od_apply_prefilter_frame_sbs(od_coeff *c, int stride, int nhsb, int nvsb, int xdec,
  int ydec) {
-  odhip_glue_calls[2]++;
+  __atomic_fetch_add(&odhip_glue_calls[2], 1, __ATOMIC_RELAXED);
   glue_load_plane(c, stride, nhsb, nvsb, xdec);
   if (!cfg()->bind_filters) {
     typedef void (*fn)(od_coeff *, int, int, int, int, int);
@@ -163,7 +163,7 @@ __attribute__((weak)) int odhip_glue_hook_postfilter_frame(od_coeff *c, int stri
    (src/encode.c:2787,:2826) is served by odhip_dering_cache_call; the frame boundary is
    the superblock-edge postfilter the encoder runs just before the search (:2670-2677) -
    in a reference build that is one line at :2697. */
-static odhip_dering_cache *g_dering_cache;
+static __thread odhip_dering_cache *g_dering_cache;   /* per host thread: see "Threads" in daala_hip_glue.h */
 static int dering_cache_enabled(void) {
   return cfg()->dering_cache;
 }
@@ -174,7 +174,7 @@ void odhip_glue_enable_dering_cache(void) {
 
 void od_apply_postfilter_frame_sbs(od_coeff *c, int stride, int nhsb, int nvsb, int xdec,
  int ydec, int q, unsigned char *skip, int skip_stride) {
-  odhip_glue_calls[3]++;
+  __atomic_fetch_add(&odhip_glue_calls[3], 1, __ATOMIC_RELAXED);
   if (dering_cache_enabled() && g_dering_cache) odhip_dering_cache_begin(g_dering_cache);
   if (odhip_glue_hook_postfilter_frame) {
     static odhip_glue_postfilter_fn next;
@@ -193,7 +193,7 @@ void od_apply_postfilter_frame_sbs(od_coeff *c, int stride, int nhsb, int nvsb, 
 
 double pvq_search_rdo_double(const int16_t *xcoeff, int n, int k, od_coeff *ypulse, double g2,
  double pvq_norm_lambda, int prev_k) {
-  odhip_glue_calls[4]++;
+  __atomic_fetch_add(&odhip_glue_calls[4], 1, __ATOMIC_RELAXED);
   if (!cfg()->bind_search) {
     typedef double (*fn)(const int16_t *, int, int, od_coeff *, double, double, int);
     static fn next;
@@ -210,22 +210,33 @@ double pvq_search_rdo_double(const int16_t *xcoeff, int n, int k, od_coeff *ypul
    odhip_cache_load_plane (one batched GPU pyramid), then laps it as before.
    With odhip_install_cached_dct_vtbl bound into od_state.opt_vtbl, every later
    fdct_2d call on that plane is served from the cache. */
-static odhip_frame_cache *g_cache;
-static const od_coeff *g_bases[4];
-static int g_nbases;
+static __thread odhip_frame_cache *g_cache;
+static __thread const od_coeff *g_bases[4];
+static __thread int g_nbases;
 #define g_bands_on (cfg()->band_cache)   /* the batched band stage behind pvq_theta */
-static void *g_enc;         /* the encoder whose frame is being coded */
-static int g_bands_frame;   /* the current frame's luma bands are loaded */
+static __thread void *g_enc;         /* the encoder whose frame is being coded */
+static __thread int g_bands_frame;   /* the current frame's luma bands are loaded */
 long odhip_glue_theta[4];   /* served from the batch / left to the reference (r0 not null) /
                                left to the reference (other reason) / searches the batch saved */
 
+/* The calling thread's frame cache (created on its first use in that thread). */
+static odhip_frame_cache *thread_cache(void) {
+  if (!g_cache) {
+    if (odhip_init(cfg()->device) != 0 || !(g_cache = odhip_cache_create())) {
+      fprintf(stderr, "daala_hip_glue: odhip_cache_create failed (no CPU fallback)\n");
+      abort();
+    }
+    odhip_cache_set_picture(g_cache, cfg()->pic_w, cfg()->pic_h);
+    odhip_cache_make_current(g_cache);
+  }
+  return g_cache;
+}
+
 void odhip_glue_enable_frame_cache(int pic_w, int pic_h) {
-  if (!g_cache) g_cache = odhip_cache_create();
-  odhip_cache_set_picture(g_cache, pic_w, pic_h);
-  odhip_cache_make_current(g_cache);
   cfg()->frame_cache = 1;
   cfg()->pic_w = pic_w;
   cfg()->pic_h = pic_h;
+  odhip_cache_set_picture(thread_cache(), pic_w, pic_h);
 }
 
 /* The transforms to put into od_state.opt_vtbl when the frame cache is on: fdct_2d served from
@@ -235,7 +246,8 @@ void odhip_glue_cached_dct_vtbl(odhip_dct_func_2d fdct[5], odhip_dct_func_2d idc
   odhip_install_cached_dct_vtbl(fdct, idct);
 }
 
-double odhip_glue_batch_ms;   /* wall time spent in the batched GPU pass (incl. PCIe both ways) */
+double odhip_glue_batch_ms;   /* wall time spent in the batched GPU passes (incl. PCIe both ways), all threads */
+static volatile int g_ms_lock;
 static void glue_load_plane_locked(const od_coeff *c, int stride, int nhsb, int nvsb, int xdec);
 static void glue_load_plane(const od_coeff *c, int stride, int nhsb, int nvsb, int xdec) {
   struct timespec a;
@@ -243,7 +255,10 @@ static void glue_load_plane(const od_coeff *c, int stride, int nhsb, int nvsb, i
   clock_gettime(CLOCK_MONOTONIC, &a);
   glue_load_plane_locked(c, stride, nhsb, nvsb, xdec);
   clock_gettime(CLOCK_MONOTONIC, &b);
+  while (__atomic_exchange_n(&g_ms_lock, 1, __ATOMIC_ACQUIRE)) {
+  }
   odhip_glue_batch_ms += (b.tv_sec - a.tv_sec)*1e3 + (b.tv_nsec - a.tv_nsec)*1e-6;
+  __atomic_store_n(&g_ms_lock, 0, __ATOMIC_RELEASE);
 }
 
 /* Advisory lock around the batched GPU pass (odhip_glue_config.gpu_pass_lock). */
@@ -271,7 +286,8 @@ static void glue_load_plane_locked(const od_coeff *c, int stride, int nhsb, int 
 
 static void glue_load_plane_timed(const od_coeff *c, int stride, int nhsb, int nvsb, int xdec) {
   int slot;
-  if (!g_cache) return;
+  if (!cfg()->frame_cache && !cfg()->band_cache) return;
+  (void)thread_cache();
   for (slot = 0; slot < g_nbases; slot++) if (g_bases[slot] == c) break;
   if (slot == g_nbases) {
     if (g_nbases == 4) return;
@@ -282,7 +298,7 @@ static void glue_load_plane_timed(const od_coeff *c, int stride, int nhsb, int n
     /* keyframe luma: the PVQ band stage of every block of every level, now, in one
        batch, with the quantiser set-up this encoder uses for this frame */
     typedef int (*setup_fn)(const void *, int *, int *, double *, unsigned char *, int16_t *, int16_t *);
-    static odhip_quant qt;
+    static __thread odhip_quant qt;
     setup_fn setup;
     double lambda;
     g_bands_frame = 0;
@@ -399,10 +415,10 @@ int pvq_theta(od_coeff *out, const od_coeff *x0, const od_coeff *r0, int n, int 
         break;
       }
     }
-    if (!null_ref) odhip_glue_theta[1]++;
+    if (!null_ref) __atomic_fetch_add(&odhip_glue_theta[1], 1, __ATOMIC_RELAXED);
     else if (!odhip_cache_band(g_cache, 0, t_bs, t_bx >> t_bs, t_by >> t_bs, band, x0, &c)
      || c.n != n || c.q != q0 || c.beta != beta || c.flags[0] == 2 || c.flags[1] == 2) {
-      odhip_glue_theta[2]++;
+      __atomic_fetch_add(&odhip_glue_theta[2], 1, __ATOMIC_RELAXED);
     }
     else {
       od_coeff y_tmp[128];
@@ -417,7 +433,7 @@ int pvq_theta(od_coeff *out, const od_coeff *x0, const od_coeff *r0, int n, int 
         gain_expand = NEXT(expand_fn, "od_gain_expand");
         synthesis = NEXT(synth_fn, "od_pvq_synthesis_partial");
       }
-      odhip_glue_theta[0]++;
+      __atomic_fetch_add(&odhip_glue_theta[0], 1, __ATOMIC_RELAXED);
       /* :415-421 with a null reference on a keyframe: the null candidate */
       qg = 0;
       best_dist = c.dist0;
@@ -467,7 +483,7 @@ int pvq_theta(od_coeff *out, const od_coeff *x0, const od_coeff *r0, int n, int 
         for (s = 0; s < 2; s++) {
           double cost;
           if (c.flags[s] != 1) continue;
-          odhip_glue_theta[3]++;
+          __atomic_fetch_add(&odhip_glue_theta[3], 1, __ATOMIC_RELAXED);
           for (i = 0; i < n; i++) y_tmp[i] = c.y[s][i];
           if (speed != 0) {
             rates[s] = rate(c.gain[s], 0, -1, 0, adapt, y_tmp, c.k[s], n, is_keyframe, pli, speed);
@@ -511,7 +527,7 @@ int pvq_theta(od_coeff *out, const od_coeff *x0, const od_coeff *r0, int n, int 
 void od_dering(const void *vtbl, int16_t *y, int ystride, const int16_t *x, int xstride, int nhb, int nvb,
  int sbx, int sby, int nhsb, int nvsb, int xdec, int dir[8][8], int pli, unsigned char *bskip,
  int skip_stride, int threshold, int overlap, int coeff_shift) {
-  odhip_glue_calls[5]++;
+  __atomic_fetch_add(&odhip_glue_calls[5], 1, __ATOMIC_RELAXED);
   if (dering_cache_enabled()) {
     if (!g_dering_cache) {
       if (odhip_init(cfg()->device) != 0 || !(g_dering_cache = odhip_dering_cache_create())) {

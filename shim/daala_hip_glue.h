@@ -44,6 +44,15 @@ typedef struct odhip_glue_config {
   int gpu_pass_lock;
 } odhip_glue_config;
 
+/* Threads.  The configuration is per process; the state the batched bindings keep between calls
+   (frame cache, band cache, dering cache, the encoder and the block a pvq_theta call belongs to) is
+   per HOST THREAD, created on a thread's first use: any number of encoder contexts may run in
+   different threads of one process and share its HIP context - which is how more than ~16 encoders
+   share one GPU (processes beyond the device's VMIDs evict each other:
+   profiles/r4_encode_mode_300frames.json).  One encoder per thread at a time; counters are totals
+   over all threads except the cache hit / miss / dering figures of odhip_glue_get_stats, which are
+   the calling thread's. */
+
 /* All per-call surfaces bound, no batched binding, no checks, device 0. */
 void odhip_glue_default_config(odhip_glue_config *cfg);
 /* Takes effect for the calls that follow.  Returns 0, or a negative ODHIP_* code when the device

@@ -65,21 +65,23 @@ def test_configs4_encode_mode_two_ranks_one_gpu(tmp_path):
                     reason="oracle/_ref (the reference encoder: the host half) not present")
 def test_configs4_encode_mode_rccl_world_size_one_two_encoders_per_gpu():
     """The RCCL branch itself: one rank launched by torch.distributed.run with backend "nccl"
-    (ODHIP_BENCH_FORCE_DIST=1 makes a process group of world size 1), two encoder processes sharing
-    the GPU (--procs-per-gpu 2), packets gathered with device tensors over RCCL
+    (ODHIP_BENCH_FORCE_DIST=1 makes a process group of world size 1), two encoder processes of two
+    encoder threads each sharing the GPU (--procs-per-gpu 2 --threads-per-proc 2), packets gathered with device tensors over RCCL
     (daala_amd.shard.gather_packets) and every frame compared with the sequential C encoder."""
     env = dict(os.environ)
     env.update(ODHIP_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     env.pop("ODHIP_BENCH_BACKEND", None)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
            "--master-addr", "127.0.0.1", "--master-port", "29635", os.path.join(ROOT, "bench.py"),
-           "--gpus", "1", "--encode-frames", "4", "--procs-per-gpu", "2", "--encode-check", "4"]
+           "--gpus", "1", "--encode-frames", "6", "--procs-per-gpu", "2", "--threads-per-proc", "2",
+           "--encode-check", "6"]
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, env=env, cwd=ROOT)
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, p.stdout[-2000:]
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 1 and d["frames"] == 4 and d["encoder_processes_per_gpu"] == 2
-    assert d["rank0"]["frames"] == 4 and len(d["rank0"]["encoder_seconds_per_process"]) == 2
-    assert d["prefix_check"]["frames"] == 4
+    assert d["n_gpus"] == 1 and d["frames"] == 6 and d["encoder_processes_per_gpu"] == 2
+    assert d["encoder_threads_per_process"] == 2 and d["encoders_per_gpu"] == 4
+    assert d["rank0"]["frames"] == 6 and len(d["rank0"]["encoder_seconds_per_process"]) == 2
+    assert d["prefix_check"]["frames"] == 6
     assert d["prefix_check"]["packets_equal_sequential_c_encoder"] is True

@@ -15,14 +15,16 @@ N=${JOB_FRAMES:-300}
 if [ "${PS:-}" != "" ]; then
   t0=$(date +%s)
   python -c "import bench; bench.write_y4m('/tmp/job.y4m', $N)"; echo "y4m written in $(( $(date +%s) - t0 )) s"
-  for P in $PS; do
-    timeout 1500 python bench.py --encode-frames $N --procs-per-gpu $P --y4m /tmp/job.y4m --encode-check ${CHECK:-6} > $OUT/encode_P$P.json 2> $OUT/encode_P$P.err; echo "P=$P rc=$?"
-    tail -2 $OUT/encode_P$P.err
-    python - $OUT/encode_P$P.json <<'PY'
+  free -g | head -2
+  for PT in $PS; do
+    P=${PT%%x*}; T=1; if [ "$PT" != "$P" ]; then T=${PT##*x}; fi
+    timeout 1500 python bench.py --encode-frames $N --procs-per-gpu $P --threads-per-proc $T --y4m /tmp/job.y4m --encode-check ${CHECK:-6} > $OUT/encode_P${P}_T$T.json 2> $OUT/encode_P${P}_T$T.err; echo "P=$P T=$T rc=$?"
+    tail -2 $OUT/encode_P${P}_T$T.err
+    python - $OUT/encode_P${P}_T$T.json <<'PY'
 import json,sys
 try:
     d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
-    print({k:d.get(k) for k in ("value","frames","encoder_processes_per_gpu","host_cores_available")}, d["seconds"], d["prefix_check"], {k:d["rank0"][k] for k in ("bands_from_batch","bands_left_to_reference","batched_gpu_pass_ms_per_frame")})
+    print({k:d.get(k) for k in ("value","frames","encoder_processes_per_gpu","encoder_threads_per_process","host_cores_available")}, d["seconds"], d["prefix_check"], {k:d["rank0"][k] for k in ("bands_from_batch","bands_left_to_reference","batched_gpu_pass_ms_per_frame")})
 except Exception as e:
     print("parse failed", repr(e))
 PY
