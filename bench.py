@@ -737,6 +737,8 @@ def encode_mode(args, D, torch, dist, rank, world, local_rank):
                   "bands_left_to_reference": sum(st["bands_left_to_reference"] for st in stats),
                   "searches_saved": sum(st["searches_saved"] for st in stats),
                   "batched_gpu_pass_ms_per_frame": batch_ms / max(1, nf0),
+                  "dering_cache_ms_per_frame": sum(st.get("dering_ms", 0) for st in stats) / max(1, nf0),
+                  "served_pvq_theta_ms_per_frame": sum(st.get("theta_ms", 0) for st in stats) / max(1, nf0),
                   "encoder_seconds_per_process": [round(st["seconds"], 2) for st in stats],
                   "stage_blocks_per_s": blocks_per_frame() * nf0 / max(batch_ms * 1e-3, 1e-9)},
         "prefix_check": check,

@@ -50,7 +50,8 @@ class GlueStats(ctypes.Structure):
     """odhip_glue_stats, shim/daala_hip_glue.h."""
     _fields_ = [("calls", ctypes.c_long * 6), ("theta", ctypes.c_long * 4), ("fdct_hits", ctypes.c_long),
                 ("fdct_misses", ctypes.c_long), ("band_hits", ctypes.c_long), ("band_misses", ctypes.c_long),
-                ("dering_launches", ctypes.c_long), ("dering_served", ctypes.c_long), ("batch_ms", ctypes.c_double)]
+                ("dering_launches", ctypes.c_long), ("dering_served", ctypes.c_long), ("batch_ms", ctypes.c_double),
+                ("dering_ms", ctypes.c_double), ("theta_ms", ctypes.c_double)]
 
 
 def reference_available():
@@ -244,7 +245,8 @@ def worker(args):
                       "bands_from_batch": st.theta[0] - st0.theta[0],
                       "bands_left_to_reference": st.theta[1] + st.theta[2] - st0.theta[1] - st0.theta[2],
                       "searches_saved": st.theta[3] - st0.theta[3],
-                      "batch_ms": st.batch_ms - st0.batch_ms,
+                      "batch_ms": st.batch_ms - st0.batch_ms, "dering_ms": st.dering_ms - st0.dering_ms,
+                      "theta_ms": st.theta_ms - st0.theta_ms,
                       "dering_served": st.dering_served - st0.dering_served}), flush=True)
     return 0
 

@@ -247,18 +247,25 @@ void odhip_glue_cached_dct_vtbl(odhip_dct_func_2d fdct[5], odhip_dct_func_2d idc
 }
 
 double odhip_glue_batch_ms;   /* wall time spent in the batched GPU passes (incl. PCIe both ways), all threads */
+double odhip_glue_dering_ms;  /* ... inside odhip_dering_cache_call (launches, copies and served superblocks) */
+double odhip_glue_theta_ms;   /* ... inside the pvq_theta calls served from the band cache (incl. batched pricing) */
 static volatile int g_ms_lock;
+static void ms_add(double *acc, const struct timespec *a) {
+  struct timespec b;
+  clock_gettime(CLOCK_MONOTONIC, &b);
+  while (__atomic_exchange_n(&g_ms_lock, 1, __ATOMIC_ACQUIRE)) {
+  }
+  *acc += (b.tv_sec - a->tv_sec)*1e3 + (b.tv_nsec - a->tv_nsec)*1e-6;
+  __atomic_store_n(&g_ms_lock, 0, __ATOMIC_RELEASE);
+}
 static void glue_load_plane_locked(const od_coeff *c, int stride, int nhsb, int nvsb, int xdec);
 static void glue_load_plane(const od_coeff *c, int stride, int nhsb, int nvsb, int xdec) {
   struct timespec a;
   struct timespec b;
   clock_gettime(CLOCK_MONOTONIC, &a);
   glue_load_plane_locked(c, stride, nhsb, nvsb, xdec);
-  clock_gettime(CLOCK_MONOTONIC, &b);
-  while (__atomic_exchange_n(&g_ms_lock, 1, __ATOMIC_ACQUIRE)) {
-  }
-  odhip_glue_batch_ms += (b.tv_sec - a.tv_sec)*1e3 + (b.tv_nsec - a.tv_nsec)*1e-6;
-  __atomic_store_n(&g_ms_lock, 0, __ATOMIC_RELEASE);
+  (void)b;
+  ms_add(&odhip_glue_batch_ms, &a);
 }
 
 /* Advisory lock around the batched GPU pass (odhip_glue_config.gpu_pass_lock). */
@@ -333,6 +340,8 @@ void odhip_glue_get_stats(odhip_glue_stats *st) {
   }
   if (g_dering_cache) odhip_dering_cache_stats(g_dering_cache, &st->dering_launches, &st->dering_served);
   st->batch_ms = odhip_glue_batch_ms;
+  st->dering_ms = odhip_glue_dering_ms;
+  st->theta_ms = odhip_glue_theta_ms;
 }
 
 /* daala_encode_img_in (include/daala/daalaenc.h:118): remembers which encoder the
@@ -433,6 +442,8 @@ int pvq_theta(od_coeff *out, const od_coeff *x0, const od_coeff *r0, int n, int 
         gain_expand = NEXT(expand_fn, "od_gain_expand");
         synthesis = NEXT(synth_fn, "od_pvq_synthesis_partial");
       }
+      struct timespec t_a;
+      clock_gettime(CLOCK_MONOTONIC, &t_a);
       __atomic_fetch_add(&odhip_glue_theta[0], 1, __ATOMIC_RELAXED);
       /* :415-421 with a null reference on a keyframe: the null candidate */
       qg = 0;
@@ -515,6 +526,7 @@ int pvq_theta(od_coeff *out, const od_coeff *x0, const od_coeff *r0, int n, int 
       }
       *vk = best_k;
       *skip_diff += skip_dist - best_dist;
+      ms_add(&odhip_glue_theta_ms, &t_a);
       return qg;
     }
   }
@@ -535,8 +547,13 @@ void od_dering(const void *vtbl, int16_t *y, int ystride, const int16_t *x, int 
         abort();
       }
     }
-    if (odhip_dering_cache_call(g_dering_cache, y, ystride, x, xstride, nhb, nvb, sbx, sby, nhsb, nvsb, xdec,
-     dir, pli, bskip, skip_stride, threshold, overlap, coeff_shift) != 0) {
+    struct timespec t_a;
+    int rc_d;
+    clock_gettime(CLOCK_MONOTONIC, &t_a);
+    rc_d = odhip_dering_cache_call(g_dering_cache, y, ystride, x, xstride, nhb, nvb, sbx, sby, nhsb, nvsb, xdec,
+     dir, pli, bskip, skip_stride, threshold, overlap, coeff_shift);
+    ms_add(&odhip_glue_dering_ms, &t_a);
+    if (rc_d != 0) {
       fprintf(stderr, "daala_hip_glue: odhip_dering_cache_call failed (no CPU fallback)\n");
       abort();
     }

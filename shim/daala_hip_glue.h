@@ -80,6 +80,8 @@ typedef struct odhip_glue_stats {
   long band_hits, band_misses;       /* band cache */
   long dering_launches, dering_served;
   double batch_ms;        /* wall time inside the batched GPU passes, PCIe both ways included */
+  double dering_ms;       /* ... inside the dering cache calls (its launches, copies, served superblocks) */
+  double theta_ms;        /* ... inside the pvq_theta calls served from the band cache (with their pricing) */
 } odhip_glue_stats;
 void odhip_glue_get_stats(odhip_glue_stats *st);
 

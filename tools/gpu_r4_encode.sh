@@ -24,7 +24,7 @@ if [ "${PS:-}" != "" ]; then
 import json,sys
 try:
     d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
-    print({k:d.get(k) for k in ("value","frames","encoder_processes_per_gpu","encoder_threads_per_process","host_cores_available")}, d["seconds"], d["prefix_check"], {k:d["rank0"][k] for k in ("bands_from_batch","bands_left_to_reference","batched_gpu_pass_ms_per_frame")})
+    print({k:d.get(k) for k in ("value","frames","encoder_processes_per_gpu","encoder_threads_per_process","host_cores_available")}, d["seconds"], d["prefix_check"], {k:d["rank0"].get(k) for k in ("batched_gpu_pass_ms_per_frame","dering_cache_ms_per_frame","served_pvq_theta_ms_per_frame","encoder_seconds_per_process")})
 except Exception as e:
     print("parse failed", repr(e))
 PY
