@@ -75,8 +75,16 @@ static void *next_sym(const char *name) {
 }
 #define NEXT(type, name) ((type)next_sym(name))
 
-/* Counters (odhip_glue_get_stats): proof that the calls really went through. */
+/* Counters (odhip_glue_get_stats): proof that the calls really went through.  The hot ones are
+   counted in thread-local copies and folded into the process totals at frame boundaries
+   (odhip_glue_flush_stats): sixteen encoder threads incrementing one shared cache line a million
+   times per frame ran three times slower than sixteen processes (profiles/r4_encode_mode_300frames.json). */
 long odhip_glue_calls[6];
+static __thread long t_calls[6];
+static __thread long t_theta[4];
+static __thread double t_dering_ms;
+static __thread double t_theta_ms;
+void odhip_glue_flush_stats(void);
 
 /* od_state_opt_vtbl_init (src/state.c:346-352): the reference's backend
    dispatch.  With bind_dct_vtbl this is the load-time form of the one
@@ -112,7 +120,7 @@ void od_state_opt_vtbl_init(void *state) {
 }
 
 void od_prefilter_split(od_coeff *c0, int stride, int bs, int f, int hfilter, int vfilter) {
-  __atomic_fetch_add(&odhip_glue_calls[0], 1, __ATOMIC_RELAXED);
+  t_calls[0]++;
   if (!cfg()->bind_filters) {
     typedef void (*fn)(od_coeff *, int, int, int, int, int);
     static fn next;
@@ -125,7 +133,7 @@ void od_prefilter_split(od_coeff *c0, int stride, int bs, int f, int hfilter, in
 
 void od_postfilter_split(od_coeff *c0, int stride, int bs, int f, int q, unsigned char *skip,
  int skip_stride, int hfilter, int vfilter) {
-  __atomic_fetch_add(&odhip_glue_calls[1], 1, __ATOMIC_RELAXED);
+  t_calls[1]++;
   if (!cfg()->bind_filters) {
     typedef void (*fn)(od_coeff *, int, int, int, int, unsigned char *, int, int, int);
     static fn next;
@@ -140,7 +148,7 @@ static void glue_load_plane(const od_coeff *c, int stride, int nhsb, int nvsb, i
 
 void od_apply_prefilter_frame_sbs(od_coeff *c, int stride, int nhsb, int nvsb, int xdec,
  int ydec) {
-  __atomic_fetch_add(&odhip_glue_calls[2], 1, __ATOMIC_RELAXED);
+  t_calls[2]++;
   glue_load_plane(c, stride, nhsb, nvsb, xdec);
   if (!cfg()->bind_filters) {
     typedef void (*fn)(od_coeff *, int, int, int, int, int);
@@ -174,7 +182,7 @@ void odhip_glue_enable_dering_cache(void) {
 
 void od_apply_postfilter_frame_sbs(od_coeff *c, int stride, int nhsb, int nvsb, int xdec,
  int ydec, int q, unsigned char *skip, int skip_stride) {
-  __atomic_fetch_add(&odhip_glue_calls[3], 1, __ATOMIC_RELAXED);
+  t_calls[3]++;
   if (dering_cache_enabled() && g_dering_cache) odhip_dering_cache_begin(g_dering_cache);
   if (odhip_glue_hook_postfilter_frame) {
     static odhip_glue_postfilter_fn next;
@@ -193,7 +201,7 @@ void od_apply_postfilter_frame_sbs(od_coeff *c, int stride, int nhsb, int nvsb, 
 
 double pvq_search_rdo_double(const int16_t *xcoeff, int n, int k, od_coeff *ypulse, double g2,
  double pvq_norm_lambda, int prev_k) {
-  __atomic_fetch_add(&odhip_glue_calls[4], 1, __ATOMIC_RELAXED);
+  t_calls[4]++;
   if (!cfg()->bind_search) {
     typedef double (*fn)(const int16_t *, int, int, od_coeff *, double, double, int);
     static fn next;
@@ -250,12 +258,34 @@ double odhip_glue_batch_ms;   /* wall time spent in the batched GPU passes (incl
 double odhip_glue_dering_ms;  /* ... inside odhip_dering_cache_call (launches, copies and served superblocks) */
 double odhip_glue_theta_ms;   /* ... inside the pvq_theta calls served from the band cache (incl. batched pricing) */
 static volatile int g_ms_lock;
-static void ms_add(double *acc, const struct timespec *a) {
+static double ms_since(const struct timespec *a) {
   struct timespec b;
   clock_gettime(CLOCK_MONOTONIC, &b);
+  return (b.tv_sec - a->tv_sec)*1e3 + (b.tv_nsec - a->tv_nsec)*1e-6;
+}
+static void ms_add(double *acc, const struct timespec *a) {
+  const double ms = ms_since(a);
   while (__atomic_exchange_n(&g_ms_lock, 1, __ATOMIC_ACQUIRE)) {
   }
-  *acc += (b.tv_sec - a->tv_sec)*1e3 + (b.tv_nsec - a->tv_nsec)*1e-6;
+  *acc += ms;
+  __atomic_store_n(&g_ms_lock, 0, __ATOMIC_RELEASE);
+}
+/* The calling thread's counters and timers into the process totals. */
+void odhip_glue_flush_stats(void) {
+  int i;
+  while (__atomic_exchange_n(&g_ms_lock, 1, __ATOMIC_ACQUIRE)) {
+  }
+  for (i = 0; i < 6; i++) {
+    odhip_glue_calls[i] += t_calls[i];
+    t_calls[i] = 0;
+  }
+  for (i = 0; i < 4; i++) {
+    odhip_glue_theta[i] += t_theta[i];
+    t_theta[i] = 0;
+  }
+  odhip_glue_dering_ms += t_dering_ms;
+  odhip_glue_theta_ms += t_theta_ms;
+  t_dering_ms = t_theta_ms = 0;
   __atomic_store_n(&g_ms_lock, 0, __ATOMIC_RELEASE);
 }
 static void glue_load_plane_locked(const od_coeff *c, int stride, int nhsb, int nvsb, int xdec);
@@ -266,6 +296,7 @@ static void glue_load_plane(const od_coeff *c, int stride, int nhsb, int nvsb, i
   glue_load_plane_locked(c, stride, nhsb, nvsb, xdec);
   (void)b;
   ms_add(&odhip_glue_batch_ms, &a);
+  odhip_glue_flush_stats();
 }
 
 /* Advisory lock around the batched GPU pass (odhip_glue_config.gpu_pass_lock). */
@@ -331,6 +362,7 @@ void odhip_glue_enable_band_cache(void) {
 
 void odhip_glue_get_stats(odhip_glue_stats *st) {
   int i;
+  odhip_glue_flush_stats();
   memset(st, 0, sizeof(*st));
   for (i = 0; i < 6; i++) st->calls[i] = odhip_glue_calls[i];
   for (i = 0; i < 4; i++) st->theta[i] = odhip_glue_theta[i];
@@ -365,6 +397,7 @@ void daala_encode_free(void *enc) {
   if (enc == g_enc) g_enc = NULL;
   g_nbases = 0;
   g_bands_frame = 0;
+  odhip_glue_flush_stats();
   next(enc);
 }
 
@@ -424,10 +457,10 @@ int pvq_theta(od_coeff *out, const od_coeff *x0, const od_coeff *r0, int n, int 
         break;
       }
     }
-    if (!null_ref) __atomic_fetch_add(&odhip_glue_theta[1], 1, __ATOMIC_RELAXED);
+    if (!null_ref) t_theta[1]++;
     else if (!odhip_cache_band(g_cache, 0, t_bs, t_bx >> t_bs, t_by >> t_bs, band, x0, &c)
      || c.n != n || c.q != q0 || c.beta != beta || c.flags[0] == 2 || c.flags[1] == 2) {
-      __atomic_fetch_add(&odhip_glue_theta[2], 1, __ATOMIC_RELAXED);
+      t_theta[2]++;
     }
     else {
       od_coeff y_tmp[128];
@@ -444,7 +477,7 @@ int pvq_theta(od_coeff *out, const od_coeff *x0, const od_coeff *r0, int n, int 
       }
       struct timespec t_a;
       clock_gettime(CLOCK_MONOTONIC, &t_a);
-      __atomic_fetch_add(&odhip_glue_theta[0], 1, __ATOMIC_RELAXED);
+      t_theta[0]++;
       /* :415-421 with a null reference on a keyframe: the null candidate */
       qg = 0;
       best_dist = c.dist0;
@@ -494,7 +527,7 @@ int pvq_theta(od_coeff *out, const od_coeff *x0, const od_coeff *r0, int n, int 
         for (s = 0; s < 2; s++) {
           double cost;
           if (c.flags[s] != 1) continue;
-          __atomic_fetch_add(&odhip_glue_theta[3], 1, __ATOMIC_RELAXED);
+          t_theta[3]++;
           for (i = 0; i < n; i++) y_tmp[i] = c.y[s][i];
           if (speed != 0) {
             rates[s] = rate(c.gain[s], 0, -1, 0, adapt, y_tmp, c.k[s], n, is_keyframe, pli, speed);
@@ -526,7 +559,7 @@ int pvq_theta(od_coeff *out, const od_coeff *x0, const od_coeff *r0, int n, int 
       }
       *vk = best_k;
       *skip_diff += skip_dist - best_dist;
-      ms_add(&odhip_glue_theta_ms, &t_a);
+      t_theta_ms += ms_since(&t_a);
       return qg;
     }
   }
@@ -539,7 +572,7 @@ int pvq_theta(od_coeff *out, const od_coeff *x0, const od_coeff *r0, int n, int 
 void od_dering(const void *vtbl, int16_t *y, int ystride, const int16_t *x, int xstride, int nhb, int nvb,
  int sbx, int sby, int nhsb, int nvsb, int xdec, int dir[8][8], int pli, unsigned char *bskip,
  int skip_stride, int threshold, int overlap, int coeff_shift) {
-  __atomic_fetch_add(&odhip_glue_calls[5], 1, __ATOMIC_RELAXED);
+  t_calls[5]++;
   if (dering_cache_enabled()) {
     if (!g_dering_cache) {
       if (odhip_init(cfg()->device) != 0 || !(g_dering_cache = odhip_dering_cache_create())) {
@@ -552,7 +585,7 @@ void od_dering(const void *vtbl, int16_t *y, int ystride, const int16_t *x, int 
     clock_gettime(CLOCK_MONOTONIC, &t_a);
     rc_d = odhip_dering_cache_call(g_dering_cache, y, ystride, x, xstride, nhb, nvb, sbx, sby, nhsb, nvsb, xdec,
      dir, pli, bskip, skip_stride, threshold, overlap, coeff_shift);
-    ms_add(&odhip_glue_dering_ms, &t_a);
+    t_dering_ms += ms_since(&t_a);
     if (rc_d != 0) {
       fprintf(stderr, "daala_hip_glue: odhip_dering_cache_call failed (no CPU fallback)\n");
       abort();

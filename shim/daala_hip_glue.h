@@ -84,6 +84,10 @@ typedef struct odhip_glue_stats {
   double theta_ms;        /* ... inside the pvq_theta calls served from the band cache (with their pricing) */
 } odhip_glue_stats;
 void odhip_glue_get_stats(odhip_glue_stats *st);
+/* Folds the calling thread's counters into the process totals (done at every frame's GPU pass, at
+   daala_encode_free and by odhip_glue_get_stats; a host that reads the totals from another thread
+   while encoders run sees them one frame late). */
+void odhip_glue_flush_stats(void);
 
 /* What the glue needs from the reference side beyond its public API: three accessors compiled
    with the reference's headers (they know the layout of od_state / daala_enc_ctx).  In this

@@ -38,6 +38,7 @@ long odhip_interposed_dering[2];      /* batched launches, calls served */
 /* ODHIP_INTERPOSE_REPORT=1: print the call counters on stderr at exit (for
    processes the test cannot ask, i.e. the reference's encoder_example). */
 __attribute__((destructor)) static void interpose_report(void) {
+  odhip_glue_flush_stats();
   if (env_on("ODHIP_INTERPOSE_REPORT")) {
     fprintf(stderr, "odhip_interposed_calls %ld %ld %ld %ld %ld %ld\n", odhip_glue_calls[0],
      odhip_glue_calls[1], odhip_glue_calls[2], odhip_glue_calls[3], odhip_glue_calls[4], odhip_glue_calls[5]);
