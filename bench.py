@@ -216,6 +216,21 @@ def stage_roofline(name, kernels_note, ab_bytes, ms_alone, in_step, pmc, pmc_key
     return out
 
 
+def host_cpu_quota():
+    """CPUs this process may use: the affinity mask capped by the cgroup CPU quota (cpu.max), which
+    `nproc` and the affinity mask do not show - the GPU boxes of this pool expose 256 logical CPUs
+    under a quota of 16."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(round(int(quota) / float(period)))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def _pin(core):
     try:
         os.sched_setaffinity(0, {core})
@@ -719,7 +734,7 @@ def encode_mode(args, D, torch, dist, rank, world, local_rank):
         "value": nframes / t_job, "unit": "frames/s", "n_gpus": world, "frames": nframes,
         "encoder_processes_per_gpu": P, "encoder_threads_per_process": max(1, args.threads_per_proc),
         "encoders_per_gpu": P * max(1, args.threads_per_proc),
-        "host_cores_available": len(cores), "gpu_pass_lock": bool(args.gpu_lock),
+        "host_cores_available": len(cores), "host_cpu_quota": host_cpu_quota(), "gpu_pass_lock": bool(args.gpu_lock),
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "data": "synthetic",
         "dtype": "int32 (lifting DCT/filters) + f64 (PVQ search)",
         "config": {"workload": "configs[4]: %d-frame %dx%d all-intra encode (-v 20, complexity 7), frame i -> "
@@ -742,11 +757,11 @@ def encode_mode(args, D, torch, dist, rank, world, local_rank):
                   "encoder_seconds_per_process": [round(st["seconds"], 2) for st in stats],
                   "stage_blocks_per_s": blocks_per_frame() * nf0 / max(batch_ms * 1e-3, 1e-9)},
         "prefix_check": check,
-        "note": "frames/s of the whole job (barrier to barrier, max over ranks); every encoder process is bound "
-                "by the reference's sequential entropy coder at ~1 frame/s, so a GPU serves several of them: the "
-                "batched GPU passes take %.0f ms of each frame (rank0.batched_gpu_pass_ms_per_frame); the job "
-                "scales with host cores until the GPU passes of P processes saturate the device"
-                % (batch_ms / max(1, nf0)),
+        "note": "frames/s of the whole job (barrier to barrier, max over ranks); every encoder context is bound "
+                "by the reference's sequential entropy coder at ~0.9 frames/s per host core, so a GPU serves many "
+                "of them (processes and / or threads): the batched GPU passes take %.0f ms of each frame "
+                "(rank0.batched_gpu_pass_ms_per_frame); the job scales with the host cores the box grants "
+                "(host_cpu_quota: the cgroup quota, not the 256 logical CPUs it shows)" % (batch_ms / max(1, nf0)),
     }
     print(json.dumps(line))
     if made:

@@ -38,20 +38,19 @@ typedef struct odhip_glue_config {
   int check_dering;      /* every served od_dering superblock against od_dering */
   /* Several encoder processes sharing one GPU (bench.py --procs-per-gpu): 1 = the batched GPU
      pass of a frame (pyramids + band stage, ~5-10 ms alone) is taken under an advisory lock on
-     /tmp/odhip_glue_gpu<device>.lock, one process at a time.  Without it the passes of more than
-     ~16 processes time-slice against each other (profiles/r4_encode_mode_300frames.json: 12 ms
-     per frame with 8 processes, 216 ms with 32). */
+     /tmp/odhip_glue_gpu<device>.lock, one process at a time.  Measured SLOWER than letting the
+     passes overlap (profiles/r4_encode_mode_300frames.json); kept as an option, off by default. */
   int gpu_pass_lock;
 } odhip_glue_config;
 
 /* Threads.  The configuration is per process; the state the batched bindings keep between calls
    (frame cache, band cache, dering cache, the encoder and the block a pvq_theta call belongs to) is
    per HOST THREAD, created on a thread's first use: any number of encoder contexts may run in
-   different threads of one process and share its HIP context - which is how more than ~16 encoders
-   share one GPU (processes beyond the device's VMIDs evict each other:
-   profiles/r4_encode_mode_300frames.json).  One encoder per thread at a time; counters are totals
-   over all threads except the cache hit / miss / dering figures of odhip_glue_get_stats, which are
-   the calling thread's. */
+   different threads of one process and share its HIP context (16 encoder threads in one process:
+   7.9 ms of GPU passes per frame, 16 processes: 50 ms - profiles/r4_encode_mode_300frames.json).
+   One encoder per thread at a time; the hot counters are counted per thread and folded into the
+   process totals at frame boundaries (odhip_glue_flush_stats); the cache hit / miss / dering
+   figures of odhip_glue_get_stats are the calling thread's. */
 
 /* All per-call surfaces bound, no batched binding, no checks, device 0. */
 void odhip_glue_default_config(odhip_glue_config *cfg);
