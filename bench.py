@@ -754,6 +754,7 @@ def encode_mode(args, D, torch, dist, rank, world, local_rank):
                   "batched_gpu_pass_ms_per_frame": batch_ms / max(1, nf0),
                   "dering_cache_ms_per_frame": sum(st.get("dering_ms", 0) for st in stats) / max(1, nf0),
                   "served_pvq_theta_ms_per_frame": sum(st.get("theta_ms", 0) for st in stats) / max(1, nf0),
+                  "od_compute_dist_served_per_frame": sum(st.get("dist_served", 0) for st in stats) / max(1, nf0),
                   "encoder_seconds_per_process": [round(st["seconds"], 2) for st in stats],
                   "stage_blocks_per_s": blocks_per_frame() * nf0 / max(batch_ms * 1e-3, 1e-9)},
         "prefix_check": check,

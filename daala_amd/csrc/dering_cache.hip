@@ -51,6 +51,15 @@ struct odhip_dering_cache {
     bool valid;
     int16_t *h_y;        /* pinned, whole filtered plane, row stride = the plane's xstride */
     size_t cap;
+    /* luma passes of a frame whose source picture is known (odhip_dering_cache_set_source): the
+       distortion parts of every 8x8 block of (source, this filtered plane), and the per-superblock
+       distortions finished from them on first request */
+    double *h_parts = nullptr;
+    size_t parts_cap = 0;
+    bool have_parts = false;
+    bool dist_ready = false;
+    int dist_key[3] = {0, 0, 0};      /* use_masking, flat_qm, coded_quantizer of `dist` */
+    std::vector<double> dist;
   };
   std::vector<Result> results;
   int32_t *d_dirs = nullptr;
@@ -63,6 +72,16 @@ struct odhip_dering_cache {
   odhip_ctx *ctx = nullptr;
   long launches = 0;
   long served = 0;
+  /* the source picture of the frame (luma, 8-bit): host copy for the identity check of a served
+     distortion, device copy for the parts kernel */
+  const uint8_t *src_h = nullptr;
+  const uint8_t *src_d = nullptr;
+  int src_stride = 0;
+  int src_use_masking = 0;
+  int src_flat = 0;
+  double *d_parts = nullptr;
+  size_t d_parts_cap = 0;
+  long dist_served = 0;
 };
 
 namespace {
@@ -157,6 +176,33 @@ int run_pass(odhip_dering_cache *c, int pli, odhip_dering_cache::Result &r) {
   if (rc) return rc;
   ODHIP_TRY(hipMemcpyAsync(r.h_y, p.d_y, ybytes, hipMemcpyDeviceToHost, c->stream));
   if (pli == 0) ODHIP_TRY(hipMemcpyAsync(c->h_dirs, c->d_dirs, dbytes, hipMemcpyDeviceToHost, c->stream));
+  r.have_parts = false;
+  r.dist_ready = false;
+  if (pli == 0 && c->src_d) {
+    /* the level search compares every filtered superblock with the source (od_compute_dist,
+       src/encode.c:2776-2801): the device part of all of them now, on the planes already here */
+    const int w = p.nhsb*64;
+    const int h = p.nvsb*64;
+    const size_t pbytes = sizeof(double)*(size_t)3*(w >> 3)*(h >> 3);
+    {
+      void *q = c->d_parts;
+      const int rcg = grow(&q, &c->d_parts_cap, pbytes);
+      if (rcg) return rcg;
+      c->d_parts = (double *)q;
+    }
+    if (pbytes > r.parts_cap) {
+      if (r.h_parts) ODHIP_TRY(hipHostFree(r.h_parts));
+      r.h_parts = nullptr;
+      r.parts_cap = 0;
+      ODHIP_TRY(hipHostMalloc((void **)&r.h_parts, pbytes, hipHostMallocDefault));
+      r.parts_cap = pbytes;
+    }
+    const int rcd = odhip_dist_parts_px16(c->d_parts, c->src_d, c->src_stride, p.d_y, p.xstride, 1, w, h, 4,
+     c->src_use_masking, c->src_flat, c->stream);
+    if (rcd) return rcd;
+    ODHIP_TRY(hipMemcpyAsync(r.h_parts, c->d_parts, pbytes, hipMemcpyDeviceToHost, c->stream));
+    r.have_parts = true;
+  }
   ODHIP_TRY(hipStreamSynchronize(c->stream));
   if (pli == 0) c->have_dirs = true;
   c->launches++;
@@ -196,7 +242,9 @@ extern "C" void odhip_dering_cache_destroy(odhip_dering_cache *c) {
   }
   for (auto &r : c->results) {
     if (r.h_y) (void)hipHostFree(r.h_y);
+    if (r.h_parts) (void)hipHostFree(r.h_parts);
   }
+  if (c->d_parts) (void)hipFree(c->d_parts);
   if (c->d_dirs) (void)hipFree(c->d_dirs);
   if (c->h_dirs) (void)hipHostFree(c->h_dirs);
   if (c->d_thr) (void)hipFree(c->d_thr);
@@ -210,8 +258,75 @@ extern "C" void odhip_dering_cache_destroy(odhip_dering_cache *c) {
 extern "C" void odhip_dering_cache_begin(odhip_dering_cache *c) {
   if (!c) return;
   for (auto &p : c->planes) p.loaded = false;
-  for (auto &r : c->results) r.valid = false;     /* the pinned buffers are kept for the next frame */
+  for (auto &r : c->results) {     /* the pinned buffers are kept for the next frame */
+    r.valid = false;
+    r.have_parts = false;
+    r.dist_ready = false;
+  }
   c->have_dirs = false;
+  c->src_h = c->src_d = nullptr;
+}
+
+/* The frame's luma source picture (8-bit samples, host and device copies of the same plane, row
+   stride in samples; the planes od_ref_buf_to_coeff converts, i.e. the padded input): from now
+   until the next odhip_dering_cache_begin every luma pass also computes the distortion parts of its
+   output against it.  use_masking / flat_qm: the encoder's od_compute_dist settings. */
+extern "C" int odhip_dering_cache_set_source(odhip_dering_cache *c, const uint8_t *h_px, const uint8_t *d_px,
+ int stride, int use_masking, int flat_qm) {
+  if (!c || !h_px || !d_px || stride <= 0) return ODHIP_EINVAL;
+  c->src_h = h_px;
+  c->src_d = d_px;
+  c->src_stride = stride;
+  c->src_use_masking = use_masking != 0;
+  c->src_flat = flat_qm != 0;
+  return ODHIP_SUCCESS;
+}
+
+/* od_compute_dist(enc, x, y, 64) of the level search, served when x IS superblock (sbx, sby) of the
+   source picture and y IS that superblock of the luma pass with this threshold (both verified
+   sample by sample: nothing is assumed about the caller's call order): 1 and *dist, or 0 when the
+   cache cannot vouch for it (the caller runs the C function). */
+extern "C" int odhip_dering_cache_dist(odhip_dering_cache *c, const od_coeff *x, const od_coeff *y, int n, int sbx,
+ int sby, int threshold, int use_masking, int flat_qm, int coded_quantizer, double *dist) {
+  if (!c || !x || !y || !dist || n != 64 || !c->src_h) return 0;
+  const odhip_dering_cache::Plane &p = c->planes[0];
+  if (!p.loaded || sbx < 0 || sby < 0 || sbx >= p.nhsb || sby >= p.nvsb) return 0;
+  if ((use_masking != 0) != (c->src_use_masking != 0) || (flat_qm != 0) != (c->src_flat != 0)) return 0;
+  odhip_dering_cache::Result *hit = nullptr;
+  for (auto &r : c->results) {
+    if (r.valid && r.pli == 0 && r.threshold == threshold && r.have_parts) {
+      hit = &r;
+      break;
+    }
+  }
+  if (!hit) return 0;
+  const uint8_t *sp = c->src_h + (long)sby*64*c->src_stride + (long)sbx*64;
+  const int16_t *fp = hit->h_y + (long)sby*64*p.xstride + (long)sbx*64;
+  for (int i = 0; i < 64; i++) {
+    for (int j = 0; j < 64; j++) {
+      if (x[i*64 + j] != ((int)sp[(long)i*c->src_stride + j] - 128) << 4) return 0;
+      if (y[i*64 + j] != fp[(long)i*p.xstride + j]) return 0;
+    }
+  }
+  if (!hit->dist_ready || hit->dist_key[0] != (use_masking != 0) || hit->dist_key[1] != (flat_qm != 0)
+   || hit->dist_key[2] != coded_quantizer) {
+    hit->dist.resize((size_t)p.nhsb*p.nvsb);
+    if (odhip_dist_finish(hit->dist.data(), hit->h_parts, 1, p.nhsb*64, p.nvsb*64, 4, use_masking, flat_qm,
+     coded_quantizer) != ODHIP_SUCCESS) {
+      return 0;
+    }
+    hit->dist_key[0] = use_masking != 0;
+    hit->dist_key[1] = flat_qm != 0;
+    hit->dist_key[2] = coded_quantizer;
+    hit->dist_ready = true;
+  }
+  *dist = hit->dist[(size_t)sby*p.nhsb + sbx];
+  c->dist_served++;
+  return 1;
+}
+
+extern "C" long odhip_dering_cache_dist_served(const odhip_dering_cache *c) {
+  return c ? c->dist_served : 0;
 }
 
 extern "C" void odhip_dering_cache_stats(const odhip_dering_cache *c, long *launches, long *served) {
@@ -275,7 +390,15 @@ extern "C" int odhip_dering_cache_call(odhip_dering_cache *c, int16_t *y, int ys
   }
   if (!hit) {
     if (!spare) {
-      c->results.push_back(odhip_dering_cache::Result{pli, threshold, overlap, coeff_shift, false, nullptr, 0});
+      odhip_dering_cache::Result fresh;
+      fresh.pli = pli;
+      fresh.threshold = threshold;
+      fresh.overlap = overlap;
+      fresh.coeff_shift = coeff_shift;
+      fresh.valid = false;
+      fresh.h_y = nullptr;
+      fresh.cap = 0;
+      c->results.push_back(fresh);
       spare = &c->results.back();
     }
     spare->pli = pli;

@@ -30,6 +30,12 @@ constexpr int kP = kTile + 1;
 struct DistArgs {
   const od_coeff *x;
   const od_coeff *y;
+  /* odhip_dist_parts_px16: x as 8-bit source samples ((p - 128) << 4, od_ref_buf_to_coeff,
+     src/state.c:1231-1237) and y as the int16 plane od_dering writes, each with its own row stride */
+  const uint8_t *x8;
+  const int16_t *y16;
+  int x8_stride;
+  int y16_stride;
   double *parts;
   int w;
   int h;
@@ -70,9 +76,15 @@ __global__ __launch_bounds__(256) void k_dist_parts(DistArgs a) {
     int xv = 0;
     int yv = 0;
     if (r < th && c < tw) {
-      const long g = plane + (long)(y0 + r)*a.w + x0 + c;
-      xv = a.x[g];
-      yv = a.y[g];
+      if (a.x8) {
+        xv = ((int)a.x8[(long)blockIdx.z*a.x8_stride*a.h + (long)(y0 + r)*a.x8_stride + x0 + c] - 128) << 4;
+        yv = a.y16[(long)blockIdx.z*a.y16_stride*a.h + (long)(y0 + r)*a.y16_stride + x0 + c];
+      }
+      else {
+        const long g = plane + (long)(y0 + r)*a.w + x0 + c;
+        xv = a.x[g];
+        yv = a.y[g];
+      }
     }
     X[r*kP + c] = xv;
     Y[r*kP + c] = yv;
@@ -155,6 +167,38 @@ extern "C" int odhip_dist_parts(double *d_parts, const od_coeff *d_x, const od_c
   DistArgs a;
   a.x = d_x;
   a.y = d_y;
+  a.x8 = nullptr;
+  a.y16 = nullptr;
+  a.x8_stride = a.y16_stride = 0;
+  a.parts = d_parts;
+  a.w = w;
+  a.h = h;
+  a.n = n;
+  a.use_masking = use_masking != 0;
+  a.flat = flat_qm != 0;
+  const dim3 grid((w + kTile - 1)/kTile, (h + kTile - 1)/kTile, nplanes);
+  if (grid.y > 65535u || grid.z > 65535u) return ODHIP_EINVAL;
+  k_dist_parts<<<grid, 256, 0, (hipStream_t)stream>>>(a);
+  return odhip_check_launch();
+}
+
+/* odhip_dist_parts with x given as 8-bit source samples and y as an int16 plane (what the deringing
+   level search compares, src/encode.c:2776-2801: the source picture against od_dering's output). */
+extern "C" int odhip_dist_parts_px16(double *d_parts, const uint8_t *d_x8, int x8_stride, const int16_t *d_y16,
+ int y16_stride, int nplanes, int w, int h, int bs, int use_masking, int flat_qm, odhip_stream stream) {
+  if (!d_parts || !d_x8 || !d_y16 || nplanes <= 0 || bs < 1 || bs >= ODHIP_NBSIZES || x8_stride < w
+   || y16_stride < w) {
+    return ODHIP_EINVAL;
+  }
+  const int n = 4 << bs;
+  if (w <= 0 || h <= 0 || w % n || h % n) return ODHIP_EINVAL;
+  DistArgs a;
+  a.x = nullptr;
+  a.y = nullptr;
+  a.x8 = d_x8;
+  a.y16 = d_y16;
+  a.x8_stride = x8_stride;
+  a.y16_stride = y16_stride;
   a.parts = d_parts;
   a.w = w;
   a.h = h;

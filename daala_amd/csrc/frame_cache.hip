@@ -198,6 +198,18 @@ void odhip_cache_stats(const odhip_frame_cache *c, long *hits, long *misses) {
   if (misses) *misses = c->misses;
 }
 
+/* The 8-bit source samples of a loaded plane, on the host (pinned) and on the device: what
+   od_ref_buf_to_coeff made the coefficients of (valid until the next load of that slot). */
+int odhip_cache_plane_pixels(const odhip_frame_cache *c, int pli, const uint8_t **h_px, const uint8_t **d_px,
+ int *w, int *h) {
+  if (!c || pli < 0 || pli >= 4 || !c->planes[pli].valid) return ODHIP_EINVAL;
+  if (h_px) *h_px = c->planes[pli].h_px;
+  if (d_px) *d_px = c->planes[pli].d_px;
+  if (w) *w = c->planes[pli].w;
+  if (h) *h = c->planes[pli].h;
+  return ODHIP_SUCCESS;
+}
+
 int odhip_cache_load_plane(odhip_frame_cache *c, int pli, const od_coeff *coef, int stride,
  int w, int h, int dec) {
   if (!c || pli < 0 || pli >= 4 || !coef || stride != w || (dec != 0 && dec != 1)) {

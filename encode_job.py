@@ -33,7 +33,12 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-REFERENCE_LIB = os.environ.get("ODHIP_REFERENCE_LIB", os.path.join(ROOT, "oracle", "_ref", "libdaalaref.so"))
+# The host encoder.  libdaalaref_distglue.so = the same build with the shim's hook in front of the file-static
+# od_compute_dist (oracle/Makefile DISTGLUE: the level search's distortions from the batched passes); without it
+# (or with ODHIP_REFERENCE_LIB pointing at another build) that binding is simply not taken.
+_DISTGLUE = os.path.join(ROOT, "oracle", "_ref", "libdaalaref_distglue.so")
+REFERENCE_LIB = os.environ.get("ODHIP_REFERENCE_LIB", _DISTGLUE if os.path.exists(_DISTGLUE)
+                               else os.path.join(ROOT, "oracle", "_ref", "libdaalaref.so"))
 GLUE_LIB = os.path.join(ROOT, "shim", "libdaalahipglue.so")
 
 _state = {}
@@ -43,7 +48,7 @@ class GlueConfig(ctypes.Structure):
     """odhip_glue_config, shim/daala_hip_glue.h."""
     _fields_ = [(n, ctypes.c_int) for n in (
         "device", "bind_filters", "bind_search", "bind_dering", "bind_dct_vtbl", "frame_cache", "band_cache",
-        "dering_cache", "pic_w", "pic_h", "check_rates", "check_dering", "gpu_pass_lock")]
+        "dering_cache", "pic_w", "pic_h", "check_rates", "check_dering", "gpu_pass_lock", "dist_cache", "check_dist")]
 
 
 class GlueStats(ctypes.Structure):
@@ -51,14 +56,16 @@ class GlueStats(ctypes.Structure):
     _fields_ = [("calls", ctypes.c_long * 6), ("theta", ctypes.c_long * 4), ("fdct_hits", ctypes.c_long),
                 ("fdct_misses", ctypes.c_long), ("band_hits", ctypes.c_long), ("band_misses", ctypes.c_long),
                 ("dering_launches", ctypes.c_long), ("dering_served", ctypes.c_long), ("batch_ms", ctypes.c_double),
-                ("dering_ms", ctypes.c_double), ("theta_ms", ctypes.c_double)]
+                ("dering_ms", ctypes.c_double), ("theta_ms", ctypes.c_double), ("dist_served", ctypes.c_long),
+                ("dist_left", ctypes.c_long)]
 
 
 def reference_available():
     return os.path.exists(REFERENCE_LIB) and os.path.exists(GLUE_LIB)
 
 
-def load_batched_encoder(w, h, device=0, dering_cache=True, check_rates=False, gpu_pass_lock=False):
+def load_batched_encoder(w, h, device=0, dering_cache=True, check_rates=False, gpu_pass_lock=False, dist_cache=True,
+                         check_dist=False):
     """(reference encoder library, glue library) with the batched GPU stage bound; once per
     process, and only in a process that has not loaded the reference library before."""
     if "r" in _state:
@@ -82,6 +89,8 @@ def load_batched_encoder(w, h, device=0, dering_cache=True, check_rates=False, g
     cfg.pic_w, cfg.pic_h = int(w), int(h)
     cfg.check_rates = int(bool(check_rates))
     cfg.gpu_pass_lock = int(bool(gpu_pass_lock))
+    cfg.dist_cache = int(bool(dist_cache and dering_cache))
+    cfg.check_dist = int(bool(check_dist))
     rc = glue.odhip_glue_configure(ctypes.byref(cfg))
     if rc != 0:
         raise RuntimeError("odhip_glue_configure failed with code %d (no CPU fallback exists)" % rc)
@@ -247,6 +256,7 @@ def worker(args):
                       "searches_saved": st.theta[3] - st0.theta[3],
                       "batch_ms": st.batch_ms - st0.batch_ms, "dering_ms": st.dering_ms - st0.dering_ms,
                       "theta_ms": st.theta_ms - st0.theta_ms,
+                      "dist_served": st.dist_served - st0.dist_served, "dist_left": st.dist_left - st0.dist_left,
                       "dering_served": st.dering_served - st0.dering_served}), flush=True)
     return 0
 

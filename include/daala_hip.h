@@ -789,6 +789,19 @@ int odhip_dering_cache_call(odhip_dering_cache *c, int16_t *y, int ystride, cons
  int nhb, int nvb, int sbx, int sby, int nhsb, int nvsb, int xdec, int dir[8][8], int pli,
  unsigned char *bskip, int skip_stride, int threshold, int overlap, int coeff_shift);
 void odhip_dering_cache_stats(const odhip_dering_cache *c, long *launches, long *served);
+/* The level search's distortions (od_compute_dist, src/encode.c:1170-1226, called six times per
+   superblock at :2776-2801) from the same batched passes: after odhip_dering_cache_begin, hand the
+   frame's luma source picture (8-bit samples; host and device copies, e.g. odhip_cache_plane_pixels
+   of the frame cache) to odhip_dering_cache_set_source - every luma pass then also computes the
+   distortion parts of its whole output against it (odhip_dist_parts_px16) - and ask
+   odhip_dering_cache_dist in front of od_compute_dist: it answers (1, *dist) only when x IS the
+   source superblock and y IS the cached filtered superblock of that threshold (both compared sample
+   by sample), with the host-libm finish of odhip_dist_finish; otherwise 0 and the C function runs. */
+int odhip_dering_cache_set_source(odhip_dering_cache *c, const uint8_t *h_px, const uint8_t *d_px, int stride,
+ int use_masking, int flat_qm);
+int odhip_dering_cache_dist(odhip_dering_cache *c, const od_coeff *x, const od_coeff *y, int n, int sbx, int sby,
+ int threshold, int use_masking, int flat_qm, int coded_quantizer, double *dist);
+long odhip_dering_cache_dist_served(const odhip_dering_cache *c);
 
 /* ---- od_compute_dist: the block-size RDO's distortion ----------
 
@@ -814,6 +827,8 @@ double od_compute_dist_hip(const od_coeff *x, const od_coeff *y, int n, int use_
  int coded_quantizer);
 int odhip_dist_parts(double *d_parts, const od_coeff *d_x, const od_coeff *d_y, int nplanes, int w,
  int h, int bs, int use_masking, int flat_qm, odhip_stream stream);
+int odhip_dist_parts_px16(double *d_parts, const uint8_t *d_x8, int x8_stride, const int16_t *d_y16,
+ int y16_stride, int nplanes, int w, int h, int bs, int use_masking, int flat_qm, odhip_stream stream);
 int odhip_dist_finish(double *dist, const double *parts, int nplanes, int w, int h, int bs,
  int use_masking, int flat_qm, int coded_quantizer);
 
@@ -884,6 +899,10 @@ odhip_frame_cache *odhip_cache_create(void);
 void odhip_cache_destroy(odhip_frame_cache *c);
 void odhip_cache_set_picture(odhip_frame_cache *c, int pic_w, int pic_h);
 void odhip_cache_make_current(odhip_frame_cache *c);
+/* The 8-bit source samples of a loaded plane (host and device copies; valid until the slot is
+   loaded again): the input of odhip_dering_cache_set_source. */
+int odhip_cache_plane_pixels(const odhip_frame_cache *c, int pli, const uint8_t **h_px, const uint8_t **d_px,
+ int *w, int *h);
 int odhip_cache_load_plane(odhip_frame_cache *c, int pli, const od_coeff *coef,
  int stride, int w, int h, int dec);
 int odhip_cache_lookup(odhip_frame_cache *c, const od_coeff *in, int in_stride,

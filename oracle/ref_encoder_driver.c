@@ -288,6 +288,16 @@ REF_EXPORT int ref_enc_band_setup(const void *encp, int *quantizer, int *use_mas
   return enc->state.frame_type == OD_I_FRAME && !enc->use_haar_wavelet && !OD_LOSSLESS(enc);
 }
 
+/* What od_compute_dist reads from the encoder besides its arguments (src/encode.c:1113-1226):
+   activity masking on / off and whether the flat quantisation matrices are in use; for
+   odhip_dering_cache_set_source (the level search's distortions from the batched passes). */
+REF_EXPORT void ref_enc_dist_setup(const void *encp, int *use_masking, int *flat_qm) {
+  const daala_enc_ctx *enc;
+  enc = (const daala_enc_ctx *)encp;
+  *use_masking = enc->use_activity_masking;
+  *flat_qm = enc->qm == OD_FLAT_QM;
+}
+
 /* Quantiser set-up the reference derives per frame on the host (SURVEY.md
    8(a) row a17): after encoding one frame at `quality`, copies out
    state.quantizer, state.pvq_qm_q4[pli][OD_QM_SIZE] (od_interp_qm,

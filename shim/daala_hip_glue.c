@@ -82,6 +82,8 @@ static void *next_sym(const char *name) {
 long odhip_glue_calls[6];
 static __thread long t_calls[6];
 static __thread long t_theta[4];
+static __thread long t_dist[2];
+long odhip_glue_dist[2];       /* od_compute_dist calls served from the dering cache / left to the C function */
 static __thread double t_dering_ms;
 static __thread double t_theta_ms;
 void odhip_glue_flush_stats(void);
@@ -180,10 +182,78 @@ void odhip_glue_enable_dering_cache(void) {
   cfg()->dering_cache = 1;
 }
 
+/* ---- the level search's distortions from the same passes (dist_cache) -------------------
+   The six od_compute_dist calls per superblock of the level search (src/encode.c:2776-2801)
+   compare the SOURCE picture with the unfiltered reconstruction and with od_dering's five outputs.
+   The frame cache holds the source picture, the dering cache the outputs: at the frame boundary
+   the luma source goes to odhip_dering_cache_set_source, every luma pass then also computes the
+   distortion parts of its whole output, and odhip_glue_compute_dist - called in front of the
+   reference's file-static od_compute_dist by the ten lines of oracle/Makefile's DISTGLUE (the glue
+   a maintainer adds) - answers the calls the cache can vouch for:
+   those whose x IS the source superblock and whose y IS the cached output of the od_dering call
+   just before (both compared sample by sample inside odhip_dering_cache_dist).  Every other
+   od_compute_dist call of the encoder (block-size RDO, the unfiltered candidate) runs the C code. */
+static __thread odhip_frame_cache *g_cache;
+static __thread void *g_enc;
+static __thread int t_dd_valid, t_dd_sbx, t_dd_sby, t_dd_thr;
+
+static odhip_dering_cache *thread_dering_cache(void) {
+  if (!g_dering_cache) {
+    if (odhip_init(cfg()->device) != 0 || !(g_dering_cache = odhip_dering_cache_create())) {
+      fprintf(stderr, "daala_hip_glue: odhip_dering_cache_create failed (no CPU fallback)\n");
+      abort();
+    }
+  }
+  return g_dering_cache;
+}
+
+static void glue_dist_source(void) {
+  typedef void (*setup_fn)(const void *, int *, int *);
+  static setup_fn setup;
+  const uint8_t *h_px;
+  const uint8_t *d_px;
+  int w;
+  int h;
+  int masking;
+  int flat;
+  t_dd_valid = 0;
+  if (!cfg()->dist_cache || !g_cache || !g_enc || !g_dering_cache) return;
+  if (odhip_cache_plane_pixels(g_cache, 0, &h_px, &d_px, &w, &h) != 0) return;
+  if (!setup) {
+    setup = (setup_fn)(g_reference ? dlsym(g_reference, "ref_enc_dist_setup")
+     : dlsym(RTLD_DEFAULT, "ref_enc_dist_setup"));
+    if (!setup) return;
+  }
+  setup(g_enc, &masking, &flat);
+  (void)odhip_dering_cache_set_source(g_dering_cache, h_px, d_px, w, masking, flat);
+}
+
+int odhip_glue_compute_dist(const od_coeff *x, const od_coeff *y, int n, int use_masking, int flat_qm,
+ int coded_quantizer, double *out) {
+  if (cfg()->dist_cache && g_dering_cache && t_dd_valid && n == 64) {
+    t_dd_valid = 0;
+    if (odhip_dering_cache_dist(g_dering_cache, x, y, n, t_dd_sbx, t_dd_sby, t_dd_thr, use_masking, flat_qm,
+     coded_quantizer, out)) {
+      t_dist[0]++;
+      return 1;
+    }
+  }
+  t_dist[1]++;
+  return 0;
+}
+
+int odhip_glue_check_dist(void) {
+  return cfg()->check_dist;
+}
+
 void od_apply_postfilter_frame_sbs(od_coeff *c, int stride, int nhsb, int nvsb, int xdec,
  int ydec, int q, unsigned char *skip, int skip_stride) {
   t_calls[3]++;
-  if (dering_cache_enabled() && g_dering_cache) odhip_dering_cache_begin(g_dering_cache);
+  if (dering_cache_enabled()) {
+    /* the frame boundary of the level search (the encoder laps every plane just before it) */
+    odhip_dering_cache_begin(thread_dering_cache());
+    glue_dist_source();
+  }
   if (odhip_glue_hook_postfilter_frame) {
     static odhip_glue_postfilter_fn next;
     if (!next) next = NEXT(odhip_glue_postfilter_fn, "od_apply_postfilter_frame_sbs");
@@ -218,11 +288,10 @@ double pvq_search_rdo_double(const int16_t *xcoeff, int n, int k, od_coeff *ypul
    odhip_cache_load_plane (one batched GPU pyramid), then laps it as before.
    With odhip_install_cached_dct_vtbl bound into od_state.opt_vtbl, every later
    fdct_2d call on that plane is served from the cache. */
-static __thread odhip_frame_cache *g_cache;
 static __thread const od_coeff *g_bases[4];
 static __thread int g_nbases;
 #define g_bands_on (cfg()->band_cache)   /* the batched band stage behind pvq_theta */
-static __thread void *g_enc;         /* the encoder whose frame is being coded */
+/* (g_enc, declared with the distortion binding above: the encoder whose frame is being coded) */
 static __thread int g_bands_frame;   /* the current frame's luma bands are loaded */
 long odhip_glue_theta[4];   /* served from the batch / left to the reference (r0 not null) /
                                left to the reference (other reason) / searches the batch saved */
@@ -282,6 +351,10 @@ void odhip_glue_flush_stats(void) {
   for (i = 0; i < 4; i++) {
     odhip_glue_theta[i] += t_theta[i];
     t_theta[i] = 0;
+  }
+  for (i = 0; i < 2; i++) {
+    odhip_glue_dist[i] += t_dist[i];
+    t_dist[i] = 0;
   }
   odhip_glue_dering_ms += t_dering_ms;
   odhip_glue_theta_ms += t_theta_ms;
@@ -373,6 +446,8 @@ void odhip_glue_get_stats(odhip_glue_stats *st) {
   if (g_dering_cache) odhip_dering_cache_stats(g_dering_cache, &st->dering_launches, &st->dering_served);
   st->batch_ms = odhip_glue_batch_ms;
   st->dering_ms = odhip_glue_dering_ms;
+  st->dist_served = odhip_glue_dist[0];
+  st->dist_left = odhip_glue_dist[1];
   st->theta_ms = odhip_glue_theta_ms;
 }
 
@@ -574,18 +649,18 @@ void od_dering(const void *vtbl, int16_t *y, int ystride, const int16_t *x, int 
  int skip_stride, int threshold, int overlap, int coeff_shift) {
   t_calls[5]++;
   if (dering_cache_enabled()) {
-    if (!g_dering_cache) {
-      if (odhip_init(cfg()->device) != 0 || !(g_dering_cache = odhip_dering_cache_create())) {
-        fprintf(stderr, "daala_hip_glue: odhip_dering_cache_create failed\n");
-        abort();
-      }
-    }
+    (void)thread_dering_cache();
     struct timespec t_a;
     int rc_d;
     clock_gettime(CLOCK_MONOTONIC, &t_a);
     rc_d = odhip_dering_cache_call(g_dering_cache, y, ystride, x, xstride, nhb, nvb, sbx, sby, nhsb, nvsb, xdec,
      dir, pli, bskip, skip_stride, threshold, overlap, coeff_shift);
     t_dering_ms += ms_since(&t_a);
+    /* the od_compute_dist call that follows a luma call of the level search compares its output */
+    t_dd_valid = pli == 0 && rc_d == 0;
+    t_dd_sbx = sbx;
+    t_dd_sby = sby;
+    t_dd_thr = threshold;
     if (rc_d != 0) {
       fprintf(stderr, "daala_hip_glue: odhip_dering_cache_call failed (no CPU fallback)\n");
       abort();

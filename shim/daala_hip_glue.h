@@ -12,6 +12,7 @@
    the three ways of linking it. */
 #ifndef DAALA_HIP_GLUE_H
 #define DAALA_HIP_GLUE_H
+#include <stdint.h>
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -41,7 +42,19 @@ typedef struct odhip_glue_config {
      /tmp/odhip_glue_gpu<device>.lock, one process at a time.  Measured SLOWER than letting the
      passes overlap (profiles/r4_encode_mode_300frames.json); kept as an option, off by default. */
   int gpu_pass_lock;
+  /* With dering_cache and frame_cache: the level search's od_compute_dist calls (src/encode.c:
+     2776-2801) from the same batched passes (odhip_dering_cache_set_source / _dist).  Needs the ten
+     lines of glue in front of the file-static od_compute_dist that call odhip_glue_compute_dist
+     (oracle/Makefile DISTGLUE; README.md); without them nothing is served and nothing changes. */
+  int dist_cache;
+  int check_dist;        /* every served distortion against the C function (abort on a difference) */
 } odhip_glue_config;
+
+/* Called by the reference's od_compute_dist (see dist_cache): 1 and *out when the call is one the
+   dering cache can vouch for, else 0 (run the C function). */
+int odhip_glue_compute_dist(const int32_t *x, const int32_t *y, int n, int use_masking, int flat_qm,
+ int coded_quantizer, double *out);
+int odhip_glue_check_dist(void);
 
 /* Threads.  The configuration is per process; the state the batched bindings keep between calls
    (frame cache, band cache, dering cache, the encoder and the block a pvq_theta call belongs to) is
@@ -81,6 +94,7 @@ typedef struct odhip_glue_stats {
   double batch_ms;        /* wall time inside the batched GPU passes, PCIe both ways included */
   double dering_ms;       /* ... inside the dering cache calls (its launches, copies, served superblocks) */
   double theta_ms;        /* ... inside the pvq_theta calls served from the band cache (with their pricing) */
+  long dist_served, dist_left;       /* od_compute_dist calls served from the dering cache / run in C */
 } odhip_glue_stats;
 void odhip_glue_get_stats(odhip_glue_stats *st);
 /* Folds the calling thread's counters into the process totals (done at every frame's GPU pass, at

@@ -28,11 +28,17 @@ void odhip_glue_startup_config(odhip_glue_config *c) {
   c->dering_cache = env_on("ODHIP_INTERPOSE_DERING_CACHE");
   c->check_rates = getenv("ODHIP_RATE_CHECK") != NULL;
   c->check_dering = getenv("ODHIP_DERING_CHECK") != NULL;
+  /* ODHIP_INTERPOSE_DIST_CACHE=1 (with the dering cache and the frame cache, and a reference build
+     that carries the DISTGLUE lines): the level search's od_compute_dist calls from the batched
+     passes; ODHIP_DIST_CHECK: every served value against the C function */
+  c->dist_cache = env_on("ODHIP_INTERPOSE_DIST_CACHE");
+  c->check_dist = getenv("ODHIP_DIST_CHECK") != NULL;
 }
 
 extern long odhip_interposed_calls[6] __attribute__((alias("odhip_glue_calls")));
 extern long odhip_interposed_theta[4] __attribute__((alias("odhip_glue_theta")));
 extern double odhip_interposed_load_ms __attribute__((alias("odhip_glue_batch_ms")));
+extern long odhip_interposed_dist[2] __attribute__((alias("odhip_glue_dist")));
 long odhip_interposed_dering[2];      /* batched launches, calls served */
 
 /* ODHIP_INTERPOSE_REPORT=1: print the call counters on stderr at exit (for

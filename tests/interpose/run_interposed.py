@@ -85,6 +85,17 @@ if ipo is not None and os.environ.get("ODHIP_INTERPOSE_DERING_CACHE") == "1":
     ipo.odhip_interpose_dering_stats()
     arr = (ctypes.c_long * 2).in_dll(ipo, "odhip_interposed_dering")
     dering = [arr[0], arr[1]]      # batched launches, od_dering calls served from them
+dist_cache = None
+if ipo is not None and os.environ.get("ODHIP_INTERPOSE_DIST_CACHE") == "1":
+    ipo.odhip_glue_flush_stats()
+    arr = (ctypes.c_long * 2).in_dll(ipo, "odhip_interposed_dist")
+    glue_calls = None
+    try:
+        g = (ctypes.c_long * 2).in_dll(r, "ref_dist_glue_calls")
+        glue_calls = [g[0], g[1]]
+    except ValueError:
+        pass
+    dist_cache = {"served": arr[0], "left_to_c": arr[1], "reference_side": glue_calls}
 dist_calls = None
 try:
     # the build with od_compute_dist bound to od_compute_dist_hip counts its calls
@@ -104,5 +115,5 @@ if os.environ.get("PACKET_DIGEST") == "1":
     pkt_digest = hh.hexdigest()
 print(json.dumps({"digest": pkt_digest, "packets": hashlib.sha256(bytes(out[:total])).hexdigest(),
                   "sizes": [sizes[i] for i in range(n)], "calls": calls, "cache": stats, "theta": theta, "dering": dering,
-                  "gpu_batch_ms": gpu_ms, "dist_hip_calls": dist_calls,
+                  "gpu_batch_ms": gpu_ms, "dist_hip_calls": dist_calls, "dist_cache": dist_cache,
                   "encode_seconds": seconds}))

@@ -263,3 +263,39 @@ def test_od_compute_dist_bound_behind_the_block_size_rdo_is_byte_identical():
           "(encode %.2f s vs %.2f s plain C)"
           % (b["dist_hip_calls"], 1e6 * (b["encode_seconds"] - a["encode_seconds"]) / b["dist_hip_calls"],
              b["encode_seconds"], a["encode_seconds"]))
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "oracle", "_ref",
+                                                    "libdaalaref_distglue.so")),
+                    reason="oracle/_ref/libdaalaref_distglue.so not built")
+def test_level_search_distortions_from_the_batched_passes():
+    """The deringing level search's od_compute_dist calls (src/encode.c:2776-2801) served from the
+    same batched passes as its od_dering calls (odhip_dering_cache_set_source / _dist behind the
+    shim's odhip_glue_compute_dist, bound by the DISTGLUE lines of oracle/Makefile): packets stay
+    byte-identical to the plain C encoder's, five of the six calls per searched superblock are served,
+    and with ODHIP_DIST_CHECK every served value was compared bit for bit with the C function's."""
+    import json
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+
+    def run(mode, w, h, **env):
+        e = dict(os.environ)
+        e.update({k: str(v) for k, v in env.items()})
+        p = subprocess.run([sys.executable, os.path.join(here, "interpose", "run_interposed.py"), str(mode), str(w),
+                            str(h)], capture_output=True, text=True, timeout=1500, env=e)
+        assert p.returncode == 0, p.stderr[-2000:]
+        return json.loads(p.stdout.strip().splitlines()[-1])
+
+    for (w, h, nframes) in ((320, 192, 2), (1920, 1080, 1)):
+        env = dict(NFRAMES=nframes, CONTENT="bench", ODHIP_INTERPOSE_PASSTHROUGH=1, ODHIP_CACHE_FDCT_ONLY=1,
+                   REF_LIB="libdaalaref_distglue.so")
+        plain = run(0, w, h, **env)
+        bound = run(3, w, h, ODHIP_INTERPOSE_DERING_CACHE=1, ODHIP_INTERPOSE_DIST_CACHE=1, ODHIP_DIST_CHECK=1, **env)
+        assert bound["sizes"] == plain["sizes"] and bound["packets"] == plain["packets"]
+        dc = bound["dist_cache"]
+        assert dc["served"] > 0 and dc["reference_side"][0] == dc["served"], dc
+        # five served calls per searched superblock (the sixth compares the unfiltered reconstruction)
+        assert dc["served"] % 5 == 0, dc
+        nsb = ((w + 63) // 64) * ((h + 63) // 64) * nframes
+        assert dc["served"] >= 5 * nsb // 2, (dc, nsb)
