@@ -29,10 +29,10 @@ What the kernels keep OFF this floor on purpose: |x_j| and the denominators are 
 integer add + convert - 13 -> 15-16 as executed for the scan alone.
 
 Reading the table: the counts are STATIC (instructions in the loop body of one pulse).  The per-lane
-searches (k_refb_lean_lane, band in registers) are straight-line scans: static = dynamic, 18 per
-candidate against 13 = 0.72 of the minimum; the five extra are v_cvt_f64_u32 of |x_j|, the integer
-denominator + its conversion, and the 4-instruction form of the pulse update (compare, two selects,
-increment).  The row searches (k_refb_lean_row, one band per 16 / 4 lanes, 8 positions per lane) carry,
+searches (k_refb_lean_lane, band in registers) are straight-line scans: static = dynamic, 15.9 per
+candidate against 13 = 0.82 of the minimum (18.1 = 0.72 before round 4 stopped reading y[pos] back
+after a greedy pulse); the extra three are v_cvt_f64_u32 of |x_j| and the integer denominator with
+its conversion.  The row searches (k_refb_lean_row, one band per 16 / 4 lanes, 8 positions per lane) carry,
 per pulse, a FIXED part that the minimum does not have - float-key proposal, DPP max, ballot, two
 64-bit broadcasts, the verification pass over the lane's 8 candidates, the (max, lowest index)
 butterfly of the tail - amortised over only 8 candidates per lane, and their tail loop holds both
