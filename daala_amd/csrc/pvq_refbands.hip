@@ -1221,6 +1221,8 @@ struct RowVector {
   int force;
   double xx;
   double norm_1;
+  double cxy;       /* sum |x_j|*y_j and sum y_j^2 as the last search of the chain left them */
+  double cyy;
   __device__ __forceinline__ void load(const int16_t *src, bool pad) {
     const int16_t *p = src + l*E;
     sg = 0;
@@ -1238,9 +1240,8 @@ struct RowVector {
     od_row_norm<E, G>(ax, &xx, &norm_1);
   }
   __device__ __forceinline__ double search(int n_true, int k, int prev_k, double g2, double lambda) {
-    double yy;
     return od_pvq_search_row<E, G>(ax, y, row, l, n_true, k, prev_k, g2, lambda, force, xx, norm_1,
-     &yy);
+     &cxy, &cyy);
   }
   __device__ __forceinline__ int moment() const {
     int m = 0;
@@ -1294,6 +1295,8 @@ struct RegVector {
   int y[N];
   double xx;
   double norm_1;
+  double cxy;       /* sum |x_j|*y_j and sum y_j^2 as the last search of the chain left them */
+  double cyy;
   __device__ __forceinline__ void load(const int16_t *src, bool pad) {
     const uint4 *p = reinterpret_cast<const uint4 *>(src - SH);
     sg = 0;
@@ -1320,8 +1323,7 @@ struct RegVector {
     od_regs_norm<N>(ax, &xx, &norm_1);
   }
   __device__ __forceinline__ double search(int n_true, int k, int prev_k, double g2, double lambda) {
-    double yy;
-    return od_pvq_search_regs<N>(ax, y, n_true, k, prev_k, g2, lambda, xx, norm_1, &yy);
+    return od_pvq_search_regs<N>(ax, y, n_true, k, prev_k, g2, lambda, xx, norm_1, &cxy, &cyy);
   }
   __device__ __forceinline__ int moment() const {
     int m = 0;

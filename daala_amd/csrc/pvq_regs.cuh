@@ -31,7 +31,7 @@ __device__ __forceinline__ void od_regs_norm(const int (&ax)[N], double *xx_out,
 
 template <int N>
 __device__ __forceinline__ double od_pvq_search_regs(const int (&ax)[N], int (&y)[N], int n, int k,
- int prev_k, double g2, double pvq_norm_lambda, double xx, double norm_1, double *yy_out) {
+ int prev_k, double g2, double pvq_norm_lambda, double xx, double norm_1, double *cxy, double *cyy) {
   const bool padded = n != N;
   /* |x_j| is converted where it is used: a second, double copy of the band costs 2N
      VGPRs and an occupancy step */
@@ -41,12 +41,12 @@ __device__ __forceinline__ double od_pvq_search_regs(const int (&ax)[N], int (&y
   double yy = 0;
   int i = 0;
   if (prev_k > 0 && prev_k <= k) {
-#pragma unroll
-    for (int j = 0; j < N; j++) {
-      xy += OD_XD(j)*y[j];
-      yy += (double)(y[j]*y[j]);
-      i += y[j];
-    }
+    /* The chain's previous search (same vector, prev_k pulses) ended on exactly these sums - integers
+       below 2^53, exact in any order - and left them in *cxy / *cyy: round 4 stopped recomputing
+       them (:116-121 of the reference does, 8 instructions per position per search). */
+    xy = *cxy;
+    yy = *cyy;
+    i = prev_k;
   }
   else if (k > 2) {
     double l1_norm = 0;
@@ -69,16 +69,18 @@ __device__ __forceinline__ double od_pvq_search_regs(const int (&ax)[N], int (&y
     for (int j = 0; j < N; j++) y[j] = 0;
   }
   const int rdo_pulses = 1 + k/4;
-  double delta_rate = __ddiv_rn(3., (double)n);
+  /* n is N or N - 1: the quotients of :154-163 are compile-time constants (correctly rounded, as
+     the divisions are), not a division sequence per search */
+  double delta_rate = padded ? 3./(N - 1) : 3./N;
   double accel_rate = 0.;
   if (k == 1) {
     if (n == 15) {
-      accel_rate = __ddiv_rn(-8., (double)n);
-      delta_rate = __ddiv_rn(4.5, (double)n) - accel_rate;
+      accel_rate = -8./15;
+      delta_rate = 4.5/15 - accel_rate;
     }
     else if (n == 8) {
-      accel_rate = __ddiv_rn(5.7, (double)n);
-      delta_rate = __ddiv_rn(9.3, (double)n) - accel_rate;
+      accel_rate = 5.7/8;
+      delta_rate = 9.3/8 - accel_rate;
     }
   }
   /* Greedy pulses, :165-187. */
@@ -122,8 +124,15 @@ __device__ __forceinline__ double od_pvq_search_regs(const int (&ax)[N], int (&y
   /* rate penalty of each candidate, (lambda*j)*(delta_rate + j*accel_rate):
      constant over the pulses of a search */
   double pen[N];
+  if (k == 1) {
 #pragma unroll
-  for (int j = 0; j < N; j++) pen[j] = (lambda*j)*(delta_rate + j*accel_rate);
+    for (int j = 0; j < N; j++) pen[j] = (lambda*j)*(delta_rate + j*accel_rate);
+  }
+  else {
+    /* accel_rate == 0: delta_rate + j*0. is delta_rate */
+#pragma unroll
+    for (int j = 0; j < N; j++) pen[j] = (lambda*j)*delta_rate;
+  }
   /* (2*t)*norm_1 == t*(2*norm_1): scaling by two is exact */
   const double norm2 = 2*norm_1;
   for (; i < k; i++) {
@@ -168,7 +177,8 @@ __device__ __forceinline__ double od_pvq_search_regs(const int (&ax)[N], int (&y
     yy = yy + (double)(2*yp) + 1;
   }
 #undef OD_XD
-  *yy_out = yy;
+  *cxy = xy;
+  *cyy = yy;
   return __ddiv_rn(xy, 1e-100 + __dsqrt_rn(xx*yy));
 }
 

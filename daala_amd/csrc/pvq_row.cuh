@@ -26,8 +26,8 @@
         comparator; a cheap float key a/b picks the row's proposal W;
      2. every lane checks every one of its candidates against W with the
         reference's two products: it must be an exact duplicate of W (same a and
-        b) or lose to W by a relative margin of 2^-30 (>> the 2^-52 rounding of
-        the products).  Then the sequential scan provably ends on the
+        b) or lose to W by a relative margin of 2^-21 (>> the 2^-52 rounding of
+        the products; round 4: tested with one product against a pre-scaled ratio).  Then the sequential scan provably ends on the
         lowest-indexed duplicate: before it the running best is a clear loser,
         which it beats; after it nothing beats it;
      3. otherwise (a near tie that is not exact, or a float key that picked a
@@ -139,20 +139,17 @@ __device__ __forceinline__ void od_row_norm(const int (&ax)[E], double *xx_out, 
 template <int E, int G>
 __device__ __forceinline__ double od_pvq_search_row(const int (&ax)[E], int (&y)[E], int row,
  int l, int n_true, int k, int prev_k, double g2, double pvq_norm_lambda, int force_scan,
- double xx, double norm_1, double *yy_out) {
+ double xx, double norm_1, double *cxy, double *cyy) {
   constexpr int n = G*E;
   const bool pad_lane = n_true != n && l == G - 1;
   const double lambda = __ddiv_rn(pvq_norm_lambda, 1e-30 + g2);
   double xy = 0;
   double yy = 0;
   int i = 0;
-  if (prev_k > 0 && prev_k <= k) {
-#pragma unroll
-    for (int e = 0; e < E; e++) {
-      xy += (double)ax[e]*y[e];
-      yy += (double)(y[e]*y[e]);
-      i += y[e];
-    }
+  const bool chained = prev_k > 0 && prev_k <= k;
+  if (chained) {
+    /* the chain's previous search (same vector, prev_k pulses) ended on exactly these band-wide sums
+       and left them in *cxy / *cyy: not recomputed (round 4; pvq_regs.cuh) */
   }
   else if (k > 2) {
     double l1 = 0;
@@ -174,12 +171,20 @@ __device__ __forceinline__ double od_pvq_search_row(const int (&ax)[E], int (&y)
 #pragma unroll
     for (int e = 0; e < E; e++) y[e] = 0;
   }
-  xy = grp_sum<G>(xy);
-  yy = grp_sum<G>(yy);
-  i = grp_sum<G>(i);
+  if (chained) {
+    xy = *cxy;
+    yy = *cyy;
+    i = prev_k;
+  }
+  else {
+    xy = grp_sum<G>(xy);
+    yy = grp_sum<G>(yy);
+    i = grp_sum<G>(i);
+  }
   const int rdo_pulses = 1 + k/4;
   const int n_greedy = k - rdo_pulses;
-  const double delta_rate = __ddiv_rn(3., (double)n_true);
+  /* n_true is n or n - 1: compile-time quotients, correctly rounded as the division is */
+  const double delta_rate = n_true == n ? 3./n : 3./(n - 1);
   /* Rows of one wavefront run different pulse counts; the ballots inside the
      loops are wave-wide, so iterate to the maximum of the calling rows with
      per-row predication. */
@@ -204,23 +209,30 @@ __device__ __forceinline__ double od_pvq_search_row(const int (&ax)[E], int (&y)
       }
     }
     /* proposal: best float key of the row, lowest lane on equal keys */
-    const float key = (float)ba*__frcp_rn((float)bb);
-    const float kmax = grp_max<G>(key);
+    /* a proposal only: one v_rcp_f32; the key is a non-negative finite float (a < 2^75), so its bit
+       pattern orders like its value and the row maximum is an integer DPP max */
+    const int key = __float_as_int((float)ba*__builtin_amdgcn_rcpf((float)bb));
+    const int kmax = grp_max<G>(key);
     const unsigned wmask = grp_ballot<G>(key == kmax, row);
     const int wl = wmask ? __ffs(wmask) - 1 : 0;
     const double wa = grp_bcast<G>(ba, row, wl);
     const double wb = grp_bcast<G>(bb, row, wl);
-    /* verification against the proposal */
+    /* verification against the proposal.  Round 4: one product per candidate instead of three -
+       wr = (wa/wb)*(1 - 2^-20) to within 2^-22 (v_rcp_f32 of a denominator below 2^31, once per
+       pulse), so a_j < fl(b_j*wr) implies a_j*wb < wa*b_j*(1 - 2^-21): still a margin 2^30 times
+       the rounding of the reference's two products. */
+    const double wr = (wa*(double)__builtin_amdgcn_rcpf((float)wb))*(1. - 9.5367431640625e-07);
     bool bad = force_scan != 0 || wmask == 0;
     int first_dup = n;
 #pragma unroll
     for (int e = E - 1; e >= 0; e--) {
-      const bool dup = a[e] == wa && b[e] == wb;
-      const bool loses = a[e]*wb < (wa*b[e])*(1. - 9.3132257461547852e-10);
-      if (dup) first_dup = l*E + e;
-      else if (!loses) bad = true;
+      const bool dup = (a[e] == wa) & (b[e] == wb);
+      const bool loses = a[e] < b[e]*wr;     /* false for a duplicate of W */
+      first_dup = dup ? l*E + e : first_dup;
+      bad |= !(dup | loses);
     }
     int pos;
+    double nb = wb;      /* the winner's denominator yy + 2*y_pos + 1 IS the next yy */
     if (grp_ballot<G>(bad && on, row) != 0) {
       /* literal scan, src/pvq_encoder.c:172-183 */
       double sa = 0;
@@ -245,24 +257,22 @@ __device__ __forceinline__ double od_pvq_search_row(const int (&ax)[E], int (&y)
           pos = j;
         }
       }
+      nb = sb;
     }
     else pos = grp_min<G>(first_dup);
-    /* xy += x[pos]; yy += 2*y[pos] + 1; y[pos]++ */
+    /* xy += x[pos]; yy += 2*y[pos] + 1 (= the winner's b, an integer below 2^31 held exactly); y[pos]++ */
     int px = 0;
-    int py = 0;
 #pragma unroll
     for (int e = 0; e < E; e++) {
       if (on && l*E + e == pos) {
         px = ax[e];
-        py = y[e];
         y[e]++;
       }
     }
     px = grp_bcast<G>(px, row, pos/E);
-    py = grp_bcast<G>(py, row, pos/E);
     if (on) {
       xy = xy + (double)px;
-      yy = yy + (double)(2*py) + 1;
+      yy = nb;
       i++;
     }
   }
@@ -336,7 +346,8 @@ __device__ __forceinline__ double od_pvq_search_row(const int (&ax)[E], int (&y)
       i++;
     }
   }
-  *yy_out = yy;
+  *cxy = xy;
+  *cyy = yy;
   return __ddiv_rn(xy, 1e-100 + __dsqrt_rn(xx*yy));
 }
 
