@@ -339,13 +339,33 @@ __device__ __forceinline__ void refb_enumerate(const RJob &jb, int band, int32_t
   }
 }
 
-/* The work class of a band: its chains place about kmax pulses. */
+/* The work class of a band.  Its chains place about kmax pulses (~240 instructions each for a
+   15-coefficient band), but most bands place 0-3 pulses and their cost is the candidates themselves
+   (~300 instructions each) and the searches (~400 each beside their pulses): round 4 measured 0.56 of
+   the lanes active in k_refb_lean_lane<15> with the pulses alone as the key
+   (SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU, tools/gpu_r4_lanes.sh), so the class is
+   pulses + candidates + 2 * distinct pulse counts (one search each). */
 struct KeySink {
   int kt = 0;
   int kn = 0;
+  int c = 0;
+  unsigned long long mt = 0;
+  unsigned long long mn = 0;
   __device__ __forceinline__ void gain(int, int, int, int) {}
-  __device__ __forceinline__ void theta(int, int, int, int, int k) { kt = k > kt ? k : kt; }
-  __device__ __forceinline__ void noref(int, int, int k) { kn = k > kn ? k : kn; }
+  __device__ __forceinline__ void theta(int, int, int, int, int k) {
+    kt = k > kt ? k : kt;
+    c++;
+    if (k) mt |= 1ull << (k & 63);
+  }
+  __device__ __forceinline__ void noref(int, int, int k) {
+    kn = k > kn ? k : kn;
+    c++;
+    if (k) mn |= 1ull << (k & 63);
+  }
+  /* w: weights in quarters, pulses | candidates << 8 | searches << 16 */
+  __device__ __forceinline__ int work(int w) const {
+    return ((w & 255)*(kt + kn) + (w >> 8 & 255)*c + (w >> 16 & 255)*(__popcll(mt) + __popcll(mn))) >> 2;
+  }
 };
 
 /* Record of the band, theta with the device acos and the uncertainty list
@@ -396,7 +416,7 @@ __device__ __forceinline__ void prep_write(const RItems &it, odhip_pvq_refband *
     const RJob &jb = it.jobs[job];
     KeySink ks;
     refb_enumerate(jb, band, o.cg, o.gain_offset, o.theta, flags, o.corr, ks);
-    jb.keys[(long)band*jb.nblocks + blk] = (unsigned short)(kSortBins - 1 - od_work_bin(ks.kt + ks.kn));
+    jb.keys[(long)band*jb.nblocks + blk] = (unsigned short)(kSortBins - 1 - od_work_bin(ks.work(it.reserved1)));
   }
 }
 
@@ -1709,11 +1729,14 @@ template <int NR> struct RateTab { static constexpr int W = (NR - 1)*kRateK + 1;
 __device__ double gRate8[(kRateK + 1)*RateTab<8>::W];
 __device__ double gRate15[(kRateK + 1)*RateTab<15>::W];
 __device__ double gRate32[(kRateK + 1)*RateTab<32>::W];
+/* round 4: the 128-coefficient bands too (1.07 MB, L2-resident): their searches run four bands to a
+   wavefront, so the two logs and two divisions were paid once per candidate per FOUR bands */
+__device__ double gRate128[(kRateK + 1)*RateTab<128>::W];
 __device__ double gRateTs[kRateTs];
 
 template <int NR>
 __device__ __forceinline__ double *rate_tab(void) {
-  return NR == 8 ? gRate8 : NR == 15 ? gRate15 : gRate32;
+  return NR == 8 ? gRate8 : NR == 15 ? gRate15 : NR == 32 ? gRate32 : gRate128;
 }
 
 template <int NR>
@@ -1733,7 +1756,7 @@ __global__ void k_rate_ts_fill(void) {
 
 template <int NR>
 __device__ __forceinline__ double lean_rate_pulses(int sum, int k) {
-  if constexpr (NR == 8 || NR == 15 || NR == 32) {
+  if constexpr (NR == 8 || NR == 15 || NR == 32 || NR == 128) {
     if (k <= kRateK) return rate_tab<NR>()[k*RateTab<NR>::W + sum];
   }
   return odq_pvq_rate_pulses(sum, k, NR);
@@ -1902,6 +1925,100 @@ __device__ __forceinline__ void refb_loops_lean(const RJob &jb, int band, long b
   }
 }
 
+/* refb_loops_lean for one band per LANE, with the searches of a wavefront gathered.  Every lane
+   walks its own candidate list exactly as refb_loops_lean does (same skips, same searches, same
+   offers in the same order: the result per band is identical), but a lane whose next candidate needs
+   a SEARCH waits while any other lane can still advance without one, so a search runs when every
+   lane still working is at one.  Lists are sorted by K, not aligned between bands: walking them in
+   lock step by index ran a search (~700 instructions beside its pulses) in almost every iteration
+   with about half of the lanes idle (0.56-0.62 of the lanes active, SQ_THREAD_CYCLES_VALU /
+   SQ_ACTIVE_INST_VALU, tools/gpu_r4_lanes.sh). */
+template <int NR, class V, class D>
+__device__ __forceinline__ void refb_loops_lean_gathered(const RJob &jb, int band, long blk,
+ const odhip_pvq_refband &r, const CandList &cl, double lambda, V &v, D &dec) {
+  const int off = jb.off[band];
+  const int n = jb.off[band + 1] - off;
+  const int len = jb.len;
+  const double s2 = (1./256)*(1./256);   /* OD_CGAIN_SCALE_2 */
+  const double t1 = 1./32768;            /* OD_TRIG_SCALE_1 */
+  const int32_t cg = r.cg;
+  const double dist0 = r.dist0;
+  if (cl.ntheta > 0) {
+    v.load(jb.xr + blk*len + off, true);
+    int prev_k = 0;
+    bool has = false;
+    double cos_dist = 0;
+    double prate = 0;
+    const int32_t theta = r.theta;
+    int idx = 0;
+    while (idx < cl.ntheta) {
+      const uint32_t w = cl.col[idx*cl.stride];
+      const int gi = (int)(w & 3u);
+      const int k = (int)(w >> 2 & 0xffffu);
+      const int i = cl.gb1 + gi;
+      const int ts = (int)cl.col[(kSlots + gi)*cl.stride];
+      const int j = (int)cl.col[(kSlots + 3 + gi)*cl.stride] + (int)(w >> 18);
+      const int32_t qcg = odq_shl32(i, ODQ_CGAIN_SHIFT) + r.gain_offset;
+      const int32_t qtheta = odq_pvq_compute_theta(j, ts);
+      /* :526-531 */
+      double dist_theta = 2 - (2.*odq_pvq_cos(theta - qtheta))*t1;
+      double dist = (1.4*(qcg - cg))*(qcg - cg) + (qcg*(double)cg)*dist_theta;
+      dist *= s2;
+      const bool skip = (dist > dist0 + 1.0*lambda && k != 0) || k > ODHIP_PVQ_MAX_K;
+      const bool want = !skip && k != 0 && k != prev_k;
+      /* over the lanes still inside the loop; evaluated by all of them */
+      const bool others = __any(!want);
+      if (want && others) continue;
+      idx++;
+      if (skip) continue;
+      const double sin_prod = ((odq_pvq_sin(theta)*t1)*odq_pvq_sin(qtheta))*t1;
+      if (k == 0) {
+        cos_dist = 0;
+        has = false;
+        prate = 0;
+      }
+      else if (want) {
+        cos_dist = v.search(n - 1, k, prev_k, ((qcg*(double)cg)*sin_prod)*s2, lambda);
+        has = true;
+        prate = lean_rate_pulses<NR>(v.moment(), k);
+      }
+      prev_k = k;
+      /* :548-552 */
+      dist_theta = 2 - (2.*odq_pvq_cos(theta - qtheta))*t1 + sin_prod*(2 - 2*cos_dist);
+      dist = (1.4*(qcg - cg))*(qcg - cg) + (qcg*(double)cg)*dist_theta;
+      dist *= s2;
+      const double lts = __hiloint2double((int)cl.col[(kSlots + 7 + 2*gi)*cl.stride],
+       (int)cl.col[(kSlots + 6 + 2*gi)*cl.stride]);
+      dec.offer(idx - 1, true, i, j, ts, k, qtheta, dist, prate, lts, has, v);
+    }
+  }
+  if (cl.nitems > cl.ntheta) {
+    v.load(jb.x16 + blk*len + off, false);
+    int prev_k = 0;
+    int idx = cl.ntheta;
+    while (idx < cl.nitems) {
+      const uint32_t w = cl.col[idx*cl.stride];
+      const int i = cl.gbn + (int)(w & 3u);
+      const int k = (int)(w >> 2 & 0xffffu);
+      const int32_t qcg = odq_shl32(i, ODQ_CGAIN_SHIFT);
+      /* :585-595 */
+      double dist = (1.4*(qcg - cg))*(qcg - cg);
+      dist *= s2;
+      const bool skip = (dist > dist0 && k != 0) || k > ODHIP_PVQ_MAX_K;
+      const bool others = __any(skip);
+      if (!skip && others) continue;
+      idx++;
+      if (skip) continue;
+      const double cos_dist = v.search(n, k, prev_k, (qcg*(double)cg)*s2, lambda);
+      prev_k = k;
+      const double prate = lean_rate_pulses<NR>(v.moment(), k);
+      dist = (1.4*(qcg - cg))*(qcg - cg) + (qcg*(double)cg)*(2 - 2*cos_dist);
+      dist *= s2;
+      dec.offer(idx - 1, false, i, -1, 0, k, 0, dist, prate, 0., true, v);
+    }
+  }
+}
+
 /* The running choice over NY pulses held by this lane (the whole band, or its E positions
    of a band spread over a group): the reference's comparisons (`<` theta candidates, :559;
    `<=` no-reference ones, :601) on cost = dist + lambda*rate.  Only the cost, the winner's
@@ -2004,7 +2121,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(3))) void
   RegVector<N> v;
   LeanDecide<N> dec;
   dec.init(r, jb, it.lambda, it.tol_scale);
-  refb_loops_lean<N>(jb, band, blk, r, cl, it.lambda, v, dec);
+  refb_loops_lean_gathered<N>(jb, band, blk, r, cl, it.lambda, v, dec);
   const RefBest best = lean_best(dec, cl, jb.is_keyframe);
   if (best.yslot >= 0) {
     uint4 *p = reinterpret_cast<uint4 *>(jb.y + blk*jb.len + jb.off[band] - SH);
@@ -2326,6 +2443,7 @@ int upload_tables_now(void) {
   k_rate_fill<8><<<((kRateK + 1)*RateTab<8>::W + 255)/256, 256, 0, 0>>>();
   k_rate_fill<15><<<((kRateK + 1)*RateTab<15>::W + 255)/256, 256, 0, 0>>>();
   k_rate_fill<32><<<((kRateK + 1)*RateTab<32>::W + 255)/256, 256, 0, 0>>>();
+  k_rate_fill<128><<<((kRateK + 1)*RateTab<128>::W + 255)/256, 256, 0, 0>>>();
   k_rate_ts_fill<<<1, kRateTs, 0, 0>>>();
   ODHIP_TRY(hipDeviceSynchronize());
   return ODHIP_SUCCESS;
@@ -2566,6 +2684,18 @@ int stage_jobs(RefState &st, const odhip_pvq_refjob *jobs, int njobs, int mode, 
   return ODHIP_SUCCESS;
 }
 
+/* Weights of the work class (KeySink::work), quarters: pulses, candidates, searches.
+   ODHIP_SORT_W="p,c,s" overrides them (experiments). */
+int sort_weights(void) {
+  static const int w = [] {
+    int p = 4, c = 4, s = 8;
+    const char *e = getenv("ODHIP_SORT_W");
+    if (e) sscanf(e, "%d,%d,%d", &p, &c, &s);
+    return (p & 255) | (c & 255) << 8 | (s & 255) << 16;
+  }();
+  return w;
+}
+
 void items_begin(RItems &it, const RefState &st, double lambda) {
   memset(&it, 0, sizeof(it));
   it.lambda = lambda;
@@ -2579,6 +2709,7 @@ void items_begin(RItems &it, const RefState &st, double lambda) {
   it.pcount = st.d_pcount;
   it.plist = st.d_plist;
   it.tol_scale = st.tol_scale;
+  it.reserved1 = sort_weights();
 }
 
 void items_add(RItems &it, int job, int band, long wgs) {
