@@ -1767,6 +1767,30 @@ void items_begin(Items &it, const BandState &st, double lambda) {
   it.reserved = e && e[0] == '1';   /* pair-mode search: always take the sequential combine */
 }
 
+/* Heaviest items first: the jobs arrive by ascending block size, and the bands of the largest
+   blocks place the most pulses (K ~ 70 against 0-25 for the 128-coefficient luma bands) in the fewest
+   wavefronts - launched last they were the tail of their kernel.  ODHIP_ITEMS_FWD=1 keeps the
+   order of the jobs (experiments). */
+void items_heavy_first(Items &it) {
+  static const bool fwd = getenv("ODHIP_ITEMS_FWD") != nullptr;
+  if (fwd) return;
+  const int n = it.nitems;
+  int size[kMaxItems];
+  for (int i = 0; i < n; i++) size[i] = it.wg_start[i + 1] - it.wg_start[i];
+  for (int i = 0; i < n/2; i++) {
+    const unsigned char j = it.job[i];
+    const unsigned char b = it.band[i];
+    const int z = size[i];
+    it.job[i] = it.job[n - 1 - i];
+    it.band[i] = it.band[n - 1 - i];
+    size[i] = size[n - 1 - i];
+    it.job[n - 1 - i] = j;
+    it.band[n - 1 - i] = b;
+    size[n - 1 - i] = z;
+  }
+  for (int i = 0; i < n; i++) it.wg_start[i + 1] = it.wg_start[i] + size[i];
+}
+
 void items_add(Items &it, int job, int band, long wgs) {
   if (wgs <= 0) return;
   it.job[it.nitems] = (unsigned char)job;
@@ -1913,6 +1937,7 @@ int noref_bands(const odhip_pvq_job *jobs, int njobs, double pvq_norm_lambda, od
     }
     const bool prof = st.prof_on && st.prof_n < kProfSlots;
     if (prof) (void)hipEventRecord(st.prof_ev[st.prof_n][0], s);
+    items_heavy_first(it);
     if (it.nitems) k_decide_pair128<<<it.wg_start[it.nitems], kWave, pair_lds, s>>>(it);
     if (prof) (void)hipEventRecord(st.prof_ev[st.prof_n++][1], s);
     items_begin(it, st, lambda);
@@ -1922,16 +1947,19 @@ int noref_bands(const odhip_pvq_job *jobs, int njobs, double pvq_norm_lambda, od
         if (host[j].off[b + 1] - host[j].off[b] == 32) items_add(it, j, b, (host[j].nblocks + kWave/2 - 1)/(kWave/2));
       }
     }
+    items_heavy_first(it);
     if (it.nitems) k_decide_lane32<<<it.wg_start[it.nitems], kWave, lane_lds, side[0]>>>(it);
     items_begin(it, st, lambda);
     it.fuse = 1;
     for (int j = 0; j < njobs; j++) items_add(it, j, 0, (host[j].nblocks + kWave - 1)/kWave);
+    items_heavy_first(it);
     if (it.nitems) k_decide_corner<0><<<it.wg_start[it.nitems], kWave, lane_lds, side[1]>>>(it);
     items_begin(it, st, lambda);
     it.fuse = 1;
     for (int j = 0; j < njobs; j++) {
       if (host[j].bs > 0) items_add(it, j, 1, (host[j].nblocks + kWave - 1)/kWave);
     }
+    items_heavy_first(it);
     if (it.nitems) k_decide_corner<1><<<it.wg_start[it.nitems], kWave, lane_lds, side[1]>>>(it);
     if (join_streams(st, s, side) != ODHIP_SUCCESS) return ODHIP_EFAULT;
     const int rc2 = price_count_begin(st, s);

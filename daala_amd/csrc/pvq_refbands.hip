@@ -2295,7 +2295,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(3))) void
   const CandList cl = refb_build_list(jb, band, r, s_list + v.row, C, v.l == 0);
   LeanDecide<E> dec;
   dec.init(r, jb, it.lambda, it.tol_scale);
-  refb_loops_lean<G*E>(jb, band, blk, r, cl, it.lambda, v, dec);
+  refb_loops_lean_gathered<G*E>(jb, band, blk, r, cl, it.lambda, v, dec);
   refb_finish_row<E, G>(it, job, jb, band, blk, r, dec, lean_best(dec, cl, jb.is_keyframe), v.l, live);
 }
 
@@ -2712,6 +2712,30 @@ void items_begin(RItems &it, const RefState &st, double lambda) {
   it.reserved1 = sort_weights();
 }
 
+/* Heaviest items first: the jobs arrive by ascending block size, and the bands of the largest
+   blocks place the most pulses (K ~ 70 against 0-25 for the 128-coefficient luma bands) in the fewest
+   wavefronts - launched last they were the tail of their kernel.  ODHIP_ITEMS_FWD=1 keeps the
+   order of the jobs (experiments). */
+void items_heavy_first(RItems &it) {
+  static const bool fwd = getenv("ODHIP_ITEMS_FWD") != nullptr;
+  if (fwd) return;
+  const int n = it.nitems;
+  int size[kMaxItems];
+  for (int i = 0; i < n; i++) size[i] = it.wg_start[i + 1] - it.wg_start[i];
+  for (int i = 0; i < n/2; i++) {
+    const unsigned char j = it.job[i];
+    const unsigned char b = it.band[i];
+    const int z = size[i];
+    it.job[i] = it.job[n - 1 - i];
+    it.band[i] = it.band[n - 1 - i];
+    size[i] = size[n - 1 - i];
+    it.job[n - 1 - i] = j;
+    it.band[n - 1 - i] = b;
+    size[n - 1 - i] = z;
+  }
+  for (int i = 0; i < n; i++) it.wg_start[i + 1] = it.wg_start[i] + size[i];
+}
+
 void items_add(RItems &it, int job, int band, long wgs) {
   if (wgs <= 0) return;
   it.job[it.nitems] = (unsigned char)job;
@@ -2936,6 +2960,7 @@ int ref_bands(const odhip_pvq_refjob *jobs, int njobs, double pvq_norm_lambda, o
         }
       }
       if (!it.nitems) continue;
+      if (fuse == 2) items_heavy_first(it);
       if (sizes[i] == 128) {
         const bool prof = st.prof_on && st.prof_n < kProfSlots;
         if (prof) (void)hipEventRecord(st.prof_ev[st.prof_n][0], s);
@@ -2950,6 +2975,7 @@ int ref_bands(const odhip_pvq_refjob *jobs, int njobs, double pvq_norm_lambda, o
     items_all(it, st, host, njobs, pvq_norm_lambda, sizes[i]);
     if (!it.nitems) continue;
     if (sizes[i] < 32 && !lane_only) {
+      if (fuse == 2) items_heavy_first(it);
       const int wgs = it.wg_start[it.nitems];
       if (fuse == 2) {
         if (sizes[i] == 15) k_refb_lean_lane<15><<<wgs, kWave, 0, s>>>(it);
