@@ -1722,16 +1722,21 @@ constexpr int kLeanAux = 12;            /* per band: ts[3], lower[3], .9*log2(ts
    small pulse counts nearly every search ends with they are read from tables filled ONCE per
    device by the very functions they replace (k_rate_fill: same code, same device log - the
    values are identical, two logs and two divisions per search become one load).  NR = band
-   size; entries [k][sum], k = 1..kRateK, sum = 0..(NR - 1)*kRateK. */
-constexpr int kRateK = 32;
+   size; entries [k][sum], k = 1..K, sum = 0..(NR - 1)*K, K = RateTab<NR>::K: the pulse counts the
+   chroma bands of a 1080p keyframe reach at the operating points measured (band 0 of the 16x16 and
+   32x32 blocks: K up to 95 / 280; the 128-coefficient bands of the 32x32 blocks: up to 47). */
 constexpr int kRateTs = 64;
-template <int NR> struct RateTab { static constexpr int W = (NR - 1)*kRateK + 1; };
-__device__ double gRate8[(kRateK + 1)*RateTab<8>::W];
-__device__ double gRate15[(kRateK + 1)*RateTab<15>::W];
-__device__ double gRate32[(kRateK + 1)*RateTab<32>::W];
-/* round 4: the 128-coefficient bands too (1.07 MB, L2-resident): their searches run four bands to a
-   wavefront, so the two logs and two divisions were paid once per candidate per FOUR bands */
-__device__ double gRate128[(kRateK + 1)*RateTab<128>::W];
+template <int NR> struct RateTab {
+  static constexpr int K = NR == 15 ? 128 : NR == 128 ? 64 : NR == 32 ? 48 : 32;
+  static constexpr int W = (NR - 1)*K + 1;
+  static constexpr int SIZE = (K + 1)*W;
+};
+__device__ double gRate8[RateTab<8>::SIZE];
+__device__ double gRate15[RateTab<15>::SIZE];
+__device__ double gRate32[RateTab<32>::SIZE];
+/* round 4: the 128-coefficient bands too (4.2 MB): their searches run four bands to a wavefront,
+   so the two logs and two divisions were paid once per candidate per FOUR bands */
+__device__ double gRate128[RateTab<128>::SIZE];
 __device__ double gRateTs[kRateTs];
 
 template <int NR>
@@ -1743,7 +1748,7 @@ template <int NR>
 __global__ void k_rate_fill(void) {
   constexpr int W = RateTab<NR>::W;
   const int i = blockIdx.x*blockDim.x + threadIdx.x;
-  if (i >= (kRateK + 1)*W) return;
+  if (i >= RateTab<NR>::SIZE) return;
   const int k = i/W;
   const int sum = i - k*W;
   rate_tab<NR>()[i] = k == 0 ? 0. : odq_pvq_rate_pulses(sum, k, NR);
@@ -1757,7 +1762,7 @@ __global__ void k_rate_ts_fill(void) {
 template <int NR>
 __device__ __forceinline__ double lean_rate_pulses(int sum, int k) {
   if constexpr (NR == 8 || NR == 15 || NR == 32 || NR == 128) {
-    if (k <= kRateK) return rate_tab<NR>()[k*RateTab<NR>::W + sum];
+    if (k <= RateTab<NR>::K) return rate_tab<NR>()[k*RateTab<NR>::W + sum];
   }
   return odq_pvq_rate_pulses(sum, k, NR);
 }
@@ -1990,6 +1995,123 @@ __device__ __forceinline__ void refb_loops_lean_gathered(const RJob &jb, int ban
       const double lts = __hiloint2double((int)cl.col[(kSlots + 7 + 2*gi)*cl.stride],
        (int)cl.col[(kSlots + 6 + 2*gi)*cl.stride]);
       dec.offer(idx - 1, true, i, j, ts, k, qtheta, dist, prate, lts, has, v);
+    }
+  }
+  if (cl.nitems > cl.ntheta) {
+    v.load(jb.x16 + blk*len + off, false);
+    int prev_k = 0;
+    int idx = cl.ntheta;
+    while (idx < cl.nitems) {
+      const uint32_t w = cl.col[idx*cl.stride];
+      const int i = cl.gbn + (int)(w & 3u);
+      const int k = (int)(w >> 2 & 0xffffu);
+      const int32_t qcg = odq_shl32(i, ODQ_CGAIN_SHIFT);
+      /* :585-595 */
+      double dist = (1.4*(qcg - cg))*(qcg - cg);
+      dist *= s2;
+      const bool skip = (dist > dist0 && k != 0) || k > ODHIP_PVQ_MAX_K;
+      const bool others = __any(skip);
+      if (!skip && others) continue;
+      idx++;
+      if (skip) continue;
+      const double cos_dist = v.search(n, k, prev_k, (qcg*(double)cg)*s2, lambda);
+      prev_k = k;
+      const double prate = lean_rate_pulses<NR>(v.moment(), k);
+      dist = (1.4*(qcg - cg))*(qcg - cg) + (qcg*(double)cg)*(2 - 2*cos_dist);
+      dist *= s2;
+      dec.offer(idx - 1, false, i, -1, 0, k, 0, dist, prate, 0., true, v);
+    }
+  }
+}
+
+/* refb_loops_lean_gathered for a band spread over a group of G lanes.  Everything a theta candidate
+   needs before its search is a function of the band record and the list entry alone (quantised gain,
+   quantised theta, the two cosine terms, whether it is skipped): in lock step every lane of the group
+   computed it again for every candidate - ~140 instructions each, the same values in all G lanes.
+   Here lane c % G of the group computes candidate c once, before the chain, into `pre` (LDS, kPreWords
+   words per candidate, the group's own slice), and the chain reads five words back. */
+constexpr int kPreWords = 6;       /* qcg, skip, (2 - 2cos(theta - qtheta)/32768) lo/hi, sin(theta)sin(qtheta)/2^30 lo/hi */
+
+template <int NR, int G, class V, class D>
+__device__ __forceinline__ void refb_loops_lean_rows(const RJob &jb, int band, long blk,
+ const odhip_pvq_refband &r, const CandList &cl, double lambda, V &v, D &dec, uint32_t *pre, int pre_stride) {
+  const int off = jb.off[band];
+  const int n = jb.off[band + 1] - off;
+  const int len = jb.len;
+  const double s2 = (1./256)*(1./256);   /* OD_CGAIN_SCALE_2 */
+  const double t1 = 1./32768;            /* OD_TRIG_SCALE_1 */
+  const int32_t cg = r.cg;
+  const double dist0 = r.dist0;
+  const int32_t theta = r.theta;
+  /* every lane takes part (a group past the end of the item replays its last band) */
+  for (int c = v.l; c < kSlots; c += G) {
+    if (c < cl.ntheta) {
+      const uint32_t w = cl.col[c*cl.stride];
+      const int gi = (int)(w & 3u);
+      const int k = (int)(w >> 2 & 0xffffu);
+      const int i = cl.gb1 + gi;
+      const int ts = (int)cl.col[(kSlots + gi)*cl.stride];
+      const int j = (int)cl.col[(kSlots + 3 + gi)*cl.stride] + (int)(w >> 18);
+      const int32_t qcg = odq_shl32(i, ODQ_CGAIN_SHIFT) + r.gain_offset;
+      const int32_t qtheta = odq_pvq_compute_theta(j, ts);
+      /* :526-531 */
+      const double cosfix = 2 - (2.*odq_pvq_cos(theta - qtheta))*t1;
+      double dist = (1.4*(qcg - cg))*(qcg - cg) + (qcg*(double)cg)*cosfix;
+      dist *= s2;
+      const bool skip = (dist > dist0 + 1.0*lambda && k != 0) || k > ODHIP_PVQ_MAX_K;
+      const double sin_prod = ((odq_pvq_sin(theta)*t1)*odq_pvq_sin(qtheta))*t1;
+      uint32_t *p = pre + c*kPreWords*pre_stride;
+      p[0] = (uint32_t)qcg;
+      p[pre_stride] = skip;
+      p[2*pre_stride] = (uint32_t)__double2loint(cosfix);
+      p[3*pre_stride] = (uint32_t)__double2hiint(cosfix);
+      p[4*pre_stride] = (uint32_t)__double2loint(sin_prod);
+      p[5*pre_stride] = (uint32_t)__double2hiint(sin_prod);
+    }
+  }
+  __syncthreads();
+  if (cl.ntheta > 0) {
+    v.load(jb.xr + blk*len + off, true);
+    int prev_k = 0;
+    bool has = false;
+    double cos_dist = 0;
+    double prate = 0;
+    int idx = 0;
+    while (idx < cl.ntheta) {
+      const uint32_t w = cl.col[idx*cl.stride];
+      const int k = (int)(w >> 2 & 0xffffu);
+      const uint32_t *p = pre + idx*kPreWords*pre_stride;
+      const bool skip = p[pre_stride] != 0;
+      const bool want = !skip && k != 0 && k != prev_k;
+      const bool others = __any(!want);
+      if (want && others) continue;
+      idx++;
+      if (skip) continue;
+      const int gi = (int)(w & 3u);
+      const int i = cl.gb1 + gi;
+      const int ts = (int)cl.col[(kSlots + gi)*cl.stride];
+      const int j = (int)cl.col[(kSlots + 3 + gi)*cl.stride] + (int)(w >> 18);
+      const int32_t qcg = (int32_t)p[0];
+      const double cosfix = __hiloint2double((int)p[3*pre_stride], (int)p[2*pre_stride]);
+      const double sin_prod = __hiloint2double((int)p[5*pre_stride], (int)p[4*pre_stride]);
+      if (k == 0) {
+        cos_dist = 0;
+        has = false;
+        prate = 0;
+      }
+      else if (want) {
+        cos_dist = v.search(n - 1, k, prev_k, ((qcg*(double)cg)*sin_prod)*s2, lambda);
+        has = true;
+        prate = lean_rate_pulses<NR>(v.moment(), k);
+      }
+      prev_k = k;
+      /* :548-552 */
+      const double dist_theta = cosfix + sin_prod*(2 - 2*cos_dist);
+      double dist = (1.4*(qcg - cg))*(qcg - cg) + (qcg*(double)cg)*dist_theta;
+      dist *= s2;
+      const double lts = __hiloint2double((int)cl.col[(kSlots + 7 + 2*gi)*cl.stride],
+       (int)cl.col[(kSlots + 6 + 2*gi)*cl.stride]);
+      dec.offer(idx - 1, true, i, j, ts, k, 0, dist, prate, lts, has, v);
     }
   }
   if (cl.nitems > cl.ntheta) {
@@ -2276,6 +2398,7 @@ template <int E, int G>
 __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(3))) void k_refb_lean_row(RItems it) {
   constexpr int C = kWave/G;            /* bands per wavefront */
   __shared__ uint32_t s_list[kLeanWords*C];
+  __shared__ uint32_t s_pre[kSlots*kPreWords*C];
   od_rsqrt_init(threadIdx.x);
   const int item = find_item(it, blockIdx.x);
   const int job = it.job[item];
@@ -2295,7 +2418,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(3))) void
   const CandList cl = refb_build_list(jb, band, r, s_list + v.row, C, v.l == 0);
   LeanDecide<E> dec;
   dec.init(r, jb, it.lambda, it.tol_scale);
-  refb_loops_lean_gathered<G*E>(jb, band, blk, r, cl, it.lambda, v, dec);
+  refb_loops_lean_rows<G*E, G>(jb, band, blk, r, cl, it.lambda, v, dec, s_pre + v.row, C);
   refb_finish_row<E, G>(it, job, jb, band, blk, r, dec, lean_best(dec, cl, jb.is_keyframe), v.l, live);
 }
 
@@ -2440,10 +2563,10 @@ int upload_tables_now(void) {
   }
   ODHIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(gRBandOf), band_of, sizeof(band_of)));
   od_rsqrt_fill_launch();
-  k_rate_fill<8><<<((kRateK + 1)*RateTab<8>::W + 255)/256, 256, 0, 0>>>();
-  k_rate_fill<15><<<((kRateK + 1)*RateTab<15>::W + 255)/256, 256, 0, 0>>>();
-  k_rate_fill<32><<<((kRateK + 1)*RateTab<32>::W + 255)/256, 256, 0, 0>>>();
-  k_rate_fill<128><<<((kRateK + 1)*RateTab<128>::W + 255)/256, 256, 0, 0>>>();
+  k_rate_fill<8><<<(RateTab<8>::SIZE + 255)/256, 256, 0, 0>>>();
+  k_rate_fill<15><<<(RateTab<15>::SIZE + 255)/256, 256, 0, 0>>>();
+  k_rate_fill<32><<<(RateTab<32>::SIZE + 255)/256, 256, 0, 0>>>();
+  k_rate_fill<128><<<(RateTab<128>::SIZE + 255)/256, 256, 0, 0>>>();
   k_rate_ts_fill<<<1, kRateTs, 0, 0>>>();
   ODHIP_TRY(hipDeviceSynchronize());
   return ODHIP_SUCCESS;
