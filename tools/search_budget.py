@@ -34,9 +34,10 @@ candidate against 13 = 0.82 of the minimum (18.1 = 0.72 before round 4 stopped r
 after a greedy pulse); the extra three are v_cvt_f64_u32 of |x_j| and the integer denominator with
 its conversion.  The row searches (k_refb_lean_row, one band per 16 / 4 lanes, 8 positions per lane) carry,
 per pulse, a FIXED part that the minimum does not have - float-key proposal, DPP max, ballot, two
-64-bit broadcasts, the verification pass over the lane's 8 candidates, the (max, lowest index)
-butterfly of the tail - amortised over only 8 candidates per lane, and their tail loop holds both
-table-lookup variants (one executes): 32-39 static, ~20-25 executed per candidate.  That fixed part is
+64-bit broadcasts, the verification pass over the lane's 8 candidates (one product each since the
+second half of round 4: 39 -> 32 static instructions per candidate in the greedy loop), the DPP max +
+ballot of the tail - amortised over only 8 candidates per lane, and their tail loop holds both
+table-lookup variants (one executes): 28-32 static, ~20-25 executed per candidate.  That fixed part is
 the price of running a 128-coefficient band on 16 lanes instead of one (one band per lane: 2.66 ms
 instead of 0.82); 16 positions per lane on 8 lanes would halve it per
 candidate at +32 VGPRs (not built).  The LDS-column searches of the luma stage (k_decide_*) sit at
