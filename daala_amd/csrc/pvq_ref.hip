@@ -262,27 +262,24 @@ __device__ __forceinline__ int odq_compute_k_dec(int32_t qcg, int itheta, int no
    The QM-scaled reference is recomputed where it is used (a lane cannot hold 128 values):
    ref16[i] = SHR_ROUND(ref[i]*qm[i], OD_QM_SHIFT + rshift), and after od_compute_householder
    element m carries + SHR_ROUND(gr*s, rshift) (src/pvq.c:498-521). */
-__global__ __launch_bounds__(64) void k_pvq_decode(od_coeff *out, const od_coeff *refa, const od_coeff *ya,
- int n, long nbands, const int4 *sym, const int16_t *qm, const int16_t *qm_inv, int q0, int beta,
- int is_keyframe, int pli, int2 *info) {
-  const long b = (long)blockIdx.x*64 + threadIdx.x;
-  if (b >= nbands) return;
-  const od_coeff *ref = refa + b*n;
-  const od_coeff *yp = ya + b*n;
-  od_coeff *xo = out + b*n;
-  const int4 sy = sym[b];
+/* The band's arithmetic, one band per lane, through accessors: REF(i) / Y(i) read the band's
+   reference and pulses, OUT(i, v) writes coefficient i (OUT(i, .) may overwrite REF(i): every loop
+   reads position i before it writes it). */
+template <class RefAt, class YAt, class OutAt>
+__device__ __forceinline__ void pvq_decode_band(RefAt REF, YAt Y, OutAt OUT, int n, int4 sy, const int16_t *qm,
+ const int16_t *qm_inv, int q0, int beta, int is_keyframe, int pli, int2 *info_b) {
   int qg = sy.x;
   int itheta = sy.y;
   const int noref = sy.z;
   /* :213-224 */
   int sr = 0;
   for (int i = 0; i < n; i++) {
-    const int tr = (int16_t)(ref[i] >> 8);
+    const int tr = (int16_t)(REF(i) >> 8);
     sr += tr*tr;
   }
   int rshift = 8 + 1 + odq_ilog(n + sr)/2 - 14;
   rshift = rshift > 0 ? rshift : 0;
-#define OD_REF16(i) ((int16_t)odq_shr_round((int32_t)((uint32_t)ref[i]*(uint32_t)(int32_t)qm[i]), ODQ_QM_SHIFT + rshift))
+#define OD_REF16(i) ((int16_t)odq_shr_round((int32_t)((uint32_t)REF(i)*(uint32_t)(int32_t)qm[i]), ODQ_QM_SHIFT + rshift))
   int32_t theta = 0;
   int32_t gr = 0;
   int32_t qcg;
@@ -328,16 +325,16 @@ __global__ __launch_bounds__(64) void k_pvq_decode(od_coeff *out, const od_coeff
     qcg = odq_shl32(qg, ODQ_CGAIN_SHIFT);
     if (qg == 0) skip = 1;
   }
-  if (info) info[b] = make_int2(odq_compute_k_dec(qcg, itheta, noref, n, beta), skip);
+  if (info_b) *info_b = make_int2(odq_compute_k_dec(qcg, itheta, noref, n, beta), skip);
   if (skip) {
-    for (int i = 0; i < n; i++) xo[i] = skip == 2 ? ref[i] : 0;
+    for (int i = 0; i < n; i++) OUT(i, skip == 2 ? REF(i) : 0);
     return;
   }
   /* od_gain_expand + od_pvq_synthesis_partial, src/pvq.c:766-811, :1037-1115 */
   const int32_t g = odq_gain_expand(qcg, q0, beta);
   const int nn = n - (!noref);
   int yy = 0;
-  for (int i = 0; i < nn; i++) yy += yp[i]*(int32_t)yp[i];
+  for (int i = 0; i < nn; i++) yy += Y(i)*(int32_t)Y(i);
   int gshift = odq_ilog(g) - 14;
   gshift = gshift > 0 ? gshift : 0;
   int32_t scale = 0;
@@ -349,8 +346,8 @@ __global__ __launch_bounds__(64) void k_pvq_decode(od_coeff *out, const od_coeff
   const int qshift = ODQ_QM_INV_SHIFT - gshift;
   if (noref) {
     for (int i = 0; i < n; i++) {
-      const int32_t x = (int32_t)odq_mult16_32_q16(yp[i], scale);
-      xo[i] = odq_shr_round(x*qm_inv[i], qshift);
+      const int32_t x = (int32_t)odq_mult16_32_q16(Y(i), scale);
+      OUT(i, odq_shr_round(x*qm_inv[i], qshift));
     }
     return;
   }
@@ -360,7 +357,7 @@ __global__ __launch_bounds__(64) void k_pvq_decode(od_coeff *out, const od_coeff
   int32_t proj = 0;
   for (int i = 0; i < n; i++) {
     const int ri = i == m ? rm : OD_REF16(i);
-    const int16_t xi = i == m ? xm : (int16_t)odq_mult16_32_q16(yp[i < m ? i : i - 1], scale);
+    const int16_t xi = i == m ? xm : (int16_t)odq_mult16_32_q16(Y(i < m ? i : i - 1), scale);
     l2r += odq_mult16_16(ri, ri);
     proj += odq_mult16_16(ri, xi);
   }
@@ -374,13 +371,90 @@ __global__ __launch_bounds__(64) void k_pvq_decode(od_coeff *out, const od_coeff
   if (outshift > 30) outshift = 30;
   for (int i = 0; i < n; i++) {
     const int ri = i == m ? rm : OD_REF16(i);
-    const int16_t xi = i == m ? xm : (int16_t)odq_mult16_32_q16(yp[i < m ? i : i - 1], scale);
+    const int16_t xi = i == m ? xm : (int16_t)odq_mult16_32_q16(Y(i < m ? i : i - 1), scale);
     int32_t tmp = odq_mult16_16(ri, proj_1);
     tmp = outshift >= 0 ? odq_shr_round(tmp, outshift) : odq_shl32(tmp, -outshift);
     const int16_t v = (int16_t)(xi - tmp);
-    xo[i] = odq_shr_round(v*qm_inv[i], qshift);
+    OUT(i, odq_shr_round(v*qm_inv[i], qshift));
   }
 #undef OD_REF16
+}
+
+/* One band per lane straight from memory (stride-n accesses): the first form, kept as the
+   cross-check of k_pvq_decode (ODHIP_DECODE_LANE=1 selects it). */
+__global__ __launch_bounds__(64) void k_pvq_decode_lane(od_coeff *out, const od_coeff *refa, const od_coeff *ya,
+ int n, long nbands, const int4 *sym, const int16_t *qm, const int16_t *qm_inv, int q0, int beta,
+ int is_keyframe, int pli, int2 *info) {
+  const long b = (long)blockIdx.x*64 + threadIdx.x;
+  if (b >= nbands) return;
+  const od_coeff *ref = refa + b*n;
+  const od_coeff *yp = ya + b*n;
+  od_coeff *xo = out + b*n;
+  pvq_decode_band([&](int i) { return ref[i]; }, [&](int i) { return yp[i]; },
+   [&](int i, od_coeff v) { xo[i] = v; }, n, sym[b], qm, qm_inv, q0, beta, is_keyframe, pli, info ? info + b : nullptr);
+}
+
+/* The same with the bands of a workgroup staged through LDS: B bands (64, or 32 above 64
+   coefficients: 2*B*(n|1) words of LDS) are contiguous in memory, so the 64 lanes read B*n
+   references and B*n pulses with unit stride, each lane then works on its band in its LDS row
+   (pitch n|1: odd, the rows of the 64 lanes start in different banks) writing the coefficients over
+   the references, and the rows leave with unit stride again.  Round 3's form read and wrote HBM
+   with a stride of n words per lane in three passes. */
+__global__ __launch_bounds__(64) void k_pvq_decode(od_coeff *out, const od_coeff *refa, const od_coeff *ya,
+ int n, int B, long nbands, const int4 *sym, const int16_t *qm, const int16_t *qm_inv, int q0, int beta,
+ int is_keyframe, int pli, int2 *info) {
+  extern __shared__ od_coeff s_dec[];
+  const int S = n | 1;
+  od_coeff *sref = s_dec;
+  od_coeff *sy = s_dec + B*S;
+  const int lane = threadIdx.x;
+  const long b0 = (long)blockIdx.x*B;
+  const long left = nbands - b0;
+  const int nb = left < B ? (int)left : B;
+  const int total = nb*n;
+  const od_coeff *gref = refa + b0*n;
+  const od_coeff *gy = ya + b0*n;
+  {
+    int band = lane/n;
+    int i = lane - band*n;
+    const int sb = 64/n;
+    const int si = 64 - sb*n;
+    for (int idx = lane; idx < total; idx += 64) {
+      sref[band*S + i] = gref[idx];
+      sy[band*S + i] = gy[idx];
+      band += sb;
+      i += si;
+      if (i >= n) {
+        i -= n;
+        band++;
+      }
+    }
+  }
+  __syncthreads();
+  if (lane < nb) {
+    od_coeff *row = sref + lane*S;
+    const od_coeff *yrow = sy + lane*S;
+    pvq_decode_band([&](int i) { return row[i]; }, [&](int i) { return yrow[i]; },
+     [&](int i, od_coeff v) { row[i] = v; }, n, sym[b0 + lane], qm, qm_inv, q0, beta, is_keyframe, pli,
+     info ? info + b0 + lane : nullptr);
+  }
+  __syncthreads();
+  {
+    od_coeff *gout = out + b0*n;
+    int band = lane/n;
+    int i = lane - band*n;
+    const int sb = 64/n;
+    const int si = 64 - sb*n;
+    for (int idx = lane; idx < total; idx += 64) {
+      gout[idx] = sref[band*S + i];
+      band += sb;
+      i += si;
+      if (i >= n) {
+        i -= n;
+        band++;
+      }
+    }
+  }
 }
 
 }  // namespace
@@ -393,7 +467,16 @@ extern "C" int odhip_pvq_decode_bands(od_coeff *d_out, const od_coeff *d_ref, co
    || ((uintptr_t)d_sym & 15) || ((uintptr_t)d_info & 7)) {
     return ODHIP_EINVAL;
   }
-  k_pvq_decode<<<(unsigned)((nbands + 63)/64), 64, 0, (hipStream_t)stream>>>(d_out, d_ref, d_y, n, nbands,
+  static const bool lane_form = getenv("ODHIP_DECODE_LANE") != nullptr;
+  if (lane_form) {
+    k_pvq_decode_lane<<<(unsigned)((nbands + 63)/64), 64, 0, (hipStream_t)stream>>>(d_out, d_ref, d_y, n, nbands,
+     reinterpret_cast<const int4 *>(d_sym), d_qm, d_qm_inv, q0, beta, is_keyframe != 0, pli,
+     reinterpret_cast<int2 *>(d_info));
+    return odhip_check_launch();
+  }
+  const int B = n > 64 ? 32 : 64;
+  const size_t lds = (size_t)2*B*(n | 1)*sizeof(od_coeff);
+  k_pvq_decode<<<(unsigned)((nbands + B - 1)/B), 64, lds, (hipStream_t)stream>>>(d_out, d_ref, d_y, n, B, nbands,
    reinterpret_cast<const int4 *>(d_sym), d_qm, d_qm_inv, q0, beta, is_keyframe != 0, pli,
    reinterpret_cast<int2 *>(d_info));
   return odhip_check_launch();
