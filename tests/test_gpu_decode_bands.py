@@ -146,3 +146,21 @@ def test_whole_1080p_keyframe_decodes_to_the_reference_synthesis(hip):
                 nbands += B
                 ncoded += int((band[:, i, 3] > 0).sum())
     assert nbands == 509490 and ncoded > 100000 and nflip > 100
+
+
+def test_lds_staged_and_per_lane_kernels_agree():
+    """odhip_pvq_decode_bands runs the LDS-staged kernel; ODHIP_DECODE_LANE=1 (read once per
+    process) selects the one-band-per-lane form it replaced.  Same random bands of four band sizes
+    through both, in child processes: the digests tools/decode_bands_time.py prints must agree."""
+    import subprocess
+    tool = os.path.join(ROOT, "tools", "decode_bands_time.py")
+    outs = []
+    for extra in ({}, {"ODHIP_DECODE_LANE": "1"}):
+        env = dict(os.environ)
+        env.update(extra)
+        r = subprocess.run([sys.executable, tool, "--child"], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        digests = [ln.split("digest")[1].strip() for ln in r.stdout.splitlines() if "digest" in ln]
+        assert len(digests) == 4, r.stdout
+        outs.append(digests)
+    assert outs[0] == outs[1]
