@@ -1208,6 +1208,54 @@ __global__ __launch_bounds__(kWave, 2) void k_decide_pair128(Items it) {
    it again; PRICE = 2 is that second decision (rates given per band). */
 /* The decision itself, on values: from the record (k_choose) or straight from the
    registers of the search that produced them (k_search with Items::fuse). */
+/* od_pvq_rate's pulse part (the whole rate of a no-reference candidate: theta == -1) is a function of
+   (sum, k, n) alone: read from tables filled ONCE per device by the function they replace (k_nrate_fill:
+   same code, same device log - identical values; pvq_refbands.hip does the same for the with-reference
+   stage), two logs and two divisions per candidate otherwise.  Entries [k][sum], k <= NRateTab<N>::K,
+   sum <= (N - 1)*K; the depths cover the pulse counts the luma bands of a 1080p keyframe reach at the
+   operating points measured except band 0 of the 32x32 / 64x64 blocks (K 100-360: computed inline). */
+template <int N> struct NRateTab {
+  static constexpr int K = N == 15 ? 128 : N == 8 ? 64 : 80;
+  static constexpr int W = (N - 1)*K + 1;
+  static constexpr int SIZE = (K + 1)*W;
+};
+__device__ double gNRate8[NRateTab<8>::SIZE];
+__device__ double gNRate15[NRateTab<15>::SIZE];
+__device__ double gNRate32[NRateTab<32>::SIZE];
+__device__ double gNRate128[NRateTab<128>::SIZE];
+
+template <int N>
+__device__ __forceinline__ double *nrate_tab(void) {
+  return N == 8 ? gNRate8 : N == 15 ? gNRate15 : N == 32 ? gNRate32 : gNRate128;
+}
+
+template <int N>
+__global__ void k_nrate_fill(void) {
+  constexpr int W = NRateTab<N>::W;
+  const int i = blockIdx.x*blockDim.x + threadIdx.x;
+  if (i >= NRateTab<N>::SIZE) return;
+  const int k = i/W;
+  const int sum = i - k*W;
+  nrate_tab<N>()[i] = k == 0 ? 0. : odq_pvq_rate_pulses(sum, k, N);
+}
+
+/* odq_pvq_rate_fast(sum, k, n, qg, 0, -1, 0, 1, 0): the join adds nothing when theta < 0 */
+__device__ __forceinline__ double noref_rate(int sum, int k, int n) {
+  if (n == 15) {
+    if (k <= NRateTab<15>::K) return gNRate15[k*NRateTab<15>::W + sum];
+  }
+  else if (n == 8) {
+    if (k <= NRateTab<8>::K) return gNRate8[k*NRateTab<8>::W + sum];
+  }
+  else if (n == 32) {
+    if (k <= NRateTab<32>::K) return gNRate32[k*NRateTab<32>::W + sum];
+  }
+  else if (n == 128) {
+    if (k <= NRateTab<128>::K) return gNRate128[k*NRateTab<128>::W + sum];
+  }
+  return odq_pvq_rate_pulses(sum, k, n);
+}
+
 /* Returns sel | close << 1. */
 template <int PRICE>
 __device__ __forceinline__ int choose_core(const Items &it, int job, const DJob &jb, long sb, int band,
@@ -1232,7 +1280,7 @@ __device__ __forceinline__ int choose_core(const Items &it, int job, const DJob 
     }
     else if (PRICE == 1) {
       const int n = jb.off[band + 1] - jb.off[band];
-      cost = cost + it.lambda*odq_pvq_rate_fast(moms[c], hd.k[c], n, hd.gain[c], 0, -1, 0, 1, 0);
+      cost = cost + it.lambda*noref_rate(moms[c], hd.k[c], n);
       const double d = cost - best_cost;
       if ((d < 0 ? -d : d) <= it.tol_scale*odq_rate_tol(cost, best_cost)) close = true;
     }
@@ -1523,6 +1571,10 @@ int upload_tables_now(void) {
   ODHIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(gInvScan), inv, sizeof(inv)));
   ODHIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(gBandOf), band_of, sizeof(band_of)));
   k_rsq_fill<<<1, kRsqN, 0, 0>>>();
+  k_nrate_fill<8><<<(NRateTab<8>::SIZE + 255)/256, 256, 0, 0>>>();
+  k_nrate_fill<15><<<(NRateTab<15>::SIZE + 255)/256, 256, 0, 0>>>();
+  k_nrate_fill<32><<<(NRateTab<32>::SIZE + 255)/256, 256, 0, 0>>>();
+  k_nrate_fill<128><<<(NRateTab<128>::SIZE + 255)/256, 256, 0, 0>>>();
   ODHIP_TRY(hipDeviceSynchronize());
   return ODHIP_SUCCESS;
 }

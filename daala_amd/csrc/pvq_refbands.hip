@@ -38,6 +38,7 @@
    is one IEEE operation per reference operation (-ffp-contract=off). */
 #include "../../include/daala_hip.h"
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include "od_ctx.cuh"
