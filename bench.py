@@ -610,18 +610,88 @@ def sequential_digest(nframes):
 
 
 def seq_encode_worker(args):
-    """Child process of encode_mode: the plain C reference encoder (nothing bound) on the
-    first N frames of the Y4M file, sequentially; prints the packet digest."""
+    """Child process of encode_mode: the plain C reference encoder (nothing bound) on frames of the
+    Y4M file, one after the other on one core.  `--seq-encode path N`: the first N frames;
+    `--seq-encode path i,j,k`: exactly those global frame indices.  Prints the digest of the packets
+    in index order and the SHA-256 of every packet."""
+    import hashlib
     import encode_job as S
     import daala_amd as D
-    path, n = args.seq_encode[0], int(args.seq_encode[1])
-    frames, w, h, got = S.read_y4m_frames(D, path, 0, 1, n)
+    path, spec = args.seq_encode[0], args.seq_encode[1]
+    if args.seq_core >= 0:
+        _pin(args.seq_core)
+    if "," in spec or spec.startswith("="):
+        want = sorted(int(x) for x in spec.lstrip("=").split(",") if x != "")
+    else:
+        want = list(range(int(spec)))
+    last = (want[-1] + 1) if want else 0
+    wanted = set(want)
+    # every frame up to the last wanted one is walked (read or skipped) by the library's reader
+    frames, w, h, got = S.read_y4m_frames_set(D, path, wanted, last)
+    idx = [i for i in want if i in frames]
     r = ctypes.CDLL(S.REFERENCE_LIB)
     t0 = time.perf_counter()
-    packets = S.encode_frames(r, list(range(got)), [frames[i] for i in range(got)], w, h)
+    packets = S.encode_frames(r, idx, [frames[i] for i in idx], w, h)
     dt = time.perf_counter() - t0
-    print(json.dumps({"digest": S.digest([packets[i] for i in range(got)]), "frames": got, "seconds": dt}))
+    print(json.dumps({"digest": S.digest([packets[i] for i in idx]), "frames": len(idx), "seconds": dt,
+                      "indices": idx, "sha256": [hashlib.sha256(packets[i]).hexdigest() for i in idx]}))
     return 0
+
+
+def sequential_c_check(path, indices, packets, ncores):
+    """The plain C reference encoder on `indices` (global frame indices), compared packet by packet
+    with `packets` (the job's gathered output).  All-intra frames are independent, so the C side is
+    spread over `ncores` child processes (frame list j of ncores, each one sequential on its own
+    core); the frames/s of ONE such process is the plain-C-on-one-core figure."""
+    import hashlib
+    import subprocess
+    indices = sorted(set(int(i) for i in indices))
+    if not indices:
+        return None
+    ncores = max(1, min(ncores, len(indices)))
+    e = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    cores = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else list(range(os.cpu_count() or 1))
+    t0 = time.perf_counter()
+    procs = []
+    for j in range(ncores):
+        part = indices[j::ncores]
+        errf = open("/tmp/odhip_seqcheck_%d_%d.err" % (os.getpid(), j), "w+")
+        procs.append((part, errf, subprocess.Popen(
+            [sys.executable, os.path.abspath(__file__), "--seq-encode", path, "=" + ",".join(map(str, part)),
+             "--seq-core", str(cores[j % len(cores)])], stdout=subprocess.PIPE, stderr=errf, text=True, env=e)))
+    equal = True
+    differing = []
+    checked = 0
+    rates = []
+    error = None
+    for part, errf, pr in procs:
+        out, _ = pr.communicate()
+        errf.seek(0)
+        err = errf.read()
+        errf.close()
+        try:
+            os.remove(errf.name)
+        except OSError:
+            pass
+        if pr.returncode != 0:
+            error = err[-500:]
+            continue
+        ref_out = json.loads(out.strip().splitlines()[-1])
+        rates.append(ref_out["frames"] / max(ref_out["seconds"], 1e-9))
+        for i, want in zip(ref_out["indices"], ref_out["sha256"]):
+            checked += 1
+            if hashlib.sha256(packets[i]).hexdigest() != want:
+                equal = False
+                differing.append(i)
+    if error is not None:
+        return {"error": error}
+    return {"frames": checked, "packets_equal_sequential_c_encoder": equal and checked == len(indices),
+            "differing_frames": differing[:16], "frame_indices": indices if len(indices) <= 64 else
+            "%d frames: %d..%d" % (len(indices), indices[0], indices[-1]),
+            "c_encoder_processes": ncores, "seconds": round(time.perf_counter() - t0, 2),
+            "c_encoder_frames_per_s_one_core": float(np.median(rates)) if rates else None}
 
 
 def encode_mode(args, D, torch, dist, rank, world, local_rank):
@@ -644,6 +714,21 @@ def encode_mode(args, D, torch, dist, rank, world, local_rank):
                          "both built by build()")
     nframes = args.encode_frames
     P = max(1, args.procs_per_gpu)
+    # encoder threads per process: by default what the host grants - the CPU quota of this box over
+    # the ranks that share it (one rank per GPU) and the encoder processes of a rank.  One encoder
+    # context is bound by the reference's sequential host chain at ~0.9 frames/s per core while its
+    # GPU passes take ~10 ms of a frame, so the job scales with host cores: 16 encoders per GPU is
+    # where one MI355X was measured (profiles/r4_encode_mode_300frames.json), fewer means the rank is
+    # host-starved (and says so).
+    quota = host_cpu_quota()
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world))) or 1
+    T_auto = max(1, min(32, quota // max(1, local_world * P)))
+    T = args.threads_per_proc if args.threads_per_proc > 0 else T_auto
+    if rank == 0 and P * T < 16:
+        print("bench.py --encode-frames: %d encoder(s) per GPU (host quota %d CPUs / %d rank(s) on this host / "
+              "%d process(es) per rank): below the 16 per GPU one MI355X was measured with - this run is bound "
+              "by the host cores it was granted, not by the GPUs" % (P * T, quota, local_world, P),
+              file=sys.stderr, flush=True)
     path = args.y4m
     made = False
     if path is None:
@@ -659,21 +744,45 @@ def encode_mode(args, D, torch, dist, rank, world, local_rank):
     t0 = time.perf_counter()
     outs = ["/tmp/odhip_job_%d_%d_%d.npz" % (os.getpid(), rank, p) for p in range(P)]
     procs = []
+    errfiles = []
     for p in range(P):
         e_idx = rank * P + p
         cmd = [sys.executable, os.path.join(ROOT, "encode_job.py"), "--worker", "--y4m", path, "--frames", str(nframes),
                "--stride", str(world * P), "--offset", str(e_idx), "--device", str(local_rank),
-               "--core", "-1" if args.threads_per_proc > 1 else str(cores[e_idx % len(cores)]), "--out", outs[p],
-               "--gpu-lock", str(int(args.gpu_lock)), "--threads", str(max(1, args.threads_per_proc))]
+               "--core", "-1" if T > 1 else str(cores[e_idx % len(cores)]), "--out", outs[p],
+               "--gpu-lock", str(int(args.gpu_lock)), "--threads", str(T), "--selfcheck", str(int(args.encode_selfcheck))]
         env = dict(os.environ)
         for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
             env.pop(k, None)
-        procs.append(subprocess.Popen(cmd, stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+        # stderr to a file: a child that logs more than a pipe holds before READY would block forever
+        errf = open("/tmp/odhip_job_%d_%d_%d.err" % (os.getpid(), rank, p), "w+")
+        errfiles.append(errf)
+        procs.append(subprocess.Popen(cmd, stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=errf,
                                       text=True, env=env))
-    for pr in procs:                      # every encoder has read its frames and coded one (untimed)
+
+    def child_stderr(k):
+        errfiles[k].seek(0)
+        return errfiles[k].read()[-800:]
+
+    def drop_children(reason):
+        # a failed start: the others would see EOF on stdin and encode the whole job for nothing
+        for q in procs:
+            if q.poll() is None:
+                q.kill()
+        for q in procs:
+            q.wait()
+        for f in errfiles:
+            f.close()
+            try:
+                os.remove(f.name)
+            except OSError:
+                pass
+        raise SystemExit(reason)
+
+    for k, pr in enumerate(procs):        # every encoder has read its frames and coded one (untimed)
         line = pr.stdout.readline()
         if line.strip() != "READY":
-            raise SystemExit("encoder process failed to start: %s %s" % (line, pr.stderr.read()[-800:]))
+            drop_children("encoder process failed to start: %s %s" % (line, child_stderr(k)))
     t_start = time.perf_counter() - t0
     if dist is not None:
         dist.barrier()
@@ -682,11 +791,17 @@ def encode_mode(args, D, torch, dist, rank, world, local_rank):
         pr.stdin.write("go\n")
         pr.stdin.flush()
     stats = []
-    for pr in procs:
-        out, err = pr.communicate()
+    for k, pr in enumerate(procs):
+        out, _ = pr.communicate()
         if pr.returncode != 0:
-            raise SystemExit("encoder process failed: %s" % err[-800:])
+            drop_children("encoder process failed: %s" % child_stderr(k))
         stats.append(json.loads(out.strip().splitlines()[-1]))
+    for f in errfiles:
+        f.close()
+        try:
+            os.remove(f.name)
+        except OSError:
+            pass
     t_enc = time.perf_counter() - t0
     if dist is not None:
         dist.barrier()
@@ -711,30 +826,42 @@ def encode_mode(args, D, torch, dist, rank, world, local_rank):
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     if rank != 0:
         return 0
-    nprefix = min(nframes, args.encode_check)
+    # Which frames the plain C encoder re-encodes (rank 0, after the timed job, spread over the host
+    # quota): --encode-check N >= the job -> every frame; N > 0 -> the first N frames AND the LAST frame
+    # of every encoder context (encoder e = frames e, e + E, ...; thread t of a process the t-th of
+    # them): steady-state frames of every thread, not only the ones coded in the untimed warm-up;
+    # -1 (default) -> that per-encoder sample alone; 0 -> no check.
+    E = world * P
+    n_check = args.encode_check
     check = None
-    if nprefix > 0:
-        e = dict(os.environ)
-        for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
-            e.pop(k, None)
-        pr = subprocess.run([sys.executable, os.path.abspath(__file__), "--seq-encode", path, str(nprefix)],
-                            capture_output=True, text=True, timeout=3600, env=e)
-        if pr.returncode == 0:
-            ref_out = json.loads(pr.stdout.strip().splitlines()[-1])
-            check = {"frames": ref_out["frames"],
-                     "packets_equal_sequential_c_encoder": ref_out["digest"] == S.digest(packets[:ref_out["frames"]]),
-                     "c_encoder_frames_per_s_one_core": ref_out["frames"] / ref_out["seconds"]}
+    if n_check != 0:
+        if n_check >= nframes:
+            idx = list(range(nframes))
         else:
-            check = {"error": pr.stderr[-500:]}
+            idx = set(range(max(0, n_check)))
+            for e_i in range(E):
+                owned = list(range(e_i, nframes, E))
+                for t in range(T):
+                    mine = owned[t::T]
+                    if mine:
+                        idx.add(mine[-1])
+            idx = sorted(idx)
+        check = sequential_c_check(path, idx, packets, quota)
+        if check is not None and "error" not in check:
+            check["covers"] = "every frame of the job" if len(idx) == nframes else \
+                "the first %d frames and the last frame of each of the %d encoder contexts" % (max(0, n_check), E * T)
     t_job = float(tt[0].item())
     nf0 = sum(st["frames"] for st in stats)
     batch_ms = sum(st["batch_ms"] for st in stats)
     line = {
         "metric": "1080p all-intra encode frames/s (frame-sharded over the GPUs of one node)",
         "value": nframes / t_job, "unit": "frames/s", "n_gpus": world, "frames": nframes,
-        "encoder_processes_per_gpu": P, "encoder_threads_per_process": max(1, args.threads_per_proc),
-        "encoders_per_gpu": P * max(1, args.threads_per_proc),
-        "host_cores_available": len(cores), "host_cpu_quota": host_cpu_quota(), "gpu_pass_lock": bool(args.gpu_lock),
+        "encoder_processes_per_gpu": P, "encoder_threads_per_process": T,
+        "encoders_per_gpu": P * T,
+        "encoder_threads_source": "--threads-per-proc" if args.threads_per_proc > 0 else
+        "host_cpu_quota %d // (%d rank(s) on this host x %d process(es))" % (quota, local_world, P),
+        "host_starved": P * T < 16, "encoder_selfchecks": int(args.encode_selfcheck),
+        "host_cores_available": len(cores), "host_cpu_quota": quota, "gpu_pass_lock": bool(args.gpu_lock),
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "data": "synthetic",
         "dtype": "int32 (lifting DCT/filters) + f64 (PVQ search)",
         "config": {"workload": "configs[4]: %d-frame %dx%d all-intra encode (-v 20, complexity 7), frame i -> "
@@ -755,6 +882,7 @@ def encode_mode(args, D, torch, dist, rank, world, local_rank):
                   "dering_cache_ms_per_frame": sum(st.get("dering_ms", 0) for st in stats) / max(1, nf0),
                   "served_pvq_theta_ms_per_frame": sum(st.get("theta_ms", 0) for st in stats) / max(1, nf0),
                   "od_compute_dist_served_per_frame": sum(st.get("dist_served", 0) for st in stats) / max(1, nf0),
+                  "dering_served_per_frame": sum(st.get("dering_served", 0) for st in stats) / max(1, nf0),
                   "encoder_seconds_per_process": [round(st["seconds"], 2) for st in stats],
                   "stage_blocks_per_s": blocks_per_frame() * nf0 / max(batch_ms * 1e-3, 1e-9)},
         "prefix_check": check,
@@ -799,17 +927,26 @@ def main():
     ap.add_argument("--procs-per-gpu", type=int, default=1,
                     help="--encode-frames: encoder processes per GPU (they share the rank's device; the host "
                          "chain of one encoder is sequential, ~1 frame/s, while its GPU passes take ~10 ms)")
-    ap.add_argument("--threads-per-proc", type=int, default=1,
+    ap.add_argument("--threads-per-proc", type=int, default=0,
                     help="--encode-frames: encoder contexts (host threads) per encoder process; they share the "
-                         "process's HIP context, so P x T encoders share a GPU with only P processes on it")
+                         "process's HIP context, so P x T encoders share a GPU with only P processes on it.  "
+                         "Default 0: the host CPU quota // (ranks on this host x processes per rank), at most 32; "
+                         "a warning is printed when that leaves fewer than 16 encoders per GPU")
     ap.add_argument("--gpu-lock", type=int, default=0,
                     help="--encode-frames: the batched GPU pass of a frame under a cross-process lock "
                          "(odhip_glue_config.gpu_pass_lock); measured slower than letting the passes "
                          "overlap (profiles/r4_encode_mode_300frames.json), default off")
-    ap.add_argument("--encode-check", type=int, default=2,
-                    help="--encode-frames: how many leading frames rank 0 re-encodes with the plain C encoder "
-                         "(sequentially, one core) to compare the gathered packets with")
+    ap.add_argument("--encode-check", type=int, default=-1,
+                    help="--encode-frames: frames rank 0 re-encodes with the plain C encoder (child processes "
+                         "spread over the host CPU quota, each sequential on one core) and compares packet by "
+                         "packet: N >= the job = every frame; N > 0 = the first N and the last frame of every "
+                         "encoder context; -1 (default) = the last frame of every encoder context; 0 = none")
+    ap.add_argument("--encode-selfcheck", type=int, default=0,
+                    help="--encode-frames: the shim's cross-checks inside every encoder (bit mask: 1 = every batched "
+                         "od_pvq_rate against od_pvq_rate, 2 = every served od_dering superblock against od_dering, "
+                         "4 = every served od_compute_dist against the C function; a difference aborts the encoder)")
     ap.add_argument("--seq-encode", nargs=2, default=None, help=argparse.SUPPRESS)
+    ap.add_argument("--seq-core", type=int, default=-1, help=argparse.SUPPRESS)
     ap.add_argument("--content", choices=sorted(CONTENT), default="checker",
                     help="synthetic picture generator: 'checker' (smooth texture + 32-pixel checker "
                          "edges + uniform noise, independent chroma) or 'natural' (cosines + AR(1) "

@@ -1051,13 +1051,17 @@ extern "C" int odhip_pipe_time_stage(odhip_pipe *p, int stage, int parity, int n
   if (rc) return rc;
   rc = odhip_pipe_sync(p);
   if (rc) return rc;
-  const bool rec = p->record;
-  p->record = false;
   hipStream_t s = p->stream[0];
   hipEvent_t a = nullptr;
   hipEvent_t b = nullptr;
+  /* the events first: a failure here must neither leak one nor leave recording switched off */
   ODHIP_TRY(hipEventCreate(&a));
-  ODHIP_TRY(hipEventCreate(&b));
+  if (hipEventCreate(&b) != hipSuccess) {
+    (void)hipEventDestroy(a);
+    return ODHIP_EFAULT;
+  }
+  const bool rec = p->record;
+  p->record = false;
   rc = odhip_pipe_stage(p, stage, parity);
   (void)hipEventRecord(a, s);
   for (int i = 0; i < n && !rc; i++) rc = odhip_pipe_stage(p, stage, parity);

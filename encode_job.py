@@ -65,7 +65,7 @@ def reference_available():
 
 
 def load_batched_encoder(w, h, device=0, dering_cache=True, check_rates=False, gpu_pass_lock=False, dist_cache=True,
-                         check_dist=False):
+                         check_dist=False, check_dering=False):
     """(reference encoder library, glue library) with the batched GPU stage bound; once per
     process, and only in a process that has not loaded the reference library before."""
     if "r" in _state:
@@ -88,6 +88,7 @@ def load_batched_encoder(w, h, device=0, dering_cache=True, check_rates=False, g
     cfg.dering_cache = int(bool(dering_cache))
     cfg.pic_w, cfg.pic_h = int(w), int(h)
     cfg.check_rates = int(bool(check_rates))
+    cfg.check_dering = int(bool(check_dering))
     cfg.gpu_pass_lock = int(bool(gpu_pass_lock))
     cfg.dist_cache = int(bool(dist_cache and dering_cache))
     cfg.check_dist = int(bool(check_dist))
@@ -193,6 +194,38 @@ def read_y4m_frames(D, path, offset, stride, limit):
     return out, w, h, i
 
 
+def read_y4m_frames_set(D, path, wanted, limit):
+    """As read_y4m_frames, for an arbitrary set of global frame indices (< limit)."""
+    L = D.lib()
+    L.odhip_y4m_open.restype = ctypes.c_void_p
+    w, h, fn, fd, err = (ctypes.c_int() for _ in range(5))
+    y = L.odhip_y4m_open(path.encode(), ctypes.byref(w), ctypes.byref(h), ctypes.byref(fn), ctypes.byref(fd),
+                         ctypes.byref(err))
+    if not y:
+        raise SystemExit("cannot read %s as progressive 8-bit 4:2:0 YUV4MPEG2 (code %d)" % (path, err.value))
+    w, h = w.value, h.value
+    cw, chh = (w + 1) >> 1, (h + 1) >> 1
+    out = {}
+    i = 0
+    while i < limit:
+        if i in wanted:
+            fr = np.empty(w * h + 2 * cw * chh, np.uint8)
+            rc = L.odhip_y4m_read(ctypes.c_void_p(y), fr[:w * h].ctypes.data_as(ctypes.c_void_p),
+                                  fr[w * h:w * h + cw * chh].ctypes.data_as(ctypes.c_void_p),
+                                  fr[w * h + cw * chh:].ctypes.data_as(ctypes.c_void_p))
+            if rc == 1:
+                out[i] = fr
+        else:
+            rc = L.odhip_y4m_skip(ctypes.c_void_p(y))
+        if rc == 0:
+            break
+        if rc < 0:
+            raise SystemExit("%s: loss of framing at frame %d (code %d)" % (path, i, rc))
+        i += 1
+    L.odhip_y4m_close(ctypes.c_void_p(y))
+    return out, w, h, i
+
+
 def worker(args):
     """One encoder process of the job (see the module docstring)."""
     if args.core >= 0:
@@ -203,10 +236,14 @@ def worker(args):
     import daala_amd as D
     frames, w, h, total = read_y4m_frames(D, args.y4m, args.offset, args.stride, args.frames)
     owned = sorted(frames)
-    r, glue = load_batched_encoder(w, h, device=args.device, gpu_pass_lock=args.gpu_lock)
+    # --selfcheck: the shim's own cross-checks against the reference's C definitions (1 = every batched
+    # od_pvq_rate, 2 = every served od_dering superblock, 4 = every served od_compute_dist; a difference aborts)
+    r, glue = load_batched_encoder(w, h, device=args.device, gpu_pass_lock=args.gpu_lock,
+                                   check_rates=bool(args.selfcheck & 1), check_dering=bool(args.selfcheck & 2),
+                                   check_dist=bool(args.selfcheck & 4))
     # T encoder contexts in T host threads of this process (the C call releases the GIL; the shim's
     # state is per thread, the HIP context is shared): thread t takes every T-th of the owned frames
-    T = max(1, args.threads)
+    T = max(1, min(args.threads, len(owned)))     # no thread without a frame
     parts = [owned[t::T] for t in range(T)]
     import threading
     go = threading.Event()
@@ -273,6 +310,7 @@ def main():
     ap.add_argument("--out")
     ap.add_argument("--gpu-lock", type=int, default=0)
     ap.add_argument("--threads", type=int, default=1)
+    ap.add_argument("--selfcheck", type=int, default=0)
     args = ap.parse_args()
     if not args.worker:
         ap.error("encode_job.py is a module; as a program it only runs as --worker (see bench.py --encode-frames)")

@@ -19,6 +19,7 @@
 #include <string.h>
 #include <stdio.h>
 #include <time.h>
+#include <pthread.h>
 #include "../include/daala_hip.h"
 #include "daala_hip_glue.h"
 
@@ -49,6 +50,8 @@ int odhip_glue_configure(const odhip_glue_config *c) {
   g_cfg = *c;
   g_cfg_set = 1;
   if (c->frame_cache || c->band_cache) odhip_glue_enable_frame_cache(c->pic_w, c->pic_h);
+  /* the caches themselves are created by the thread that first loads a plane (thread_cache): a
+     device that cannot be initialised is reported here, not by an abort inside a cache constructor */
   return odhip_init(c->device);
 }
 
@@ -87,6 +90,20 @@ long odhip_glue_dist[2];       /* od_compute_dist calls served from the dering c
 static __thread double t_dering_ms;
 static __thread double t_theta_ms;
 void odhip_glue_flush_stats(void);
+
+/* Per-thread caches are freed when their thread exits (a host with short-lived encoder threads
+   would otherwise leak their pinned and device memory): a pthread key whose destructor folds the
+   thread's counters into the process totals and destroys its frame / dering cache. */
+static pthread_key_t g_thread_key;
+static pthread_once_t g_thread_key_once = PTHREAD_ONCE_INIT;
+static void thread_teardown(void *unused);
+static void thread_key_make(void) {
+  (void)pthread_key_create(&g_thread_key, thread_teardown);
+}
+static void thread_register(void) {
+  (void)pthread_once(&g_thread_key_once, thread_key_make);
+  (void)pthread_setspecific(g_thread_key, (void *)1);
+}
 
 /* od_state_opt_vtbl_init (src/state.c:346-352): the reference's backend
    dispatch.  With bind_dct_vtbl this is the load-time form of the one
@@ -203,6 +220,7 @@ static odhip_dering_cache *thread_dering_cache(void) {
       fprintf(stderr, "daala_hip_glue: odhip_dering_cache_create failed (no CPU fallback)\n");
       abort();
     }
+    thread_register();
   }
   return g_dering_cache;
 }
@@ -305,15 +323,18 @@ static odhip_frame_cache *thread_cache(void) {
     }
     odhip_cache_set_picture(g_cache, cfg()->pic_w, cfg()->pic_h);
     odhip_cache_make_current(g_cache);
+    thread_register();
   }
   return g_cache;
 }
 
+/* The cache itself is created by the thread that first loads a plane (glue_load_plane_timed): the
+   configuring thread of a multi-threaded host (encode_job.py's main thread) never encodes. */
 void odhip_glue_enable_frame_cache(int pic_w, int pic_h) {
   cfg()->frame_cache = 1;
   cfg()->pic_w = pic_w;
   cfg()->pic_h = pic_h;
-  odhip_cache_set_picture(thread_cache(), pic_w, pic_h);
+  if (g_cache) odhip_cache_set_picture(g_cache, pic_w, pic_h);
 }
 
 /* The transforms to put into od_state.opt_vtbl when the frame cache is on: fdct_2d served from
@@ -339,10 +360,26 @@ static void ms_add(double *acc, const struct timespec *a) {
   *acc += ms;
   __atomic_store_n(&g_ms_lock, 0, __ATOMIC_RELEASE);
 }
+/* Cache figures of every thread, folded as deltas (a thread's caches keep running totals). */
+static long g_cache_tot[6];            /* fdct hits / misses, band hits / misses, dering launches / served */
+static __thread long t_cache_seen[6];
 /* The calling thread's counters and timers into the process totals. */
 void odhip_glue_flush_stats(void) {
   int i;
+  long cur[6];
+  memset(cur, 0, sizeof(cur));
+  for (i = 0; i < 6; i++) cur[i] = t_cache_seen[i];
+  if (g_cache) {
+    odhip_cache_stats(g_cache, &cur[0], &cur[1]);
+    odhip_cache_band_stats(g_cache, &cur[2], &cur[3]);
+  }
+  if (g_dering_cache) odhip_dering_cache_stats(g_dering_cache, &cur[4], &cur[5]);
   while (__atomic_exchange_n(&g_ms_lock, 1, __ATOMIC_ACQUIRE)) {
+  }
+  for (i = 0; i < 6; i++) {
+    /* a cache that was re-created starts from zero again */
+    g_cache_tot[i] += cur[i] >= t_cache_seen[i] ? cur[i] - t_cache_seen[i] : cur[i];
+    t_cache_seen[i] = cur[i];
   }
   for (i = 0; i < 6; i++) {
     odhip_glue_calls[i] += t_calls[i];
@@ -376,16 +413,28 @@ static void glue_load_plane(const od_coeff *c, int stride, int nhsb, int nvsb, i
 #include <fcntl.h>
 #include <sys/file.h>
 #include <unistd.h>
+/* flock() excludes open file descriptions, i.e. other PROCESSES; the threads of one process share
+   the description, so they are excluded from each other by a mutex taken first (and released
+   last: the flock is never dropped while a sibling thread is inside its pass). */
 static int g_lock_fd = -1;
+static pthread_once_t g_lock_once = PTHREAD_ONCE_INIT;
+static pthread_mutex_t g_lock_mutex = PTHREAD_MUTEX_INITIALIZER;
+static void gpu_pass_lock_open(void) {
+  char path[64];
+  snprintf(path, sizeof(path), "/tmp/odhip_glue_gpu%d.lock", cfg()->device);
+  g_lock_fd = open(path, O_CREAT | O_RDWR | O_CLOEXEC, 0666);
+}
 static void gpu_pass_lock(int on) {
   if (!cfg()->gpu_pass_lock) return;
-  if (g_lock_fd < 0) {
-    char path[64];
-    snprintf(path, sizeof(path), "/tmp/odhip_glue_gpu%d.lock", cfg()->device);
-    g_lock_fd = open(path, O_CREAT | O_RDWR, 0666);
-    if (g_lock_fd < 0) return;
+  (void)pthread_once(&g_lock_once, gpu_pass_lock_open);
+  if (on) {
+    (void)pthread_mutex_lock(&g_lock_mutex);
+    if (g_lock_fd >= 0) (void)flock(g_lock_fd, LOCK_EX);
   }
-  (void)flock(g_lock_fd, on ? LOCK_EX : LOCK_UN);
+  else {
+    if (g_lock_fd >= 0) (void)flock(g_lock_fd, LOCK_UN);
+    (void)pthread_mutex_unlock(&g_lock_mutex);
+  }
 }
 
 static void glue_load_plane_timed(const od_coeff *c, int stride, int nhsb, int nvsb, int xdec);
@@ -439,16 +488,32 @@ void odhip_glue_get_stats(odhip_glue_stats *st) {
   memset(st, 0, sizeof(*st));
   for (i = 0; i < 6; i++) st->calls[i] = odhip_glue_calls[i];
   for (i = 0; i < 4; i++) st->theta[i] = odhip_glue_theta[i];
-  if (g_cache) {
-    odhip_cache_stats(g_cache, &st->fdct_hits, &st->fdct_misses);
-    odhip_cache_band_stats(g_cache, &st->band_hits, &st->band_misses);
-  }
-  if (g_dering_cache) odhip_dering_cache_stats(g_dering_cache, &st->dering_launches, &st->dering_served);
+  st->fdct_hits = g_cache_tot[0];
+  st->fdct_misses = g_cache_tot[1];
+  st->band_hits = g_cache_tot[2];
+  st->band_misses = g_cache_tot[3];
+  st->dering_launches = g_cache_tot[4];
+  st->dering_served = g_cache_tot[5];
   st->batch_ms = odhip_glue_batch_ms;
   st->dering_ms = odhip_glue_dering_ms;
   st->dist_served = odhip_glue_dist[0];
   st->dist_left = odhip_glue_dist[1];
   st->theta_ms = odhip_glue_theta_ms;
+}
+
+static void thread_teardown(void *unused) {
+  (void)unused;
+  odhip_glue_flush_stats();
+  if (g_cache) {
+    odhip_cache_destroy(g_cache);
+    g_cache = NULL;
+  }
+  if (g_dering_cache) {
+    odhip_dering_cache_destroy(g_dering_cache);
+    g_dering_cache = NULL;
+  }
+  memset(t_cache_seen, 0, sizeof(t_cache_seen));
+  g_nbases = 0;
 }
 
 /* daala_encode_img_in (include/daala/daalaenc.h:118): remembers which encoder the
@@ -506,20 +571,27 @@ int od_pvq_encode(void *enc, od_coeff *ref, const od_coeff *in, od_coeff *out, i
    state, apply `cost <= best_cost`, the skip rule, and synthesise the winner with the
    reference's own od_gain_expand / od_pvq_synthesis_partial.  Every other band goes
    to the reference's pvq_theta untouched. */
+typedef double (*theta_rate_fn)(int, int, int, int, const void *, const od_coeff *, int, int, int, int, int);
+typedef int32_t (*theta_expand_fn)(int32_t, int, int16_t);
+typedef void (*theta_synth_fn)(od_coeff *, const od_coeff *, const int16_t *, int, int, int32_t, int32_t,
+ int, int, const int16_t *);
+static theta_rate_fn g_theta_rate;
+static theta_expand_fn g_theta_gain_expand;
+static theta_synth_fn g_theta_synthesis;
+static pthread_once_t g_theta_syms_once = PTHREAD_ONCE_INIT;
+static void theta_syms_resolve(void) {
+  g_theta_rate = NEXT(theta_rate_fn, "od_pvq_rate");
+  g_theta_gain_expand = NEXT(theta_expand_fn, "od_gain_expand");
+  g_theta_synthesis = NEXT(theta_synth_fn, "od_pvq_synthesis_partial");
+}
+
 int pvq_theta(od_coeff *out, const od_coeff *x0, const od_coeff *r0, int n, int q0, od_coeff *y,
  int *itheta, int *max_theta, int *vk, int16_t beta, double *skip_diff, int nodesync, int is_keyframe,
  int pli, const void *adapt, const int16_t *qm, const int16_t *qm_inv, double pvq_norm_lambda,
  int speed) {
   typedef int (*fn)(od_coeff *, const od_coeff *, const od_coeff *, int, int, od_coeff *, int *, int *,
    int *, int16_t, double *, int, int, int, const void *, const int16_t *, const int16_t *, double, int);
-  typedef double (*rate_fn)(int, int, int, int, const void *, const od_coeff *, int, int, int, int, int);
-  typedef int32_t (*expand_fn)(int32_t, int, int16_t);
-  typedef void (*synth_fn)(od_coeff *, const od_coeff *, const int16_t *, int, int, int32_t, int32_t,
-   int, int, const int16_t *);
   static fn next;
-  static rate_fn rate;
-  static expand_fn gain_expand;
-  static synth_fn synthesis;
   odhip_band_cands c;
   const int band = t_band++;
   int i;
@@ -545,11 +617,13 @@ int pvq_theta(od_coeff *out, const od_coeff *x0, const od_coeff *r0, int n, int 
       int qg;
       int best_k;
       int s;
-      if (!rate) {
-        rate = NEXT(rate_fn, "od_pvq_rate");
-        gain_expand = NEXT(expand_fn, "od_gain_expand");
-        synthesis = NEXT(synth_fn, "od_pvq_synthesis_partial");
-      }
+      /* three pointers, resolved together exactly once: sixteen encoder threads reach their first
+         served band at the same time (a single `if (!rate)` guard let a second thread see `rate`
+         set while the other two were still NULL) */
+      (void)pthread_once(&g_theta_syms_once, theta_syms_resolve);
+      const theta_rate_fn rate = g_theta_rate;
+      const theta_expand_fn gain_expand = g_theta_gain_expand;
+      const theta_synth_fn synthesis = g_theta_synthesis;
       struct timespec t_a;
       clock_gettime(CLOCK_MONOTONIC, &t_a);
       t_theta[0]++;

@@ -62,8 +62,10 @@ int odhip_glue_check_dist(void);
    different threads of one process and share its HIP context (16 encoder threads in one process:
    7.9 ms of GPU passes per frame, 16 processes: 50 ms - profiles/r4_encode_mode_300frames.json).
    One encoder per thread at a time; the hot counters are counted per thread and folded into the
-   process totals at frame boundaries (odhip_glue_flush_stats); the cache hit / miss / dering
-   figures of odhip_glue_get_stats are the calling thread's. */
+   process totals at frame boundaries (odhip_glue_flush_stats), the cache hit / miss / dering
+   figures with them (as deltas of each thread's caches), so odhip_glue_get_stats reports the whole
+   process from any thread.  A thread's caches are created on its first plane load - not by the
+   configuring thread - and destroyed when the thread exits (a pthread key destructor). */
 
 /* All per-call surfaces bound, no batched binding, no checks, device 0. */
 void odhip_glue_default_config(odhip_glue_config *cfg);

@@ -49,16 +49,28 @@ def test_configs4_encode_mode_two_ranks_one_gpu(tmp_path):
     env.update(ODHIP_BENCH_ONE_GPU="1", ODHIP_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
            "--master-addr", "127.0.0.1", "--master-port", "29633", os.path.join(ROOT, "bench.py"),
-           "--gpus", "2", "--encode-frames", "5", "--encode-check", "5"]
+           "--gpus", "2", "--encode-frames", "12", "--encode-check", "12"]
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, env=env, cwd=ROOT)
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, p.stdout[-2000:]
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["frames"] == 5 and d["unit"] == "frames/s" and d["value"] > 0
-    assert d["rank0"]["frames"] == 3 and d["rank0"]["bands_from_batch"] > 100000
-    assert d["prefix_check"]["frames"] == 5          # every frame of the job, not a prefix
+    assert d["n_gpus"] == 2 and d["frames"] == 12 and d["unit"] == "frames/s" and d["value"] > 0
+    assert d["rank0"]["frames"] == 6 and d["rank0"]["bands_from_batch"] > 100000
+    # no --threads-per-proc: the encoder threads of a rank are sized from what the host grants -
+    # the CPU quota over the two ranks that share this box - and the line says whether that starves a GPU
+    sys.path.insert(0, ROOT)
+    import bench
+    quota = bench.host_cpu_quota()
+    assert d["host_cpu_quota"] == quota
+    assert d["encoder_threads_per_process"] == max(1, min(32, quota // 2))
+    assert d["encoder_threads_source"].startswith("host_cpu_quota")
+    assert d["host_starved"] == (d["encoders_per_gpu"] < 16)
+    if d["host_starved"]:
+        assert "below the 16 per GPU" in p.stderr
+    assert d["prefix_check"]["frames"] == 12         # every frame of the job, not a prefix
     assert d["prefix_check"]["packets_equal_sequential_c_encoder"] is True
+    assert d["prefix_check"]["covers"] == "every frame of the job"
 
 
 @pytest.mark.skipif(not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libdaalaref.so")),
@@ -85,3 +97,28 @@ def test_configs4_encode_mode_rccl_world_size_one_two_encoders_per_gpu():
     assert d["rank0"]["frames"] == 6 and len(d["rank0"]["encoder_seconds_per_process"]) == 2
     assert d["prefix_check"]["frames"] == 6
     assert d["prefix_check"]["packets_equal_sequential_c_encoder"] is True
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libdaalaref_distglue.so")),
+                    reason="oracle/_ref (the reference encoder: the host half) not present")
+def test_configs4_four_encoder_threads_with_the_shims_cross_checks():
+    """Four encoder THREADS of one process sharing one HIP context, every batched price, every served
+    od_dering superblock and every served od_compute_dist cross-checked inside the encoders against the
+    reference's own C definitions (a difference aborts the encoder), and the check on the steady-state
+    frames of every thread - the LAST frame each thread coded - not on the warm-up prefix."""
+    env = dict(os.environ)
+    env.update(HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("ODHIP_BENCH_BACKEND", "ODHIP_BENCH_FORCE_DIST", "ODHIP_BENCH_ONE_GPU"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--encode-frames", "12", "--threads-per-proc", "4",
+           "--encode-selfcheck", "7"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-3000:]
+    d = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["encoder_threads_per_process"] == 4 and d["encoder_selfchecks"] == 7
+    chk = d["prefix_check"]
+    assert chk["frame_indices"] == [8, 9, 10, 11], chk      # thread t's last frame: 8 + t
+    assert chk["packets_equal_sequential_c_encoder"] is True, chk
+    r0 = d["rank0"]
+    assert r0["bands_from_batch"] > 12 * 100000 and r0["od_compute_dist_served_per_frame"] > 2000
+    assert r0["dering_served_per_frame"] > 2000
