@@ -422,6 +422,71 @@ def cpu_baseline(D, qt, chroma_cfl, args, gpu_frame0, timed_recon=None, timed_de
     return base, host, ver
 
 
+SWEEP_POINTS = (("checker", 5), ("checker", 10), ("checker", 40), ("natural", 5), ("natural", 10), ("natural", 40))
+
+
+def quality_sweep(D, torch, frames, steps, local_rank, cfl, seed, verify=True):
+    """Auxiliary entries (never `value`): the same priced step at other operating points than
+    `-v 20` - quantisers 5, 10 and 40 on both content types (K from ~1 to tens of pulses per band) -
+    each one timed like the headline (warm-up, `steps` steps, flush, sync) and VERIFIED like it on
+    frame 0 of its batch: pixels of every partition level and gain / theta / K / pulses of every band
+    against the compiled reference's pvq_theta with that quantiser set-up."""
+    global GENERATOR
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import _pipeline_check as C
+    from _libs import ref
+    saved = GENERATOR
+    pics = {}
+    out = []
+    try:
+        for content, q in SWEEP_POINTS:
+            GENERATOR = CONTENT[content]
+            if content not in pics:
+                pics[content] = synth_pictures(frames, seed)
+            luma_pic, chroma_pic = pics[content]
+            qt = D.QuantTables.for_quality(q)
+            pipe = D.Pipe(qt, frames, PIC_W, PIC_H, chroma_cfl=cfl, device=local_rank, price=True)
+            pipe.set_pictures(luma_pic, chroma_pic)
+            for _ in range(2):
+                pipe.step()
+            pipe.flush()
+            pipe.sync()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                pipe.step()
+            pipe.flush()
+            pipe.sync()
+            dt = time.perf_counter() - t0
+            ent = {"content": content, "quality": "-v %d" % q, "quantizer": int(qt.quantizer),
+                   "ms_per_step": dt / steps * 1e3, "steps": steps,
+                   "value": frames * steps * blocks_per_frame() / dt, "unit": "blocks/s",
+                   "theta_margin_reruns": pipe.theta_reruns(), "price_margin_reruns": pipe.price_reruns(),
+                   "verified": None}
+            if verify and ref() is not None:
+                F = frames
+                recon = [[pipe.read(D.BUF_RECON, 0, bs).reshape(F, H, W) for bs in range(5)],
+                         [pipe.read(D.BUF_RECON, 1, bs).reshape(2 * F, H // 2, W // 2) for bs in range(4)]]
+                dec = C.gpu_decisions(D, pipe)
+                want = []
+                frame0 = [luma_pic[0], chroma_pic[0], chroma_pic[F]]
+                c0 = time.perf_counter()
+                cpu, blocks, _ = C.cpu_frame(qt, frame0, PIC_W, PIC_H, chroma_cfl=cfl, decisions=want)
+                cdt = time.perf_counter() - c0
+                bad = C.compare_frame(recon, cpu, frame=0, frames=F)
+                dbad = C.compare_decisions(dec, want, frame=0, frames=F)
+                ks = [int(b[..., 3].sum()) for plane in want for (_, b) in plane]
+                nbands = int(sum(b.shape[0] * b.shape[1] for plane in want for (_, b) in plane))
+                ent.update({"verified": not bad and not dbad, "bands_compared": nbands,
+                            "mean_k_per_band": round(sum(ks) / max(1, nbands), 3),
+                            "pixel_mismatches": bad[:4], "decision_mismatches": dbad[:4],
+                            "reference_c_blocks_per_s_one_core": blocks / cdt})
+            out.append(ent)
+            pipe.destroy()
+    finally:
+        GENERATOR = saved
+    return out
+
+
 def sharded_encode_check(rank, world, local_rank, dist, torch):
     """--gpus N > 1, when the compiled reference travelled with the snapshot: BASELINE
     configs[4] in miniature on the N GPUs - one 1080p frame per rank through the real
@@ -913,6 +978,9 @@ def main():
                     help="skip the serial replay after the timed region (profiling runs: no extra launches)")
     ap.add_argument("--no-streaming", action="store_true",
                     help="skip the auxiliary run that feeds every step's pictures from pinned host memory")
+    ap.add_argument("--no-sweep", action="store_true",
+                    help="skip the auxiliary operating-point sweep (-v 5 / 10 / 40 on both content types, each "
+                         "verified on frame 0 against the compiled reference: ~1 minute of host time)")
     ap.add_argument("--no-price", action="store_true",
                     help="choose on distortion alone inside the step (no od_pvq_rate)")
     ap.add_argument("--no-shard-check", action="store_true",
@@ -1111,6 +1179,41 @@ def main():
                              "(odhip_pipe_feed: own copy stream, double-buffered, overlapped with the previous "
                              "step) - the input side of the PCIe-inclusive rate; this rank only; the outputs "
                              "stay on the device (DESIGN.md section 5b for what exporting candidates costs)"}
+    # ... and the OUTPUT side too (VERDICT r4 missing #5): the same fed steps with what a host entropy
+    # coder consumes - the choice record and pulse vector of every band - copied back to pinned host
+    # memory on a third stream, overlapped (odhip_pipe_set_export).  Never `value`.
+    streaming_io = None
+    if rank == 0 and not args.no_streaming and cfl and price:
+        nbytes = pipe.export_bytes()
+        if nbytes > 0:
+            hout = torch.empty(nbytes, dtype=torch.uint8).pin_memory()
+            pipe.set_export(hout)
+            for _ in range(2):
+                pipe.feed(hl, hc)
+                pipe.step()
+            pipe.flush()
+            pipe.sync()
+            io_steps = max(3, args.steps // 2)
+            s0 = time.perf_counter()
+            for _ in range(io_steps):
+                pipe.feed(hl, hc)
+                pipe.step()
+            pipe.flush()
+            pipe.sync()
+            sdt = time.perf_counter() - s0
+            pipe.set_export(None)
+            streaming_io = {"value": args.frames * io_steps * blocks_per_frame() / sdt, "unit": "blocks/s",
+                            "ms_per_step": sdt / io_steps * 1e3, "steps": io_steps,
+                            "h2d_bytes_per_step": int(h2d), "d2h_bytes_per_step": int(nbytes),
+                            "d2h_GBs": nbytes * io_steps / sdt / 1e9,
+                            "d2h_bytes_per_frame": int(nbytes // args.frames),
+                            "note": "streaming_input plus the decisions of every step - choice records and pulse "
+                                    "vectors of every band of every level, what a host entropy coder consumes - "
+                                    "copied to pinned host memory on a third stream behind the stage that produced "
+                                    "them (odhip_pipe_set_export): the PCIe-inclusive rate of the stage with both "
+                                    "directions counted; D2H-bound (the step EVALUATES every block of every level; "
+                                    "an encoder that exports only the partition it codes moves ~2 % of this)"}
+            del hout
     shard_check = None
     if dist is not None and not args.no_shard_check:
         shard_check = sharded_encode_check(rank, world, local_rank, dist, torch)
@@ -1298,6 +1401,7 @@ def main():
             "theta_margin_reruns": pipe.theta_reruns(),
             "price_margin_reruns": pipe.price_reruns() if price else None,
             "streaming_input": streaming,
+            "streaming_io": streaming_io,
             "single_frame_step": single,
             "step_counters": step_counters(pmc, pmc_src, pmc_stale, step_ms),
             "kernels": kernels,
@@ -1320,6 +1424,10 @@ def main():
                 line["speedup_vs_all_host_cores"] = line["value"] / host["value"]
             line["verified"] = ver["verified"]
             line["verification"] = ver
+            if price and cfl and not args.no_sweep:
+                # other operating points: -v 5 / 10 / 40 on both content types
+                line["quality_sweep"] = quality_sweep(D, torch, args.frames, max(3, args.steps // 2), local_rank,
+                                                      cfl, 1234 + rank)
             line["coded_blocks_per_frame"] = ver.pop("coded_blocks_frame0", None)
         print(json.dumps(line))
     pipe.destroy()

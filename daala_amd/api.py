@@ -1049,6 +1049,21 @@ class Pipe:
         assert tuple(chroma.shape) == (2 * self.frames, self.pic_h // 2, self.pic_w // 2)
         _check(lib().odhip_pipe_feed(self._p(), ctypes.c_void_p(pl), ctypes.c_void_p(pc)), "odhip_pipe_feed")
 
+    def export_bytes(self):
+        """Bytes one step copies to the host with set_export (odhip_pipe_export_bytes)."""
+        lib().odhip_pipe_export_bytes.restype = ctypes.c_size_t
+        return int(lib().odhip_pipe_export_bytes(self._p()))
+
+    def set_export(self, host):
+        """host: a pinned CPU uint8 torch tensor of export_bytes() bytes (kept alive by the caller
+        until set_export(None)), or None to stop: every following step copies its choice records and
+        pulse vectors there on the pipe's export stream (odhip_pipe_set_export)."""
+        if host is None:
+            _check(lib().odhip_pipe_set_export(self._p(), ctypes.c_void_p(0)), "odhip_pipe_set_export")
+            return
+        assert not host.is_cuda and host.is_contiguous() and host.numel() * host.element_size() >= self.export_bytes()
+        _check(lib().odhip_pipe_set_export(self._p(), ctypes.c_void_p(host.data_ptr())), "odhip_pipe_set_export")
+
     def step(self):
         _check(lib().odhip_pipe_step(self._p()), "odhip_pipe_step")
 

@@ -99,6 +99,13 @@ struct odhip_pipe {
   hipEvent_t ev_pad[2];           /* the padding kernel of a chain has read its pictures */
   int front;
   bool fed;
+  /* odhip_pipe_set_export: what a host entropy coder consumes - choice records and pulse vectors of
+     every band - leaves for pinned host memory on a third stream, behind the stage that produced it */
+  hipStream_t export_stream;
+  uint8_t *export_host;
+  hipEvent_t ev_exp_luma[2];      /* the luma outputs of parity [i] have left */
+  hipEvent_t ev_exp_chroma;       /* the chroma outputs (shared between the parities) have left */
+  hipEvent_t ev_chroma_done;
   std::vector<hipEvent_t> timed[kStages];    /* pairs */
   std::vector<void *> owned;
 };
@@ -627,17 +634,82 @@ int step_noref(odhip_pipe *p) {
   return stage_inverse_noref(p, 1, s, 0);
 }
 
+/* ---- the output side of the PCIe-inclusive rate (odhip_pipe_set_export) ------------------
+   Layout of the host buffer: per luma level the choice records (int32 [blocks][bands][4]) then
+   the pulse vectors (int16 [2][blocks][len]: a band's winner lies in the slot its record names),
+   then per chroma level the choice records (int32 [blocks][bands][16]) and the winners' pulse
+   vectors (slot 0, int16 [blocks][len]). */
+size_t export_luma_bytes(const odhip_pipe *p, int bs) {
+  int nb = 0;
+  int len = 0;
+  odhip_pvq_band_layout(bs, &nb, nullptr, &len);
+  const size_t B = (size_t)p->set[0].nblocks[bs];
+  return sizeof(int32_t)*B*nb*4 + sizeof(int16_t)*2*B*len;
+}
+
+size_t export_chroma_bytes(const odhip_pipe *p, int bs) {
+  int nb = 0;
+  int len = 0;
+  odhip_pvq_band_layout(bs, &nb, nullptr, &len);
+  const size_t B = (size_t)p->set[1].nblocks[bs];
+  return sizeof(int32_t)*B*nb*16 + sizeof(int16_t)*B*len;
+}
+
+int export_luma(odhip_pipe *p, int par) {
+  hipStream_t x = p->export_stream;
+  ODHIP_TRY(hipStreamWaitEvent(x, p->ev_refs[par], 0));         /* the luma choices of this step are final */
+  uint8_t *dst = p->export_host;
+  for (int bs = 0; bs < 5; bs++) {
+    int nb = 0;
+    int len = 0;
+    odhip_pvq_band_layout(bs, &nb, nullptr, &len);
+    const size_t B = (size_t)p->set[0].nblocks[bs];
+    const odhip_pvq_job &j = p->jobs[par][bs];
+    ODHIP_TRY(hipMemcpyAsync(dst, j.cands.choice, sizeof(int32_t)*B*nb*4, hipMemcpyDeviceToHost, x));
+    dst += sizeof(int32_t)*B*nb*4;
+    ODHIP_TRY(hipMemcpyAsync(dst, j.cands.y, sizeof(int16_t)*2*B*len, hipMemcpyDeviceToHost, x));
+    dst += sizeof(int16_t)*2*B*len;
+  }
+  ODHIP_TRY(hipEventRecord(p->ev_exp_luma[par], x));
+  return ODHIP_SUCCESS;
+}
+
+int export_chroma(odhip_pipe *p, int par) {
+  hipStream_t x = p->export_stream;
+  ODHIP_TRY(hipEventRecord(p->ev_chroma_done, p->stream[1]));
+  ODHIP_TRY(hipStreamWaitEvent(x, p->ev_chroma_done, 0));
+  uint8_t *dst = p->export_host;
+  for (int bs = 0; bs < 5; bs++) dst += export_luma_bytes(p, bs);
+  for (int bs = 0; bs < 4; bs++) {
+    int nb = 0;
+    int len = 0;
+    odhip_pvq_band_layout(bs, &nb, nullptr, &len);
+    const size_t B = (size_t)p->set[1].nblocks[bs];
+    const odhip_pvq_refjob &j = p->refjobs[par][bs];
+    ODHIP_TRY(hipMemcpyAsync(dst, j.choice, sizeof(int32_t)*B*nb*16, hipMemcpyDeviceToHost, x));
+    dst += sizeof(int32_t)*B*nb*16;
+    ODHIP_TRY(hipMemcpyAsync(dst, j.y, sizeof(int16_t)*B*len, hipMemcpyDeviceToHost, x));
+    dst += sizeof(int16_t)*B*len;
+  }
+  ODHIP_TRY(hipEventRecord(p->ev_exp_chroma, x));
+  return ODHIP_SUCCESS;
+}
+
 int step_cfl(odhip_pipe *p) {
   hipStream_t main = p->stream[0];
   hipStream_t side = p->stream[1];
   const int par = (int)(p->nstep & 1);
+  const bool exporting = p->export_host != nullptr;
   {
     Current cur(p->ctx[0]);
+    /* exporting: the band stage overwrites the choices and pulses of step i - 2, which must have left */
+    if (exporting) ODHIP_TRY(hipStreamWaitEvent(main, p->ev_exp_luma[par], 0));
     STEP_TRY(luma_front(p, main, par));
     STEP_TRY(luma_choose(p, main, par));
     /* the luma choices of this step are final: the chroma chain takes its references from
        them (odhip_pvq_refjob.luma) */
     ODHIP_TRY(hipEventRecord(p->ev_refs[par], main));
+    if (exporting) STEP_TRY(export_luma(p, par));
     STEP_TRY(stage_inverse_noref(p, 0, main, par));
   }
   STEP_TRY(finish_pending(p));
@@ -646,9 +718,12 @@ int step_cfl(odhip_pipe *p) {
     STEP_TRY(stage_pad(p, 1, side));
     STEP_TRY(stage_pyramid(p, 1, side));
     ODHIP_TRY(hipStreamWaitEvent(side, p->ev_refs[par], 0));
+    /* exporting: the two parities share the chroma outputs - those of step i - 1 must have left */
+    if (exporting) ODHIP_TRY(hipStreamWaitEvent(side, p->ev_exp_chroma, 0));
     STEP_TRY(chroma_bands(p, par, side));
     /* only the preparation kernels of the band stage read the luma choices */
     ODHIP_TRY(hipEventRecord(p->ev_used[par], side));
+    if (exporting) STEP_TRY(export_chroma(p, par));
     STEP_TRY(chroma_tail(p, par, side));
   }
   p->pending = par;
@@ -681,6 +756,9 @@ extern "C" odhip_pipe *odhip_pipe_create(const odhip_pipe_config *cfg) {
   p->ev_pad[0] = p->ev_pad[1] = nullptr;
   p->front = 0;
   p->fed = false;
+  p->export_stream = nullptr;
+  p->export_host = nullptr;
+  p->ev_exp_luma[0] = p->ev_exp_luma[1] = p->ev_exp_chroma = p->ev_chroma_done = nullptr;
   if (pipe_init(p) != ODHIP_SUCCESS) {
     odhip_pipe_destroy(p);
     return nullptr;
@@ -702,6 +780,10 @@ extern "C" void odhip_pipe_destroy(odhip_pipe *p) {
   }
   if (p->ev_fed) (void)hipEventDestroy(p->ev_fed);
   if (p->copy_stream) (void)hipStreamDestroy(p->copy_stream);
+  for (hipEvent_t e : {p->ev_exp_luma[0], p->ev_exp_luma[1], p->ev_exp_chroma, p->ev_chroma_done}) {
+    if (e) (void)hipEventDestroy(e);
+  }
+  if (p->export_stream) (void)hipStreamDestroy(p->export_stream);
   if (p->stream[1] && p->stream[1] != p->stream[0]) (void)hipStreamDestroy(p->stream[1]);
   if (p->stream[0]) (void)hipStreamDestroy(p->stream[0]);
   for (int i = 0; i < kStages; i++) {
@@ -754,6 +836,37 @@ extern "C" int odhip_pipe_feed(odhip_pipe *p, const uint8_t *luma, const uint8_t
   return ODHIP_SUCCESS;
 }
 
+/* Bytes one step exports (odhip_pipe_set_export), 0 for the modes that do not export. */
+extern "C" size_t odhip_pipe_export_bytes(const odhip_pipe *p) {
+  if (!p || !p->cfg.chroma_cfl || p->cfg.inter || !p->cfg.price) return 0;
+  size_t n = 0;
+  for (int bs = 0; bs < 5; bs++) n += export_luma_bytes(p, bs);
+  for (int bs = 0; bs < 4; bs++) n += export_chroma_bytes(p, bs);
+  return n;
+}
+
+/* host != NULL: every following step copies its decisions (choice records + pulse vectors of every
+   band, the layout above export_luma_bytes) to `host` - odhip_pipe_export_bytes(p) bytes of pinned
+   host memory - on the pipe's export stream, overlapped with the rest of the step; the buffer holds
+   step i once odhip_pipe_sync() returns after step i (a band the host-libm resolve re-decides one
+   step late - none on any content measured - is not re-exported).  NULL: stop exporting.  Keyframe
+   steps with chroma from luma and pricing on the device only (ODHIP_EIMPL otherwise). */
+extern "C" int odhip_pipe_set_export(odhip_pipe *p, void *host) {
+  if (!p) return ODHIP_EINVAL;
+  if (host && odhip_pipe_export_bytes(p) == 0) return ODHIP_EIMPL;
+  const int rc = odhip_pipe_sync(p);
+  if (rc) return rc;
+  ODHIP_TRY(hipSetDevice(p->cfg.device));
+  if (host && !p->export_stream) {
+    ODHIP_TRY(hipStreamCreateWithFlags(&p->export_stream, hipStreamNonBlocking));
+    for (hipEvent_t *e : {&p->ev_exp_luma[0], &p->ev_exp_luma[1], &p->ev_exp_chroma, &p->ev_chroma_done}) {
+      ODHIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
+    }
+  }
+  p->export_host = static_cast<uint8_t *>(host);
+  return ODHIP_SUCCESS;
+}
+
 extern "C" int odhip_pipe_step(odhip_pipe *p) {
   if (!p) return ODHIP_EINVAL;
   ODHIP_TRY(hipSetDevice(p->cfg.device));
@@ -802,6 +915,7 @@ extern "C" int odhip_pipe_sync(odhip_pipe *p) {
   ODHIP_TRY(hipStreamSynchronize(p->stream[0]));
   if (p->stream[1] != p->stream[0]) ODHIP_TRY(hipStreamSynchronize(p->stream[1]));
   ODHIP_TRY(hipStreamSynchronize(p->copy_stream));
+  if (p->export_stream) ODHIP_TRY(hipStreamSynchronize(p->export_stream));
   return ODHIP_SUCCESS;
 }
 

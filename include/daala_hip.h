@@ -1136,6 +1136,18 @@ int odhip_pipe_set_pictures(odhip_pipe *p, const uint8_t *luma, const uint8_t *c
    odhip_pipe_sync (or any later odhip_pipe_feed of the same pipe followed by a sync).
      for (;;) { odhip_pipe_feed(p, next_luma, next_chroma); odhip_pipe_step(p); ... } */
 int odhip_pipe_feed(odhip_pipe *p, const uint8_t *luma, const uint8_t *chroma);
+/* The OUTPUT side of a streaming host (SURVEY hard part 5: "timed GPU-side incl. transfers"): with a
+   host buffer set, every following step copies what a host entropy coder consumes - the choice
+   record and the pulse vector of every band (what od_pvq_encode would hand to
+   od_encode_pvq_codeword, src/pvq_encoder.c:789-979) - to pinned host memory on a third stream,
+   overlapped with the rest of the step.  Per luma level: int32 [blocks][bands][4] choice records,
+   int16 [2][blocks][len] pulse vectors (the winner lies in the slot its record names); per chroma
+   level: int32 [blocks][bands][16] and int16 [blocks][len] (slot 0 holds the winner).
+   odhip_pipe_export_bytes: bytes per step (0: this pipe's mode does not export - keyframe steps
+   with chroma from luma and device pricing only).  The buffer holds step i after the
+   odhip_pipe_sync that follows it. */
+size_t odhip_pipe_export_bytes(const odhip_pipe *p);
+int odhip_pipe_set_export(odhip_pipe *p, void *pinned_host);
 /* Inter mode (odhip_pipe_config.inter): the prediction pictures of the batch, same layouts
    and depth as odhip_pipe_set_pictures. */
 int odhip_pipe_set_reference_pictures(odhip_pipe *p, const uint8_t *luma, const uint8_t *chroma,

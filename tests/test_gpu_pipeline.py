@@ -346,3 +346,69 @@ def test_device_priced_step_across_quantisers(quality, masking, hvs):
         cpu, _, _ = C.cpu_frame(qt, pics, pw, ph, chroma_cfl=True, decisions=want)
         assert C.compare_frame(gpu, cpu) == [], (quality, masking, hvs, gen.__name__)
         assert C.compare_decisions(dec, want) == [], (quality, masking, hvs, gen.__name__)
+
+
+def test_exported_decisions_are_the_device_buffers():
+    """odhip_pipe_set_export (the output side of the PCIe-inclusive rate): fed steps whose choice
+    records and pulse vectors leave for pinned host memory on a third stream.  After the sync that
+    follows step i the host buffer holds, level by level, exactly what the device buffers of step i
+    hold (read back through odhip_pipe_read), for odd and even steps (the luma outputs are
+    double-buffered by step parity, the chroma ones shared); the reconstruction is the one of the
+    same steps without export; a pipe mode that cannot export says so."""
+    import torch
+    import daala_amd as D
+    D.init(0)
+    b = _bench()
+    qt = D.QuantTables.load()
+    F, pw, ph = 2, 640, 360
+    full = [b.picture_planes(b.synth_frame_np(i, 99)) for i in range(F + 1)]
+    def pics(k0):
+        lum = np.stack([full[k0 + i][0][:ph, :pw] for i in range(F - 0)][:F])
+        chr_ = np.concatenate([np.stack([full[k0 + i][1][:ph // 2, :pw // 2] for i in range(F)]),
+                               np.stack([full[k0 + i][2][:ph // 2, :pw // 2] for i in range(F)])])
+        return np.ascontiguousarray(lum), np.ascontiguousarray(chr_)
+    sets = [pics(0), pics(1)]
+    pipe = D.Pipe(qt, F, pw, ph, chroma_cfl=True, price=True)
+    plain = D.Pipe(qt, F, pw, ph, chroma_cfl=True, price=True)
+    nbytes = pipe.export_bytes()
+    assert nbytes > 0
+    host = torch.zeros(nbytes, dtype=torch.uint8).pin_memory()
+    pinned = [(torch.from_numpy(l).pin_memory(), torch.from_numpy(c).pin_memory()) for l, c in sets]
+    pipe.set_export(host)
+    for step in range(5):
+        l, c = pinned[step & 1]
+        pipe.feed(l, c)
+        pipe.step()
+        if step < 2:
+            continue          # from the third step on every wait of the export path has a predecessor
+        pipe.flush()
+        pipe.sync()
+        got = host.numpy()
+        pos = 0
+        for set_ in (0, 1):
+            for bs in range(5 - set_):
+                ch = pipe.read(D.BUF_CHOICE, set_, bs)
+                assert np.array_equal(got[pos:pos + ch.size], ch), (step, set_, bs, "choice")
+                pos += ch.size
+                y = pipe.read(D.BUF_Y, set_, bs)
+                if set_:
+                    nb, offs, ln = D.pvq_band_layout(bs)
+                    y = y[:pipe.nblocks(1, bs) * ln * 2]          # slot 0: the winners' vectors
+                assert np.array_equal(got[pos:pos + y.size], y), (step, set_, bs, "pulses")
+                pos += y.size
+        assert pos == nbytes
+        plain.set_pictures(*sets[step & 1])
+        plain.step()
+        plain.flush()
+        plain.sync()
+        for set_ in (0, 1):
+            for bs in range(5 - set_):
+                assert np.array_equal(pipe.read(D.BUF_RECON, set_, bs), plain.read(D.BUF_RECON, set_, bs))
+    pipe.set_export(None)
+    pipe.destroy()
+    plain.destroy()
+    noref = D.Pipe(qt, F, pw, ph, chroma_cfl=False, price=True)
+    assert noref.export_bytes() == 0
+    with pytest.raises(Exception):
+        noref.set_export(host)
+    noref.destroy()
