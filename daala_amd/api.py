@@ -17,6 +17,11 @@ class DaalaHipError(RuntimeError):
     pass
 
 
+# The experiments build (-DODHIP_EXPERIMENTS: superseded kernel generations and ablations behind
+# their ODHIP_* switches; daala_amd/build.py): ODHIP_LIB=EXPERIMENTS_LIB selects it for a process.
+EXPERIMENTS_LIB = os.path.join(_HERE, "lib", "libdaalahip_exp.so")
+
+
 def lib_path():
     # ODHIP_LIB: another build of the same library (kernel A/B experiments, tools/)
     return os.environ.get("ODHIP_LIB") or os.path.join(_HERE, "lib", "libdaalahip.so")

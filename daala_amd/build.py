@@ -3,6 +3,12 @@
 `python -m daala_amd.build` or `daala_amd.build.build()`.  hipcc cross-compiles
 without a GPU; the resulting daala_amd/lib/libdaalahip.so is git-ignored but
 travels to the GPU box with the gpurun snapshot.
+
+Two libraries come out of the same sources: lib/libdaalahip.so, the DEFAULT build (the product:
+three environment switches, od_ctx.cuh), and lib/libdaalahip_exp.so, the same with
+-DODHIP_EXPERIMENTS: superseded kernel generations, ablations and tuning knobs behind their
+ODHIP_* environment switches, for tools/ and the cross-check tests (selected with
+ODHIP_LIB=daala_amd/lib/libdaalahip_exp.so, daala_amd.EXPERIMENTS_LIB).
 """
 import os
 import subprocess
@@ -13,6 +19,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libdaalahip.so")
+EXP_LIB = os.path.join(LIBDIR, "libdaalahip_exp.so")
+EXP_OBJDIR = os.path.join(LIBDIR, "exp")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 SOURCES = ["dct_kernels.hip", "lapped_kernels.hip", "pvq_kernels.hip", "pvq_bands.hip", "pvq_ref.hip", "pvq_refbands.hip", "image_kernels.hip", "dering_kernels.hip", "dering_cache.hip", "frame_cache.hip",
            "odhip_host.hip", "ctx.hip", "quant.hip", "pipeline.hip", "y4m.hip", "dist_kernels.hip", "rate_host.hip"]
@@ -39,16 +47,25 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False):
+def build(force=False, verbose=False, experiments=True):
     os.makedirs(LIBDIR, exist_ok=True)
+    os.makedirs(EXP_OBJDIR, exist_ok=True)
     deps = _deps()
-    objs = []
+    variants = [(LIB, LIBDIR, [])]
+    if experiments:
+        variants.append((EXP_LIB, EXP_OBJDIR, ["-DODHIP_EXPERIMENTS"]))
     jobs = []
-    for src in SOURCES:
-        obj = os.path.join(LIBDIR, src.replace(".hip", ".o"))
-        objs.append(obj)
-        if force or _stale(obj, deps):
-            jobs.append([HIPCC] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj])
+    links = []
+    for lib, objdir, extra in variants:
+        objs = []
+        stale = False
+        for src in SOURCES:
+            obj = os.path.join(objdir, src.replace(".hip", ".o"))
+            objs.append(obj)
+            if force or _stale(obj, deps):
+                jobs.append([HIPCC] + FLAGS + extra + ["-c", os.path.join(CSRC, src), "-o", obj])
+                stale = True
+        links.append((lib, objs, stale))
 
     def run(cmd):
         if verbose:
@@ -58,12 +75,13 @@ def build(force=False, verbose=False):
             raise RuntimeError("hipcc failed:\n%s\n%s" % (" ".join(cmd), r.stderr))
         return r.stderr
 
-    with ThreadPoolExecutor(max_workers=4) as ex:
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 4)) as ex:
         for warn in ex.map(run, jobs):
             if verbose and warn:
                 print(warn)
-    if jobs or force or _stale(LIB, objs):
-        run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
+    for lib, objs, stale in links:
+        if stale or force or _stale(lib, objs):
+            run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs)
     return LIB
 
 

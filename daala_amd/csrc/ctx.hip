@@ -64,6 +64,19 @@ odhip_ctx *odhip_ctx_current(void) {
   return c;
 }
 
+/* The two environment switches of a default build that the band stages and the pipe share
+   (od_ctx.cuh).  ODHIP_PVQ_SERIAL is read once per process; ODHIP_PVQ_FORCE_SEQ at every call
+   (the tests flip it inside one process). */
+int odhip_env_serial(void) {
+  static const int on = getenv("ODHIP_PVQ_SERIAL") != nullptr;
+  return on;
+}
+
+int odhip_env_force_seq(void) {
+  const char *e = getenv("ODHIP_PVQ_FORCE_SEQ");
+  return e && e[0] == '1';
+}
+
 extern "C" odhip_ctx *odhip_create(int device) {
   int count = 0;
   if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count

@@ -712,154 +712,9 @@ __global__ __launch_bounds__(128) void k_forward_pyramid32x2(PyramidArgs a) {
   pyramid_level<TILE, 2, T, 64>(t[wv], z[wv], a, plane_off, xb + wv*TILE, y0, lane);
 }
 
-/* ONE luma superblock per 128-thread workgroup, and after the 64-point level NO
-   workgroup barrier at all: blocks of 32x32 and smaller never straddle the
-   horizontal mid-line of the superblock, so each of the two waves owns one half
-   (32 rows x 64 columns) of the tile and runs the 32-, 16-, 8- and 4-point levels of
-   its half on its own - column pass, row pass, split pre-filters and stores - with
-   only "my LDS operations have completed" between the phases (LDS operations of one
-   wave execute in order; od_wave_sync waits for their data and keeps the compiler
-   from moving accesses across it).  The two waves of a workgroup and the six
-   workgroups of a CU drift apart, so the arithmetic of one overlaps the stores and
-   LDS traffic of the others instead of all meeting at a barrier eighteen times per
-   superblock. */
-__device__ __forceinline__ void od_wave_sync() {
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_wave_barrier();
-}
-
-/* Levels LN <= 3 of rows [r0, r0 + 32) of a 64-wide tile, one wave. */
-template <int LN, typename T>
-__device__ __forceinline__ void half_level(short *t, int *z, const PyramidArgs &a, long plane_off,
- int x0, int y0, int r0, int lane) {
-  constexpr int TILE = 64;
-  constexpr int P = Geo<TILE>::kPitch;
-  constexpr int ROWS = 32;
-  if constexpr (LN == 0) {
-    /* one 4x4 block per lane and iteration, both passes in registers */
-    constexpr int NBX = TILE/4;
-    for (int blk = lane; blk < NBX*(ROWS/4); blk += 64) {
-      const int bx = blk % NBX;
-      const int by = blk/NBX;
-      T m[4][4];
-#pragma unroll
-      for (int r = 0; r < 4; r++) {
-        const short4 v = *reinterpret_cast<const short4 *>(t + (r0 + by*4 + r)*P + bx*4);
-        m[r][0] = T(v.x);
-        m[r][1] = T(v.y);
-        m[r][2] = T(v.z);
-        m[r][3] = T(v.w);
-      }
-#pragma unroll
-      for (int c = 0; c < 4; c++) {
-        T in[4] = {m[0][c], m[1][c], m[2][c], m[3][c]};
-        T out[4];
-        od_fdct4_lift(out, in);
-        m[0][c] = out[0];
-        m[1][c] = out[1];
-        m[2][c] = out[2];
-        m[3][c] = out[3];
-      }
-      if (!a.levels[0]) continue;
-      od_coeff *plane = a.levels[0] + plane_off;
-#pragma unroll
-      for (int r = 0; r < 4; r++) {
-        T out[4];
-        od_fdct4_lift(out, m[r]);
-        od_store_coef4(plane + (long)(y0 + r0 + by*4 + r)*a.w + x0 + bx*4, make_int4(out[0], out[1], out[2], out[3]));
-      }
-    }
-  }
-  else {
-    constexpr int N = 4 << LN;
-    /* column pass: lane = (column, block row of the half) */
-    for (int k = lane; k < TILE*(ROWS/N); k += 64) {
-      const int x = k % TILE;
-      const int by = k/TILE;
-      const int base = (r0 + by*N)*P + x;
-      T in[N];
-      T out[N];
-#pragma unroll
-      for (int r = 0; r < N; r++) in[r] = T(t[base + r*P]);
-      od_fdct_lift<LN>(out, in);
-#pragma unroll
-      for (int r = 0; r < N; r++) z[base + r*P] = out[r];
-    }
-    od_wave_sync();
-    /* row pass in place: lane = (row of the half, block column), 16 bytes per access */
-    for (int k = lane; k < ROWS*(TILE/N); k += 64) {
-      const int y = k % ROWS;
-      const int bx = k/ROWS;
-      const int base = (r0 + y)*P + bx*N;
-      T in[N];
-      T out[N];
-#pragma unroll
-      for (int c = 0; c < N; c += 4) {
-        const int4 v = *reinterpret_cast<const int4 *>(z + base + c);
-        in[c] = T(v.x);
-        in[c + 1] = T(v.y);
-        in[c + 2] = T(v.z);
-        in[c + 3] = T(v.w);
-      }
-      od_fdct_lift<LN>(out, in);
-#pragma unroll
-      for (int c = 0; c < N; c += 4) {
-        *reinterpret_cast<int4 *>(z + base + c) = make_int4(out[c], out[c + 1], out[c + 2], out[c + 3]);
-      }
-    }
-    /* od_prefilter_split of this level's blocks, column taps (the tile is free) */
-    for (int k = lane; k < TILE*(ROWS/N); k += 64) {
-      const int x = k % TILE;
-      const int by = k/TILE;
-      const int gbx = (x0 + x)/N;
-      if ((gbx + 1)*N <= a.pic_w) lds_filter4<false>(t + (r0 + by*N + N/2 - 2)*P + x, P);
-    }
-    od_wave_sync();
-    if (a.levels[LN]) {
-      od_coeff *plane = a.levels[LN] + plane_off;
-      for (int i = lane; i < ROWS*TILE/4; i += 64) {
-        const int y = r0 + i/(TILE/4);
-        const int x = (i % (TILE/4))*4;
-        od_store_coef4(plane + (long)(y0 + y)*a.w + x0 + x, *reinterpret_cast<const int4 *>(z + y*P + x));
-      }
-    }
-    /* ... and row taps */
-    for (int k = lane; k < ROWS*(TILE/N); k += 64) {
-      const int y = r0 + k % ROWS;
-      const int bx = k/ROWS;
-      const int gby = (y0 + y)/N;
-      if ((gby + 1)*N <= a.pic_h) lds_filter4<false>(t + y*P + bx*N + N/2 - 2, 1);
-    }
-    od_wave_sync();
-    half_level<LN - 1, T>(t, z, a, plane_off, x0, y0, r0, lane);
-  }
-}
-
-template <typename T>
-__global__ __launch_bounds__(128) void k_forward_pyramid_halves(PyramidArgs a) {
-  constexpr int TILE = 64;
-  constexpr int NT = 128;
-  using G = Geo<TILE>;
-  constexpr int P = G::kPitch;
-  __shared__ __attribute__((aligned(16))) short t[G::kHaloWords];
-  __shared__ __attribute__((aligned(16))) int z[TILE*P];
-  const int tid = threadIdx.x;
-  const int x0 = blockIdx.x*TILE;
-  const int y0 = blockIdx.y*TILE;
-  const uint8_t *px = pyr_plane(a, blockIdx.z);
-  const long plane_off = (long)blockIdx.z*a.w*a.h;
-  sb_load<TILE, NT>(&t, a, px, x0, y0, tid);
-  od_lds_barrier();
-  sb_edge_cols<TILE, NT>(t, a, x0, y0, tid);
-  od_lds_barrier();
-  sb_edge_rows<TILE, NT>(t, a, x0, tid);
-  od_lds_barrier();
-  /* 64-point level: the two waves run the even and the odd half network of every
-     column, then of every row (workgroup barriers inside); its split pre-filter
-     crosses the mid-line between the halves, so one more barrier follows it */
-  pyramid_level_split64<4, T, NT>(t, z, a, plane_off, x0, y0, tid);
-  half_level<3, T>(t, z, a, plane_off, x0, y0, (tid >> 6)*32, tid & 63);
-}
+#ifdef ODHIP_EXPERIMENTS
+#include "lapped_pyramid_exp.cuh"
+#endif
 
 /* ---- inverse ------------------------------------------------------------ */
 
@@ -1570,6 +1425,12 @@ __global__ __launch_bounds__(256) void k_inverse_sb_top2(InverseArgsMulti mm) {
 #ifndef OD_WALK_WAVES
 #define OD_WALK_WAVES 1
 #endif
+/* InverseArgs::dbg (ODHIP_INVERSE_DBG) exists in the experiments build only. */
+#ifdef ODHIP_EXPERIMENTS
+#define OD_INV_DBG(a, bit) (((a).dbg & (bit)) != 0)
+#else
+#define OD_INV_DBG(a, bit) false
+#endif
 struct InverseWalkArgs {
   InverseArgs a[kMaxInvLevels];
   int nplanes;
@@ -1934,7 +1795,7 @@ __device__ __forceinline__ void walk_store(int *t, const InverseArgs &a, int pla
   od_coeff *hs = a.hs + (long)plane*nh*4*a.w;
   auto put = [&](int r, int x, int4 v) {
     const long at = (long)(y0 + r)*a.px_stride + x;
-    if (a.dbg & 1) {
+    if (OD_INV_DBG(a, 1)) {
     }
     else if (px16) {
       *reinterpret_cast<short4 *>(reinterpret_cast<short *>(px) + at) =
@@ -1950,7 +1811,7 @@ __device__ __forceinline__ void walk_store(int *t, const InverseArgs &a, int pla
     }
     /* rows 0, 1 / TILE-2, TILE-1 also feed the post-filter across the horizontal superblock edge
        above / below (k_edge_cols) */
-    if (a.dbg & 2) {
+    if (OD_INV_DBG(a, 2)) {
     }
     else if (r < 2) {
       if (sby > 0) *reinterpret_cast<int4 *>(hs + ((long)(sby - 1)*4 + r + 2)*a.w + x) = v;
@@ -2030,7 +1891,7 @@ __device__ __forceinline__ void walk_pack(int *t, uint32_t *pxb, const InverseAr
     const unsigned q = j % Q;
     const int4 v = *reinterpret_cast<const int4 *>(t + s*(TILE*P) + r*P + 4*q);
     pxb[i] = walk_pack4(v);
-    if (!(a.dbg & 2) && !(s == G - 1 && q == Q - 1)) {
+    if (!OD_INV_DBG(a, 2) && !(s == G - 1 && q == Q - 1)) {
       const int x = xg + s*TILE + 4*q;
       if (r < 2) {
         if (sby > 0) *reinterpret_cast<int4 *>(hs + ((long)(sby - 1)*4 + r + 2)*a.w + x) = v;
@@ -2065,7 +1926,7 @@ __device__ __forceinline__ void walk_store_prev(const int *t, const uint32_t *px
     if (q == PR - 1) {
       const int4 k = *reinterpret_cast<const int4 *>(t + r*P + TILE);
       v.w = walk_pack4(k);
-      if (!(a.dbg & 2)) {
+      if (!OD_INV_DBG(a, 2)) {
         const int x = xp + G*TILE - 4;
         if (r < 2) {
           if (sby > 0) *reinterpret_cast<int4 *>(hs + ((long)(sby - 1)*4 + r + 2)*a.w + x) = k;
@@ -2075,7 +1936,7 @@ __device__ __forceinline__ void walk_store_prev(const int *t, const uint32_t *px
         }
       }
     }
-    if (!(a.dbg & 1)) *reinterpret_cast<uint4 *>(px + (long)(y0 + r)*a.px_stride + xp + 16*q) = v;
+    if (!OD_INV_DBG(a, 1)) *reinterpret_cast<uint4 *>(px + (long)(y0 + r)*a.px_stride + xp + 16*q) = v;
   }
 }
 
@@ -2097,7 +1958,7 @@ __device__ __forceinline__ void inverse_walk(int *t, uint32_t *pxb, const Invers
     /* per-lane index arithmetic is redone for every group (as one workgroup per superblock did):
        hoisted out of this loop it occupies ~50 VGPRs and halves the occupancy */
     asm volatile("" : "+v"(tid));
-    if (a.dbg & 4) walk_zero<TILE, G, NT>(t, tid);
+    if (OD_INV_DBG(a, 4)) walk_zero<TILE, G, NT>(t, tid);
     else if constexpr (SRC == 0) walk_load_plane<TILE, G, NT>(t, a.coef + plane_off, a.w, xg, y0, tid);
     else if constexpr (SRC == 1) walk_load_pvq<TILE, G, NT, LEAF>(t, a, plane, plane_off, xg, y0, tid);
     else walk_load_ref<TILE, G, NT, LEAF>(t, a, plane, plane_off, xg, y0, tid);
@@ -2297,6 +2158,7 @@ extern "C" int odhip_forward_pyramid(od_coeff *const d_levels[ODHIP_NBSIZES],
   }
   const dim3 grid(w/tile, h/tile, nplanes);
   hipStream_t s = (hipStream_t)stream;
+#ifdef ODHIP_EXPERIMENTS
   /* ODHIP_PYR_VARIANT selects the kernel shapes round 2 measured against each other
      (tools/pyr_variants.py; all bit-identical): bit 1 = OD_DCT_RSHIFT in two
      instructions (OdMul24S; default), bit 0 = one luma superblock per 128-thread
@@ -2307,29 +2169,43 @@ extern "C" int odhip_forward_pyramid(od_coeff *const d_levels[ODHIP_NBSIZES],
   /* ODHIP_PYR_LDS_PAD: extra dynamic LDS bytes per workgroup of the luma kernel, to measure how the
      time follows occupancy (tools/pyr_stalls.py); 0 outside that experiment. */
   static const unsigned lds_pad = getenv("ODHIP_PYR_LDS_PAD") ? (unsigned)atoi(getenv("ODHIP_PYR_LDS_PAD")) : 0;
-  if (dec) {
-    /* pairs of chroma superblocks (k_forward_pyramid32x2) whenever the plane is an even number of
-       them wide; ODHIP_PYRAMID_X1=1: one per wavefront (the A/B baseline) */
-    if ((w/tile) % 2 == 0 && !getenv("ODHIP_PYRAMID_X1")) {
-      if (variant & 2) k_forward_pyramid32x2<OdMul24S><<<dim3(w/(2*tile), h/tile, nplanes), 128, 0, s>>>(a);
-      else k_forward_pyramid32x2<OdMul24><<<dim3(w/(2*tile), h/tile, nplanes), 128, 0, s>>>(a);
+  static const bool x1 = getenv("ODHIP_PYRAMID_X1") != nullptr;      /* one superblock per workgroup (A/B baseline) */
+  if (variant != 2 || lds_pad || x1) {
+    if (dec) {
+      if ((w/tile) % 2 == 0 && !x1) {
+        if (variant & 2) k_forward_pyramid32x2<OdMul24S><<<dim3(w/(2*tile), h/tile, nplanes), 128, 0, s>>>(a);
+        else k_forward_pyramid32x2<OdMul24><<<dim3(w/(2*tile), h/tile, nplanes), 128, 0, s>>>(a);
+      }
+      else if (variant & 2) k_forward_pyramid<32, OdMul24S><<<grid, Geo<32>::kNT, 0, s>>>(a);
+      else k_forward_pyramid<32><<<grid, Geo<32>::kNT, 0, s>>>(a);
     }
-    else if (variant & 2) k_forward_pyramid<32, OdMul24S><<<grid, Geo<32>::kNT, 0, s>>>(a);
-    else k_forward_pyramid<32><<<grid, Geo<32>::kNT, 0, s>>>(a);
+    else if (variant & 4) {
+      if (variant & 2) k_forward_pyramid_halves<OdMul24S><<<grid, 128, 0, s>>>(a);
+      else k_forward_pyramid_halves<OdMul24><<<grid, 128, 0, s>>>(a);
+    }
+    else if (variant & 1) {
+      if (variant & 2) k_forward_pyramid<64, OdMul24S, 128><<<grid, 128, 0, s>>>(a);
+      else k_forward_pyramid<64, OdMul24, 128><<<grid, 128, 0, s>>>(a);
+    }
+    else if ((w/tile) % 2 == 0 && !x1) {
+      if (variant & 2) k_forward_pyramid64x2<OdMul24S><<<dim3(w/(2*tile), h/tile, nplanes), 256, lds_pad, s>>>(a);
+      else k_forward_pyramid64x2<OdMul24><<<dim3(w/(2*tile), h/tile, nplanes), 256, 0, s>>>(a);
+    }
+    else if (variant & 2) k_forward_pyramid<64, OdMul24S><<<grid, Geo<64>::kNT, 0, s>>>(a);
+    else k_forward_pyramid<64><<<grid, Geo<64>::kNT, 0, s>>>(a);
+    return odhip_check_launch();
   }
-  else if (variant & 4) {
-    if (variant & 2) k_forward_pyramid_halves<OdMul24S><<<grid, 128, 0, s>>>(a);
-    else k_forward_pyramid_halves<OdMul24><<<grid, 128, 0, s>>>(a);
+#endif
+  /* Pairs of superblocks per workgroup (k_forward_pyramid64x2: 256 threads per two 64x64 luma tiles;
+     k_forward_pyramid32x2: 128 threads per two 32x32 chroma tiles) whenever the plane is an even
+     number of them wide, one superblock per workgroup otherwise; OD_DCT_RSHIFT in two instructions
+     (OdMul24S). */
+  if (dec) {
+    if ((w/tile) % 2 == 0) k_forward_pyramid32x2<OdMul24S><<<dim3(w/(2*tile), h/tile, nplanes), 128, 0, s>>>(a);
+    else k_forward_pyramid<32, OdMul24S><<<grid, Geo<32>::kNT, 0, s>>>(a);
   }
-  else if (variant & 1) {
-    if (variant & 2) k_forward_pyramid<64, OdMul24S, 128><<<grid, 128, 0, s>>>(a);
-    else k_forward_pyramid<64, OdMul24, 128><<<grid, 128, 0, s>>>(a);
-  }
-  else if ((w/tile) % 2 == 0 && !getenv("ODHIP_PYRAMID_X1")) {
-    if (variant & 2) k_forward_pyramid64x2<OdMul24S><<<dim3(w/(2*tile), h/tile, nplanes), 256, lds_pad, s>>>(a);
-    else k_forward_pyramid64x2<OdMul24><<<dim3(w/(2*tile), h/tile, nplanes), 256, 0, s>>>(a);
-  }
-  else k_forward_pyramid<64><<<grid, Geo<64>::kNT, 0, s>>>(a);
+  else if ((w/tile) % 2 == 0) k_forward_pyramid64x2<OdMul24S><<<dim3(w/(2*tile), h/tile, nplanes), 256, 0, s>>>(a);
+  else k_forward_pyramid<64, OdMul24S><<<grid, Geo<64>::kNT, 0, s>>>(a);
   return odhip_check_launch();
 }
 
@@ -2367,9 +2243,13 @@ int inverse_launch(const InverseArgs *levels, int nlevels, int nplanes, int dec,
   for (int l = 0; l < nlevels; l++) {
     if (levels[l].w != w || levels[l].h != h) return ODHIP_EINVAL;
     im.a[l] = levels[l];
+#ifdef ODHIP_EXPERIMENTS
+    /* timing ablations of k_inverse_walk (WRONG results by design): experiments build only - a stray
+       environment variable cannot corrupt a reconstruction of the default build */
     static const int dbg = getenv("ODHIP_INVERSE_DBG") ? atoi(getenv("ODHIP_INVERSE_DBG")) : 0;
     im.a[l].dbg = dbg;
-    static const bool narrow = getenv("ODHIP_INVERSE_NARROW") != nullptr;     /* A/B: the shifted window */
+#endif
+    static const bool narrow = ODHIP_EXP_ENV("ODHIP_INVERSE_NARROW") != nullptr;     /* A/B: the shifted window */
     im.a[l].wide = !narrow && !ctx->fpr && !(levels[l].px_stride & 15) && !(levels[l].px_plane_stride & 15)
      && !((uintptr_t)levels[l].px & 15);
     im.a[l].px16 = ctx->fpr != 0;
@@ -2398,11 +2278,11 @@ int inverse_launch(const InverseArgs *levels, int nlevels, int nplanes, int dec,
      workgroups per CU, where segments long enough to matter leave a partially filled last round.
      ODHIP_INVERSE_OLD=1: one workgroup per superblock for everything (the A/B baseline);
      ODHIP_INVERSE_SEG=n: groups per workgroup. */
-  static const bool old_kernels = getenv("ODHIP_INVERSE_OLD") != nullptr;
+  static const bool old_kernels = ODHIP_EXP_ENV("ODHIP_INVERSE_OLD") != nullptr;
   const int src = ref ? 2 : (levels[0].y ? 1 : 0);
   bool same_src = true;
   for (int l = 0; l < nlevels; l++) same_src = same_src && ((levels[l].y != nullptr) == (levels[0].y != nullptr));
-  const bool top2_ok = !dec && (w/tile) % 2 == 0 && !getenv("ODHIP_INVERSE_X1");
+  const bool top2_ok = !dec && (w/tile) % 2 == 0 && !ODHIP_EXP_ENV("ODHIP_INVERSE_X1");
   const int G = dec ? 2 : 1;
   const int ng = w/(tile*G);
   const bool walk = !old_kernels && same_src && (w/tile) % G == 0;
@@ -2414,7 +2294,7 @@ int inverse_launch(const InverseArgs *levels, int nlevels, int nplanes, int dec,
      ODHIP_INVERSE_SEG="luma,chroma_lo,chroma_hi" overrides. */
   static int seg_cfg[3] = {6, 3, 3};
   static const bool seg_parsed = [] {
-    const char *e = getenv("ODHIP_INVERSE_SEG");
+    const char *e = ODHIP_EXP_ENV("ODHIP_INVERSE_SEG");
     if (e) (void)sscanf(e, "%d,%d,%d", &seg_cfg[0], &seg_cfg[1], &seg_cfg[2]);
     for (int i = 0; i < 3; i++) if (seg_cfg[i] < 1) seg_cfg[i] = 1;
     return true;

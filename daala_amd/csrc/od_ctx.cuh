@@ -49,6 +49,22 @@ static inline T *odhip_ctx_state(odhip_ctx *c, int slot) {
   return static_cast<T *>(c->slot[slot]);
 }
 
+/* Environment switches.  A DEFAULT build of the library reads exactly three: ODHIP_PVQ_SERIAL (no
+   side streams inside the band stages and the pipe: exclusive kernel times), ODHIP_PVQ_FORCE_SEQ
+   (every greedy pulse of the pair / row searches by the literal left-to-right scan: the cross-check
+   of their exact-argmax shortcuts) - both below, ctx.hip - and ODHIP_CACHE_CHECK (frame_cache.hip).
+   Everything else - superseded kernel generations kept as A/B baselines, ablations, tuning knobs -
+   exists only in a build with -DODHIP_EXPERIMENTS (daala_amd/build.py: lib/libdaalahip_exp.so,
+   selected with ODHIP_LIB; tools/ and the cross-check tests use it): there ODHIP_EXP_ENV(name) is
+   getenv(name), in a default build it is a null pointer and the code behind it is not compiled. */
+int odhip_env_serial(void);
+int odhip_env_force_seq(void);
+#ifdef ODHIP_EXPERIMENTS
+#define ODHIP_EXP_ENV(name) getenv(name)
+#else
+#define ODHIP_EXP_ENV(name) (static_cast<const char *>(nullptr))
+#endif
+
 #define ODHIP_CTX_OR_RETURN(var) \
   odhip_ctx *var = odhip_ctx_current(); \
   if (!var) return ODHIP_EINVAL

@@ -285,7 +285,7 @@ int pipe_init(odhip_pipe *p) {
   p->pic_h = c.pic_h;
   p->W = (c.pic_w + 63) & ~63;     /* coded frame size, src/state.c:376-379 */
   p->H = (c.pic_h + 63) & ~63;
-  p->serial = c.serial || getenv("ODHIP_PVQ_SERIAL") != nullptr;
+  p->serial = c.serial || odhip_env_serial();
   for (int i = 0; i < 2; i++) {
     p->ctx[i] = odhip_create(c.device);
     if (!p->ctx[i]) return ODHIP_EFAULT;
@@ -298,7 +298,7 @@ int pipe_init(odhip_pipe *p) {
        Rounds 1-2 read the variable as a flag ("set = both chains fork"): a value that is not a
        number in 0..3 (e.g. "yes", "true") keeps that meaning; the parsed mask is logged once. */
     int forkmask = 0;
-    if (const char *fe = getenv("ODHIP_PIPE_FORK")) {
+    if (const char *fe = ODHIP_EXP_ENV("ODHIP_PIPE_FORK")) {
       char *end = nullptr;
       const long v = strtol(fe, &end, 10);
       forkmask = (end == fe || *end != '\0' || v < 0 || v > 3) ? 3 : (int)v;
@@ -315,7 +315,7 @@ int pipe_init(odhip_pipe *p) {
   /* Experiment knob: ODHIP_PIPE_CUSPLIT=n (1..7) gives the luma chain n of every 8 compute
      units and the chroma chain the other 8 - n (hipExtStreamCreateWithCUMask) instead of
      letting the two chains share every CU. */
-  const char *split_env = getenv("ODHIP_PIPE_CUSPLIT");
+  const char *split_env = ODHIP_EXP_ENV("ODHIP_PIPE_CUSPLIT");
   const int split = split_env ? atoi(split_env) : 0;
   if (!p->serial && split >= 1 && split <= 7) {
     hipDeviceProp_t prop;

@@ -1782,7 +1782,7 @@ int scratch_reserve(BandState &st, size_t x16_elems, size_t band_elems, hipStrea
 
 /* Side streams for kernels that may overlap (created once per context). */
 int fork_streams(BandState &st, hipStream_t s, hipStream_t side[2]) {
-  if (st.serial || getenv("ODHIP_PVQ_SERIAL")) return ODHIP_SUCCESS;
+  if (st.serial || odhip_env_serial()) return ODHIP_SUCCESS;
   if (!st.fork) {
     ODHIP_TRY(hipEventCreateWithFlags(&st.fork, hipEventDisableTiming));
     for (int i = 0; i < 2; i++) {
@@ -1815,8 +1815,7 @@ void items_begin(Items &it, const BandState &st, double lambda) {
   it.pcount = st.d_pcount;
   it.plist = st.d_plist;
   it.tol_scale = st.tol_scale;
-  const char *e = getenv("ODHIP_PVQ_FORCE_SEQ");
-  it.reserved = e && e[0] == '1';   /* pair-mode search: always take the sequential combine */
+  it.reserved = odhip_env_force_seq();   /* pair-mode search: always take the sequential combine */
 }
 
 /* Heaviest items first: the jobs arrive by ascending block size, and the bands of the largest
@@ -1824,7 +1823,7 @@ void items_begin(Items &it, const BandState &st, double lambda) {
    wavefronts - launched last they were the tail of their kernel.  ODHIP_ITEMS_FWD=1 keeps the
    order of the jobs (experiments). */
 void items_heavy_first(Items &it) {
-  static const bool fwd = getenv("ODHIP_ITEMS_FWD") != nullptr;
+  static const bool fwd = ODHIP_EXP_ENV("ODHIP_ITEMS_FWD") != nullptr;
   if (fwd) return;
   const int n = it.nitems;
   int size[kMaxItems];

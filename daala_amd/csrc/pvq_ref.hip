@@ -380,8 +380,9 @@ __device__ __forceinline__ void pvq_decode_band(RefAt REF, YAt Y, OutAt OUT, int
 #undef OD_REF16
 }
 
-/* One band per lane straight from memory (stride-n accesses): the first form, kept as the
-   cross-check of k_pvq_decode (ODHIP_DECODE_LANE=1 selects it). */
+#ifdef ODHIP_EXPERIMENTS
+/* One band per lane straight from memory (stride-n accesses): the first form, kept in the
+   experiments build as the cross-check of k_pvq_decode (ODHIP_DECODE_LANE=1 selects it). */
 __global__ __launch_bounds__(64) void k_pvq_decode_lane(od_coeff *out, const od_coeff *refa, const od_coeff *ya,
  int n, long nbands, const int4 *sym, const int16_t *qm, const int16_t *qm_inv, int q0, int beta,
  int is_keyframe, int pli, int2 *info) {
@@ -393,6 +394,7 @@ __global__ __launch_bounds__(64) void k_pvq_decode_lane(od_coeff *out, const od_
   pvq_decode_band([&](int i) { return ref[i]; }, [&](int i) { return yp[i]; },
    [&](int i, od_coeff v) { xo[i] = v; }, n, sym[b], qm, qm_inv, q0, beta, is_keyframe, pli, info ? info + b : nullptr);
 }
+#endif
 
 /* The same with the bands of a workgroup staged through LDS: B bands (64, or 32 above 64
    coefficients: 2*B*(n|1) words of LDS) are contiguous in memory, so the 64 lanes read B*n
@@ -467,6 +469,8 @@ extern "C" int odhip_pvq_decode_bands(od_coeff *d_out, const od_coeff *d_ref, co
    || ((uintptr_t)d_sym & 15) || ((uintptr_t)d_info & 7)) {
     return ODHIP_EINVAL;
   }
+#ifdef ODHIP_EXPERIMENTS
+  /* the one-band-per-lane form of rounds 1-3 (the cross-check of the LDS-staged kernel) */
   static const bool lane_form = getenv("ODHIP_DECODE_LANE") != nullptr;
   if (lane_form) {
     k_pvq_decode_lane<<<(unsigned)((nbands + 63)/64), 64, 0, (hipStream_t)stream>>>(d_out, d_ref, d_y, n, nbands,
@@ -474,6 +478,7 @@ extern "C" int odhip_pvq_decode_bands(od_coeff *d_out, const od_coeff *d_ref, co
      reinterpret_cast<int2 *>(d_info));
     return odhip_check_launch();
   }
+#endif
   const int B = n > 64 ? 32 : 64;
   const size_t lds = (size_t)2*B*(n | 1)*sizeof(od_coeff);
   k_pvq_decode<<<(unsigned)((nbands + B - 1)/B), 64, lds, (hipStream_t)stream>>>(d_out, d_ref, d_y, n, B, nbands,

@@ -1196,6 +1196,8 @@ struct LdsVector {
   int cur;
 };
 
+#ifdef ODHIP_EXPERIMENTS
+/* ODHIP_PVQ_REF_LANE (experiments build): every band size one band per lane, vectors in LDS. */
 __global__ __launch_bounds__(kWave) void k_refb_search(RItems it) {
   extern __shared__ __attribute__((aligned(16))) unsigned short lds[];
   od_rsqrt_init(threadIdx.x);
@@ -1210,6 +1212,7 @@ __global__ __launch_bounds__(kWave) void k_refb_search(RItems it) {
   NoDecide nd;
   refb_loops(jb, band, blk, true, true, it.lambda, v, nd);
 }
+#endif
 
 /* One listed band per wavefront (lane 0): the list is a handful of bands. */
 __global__ __launch_bounds__(kWave) void k_refb_search_list(const RJob *jobs, const Unc *list, int count,
@@ -1851,89 +1854,12 @@ __device__ __forceinline__ CandList refb_build_list(const RJob &jb, int band, co
   return cl;
 }
 
-/* refb_loops without a single store: candidates from the LDS list, every searched
-   candidate offered to the decider with its rate halves. */
-template <int NR, class V, class D>
-__device__ __forceinline__ void refb_loops_lean(const RJob &jb, int band, long blk,
- const odhip_pvq_refband &r, const CandList &cl, double lambda, V &v, D &dec) {
-  const int off = jb.off[band];
-  const int n = jb.off[band + 1] - off;
-  const int len = jb.len;
-  const double s2 = (1./256)*(1./256);   /* OD_CGAIN_SCALE_2 */
-  const double t1 = 1./32768;            /* OD_TRIG_SCALE_1 */
-  const int32_t cg = r.cg;
-  const double dist0 = r.dist0;
-  if (cl.ntheta > 0) {
-    v.load(jb.xr + blk*len + off, true);
-    int prev_k = 0;
-    bool has = false;
-    double cos_dist = 0;
-    double prate = 0;
-    const int32_t theta = r.theta;
-    for (int idx = 0; idx < cl.ntheta; idx++) {
-      const uint32_t w = cl.col[idx*cl.stride];
-      const int gi = (int)(w & 3u);
-      const int k = (int)(w >> 2 & 0xffffu);
-      const int i = cl.gb1 + gi;
-      const int ts = (int)cl.col[(kSlots + gi)*cl.stride];
-      const int j = (int)cl.col[(kSlots + 3 + gi)*cl.stride] + (int)(w >> 18);
-      const int32_t qcg = odq_shl32(i, ODQ_CGAIN_SHIFT) + r.gain_offset;
-      const int32_t qtheta = odq_pvq_compute_theta(j, ts);
-      /* :526-531 */
-      double dist_theta = 2 - (2.*odq_pvq_cos(theta - qtheta))*t1;
-      double dist = (1.4*(qcg - cg))*(qcg - cg) + (qcg*(double)cg)*dist_theta;
-      dist *= s2;
-      if (dist > dist0 + 1.0*lambda && k != 0) continue;
-      /* pulses are kept in 16 bits: never searched or chosen (sorted by K: every later
-         candidate is skipped as well) */
-      if (k > ODHIP_PVQ_MAX_K) continue;
-      const double sin_prod = ((odq_pvq_sin(theta)*t1)*odq_pvq_sin(qtheta))*t1;
-      if (k == 0) {
-        cos_dist = 0;
-        has = false;
-        prate = 0;
-      }
-      else if (k != prev_k) {
-        cos_dist = v.search(n - 1, k, prev_k, ((qcg*(double)cg)*sin_prod)*s2, lambda);
-        has = true;
-        prate = lean_rate_pulses<NR>(v.moment(), k);
-      }
-      prev_k = k;
-      /* :548-552 */
-      dist_theta = 2 - (2.*odq_pvq_cos(theta - qtheta))*t1 + sin_prod*(2 - 2*cos_dist);
-      dist = (1.4*(qcg - cg))*(qcg - cg) + (qcg*(double)cg)*dist_theta;
-      dist *= s2;
-      const double lts = __hiloint2double((int)cl.col[(kSlots + 7 + 2*gi)*cl.stride],
-       (int)cl.col[(kSlots + 6 + 2*gi)*cl.stride]);
-      dec.offer(idx, true, i, j, ts, k, qtheta, dist, prate, lts, has, v);
-    }
-  }
-  if (cl.nitems > cl.ntheta) {
-    v.load(jb.x16 + blk*len + off, false);
-    int prev_k = 0;
-    for (int idx = cl.ntheta; idx < cl.nitems; idx++) {
-      const uint32_t w = cl.col[idx*cl.stride];
-      const int i = cl.gbn + (int)(w & 3u);
-      const int k = (int)(w >> 2 & 0xffffu);
-      const int32_t qcg = odq_shl32(i, ODQ_CGAIN_SHIFT);
-      /* :585-595 */
-      double dist = (1.4*(qcg - cg))*(qcg - cg);
-      dist *= s2;
-      if (dist > dist0 && k != 0) continue;
-      if (k > ODHIP_PVQ_MAX_K) continue;
-      const double cos_dist = v.search(n, k, prev_k, (qcg*(double)cg)*s2, lambda);
-      prev_k = k;
-      const double prate = lean_rate_pulses<NR>(v.moment(), k);
-      dist = (1.4*(qcg - cg))*(qcg - cg) + (qcg*(double)cg)*(2 - 2*cos_dist);
-      dist *= s2;
-      dec.offer(idx, false, i, -1, 0, k, 0, dist, prate, 0., true, v);
-    }
-  }
-}
-
-/* refb_loops_lean for one band per LANE, with the searches of a wavefront gathered.  Every lane
-   walks its own candidate list exactly as refb_loops_lean does (same skips, same searches, same
-   offers in the same order: the result per band is identical), but a lane whose next candidate needs
+/* The decided stage's walk over a band's candidate list (refb_loops without a single store:
+   candidates from the LDS list, every searched candidate offered to the decider with its rate halves)
+   for one band per LANE, with the searches of a wavefront gathered.  Every lane walks its own
+   candidate list in list order (the skips, searches and offers a lock-step walk by list index would
+   make - round 3's form, removed in round 5 - in the same order: the result per band is identical),
+   but a lane whose next candidate needs
    a SEARCH waits while any other lane can still advance without one, so a search runs when every
    lane still working is at one.  Lists are sorted by K, not aligned between bands: walking them in
    lock step by index ran a search (~700 instructions beside its pulses) in almost every iteration
@@ -2813,7 +2739,7 @@ int stage_jobs(RefState &st, const odhip_pvq_refjob *jobs, int njobs, int mode, 
 int sort_weights(void) {
   static const int w = [] {
     int p = 4, c = 4, s = 8;
-    const char *e = getenv("ODHIP_SORT_W");
+    const char *e = ODHIP_EXP_ENV("ODHIP_SORT_W");
     if (e) sscanf(e, "%d,%d,%d", &p, &c, &s);
     return (p & 255) | (c & 255) << 8 | (s & 255) << 16;
   }();
@@ -2841,7 +2767,7 @@ void items_begin(RItems &it, const RefState &st, double lambda) {
    wavefronts - launched last they were the tail of their kernel.  ODHIP_ITEMS_FWD=1 keeps the
    order of the jobs (experiments). */
 void items_heavy_first(RItems &it) {
-  static const bool fwd = getenv("ODHIP_ITEMS_FWD") != nullptr;
+  static const bool fwd = ODHIP_EXP_ENV("ODHIP_ITEMS_FWD") != nullptr;
   if (fwd) return;
   const int n = it.nitems;
   int size[kMaxItems];
@@ -2882,7 +2808,7 @@ void items_all(RItems &it, const RefState &st, const RJob *host, int njobs, doub
 /* Side streams for the searches of the four band sizes (independent launches;
    the no-reference stage measured the same fork at 1.40 -> 1.19 ms). */
 int rfork(RefState &st, hipStream_t s, hipStream_t side[2]) {
-  if (st.serial || getenv("ODHIP_PVQ_SERIAL")) return ODHIP_SUCCESS;
+  if (st.serial || odhip_env_serial()) return ODHIP_SUCCESS;
   if (!st.fork) {
     ODHIP_TRY(hipEventCreateWithFlags(&st.fork, hipEventDisableTiming));
     for (int i = 0; i < 2; i++) {
@@ -3064,7 +2990,7 @@ int ref_bands(const odhip_pvq_refjob *jobs, int njobs, double pvq_norm_lambda, o
     k_refb_scatter<<<chunks.wg_start[chunks.nitems], 256, 0, s>>>(chunks);
   }
   /* 128- and 32-coefficient bands: one band per 16-lane row; 15 and 8: per lane */
-  const bool lane_only = fuse != 2 && getenv("ODHIP_PVQ_REF_LANE") != nullptr;
+  const bool lane_only = fuse != 2 && ODHIP_EXP_ENV("ODHIP_PVQ_REF_LANE") != nullptr;
   static const int sizes[4] = {128, 32, 15, 8};
   hipStream_t side[2] = {s, s};
   if (rfork(st, s, side) != ODHIP_SUCCESS) return ODHIP_EFAULT;
@@ -3074,8 +3000,7 @@ int ref_bands(const odhip_pvq_refjob *jobs, int njobs, double pvq_norm_lambda, o
     s = sizes[i] == 128 ? main_stream : sizes[i] == 32 ? side[0] : side[1];
     if (sizes[i] >= 32 && !lane_only) {
       items_begin(it, st, pvq_norm_lambda);
-      const char *e = getenv("ODHIP_PVQ_FORCE_SEQ");
-      if (e && e[0] == '1') it.perturb |= 2;   /* every greedy pulse by the literal scan */
+      if (odhip_env_force_seq()) it.perturb |= 2;   /* every greedy pulse by the literal scan */
       for (int j = 0; j < njobs; j++) {
         for (int b = 0; b < host[j].nb_bands; b++) {
           if (host[j].off[b + 1] - host[j].off[b] == sizes[i]) {
@@ -3113,8 +3038,11 @@ int ref_bands(const odhip_pvq_refjob *jobs, int njobs, double pvq_norm_lambda, o
       else k_refb_search_regs<8, false><<<wgs, kWave, 0, s>>>(it);
       continue;
     }
+#ifdef ODHIP_EXPERIMENTS
+    /* ODHIP_PVQ_REF_LANE: every size one band per lane with its vectors in LDS (rounds 1-2) */
     const size_t lds = (size_t)2*sizes[i]*kWave*sizeof(unsigned short);
     k_refb_search<<<it.wg_start[it.nitems], kWave, lds, s>>>(it);
+#endif
   }
   s = main_stream;
   if (rjoin(st, s, side) != ODHIP_SUCCESS) return ODHIP_EFAULT;

@@ -83,3 +83,57 @@ def test_band_stage_and_reference_path_validation_without_gpu(built):
     assert api.BAND_RECORD.itemsize == 64 and api.BAND_RECORD.fields["dist0"][1] == 24
     assert api.BAND_RECORD.fields["yy"][1] == 32 and api.BAND_RECORD.fields["dist"][1] == 40
     assert api.REFPREP_RECORD.fields["corr"][1] == 48
+
+
+def _default_build_source(text):
+    """`text` as the DEFAULT build compiles it: `#ifdef ODHIP_EXPERIMENTS` ... (`#else`) ... `#endif`
+    blocks resolved for an undefined ODHIP_EXPERIMENTS (other conditionals are kept whole)."""
+    out = []
+    stack = []          # per open conditional: None (not ours) or True / False = currently emitting
+    for line in text.splitlines():
+        t = line.strip()
+        if t.startswith("#if"):
+            if t.replace(" ", "") in ("#ifdefODHIP_EXPERIMENTS", "#ifdefined(ODHIP_EXPERIMENTS)"):
+                stack.append(False)
+                continue
+            stack.append(None)
+        elif t.startswith("#else") and stack and stack[-1] is not None:
+            stack[-1] = not stack[-1]
+            continue
+        elif t.startswith("#endif"):
+            ours = stack.pop() if stack else None
+            if ours is not None:
+                continue
+        if all(s is not False for s in stack):
+            out.append(line)
+    return "\n".join(out)
+
+
+def test_default_build_reads_at_most_six_environment_switches(built):
+    """superseded kernel generations, ablations and tuning knobs live behind
+    -DODHIP_EXPERIMENTS (lib/libdaalahip_exp.so); what the DEFAULT library still reads from the
+    environment is counted here from the sources as that build compiles them: ODHIP_PVQ_SERIAL,
+    ODHIP_PVQ_FORCE_SEQ (ctx.hip) and ODHIP_CACHE_CHECK (frame_cache.hip)."""
+    import re
+    names = set()
+    calls = 0
+    csrc = os.path.join(ROOT, "daala_amd", "csrc")
+    for root, _, files in os.walk(csrc):
+        for f in files:
+            if f.endswith((".hip", ".cuh", ".h")):
+                src = _default_build_source(open(os.path.join(root, f)).read())
+                src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+                calls += len(re.findall(r"\bgetenv\s*\(", src))
+                names.update(re.findall(r"\bgetenv\s*\(\s*\"([A-Z_0-9]+)\"", src))
+    assert calls <= 6, (calls, sorted(names))
+    assert names == {"ODHIP_PVQ_SERIAL", "ODHIP_PVQ_FORCE_SEQ", "ODHIP_CACHE_CHECK"}, sorted(names)
+    # the ablation that removes loads / stores on purpose cannot be reached in the default build
+    lap = _default_build_source(open(os.path.join(csrc, "lapped_kernels.hip")).read())
+    assert "ODHIP_INVERSE_DBG\")" not in lap and "#define OD_INV_DBG(a, bit) false" in lap
+    # both builds exist and export the same C ABI
+    import daala_amd
+    assert os.path.exists(daala_amd.EXPERIMENTS_LIB)
+    def syms(p):
+        out = subprocess.run(["nm", "-D", "--defined-only", p], capture_output=True, text=True).stdout
+        return {ln.split()[-1] for ln in out.splitlines() if " T " in ln and ("odhip_" in ln or "od_" in ln)}
+    assert syms(built) == syms(daala_amd.EXPERIMENTS_LIB)

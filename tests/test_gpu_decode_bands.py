@@ -149,13 +149,16 @@ def test_whole_1080p_keyframe_decodes_to_the_reference_synthesis(hip):
 
 
 def test_lds_staged_and_per_lane_kernels_agree():
-    """odhip_pvq_decode_bands runs the LDS-staged kernel; ODHIP_DECODE_LANE=1 (read once per
-    process) selects the one-band-per-lane form it replaced.  Same random bands of four band sizes
-    through both, in child processes: the digests tools/decode_bands_time.py prints must agree."""
+    """odhip_pvq_decode_bands runs the LDS-staged kernel; the one-band-per-lane form it replaced lives
+    in the experiments build of the library (-DODHIP_EXPERIMENTS, lib/libdaalahip_exp.so) behind
+    ODHIP_DECODE_LANE=1.  Same random bands of four band sizes through both, in child processes (the
+    default library / the experiments library with the switch): the digests
+    tools/decode_bands_time.py prints must agree."""
     import subprocess
+    import daala_amd
     tool = os.path.join(ROOT, "tools", "decode_bands_time.py")
     outs = []
-    for extra in ({}, {"ODHIP_DECODE_LANE": "1"}):
+    for extra in ({}, {"ODHIP_DECODE_LANE": "1", "ODHIP_LIB": daala_amd.EXPERIMENTS_LIB}):
         env = dict(os.environ)
         env.update(extra)
         r = subprocess.run([sys.executable, tool, "--child"], env=env, capture_output=True, text=True, timeout=300)

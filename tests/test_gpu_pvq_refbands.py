@@ -7,9 +7,13 @@ lists in search order, every candidate's pruning decision, pulse vector, cosine
 and distortion, and - with the host pricing every candidate as the reference's
 od_pvq_rate does - the choice and the dequantised plane."""
 import math
+import os
+import sys
 
 import numpy as np
 import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 from _refbands import (THETA_SCALE, Mismatch, compare_bands, compare_choice, host_rates,
                        make_planes, oracle_traces)
@@ -45,11 +49,10 @@ MODES = [(1, 1), (0, 0), (0, 1), (1, 0)]   # (is_keyframe, pli): CfL, inter luma
 
 
 @pytest.mark.parametrize("is_keyframe,pli,env", [m + (None,) for m in MODES]
-                         + [(1, 1, "ODHIP_PVQ_FORCE_SEQ"), (0, 0, "ODHIP_PVQ_REF_LANE")])
+                         + [(1, 1, "ODHIP_PVQ_FORCE_SEQ")])
 def test_ref_band_stage_matches_oracle(hip, is_keyframe, pli, env, monkeypatch):
     """env: ODHIP_PVQ_FORCE_SEQ=1 makes the row-parallel search take the literal
-    left-to-right scan for every greedy pulse; ODHIP_PVQ_REF_LANE=1 searches the
-    32- and 128-coefficient bands one band per lane instead of one per row."""
+    left-to-right scan for every greedy pulse."""
     import torch
     if env:
         monkeypatch.setenv(env, "1")
@@ -81,6 +84,21 @@ def test_ref_band_stage_matches_oracle(hip, is_keyframe, pli, env, monkeypatch):
         compare_choice(job, traces, mm)
     assert mm.total() == 0, mm.summary()
     assert mm.checked["dq"] > 1000
+
+
+def test_ref_band_stage_one_band_per_lane_experiments_build():
+    """ODHIP_PVQ_REF_LANE=1 - the 32- and 128-coefficient bands searched one band per lane instead of
+    one per quad / row - is a form of rounds 1-2 that only the EXPERIMENTS build of the library still
+    holds (-DODHIP_EXPERIMENTS): the inter-luma case of the test above in a child process that loads
+    that build with the switch set."""
+    import subprocess
+    import daala_amd
+    env = dict(os.environ)
+    env.update(ODHIP_LIB=daala_amd.EXPERIMENTS_LIB, ODHIP_PVQ_REF_LANE="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k",
+                        "test_ref_band_stage_matches_oracle and 0-0-None"], env=env, capture_output=True,
+                       text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0 and "1 passed" in r.stdout, r.stdout[-2000:] + r.stderr[-1000:]
 
 
 def test_device_theta_argument_agrees_with_host_libm(hip):

@@ -1,4 +1,6 @@
 #!/bin/bash
+# (round 5) the A/B switches below exist in the experiments build of the library only
+export ODHIP_LIB=${ODHIP_LIB:-$(cd "$(dirname "$0")/.." && pwd)/daala_amd/lib/libdaalahip_exp.so}
 # Round-4 GPU call: the GPU test suite with the walking inverse kernels, then the filter + DCT stages
 # timed alone for the kernel variants named by environment knobs, a kernel trace, and short bench lines.
 set -u

@@ -1,4 +1,6 @@
 #!/bin/bash
+# (round 5) the A/B switches below exist in the experiments build of the library only
+export ODHIP_LIB=${ODHIP_LIB:-$(cd "$(dirname "$0")/.." && pwd)/daala_amd/lib/libdaalahip_exp.so}
 # Sweep of the work-class weights of the with-reference stage (ODHIP_SORT_W = pulses,candidates,searches in quarters).
 cd $GRAFT_REPO_ROOT
 DEF="4,0,0 4,4,8 4,8,8 4,4,16 4,8,16 4,12,24 2,8,16 4,16,16"

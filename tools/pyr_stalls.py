@@ -6,6 +6,9 @@
   (b) with extra dynamic LDS per workgroup (ODHIP_PYR_LDS_PAD) so that only 2 or 1 workgroups
       fit a CU instead of 3 - how the time follows occupancy (latency-bound: ~1/occupancy)."""
 import os
+# (round 5) ODHIP_PYR_* exist in the experiments build of the library only
+os.environ.setdefault("ODHIP_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                                "daala_amd", "lib", "libdaalahip_exp.so"))
 import subprocess
 import sys
 

@@ -2,6 +2,9 @@
 1080p and check each against variant 0 bit for bit.  One child process per variant."""
 import hashlib
 import os
+# (round 5) ODHIP_PYR_* exist in the experiments build of the library only
+os.environ.setdefault("ODHIP_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                                "daala_amd", "lib", "libdaalahip_exp.so"))
 import subprocess
 import sys
 

@@ -1,4 +1,6 @@
 #!/bin/bash
+# (round 5) the A/B switches below exist in the experiments build of the library only
+export ODHIP_LIB=${ODHIP_LIB:-$(cd "$(dirname "$0")/.." && pwd)/daala_amd/lib/libdaalahip_exp.so}
 # Development: the 16-frame step against the number of hardware queues and the per-chain stream forks (one box).
 run() { python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-replay 2>/dev/null | python -c "
 import json,sys
