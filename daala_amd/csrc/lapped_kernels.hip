@@ -26,6 +26,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <type_traits>
 #include "od_ctx.cuh"
 #include "od_tile.cuh"
 #include "od_pvq_math.cuh"
@@ -779,6 +780,26 @@ __device__ __forceinline__ void od_store_px(uint8_t *plane, long at, int c, bool
   else plane[at] = od_to_px(c);
 }
 
+/* OD_MULT16_32_Q16(y, scale) = (int16)y * (int32)scale >> 16 (src/internal.h) without a 32-bit
+   multiply: v_mul_hi_i32 and v_mul_lo_u32 issue at a quarter of the rate of the 24-bit multiplier.
+   scale = sh*65536 + sl with sh = scale >> 16 (16 bits, signed) and sl = scale & 0xffff, so
+   y*scale >> 16 = y*sh + (y*sl >> 16) EXACTLY (y*sh*65536 is a multiple of 65536; |y*sl| < 2^31):
+   two 24-bit multiplies of 16-bit operands and a shift.  The value it returns is a QM-scaled
+   coefficient of the synthesis, |x| < 2^16 by construction (od_pvq_synthesis_partial scales g so
+   that the vector's NORM fits 16 bits, src/pvq.c:1055-1075, and |y_i| <= sqrt(yy)), so the inverse
+   quantisation-matrix product x*qm_inv[i] that follows (src/pvq.c:1092) goes through the 24-bit
+   multiplier too: the low 32 bits of its 48-bit product are the reference's int product. */
+struct OdQ16 {
+  int sh;
+  int sl;
+  __device__ __forceinline__ explicit OdQ16(int scale) : sh(scale >> 16), sl(scale & 0xffff) {}
+  __device__ __forceinline__ int mul(int y) const { return __mul24(y, sh) + (__mul24(y, sl) >> 16); }
+};
+/* pulse j of four packed 16-byte words (eight int16 per pair of words), sign-extended */
+__device__ __forceinline__ int od_pulse16(unsigned w, int odd) {
+  return odd ? (int)w >> 16 : (int)(w << 16) >> 16;
+}
+
 /* Raster plane -> tile, every lane's global loads in flight before its first LDS write. */
 template <int TILE>
 __device__ __forceinline__ void load_plane_tile(int *t, const od_coeff *plane, int w, int x0, int y0, int tid) {
@@ -1318,16 +1339,16 @@ __global__ __launch_bounds__(256) void k_inverse_sb_top2(InverseArgsMulti mm) {
       const int sd[4] = {sc4[hf].x, sc4[hf].y, sc4[hf].z, sc4[hf].w};
       const int4 ch = chs[hf];
       const int rnd = (1 << ch.w) >> 1;
+      const OdQ16 sc(ch.z);
 #pragma unroll
       for (int e = 0; e < 4; e++) {
 #pragma unroll
         for (int u = 0; u < 2; u++) {
-          /* OD_MULT16_32_Q16: (int16)y * (int32)scale >> 16 == mulhi(y << 16, scale) */
-          const int yhi = u ? (yd[e] & (int)0xffff0000) : yd[e] << 16;
+          const int yv = od_pulse16((unsigned)yd[e], u);
           const int qmi = u ? qd[e] >> 16 : (int)(short)qd[e];
           const int xy = u ? (unsigned)sd[e] >> 16 : sd[e] & 0xffff;
-          int v = (__mulhi(yhi, ch.z)*qmi + rnd) >> ch.w;
-          if (ch.y == 0) v = 0;
+          /* (pulses of a band that codes nothing were not read: zero in, zero out) */
+          int v = (__mul24(sc.mul(yv), qmi) + rnd) >> ch.w;
           if (hf == 0 && e == 0 && u == 0 && j0 == 0) v = dc;
           tt[base + (xy >> 8)*P + (xy & 255)] = v;
         }
@@ -1355,14 +1376,18 @@ __global__ __launch_bounds__(256) void k_inverse_sb_top2(InverseArgsMulti mm) {
       const int base = (tid & 31)*P;
       T in[64];
       T out[64];
+      /* ... and only columns 0..31 of a live row: the upper 32 inputs are literal zeros, which prunes
+         the 64-point network at compile time (round 5) */
 #pragma unroll
-      for (int c = 0; c < 64; c += 4) {
+      for (int c = 0; c < 32; c += 4) {
         const int4 v = *reinterpret_cast<const int4 *>(tt + base + c);
         in[c] = T(v.x);
         in[c + 1] = T(v.y);
         in[c + 2] = T(v.z);
         in[c + 3] = T(v.w);
       }
+#pragma unroll
+      for (int c = 32; c < 64; c++) in[c] = T(0);
       od_idct_lift<4>(out, in);
 #pragma unroll
       for (int c = 0; c < 64; c += 4) {
@@ -1370,7 +1395,19 @@ __global__ __launch_bounds__(256) void k_inverse_sb_top2(InverseArgsMulti mm) {
       }
     }
     __syncthreads();
-    if (g < 2) od_tile_cols<TILE, 4, true, T, 64>(t[g], t[g], tid & 63, OdAllBlocks());
+    if (g < 2) {
+      /* columns: rows 32..63 of the tile were not transformed and are zero - the same pruned network */
+      int *tt = t[g] + (tid & 63);
+      T in[64];
+      T out[64];
+#pragma unroll
+      for (int r = 0; r < 32; r++) in[r] = T(tt[r*P]);
+#pragma unroll
+      for (int r = 32; r < 64; r++) in[r] = T(0);
+      od_idct_lift<4>(out, in);
+#pragma unroll
+      for (int r = 0; r < 64; r++) tt[r*P] = out[r];
+    }
     __syncthreads();
   }
   if (a.leaf_bs == 3) {
@@ -1584,85 +1621,192 @@ __device__ __forceinline__ void walk_load_plane(int *t, const od_coeff *plane, i
   }
 }
 
+/* Compile-time loop: f(std::integral_constant<int, J>) for J in [J0, J1) (register arrays indexed with
+   scan-table entries stay in registers only when the indices are constant expressions). */
+template <int J0, int J1, class F>
+__device__ __forceinline__ void inv_static_for(F &&f) {
+  if constexpr (J0 < J1) {
+    f(std::integral_constant<int, J0>{});
+    inv_static_for<J0 + 1, J1>(f);
+  }
+}
+
 /* Source 1: the no-reference band stage's choices, dequantised on load (od_pvq_synthesis_partial
    noref, src/pvq.c:1081-1092; od_coding_order_to_raster, src/partition.c:176-194): one chunk of 16
-   consecutive coding indices of one block per thread and trip, as in k_inverse_sb. */
+   consecutive coding indices of one block per thread and trip, as in k_inverse_sb.
+
+   Round 5: the loads of a group are issued one group AHEAD.  The ablations of
+   profiles/r5_inverse_phases.txt put half of the walking kernels' time into this load - not into its
+   arithmetic (removing a quarter of the instructions of a level, or both quarter-rate multiplies of
+   every coefficient, moved nothing) but into its two DEPENDENT memory latencies per group (choice
+   record -> pulse vector), which a workgroup spent idle before its first barrier.  heads() (choice
+   records, the DC) of group g + 1 goes out right after group g's tile has been filled, pulses() (which
+   needs the records) after the leaf transforms, commit() dequantises from registers into the tile at
+   the top of the next iteration: 17 VGPRs per trip. */
 template <int TILE, int G, int NT, int LEAF>
-__device__ __forceinline__ void walk_load_pvq(int *t, const InverseArgs &a, int plane, long plane_off, int xg,
- int y0, unsigned tid) {
-  constexpr int P = TILE + 4;
-  constexpr int sh = LEAF + 2;
-  constexpr int n = 4 << LEAF;
-  constexpr int len = n*n < OD_SCAN_LEN ? n*n : OD_SCAN_LEN;
-  constexpr int lsh = LEAF >= 3 ? 9 : 2*LEAF + 4;           /* log2(len) */
+struct WalkPvq {
+  static constexpr int P = TILE + 4;
+  static constexpr int sh = LEAF + 2;
+  static constexpr int n = 4 << LEAF;
+  static constexpr int len = n*n < OD_SCAN_LEN ? n*n : OD_SCAN_LEN;
+  static constexpr int lsh = LEAF >= 3 ? 9 : 2*LEAF + 4;           /* log2(len) */
   static_assert((1 << lsh) == len, "len is a power of two");
-  constexpr int nbw = TILE >> sh;
-  constexpr int cpb = len/16;                                /* chunks per block */
-  constexpr int nch = nbw*nbw*cpb;                           /* chunks per tile */
-  const int bw = a.w >> sh;
-  const int bh = a.h >> sh;
-  if constexpr (len < n*n) {                                 /* 32x32 / 64x64: uncoded positions are zero */
-    walk_zero<TILE, G, NT>(t, tid);
-    od_lds_barrier();
-  }
-  for (unsigned c = tid; c < G*nch; c += NT) {
-    const unsigned s = c/nch;
+  static constexpr int nbw = TILE >> sh;
+  static constexpr int cpb = len/16;                                /* chunks per block */
+  static constexpr int nch = nbw*nbw*cpb;                           /* chunks per tile */
+  static constexpr int K = (G*nch + NT - 1)/NT;                     /* trips per thread */
+  static constexpr int NBANDS = OD_NBANDS[LEAF];
+  int4 chs[K][2];
+  int4 yq[K][2];
+  int dc[K];
+  struct Where {
+    bool on;
+    unsigned s;
+    unsigned j0;
+    unsigned lby;
+    unsigned lbx;
+  };
+  __device__ __forceinline__ static Where where(unsigned tid, int k) {
+    const unsigned c = tid + k*NT;
+    Where q;
+    q.on = c < (unsigned)(G*nch);
+    q.s = c/nch;
     const unsigned cc = c % nch;
     const unsigned b = cc/cpb;
-    const unsigned j0 = (cc % cpb) << 4;
-    const unsigned lby = b/nbw;
-    const unsigned lbx = b % nbw;
-    const int x0 = xg + s*TILE;
-    const unsigned blk = (unsigned)(((long)plane*bh + (y0 >> sh) + lby)*bw + (x0 >> sh) + lbx);
-    int o0;
-    int o1;
-    const int bnd0 = walk_band_of<LEAF>(j0 ? j0 : 1, o0);
-    const int bnd1 = walk_band_of<LEAF>(j0 + 8, o1);
-    int4 chs[2];
-    int4 yq[2] = {make_int4(0, 0, 0, 0), make_int4(0, 0, 0, 0)};
-    int4 qm4[2];
-    int4 sc4[2];
+    q.j0 = (cc % cpb) << 4;
+    q.lby = b/nbw;
+    q.lbx = b % nbw;
+    return q;
+  }
+  __device__ __forceinline__ static unsigned block(const InverseArgs &a, int plane, int xg, int y0, const Where &q) {
+    const int bw = a.w >> sh;
+    const int bh = a.h >> sh;
+    return (unsigned)(((long)plane*bh + (y0 >> sh))*bw + (xg >> sh)) + q.lby*(unsigned)bw + q.s*nbw + q.lbx;
+  }
+  /* choice records and the DC of the group at xg */
+  __device__ __forceinline__ void heads(const InverseArgs &a, int plane, long plane_off, int xg, int y0, unsigned tid) {
 #pragma unroll
-    for (int hf = 0; hf < 2; hf++) {
-      qm4[hf] = *reinterpret_cast<const int4 *>(a.qm_inv + j0 + 8*hf);
-      sc4[hf] = *reinterpret_cast<const int4 *>(gInvScanXY + j0 + 8*hf);
+    for (int k = 0; k < K; k++) {
+      const Where q = where(tid, k);
+      chs[k][0] = chs[k][1] = make_int4(0, 0, 0, 0);
+      dc[k] = 0;
+      if (!q.on) continue;
+      const unsigned blk = block(a, plane, xg, y0, q);
+      int o0;
+      int o1;
+      const int bnd0 = walk_band_of<LEAF>(q.j0 ? q.j0 : 1, o0);
+      const int bnd1 = walk_band_of<LEAF>(q.j0 + 8, o1);
+      if (q.j0 == 0) dc[k] = a.coef[plane_off + (long)(y0 + (q.lby << sh))*a.w + xg + q.s*TILE + (q.lbx << sh)];
+      chs[k][0] = a.choice[(long)blk*NBANDS + bnd0];
+      if constexpr (LEAF > 0) chs[k][1] = a.choice[(long)blk*NBANDS + bnd1];
+      else chs[k][1] = chs[k][0];
     }
-    int dc = 0;
-    if (j0 == 0) dc = a.coef[plane_off + (long)(y0 + (lby << sh))*a.w + x0 + (lbx << sh)];
-    chs[0] = a.choice[(long)blk*a.nb_bands + bnd0];
-    chs[1] = a.choice[(long)blk*a.nb_bands + bnd1];
+  }
+  /* ... and, once those records are here, the chosen pulse vectors */
+  __device__ __forceinline__ void pulses(const InverseArgs &a, int plane, int xg, int y0, unsigned tid) {
 #pragma unroll
-    for (int hf = 0; hf < 2; hf++) {
-      if (chs[hf].y != 0) {
-        yq[hf] = *reinterpret_cast<const int4 *>(a.y
-         + (((unsigned)chs[hf].x*(unsigned)a.nblocks + blk) << lsh) + j0 + 8*hf);
-      }
-    }
-    int *ts = t + s*(TILE*P) + (lby << sh)*P + (lbx << sh);
+    for (int k = 0; k < K; k++) {
+      const Where q = where(tid, k);
+      yq[k][0] = yq[k][1] = make_int4(0, 0, 0, 0);
+      if (!q.on) continue;
+      const unsigned blk = block(a, plane, xg, y0, q);
 #pragma unroll
-    for (int hf = 0; hf < 2; hf++) {
-      const int yd[4] = {yq[hf].x, yq[hf].y, yq[hf].z, yq[hf].w};
-      const int qd[4] = {qm4[hf].x, qm4[hf].y, qm4[hf].z, qm4[hf].w};
-      const int sd[4] = {sc4[hf].x, sc4[hf].y, sc4[hf].z, sc4[hf].w};
-      const int4 ch = chs[hf];
-      const int rnd = (1 << ch.w) >> 1;
-#pragma unroll
-      for (int e = 0; e < 4; e++) {
-#pragma unroll
-        for (int u = 0; u < 2; u++) {
-          /* OD_MULT16_32_Q16: (int16)y * (int32)scale >> 16 == mulhi(y << 16, scale) */
-          const int yhi = u ? (yd[e] & (int)0xffff0000) : yd[e] << 16;
-          const int qmi = u ? qd[e] >> 16 : (int)(short)qd[e];
-          const int xy = u ? (unsigned)sd[e] >> 16 : sd[e] & 0xffff;
-          int v = (__mulhi(yhi, ch.z)*qmi + rnd) >> ch.w;
-          if (ch.y == 0) v = 0;
-          if (hf == 0 && e == 0 && u == 0 && j0 == 0) v = dc;
-          ts[(xy >> 8)*P + (xy & 255)] = v;
+      for (int hf = 0; hf < 2; hf++) {
+        if (chs[k][hf].y != 0) {
+          yq[k][hf] = *reinterpret_cast<const int4 *>(a.y
+           + (((unsigned)chs[k][hf].x*(unsigned)a.nblocks + blk) << lsh) + q.j0 + 8*hf);
         }
       }
     }
   }
-}
+  /* registers -> tile: the scatter to raster through the scan table (any leaf level) */
+  __device__ __forceinline__ void commit(int *t, const InverseArgs &a, unsigned tid) const {
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+      const Where q = where(tid, k);
+      if (!q.on) continue;
+      int4 qm4[2];
+      int4 sc4[2];
+#pragma unroll
+      for (int hf = 0; hf < 2; hf++) {
+        qm4[hf] = *reinterpret_cast<const int4 *>(a.qm_inv + q.j0 + 8*hf);
+        sc4[hf] = *reinterpret_cast<const int4 *>(gInvScanXY + q.j0 + 8*hf);
+      }
+      int *ts = t + q.s*(TILE*P) + (q.lby << sh)*P + (q.lbx << sh);
+#pragma unroll
+      for (int hf = 0; hf < 2; hf++) {
+        const int yd[4] = {yq[k][hf].x, yq[k][hf].y, yq[k][hf].z, yq[k][hf].w};
+        const int qd[4] = {qm4[hf].x, qm4[hf].y, qm4[hf].z, qm4[hf].w};
+        const int sd[4] = {sc4[hf].x, sc4[hf].y, sc4[hf].z, sc4[hf].w};
+        const int4 ch = chs[k][hf];
+        const int rnd = (1 << ch.w) >> 1;
+        const OdQ16 sc(ch.z);
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+#pragma unroll
+          for (int u = 0; u < 2; u++) {
+            const int yv = od_pulse16((unsigned)yd[e], u);
+            const int qmi = u ? qd[e] >> 16 : (int)(short)qd[e];
+            const int xy = u ? (unsigned)sd[e] >> 16 : sd[e] & 0xffff;
+            /* a band that codes nothing (qg == 0) left its pulses unread: zero, and (0 + rnd) >> qshift == 0 */
+            int v = (__mul24(sc.mul(yv), qmi) + rnd) >> ch.w;
+            if (hf == 0 && e == 0 && u == 0 && q.j0 == 0) v = dc[k];
+            ts[(xy >> 8)*P + (xy & 255)] = v;
+          }
+        }
+      }
+    }
+  }
+  /* registers -> tile for 4x4 leaves: a chunk IS a block (one band of 15 coefficients and the DC) -
+     the sixteen coding positions dequantised straight into a 4x4 register array (the scan is a
+     compile-time constant: no scan table, no scatter through LDS, the inverse quantisation matrix in
+     scalar registers), od_bin_idct4x4 (rows, then columns, src/dct.c:158-163) in registers, the four
+     rows of the block written into the tile as 16-byte pieces.  Replaces commit(), two barriers and
+     both 4-point LDS passes. */
+  __device__ __forceinline__ void commit_leaf4(int *t, const InverseArgs &a, unsigned tid) const {
+    static_assert(LEAF == 0 || sizeof(int) == 4, "");
+    using T = OdMul24;
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+      const Where q = where(tid, k);
+      if (!q.on) continue;
+      const int4 ch = chs[k][0];
+      const unsigned yw[8] = {(unsigned)yq[k][0].x, (unsigned)yq[k][0].y, (unsigned)yq[k][0].z, (unsigned)yq[k][0].w,
+       (unsigned)yq[k][1].x, (unsigned)yq[k][1].y, (unsigned)yq[k][1].z, (unsigned)yq[k][1].w};
+      const int rnd = (1 << ch.w) >> 1;
+      const OdQ16 sc(ch.z);
+      int m[4][4];
+      m[0][0] = dc[k];
+      inv_static_for<1, 16>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        m[OD_SCAN_XY[j][1]][OD_SCAN_XY[j][0]] =
+         (__mul24(sc.mul(od_pulse16(yw[j >> 1], j & 1)), (int)a.qm_inv[j]) + rnd) >> ch.w;
+      });
+      T qr[4][4];
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const T in[4] = {T(m[r][0]), T(m[r][1]), T(m[r][2]), T(m[r][3])};
+        od_idct_lift<0>(qr[r], in);
+      }
+      T o[4][4];
+#pragma unroll
+      for (int c = 0; c < 4; c++) {
+        const T in[4] = {qr[0][c], qr[1][c], qr[2][c], qr[3][c]};
+        T out[4];
+        od_idct_lift<0>(out, in);
+        o[0][c] = out[0];
+        o[1][c] = out[1];
+        o[2][c] = out[2];
+        o[3][c] = out[3];
+      }
+      int *ts = t + q.s*(TILE*P) + (4*q.lby)*P + 4*q.lbx;
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        *reinterpret_cast<int4 *>(ts + r*P) = make_int4(o[r][0], o[r][1], o[r][2], o[r][3]);
+      }
+    }
+  }
+};
 
 /* Source 2: the with-reference band stage's choices (the per-coefficient part of
    od_pvq_synthesis_partial, src/pvq.c:1081-1114, with or without reference, skip-copy and skip-zero
@@ -1746,14 +1890,15 @@ __device__ __forceinline__ void walk_load_ref(int *t, const InverseArgs &a, int 
       yw[3] = y4.w;
       if (mode == 3 && c0 > off) yprev = yp[-1];
     }
+    const OdQ16 sc(scale);
     if (mode == 2) {
 #pragma unroll
       for (int e = 0; e < 8; e++) {
         if (first && e == 0) continue;
-        /* OD_MULT16_32_Q16 as mulhi(y << 16, scale); OD_SHR_ROUND in the reference's 32 bits */
-        const int yhi = (e & 1) ? (int)(yw[e >> 1] & 0xffff0000u) : (int)(yw[e >> 1] << 16);
+        /* OD_MULT16_32_Q16 (OdQ16); OD_SHR_ROUND in the reference's 32 bits */
+        const int yv = od_pulse16(yw[e >> 1], e & 1);
         const int qmi = (int16_t)(qw[e >> 1] >> (16*(e & 1)));
-        ts[py[e]*P + px_[e]] = (__mulhi(yhi, scale)*qmi + rnd) >> qshift;
+        ts[py[e]*P + px_[e]] = (__mul24(sc.mul(yv), qmi) + rnd) >> qshift;
       }
       continue;
     }
@@ -1765,16 +1910,134 @@ __device__ __forceinline__ void walk_load_ref(int *t, const InverseArgs &a, int 
     for (int e = 0; e < 8; e++) {
       if (first && e == 0) continue;
       const int i = c0 + e - off;
-      const int yhi = (e & 1) ? (int)(yw[e >> 1] & 0xffff0000u) : (int)(yw[e >> 1] << 16);
-      const int ym1hi = e == 0 ? yprev << 16
-       : ((e - 1) & 1) ? (int)(yw[(e - 1) >> 1] & 0xffff0000u) : (int)(yw[(e - 1) >> 1] << 16);
+      const int yv = od_pulse16(yw[e >> 1], e & 1);
+      const int ym1 = e == 0 ? yprev : od_pulse16(yw[(e - 1) >> 1], (e - 1) & 1);
       const int qmi = (int16_t)(qw[e >> 1] >> (16*(e & 1)));
       const int ri = (int16_t)(rw[e >> 1] >> (16*(e & 1)));
-      const int16_t xi = i == m ? (int16_t)cb.x : (int16_t)__mulhi(i < m ? yhi : ym1hi, scale);
+      const int16_t xi = i == m ? (int16_t)cb.x : (int16_t)sc.mul(i < m ? yv : ym1);
       int32_t tmp = ri*(int)(int16_t)cb.z;                    /* OD_MULT16_16(r[i], proj_1) */
       tmp = cb.w >= 0 ? (tmp + ((1 << cb.w) >> 1)) >> cb.w : (int32_t)((uint32_t)tmp << -cb.w);
       const int16_t v = (int16_t)(xi - tmp);
       ts[py[e]*P + px_[e]] = (v*qmi + rnd) >> qshift;
+    }
+  }
+}
+
+/* ---- leaf level 0 in registers, with-reference source (round 5) ------------------------------
+   (The no-reference source: WalkPvq::commit_leaf4 above.)
+   A 4x4 leaf block is ONE band of 15 coefficients plus its DC: one lane takes the whole block -
+   its choice record(s), its 32 bytes of pulses (and of the reference, with-reference source), the DC
+   - dequantises the sixteen coding positions straight into a 4x4 register array (the scan is a
+   compile-time constant: no scan table, no coding-order -> raster scatter through LDS, the inverse
+   quantisation matrix in scalar registers), runs od_bin_idct4x4 (rows, then columns,
+   src/dct.c:158-163) on it and writes the four rows of the block into the tile as 16-byte pieces.
+   That replaces the dequantise-on-load of walk_load_pvq / walk_load_ref, two barriers and both
+   4-point LDS passes (12 of whose 20 instructions per network were LDS addressing and loop control,
+   profiles/r4_inverse_budget.txt).  Same arithmetic, same results. */
+template <int TILE, int G, int NT, int SRC>
+__device__ __forceinline__ void walk_leaf4(int *t, const InverseArgs &a, int plane, long plane_off, int xg,
+ int y0, unsigned tid) {
+  using T = OdMul24;
+  constexpr int P = TILE + 4;
+  constexpr int NB = TILE/4;
+  static_assert(SRC == 2, "the with-reference source (the no-reference one: WalkPvq::commit_leaf4)");
+  const int bw = a.w >> 2;
+  const int bh = a.h >> 2;
+  for (unsigned k = tid; k < G*NB*NB; k += NT) {
+    const unsigned s = k/(NB*NB);
+    const unsigned kk = k % (NB*NB);
+    const unsigned lby = kk/NB;
+    const unsigned lbx = kk % NB;
+    const int x0 = xg + s*TILE;
+    const unsigned blk = (unsigned)(((long)plane*bh + (y0 >> 2) + lby)*bw + (x0 >> 2) + lbx);
+    const long gbase = plane_off + (long)(y0 + 4*lby)*a.w + x0 + 4*lbx;
+    int m[4][4];
+    const int dc = a.coef[gbase];
+    {
+      const int4 *choice4 = a.choice;
+      const int4 ca = choice4[(long)blk*4 + 2];          /* mode, slot, scale, qshift (nb_bands == 1) */
+      const int mode = ca.x;
+      m[0][0] = dc;
+      if (mode == 0) {
+        inv_static_for<1, 16>([&](auto jc) {
+          constexpr int j = decltype(jc)::value;
+          m[OD_SCAN_XY[j][1]][OD_SCAN_XY[j][0]] = 0;
+        });
+      }
+      else if (mode == 1 || mode == 4) {
+        inv_static_for<1, 16>([&](auto jc) {
+          constexpr int j = decltype(jc)::value;
+          const od_coeff rv = a.ref[gbase + (long)OD_SCAN_XY[j][1]*a.w + OD_SCAN_XY[j][0]];
+          m[OD_SCAN_XY[j][1]][OD_SCAN_XY[j][0]] = mode == 4 ? -rv : rv;
+        });
+      }
+      else {
+        const int yslot = ca.y;
+        const int32_t scale = ca.z;
+        const int qshift = ca.w;
+        const int rnd = (1 << qshift) >> 1;
+        uint4 yq[2] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
+        if (yslot >= 0) {
+          const int16_t *yp = a.y + (((long)yslot*a.nblocks + blk) << 4);
+          yq[0] = *reinterpret_cast<const uint4 *>(yp);
+          yq[1] = *reinterpret_cast<const uint4 *>(yp + 8);
+        }
+        const unsigned yw[8] = {yq[0].x, yq[0].y, yq[0].z, yq[0].w, yq[1].x, yq[1].y, yq[1].z, yq[1].w};
+        const OdQ16 sc(scale);
+        if (mode == 2) {
+          inv_static_for<1, 16>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            m[OD_SCAN_XY[j][1]][OD_SCAN_XY[j][0]] =
+             (__mul24(sc.mul(od_pulse16(yw[j >> 1], j & 1)), (int)a.qm_inv[j]) + rnd) >> qshift;
+          });
+        }
+        else {
+          const int4 cb = choice4[(long)blk*4 + 3];      /* xm, m, proj_1, outshift */
+          const int mm = cb.y;
+          const int16_t *rp = a.r16 + ((long)blk << 4);
+          const uint4 r0 = *reinterpret_cast<const uint4 *>(rp);
+          const uint4 r1 = *reinterpret_cast<const uint4 *>(rp + 8);
+          const unsigned rw[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+          const int proj = (int)(int16_t)cb.z;
+          inv_static_for<1, 16>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            constexpr int i = j - 1;                       /* the band starts at coding index 1 */
+            const int yv = od_pulse16(yw[j >> 1], j & 1);
+            /* the pulse before: y[j - 1] (position 0 of the vector, the DC's unused slot, for j = 1:
+               only selected when i > m, which i = 0 never is) */
+            const int ym1 = od_pulse16(yw[(j - 1) >> 1], (j - 1) & 1);
+            const int ri = (int16_t)(rw[j >> 1] >> (16*(j & 1)));
+            const int16_t xi = i == mm ? (int16_t)cb.x : (int16_t)sc.mul(i < mm ? yv : ym1);
+            int32_t tmp = ri*proj;                         /* OD_MULT16_16(r[i], proj_1) */
+            tmp = cb.w >= 0 ? (tmp + ((1 << cb.w) >> 1)) >> cb.w : (int32_t)((uint32_t)tmp << -cb.w);
+            const int16_t v = (int16_t)(xi - tmp);
+            m[OD_SCAN_XY[j][1]][OD_SCAN_XY[j][0]] = (v*(int)a.qm_inv[j] + rnd) >> qshift;
+          });
+        }
+      }
+    }
+    /* od_bin_idct4x4: rows, then columns */
+    T q[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const T in[4] = {T(m[r][0]), T(m[r][1]), T(m[r][2]), T(m[r][3])};
+      od_idct_lift<0>(q[r], in);
+    }
+    int *ts = t + s*(TILE*P) + (4*lby)*P + 4*lbx;
+    T o[4][4];
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+      const T in[4] = {q[0][c], q[1][c], q[2][c], q[3][c]};
+      T out[4];
+      od_idct_lift<0>(out, in);
+      o[0][c] = out[0];
+      o[1][c] = out[1];
+      o[2][c] = out[2];
+      o[3][c] = out[3];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      *reinterpret_cast<int4 *>(ts + r*P) = make_int4(o[r][0], o[r][1], o[r][2], o[r][3]);
     }
   }
 }
@@ -1953,21 +2216,63 @@ __device__ __forceinline__ void inverse_walk(int *t, uint32_t *pxb, const Invers
   const long plane_off = (long)plane*a.w*a.h;
   const int nv = a.w/TILE - 1;
   od_coeff *vs = a.vs + (long)plane*nv*a.h*4;
+  /* no-reference source: the loads of a group go out one group ahead (WalkPvq) */
+  using Fetch = WalkPvq<TILE, G, NT, LEAF>;
+  [[maybe_unused]] Fetch f;
+  const bool ahead = SRC == 1 && !OD_INV_DBG(a, 4) && !OD_INV_DBG(a, 128);
+  if constexpr (SRC == 1) {
+    if (ahead && g0 < g1) {
+      f.heads(a, plane, plane_off, g0*G*TILE, y0, tid);
+      f.pulses(a, plane, g0*G*TILE, y0, tid);
+    }
+  }
   for (int g = g0; g < g1; g++) {
     const int xg = g*G*TILE;
     /* per-lane index arithmetic is redone for every group (as one workgroup per superblock did):
        hoisted out of this loop it occupies ~50 VGPRs and halves the occupancy */
     asm volatile("" : "+v"(tid));
-    if (OD_INV_DBG(a, 4)) walk_zero<TILE, G, NT>(t, tid);
-    else if constexpr (SRC == 0) walk_load_plane<TILE, G, NT>(t, a.coef + plane_off, a.w, xg, y0, tid);
-    else if constexpr (SRC == 1) walk_load_pvq<TILE, G, NT, LEAF>(t, a, plane, plane_off, xg, y0, tid);
-    else walk_load_ref<TILE, G, NT, LEAF>(t, a, plane, plane_off, xg, y0, tid);
-    od_lds_barrier();
-    walk_idct_pass<TILE, G, NT, LEAF, true>(t, tid);
-    od_lds_barrier();
-    walk_idct_pass<TILE, G, NT, LEAF, false>(t, tid);
-    od_lds_barrier();
-    walk_split_levels<TILE, G, NT, LEAF, 1>(t, tid, xg, y0, a.pic_w, a.pic_h);
+    /* 4x4 leaves of a pulse-fed source: dequantisation and both 4-point passes in registers, one
+       block per lane (WalkPvq::commit_leaf4 / walk_leaf4; OD_INV_DBG bit 8, experiments build: the
+       LDS passes of round 4) */
+    const bool leaf4 = LEAF == 0 && SRC != 0 && !OD_INV_DBG(a, 4) && !OD_INV_DBG(a, 8);
+    if constexpr (SRC == 1) {
+      if (!OD_INV_DBG(a, 4)) {
+        if (!ahead) {                      /* (experiments build, bit 128: the loads where round 4 had them) */
+          f.heads(a, plane, plane_off, xg, y0, tid);
+          f.pulses(a, plane, xg, y0, tid);
+        }
+        if constexpr (Fetch::len < Fetch::n*Fetch::n) {   /* 32x32 / 64x64: uncoded positions are zero */
+          walk_zero<TILE, G, NT>(t, tid);
+          od_lds_barrier();
+        }
+        if (leaf4) f.commit_leaf4(t, a, tid);
+        else f.commit(t, a, tid);
+      }
+      else walk_zero<TILE, G, NT>(t, tid);
+      od_lds_barrier();
+      if (ahead && g + 1 < g1) f.heads(a, plane, plane_off, xg + G*TILE, y0, tid);
+    }
+    else if (leaf4) {
+      if constexpr (LEAF == 0 && SRC == 2) walk_leaf4<TILE, G, NT, SRC>(t, a, plane, plane_off, xg, y0, tid);
+      od_lds_barrier();
+    }
+    else {
+      if (OD_INV_DBG(a, 4)) walk_zero<TILE, G, NT>(t, tid);
+      else if constexpr (SRC == 0) walk_load_plane<TILE, G, NT>(t, a.coef + plane_off, a.w, xg, y0, tid);
+      else if constexpr (SRC == 2) walk_load_ref<TILE, G, NT, LEAF>(t, a, plane, plane_off, xg, y0, tid);
+      od_lds_barrier();
+    }
+    if (!leaf4 && !OD_INV_DBG(a, 16)) {           /* (bit 16, experiments build: timing ablation, WRONG results) */
+      walk_idct_pass<TILE, G, NT, LEAF, true>(t, tid);
+      od_lds_barrier();
+      walk_idct_pass<TILE, G, NT, LEAF, false>(t, tid);
+      od_lds_barrier();
+    }
+    if constexpr (SRC == 1) {
+      /* the choice records of the next group have had the leaf transforms to arrive */
+      if (ahead && g + 1 < g1) f.pulses(a, plane, xg + G*TILE, y0, tid);
+    }
+    if (!OD_INV_DBG(a, 32)) walk_split_levels<TILE, G, NT, LEAF, 1>(t, tid, xg, y0, a.pic_w, a.pic_h);
     /* the vertical superblock edges of the group: left of every tile (against the keep for the
        first tile; a segment's first group hands its columns 0..1 to the strips instead) and, at a
        segment's end inside the plane, columns TILE-2..TILE-1 of the last tile to the strips */
@@ -1999,7 +2304,9 @@ __device__ __forceinline__ void inverse_walk(int *t, uint32_t *pxb, const Invers
       }
     }
     od_lds_barrier();
-    if (a.wide) {
+    if (OD_INV_DBG(a, 64)) {
+    }
+    else if (a.wide) {
       if (g != g0) walk_store_prev<TILE, G, NT>(t, pxb, a, plane, xg - G*TILE, y0, sby, tid);
       od_lds_barrier();
       walk_pack<TILE, G, NT>(t, pxb, a, plane, xg, y0, sby, tid);
@@ -2088,10 +2395,18 @@ __global__ __launch_bounds__(256) void k_edge_rows(EdgeArgsMulti mm) {
     uint8_t *pl = a.px + ((long)plane*a.px_plane_stride << a.px16);
     const long at = (long)y*a.px_stride + x;
     const bool px16 = a.px16 != 0;
-    od_store_px(pl, at, t0, px16);
-    od_store_px(pl, at + 1, t1, px16);
-    od_store_px(pl, at + 2, t2, px16);
-    od_store_px(pl, at + 3, t3, px16);
+    if (!px16 && !((a.px_stride | a.px_plane_stride | (long)(uintptr_t)a.px) & 1)) {
+      /* x = (e + 1)*tile - 2 is even: the four samples as two aligned 16-bit stores */
+      unsigned short *p2 = reinterpret_cast<unsigned short *>(pl + at);
+      p2[0] = (unsigned short)(od_to_px(t0) | od_to_px(t1) << 8);
+      p2[1] = (unsigned short)(od_to_px(t2) | od_to_px(t3) << 8);
+    }
+    else {
+      od_store_px(pl, at, t0, px16);
+      od_store_px(pl, at + 1, t1, px16);
+      od_store_px(pl, at + 2, t2, px16);
+      od_store_px(pl, at + 3, t3, px16);
+    }
   }
 }
 
