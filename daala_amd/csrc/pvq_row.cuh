@@ -22,17 +22,19 @@
    a_best*b_j` with a = (xy + x_j)^2, b = yy + 2*y_j + 1, scanning j upward from
    0; that relation need not be transitive, so a reduction is not equivalent a
    priori.  It is made exact:
-     1. each lane folds its own E candidates left to right with the reference
-        comparator; a cheap float key a/b picks the row's proposal W;
-     2. every lane checks every one of its candidates against W with the
-        reference's two products: it must be an exact duplicate of W (same a and
-        b) or lose to W by a relative margin of 2^-21 (>> the 2^-52 rounding of
-        the products; round 4: tested with one product against a pre-scaled ratio).  Then the sequential scan provably ends on the
-        lowest-indexed duplicate: before it the running best is a clear loser,
-        which it beats; after it nothing beats it;
-     3. otherwise (a near tie that is not exact, or a float key that picked a
+     1. each lane folds its own E candidates left to right in SINGLE precision
+        (round 5; rounds 2-4 folded with the reference's double-precision
+        comparator); a float key a/b picks the row's proposal W;
+     2. every lane checks every one of its candidates against W: it must be an
+        exact duplicate of W (same |x| and same y as integers, hence same a and
+        b) or lose to W by a relative margin of 2^-18 in single precision (>> the
+        2^-52 rounding of the reference's products; the error of the
+        single-precision ratios is below 2^-20).  Then the sequential scan
+        provably ends on the lowest-indexed duplicate: before it the running
+        best is a clear loser, which it beats; after it nothing beats it;
+     3. otherwise (a near tie that is not exact, or a key that picked a
         non-maximal proposal) the row replays that pulse with the literal
-        left-to-right scan.
+        left-to-right scan in double precision.
    The last 1 + k/4 pulses (:192-219) maximise one double per candidate with
    `>`: (max value, lowest index) is a total order, so the reduction is exact.
 
@@ -189,87 +191,111 @@ __device__ __forceinline__ double od_pvq_search_row(const int (&ax)[E], int (&y)
      loops are wave-wide, so iterate to the maximum of the calling rows with
      per-row predication. */
   /* ---- greedy pulses ---------------------------------------------------- */
+  /* Round 5: the candidates are SCREENED in single precision and the reference's double-precision
+     comparison runs only when the screen cannot vouch for the pulse (header, points 1-3):
+       key_j = fl32(a_j)/fl32(b_j) is within 6*2^-24 of the rational a_j/b_j (xy < 2^53 and b < 2^31
+       converted once, one add, one multiply: every operand positive);
+       the row's proposal W = best key (each lane folds its eight candidates by cross-multiplied
+       single-precision products, one v_rcp_f32 per lane makes its key, an integer DPP max picks the row's);
+       a candidate with a_j < b_j*thr, thr = key_W*(1 - 2^-17), is a CLEAR LOSER: its rational lies
+       below W's by a relative 2^-18, 2^34 times the rounding of the reference's two products;
+       every other candidate must be an exact DUPLICATE of W - the same |x_j| and the same y_j, hence the
+       same a and b in the reference's arithmetic (compared as integers: equal single-precision values
+       would not imply it).
+     Then the sequential scan provably ends on the lowest-indexed duplicate (before it the running best
+     is a clear loser, which it beats; after it nothing beats it); otherwise the row replays the pulse
+     with the literal left-to-right scan in double precision.  Per candidate: 6 single-precision
+     operations, 3 integer ones and 7 selects / compares against 12 double-precision operations and 11
+     selects before (profiles/r5_search_budget.txt). */
   while (__any(i < n_greedy)) {
     const bool on = i < n_greedy;
-    double a[E];
-    double b[E];
-    double ba = 0;
-    double bb = 1;
-    /* yy + 2*y_j + 1 (:175) is an integer below 2^31: formed in integers, converted once */
+    /* yy + 2*y_j + 1 (:175) is an integer below 2^31: formed in integers */
     const int yyp1 = (int)yy + 1;
+    const float xyf = (float)xy;
+    float af[E];
+    float bf[E];
+    int bi[E];
+    float baf = 0;
+    float bbf = 1;
+    int bax = 0;
+    int bbi = 1;
 #pragma unroll
     for (int e = 0; e < E; e++) {
-      const double t = xy + od_cvt_u(ax[e]);
-      a[e] = t*t;
-      b[e] = (double)(yyp1 + 2*y[e]);
-      if (e == E - 1 && pad_lane) a[e] = -1;   /* PAD: loses every comparison */
-      if (e == 0 || a[e]*bb > ba*b[e]) {
-        ba = a[e];
-        bb = b[e];
+      const float tf = xyf + (float)ax[e];
+      af[e] = tf*tf;
+      bi[e] = yyp1 + 2*y[e];
+      bf[e] = (float)bi[e];
+      if (e == E - 1 && pad_lane) af[e] = -1.f;   /* PAD: a clear loser against any proposal */
+      if (e == 0 || af[e]*bbf > baf*bf[e]) {
+        baf = af[e];
+        bbf = bf[e];
+        bax = ax[e];
+        bbi = bi[e];
       }
     }
-    /* proposal: best float key of the row, lowest lane on equal keys */
-    /* a proposal only: one v_rcp_f32; the key is a non-negative finite float (a < 2^75), so its bit
+    /* proposal: the row's best key, lowest lane on equal keys.  The key is a non-negative finite
+       float (a < 2^75; a lane's fold starts from its first candidate, never the PAD), so its bit
        pattern orders like its value and the row maximum is an integer DPP max */
-    const int key = __float_as_int((float)ba*__builtin_amdgcn_rcpf((float)bb));
+    const int key = __float_as_int(baf*__builtin_amdgcn_rcpf(bbf));
     const int kmax = grp_max<G>(key);
     const unsigned wmask = grp_ballot<G>(key == kmax, row);
     const int wl = wmask ? __ffs(wmask) - 1 : 0;
-    const double wa = grp_bcast<G>(ba, row, wl);
-    const double wb = grp_bcast<G>(bb, row, wl);
-    /* verification against the proposal.  Round 4: one product per candidate instead of three -
-       wr = (wa/wb)*(1 - 2^-20) to within 2^-22 (v_rcp_f32 of a denominator below 2^31, once per
-       pulse), so a_j < fl(b_j*wr) implies a_j*wb < wa*b_j*(1 - 2^-21): still a margin 2^30 times
-       the rounding of the reference's two products. */
-    const double wr = (wa*(double)__builtin_amdgcn_rcpf((float)wb))*(1. - 9.5367431640625e-07);
+    const int wx = grp_bcast<G>(bax, row, wl);
+    const int wbi = grp_bcast<G>(bbi, row, wl);
+    const float thr = __int_as_float(kmax)*(1.f - 7.62939453125e-06f);      /* 1 - 2^-17 */
     bool bad = force_scan != 0 || wmask == 0;
     int first_dup = n;
 #pragma unroll
     for (int e = E - 1; e >= 0; e--) {
-      const bool dup = (a[e] == wa) & (b[e] == wb);
-      const bool loses = a[e] < b[e]*wr;     /* false for a duplicate of W */
+      bool dup = (ax[e] == wx) & (bi[e] == wbi);
+      if (e == E - 1 && pad_lane) dup = false;
+      const bool loses = af[e] < bf[e]*thr;     /* false for W and its duplicates */
       first_dup = dup ? l*E + e : first_dup;
       bad |= !(dup | loses);
     }
     int pos;
-    double nb = wb;      /* the winner's denominator yy + 2*y_pos + 1 IS the next yy */
+    int px = wx;                 /* every duplicate of W has W's |x| ... */
+    double nb = (double)wbi;     /* ... and the winner's denominator yy + 2*y_pos + 1 IS the next yy */
     if (grp_ballot<G>(bad && on, row) != 0) {
-      /* literal scan, src/pvq_encoder.c:172-183 */
+      /* literal scan, src/pvq_encoder.c:172-183, in the reference's double precision */
       double sa = 0;
       double sb = 1;
+      int sx = 0;
       pos = 0;
+#pragma unroll 1
       for (int j = 0; j < n; j++) {
         const int e = j % E;
-        double ca = a[0];
-        double cb = b[0];
+        int cx = ax[0];
+        int cy = y[0];
 #pragma unroll
         for (int t = 1; t < E; t++) {
           if (e == t) {
-            ca = a[t];
-            cb = b[t];
+            cx = ax[t];
+            cy = y[t];
           }
         }
-        ca = grp_bcast<G>(ca, row, j/E);
-        cb = grp_bcast<G>(cb, row, j/E);
+        cx = grp_bcast<G>(cx, row, j/E);
+        cy = grp_bcast<G>(cy, row, j/E);
+        const double tt = xy + od_cvt_u(cx);
+        double ca = tt*tt;
+        const double cb = (double)(yyp1 + 2*cy);
+        if (n_true != n && j == n - 1) ca = -1;     /* PAD: loses every comparison */
         if (j == 0 || ca*sb > sa*cb) {
           sa = ca;
           sb = cb;
+          sx = cx;
           pos = j;
         }
       }
       nb = sb;
+      px = sx;
     }
     else pos = grp_min<G>(first_dup);
     /* xy += x[pos]; yy += 2*y[pos] + 1 (= the winner's b, an integer below 2^31 held exactly); y[pos]++ */
-    int px = 0;
 #pragma unroll
     for (int e = 0; e < E; e++) {
-      if (on && l*E + e == pos) {
-        px = ax[e];
-        y[e]++;
-      }
+      if (on && l*E + e == pos) y[e]++;
     }
-    px = grp_bcast<G>(px, row, pos/E);
     if (on) {
       xy = xy + (double)px;
       yy = nb;
