@@ -9,6 +9,7 @@
    Reference: od_bin_fdctNxN / od_bin_idctNxN, src/dct.c:151-163, 351-363,
    792-806, 4890-4920. */
 #include "../../include/daala_hip.h"
+#include <type_traits>
 #include "od_common.cuh"
 #include "od_tile.cuh"
 #include "od_filters.cuh"
@@ -132,6 +133,192 @@ __global__ __launch_bounds__(DctGeo<LN>::kNT) void k_dct2d_plane(od_coeff *out,
   dct2d_tile<LN, INV, T>(out, in, im, om);
 }
 
+/* ---- 64x64 forward, two wavefronts per block (round 5) -------------------------------------
+   One wavefront per 64x64 block (above) runs a 1191-instruction dependent network twice with
+   17 KB of LDS per wavefront: 2.25 wavefronts per SIMD, each a long dependency chain - measured at
+   8.5 cycles per VALU instruction, twice what a filled SIMD sustains (0.44 of the HBM spec,
+   profiles/r4_microbench_configs2_3.txt).  Here every column, then every row, is shared by TWO
+   lanes running the even / odd half network (od_fdct_lift_half: after its first butterfly stage a
+   forward transform separates into two independent halves), the halves wave-uniform: 128 threads
+   per block, half the registers per lane, and the columns are read straight from global memory
+   (coalesced over the 64 lanes of a wavefront; the second wavefront's reads hit the cache), so the
+   only LDS is the intermediate - kept TRANSPOSED and in parity-split order (position p' =
+   (p & 1)*32 + (p >> 1)) at an odd pitch of 65 words, every access of both passes and of the
+   copy-out a conflict-free ds_read / write_b32 (the layout of pyramid_level_split64,
+   lapped_kernels.hip).  16.6 KB per block of two wavefronts: 4.5 wavefronts per SIMD. */
+template <typename T>
+__global__ __launch_bounds__(128) void k_fdct64_split(od_coeff *out, long out_stride, long out_block,
+ const od_coeff *in, long in_stride, long in_block, int blocks_x) {
+  constexpr int N = 64;
+  constexpr int H = 32;
+  constexpr int PZ = 65;
+  __shared__ int z[N*PZ];
+  const int tid = threadIdx.x;
+  const int half = tid >> 6;
+  const int c = tid & 63;
+  /* batch: block b at b*4096, rows 64 apart; plane: block (bx, by) at (by*64)*stride + bx*64 */
+  const long bx = blocks_x ? blockIdx.x % blocks_x : 0;
+  const long by = blocks_x ? blockIdx.x / blocks_x : blockIdx.x;
+  const od_coeff *src = in + by*in_block + bx*N;
+  od_coeff *dst = out + by*out_block + bx*N;
+  {
+    T a[N];
+    T o[H];
+#pragma unroll
+    for (int r = 0; r < N; r++) a[r] = T(src[r*in_stride + c]);
+    if (half == 0) od_fdct_lift_half<4, 0>(o, a);
+    else od_fdct_lift_half<4, 1>(o, a);
+#pragma unroll
+    for (int k = 0; k < H; k++) z[c*PZ + half*H + k] = o[k];
+  }
+  __syncthreads();
+  {
+    T a[N];
+    T o[H];
+#pragma unroll
+    for (int i = 0; i < N; i++) a[i] = T(z[i*PZ + c]);
+    __syncthreads();          /* the partner lane reads the same words */
+    if (half == 0) od_fdct_lift_half<4, 0>(o, a);
+    else od_fdct_lift_half<4, 1>(o, a);
+#pragma unroll
+    for (int k = 0; k < H; k++) z[(half*H + k)*PZ + c] = o[k];
+  }
+  __syncthreads();
+  /* raster (y, x) <- z[x'][y']: 16 bytes per lane and store */
+  constexpr int K = N*N/4/128;
+  int q[K][4];
+#pragma unroll
+  for (int k = 0; k < K; k++) {
+    const int i = tid + k*128;
+    const int y = i/(N/4);
+    const int x = (i % (N/4))*4;
+    const int col = (y & 1)*H + (y >> 1);
+#pragma unroll
+    for (int j = 0; j < 4; j++) q[k][j] = z[(((x + j) & 1)*H + ((x + j) >> 1))*PZ + col];
+  }
+#pragma unroll
+  for (int k = 0; k < K; k++) {
+    const int i = tid + k*128;
+    *reinterpret_cast<int4 *>(dst + (long)(i/(N/4))*out_stride + (i % (N/4))*4) =
+     make_int4(q[k][0], q[k][1], q[k][2], q[k][3]);
+  }
+}
+
+/* ---- 64x64 inverse, two wavefronts per block (round 5) -------------------------------------
+   The same occupancy argument as k_fdct64_split.  An inverse network does not split by output
+   parity; read backwards it STARTS with two independent sub-networks - one fed by the even-indexed
+   inputs, one by the odd-indexed ones - and ends in a joining stage (od_idct64_lift_part / _join,
+   od_lift.cuh): the lane pair of a line runs one part each, exchanges through LDS the 32 values the
+   other lane's join needs, and each produces one half of the outputs.  The block is staged in one
+   64 x 68 tile (16-byte global loads); the exchange area aliases the tile once every lane holds its
+   inputs in registers; the rows go back into the tile as 16-byte pieces, the columns straight to
+   global memory (coalesced over the 64 lanes of a wavefront).  17 KB per block of two wavefronts. */
+template <int J0, int J1, class F>
+__device__ __forceinline__ void dct_static_for(F &&f) {
+  if constexpr (J0 < J1) {
+    f(std::integral_constant<int, J0>{});
+    dct_static_for<J0 + 1, J1>(f);
+  }
+}
+
+/* One lane's share of a 64-point inverse line in three steps with a workgroup barrier between them
+   (the barriers stay OUTSIDE the wave-uniform branches on the half): part HALF on its 32 inputs;
+   export of what the other lane's join needs into x[slot][lane]; import + join HALF. */
+template <int HALF, typename T>
+__device__ __forceinline__ void idct64_export(const T (&own)[48], int *x, int c) {
+  dct_static_for<0, 32>([&](auto jc) {
+    constexpr int j = decltype(jc)::value;
+    constexpr int idx = HALF == 0 ? kIdct64NeedIdx1[j] : kIdct64NeedIdx0[j];
+    x[(HALF*32 + j)*64 + c] = own[idx];
+  });
+}
+
+template <int HALF, typename T>
+__device__ __forceinline__ void idct64_join(T (&o)[32], const T (&own)[48], const int *x, int c) {
+  T other[48];
+  dct_static_for<0, 32>([&](auto jc) {
+    constexpr int j = decltype(jc)::value;
+    constexpr int idx = HALF == 0 ? kIdct64NeedIdx0[j] : kIdct64NeedIdx1[j];
+    other[idx] = T(x[((1 - HALF)*32 + j)*64 + c]);
+  });
+  if constexpr (HALF == 0) od_idct64_lift_join<0>(o, own, other);
+  else od_idct64_lift_join<1>(o, other, own);
+}
+
+/* a[]: the lane's 32 inputs (parity `half`) -> o[]: outputs half*32 .. half*32 + 31 of the line. */
+template <typename T>
+__device__ __forceinline__ void idct64_pair(T (&o)[32], const T (&a)[32], int *x, int c, int half) {
+  T own[48];
+  if (half == 0) od_idct64_lift_part<0>(own, a);
+  else od_idct64_lift_part<1>(own, a);
+  __syncthreads();                       /* every lane of the block holds its inputs: the tile is free */
+  if (half == 0) idct64_export<0>(own, x, c);
+  else idct64_export<1>(own, x, c);
+  __syncthreads();
+  if (half == 0) idct64_join<0>(o, own, x, c);
+  else idct64_join<1>(o, own, x, c);
+}
+
+template <typename T>
+__global__ __launch_bounds__(128) void k_idct64_split(od_coeff *out, long out_stride, long out_block,
+ const od_coeff *in, long in_stride, long in_block, int blocks_x) {
+  constexpr int N = 64;
+  constexpr int H = 32;
+  constexpr int P = OdTile<kTile>::kPitch;
+  static_assert(kIdct64Need0 == 32 && kIdct64Need1 == 32, "exchange area: 64 slots of 64 lanes");
+  __shared__ __attribute__((aligned(16))) int t[N*P];
+  const int tid = threadIdx.x;
+  const int half = tid >> 6;
+  const int c = tid & 63;
+  const long bx = blocks_x ? blockIdx.x % blocks_x : 0;
+  const long by = blocks_x ? blockIdx.x / blocks_x : blockIdx.x;
+  const od_coeff *src = in + by*in_block + bx*N;
+  od_coeff *dst = out + by*out_block + bx*N;
+  {
+    constexpr int K = N*N/4/128;
+    int4 v[K];
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+      const int i = tid + k*128;
+      v[k] = *reinterpret_cast<const int4 *>(src + (long)(i/(N/4))*in_stride + (i % (N/4))*4);
+    }
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+      const int i = tid + k*128;
+      *reinterpret_cast<int4 *>(t + (i/(N/4))*P + (i % (N/4))*4) = v[k];
+    }
+  }
+  __syncthreads();
+  /* rows (od_bin_idct64x64: rows, then columns): lane c of wavefront `half` takes row c */
+  {
+    T a[H];
+    T o[H];
+#pragma unroll
+    for (int q = 0; q < N/4; q++) {
+      const int4 v = *reinterpret_cast<const int4 *>(t + c*P + 4*q);
+      a[2*q] = T(half ? v.y : v.x);
+      a[2*q + 1] = T(half ? v.w : v.z);
+    }
+    idct64_pair(o, a, t, c, half);
+    __syncthreads();                     /* the exchange area is read: the tile takes the rows back */
+#pragma unroll
+    for (int q = 0; q < H/4; q++) {
+      *reinterpret_cast<int4 *>(t + c*P + half*H + 4*q) = make_int4(o[4*q], o[4*q + 1], o[4*q + 2], o[4*q + 3]);
+    }
+  }
+  __syncthreads();
+  /* columns: lane c takes column c, its outputs go straight to global memory */
+  {
+    T a[H];
+    T o[H];
+#pragma unroll
+    for (int k = 0; k < H; k++) a[k] = T(t[(2*k + half)*P + c]);
+    idct64_pair(o, a, t, c, half);
+#pragma unroll
+    for (int k = 0; k < H; k++) dst[(long)(half*H + k)*out_stride + c] = o[k];
+  }
+}
+
 template <bool INV, typename T>
 int launch_batch(int ln, od_coeff *out, const od_coeff *in, long nblocks,
  hipStream_t s) {
@@ -145,7 +332,10 @@ int launch_batch(int ln, od_coeff *out, const od_coeff *in, long nblocks,
     case 1: k_dct2d_batch<1, INV, T><<<(unsigned)grid, DctGeo<1>::kNT, 0, s>>>(out, in, nblocks); break;
     case 2: k_dct2d_batch<2, INV, T><<<(unsigned)grid, DctGeo<2>::kNT, 0, s>>>(out, in, nblocks); break;
     case 3: k_dct2d_batch<3, INV, T><<<(unsigned)grid, DctGeo<3>::kNT, 0, s>>>(out, in, nblocks); break;
-    case 4: k_dct2d_batch<4, INV, T><<<(unsigned)grid, DctGeo<4>::kNT, 0, s>>>(out, in, nblocks); break;
+    case 4:
+      if constexpr (!INV) k_fdct64_split<T><<<(unsigned)grid, 128, 0, s>>>(out, 64, 4096, in, 64, 4096, 0);
+      else k_idct64_split<T><<<(unsigned)grid, 128, 0, s>>>(out, 64, 4096, in, 64, 4096, 0);
+      break;
     default: return ODHIP_EINVAL;
   }
   return odhip_check_launch();
@@ -164,7 +354,17 @@ int launch_plane(int ln, od_coeff *out, int out_stride, const od_coeff *in,
     case 1: k_dct2d_plane<1, INV, T><<<grid, DctGeo<1>::kNT, 0, s>>>(out, out_stride, in, in_stride, w, h); break;
     case 2: k_dct2d_plane<2, INV, T><<<grid, DctGeo<2>::kNT, 0, s>>>(out, out_stride, in, in_stride, w, h); break;
     case 3: k_dct2d_plane<3, INV, T><<<grid, DctGeo<3>::kNT, 0, s>>>(out, out_stride, in, in_stride, w, h); break;
-    case 4: k_dct2d_plane<4, INV, T><<<grid, DctGeo<4>::kNT, 0, s>>>(out, out_stride, in, in_stride, w, h); break;
+    case 4:
+      if constexpr (!INV) {
+        /* whole 64x64 blocks only (w, h are multiples of n) */
+        k_fdct64_split<T><<<(unsigned)(grid.x*grid.y), 128, 0, s>>>(out, out_stride, 64L*out_stride, in, in_stride,
+         64L*in_stride, (int)grid.x);
+      }
+      else {
+        k_idct64_split<T><<<(unsigned)(grid.x*grid.y), 128, 0, s>>>(out, out_stride, 64L*out_stride, in, in_stride,
+         64L*in_stride, (int)grid.x);
+      }
+      break;
     default: return ODHIP_EINVAL;
   }
   return odhip_check_launch();

@@ -120,6 +120,24 @@ __device__ __forceinline__ void od_fdct_lift_half(T (&out)[2 << LN], const T (&i
   }
 }
 
+/* Split inverse networks (round 5; generated: tools/extract_lifting.py emit_device_inverse_split): part P
+   runs the sub-network fed by the inputs of parity P alone (in_P[k] = in[2k + P]) and leaves the values
+   that cross into the joining stage in mid[]; join H produces outputs H*N/2 .. H*N/2 + N/2 - 1 from both
+   parts' mid[] - of the other part's only the entries kIdctNNeedIdxH lists.  Two lanes can share one line:
+   each runs one part, exports what the other's join needs, and joins its own half. */
+template <int PART, typename T>
+__device__ __forceinline__ void od_idct64_lift_part(T (&mid)[48], const T (&in)[32]) {
+  static_assert(kIdct64Mid0 == 48 && kIdct64Mid1 == 48, "array sizes below");
+  if constexpr (PART == 0) od_idct64_lift_part0(mid, in);
+  else od_idct64_lift_part1(mid, in);
+}
+
+template <int HALF, typename T>
+__device__ __forceinline__ void od_idct64_lift_join(T (&out)[32], const T (&m0)[48], const T (&m1)[48]) {
+  if constexpr (HALF == 0) od_idct64_lift_join0(out, m0, m1);
+  else od_idct64_lift_join1(out, m0, m1);
+}
+
 template <int LN, typename T>
 __device__ __forceinline__ void od_idct_lift(T (&out)[4 << LN], const T (&in)[4 << LN]) {
   if constexpr (LN == 0) od_idct4_lift(out, in);

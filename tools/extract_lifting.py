@@ -449,6 +449,188 @@ def emit_device_half(name, n, p, parity):
     return "\n".join(lines), sum(keep)
 
 
+def emit_device_inverse_split(n, p):
+    """An n-point INVERSE network as two independent parts and a joining stage (round 5).
+
+    Read backwards, the forward network's structure (an n/2-point asymmetric DCT of the sums, an
+    n/2-point asymmetric DST of the differences, then butterflies) makes the inverse start with two
+    sub-networks that share nothing - one fed by the even-indexed inputs only, one by the odd-indexed
+    ones - and end in a joining stage (the butterflies) that needs both.  Nothing here assumes that
+    structure: the statements are put in SSA form and classified by the parity of the inputs they
+    transitively depend on; part P holds the statements that depend on inputs of parity P alone,
+    the join the rest.  Two lanes can each run one part on the same input line, exchange the
+    values that cross the cut and produce half of the outputs each:
+
+      od_idctN_lift_part<P>(mid[M_P], in_P[n/2])       in_P[k] = in[2k + P]
+      od_idctN_lift_join<H>(out_H[n/2], mid0, mid1)    out_H[k] = out[H*n/2 + k]
+
+    Returns (code, stats)."""
+    ver = {}
+    cur = {}
+
+    def rename(e):
+        k = e[0]
+        if k == "reg":
+            return ("ssa", cur[e[1]])
+        if k in ("const", "in", "stride", "out"):
+            return e
+        return (k,) + tuple(rename(c) if isinstance(c, tuple) else c for c in e[1:])
+
+    ssa = []      # (name or ('out', i), expr)
+    for _, lhs, op, e in p.stmts:
+        rhs = rename(e)
+        if lhs[0] == "out":
+            ssa.append((lhs, rhs))
+            continue
+        r = lhs[1]
+        if op == "+=":
+            rhs = ("add", ("ssa", cur[r]), rhs)
+        elif op == "-=":
+            rhs = ("sub", ("ssa", cur[r]), rhs)
+        elif op != "=":
+            raise ValueError(op)
+        ver[r] = ver.get(r, -1) + 1
+        name = "v%d_%d" % (r, ver[r])
+        cur[r] = name
+        ssa.append((name, rhs))
+
+    dep = {}
+
+    def deps(e):
+        k = e[0]
+        if k == "in":
+            return {e[1] & 1}
+        if k == "ssa":
+            return set(dep[e[1]])
+        if k in ("const", "stride", "out"):
+            return set()
+        d = set()
+        for c in e[1:]:
+            if isinstance(c, tuple):
+                d |= deps(c)
+        return d
+
+    def uses(e, acc):
+        if e[0] == "ssa":
+            acc.add(e[1])
+        elif e[0] not in ("const", "in", "stride", "out"):
+            for c in e[1:]:
+                if isinstance(c, tuple):
+                    uses(c, acc)
+        return acc
+
+    cls = []
+    for lhs, rhs in ssa:
+        d = deps(rhs)
+        if isinstance(lhs, tuple):
+            cls.append(2)             # an output assignment belongs to the join
+        else:
+            dep[lhs] = d
+            if not d:
+                raise ValueError("statement without an input: %s" % lhs)
+            cls.append(2 if len(d) == 2 else next(iter(d)))
+    # values that cross the cut, in the order the join first reads them
+    mids = [[], []]
+    seen = set()
+    for (lhs, rhs), c in zip(ssa, cls):
+        if c != 2:
+            continue
+        for u in sorted(uses(rhs, set())):
+            if u not in seen and len(dep[u]) == 1:
+                seen.add(u)
+                mids[next(iter(dep[u]))].append(u)
+
+    def cx(e, part):
+        k = e[0]
+        if k == "ssa":
+            return e[1]
+        if k == "in":
+            assert part is not None and (e[1] & 1) == part
+            return "in[%d]" % (e[1] >> 1)
+        if k == "const":
+            return str(e[1])
+        if k == "rs1":
+            return "od_rs1(%s)" % cx(e[1], part)
+        if k == "neg":
+            return "(-%s)" % cx(e[1], part)
+        if k == "shr":
+            x = e[1]
+            if x[0] == "add" and x[1][0] == "mul" and x[2][0] == "const" and x[1][2][0] == "const":
+                return "od_lift(%s, %d, %d, %d)" % (cx(x[1][1], part), x[1][2][1], x[2][1], e[2][1])
+            return "((%s) >> %s)" % (cx(e[1], part), cx(e[2], part))
+        if k == "add":
+            return "(%s + %s)" % (cx(e[1], part), cx(e[2], part))
+        if k == "sub":
+            return "(%s - %s)" % (cx(e[1], part), cx(e[2], part))
+        if k == "mul":
+            return "(%s*%s)" % (cx(e[1], part), cx(e[2], part))
+        raise ValueError(e)
+
+    out = []
+    stats = []
+    h = n // 2
+    out.append("/* od_idct%d_lift as two independent parts (inputs of one parity each) and a joining stage:\n"
+               "   see tools/extract_lifting.py emit_device_inverse_split.  %d / %d values cross the cut. */"
+               % (n, len(mids[0]), len(mids[1])))
+    out.append("constexpr int kIdct%dMid0 = %d;\nconstexpr int kIdct%dMid1 = %d;" % (n, len(mids[0]), n, len(mids[1])))
+    for part in (0, 1):
+        lines = ["template <typename T> __device__ __forceinline__ void od_idct%d_lift_part%d("
+                 "T (&mid)[%d], const T (&in)[%d]) {" % (n, part, len(mids[part]), h)]
+        cnt = 0
+        for (lhs, rhs), c in zip(ssa, cls):
+            if c == part:
+                lines.append("  const T %s = %s;" % (lhs, strip_parens(cx(rhs, part))))
+                cnt += 1
+        for i, m in enumerate(mids[part]):
+            lines.append("  mid[%d] = %s;" % (i, m))
+        lines.append("}")
+        out.append("\n".join(lines))
+        stats.append(("  idct%d part %d" % (n, part), cnt, len(mids[part]), 0))
+    index = {m: ("m%d[%d]" % (pp, i)) for pp in (0, 1) for i, m in enumerate(mids[pp])}
+    for half in (0, 1):
+        want = set(range(half*h, half*h + h))
+        # backward slice of the join for these outputs
+        live = set()
+        keep = [False]*len(ssa)
+        for idx in range(len(ssa) - 1, -1, -1):
+            lhs, rhs = ssa[idx]
+            if cls[idx] != 2:
+                continue
+            if isinstance(lhs, tuple):
+                if lhs[1] in want:
+                    keep[idx] = True
+                    uses(rhs, live)
+            elif lhs in live:
+                keep[idx] = True
+                uses(rhs, live)
+        lines = ["template <typename T> __device__ __forceinline__ void od_idct%d_lift_join%d("
+                 "T (&out)[%d], const T (&m0)[%d], const T (&m1)[%d]) {" % (n, half, h, len(mids[0]), len(mids[1]))]
+        cnt = 0
+        used_mids = sorted(u for u in live if u in index)
+        for u in used_mids:
+            lines.append("  const T %s = %s;" % (u, index[u]))
+        for idx, ((lhs, rhs), k) in enumerate(zip(ssa, keep)):
+            if not k:
+                continue
+            if isinstance(lhs, tuple):
+                lines.append("  out[%d] = %s;" % (lhs[1] - half*h, strip_parens(cx(rhs, None))))
+            else:
+                lines.append("  const T %s = %s;" % (lhs, strip_parens(cx(rhs, None))))
+                cnt += 1
+        lines.append("}")
+        out.append("\n".join(lines))
+        stats.append(("  idct%d join %d" % (n, half), cnt, len(used_mids), 0))
+        # what this join needs from the OTHER part: indices into that part's mid[] (the lane that ran
+        # part 1 - half exports exactly these to the lane that runs this join)
+        other = 1 - half
+        need = [i for i, m in enumerate(mids[other]) if m in live]
+        out.append("/* join%d reads these entries of part%d's mid[] (the other lane's values that cross the cut) */\n"
+                   "constexpr int kIdct%dNeed%d = %d;\n"
+                   "static constexpr unsigned char kIdct%dNeedIdx%d[%d] = {%s};"
+                   % (half, other, n, half, len(need), n, half, len(need), ", ".join(map(str, need))))
+    return "\n\n".join(out), stats
+
+
 def emit_device(name, n, p):
     lines = []
     lines.append("template <typename T> __device__ __forceinline__ void "
@@ -498,6 +680,10 @@ def main():
                     code, cnt = emit_device_half("od_fdct%d_lift_%s" % (n, tag), n, p, parity)
                     device.append(code)
                     stats.append(("  fdct%d %s half" % (n, tag), cnt, 0, 0))
+            if kind == "idct" and n >= 32:
+                code, st = emit_device_inverse_split(n, p)
+                device.append(code)
+                stats.extend(st)
 
     hdr = (
         "/* GENERATED by tools/extract_lifting.py - do not edit.\n"
