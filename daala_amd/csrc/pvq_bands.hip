@@ -814,8 +814,8 @@ __global__ __launch_bounds__(kWave, (S == 2 ? 2 : 1)) void k_search(Items it) {
    sort by pulse class costs these short bands 3-12 % (measured with the sort keys forced
    equal); the records of a band listed as a close call are written whole, for the resolve.
    Band 3 of the larger blocks (32 coefficients) stays with the sorted two-pass stage. */
-/* N = band size, S = lanes per band (2: the lane pair of pvq_lane.cuh, `half` = lane & 1, each lane
-   holding NL = N/S coefficients in xs). */
+/* N = band size, S = lanes per band (2: the lane pair of pvq_lane.cuh, 4: the quad; `half` = the lane's
+   index in its group, each lane holding NL = N/S coefficients in xs). */
 /* MASK: the lane's LDS column already holds |x| << 16 and the signs come as one bit per coefficient in
    `sg` (a band too long to keep signed in registers across the searches); xs is not read. */
 template <int N, int S = 1, bool MASK = false>
@@ -827,8 +827,8 @@ __device__ __forceinline__ void od_decide_band(const Items &it, int job, const D
   constexpr int NV = (NL + PAD)/8;
   /* a long band's first candidate leaves as it is packed (32 registers not held across the second
      search); a short one waits for the decision */
-  constexpr bool EARLY0 = NL >= 64;
-  static_assert(S == 1 || PAD == 0, "pair mode has no padded band");
+  constexpr bool EARLY0 = NL >= 64 || (S == 4 && NL >= 32);
+  static_assert(S == 1 || PAD == 0, "group mode has no padded band");
   RecHead hd;
   hd.cg = bh.h0.x;
   hd.gain[0] = bh.h0.y;
@@ -898,7 +898,7 @@ __device__ __forceinline__ void od_decide_band(const Items &it, int job, const D
       }
       q[v] = make_int4(o[0], o[1], o[2], o[3]);
     }
-    if (S == 2) mom += od_pair_swap(mom);    /* the two halves of the band */
+    mom = od_grp_add<S>(mom);                /* the parts of the band */
     /* selects, not [c]: dynamically indexed locals live in scratch */
     if (c) {
       yyv[1] = yyc;
@@ -933,10 +933,7 @@ __device__ __forceinline__ void od_decide_band(const Items &it, int job, const D
     res = choose_core<1>(it, job, jb, blk*jb.nb_bands + band, band, hd, dist0, yyv[0], yyv[1], momv[0],
      momv[1], distv[0], distv[1], nullptr);
   }
-  if (S == 2) {
-    const int other = od_pair_swap(res);
-    if (half) res = other;
-  }
+  if constexpr (S > 1) res = od_grp_bcast<S, 0>(res);      /* decided by lane 0 of the group */
   if (!live) return;
   /* sel | close << 1: the chosen candidate's pulses; both, and the whole record, for a close call */
   if constexpr (!EARLY0) {
@@ -1192,6 +1189,83 @@ __global__ __launch_bounds__(kWave, 2) void k_decide_pair128(Items it) {
   od_decide_band<128, 2, true>(it, job, jb, band, bp.blk, bp.live, od_band_head(jb.beta[band], 128, cg), nullptr, pk,
    rsq, lane, half, sg);
 }
+
+#ifdef ODHIP_EXPERIMENTS
+/* The 128-coefficient bands on a QUAD of lanes per band (round 5; k_decide_pair128 above is the pair form it
+   was measured against, experiments build only): 32 coding positions per lane, 8 KiB of LDS columns per wavefront instead
+   of 16.  The pair form held two wavefronts per SIMD (20 KiB each) and ran at 0.67 of VALU issue: its
+   argmax scans are chains of dependent selects, and two wavefronts do not cover a dependency chain
+   (the same effect the 64x64 transforms showed at 2.25 wavefronts per SIMD).  Same bands
+   in flight per CU, twice the wavefronts, every scan half as long; the 64 gathers per lane become 32 and
+   the raw coefficients held until the band's shift is known 32 registers instead of 64. */
+__global__ __launch_bounds__(kWave, 3) void k_decide_quad128(Items it) {
+  constexpr int NL = 32;
+  extern __shared__ __attribute__((aligned(16))) double lds_d[];
+  double *rsq = lds_d;                                   /* [kRsqN]  */
+  uint32_t *pk = (uint32_t *)(rsq + kRsqN);              /* [32][64] */
+  const int lane = threadIdx.x;
+  {
+    double r[kRsqN/kWave];
+#pragma unroll
+    for (int i = 0; i < kRsqN/kWave; i++) r[i] = gRsqTable[i*kWave + lane];
+#pragma unroll
+    for (int i = 0; i < kRsqN/kWave; i++) rsq[i*kWave + lane] = r[i];
+  }
+  const int item = find_item(it, blockIdx.x);
+  const int job = it.job[item];
+  const DJob &jb = it.jobs[job];
+  const int band = it.band[item];
+  const int sub = lane & 3;
+  const int off = jb.off[band];
+  const BlockPos bp = locate(jb, (long)(blockIdx.x - it.wg_start[item])*(kWave/4) + (lane >> 2));
+  const int w = jb.w;
+  const int16_t *const qmp = jb.qm + off + sub*NL;
+  int v[NL];
+  int sum = 0;
+#pragma unroll
+  for (int j = 0; j < NL; j++) {
+    /* the scan positions of the four parts are wave-uniform (scalar loads), the lane takes its own */
+    const int xa = kScanXY[off + j][0];
+    const int ya = kScanXY[off + j][1];
+    const int xb = kScanXY[off + NL + j][0];
+    const int yb = kScanXY[off + NL + j][1];
+    const int xc = kScanXY[off + 2*NL + j][0];
+    const int yc = kScanXY[off + 2*NL + j][1];
+    const int xd = kScanXY[off + 3*NL + j][0];
+    const int yd = kScanXY[off + 3*NL + j][1];
+    const int oa = ya*w + xa;
+    const int ob = yb*w + xb;
+    const int oc = yc*w + xc;
+    const int od = yd*w + xd;
+    v[j] = bp.src[sub == 0 ? oa : sub == 1 ? ob : sub == 2 ? oc : od];
+  }
+  __syncthreads();   /* the 1/sqrt table */
+#pragma unroll
+  for (int j = 0; j < NL; j++) {
+    const int t = (int16_t)(v[j] >> 8);
+    sum += t*t;
+  }
+  sum = od_grp_add<4>(sum);
+  int xshift = 8 + 1 + odq_ilog(4*NL + sum)/2 - 15;
+  xshift = xshift > 0 ? xshift : 0;
+  unsigned long long sg = 0;
+  int acc = 0;
+#pragma unroll
+  for (int j = 0; j < NL; j++) {
+    const int x = (int16_t)odq_shr_round(v[j]*qmp[j], ODQ_QM_SHIFT + xshift);
+    acc += x*x;
+    sg |= (unsigned long long)(x < 0) << j;
+    pk[j*kWave + lane] = (uint32_t)abs(x) << 16;
+  }
+  acc = od_grp_add<4>(acc);
+  const int qb = bp.blk >= jb.split_blk ? jb.q2[band] : jb.q[band];
+  int32_t g;
+  const int32_t cg = odq_gain_from_acc(acc, qb, jb.beta[band], xshift, &g);
+  od_decide_band<128, 4, true>(it, job, jb, band, bp.blk, bp.live, od_band_head(jb.beta[band], 128, cg), nullptr, pk,
+   rsq, lane, sub, sg);
+}
+
+#endif
 
 /* ---- choice: one (block, band) per lane --------------------------------------
    The comparison `cost <= best_cost` of src/pvq_encoder.c:597-609 with
@@ -1979,17 +2053,32 @@ int noref_bands(const odhip_pvq_job *jobs, int njobs, double pvq_norm_lambda, od
        vectors or records in memory.  Four independent launches. */
     constexpr size_t lane_lds = kRsqN*sizeof(double) + (size_t)16*kPitch*4;
     constexpr size_t pair_lds = kRsqN*sizeof(double) + (size_t)64*kPitch*4;
+    /* the 128-coefficient bands: a lane pair per band.  Round 5 measured a QUAD per band
+       (k_decide_quad128: half the LDS per wavefront, three wavefronts per SIMD instead of two, every scan
+       half as long) at 586 us against 550-568 for the pair on the same content: what the pair form lacks
+       is not occupancy, and the quad pays a two-level combine per pulse.  The quad stays in the experiments
+       build (ODHIP_PVQ_QUAD128=1), bit-identical. */
+    const bool pair128 = ODHIP_EXP_ENV("ODHIP_PVQ_QUAD128") == nullptr;
+    const int per_wg = pair128 ? kWave/2 : kWave/4;
     items_begin(it, st, lambda);
     it.fuse = 1;
     for (int j = 0; j < njobs; j++) {
       for (int b = 0; b < host[j].nb_bands; b++) {
-        if (host[j].off[b + 1] - host[j].off[b] == 128) items_add(it, j, b, (host[j].nblocks + kWave/2 - 1)/(kWave/2));
+        if (host[j].off[b + 1] - host[j].off[b] == 128) items_add(it, j, b, (host[j].nblocks + per_wg - 1)/per_wg);
       }
     }
     const bool prof = st.prof_on && st.prof_n < kProfSlots;
     if (prof) (void)hipEventRecord(st.prof_ev[st.prof_n][0], s);
     items_heavy_first(it);
-    if (it.nitems) k_decide_pair128<<<it.wg_start[it.nitems], kWave, pair_lds, s>>>(it);
+    if (it.nitems) {
+      if (pair128) k_decide_pair128<<<it.wg_start[it.nitems], kWave, pair_lds, s>>>(it);
+#ifdef ODHIP_EXPERIMENTS
+      else {
+        constexpr size_t quad_lds = kRsqN*sizeof(double) + (size_t)32*kPitch*4;
+        k_decide_quad128<<<it.wg_start[it.nitems], kWave, quad_lds, s>>>(it);
+      }
+#endif
+    }
     if (prof) (void)hipEventRecord(st.prof_ev[st.prof_n++][1], s);
     items_begin(it, st, lambda);
     it.fuse = 1;

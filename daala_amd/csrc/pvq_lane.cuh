@@ -82,6 +82,62 @@ __device__ __forceinline__ unsigned long long od_pair_swap(unsigned long long v)
   return (unsigned long long)hi << 32 | lo;
 }
 
+/* GROUP MODE in general (S = 2 or 4 lanes per band; round 5 added the quad): lane `sub` = lane % S of the
+   group holds coding positions sub*N .. sub*N + N - 1.  Four lanes per 128-coefficient band halve the
+   LDS of a wavefront again (8 KiB of columns): twice the wavefronts per SIMD for the same bands in
+   flight, each lane's argmax chain half as long - the pair form ran at 2 wavefronts per SIMD and 0.67 of
+   VALU issue, a dependency-latency bound. */
+__device__ __forceinline__ int od_quad_swap2(int v) {
+  return row_mov<OD_DPP_XOR2>(v);
+}
+__device__ __forceinline__ unsigned od_quad_swap2(unsigned v) {
+  return (unsigned)row_mov<OD_DPP_XOR2>((int)v);
+}
+__device__ __forceinline__ double od_quad_swap2(double v) {
+  return row_mov<OD_DPP_XOR2>(v);
+}
+__device__ __forceinline__ unsigned long long od_quad_swap2(unsigned long long v) {
+  const unsigned lo = od_quad_swap2((unsigned)v);
+  const unsigned hi = od_quad_swap2((unsigned)(v >> 32));
+  return (unsigned long long)hi << 32 | lo;
+}
+/* sum / maximum / bitwise or over the S lanes of a group, in every lane of it */
+template <int S, typename V>
+__device__ __forceinline__ V od_grp_add(V v) {
+  if (S >= 2) v += od_pair_swap(v);
+  if (S >= 4) v += od_quad_swap2(v);
+  return v;
+}
+template <int S>
+__device__ __forceinline__ unsigned od_grp_umax(unsigned v) {
+  if (S >= 2) {
+    const unsigned o = od_pair_swap(v);
+    v = o > v ? o : v;
+  }
+  if (S >= 4) {
+    const unsigned o = od_quad_swap2(v);
+    v = o > v ? o : v;
+  }
+  return v;
+}
+template <int S>
+__device__ __forceinline__ uint32_t od_grp_or(uint32_t v) {
+  if (S >= 2) v |= od_pair_swap(v);
+  if (S >= 4) v |= od_quad_swap2(v);
+  return v;
+}
+/* the value of lane Q of every group of S lanes, in all of its lanes: quad_perm [Q,Q,Q,Q] for a quad,
+   [0,0,2,2] / [1,1,3,3] for the two pairs of a quad */
+template <int S, int Q>
+__device__ __forceinline__ int od_grp_bcast(int v) {
+  static_assert((S == 4 && Q < 4) || (S == 2 && Q < 2), "a lane of the group");
+  return row_mov<(S == 4 ? Q*0x55 : Q == 0 ? 0xA0 : 0xF5)>(v);
+}
+template <int S, int Q>
+__device__ __forceinline__ double od_grp_bcast(double v) {
+  return row_mov<(S == 4 ? Q*0x55 : Q == 0 ? 0xA0 : 0xF5)>(v);
+}
+
 /* Per-band constants: xx, 2/sqrt(1e-30 + xx), 1/max(L1, 1e-100)
    (src/pvq_encoder.c:118-125,:139-141). */
 template <int N, int S>
@@ -96,12 +152,9 @@ __device__ __forceinline__ void od_lane_prepare(LaneSearch &s, const uint32_t *p
     l1 += ax;
     xmax = ax > xmax ? ax : xmax;
   }
-  if (S == 2) {
-    xx += od_pair_swap(xx);
-    l1 += od_pair_swap(l1);
-    const unsigned o = od_pair_swap(xmax);
-    xmax = o > xmax ? o : xmax;
-  }
+  xx = od_grp_add<S>(xx);
+  l1 = od_grp_add<S>(l1);
+  xmax = od_grp_umax<S>(xmax);
   s.xx = (double)xx;
   s.norm2 = 2*__ddiv_rn(1., __dsqrt_rn(1e-30 + s.xx));
   const double l1d = (double)l1;
@@ -319,7 +372,8 @@ __device__ __forceinline__ double od_lane_search(LaneSearch &s, uint32_t *pk, co
  int lane, int half, bool on, bool fresh, int k, double g2, double pvq_norm_lambda,
  bool force_seq) {
   constexpr int NBAND = N*S;
-  const int jbase = S == 2 ? half*N : 0;
+  static_assert(S == 1 || S == 2 || S == 4, "one lane, a pair or a quad per band");
+  const int jbase = S > 1 ? half*N : 0;       /* `half` = the lane's index in its group */
   fresh = fresh && on;
   if (__any(fresh)) {
     /* src/pvq_encoder.c:139-153; k <= 2 starts from zero, which is the same
@@ -339,11 +393,9 @@ __device__ __forceinline__ double od_lane_search(LaneSearch &s, uint32_t *pk, co
       yy += (unsigned)yj*(unsigned)yj;
       i += yj;
     }
-    if (S == 2) {
-      xy += od_pair_swap(xy);
-      yy += od_pair_swap(yy);
-      i += od_pair_swap(i);
-    }
+    xy = od_grp_add<S>(xy);
+    yy = od_grp_add<S>(yy);
+    i = od_grp_add<S>(i);
     if (fresh) {
       s.xy = xy;
       s.yy = yy;
@@ -358,52 +410,98 @@ __device__ __forceinline__ double od_lane_search(LaneSearch &s, uint32_t *pk, co
     double ba;
     double bb;
     int pos = od_lane_greedy_scan<N>(pk, lane, s.xy, s.yy + 1, jbase, ba, bb);
-    if (S == 2) {
-      /* lower (A) and upper (B) half's best, the same in both lanes */
-      const double oa = od_pair_swap(ba);
-      const double ob = od_pair_swap(bb);
-      const int op = od_pair_swap(pos);
-      const double aa = half ? oa : ba;
-      const double ab = half ? ob : bb;
-      const int ap = half ? op : pos;
-      double xa = half ? ba : oa;
-      double xb = half ? bb : ob;
-      int xp = half ? pos : op;
+    if constexpr (S > 1) {
       const double tmax = (double)(s.xy + s.xmax);
       const bool exact = !force_seq
        && (tmax*tmax)*(double)(s.yy + 2*(unsigned)k + 1) < 4503599627370496.;   /* 2^52: a factor 2 of margin for the bound's own rounding */
       if (__any(step && !exact)) {
-        /* sequential: the upper lane rescans from the lower half's best */
-        double ra = aa;
-        double rb = ab;
-        int rp = ap;
+        /* sequential: lane q of the group rescans its part starting from the result of lanes 0..q-1
+           (lane 0's own scan IS the start of the sequential scan) */
+        double ra = od_grp_bcast<S, 0>(ba);
+        double rb = od_grp_bcast<S, 0>(bb);
+        int rp = od_grp_bcast<S, 0>(pos);
+        auto rescan = [&](double &xa, double &xb, int &xp) {
 #pragma unroll 1
-        for (int j = 0; j < N; j++) {
-          const uint32_t w = pk[j*kPitch + lane];
-          const double tt = (double)(s.xy + (w >> 16));
-          const double a = tt*tt;
-          const double b = (double)(s.yy + 1 + (w & 0xffffu));
-          if (a*rb > ra*b) {
-            ra = a;
-            rb = b;
-            rp = jbase + j;
+          for (int j = 0; j < N; j++) {
+            const uint32_t w = pk[j*kPitch + lane];
+            const double tt = (double)(s.xy + (w >> 16));
+            const double a = tt*tt;
+            const double b = (double)(s.yy + 1 + (w & 0xffffu));
+            if (a*xb > xa*b) {
+              xa = a;
+              xb = b;
+              xp = jbase + j;
+            }
           }
+        };
+        {
+          double ta = ra;
+          double tb = rb;
+          int tp = rp;
+          rescan(ta, tb, tp);                    /* valid in lane 1 */
+          ra = od_grp_bcast<S, 1>(ta);
+          rb = od_grp_bcast<S, 1>(tb);
+          rp = od_grp_bcast<S, 1>(tp);
         }
-        /* valid in the upper lane; hand it to the lower one */
-        const int up = od_pair_swap(rp);
-        pos = half ? rp : up;
+        if constexpr (S == 4) {
+          double ta = ra;
+          double tb = rb;
+          int tp = rp;
+          rescan(ta, tb, tp);                    /* valid in lane 2 */
+          ra = od_grp_bcast<4, 2>(ta);
+          rb = od_grp_bcast<4, 2>(tb);
+          rp = od_grp_bcast<4, 2>(tp);
+          ta = ra;
+          tb = rb;
+          tp = rp;
+          rescan(ta, tb, tp);                    /* valid in lane 3 */
+          rp = od_grp_bcast<4, 3>(tp);
+        }
+        pos = rp;
       }
-      else pos = xa*ab > aa*xb ? xp : ap;
+      else {
+        /* exact regime: the comparison is the exact order of the rationals, so a tournament in which
+           the part with the HIGHER positions wins only when strictly greater is the sequential scan */
+        {
+          const double oa = od_pair_swap(ba);
+          const double ob = od_pair_swap(bb);
+          const int op = od_pair_swap(pos);
+          const bool up = (half & 1) != 0;
+          const double la = up ? oa : ba;      /* lower positions */
+          const double lb = up ? ob : bb;
+          const int lp = up ? op : pos;
+          const double xa = up ? ba : oa;      /* upper positions */
+          const double xb = up ? bb : ob;
+          const int xp = up ? pos : op;
+          const bool win = xa*lb > la*xb;
+          ba = win ? xa : la;
+          bb = win ? xb : lb;
+          pos = win ? xp : lp;
+        }
+        if constexpr (S == 4) {
+          const double oa = od_quad_swap2(ba);
+          const double ob = od_quad_swap2(bb);
+          const int op = od_quad_swap2(pos);
+          const bool up = (half & 2) != 0;
+          const double la = up ? oa : ba;
+          const double lb = up ? ob : bb;
+          const int lp = up ? op : pos;
+          const double xa = up ? ba : oa;
+          const double xb = up ? bb : ob;
+          const int xp = up ? pos : op;
+          pos = xa*lb > la*xb ? xp : lp;
+        }
+      }
     }
     int owner = 1;
     int local = pos;
-    if (S == 2) {
-      owner = (pos >= N) == (half != 0);
+    if constexpr (S > 1) {
+      owner = pos/N == half;
       local = pos - jbase;
     }
     uint32_t w = 0;
     if (step && owner) w = pk[local*kPitch + lane];
-    if (S == 2) w |= od_pair_swap(w);
+    w = od_grp_or<S>(w);
     if (step) {
       s.xy += w >> 16;
       s.yy += (w & 0xffffu) + 1;
@@ -462,24 +560,41 @@ __device__ __forceinline__ double od_lane_search(LaneSearch &s, uint32_t *pk, co
         }
       }
     }
-    if (S == 2) {
-      const double ob = od_pair_swap(best);
-      const int op = od_pair_swap(pos);
-      const double va = half ? ob : best;   /* lower half */
-      const double vb = half ? best : ob;   /* upper half */
-      const int pa = half ? op : pos;
-      const int pb = half ? pos : op;
-      pos = vb > va ? pb : pa;
+    if constexpr (S > 1) {
+      /* (max cost, lowest position): a total order - a tournament in which the higher positions win
+         only when strictly greater */
+      {
+        const double ob = od_pair_swap(best);
+        const int op = od_pair_swap(pos);
+        const bool up = (half & 1) != 0;
+        const double va = up ? ob : best;   /* lower positions */
+        const double vb = up ? best : ob;   /* upper positions */
+        const int pa = up ? op : pos;
+        const int pb = up ? pos : op;
+        const bool win = vb > va;
+        best = win ? vb : va;
+        pos = win ? pb : pa;
+      }
+      if constexpr (S == 4) {
+        const double ob = od_quad_swap2(best);
+        const int op = od_quad_swap2(pos);
+        const bool up = (half & 2) != 0;
+        const double va = up ? ob : best;
+        const double vb = up ? best : ob;
+        const int pa = up ? op : pos;
+        const int pb = up ? pos : op;
+        pos = vb > va ? pb : pa;
+      }
     }
     int owner = 1;
     int local = pos;
-    if (S == 2) {
-      owner = (pos >= N) == (half != 0);
+    if constexpr (S > 1) {
+      owner = pos/N == half;
       local = pos - jbase;
     }
     uint32_t w = 0;
     if (step && owner) w = pk[local*kPitch + lane];
-    if (S == 2) w |= od_pair_swap(w);
+    w = od_grp_or<S>(w);
     if (step) {
       s.xy += w >> 16;
       s.yy += (w & 0xffffu) + 1;
