@@ -76,6 +76,15 @@ def main():
         print("%s executed (round 4, walking kernels + top2 + edges): %.1f M wave-instructions per step = %.1f per "
               "pixel of the plane (%.1f per pixel and level); minimum %.1f -> %.2fx the minimum" % (
                   k, valu / 1e6, per_px, per_px / nlev, mins[k], per_px / mins[k]))
+    # round 5 (profiles/r5_pmc_traffic.json): 4x4 leaves in registers, 24-bit multiplies, loads one group ahead.
+    # The luma walker executes MORE instructions than round 4's (the prefetch recomputes its block indices in
+    # three places, OD_MULT16_32_Q16 became three full-rate instructions instead of one quarter-rate one) and is
+    # faster: profiles/r5_inverse_phases.txt - the stage does not follow its instruction count.
+    r5 = {"luma": (85.3e6 + 48.2e6 + 1.23e6 + 2.35e6, px_luma, 5), "chroma": (65.6e6 + 17.6e6 + 0.50e6 + 2.94e6, px_chroma, 4)}
+    for k, (valu, px, nlev) in r5.items():
+        per_px = valu * 64 / px
+        print("%s executed (round 5): %.1f M wave-instructions per step = %.1f per pixel of the plane (%.1f per pixel "
+              "and level) -> %.2fx the minimum" % (k, valu / 1e6, per_px, per_px / nlev, per_px / mins[k]))
     r3 = {"luma": 84.1e6 + 54.2e6 + 3.69e6 + 2.35e6, "chroma": 100.4e6 + 3.48e6 + 2.94e6}
     for k, valu in r3.items():
         per_px = valu * 64 / ex[k][1]

@@ -117,6 +117,39 @@ def main():
     print("%-28s %-6s %-28s %s" % ("kernel", "N/lane", "pulse loop (VALU per candidate)", "fraction of the minimum"))
     for pat, src, n, what in KERNELS:
         ls = loops(asm[src], pat)
+        if "lean_row" in pat:
+            # round 5: the greedy loop of the row searches is single precision (one v_rcp_f32 per pulse, no
+            # double-precision arithmetic outside the replay), the tail loop holds two table-lookup variants of which
+            # one executes: identified by what they contain, counted per executed variant
+            start = next(i for i, l in enumerate(asm[src]) if pat in l and re.match(r"^_Z\S+:", l))
+            end = next(i for i in range(start, len(asm[src])) if ".amdhsa_kernel" in asm[src][i] or asm[src][i].startswith(".Lfunc_end"))
+            insts = [t.split(";")[0].strip() for t in (l.strip() for l in asm[src][start:end])
+                     if t and not t.startswith(";") and not t.startswith(".") and not re.match(r"^\.LBB\d+_\d+:", t)]
+            cands = []
+            for a, b, c in ls:
+                body = insts[a:b + 1]
+                nrcp = sum(1 for x in body if x.startswith("v_rcp_f32"))
+                nf32 = sum(1 for x in body if re.match(r"v_(mul|add|fma|cvt)_f32", x) or x.startswith("v_cmp_") and "f32" in x)
+                valu = c["f64"] + c["sel"] + c["valu"]
+                if nrcp >= 1 and nf32 >= 3*n and valu < 40*n:
+                    cands.append((a, b, c, valu))
+            # several back edges close one source loop: keep the OUTERMOST range of every nest
+            outer = [x for x in cands if not any(y[0] <= x[0] and y[1] >= x[1] and (y[0], y[1]) != (x[0], x[1]) for y in cands)]
+            for a, b, c, valu in outer:
+                # the literal double-precision replay inside it (#pragma unroll 1) runs only on a failed screen:
+                # the inner loops without a v_rcp_f32, one per start address (its largest extent)
+                inner = {}
+                for x in ls:
+                    if x[0] > a and x[1] < b and not any(t.startswith("v_rcp_f32") for t in insts[x[0]:x[1] + 1]):
+                        if x[0] not in inner or x[1] > inner[x[0]][1]:
+                            inner[x[0]] = x
+                rep = sum(x[2]["f64"] + x[2]["sel"] + x[2]["valu"] for x in inner.values())
+                per = (valu - rep)/float(n)
+                print("%-28s %-6d %-28s %.2f" % (pat.replace("ILi", "<").replace("ELi", ",").rstrip("E"), n,
+                      "greedy, f32 screen: %.1f (+ %.1f in the replay path; f64 %.1f, select %.1f)" % (
+                          per, rep/float(n), c["f64"]/n, c["sel"]/n), MIN_GREEDY/per))
+            print("    %s" % what)
+            continue
         # innermost pulse loops: bodies with at least 3 fp64 operations per candidate and no larger loop inside
         cand = []
         for a, b, c in ls:
