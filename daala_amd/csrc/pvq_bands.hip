@@ -110,6 +110,16 @@ struct Items {
    their table into LDS first - a constant-memory access with 64 different
    addresses serialises. */
 __constant__ unsigned char kScanXY[OD_SCAN_LEN][2];
+/* Round 5, k_decide_pair128's staged load.  A 128-coefficient band (coding positions 128..255, 256..383 or
+   384..511) covers a region of its block that consists of 32 aligned 4-coefficient row segments: kSeg128[g][q] =
+   y << 8 | x of segment q of geometry g = off/128 - 1, in raster order; kSlot128[g][p] = where coding position
+   off + p sits in that staged order (segment*4 + element). */
+__constant__ unsigned short kSeg128[3][32];
+__constant__ unsigned char kSlot128[3][128];
+/* ... and the 32-coefficient bands (coding positions 32..63, 64..95, 96..127; k_decide_lane32): 16 aligned
+   2-coefficient segments (band 3 of an 8x8 block starts at x = 2 in its rows 4..7), geometry off/32 - 1. */
+__constant__ unsigned short kSeg32[3][16];
+__constant__ unsigned char kSlot32[3][32];
 __device__ __attribute__((aligned(16))) unsigned short gScanXY[OD_SCAN_LEN];  /* y << 8 | x */
 __device__ short gInvScan[32*32];                /* raster (y*32 + x) -> coding index, -1 */
 __device__ unsigned char gBandOf[OD_SCAN_LEN];
@@ -1091,15 +1101,32 @@ __global__ __launch_bounds__(kWave) void k_decide_lane32(Items it) {
   const int16_t *const qmp = jb.qm + off + half*NL;
   int v[NL];
   int qm[NL];
+  /* Round 5 (as k_decide_pair128): the band's 32 coefficients come in as 16 aligned 8-byte row segments, 8 per
+     lane of the pair, are parked in the pair's two LDS columns and picked out in coding order (kSlot32). */
+  {
+    const int geo = (off >> 5) - 1;
+    int2 raw[8];
 #pragma unroll
-  for (int j = 0; j < NL; j++) {
-    /* the scan positions of both halves are wave-uniform (scalar loads), the lane takes its own */
-    const int x0 = kScanXY[off + j][0];
-    const int y0 = kScanXY[off + j][1];
-    const int x1 = kScanXY[off + NL + j][0];
-    const int y1 = kScanXY[off + NL + j][1];
-    v[j] = bp.src[(half ? y1 : y0)*w + (half ? x1 : x0)];
-    qm[j] = qmp[j];
+    for (int i = 0; i < 8; i++) {
+      const int s0 = kSeg32[geo][i];
+      const int s1 = kSeg32[geo][8 + i];
+      const int sg_ = half ? s1 : s0;
+      raw[i] = *reinterpret_cast<const int2 *>(bp.src + (sg_ >> 8)*w + (sg_ & 255));
+    }
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      pk[(2*i)*kWave + lane] = (uint32_t)raw[i].x;
+      pk[(2*i + 1)*kWave + lane] = (uint32_t)raw[i].y;
+    }
+    const int pair0 = lane & ~1;
+#pragma unroll
+    for (int j = 0; j < NL; j++) {
+      const int t0 = kSlot32[geo][j];
+      const int t1 = kSlot32[geo][NL + j];
+      const int sl = half ? t1 : t0;
+      v[j] = (int)pk[(sl & 15)*kWave + pair0 + (sl >> 4)];
+      qm[j] = qmp[j];
+    }
   }
   __syncthreads();   /* the 1/sqrt table */
   int sum = 0;
@@ -1155,14 +1182,37 @@ __global__ __launch_bounds__(kWave, 2) void k_decide_pair128(Items it) {
   const int16_t *const qmp = jb.qm + off + half*NL;
   int v[NL];
   int sum = 0;
+  /* Round 5: the band's 128 coefficients come in as 32 aligned 16-byte row segments, 16 per lane of the pair
+     (whole sectors, every byte fetched is used; the 64 four-byte gathers per lane this replaces touched a
+     different 64-byte line per lane and instruction: 951 MB of HBM traffic per launch for 198 MB of
+     coefficients, profiles/r4_pmc_traffic.json), are parked in the pair's two LDS columns in that staged order
+     (the column is free until the scaled vector is written below), and each lane picks its 64 coding positions
+     out of them (kSlot128; both lanes of a pair are in one wavefront: no barrier). */
+  {
+    const int geo = (off >> 7) - 1;
+    int4 raw[16];
 #pragma unroll
-  for (int j = 0; j < NL; j++) {
-    /* the scan positions of both halves are wave-uniform (scalar loads), the lane takes its own */
-    const int x0 = kScanXY[off + j][0];
-    const int y0 = kScanXY[off + j][1];
-    const int x1 = kScanXY[off + NL + j][0];
-    const int y1 = kScanXY[off + NL + j][1];
-    v[j] = bp.src[(half ? y1 : y0)*w + (half ? x1 : x0)];
+    for (int i = 0; i < 16; i++) {
+      const int s0 = kSeg128[geo][i];
+      const int s1 = kSeg128[geo][16 + i];
+      const int sg_ = half ? s1 : s0;
+      raw[i] = *reinterpret_cast<const int4 *>(bp.src + (sg_ >> 8)*w + (sg_ & 255));
+    }
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+      pk[(4*i)*kWave + lane] = (uint32_t)raw[i].x;
+      pk[(4*i + 1)*kWave + lane] = (uint32_t)raw[i].y;
+      pk[(4*i + 2)*kWave + lane] = (uint32_t)raw[i].z;
+      pk[(4*i + 3)*kWave + lane] = (uint32_t)raw[i].w;
+    }
+    const int pair0 = lane & ~1;
+#pragma unroll
+    for (int j = 0; j < NL; j++) {
+      const int t0 = kSlot128[geo][j];
+      const int t1 = kSlot128[geo][NL + j];
+      const int sl = half ? t1 : t0;
+      v[j] = (int)pk[(sl & 63)*kWave + pair0 + (sl >> 6)];
+    }
   }
   __syncthreads();   /* the 1/sqrt table */
 #pragma unroll
@@ -1641,6 +1691,59 @@ int upload_tables_now(void) {
   unsigned short packed[OD_SCAN_LEN];
   for (int j = 0; j < OD_SCAN_LEN; j++) packed[j] = (unsigned short)(OD_SCAN_XY[j][1] << 8 | OD_SCAN_XY[j][0]);
   ODHIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(kScanXY), OD_SCAN_XY, sizeof(OD_SCAN_XY)));
+  {
+    unsigned short seg[3][32];
+    unsigned char slot[3][128];
+    for (int g = 0; g < 3; g++) {
+      const int off = 128*(g + 1);
+      /* the distinct (y, x / 4) groups of the band's positions, in raster order */
+      int n = 0;
+      for (int y = 0; y < 32; y++) {
+        for (int x4 = 0; x4 < 8; x4++) {
+          int cnt = 0;
+          for (int p = 0; p < 128; p++) cnt += OD_SCAN_XY[off + p][1] == y && OD_SCAN_XY[off + p][0]/4 == x4;
+          if (cnt == 0) continue;
+          if (cnt != 4 || n >= 32) return ODHIP_EFAULT;     /* the region is made of whole aligned segments */
+          seg[g][n++] = (unsigned short)(y << 8 | 4*x4);
+        }
+      }
+      if (n != 32) return ODHIP_EFAULT;
+      for (int p = 0; p < 128; p++) {
+        const int key = OD_SCAN_XY[off + p][1] << 8 | (OD_SCAN_XY[off + p][0] & ~3);
+        int q = 0;
+        while (seg[g][q] != key) q++;
+        slot[g][p] = (unsigned char)(4*q + (OD_SCAN_XY[off + p][0] & 3));
+      }
+    }
+    ODHIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(kSeg128), seg, sizeof(seg)));
+    ODHIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(kSlot128), slot, sizeof(slot)));
+  }
+  {
+    unsigned short seg[3][16];
+    unsigned char slot[3][32];
+    for (int g = 0; g < 3; g++) {
+      const int off = 32*(g + 1);
+      int n = 0;
+      for (int y = 0; y < 16; y++) {
+        for (int x2 = 0; x2 < 8; x2++) {
+          int cnt = 0;
+          for (int p = 0; p < 32; p++) cnt += OD_SCAN_XY[off + p][1] == y && OD_SCAN_XY[off + p][0]/2 == x2;
+          if (cnt == 0) continue;
+          if (cnt != 2 || n >= 16) return ODHIP_EFAULT;
+          seg[g][n++] = (unsigned short)(y << 8 | 2*x2);
+        }
+      }
+      if (n != 16) return ODHIP_EFAULT;
+      for (int p = 0; p < 32; p++) {
+        const int key = OD_SCAN_XY[off + p][1] << 8 | (OD_SCAN_XY[off + p][0] & ~1);
+        int q = 0;
+        while (seg[g][q] != key) q++;
+        slot[g][p] = (unsigned char)(2*q + (OD_SCAN_XY[off + p][0] & 1));
+      }
+    }
+    ODHIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(kSeg32), seg, sizeof(seg)));
+    ODHIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(kSlot32), slot, sizeof(slot)));
+  }
   ODHIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(gScanXY), packed, sizeof(packed)));
   ODHIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(gInvScan), inv, sizeof(inv)));
   ODHIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(gBandOf), band_of, sizeof(band_of)));
