@@ -39,6 +39,7 @@
 #include "od_ctx.cuh"
 #include "od_pvq_math.cuh"
 #include "gen/od_scan_tables.h"
+#define OD_RSQ_HUGE
 #include "pvq_search.cuh"
 #include "pvq_lane.cuh"
 
@@ -1748,6 +1749,7 @@ int upload_tables_now(void) {
   ODHIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(gInvScan), inv, sizeof(inv)));
   ODHIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(gBandOf), band_of, sizeof(band_of)));
   k_rsq_fill<<<1, kRsqN, 0, 0>>>();
+  od_rsqrt_huge_fill_launch();
   k_nrate_fill<8><<<(NRateTab<8>::SIZE + 255)/256, 256, 0, 0>>>();
   k_nrate_fill<15><<<(NRateTab<15>::SIZE + 255)/256, 256, 0, 0>>>();
   k_nrate_fill<32><<<(NRateTab<32>::SIZE + 255)/256, 256, 0, 0>>>();

@@ -551,7 +551,7 @@ __device__ __forceinline__ double od_lane_search(LaneSearch &s, uint32_t *pk, co
         const unsigned idx = s.yy + (w & 0xffffu) + 1;
         double r;
         if (step && idx <= (unsigned)kRsqN) r = rsq[idx - 1];
-        else r = __ddiv_rn(1., __dsqrt_rn((double)idx));
+        else r = od_rsqrt_beyond((int)(idx ? idx : 1));      /* (idx >= 1; a lane that does not step computes nothing used) */
         const int jg = jbase + j;
         const double val = (t*s.norm2)*r - (lambda*jg)*(delta_rate + jg*accel_rate);
         if (j == 0 || val > best) {

@@ -45,6 +45,7 @@
 #include "od_pvq_math.cuh"
 #include "gen/od_scan_tables.h"
 #define OD_RSQ_TABLE_N 512
+#define OD_RSQ_HUGE
 #include "pvq_search.cuh"
 #include "pvq_row.cuh"
 #include "pvq_regs.cuh"
@@ -2490,6 +2491,7 @@ int upload_tables_now(void) {
   }
   ODHIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(gRBandOf), band_of, sizeof(band_of)));
   od_rsqrt_fill_launch();
+  od_rsqrt_huge_fill_launch();
   k_rate_fill<8><<<(RateTab<8>::SIZE + 255)/256, 256, 0, 0>>>();
   k_rate_fill<15><<<(RateTab<15>::SIZE + 255)/256, 256, 0, 0>>>();
   k_rate_fill<32><<<(RateTab<32>::SIZE + 255)/256, 256, 0, 0>>>();

@@ -63,9 +63,36 @@ __device__ __forceinline__ void od_rsqrt_init(int tid) {
 }
 #endif
 
+/* Beyond the LDS table (bands that place tens of pulses: fine quantisers, band 0 of the large blocks): the same
+   correctly rounded values from a table in global memory (512 KB, cache resident; filled once per device by the
+   expression it replaces), an fp64 square root and division - ~40 instructions - only beyond THAT (round 5:
+   `quality_sweep` at -v 5). */
+#ifdef OD_RSQ_HUGE      /* defined by the translation units that fill the table in their per-device set-up */
+constexpr int kRsqHugeN = 65536;
+__device__ double gRsqHuge[kRsqHugeN];
+
+__global__ void k_rsq_huge_fill(void) {
+  const int i = blockIdx.x*blockDim.x + threadIdx.x;
+  if (i < kRsqHugeN) gRsqHuge[i] = i < 16 ? kRsqrtTable[i] : __ddiv_rn(1., __dsqrt_rn((double)(i + 1)));
+}
+
+static inline void od_rsqrt_huge_fill_launch(void) {
+  k_rsq_huge_fill<<<(kRsqHugeN + 255)/256, 256, 0, 0>>>();
+}
+
+__device__ __forceinline__ double od_rsqrt_beyond(int i) {
+  if (i <= kRsqHugeN) return gRsqHuge[i - 1];
+  return __ddiv_rn(1., __dsqrt_rn((double)i));
+}
+#else
+__device__ __forceinline__ double od_rsqrt_beyond(int i) {
+  return __ddiv_rn(1., __dsqrt_rn((double)i));
+}
+#endif
+
 __device__ __forceinline__ double od_rsqrt_table(int i) {
   if (i <= OD_RSQ_TABLE_N) return od_rsq_lds[i - 1];
-  return __ddiv_rn(1., __dsqrt_rn((double)i));
+  return od_rsqrt_beyond(i);
 }
 
 #include "od_dpp.cuh"
