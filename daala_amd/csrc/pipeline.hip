@@ -330,6 +330,16 @@ int pipe_init(odhip_pipe *p) {
     ODHIP_TRY(hipExtStreamCreateWithCUMask(&p->stream[0], (uint32_t)words, ma.data()));
     ODHIP_TRY(hipExtStreamCreateWithCUMask(&p->stream[1], (uint32_t)words, mb.data()));
   }
+  else if (const char *prio_env = p->serial ? nullptr : ODHIP_EXP_ENV("ODHIP_PIPE_PRIO")) {
+    /* Experiment knob: ODHIP_PIPE_PRIO=1 gives the luma chain the highest queue priority the device
+       offers and the chroma chain the lowest, 2 the other way round. */
+    int lo = 0;
+    int hi = 0;
+    ODHIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    const bool luma_high = atoi(prio_env) == 1;
+    ODHIP_TRY(hipStreamCreateWithPriority(&p->stream[0], hipStreamNonBlocking, luma_high ? hi : lo));
+    ODHIP_TRY(hipStreamCreateWithPriority(&p->stream[1], hipStreamNonBlocking, luma_high ? lo : hi));
+  }
   else {
     ODHIP_TRY(hipStreamCreateWithFlags(&p->stream[0], hipStreamNonBlocking));
     if (p->serial) p->stream[1] = p->stream[0];

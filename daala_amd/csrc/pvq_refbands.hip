@@ -1265,9 +1265,23 @@ struct RowVector {
     od_row_norm<E, G>(ax, &xx, &norm_1);
   }
   __device__ __forceinline__ double search(int n_true, int k, int prev_k, double g2, double lambda) {
+#ifdef ODHIP_EXPERIMENTS
+    /* how often the double-precision replay of a greedy pulse fires on real content
+       (odhip_exp_row_replay_stats; tools/replay_rate.py) */
+    const int placed = prev_k > 0 && prev_k <= k ? prev_k : 0;
+    const int greedy = k - (1 + k/4) - placed;
+    pulses += greedy > 0 ? greedy : 0;
+    return od_pvq_search_row<E, G>(ax, y, row, l, n_true, k, prev_k, g2, lambda, force, xx, norm_1,
+     &cxy, &cyy, &replays);
+#else
     return od_pvq_search_row<E, G>(ax, y, row, l, n_true, k, prev_k, g2, lambda, force, xx, norm_1,
      &cxy, &cyy);
+#endif
   }
+#ifdef ODHIP_EXPERIMENTS
+  int replays = 0;
+  int pulses = 0;
+#endif
   __device__ __forceinline__ int moment() const {
     int m = 0;
 #pragma unroll
@@ -1289,6 +1303,63 @@ struct RowVector {
     }
   }
 };
+
+#ifdef ODHIP_EXPERIMENTS
+/* [0] greedy pulses placed by the row searches of the with-reference stage, [1] those that took the
+   double-precision replay (pvq_row.cuh, point 3) - counted once per band */
+__device__ unsigned long long gRowReplayStats[2];
+#endif
+
+/* The row search on plain band vectors (odhip_pvq_search_row_batch): one band per group of G lanes,
+   no chain (prev_k = 0).  replays_out[b] = the greedy pulses of band b that the single-precision
+   screen could not vouch for and replayed with the literal double-precision scan. */
+template <int E, int G>
+__global__ __launch_bounds__(kWave) void k_pvq_search_row(const int16_t *x_in, int n_true, const int32_t *k_in,
+ od_coeff *y_out, const double *g2_in, double lambda, int force_scan, double *cos_out, int32_t *replays_out,
+ long nbands) {
+  constexpr int n = E*G;
+  constexpr int C = kWave/G;
+  od_rsqrt_init(threadIdx.x);
+  const int lane = threadIdx.x;
+  const int row = lane/G;
+  const int l = lane%G;
+  const long band = (long)blockIdx.x*C + row;
+  const bool live = band < nbands;
+  const long b = live ? band : nbands - 1;
+  int ax[E];
+  int y[E];
+  unsigned sg = 0;
+#pragma unroll
+  for (int e = 0; e < E; e++) {
+    const int j = l*E + e;
+    const int v = j < n_true ? x_in[b*n_true + j] : 0;
+    ax[e] = abs(v);
+    sg |= (unsigned)(v < 0) << e;
+    y[e] = 0;
+  }
+  double xx;
+  double norm_1;
+  od_row_norm<E, G>(ax, &xx, &norm_1);
+  double cxy = 0;
+  double cyy = 0;
+  int replays = 0;
+  int k = k_in[b];
+  k = k < 0 ? 0 : k > 32767 ? 32767 : k;
+  const double c = od_pvq_search_row<E, G>(ax, y, row, l, n_true, k, 0, g2_in[b], lambda, force_scan, xx, norm_1,
+   &cxy, &cyy, &replays);
+  if (live) {
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+      const int j = l*E + e;
+      if (j < n_true) y_out[band*n_true + j] = sg >> e & 1 ? -y[e] : y[e];
+    }
+    if (l == 0) {
+      cos_out[band] = c;
+      if (replays_out) replays_out[band] = replays;
+    }
+  }
+  (void)n;
+}
 
 template <int E, int G>
 __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_refb_search_row(RItems it) {
@@ -2872,6 +2943,50 @@ extern "C" int odhip_pvq_ref_theta_probe(const double *d_corr, double *d_t, long
   k_theta_probe<<<(unsigned)((n + kWave - 1)/kWave), kWave, 0, (hipStream_t)stream>>>(d_corr, d_t, n);
   return odhip_check_launch();
 }
+
+namespace {
+int upload_tables(void);
+}
+
+/* pvq_search_rdo_double (src/pvq_encoder.c:93-224) in its ROW form - what the 32- and 128-coefficient
+   bands of the with-reference stage run (pvq_row.cuh) - on plain band vectors. */
+extern "C" int odhip_pvq_search_row_batch(const int16_t *d_x, int n, const int32_t *d_k, od_coeff *d_y,
+ const double *d_g2, double pvq_norm_lambda, int force_scan, double *d_cos, int32_t *d_replays, long nbands,
+ odhip_stream stream) {
+  if (!d_x || !d_k || !d_y || !d_g2 || !d_cos || nbands < 0) return ODHIP_EINVAL;
+  if (n != 31 && n != 32 && n != 127 && n != 128) return ODHIP_EINVAL;
+  if (nbands == 0) return ODHIP_SUCCESS;
+  const int rc = upload_tables();
+  if (rc) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  const int per_wg = n >= 127 ? 4 : 16;
+  const long grid = (nbands + per_wg - 1)/per_wg;
+  if (grid > 0x7fffffffL) return ODHIP_EINVAL;
+  if (n >= 127) {
+    k_pvq_search_row<8, 16><<<(unsigned)grid, kWave, 0, s>>>(d_x, n, d_k, d_y, d_g2, pvq_norm_lambda, force_scan, d_cos,
+     d_replays, nbands);
+  }
+  else {
+    k_pvq_search_row<8, 4><<<(unsigned)grid, kWave, 0, s>>>(d_x, n, d_k, d_y, d_g2, pvq_norm_lambda, force_scan, d_cos,
+     d_replays, nbands);
+  }
+  return odhip_check_launch();
+}
+
+#ifdef ODHIP_EXPERIMENTS
+/* out[0] = greedy pulses placed by the row searches of the with-reference band stage since the last
+   reset, out[1] = those that took the double-precision replay.  Synchronises the device. */
+extern "C" int odhip_exp_row_replay_stats(unsigned long long *out, int reset) {
+  if (!out) return ODHIP_EINVAL;
+  ODHIP_TRY(hipDeviceSynchronize());
+  ODHIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(gRowReplayStats), 2*sizeof(unsigned long long)));
+  if (reset) {
+    const unsigned long long zero[2] = {0, 0};
+    ODHIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(gRowReplayStats), zero, sizeof(zero)));
+  }
+  return ODHIP_SUCCESS;
+}
+#endif
 
 namespace {
 int ref_bands(const odhip_pvq_refjob *jobs, int njobs, double pvq_norm_lambda, odhip_stream stream, int fuse);

@@ -141,8 +141,14 @@ __device__ __forceinline__ void od_row_norm(const int (&ax)[E], double *xx_out, 
 template <int E, int G>
 __device__ __forceinline__ double od_pvq_search_row(const int (&ax)[E], int (&y)[E], int row,
  int l, int n_true, int k, int prev_k, double g2, double pvq_norm_lambda, int force_scan,
- double xx, double norm_1, double *cxy, double *cyy) {
+ double xx, double norm_1, double *cxy, double *cyy, int *replays = nullptr) {
   constexpr int n = G*E;
+  /* the screen's invariants: a lane's fold starts from a real candidate, never the PAD
+     (E > 1: the PAD is the LAST of the last lane's E positions), and every operand of a key is
+     non-negative - ax[] holds magnitudes, y[] pulse counts, xy = sum ax*y >= 0 - so the relative
+     error bound of the single-precision ratios holds */
+  static_assert(E > 1, "the single-precision screen folds from candidate 0 of each lane, which must not be the PAD");
+  static_assert(G == 4 || G == 16, "a quad or a DPP row");
   const bool pad_lane = n_true != n && l == G - 1;
   const double lambda = __ddiv_rn(pvq_norm_lambda, 1e-30 + g2);
   double xy = 0;
@@ -258,6 +264,7 @@ __device__ __forceinline__ double od_pvq_search_row(const int (&ax)[E], int (&y)
     double nb = (double)wbi;     /* ... and the winner's denominator yy + 2*y_pos + 1 IS the next yy */
     if (grp_ballot<G>(bad && on, row) != 0) {
       /* literal scan, src/pvq_encoder.c:172-183, in the reference's double precision */
+      if (replays) ++*replays;     /* (odhip_pvq_search_row_batch reports it; a null pointer folds away) */
       double sa = 0;
       double sb = 1;
       int sx = 0;
