@@ -242,6 +242,23 @@ def pvq_search_batch(x, k, g2, pvq_norm_lambda, prev_k=None, y=None, cos=None):
     return y, cos
 
 
+def pvq_search_row_batch(x, k, g2, pvq_norm_lambda, force_scan=False):
+    """odhip_pvq_search_row_batch: pvq_search_rdo_double one band per quad / 16-lane row (n = 31, 32,
+    127, 128).  Returns (y int32 [nbands, n], cos float64 [nbands], replays int32 [nbands])."""
+    import torch
+    _need(x, torch.int16, "x")
+    _need(k, torch.int32, "k")
+    _need(g2, torch.float64, "g2")
+    nbands, n = x.shape
+    y = torch.zeros((nbands, n), dtype=torch.int32, device=x.device)
+    cos = torch.empty(nbands, dtype=torch.float64, device=x.device)
+    rep = torch.zeros(nbands, dtype=torch.int32, device=x.device)
+    _check(lib().odhip_pvq_search_row_batch(_p(x), int(n), _p(k), _p(y), _p(g2), ctypes.c_double(pvq_norm_lambda),
+                                            int(bool(force_scan)), _p(cos), _p(rep), ctypes.c_long(nbands), _stream()),
+           "odhip_pvq_search_row_batch")
+    return y, cos, rep
+
+
 # ---- per-call host-pointer surfaces (numpy) ---------------------------------
 class _Host:
     """The reference-signature entry points, callable on numpy arrays."""

@@ -85,5 +85,42 @@ def build(force=False, verbose=False, experiments=True):
     return LIB
 
 
+def build_variant(name, extra_flags, verbose=False):
+    """A/B builds (tools/ab_bench.sh): the default sources with extra compiler flags (-DODHIP_...=n) into
+    daala_amd/lib_<name>/libdaalahip.so, selected at run time with ODHIP_LIB."""
+    outdir = os.path.join(HERE, "lib_" + name)
+    os.makedirs(outdir, exist_ok=True)
+    lib = os.path.join(outdir, "libdaalahip.so")
+    stamp = os.path.join(outdir, "flags.txt")
+    flags_changed = not os.path.exists(stamp) or open(stamp).read() != " ".join(extra_flags)
+    deps = _deps()
+    jobs = []
+    objs = []
+    for src in SOURCES:
+        obj = os.path.join(outdir, src.replace(".hip", ".o"))
+        objs.append(obj)
+        if flags_changed or _stale(obj, deps):
+            jobs.append([HIPCC] + FLAGS + list(extra_flags) + ["-c", os.path.join(CSRC, src), "-o", obj])
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed:\n%s\n%s" % (" ".join(cmd), r.stderr))
+
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 4)) as ex:
+        list(ex.map(run, jobs))
+    if jobs or not os.path.exists(lib):
+        run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs)
+    with open(stamp, "w") as f:
+        f.write(" ".join(extra_flags))
+    return lib
+
+
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    if "--variant" in sys.argv:
+        i = sys.argv.index("--variant")
+        print(build_variant(sys.argv[i + 1], sys.argv[i + 2:], verbose=True))
+    else:
+        print(build(force="--force" in sys.argv, verbose=True))

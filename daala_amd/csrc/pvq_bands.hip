@@ -38,6 +38,7 @@
 #include <type_traits>
 #include "od_ctx.cuh"
 #include "od_pvq_math.cuh"
+#include "od_occupancy.cuh"
 #include "gen/od_scan_tables.h"
 #define OD_RSQ_HUGE
 #include "pvq_search.cuh"
@@ -973,8 +974,9 @@ __device__ __forceinline__ void od_decide_band(const Items &it, int job, const D
    rather than one per block: searched in one kernel the three bands hold 150 VGPRs (three waves
    per SIMD), apart 121 and ~100 (four and five). */
 template <int PART>
-__global__ __launch_bounds__(kWave) void k_decide_corner(Items it) {
+__global__ __launch_bounds__(kWave) OD_DECIDE_OCC_ATTR void k_decide_corner(Items it) {
   extern __shared__ __attribute__((aligned(16))) double lds_d[];
+  OD_SEARCH_VGPR_FLOOR();
   double *rsq = lds_d;                                   /* [kRsqN]  */
   uint32_t *pk = (uint32_t *)(rsq + kRsqN);              /* [15][64] */
   const int lane = threadIdx.x;
@@ -1078,9 +1080,10 @@ __global__ __launch_bounds__(kWave) void k_decide_corner(Items it) {
 /* The 32-coefficient bands the same way (band 3 of every block of 8x8 and up, bands 4 and 5 of 16x16 and
    up), two lanes per band as in k_search<32, 2, 1>: each lane gathers its 16 coding positions, the
    pair shares the sums by DPP.  Natural order costs these bands 1 % (measured). */
-__global__ __launch_bounds__(kWave) void k_decide_lane32(Items it) {
+__global__ __launch_bounds__(kWave) OD_DECIDE_OCC_ATTR void k_decide_lane32(Items it) {
   constexpr int NL = 16;
   extern __shared__ __attribute__((aligned(16))) double lds_d[];
+  OD_SEARCH_VGPR_FLOOR();
   double *rsq = lds_d;                                   /* [kRsqN]  */
   uint32_t *pk = (uint32_t *)(rsq + kRsqN);              /* [16][64] */
   const int lane = threadIdx.x;

@@ -43,6 +43,7 @@
 #include <string.h>
 #include "od_ctx.cuh"
 #include "od_pvq_math.cuh"
+#include "od_occupancy.cuh"
 #include "gen/od_scan_tables.h"
 #define OD_RSQ_TABLE_N 512
 #define OD_RSQ_HUGE
@@ -1849,6 +1850,12 @@ __device__ __forceinline__ double lean_rate_ts(int ts) {
 }
 constexpr int kLeanWords = kSlots + kLeanAux;
 
+/* The lean kernels run kSearchWaves INDEPENDENT wavefronts per workgroup (wavefront w of workgroup g is
+   work unit g*kSearchWaves + w: what a 64-thread workgroup was in rounds 3-5) that share one 1/sqrt
+   table; how many of them a CU holds: od_occupancy.cuh. */
+constexpr int kSearchWaves = ODHIP_SEARCH_WAVES;
+constexpr int kSearchThreads = kSearchWaves*kWave;
+
 /* A band's candidate list in LDS: word s of the band at col[s*stride].  Theta candidate:
    gi | min(k, 65535) << 2 | (j - lower[gi]) << 18 - the low 18 bits order by (k, gain) as
    items_compare does (src/pvq_encoder.c:301-305); no-reference candidate: c | k << 2. */
@@ -2226,19 +2233,25 @@ __device__ __forceinline__ RefBest lean_best(const LeanDecide<NY> &dec, const Ca
 }
 
 template <int N>
-__global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(3))) void k_refb_lean_lane(RItems it) {
+__global__ __launch_bounds__(kSearchThreads) OD_SEARCH_OCC_ATTR void k_refb_lean_lane(RItems it) {
   constexpr int SH = N == 15 ? 1 : 0;
-  __shared__ uint32_t s_list[kLeanWords*kWave];
+  __shared__ uint32_t s_list_w[kSearchWaves][kLeanWords*kWave];
+  OD_SEARCH_VGPR_FLOOR();
   od_rsqrt_init(threadIdx.x);
-  const int item = find_item(it, blockIdx.x);
+  const int lane = threadIdx.x%kWave;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x/kWave);     /* (uniform: keeps the item search scalar) */
+  const int unit = blockIdx.x*kSearchWaves + wave;
+  if (unit >= it.wg_start[it.nitems]) return;
+  uint32_t *s_list = s_list_w[wave];
+  const int item = find_item(it, unit);
   const int job = it.job[item];
   const RJob &jb = it.jobs[job];
-  const long pos = (long)(blockIdx.x - it.wg_start[item])*kWave + threadIdx.x;
+  const long pos = (long)(unit - it.wg_start[item])*kWave + lane;
   if (pos >= jb.nblocks) return;
   const int band = it.band[item];
   const long blk = jb.ids[(long)band*jb.nblocks + pos];
   const odhip_pvq_refband r = jb.rec[blk*jb.nb_bands + band];
-  const CandList cl = refb_build_list(jb, band, r, s_list + threadIdx.x, kWave, true);
+  const CandList cl = refb_build_list(jb, band, r, s_list + lane, kWave, true);
   RegVector<N> v;
   LeanDecide<N> dec;
   dec.init(r, jb, it.lambda, it.tol_scale);
@@ -2394,22 +2407,28 @@ __device__ __forceinline__ void refb_finish_row(const RItems &it, int job, const
 }
 
 template <int E, int G>
-__global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(3))) void k_refb_lean_row(RItems it) {
+__global__ __launch_bounds__(kSearchThreads) OD_SEARCH_OCC_ATTR void k_refb_lean_row(RItems it) {
   constexpr int C = kWave/G;            /* bands per wavefront */
-  __shared__ uint32_t s_list[kLeanWords*C];
-  __shared__ uint32_t s_pre[kSlots*kPreWords*C];
+  __shared__ uint32_t s_list_w[kSearchWaves][kLeanWords*C];
+  __shared__ uint32_t s_pre_w[kSearchWaves][kSlots*kPreWords*C];
+  OD_SEARCH_VGPR_FLOOR();
   od_rsqrt_init(threadIdx.x);
-  const int item = find_item(it, blockIdx.x);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x/kWave);     /* (uniform: keeps the item search scalar) */
+  const int unit = blockIdx.x*kSearchWaves + wave;
+  if (unit >= it.wg_start[it.nitems]) return;
+  uint32_t *s_list = s_list_w[wave];
+  uint32_t *s_pre = s_pre_w[wave];
+  const int item = find_item(it, unit);
   const int job = it.job[item];
   const RJob &jb = it.jobs[job];
   const int band = it.band[item];
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x%kWave;
   RowVector<E, G> v;
   v.row = lane/G;
   v.l = lane%G;
   v.force = it.perturb >> 1;
   const long nblocks = jb.nblocks;
-  const long pos = (long)(blockIdx.x - it.wg_start[item])*C + v.row;
+  const long pos = (long)(unit - it.wg_start[item])*C + v.row;
   const bool live = pos < nblocks;
   /* rows beyond the end redo the last band without storing anything */
   const long blk = jb.ids[(long)band*nblocks + (live ? pos : nblocks - 1)];
@@ -2419,6 +2438,12 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(3))) void
   dec.init(r, jb, it.lambda, it.tol_scale);
   refb_loops_lean_rows<G*E, G>(jb, band, blk, r, cl, it.lambda, v, dec, s_pre + v.row, C);
   refb_finish_row<E, G>(it, job, jb, band, blk, r, dec, lean_best(dec, cl, jb.is_keyframe), v.l, live);
+#ifdef ODHIP_EXPERIMENTS
+  if (live && v.l == 0 && v.pulses) {
+    atomicAdd(&gRowReplayStats[0], (unsigned long long)v.pulses);
+    if (v.replays) atomicAdd(&gRowReplayStats[1], (unsigned long long)v.replays);
+  }
+#endif
 }
 
 /* The bands a theta-margin re-run rebuilt (records, candidates and pulses of every slot, by
@@ -3130,11 +3155,11 @@ int ref_bands(const odhip_pvq_refjob *jobs, int njobs, double pvq_norm_lambda, o
       if (sizes[i] == 128) {
         const bool prof = st.prof_on && st.prof_n < kProfSlots;
         if (prof) (void)hipEventRecord(st.prof_ev[st.prof_n][0], s);
-        if (fuse == 2) k_refb_lean_row<8, 16><<<it.wg_start[it.nitems], kWave, 0, s>>>(it);
+        if (fuse == 2) k_refb_lean_row<8, 16><<<(it.wg_start[it.nitems] + kSearchWaves - 1)/kSearchWaves, kSearchThreads, 0, s>>>(it);
         else k_refb_search_row<8, 16><<<it.wg_start[it.nitems], kWave, 0, s>>>(it);
         if (prof) (void)hipEventRecord(st.prof_ev[st.prof_n++][1], s);
       }
-      else if (fuse == 2) k_refb_lean_row<8, 4><<<it.wg_start[it.nitems], kWave, 0, s>>>(it);
+      else if (fuse == 2) k_refb_lean_row<8, 4><<<(it.wg_start[it.nitems] + kSearchWaves - 1)/kSearchWaves, kSearchThreads, 0, s>>>(it);
       else k_refb_search_row<8, 4><<<it.wg_start[it.nitems], kWave, 0, s>>>(it);
       continue;
     }
@@ -3144,8 +3169,9 @@ int ref_bands(const odhip_pvq_refjob *jobs, int njobs, double pvq_norm_lambda, o
       if (fuse == 2) items_heavy_first(it);
       const int wgs = it.wg_start[it.nitems];
       if (fuse == 2) {
-        if (sizes[i] == 15) k_refb_lean_lane<15><<<wgs, kWave, 0, s>>>(it);
-        else k_refb_lean_lane<8><<<wgs, kWave, 0, s>>>(it);
+        const int groups = (wgs + kSearchWaves - 1)/kSearchWaves;
+        if (sizes[i] == 15) k_refb_lean_lane<15><<<groups, kSearchThreads, 0, s>>>(it);
+        else k_refb_lean_lane<8><<<groups, kSearchThreads, 0, s>>>(it);
       }
       else if (fuse) {
         if (sizes[i] == 15) k_refb_search_regs<15, true><<<wgs, kWave, 0, s>>>(it);

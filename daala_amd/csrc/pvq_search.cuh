@@ -52,8 +52,9 @@ static inline void od_rsqrt_fill_launch(void) {
   k_rsq_big_fill<<<(OD_RSQ_TABLE_N + 255)/256, 256, 0, 0>>>();
 }
 
+/* (every thread of the workgroup calls it, before any of them leaves: one table per workgroup) */
 __device__ __forceinline__ void od_rsqrt_init(int tid) {
-  for (int i = tid; i < OD_RSQ_TABLE_N; i += kWave) od_rsq_lds[i] = gRsqBig[i];
+  for (int i = tid; i < OD_RSQ_TABLE_N; i += (int)blockDim.x) od_rsq_lds[i] = gRsqBig[i];
   __syncthreads();
 }
 #else

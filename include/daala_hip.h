@@ -291,6 +291,18 @@ int odhip_pvq_search_batch(const int16_t *d_x, int n, const int32_t *d_k,
  od_coeff *d_y, const double *d_g2, double pvq_norm_lambda,
  const int32_t *d_prev_k, double *d_cos, long nbands, odhip_stream stream);
 
+/* The same search (src/pvq_encoder.c:93-224, no chain: prev_k = 0) in its ROW form - one band per
+   quad (n = 31, 32) or per 16-lane row (n = 127, 128), what the 32- and 128-coefficient bands of
+   the with-reference stage run.  Its greedy pulses are screened in single precision and replayed
+   with the reference's left-to-right double-precision scan whenever the screen cannot vouch for
+   the argmax (a candidate within a relative 2^-17 of the best key that is not its exact
+   duplicate); d_replays[b], when given, receives the number of pulses of band b that were
+   replayed, force_scan != 0 replays every one (the cross-check).  Other n: ODHIP_EINVAL;
+   K is clamped to 0..32767. */
+int odhip_pvq_search_row_batch(const int16_t *d_x, int n, const int32_t *d_k, od_coeff *d_y,
+ const double *d_g2, double pvq_norm_lambda, int force_scan, double *d_cos, int32_t *d_replays,
+ long nbands, odhip_stream stream);
+
 /* ---- PVQ band stage (the data-parallel part of pvq_theta) -------------------
 
    For every block of side N = 4 << bs of a batch of coefficient planes and

@@ -136,4 +136,5 @@ def test_default_build_reads_at_most_six_environment_switches(built):
     def syms(p):
         out = subprocess.run(["nm", "-D", "--defined-only", p], capture_output=True, text=True).stdout
         return {ln.split()[-1] for ln in out.splitlines() if " T " in ln and ("odhip_" in ln or "od_" in ln)}
-    assert syms(built) == syms(daala_amd.EXPERIMENTS_LIB)
+    # (odhip_exp_*: read-outs of counters only the experiments build keeps, e.g. odhip_exp_row_replay_stats)
+    assert syms(built) == {s for s in syms(daala_amd.EXPERIMENTS_LIB) if not s.startswith("odhip_exp_")}
