@@ -11,7 +11,7 @@ has not been built, and every call raises if the library reports an error.
 """
 from .api import (DaalaHipError, lib, lib_path, EXPERIMENTS_LIB, init, fdct2d_batch, idct2d_batch,  # noqa: F401
                   fdct2d_plane, idct2d_plane, filter_batch, dering_planes, forward_pyramid, inverse_level,
-                  pvq_search_batch, pvq_search_row_batch, pvq_band_layout, alloc_pvq_cands, unpack_cands, BAND_RECORD,
+                  pvq_search_batch, pvq_search_row_batch, copy_ceiling, decode_export_sections, export_layout_make, pvq_band_layout, alloc_pvq_cands, unpack_cands, BAND_RECORD,
                   pvq_noref_bands,
                   pvq_select_synth_noref, PvqJob, pvq_noref_bands_multi,
                   pvq_select_synth_noref_multi, pvq_choose_multi, inverse_level_pvq, inverse_levels_pvq, pvq_profile, pvq_profile_read, pvq_ref_prepare,

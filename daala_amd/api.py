@@ -242,6 +242,17 @@ def pvq_search_batch(x, k, g2, pvq_norm_lambda, prev_k=None, y=None, cos=None):
     return y, cos
 
 
+def copy_ceiling(nbytes=1 << 30, n=10):
+    """odhip_copy_ceiling: the best of the library's three 16-byte-vector copy kernels, GB/s read + written."""
+    best = 0.0
+    for variant in range(3):
+        g = ctypes.c_double(0)
+        _check(lib().odhip_copy_ceiling(ctypes.c_size_t(nbytes), int(n), variant, ctypes.byref(g), _stream()),
+               "odhip_copy_ceiling")
+        best = max(best, g.value)
+    return best
+
+
 def pvq_search_row_batch(x, k, g2, pvq_norm_lambda, force_scan=False):
     """odhip_pvq_search_row_batch: pvq_search_rdo_double one band per quad / 16-lane row (n = 31, 32,
     127, 128).  Returns (y int32 [nbands, n], cos float64 [nbands], replays int32 [nbands])."""
@@ -983,6 +994,90 @@ class _PipeConfig(ctypes.Structure):
                 ("pvq_norm_lambda", ctypes.c_double), ("quant", ctypes.c_void_p)]
 
 
+def export_layout_make(nblocks, bs):
+    """odhip_export_layout_make for sections of nblocks[i] blocks at level bs[i] -> (ctypes layout, dict)."""
+    lay = _ExportLayout()
+    n = len(bs)
+    _check(lib().odhip_export_layout_make(ctypes.byref(lay), n, (ctypes.c_long * n)(*nblocks), (ctypes.c_int * n)(*bs)),
+           "odhip_export_layout_make")
+    return lay, _layout_dict(lay)
+
+
+def _layout_dict(lay):
+    secs = [{k: int(getattr(lay.section[i], k)) for k in ("bs", "ngroups", "cap_words", "nrecords", "records_off",
+                                                         "group_base_off", "stream_off")}
+            for i in range(lay.nsections)]
+    return {"nsections": int(lay.nsections), "fixed_bytes": int(lay.fixed_bytes),
+            "total_bytes": int(lay.total_bytes), "sections": secs}
+
+
+def decode_export_sections(host, lay):
+    """Reference-side decoder of the export format (include/daala_hip.h, export_kernels.hip): `host` = the buffer
+    as numpy uint8, `lay` = the layout dict.  Per section (y int32 [B][len], band int32 [B][nb][4] = {coded gain
+    index, itheta, max_theta, k}, coded bool [B][nb]).  A host entropy coder walks the same records and words
+    sequentially; this vectorised form exists for the tests and the bench."""
+    hdr = host[:128].view(np.uint32)
+    out = []
+    rec_dt = np.dtype([("qg", "<i2"), ("itheta", "<i2"), ("max_theta", "<i2"), ("k", "<u2"), ("flags", "u1"),
+                       ("reserved", "u1"), ("nwords", "<u2")])
+    G = 256
+    for si, sec in enumerate(lay["sections"]):
+        nb, offs, ln = pvq_band_layout(sec["bs"])
+        B = sec["nrecords"] // nb
+        assert int(hdr[16 + si]) == 0, "export stream of section %d overflowed" % si
+        rec = host[sec["records_off"]:sec["records_off"] + sec["nrecords"] * 12].view(rec_dt)
+        gbase = host[sec["group_base_off"]:sec["group_base_off"] + sec["ngroups"] * 4].view(np.uint32).astype(np.int64)
+        total = int(hdr[si])
+        words = host[sec["stream_off"]:sec["stream_off"] + total * 2].view(np.uint16)
+        nw = rec["nwords"].astype(np.int64)
+        assert total == int(nw.sum()), (si, total, int(nw.sum()))
+        # first word of every band: its group's base + the words of the group's earlier bands
+        pad = (-len(nw)) % G
+        nwp = np.concatenate([nw, np.zeros(pad, np.int64)]).reshape(-1, G)
+        start = (gbase[:, None] + np.cumsum(nwp, axis=1) - nwp).reshape(-1)[:len(nw)]
+        band_of_word = np.repeat(np.arange(len(nw)), nw)
+        rank = np.arange(len(band_of_word)) - np.repeat(np.cumsum(nw) - nw, nw)
+        w = words[start[band_of_word] + rank].astype(np.int64)
+        pos = w & 127
+        val = ((w >> 7) ^ 256) - 256          # sign-extend the 9-bit count
+        keep = np.ones(len(w), bool)
+        idx = np.nonzero(val == -256)[0]
+        # escapes: the word after a count of -256 is the count itself.  (A payload word can look like an escape:
+        # walk them in order so that a payload is never taken for one.)
+        if len(idx):
+            is_payload = np.zeros(len(w), bool)
+            for i in idx:
+                if is_payload[i]:
+                    continue
+                is_payload[i + 1] = True
+                full = int(w[i + 1])
+                val[i] = full - 65536 if full >= 32768 else full
+            keep = ~is_payload
+        y = np.zeros((B, ln), np.int32)
+        bw = band_of_word[keep]
+        y[bw // nb, np.asarray(offs)[bw % nb] + pos[keep]] = val[keep]
+        band = np.zeros((B, nb, 4), np.int32)
+        r = rec.reshape(B, nb)
+        band[..., 0] = r["qg"]
+        band[..., 1] = r["itheta"]
+        band[..., 2] = r["max_theta"]
+        band[..., 3] = r["k"]
+        coded = ((r["flags"] >> 1) & 3) == 0
+        out.append((y, band, coded))
+    return out
+
+
+class _ExportSection(ctypes.Structure):
+    _fields_ = [("bs", ctypes.c_int32), ("ngroups", ctypes.c_uint32), ("cap_words", ctypes.c_uint32),
+                ("pad", ctypes.c_uint32), ("nrecords", ctypes.c_uint64), ("records_off", ctypes.c_uint64),
+                ("group_base_off", ctypes.c_uint64), ("stream_off", ctypes.c_uint64)]
+
+
+class _ExportLayout(ctypes.Structure):
+    _fields_ = [("nsections", ctypes.c_int32), ("pad", ctypes.c_int32), ("fixed_bytes", ctypes.c_uint64),
+                ("total_bytes", ctypes.c_uint64), ("section", _ExportSection * 16)]
+
+
 class Pipe:
     """ctypes mirror of odhip_pipe (include/daala_hip.h): F resident 4:2:0 pictures,
     one C call per step.  Buffers are read / written as numpy arrays."""
@@ -1078,13 +1173,42 @@ class Pipe:
 
     def set_export(self, host):
         """host: a pinned CPU uint8 torch tensor of export_bytes() bytes (kept alive by the caller
-        until set_export(None)), or None to stop: every following step copies its choice records and
-        pulse vectors there on the pipe's export stream (odhip_pipe_set_export)."""
+        until set_export(None)), or None to stop: every following step leaves the record and the pulses of
+        every band there, compacted on the device (odhip_pipe_set_export; decode_export reads it back)."""
         if host is None:
             _check(lib().odhip_pipe_set_export(self._p(), ctypes.c_void_p(0)), "odhip_pipe_set_export")
             return
         assert not host.is_cuda and host.is_contiguous() and host.numel() * host.element_size() >= self.export_bytes()
         _check(lib().odhip_pipe_set_export(self._p(), ctypes.c_void_p(host.data_ptr())), "odhip_pipe_set_export")
+
+    def export_layout(self):
+        """odhip_pipe_export_layout as a dict: nsections, fixed_bytes, total_bytes, sections[] of
+        {bs, ngroups, cap_words, nrecords, records_off, group_base_off, stream_off}."""
+        lay = _ExportLayout()
+        _check(lib().odhip_pipe_export_layout(self._p(), ctypes.byref(lay)), "odhip_pipe_export_layout")
+        return _layout_dict(lay)
+
+    def export_stale(self):
+        lib().odhip_pipe_export_stale.restype = ctypes.c_long
+        return int(lib().odhip_pipe_export_stale(self._p()))
+
+    def export_shipped_bytes(self, host):
+        """Bytes of the export buffer `host` (numpy uint8 view) that crossed the bus for the step it holds: the
+        fixed part plus the used prefix of every stream (rounded up to the 16-byte vectors the ship kernel
+        moves)."""
+        lay = self.export_layout()
+        totals = host[:64].view(np.uint32)
+        n = lay["fixed_bytes"]
+        for i, sec in enumerate(lay["sections"]):
+            n += (min(int(totals[i]), sec["cap_words"]) * 2 + 15) // 16 * 16
+        return n
+
+    def decode_export(self, host):
+        """The export buffer `host` (numpy uint8) decoded back to what tests/_pipeline_check.gpu_decisions reads from
+        the dense device buffers: {(set, level): (y int32 [B][len], band int32 [B][nb][4] = {coded gain index,
+        itheta, max_theta, k}, coded bool [B][nb])}."""
+        secs = decode_export_sections(host, self.export_layout())
+        return {((0, i) if i < 5 else (1, i - 5)): v for i, v in enumerate(secs)}
 
     def step(self):
         _check(lib().odhip_pipe_step(self._p()), "odhip_pipe_step")

@@ -162,3 +162,71 @@ extern "C" int odhip_image_planes_copy_pad16(uint16_t *d_dst, int dst_stride, lo
   }
   return odhip_check_launch();
 }
+
+/* ---- the practical HBM ceiling of this GPU, measured by the library itself ----
+   A device-to-device copy in 16-byte vectors: U vectors per lane a whole workgroup stride apart (every
+   instruction of a wavefront touches 1 KB of consecutive bytes), all U loads in flight before the first
+   store.  What the filter + DCT rooflines are read against beside the 8 TB/s specification
+   (bench.py `copy_ceiling`): round 5 used a torch copy_ (4.8 TB/s), which this repository's own 4x4
+   transform kernel exceeds. */
+namespace {
+template <int U>
+__global__ __launch_bounds__(256) void k_copy16(const int4 *__restrict__ src, int4 *__restrict__ dst, size_t nvec) {
+  const size_t base = (size_t)blockIdx.x*(256*U) + threadIdx.x;
+  int4 v[U];
+#pragma unroll
+  for (int u = 0; u < U; u++) {
+    const size_t i = base + (size_t)u*256;
+    if (i < nvec) v[u] = src[i];
+  }
+#pragma unroll
+  for (int u = 0; u < U; u++) {
+    const size_t i = base + (size_t)u*256;
+    if (i < nvec) dst[i] = v[u];
+  }
+}
+}  // namespace
+
+/* Copies `bytes` (a multiple of 16, buffers owned by this call) n times after one warm-up and reports
+   (read + written bytes) / time in GB/s; variant 0..2 = 2 / 4 / 8 vectors per lane. */
+extern "C" int odhip_copy_ceiling(size_t bytes, int n, int variant, double *gbs, odhip_stream stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (!gbs || n <= 0 || bytes < 16 || (bytes & 15) || variant < 0 || variant > 2) return ODHIP_EINVAL;
+  int4 *a = nullptr;
+  int4 *b = nullptr;
+  if (hipMalloc((void **)&a, bytes) != hipSuccess) return ODHIP_EFAULT;
+  if (hipMalloc((void **)&b, bytes) != hipSuccess) {
+    (void)hipFree(a);
+    return ODHIP_EFAULT;
+  }
+  hipEvent_t e0 = nullptr;
+  hipEvent_t e1 = nullptr;
+  int rc = ODHIP_SUCCESS;
+  const size_t nvec = bytes/16;
+  auto launch = [&]() {
+    const int u = 2 << variant;
+    const unsigned grid = (unsigned)((nvec + (size_t)256*u - 1)/((size_t)256*u));
+    if (variant == 0) k_copy16<2><<<grid, 256, 0, s>>>(a, b, nvec);
+    else if (variant == 1) k_copy16<4><<<grid, 256, 0, s>>>(a, b, nvec);
+    else k_copy16<8><<<grid, 256, 0, s>>>(a, b, nvec);
+  };
+  if (hipMemsetAsync(a, 1, bytes, s) != hipSuccess || hipEventCreate(&e0) != hipSuccess
+   || hipEventCreate(&e1) != hipSuccess) {
+    rc = ODHIP_EFAULT;
+  }
+  if (!rc) {
+    launch();
+    (void)hipEventRecord(e0, s);
+    for (int i = 0; i < n; i++) launch();
+    (void)hipEventRecord(e1, s);
+    float ms = 0;
+    if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess || ms <= 0) rc = ODHIP_EFAULT;
+    else *gbs = 2.*(double)bytes*n/(ms*1e-3)/1e9;
+    if (!rc) rc = odhip_check_launch();
+  }
+  if (e0) (void)hipEventDestroy(e0);
+  if (e1) (void)hipEventDestroy(e1);
+  (void)hipFree(a);
+  (void)hipFree(b);
+  return rc;
+}

@@ -103,6 +103,10 @@ struct odhip_pipe {
      every band - leaves for pinned host memory on a third stream, behind the stage that produced it */
   hipStream_t export_stream;
   uint8_t *export_host;
+  uint8_t *export_dev;            /* the packed decisions of the step being exported (export_kernels.hip) */
+  odhip_export_layout export_lay;
+  long export_stale;              /* steps re-decided by a late resolve after their export had left */
+  bool in_flush;
   hipEvent_t ev_exp_luma[2];      /* the luma outputs of parity [i] have left */
   hipEvent_t ev_exp_chroma;       /* the chroma outputs (shared between the parities) have left */
   hipEvent_t ev_chroma_done;
@@ -419,6 +423,8 @@ struct Current {
 };
 
 int stage_pad_run(odhip_pipe *p, int si, hipStream_t s);
+int export_luma(odhip_pipe *p, int par);
+int export_chroma(odhip_pipe *p, int par);
 
 /* Padding is the only reader of the resident pictures: its completion frees them for the
    next feed. */
@@ -477,6 +483,9 @@ int finish_pending(odhip_pipe *p) {
   const int par = p->pending;
   p->pending = -1;
   Current cur(p->ctx[1]);
+  const bool exporting = p->export_host != nullptr;
+  /* a resolve rewrites choices and pulses of that step: not while the pack kernels read them */
+  if (exporting) ODHIP_TRY(hipStreamWaitEvent(p->stream[1], p->ev_exp_chroma, 0));
   const auto t0 = std::chrono::steady_clock::now();
   /* with cfg.price a band re-run with the host's theta is also decided again by the resolve */
   const int n = odhip_pvq_ref_resolve_finish(p->refjobs[par], 4, p->cfg.pvq_norm_lambda, p->stream[1]);
@@ -500,6 +509,16 @@ int finish_pending(odhip_pipe *p) {
   /* the resolves and the re-run read that step's luma pulses and choices (the chroma-from-luma
      references, in place): the luma chain of step + 2 reuses those buffers and waits for this */
   if (n > 0 || m > 0) ODHIP_TRY(hipEventRecord(p->ev_used[par], p->stream[1]));
+  if (exporting && (n > 0 || m > 0)) {
+    /* what left for the host is superseded.  Inside odhip_pipe_flush nothing newer has been packed: the step is
+       exported again (step, flush, sync, read is exact); inside the NEXT step the host has already been told
+       the buffer was complete - counted (odhip_pipe_export_stale) */
+    if (p->in_flush) {
+      STEP_TRY(export_luma(p, par));
+      STEP_TRY(export_chroma(p, par));
+    }
+    else p->export_stale++;
+  }
   return ODHIP_SUCCESS;
 }
 
@@ -645,40 +664,33 @@ int step_noref(odhip_pipe *p) {
 }
 
 /* ---- the output side of the PCIe-inclusive rate (odhip_pipe_set_export) ------------------
-   Layout of the host buffer: per luma level the choice records (int32 [blocks][bands][4]) then
-   the pulse vectors (int16 [2][blocks][len]: a band's winner lies in the slot its record names),
-   then per chroma level the choice records (int32 [blocks][bands][16]) and the winners' pulse
-   vectors (slot 0, int16 [blocks][len]). */
-size_t export_luma_bytes(const odhip_pipe *p, int bs) {
-  int nb = 0;
-  int len = 0;
-  odhip_pvq_band_layout(bs, &nb, nullptr, &len);
-  const size_t B = (size_t)p->set[0].nblocks[bs];
-  return sizeof(int32_t)*B*nb*4 + sizeof(int16_t)*2*B*len;
-}
-
-size_t export_chroma_bytes(const odhip_pipe *p, int bs) {
-  int nb = 0;
-  int len = 0;
-  odhip_pvq_band_layout(bs, &nb, nullptr, &len);
-  const size_t B = (size_t)p->set[1].nblocks[bs];
-  return sizeof(int32_t)*B*nb*16 + sizeof(int16_t)*B*len;
+   Sections of the export buffer (include/daala_hip.h, export_kernels.hip): luma levels 0..4, chroma
+   levels 0..3.  The luma sections are packed as soon as the luma choices are final, the chroma ones
+   behind the chroma band stage; then ONE ship kernel moves the header, the records and the used part
+   of every stream to the host.  The band stages may overwrite choices and pulses as soon as the PACK
+   kernels have read them (ev_exp_luma / ev_exp_chroma), not only after the transfer. */
+int export_layout(const odhip_pipe *p, odhip_export_layout *lay) {
+  long nblocks[9];
+  int bs[9];
+  for (int i = 0; i < 5; i++) {
+    nblocks[i] = p->set[0].nblocks[i];
+    bs[i] = i;
+  }
+  for (int i = 0; i < 4; i++) {
+    nblocks[5 + i] = p->set[1].nblocks[i];
+    bs[5 + i] = i;
+  }
+  return odhip_export_layout_make(lay, 9, nblocks, bs);
 }
 
 int export_luma(odhip_pipe *p, int par) {
   hipStream_t x = p->export_stream;
   ODHIP_TRY(hipStreamWaitEvent(x, p->ev_refs[par], 0));         /* the luma choices of this step are final */
-  uint8_t *dst = p->export_host;
+  STEP_TRY(odhip_export_begin(p->export_dev, &p->export_lay, x));
   for (int bs = 0; bs < 5; bs++) {
-    int nb = 0;
-    int len = 0;
-    odhip_pvq_band_layout(bs, &nb, nullptr, &len);
-    const size_t B = (size_t)p->set[0].nblocks[bs];
     const odhip_pvq_job &j = p->jobs[par][bs];
-    ODHIP_TRY(hipMemcpyAsync(dst, j.cands.choice, sizeof(int32_t)*B*nb*4, hipMemcpyDeviceToHost, x));
-    dst += sizeof(int32_t)*B*nb*4;
-    ODHIP_TRY(hipMemcpyAsync(dst, j.cands.y, sizeof(int16_t)*2*B*len, hipMemcpyDeviceToHost, x));
-    dst += sizeof(int16_t)*2*B*len;
+    STEP_TRY(odhip_export_pack(p->export_dev, &p->export_lay, bs, j.cands.choice, j.cands.y, p->set[0].nblocks[bs], bs,
+     0, x));
   }
   ODHIP_TRY(hipEventRecord(p->ev_exp_luma[par], x));
   return ODHIP_SUCCESS;
@@ -688,21 +700,12 @@ int export_chroma(odhip_pipe *p, int par) {
   hipStream_t x = p->export_stream;
   ODHIP_TRY(hipEventRecord(p->ev_chroma_done, p->stream[1]));
   ODHIP_TRY(hipStreamWaitEvent(x, p->ev_chroma_done, 0));
-  uint8_t *dst = p->export_host;
-  for (int bs = 0; bs < 5; bs++) dst += export_luma_bytes(p, bs);
   for (int bs = 0; bs < 4; bs++) {
-    int nb = 0;
-    int len = 0;
-    odhip_pvq_band_layout(bs, &nb, nullptr, &len);
-    const size_t B = (size_t)p->set[1].nblocks[bs];
     const odhip_pvq_refjob &j = p->refjobs[par][bs];
-    ODHIP_TRY(hipMemcpyAsync(dst, j.choice, sizeof(int32_t)*B*nb*16, hipMemcpyDeviceToHost, x));
-    dst += sizeof(int32_t)*B*nb*16;
-    ODHIP_TRY(hipMemcpyAsync(dst, j.y, sizeof(int16_t)*B*len, hipMemcpyDeviceToHost, x));
-    dst += sizeof(int16_t)*B*len;
+    STEP_TRY(odhip_export_pack(p->export_dev, &p->export_lay, 5 + bs, j.choice, j.y, p->set[1].nblocks[bs], bs, 1, x));
   }
   ODHIP_TRY(hipEventRecord(p->ev_exp_chroma, x));
-  return ODHIP_SUCCESS;
+  return odhip_export_ship(p->export_host, p->export_dev, &p->export_lay, x);
 }
 
 int step_cfl(odhip_pipe *p) {
@@ -768,6 +771,9 @@ extern "C" odhip_pipe *odhip_pipe_create(const odhip_pipe_config *cfg) {
   p->fed = false;
   p->export_stream = nullptr;
   p->export_host = nullptr;
+  p->export_dev = nullptr;
+  p->export_stale = 0;
+  p->in_flush = false;
   p->ev_exp_luma[0] = p->ev_exp_luma[1] = p->ev_exp_chroma = p->ev_chroma_done = nullptr;
   if (pipe_init(p) != ODHIP_SUCCESS) {
     odhip_pipe_destroy(p);
@@ -846,32 +852,46 @@ extern "C" int odhip_pipe_feed(odhip_pipe *p, const uint8_t *luma, const uint8_t
   return ODHIP_SUCCESS;
 }
 
-/* Bytes one step exports (odhip_pipe_set_export), 0 for the modes that do not export. */
+/* Size of the export buffer (odhip_pipe_set_export), 0 for the modes that do not export. */
 extern "C" size_t odhip_pipe_export_bytes(const odhip_pipe *p) {
   if (!p || !p->cfg.chroma_cfl || p->cfg.inter || !p->cfg.price) return 0;
-  size_t n = 0;
-  for (int bs = 0; bs < 5; bs++) n += export_luma_bytes(p, bs);
-  for (int bs = 0; bs < 4; bs++) n += export_chroma_bytes(p, bs);
-  return n;
+  odhip_export_layout lay;
+  if (export_layout(p, &lay) != ODHIP_SUCCESS) return 0;
+  return (size_t)lay.total_bytes;
 }
 
-/* host != NULL: every following step copies its decisions (choice records + pulse vectors of every
-   band, the layout above export_luma_bytes) to `host` - odhip_pipe_export_bytes(p) bytes of pinned
-   host memory - on the pipe's export stream, overlapped with the rest of the step; the buffer holds
-   step i once odhip_pipe_sync() returns after step i (a band the host-libm resolve re-decides one
-   step late - none on any content measured - is not re-exported).  NULL: stop exporting.  Keyframe
-   steps with chroma from luma and pricing on the device only (ODHIP_EIMPL otherwise). */
+extern "C" int odhip_pipe_export_layout(const odhip_pipe *p, odhip_export_layout *out) {
+  if (!p || !out) return ODHIP_EINVAL;
+  if (odhip_pipe_export_bytes(p) == 0) return ODHIP_EIMPL;
+  return export_layout(p, out);
+}
+
+extern "C" long odhip_pipe_export_stale(const odhip_pipe *p) {
+  return p ? p->export_stale : 0;
+}
+
+/* host != NULL: every following step leaves its decisions - record and pulses of every band, compacted on the
+   device (export_kernels.hip) - in `host`, odhip_pipe_export_bytes(p) bytes of pinned host memory, on the
+   pipe's export stream, overlapped with the rest of the step; the buffer holds step i once odhip_pipe_sync()
+   returns after step i.  NULL: stop exporting.  Keyframe steps with chroma from luma and pricing on the
+   device only (ODHIP_EIMPL otherwise). */
 extern "C" int odhip_pipe_set_export(odhip_pipe *p, void *host) {
   if (!p) return ODHIP_EINVAL;
   if (host && odhip_pipe_export_bytes(p) == 0) return ODHIP_EIMPL;
   const int rc = odhip_pipe_sync(p);
   if (rc) return rc;
   ODHIP_TRY(hipSetDevice(p->cfg.device));
-  if (host && !p->export_stream) {
-    ODHIP_TRY(hipStreamCreateWithFlags(&p->export_stream, hipStreamNonBlocking));
+  if (host) {
+    /* each object on its own: a call that failed half way is completed by the next one */
+    if (!p->export_stream) ODHIP_TRY(hipStreamCreateWithFlags(&p->export_stream, hipStreamNonBlocking));
     for (hipEvent_t *e : {&p->ev_exp_luma[0], &p->ev_exp_luma[1], &p->ev_exp_chroma, &p->ev_chroma_done}) {
-      ODHIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
+      if (!*e) ODHIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
     }
+  }
+  if (host && !p->export_dev) {
+    STEP_TRY(export_layout(p, &p->export_lay));
+    PIPE_ALLOC(p, p->export_dev, (size_t)p->export_lay.total_bytes, false);
+    ODHIP_TRY(hipMemset(p->export_dev, 0, (size_t)p->export_lay.fixed_bytes));
   }
   p->export_host = static_cast<uint8_t *>(host);
   return ODHIP_SUCCESS;
@@ -900,7 +920,10 @@ extern "C" int odhip_pipe_flush(odhip_pipe *p) {
     STEP_TRY(inter_finish(p, 0));
     return inter_finish(p, 1);
   }
-  return finish_pending(p);
+  p->in_flush = true;
+  const int rc = finish_pending(p);
+  p->in_flush = false;
+  return rc;
 }
 
 /* Inter mode: the prediction pictures (what motion compensation produced for each picture

@@ -1148,17 +1148,74 @@ int odhip_pipe_set_pictures(odhip_pipe *p, const uint8_t *luma, const uint8_t *c
    odhip_pipe_sync (or any later odhip_pipe_feed of the same pipe followed by a sync).
      for (;;) { odhip_pipe_feed(p, next_luma, next_chroma); odhip_pipe_step(p); ... } */
 int odhip_pipe_feed(odhip_pipe *p, const uint8_t *luma, const uint8_t *chroma);
+/* ---- the decisions of a step in the form a host entropy coder reads them (export_kernels.hip) ----
+   What od_pvq_encode hands to its entropy coder per band (src/pvq_encoder.c:874-979, the arguments of
+   pvq_encode_partition): the coded gain index, theta and its range, K, the skip / no-reference flags and
+   the pulse vector - K pulses over n positions, nearly all zero.  One SECTION per (plane set, level):
+     records     odhip_export_record [blocks][bands]
+     stream      uint16 words.  The words of a band are consecutive; the bands of one GROUP (the
+                 ODHIP_EXPORT_GROUP_BANDS consecutive records g*256 ..) follow each other in record order;
+                 group g starts at word group_base[g] of the section's stream (groups are placed in the
+                 order their workgroups finish: placement varies from run to run, content does not).
+     word        bits 0-6 the position inside the band, bits 7-15 the signed pulse count (-255 .. 255); a
+                 count of -256 is an escape - the next word holds the count as an int16.
+   A band with nwords == 0 holds no pulse (skipped, null gain, or K = 0).  Header first: words written per
+   section, and a flag per section that is set when a stream outgrew its capacity (as many words as the
+   level has coefficients; never seen - the dense vectors remain readable through odhip_pipe_read). */
+#define ODHIP_EXPORT_GROUP_BANDS 256
+#define ODHIP_EXPORT_MAX_SECTIONS 16
+#define ODHIP_EXPORT_NOREF 1             /* flags bit 0: coded without reference (pvq_theta's noref) */
+                                         /* flags bits 1-2: skip (0, OD_PVQ_SKIP_ZERO 1, OD_PVQ_SKIP_COPY 2) */
+typedef struct {
+  int16_t qg;          /* the coded gain index: pvq_theta's return value (:636-637); 0 = null without reference */
+  int16_t itheta;      /* -1 without reference */
+  int16_t max_theta;
+  uint16_t k;          /* K of the chosen candidate = SUM |y_j| of a coded band's pulses (saturates at 65535) */
+  uint8_t flags;
+  uint8_t reserved;
+  uint16_t nwords;     /* words of this band in the stream */
+} odhip_export_record;  /* 12 bytes */
+typedef struct {
+  uint32_t total_words[ODHIP_EXPORT_MAX_SECTIONS];
+  uint32_t overflow[ODHIP_EXPORT_MAX_SECTIONS];
+} odhip_export_header;
+typedef struct {
+  int32_t bs;
+  uint32_t ngroups;
+  uint32_t cap_words;
+  uint32_t pad;
+  uint64_t nrecords;         /* blocks x bands */
+  uint64_t records_off;      /* byte offsets from the start of the buffer, multiples of 16 */
+  uint64_t group_base_off;   /* uint32 [ngroups] */
+  uint64_t stream_off;
+} odhip_export_section;
+typedef struct {
+  int32_t nsections;
+  int32_t pad;
+  uint64_t fixed_bytes;      /* header + records + group bases of every section (always shipped) */
+  uint64_t total_bytes;      /* the whole buffer: fixed part + the streams at full capacity */
+  odhip_export_section section[ODHIP_EXPORT_MAX_SECTIONS];
+} odhip_export_layout;
+int odhip_export_layout_make(odhip_export_layout *lay, int nsections, const long *nblocks, const int *bs);
+int odhip_export_begin(void *d_buf, const odhip_export_layout *lay, odhip_stream stream);
+int odhip_export_pack(void *d_buf, const odhip_export_layout *lay, int section, const int32_t *d_choice,
+ const int16_t *d_y, long nblocks, int bs, int with_ref, odhip_stream stream);
+int odhip_export_ship(void *pinned_host, const void *d_buf, const odhip_export_layout *lay, odhip_stream stream);
+
 /* The OUTPUT side of a streaming host (SURVEY hard part 5: "timed GPU-side incl. transfers"): with a
-   host buffer set, every following step copies what a host entropy coder consumes - the choice
-   record and the pulse vector of every band (what od_pvq_encode would hand to
-   od_encode_pvq_codeword, src/pvq_encoder.c:789-979) - to pinned host memory on a third stream,
-   overlapped with the rest of the step.  Per luma level: int32 [blocks][bands][4] choice records,
-   int16 [2][blocks][len] pulse vectors (the winner lies in the slot its record names); per chroma
-   level: int32 [blocks][bands][16] and int16 [blocks][len] (slot 0 holds the winner).
-   odhip_pipe_export_bytes: bytes per step (0: this pipe's mode does not export - keyframe steps
-   with chroma from luma and device pricing only).  The buffer holds step i after the
-   odhip_pipe_sync that follows it. */
+   host buffer set, every following step leaves what a host entropy coder consumes - the record and the
+   pulses of every band of every level, compacted as above (sections: luma levels 0..4, then chroma
+   levels 0..3) - in pinned host memory, packed and shipped on a third stream behind the stage that
+   produced it, overlapped with the rest of the step.  odhip_pipe_export_layout: the offsets;
+   odhip_pipe_export_bytes: the size the host buffer must have (= total_bytes; only the used part of
+   every stream crosses the bus; 0: this pipe's mode does not export - keyframe steps with chroma from
+   luma and device pricing only).  The buffer holds step i after the odhip_pipe_sync that follows it.
+   A band that the host-libm resolve re-decides one step late (none on any content measured) is shipped
+   again when that happens inside odhip_pipe_flush - step, flush, sync, read is exact - and counted by
+   odhip_pipe_export_stale when it happens inside the next step, i.e. after the host read the buffer. */
 size_t odhip_pipe_export_bytes(const odhip_pipe *p);
+int odhip_pipe_export_layout(const odhip_pipe *p, odhip_export_layout *out);
+long odhip_pipe_export_stale(const odhip_pipe *p);
 int odhip_pipe_set_export(odhip_pipe *p, void *pinned_host);
 /* Inter mode (odhip_pipe_config.inter): the prediction pictures of the batch, same layouts
    and depth as odhip_pipe_set_pictures. */
@@ -1179,6 +1236,11 @@ int odhip_pipe_record(odhip_pipe *p, int enable);
 int odhip_pipe_timings(odhip_pipe *p, double avg_ms[ODHIP_PIPE_NSTAGES], int count[ODHIP_PIPE_NSTAGES]);
 int odhip_pipe_search_timings(odhip_pipe *p, int chroma, float *ms, int max_n);
 int odhip_pipe_time_pyramid(odhip_pipe *p, int n, double *avg_ms);
+/* The practical HBM ceiling beside the 8 TB/s specification: a device-to-device copy of
+   `bytes` (a multiple of 16; scratch owned by the call) in 16-byte vectors, n timed launches after a
+   warm-up, (read + written) bytes per second in GB/s.  variant 0 / 1 / 2: 2 / 4 / 8 vectors in flight
+   per lane. */
+int odhip_copy_ceiling(size_t bytes, int n, int variant, double *gbs, odhip_stream stream);
 /* One stage of the filter + DCT path (ODHIP_PIPE_PAD_*, _PYRAMID_*, _INVERSE_*) launched n times on
    the idle GPU over the buffers the last step left: average milliseconds per launch group (the
    roofline_* entries of bench.py).  parity as for odhip_pipe_stage, -1 = the last step's. */

@@ -104,6 +104,24 @@ static void thread_register(void) {
   (void)pthread_once(&g_thread_key_once, thread_key_make);
   (void)pthread_setspecific(g_thread_key, (void *)1);
 }
+/* Every bound surface counts its calls per thread: the first one registers the thread, so that a
+   thread that never creates a cache still folds its counters at exit. */
+static __thread int t_registered;
+#define COUNT_CALL(i) \
+  do { \
+    if (!t_registered) { \
+      t_registered = 1; \
+      thread_register(); \
+    } \
+    t_calls[i]++; \
+  } while (0)
+/* Running totals of this thread's caches as of its last flush (odhip_glue_flush_stats): fdct hits /
+   misses, band hits / misses, dering launches / served. */
+static __thread long t_cache_seen[6];
+static void cache_seen_reset(int from, int to) {
+  int i;
+  for (i = from; i < to; i++) t_cache_seen[i] = 0;
+}
 
 /* od_state_opt_vtbl_init (src/state.c:346-352): the reference's backend
    dispatch.  With bind_dct_vtbl this is the load-time form of the one
@@ -139,7 +157,7 @@ void od_state_opt_vtbl_init(void *state) {
 }
 
 void od_prefilter_split(od_coeff *c0, int stride, int bs, int f, int hfilter, int vfilter) {
-  t_calls[0]++;
+  COUNT_CALL(0);
   if (!cfg()->bind_filters) {
     typedef void (*fn)(od_coeff *, int, int, int, int, int);
     static fn next;
@@ -152,7 +170,7 @@ void od_prefilter_split(od_coeff *c0, int stride, int bs, int f, int hfilter, in
 
 void od_postfilter_split(od_coeff *c0, int stride, int bs, int f, int q, unsigned char *skip,
  int skip_stride, int hfilter, int vfilter) {
-  t_calls[1]++;
+  COUNT_CALL(1);
   if (!cfg()->bind_filters) {
     typedef void (*fn)(od_coeff *, int, int, int, int, unsigned char *, int, int, int);
     static fn next;
@@ -167,7 +185,7 @@ static void glue_load_plane(const od_coeff *c, int stride, int nhsb, int nvsb, i
 
 void od_apply_prefilter_frame_sbs(od_coeff *c, int stride, int nhsb, int nvsb, int xdec,
  int ydec) {
-  t_calls[2]++;
+  COUNT_CALL(2);
   glue_load_plane(c, stride, nhsb, nvsb, xdec);
   if (!cfg()->bind_filters) {
     typedef void (*fn)(od_coeff *, int, int, int, int, int);
@@ -220,6 +238,7 @@ static odhip_dering_cache *thread_dering_cache(void) {
       fprintf(stderr, "daala_hip_glue: odhip_dering_cache_create failed (no CPU fallback)\n");
       abort();
     }
+    cache_seen_reset(4, 6);
     thread_register();
   }
   return g_dering_cache;
@@ -266,7 +285,7 @@ int odhip_glue_check_dist(void) {
 
 void od_apply_postfilter_frame_sbs(od_coeff *c, int stride, int nhsb, int nvsb, int xdec,
  int ydec, int q, unsigned char *skip, int skip_stride) {
-  t_calls[3]++;
+  COUNT_CALL(3);
   if (dering_cache_enabled()) {
     /* the frame boundary of the level search (the encoder laps every plane just before it) */
     odhip_dering_cache_begin(thread_dering_cache());
@@ -289,7 +308,7 @@ void od_apply_postfilter_frame_sbs(od_coeff *c, int stride, int nhsb, int nvsb, 
 
 double pvq_search_rdo_double(const int16_t *xcoeff, int n, int k, od_coeff *ypulse, double g2,
  double pvq_norm_lambda, int prev_k) {
-  t_calls[4]++;
+  COUNT_CALL(4);
   if (!cfg()->bind_search) {
     typedef double (*fn)(const int16_t *, int, int, od_coeff *, double, double, int);
     static fn next;
@@ -323,6 +342,9 @@ static odhip_frame_cache *thread_cache(void) {
     }
     odhip_cache_set_picture(g_cache, cfg()->pic_w, cfg()->pic_h);
     odhip_cache_make_current(g_cache);
+    /* a new cache counts from zero: what was seen of an earlier one is forgotten HERE (not inferred
+       from the totals going backwards, which a busy new cache never does) */
+    cache_seen_reset(0, 4);
     thread_register();
   }
   return g_cache;
@@ -362,7 +384,6 @@ static void ms_add(double *acc, const struct timespec *a) {
 }
 /* Cache figures of every thread, folded as deltas (a thread's caches keep running totals). */
 static long g_cache_tot[6];            /* fdct hits / misses, band hits / misses, dering launches / served */
-static __thread long t_cache_seen[6];
 /* The calling thread's counters and timers into the process totals. */
 void odhip_glue_flush_stats(void) {
   int i;
@@ -377,8 +398,8 @@ void odhip_glue_flush_stats(void) {
   while (__atomic_exchange_n(&g_ms_lock, 1, __ATOMIC_ACQUIRE)) {
   }
   for (i = 0; i < 6; i++) {
-    /* a cache that was re-created starts from zero again */
-    g_cache_tot[i] += cur[i] >= t_cache_seen[i] ? cur[i] - t_cache_seen[i] : cur[i];
+    /* (t_cache_seen is zeroed where a cache is created or destroyed: cur >= seen always) */
+    g_cache_tot[i] += cur[i] - t_cache_seen[i];
     t_cache_seen[i] = cur[i];
   }
   for (i = 0; i < 6; i++) {
@@ -721,7 +742,7 @@ int pvq_theta(od_coeff *out, const od_coeff *x0, const od_coeff *r0, int n, int 
 void od_dering(const void *vtbl, int16_t *y, int ystride, const int16_t *x, int xstride, int nhb, int nvb,
  int sbx, int sby, int nhsb, int nvsb, int xdec, int dir[8][8], int pli, unsigned char *bskip,
  int skip_stride, int threshold, int overlap, int coeff_shift) {
-  t_calls[5]++;
+  COUNT_CALL(5);
   if (dering_cache_enabled()) {
     (void)thread_dering_cache();
     struct timespec t_a;

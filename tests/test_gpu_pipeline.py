@@ -349,14 +349,18 @@ def test_device_priced_step_across_quantisers(quality, masking, hvs):
 
 
 def test_exported_decisions_are_the_device_buffers():
-    """odhip_pipe_set_export (the output side of the PCIe-inclusive rate): fed steps whose choice
-    records and pulse vectors leave for pinned host memory on a third stream.  After the sync that
-    follows step i the host buffer holds, level by level, exactly what the device buffers of step i
-    hold (read back through odhip_pipe_read), for odd and even steps (the luma outputs are
-    double-buffered by step parity, the chroma ones shared); the reconstruction is the one of the
-    same steps without export; a pipe mode that cannot export says so."""
+    """odhip_pipe_set_export (the output side of the PCIe-inclusive rate): fed steps whose decisions - the
+    record and the pulses of every band, compacted on the device (export_kernels.hip: 12-byte records + 16-bit
+    (position, count) words) - leave for pinned host memory on a third stream.  After the sync that follows
+    step i the host buffer DECODES (daala_amd.decode_export_sections, the reference-side reader of the format)
+    to exactly what the dense device buffers of step i hold (gain index, theta, its range, K, skip and every
+    pulse of every band of every level, read back through odhip_pipe_read), for odd and even steps (the luma
+    outputs are double-buffered by step parity, the chroma ones shared); far fewer bytes cross the bus than
+    the dense vectors hold; the reconstruction is the one of the same steps without export; a pipe mode that
+    cannot export says so."""
     import torch
     import daala_amd as D
+    import _pipeline_check as C
     D.init(0)
     b = _bench()
     qt = D.QuantTables.load()
@@ -371,7 +375,8 @@ def test_exported_decisions_are_the_device_buffers():
     pipe = D.Pipe(qt, F, pw, ph, chroma_cfl=True, price=True)
     plain = D.Pipe(qt, F, pw, ph, chroma_cfl=True, price=True)
     nbytes = pipe.export_bytes()
-    assert nbytes > 0
+    lay = pipe.export_layout()
+    assert nbytes == lay["total_bytes"] > lay["fixed_bytes"] > 0 and lay["nsections"] == 9
     host = torch.zeros(nbytes, dtype=torch.uint8).pin_memory()
     pinned = [(torch.from_numpy(l).pin_memory(), torch.from_numpy(c).pin_memory()) for l, c in sets]
     pipe.set_export(host)
@@ -383,20 +388,20 @@ def test_exported_decisions_are_the_device_buffers():
             continue          # from the third step on every wait of the export path has a predecessor
         pipe.flush()
         pipe.sync()
-        got = host.numpy()
-        pos = 0
-        for set_ in (0, 1):
-            for bs in range(5 - set_):
-                ch = pipe.read(D.BUF_CHOICE, set_, bs)
-                assert np.array_equal(got[pos:pos + ch.size], ch), (step, set_, bs, "choice")
-                pos += ch.size
-                y = pipe.read(D.BUF_Y, set_, bs)
-                if set_:
-                    nb, offs, ln = D.pvq_band_layout(bs)
-                    y = y[:pipe.nblocks(1, bs) * ln * 2]          # slot 0: the winners' vectors
-                assert np.array_equal(got[pos:pos + y.size], y), (step, set_, bs, "pulses")
-                pos += y.size
-        assert pos == nbytes
+        got = pipe.decode_export(host.numpy())
+        want = C.gpu_decisions(D, pipe)
+        assert set(got) == set(want)
+        dense = 0
+        for key in sorted(want):
+            yw, bw, cw = want[key]
+            yg, bg, cg = got[key]
+            assert np.array_equal(cg, cw), (step, key, "coded")
+            assert np.array_equal(bg, bw), (step, key, "gain index / theta / max_theta / K")
+            assert np.array_equal(yg, yw), (step, key, "pulses")
+            dense += yw.size * 2
+        shipped = pipe.export_shipped_bytes(host.numpy())
+        assert shipped < dense / 2, (shipped, dense)
+        assert pipe.export_stale() == 0
         plain.set_pictures(*sets[step & 1])
         plain.step()
         plain.flush()
@@ -412,3 +417,89 @@ def test_exported_decisions_are_the_device_buffers():
     with pytest.raises(Exception):
         noref.set_export(host)
     noref.destroy()
+
+
+def test_export_words_escape_and_group_order():
+    """The export format on hand-made buffers (odhip_export_pack / odhip_export_ship called directly): pulse counts
+    beyond +-255 take the two-word escape, a theta winner's last position is not exported, null and skipped bands
+    carry no words, groups of 256 bands decode whatever order their workgroups finished in, and the ship kernel
+    moves exactly the used prefix of each stream."""
+    import ctypes
+    import torch
+    import daala_amd as D
+    D.init(0)
+    L = D.lib()
+    rng = np.random.RandomState(77)
+    bs_list = [0, 2, 1]
+    with_ref = [0, 0, 1]
+    nblocks = [1500, 300, 700]
+    lay_c, lay = D.export_layout_make(nblocks, bs_list)
+    dev = torch.zeros(lay["total_bytes"], dtype=torch.uint8, device="cuda")
+    host = torch.zeros(lay["total_bytes"], dtype=torch.uint8).pin_memory()
+    host.fill_(0xAB)
+    assert L.odhip_export_begin(ctypes.c_void_p(dev.data_ptr()), ctypes.byref(lay_c), None) == 0
+    want = []
+    keep = []
+    for si, (bs, wr, B) in enumerate(zip(bs_list, with_ref, nblocks)):
+        nb, offs, ln = D.pvq_band_layout(bs)
+        slots = 3 if wr else 2
+        y = np.zeros((slots, B, ln), np.int16)
+        mask = rng.rand(slots, B, ln) < 0.08
+        y[mask] = rng.randint(-6, 7, size=int(mask.sum()))
+        big = rng.rand(slots, B, ln) < 0.004
+        y[big] = rng.choice([-256, 256, -300, 1000, -32768, 32767, 255, -255], size=int(big.sum()))
+        yw = np.zeros((B, ln), np.int32)
+        band = np.zeros((B, nb, 4), np.int32)
+        coded = np.ones((B, nb), bool)
+        if wr:
+            ch = np.zeros((B, nb, 16), np.int32)
+            ch[..., 2] = rng.randint(0, 2, size=(B, nb))                      # noref
+            ch[..., 3] = rng.randint(0, 40, size=(B, nb))                     # itheta
+            ch[..., 4] = ch[..., 3] + rng.randint(1, 9, size=(B, nb))         # max_theta
+            ch[..., 5] = rng.randint(0, 500, size=(B, nb))                    # k
+            ch[..., 6] = rng.choice([0, 0, 0, 1, 2], size=(B, nb))            # skip
+            ch[..., 7] = rng.randint(-3, 300, size=(B, nb))                   # coded gain index
+            ch[..., 9] = rng.choice([-1, 0, 1, 2], size=(B, nb))              # yslot
+            for i in range(nb):
+                a, b_ = offs[i], offs[i + 1]
+                on = (ch[:, i, 6] == 0) & (ch[:, i, 9] >= 0)
+                idx = np.nonzero(on)[0]
+                v = y[ch[idx, i, 9], idx, a:b_].astype(np.int32)
+                v[ch[idx, i, 2] == 0, -1] = 0
+                yw[idx, a:b_] = v
+            band[..., 0] = ch[..., 7]
+            band[..., 1] = ch[..., 3]
+            band[..., 2] = ch[..., 4]
+            band[..., 3] = ch[..., 5]
+            coded = ch[..., 6] == 0
+        else:
+            ch = np.zeros((B, nb, 4), np.int32)
+            ch[..., 0] = rng.randint(0, 2, size=(B, nb))
+            ch[..., 1] = rng.choice([0, 1, 2, 7, 300], size=(B, nb))
+            for i in range(nb):
+                a, b_ = offs[i], offs[i + 1]
+                idx = np.nonzero(ch[:, i, 1] != 0)[0]
+                yw[idx, a:b_] = y[ch[idx, i, 0], idx, a:b_]
+                band[:, i, 3] = np.abs(yw[:, a:b_]).sum(axis=1).clip(max=65535)
+            band[..., 0] = ch[..., 1]
+            band[..., 1] = -1
+        d_ch = torch.from_numpy(ch).cuda()
+        d_y = torch.from_numpy(y).cuda()
+        keep += [d_ch, d_y]
+        assert L.odhip_export_pack(ctypes.c_void_p(dev.data_ptr()), ctypes.byref(lay_c), si, ctypes.c_void_p(d_ch.data_ptr()),
+                                   ctypes.c_void_p(d_y.data_ptr()), ctypes.c_long(B), bs, wr, None) == 0
+        want.append((yw, band, coded))
+    assert L.odhip_export_ship(ctypes.c_void_p(host.data_ptr()), ctypes.c_void_p(dev.data_ptr()), ctypes.byref(lay_c), None) == 0
+    torch.cuda.synchronize()
+    h = host.numpy()
+    got = D.decode_export_sections(h, lay)
+    for si in range(3):
+        for name, g_, w_ in zip(("pulses", "record", "coded"), got[si], want[si]):
+            assert np.array_equal(g_, w_), (si, name)
+    # only the used prefix of a stream crossed: the byte after its last 16-byte vector still holds the fill pattern
+    totals = h[:64].view(np.uint32)
+    for si, sec in enumerate(lay["sections"]):
+        used = (int(totals[si]) * 2 + 15) // 16 * 16
+        assert 0 < used < sec["cap_words"] * 2
+        assert (h[sec["stream_off"] + used:sec["stream_off"] + sec["cap_words"] * 2] == 0xAB).all()
+    assert int(h[64:128].view(np.uint32).sum()) == 0          # no overflow flag
