@@ -50,6 +50,12 @@ import time
 
 import numpy as np
 
+# A pipe that feeds pictures AND exports decisions drives five HIP streams (two chains, picture copies, export, the
+# default one); the runtime maps streams onto GPU_MAX_HW_QUEUES (default 4) hardware queues, and two streams on one
+# queue serialise - the H2D copy of the next pictures behind a chain cost 0.6 ms per step (profiles/r6_export.txt).
+# Read once, when the HIP runtime initialises: set before torch is imported.  No effect on the resident step.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
@@ -1182,7 +1188,7 @@ def main():
                 pipe.step()
             pipe.flush()
             pipe.sync()
-            io_steps = max(3, args.steps // 2)
+            io_steps = max(5, args.steps)
             s0 = time.perf_counter()
             for _ in range(io_steps):
                 pipe.feed(hl, hc)
@@ -1202,8 +1208,8 @@ def main():
                                 2 * pipe.nblocks(s_, b_) * D.pvq_band_layout(b_)[2] for s_ in (0, 1) for b_ in range(5 - s_))
                                 // args.frames),
                             "export_buffer_bytes": int(nbytes), "stale_exports": int(stale),
-                            "note": "streaming_input plus the decisions of every step - a 12-byte record (coded gain "
-                                    "index, theta and its range, K, skip / no-reference flags) and the pulses of every "
+                            "note": "streaming_input plus the decisions of every step - a 4- / 8-byte record (coded gain "
+                                    "index, theta and its range, skip / no-reference flags) and the pulses of every "
                                     "band of every level as 16-bit (position, count) words, what a host entropy coder "
                                     "consumes - compacted on the device and shipped to pinned host memory on a third "
                                     "stream behind the stage that produced them (odhip_pipe_set_export, "

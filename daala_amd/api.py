@@ -994,18 +994,19 @@ class _PipeConfig(ctypes.Structure):
                 ("pvq_norm_lambda", ctypes.c_double), ("quant", ctypes.c_void_p)]
 
 
-def export_layout_make(nblocks, bs):
+def export_layout_make(nblocks, bs, with_ref):
     """odhip_export_layout_make for sections of nblocks[i] blocks at level bs[i] -> (ctypes layout, dict)."""
     lay = _ExportLayout()
     n = len(bs)
-    _check(lib().odhip_export_layout_make(ctypes.byref(lay), n, (ctypes.c_long * n)(*nblocks), (ctypes.c_int * n)(*bs)),
+    _check(lib().odhip_export_layout_make(ctypes.byref(lay), n, (ctypes.c_long * n)(*nblocks), (ctypes.c_int * n)(*bs),
+                                          (ctypes.c_int * n)(*[int(bool(w)) for w in with_ref])),
            "odhip_export_layout_make")
     return lay, _layout_dict(lay)
 
 
 def _layout_dict(lay):
-    secs = [{k: int(getattr(lay.section[i], k)) for k in ("bs", "ngroups", "cap_words", "nrecords", "records_off",
-                                                         "group_base_off", "stream_off")}
+    secs = [{k: int(getattr(lay.section[i], k)) for k in ("bs", "ngroups", "cap_words", "blocks_per_group", "record_bytes",
+                                                         "nrecords", "records_off", "group_base_off", "stream_off")}
             for i in range(lay.nsections)]
     return {"nsections": int(lay.nsections), "fixed_bytes": int(lay.fixed_bytes),
             "total_bytes": int(lay.total_bytes), "sections": secs}
@@ -1015,21 +1016,22 @@ def decode_export_sections(host, lay):
     """Reference-side decoder of the export format (include/daala_hip.h, export_kernels.hip): `host` = the buffer
     as numpy uint8, `lay` = the layout dict.  Per section (y int32 [B][len], band int32 [B][nb][4] = {coded gain
     index, itheta, max_theta, k}, coded bool [B][nb]).  A host entropy coder walks the same records and words
-    sequentially; this vectorised form exists for the tests and the bench."""
+    sequentially; this vectorised form exists for the tests and the bench.  k of a band that is not coded is 0."""
     hdr = host[:128].view(np.uint32)
     out = []
-    rec_dt = np.dtype([("qg", "<i2"), ("itheta", "<i2"), ("max_theta", "<i2"), ("k", "<u2"), ("flags", "u1"),
-                       ("reserved", "u1"), ("nwords", "<u2")])
-    G = 256
+    rec4 = np.dtype([("qg", "<i2"), ("fn", "<u2")])
+    rec8 = np.dtype([("qg", "<i2"), ("itheta", "<i2"), ("max_theta", "<i2"), ("fn", "<u2")])
     for si, sec in enumerate(lay["sections"]):
         nb, offs, ln = pvq_band_layout(sec["bs"])
+        G = sec["blocks_per_group"] * nb          # records per group
         B = sec["nrecords"] // nb
         assert int(hdr[16 + si]) == 0, "export stream of section %d overflowed" % si
-        rec = host[sec["records_off"]:sec["records_off"] + sec["nrecords"] * 12].view(rec_dt)
+        rb = sec["record_bytes"]
+        rec = host[sec["records_off"]:sec["records_off"] + sec["nrecords"] * rb].view(rec8 if rb == 8 else rec4)
         gbase = host[sec["group_base_off"]:sec["group_base_off"] + sec["ngroups"] * 4].view(np.uint32).astype(np.int64)
         total = int(hdr[si])
         words = host[sec["stream_off"]:sec["stream_off"] + total * 2].view(np.uint16)
-        nw = rec["nwords"].astype(np.int64)
+        nw = (rec["fn"] & 0x1ff).astype(np.int64)
         assert total == int(nw.sum()), (si, total, int(nw.sum()))
         # first word of every band: its group's base + the words of the group's earlier bands
         pad = (-len(nw)) % G
@@ -1059,17 +1061,20 @@ def decode_export_sections(host, lay):
         band = np.zeros((B, nb, 4), np.int32)
         r = rec.reshape(B, nb)
         band[..., 0] = r["qg"]
-        band[..., 1] = r["itheta"]
-        band[..., 2] = r["max_theta"]
-        band[..., 3] = r["k"]
-        coded = ((r["flags"] >> 1) & 3) == 0
+        band[..., 1] = r["itheta"] if rb == 8 else -1
+        band[..., 2] = r["max_theta"] if rb == 8 else 0
+        # K of a coded band = the magnitudes of its counts (not exported)
+        for i in range(nb):
+            band[:, i, 3] = np.abs(y[:, offs[i]:offs[i + 1]]).sum(axis=1)
+        coded = ((r["fn"] >> 10) & 3) == 0
         out.append((y, band, coded))
     return out
 
 
 class _ExportSection(ctypes.Structure):
     _fields_ = [("bs", ctypes.c_int32), ("ngroups", ctypes.c_uint32), ("cap_words", ctypes.c_uint32),
-                ("pad", ctypes.c_uint32), ("nrecords", ctypes.c_uint64), ("records_off", ctypes.c_uint64),
+                ("blocks_per_group", ctypes.c_uint32), ("record_bytes", ctypes.c_uint32), ("pad", ctypes.c_uint32),
+                ("nrecords", ctypes.c_uint64), ("records_off", ctypes.c_uint64),
                 ("group_base_off", ctypes.c_uint64), ("stream_off", ctypes.c_uint64)]
 
 

@@ -6,9 +6,9 @@
    arguments) is the coded gain index, theta and its range, K, the skip / no-reference flags and the pulse
    vector - K pulses over n positions, almost all of them zero.  One SECTION per (plane set, level):
 
-     records   odhip_export_record [blocks][bands], 12 bytes
-     stream    uint16 words; the words of a band are consecutive, the bands of one 256-band group
-               (odhip_export_group_bands consecutive records) are consecutive in record order, and group g
+     records   odhip_export_record4 (no reference) / odhip_export_record8 (with reference) [blocks][bands]
+     stream    uint16 words; the words of a band are consecutive, the bands of one GROUP (the records of
+               blocks_per_group = 2048/len consecutive blocks) are consecutive in record order, and group g
                starts at word group_base[g] (groups are placed in the order their workgroups finish: the
                placement differs from run to run, the decoded content does not)
      word      position within the band in bits 0-6, the signed pulse count in bits 7-15 (-255 .. 255);
@@ -23,7 +23,7 @@
 
 namespace {
 
-constexpr int kGroup = ODHIP_EXPORT_GROUP_BANDS;
+constexpr int kPackThreads = 256;
 
 struct PackArgs {
   const int32_t *choice;      /* [B][nb][4] (no reference) or [B][nb][16] (with reference) */
@@ -32,8 +32,9 @@ struct PackArgs {
   int nb;
   int len;
   int with_ref;
+  int bpg;                    /* blocks per group = per workgroup: 2048/len */
   int off[ODHIP_MAX_BANDS + 1];
-  odhip_export_record *rec;
+  void *rec;
   uint32_t *group_base;
   uint16_t *stream;
   uint32_t cap_words;
@@ -45,66 +46,86 @@ __device__ __forceinline__ int words_of(int v) {
   return v == 0 ? 0 : (v >= -255 && v <= 255) ? 1 : 2;
 }
 
-__global__ __launch_bounds__(kGroup) void k_export_pack(PackArgs a) {
-  __shared__ uint32_t s_scan[kGroup];
+/* One 16-byte chunk (eight coding positions) of one block per lane, len/8 consecutive lanes per block, 2048/len
+   blocks per workgroup: every coefficient is read once, by one aligned vector load, and a chunk never straddles a
+   band (bands start at 1, 16, 24, 32, 64, ... - the chunk at 0 holds the DC slot, which is skipped, and the first
+   seven positions of band 0).  One workgroup scan of the lanes' word counts places every band's words in record
+   order; the lane that holds a band's first chunk writes its record. */
+__global__ __launch_bounds__(kPackThreads) void k_export_pack(PackArgs a) {
+  __shared__ uint32_t s_scan[kPackThreads];
   __shared__ uint32_t s_base;
-  const long g = (long)blockIdx.x*kGroup + threadIdx.x;
-  const long nbands = a.nblocks*a.nb;
-  const bool live = g < nbands;
-  const long blk = live ? g/a.nb : 0;
-  const int i = live ? (int)(g - blk*a.nb) : 0;
-  const int n = a.off[i + 1] - a.off[i];
+  __shared__ uint32_t s_wave[kPackThreads/64];
+  const int t = threadIdx.x;
+  const int cpb = a.len >> 3;                    /* chunks per block */
+  const int bl = t/cpb;                          /* block within the group */
+  const int c = t - bl*cpb;
+  const long blk = (long)blockIdx.x*a.bpg + bl;
+  const bool live = blk < a.nblocks;
+  const int q0 = c << 3;
+  int i = 0;
+  while (i + 1 < a.nb && q0 >= a.off[i + 1]) i++;
+  const int band_first = i == 0 ? 0 : a.off[i] >> 3;          /* first chunk of the band */
+  const int band_last = (a.off[i + 1] >> 3) - 1;
+  const long g = blk*a.nb + i;
   int qg = 0;
   int itheta = -1;
   int max_theta = 0;
   int flags = 0;
-  int k_rec = 0;
-  int cnt = n;                 /* positions that hold pulses */
+  int last_q = a.off[i + 1];                     /* positions from here on hold no pulse */
   const int16_t *src = nullptr;
   if (live) {
     if (a.with_ref) {
       /* include/daala_hip.h: {item, qg, noref, itheta, max_theta, k, skip, coded gain index, .., [9] yslot} */
       const int32_t *ch = a.choice + g*16;
-      const int noref = ch[2];
-      const int skip = ch[6];
+      const int4 c0 = *reinterpret_cast<const int4 *>(ch);
+      const int4 c1 = *reinterpret_cast<const int4 *>(ch + 4);
+      const int noref = c0.z;
+      const int skip = c1.z;
       const int slot = ch[9];
-      qg = ch[7];
-      k_rec = ch[5];
-      itheta = ch[3];
-      max_theta = ch[4];
-      flags = (noref ? ODHIP_EXPORT_NOREF : 0) | (skip & 3) << 1;
-      if (skip == 0 && slot >= 0) src = a.y + ((long)slot*a.nblocks + blk)*a.len + a.off[i];
-      if (!noref) cnt = n - 1;      /* a theta winner holds n - 1 pulses (src/pvq_encoder.c:530) */
+      qg = c1.w;
+      itheta = c0.w;
+      max_theta = c1.x;
+      flags = (noref ? 1 : 0) | (skip & 3) << 1;
+      if (skip == 0 && slot >= 0) src = a.y + ((long)slot*a.nblocks + blk)*a.len;
+      if (!noref) last_q = a.off[i + 1] - 1;     /* a theta winner holds n - 1 pulses (src/pvq_encoder.c:530) */
     }
     else {
       /* {chosen slot, chosen gain index (0 = null), synthesis scale, qshift} */
-      const int32_t *ch = a.choice + g*4;
-      qg = ch[1];
-      flags = ODHIP_EXPORT_NOREF;
-      if (qg != 0) src = a.y + ((long)ch[0]*a.nblocks + blk)*a.len + a.off[i];
+      const int2 c0 = *reinterpret_cast<const int2 *>(a.choice + g*4);
+      qg = c0.y;
+      flags = 1;
+      if (qg != 0) src = a.y + ((long)c0.x*a.nblocks + blk)*a.len;
     }
   }
-  /* pass 1: words and K */
-  int nwords = 0;
-  int k = 0;
+  int v[8];
+#pragma unroll
+  for (int e = 0; e < 8; e++) v[e] = 0;
   if (src) {
-    for (int j = 0; j < cnt; j++) {
-      const int v = src[j];
-      nwords += words_of(v);
-      k += v < 0 ? -v : v;
+    const uint4 raw = *reinterpret_cast<const uint4 *>(src + q0);
+    const uint32_t w4[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+      const int q = q0 + e;
+      const int val = (int)(int16_t)(w4[e >> 1] >> ((e & 1)*16));
+      v[e] = (q >= a.off[i] && q < last_q) ? val : 0;
     }
   }
-  /* exclusive scan over the group */
-  s_scan[threadIdx.x] = (uint32_t)nwords;
-  __syncthreads();
-  for (int d = 1; d < kGroup; d <<= 1) {
-    const uint32_t t = threadIdx.x >= (unsigned)d ? s_scan[threadIdx.x - d] : 0;
-    __syncthreads();
-    s_scan[threadIdx.x] += t;
-    __syncthreads();
+  int nwords = 0;
+#pragma unroll
+  for (int e = 0; e < 8; e++) nwords += words_of(v[e]);
+  /* inclusive scan of the word counts: inside each wavefront by shuffles, the four wavefront totals through LDS */
+  uint32_t incl = (uint32_t)nwords;
+  const int lane = t & 63;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t up = __shfl_up(incl, d, 64);
+    if (lane >= d) incl += up;
   }
-  const uint32_t incl = s_scan[threadIdx.x];
-  if (threadIdx.x == kGroup - 1) {
+  if (lane == 63) s_wave[t >> 6] = incl;
+  __syncthreads();
+  for (int wv = 0; wv < (t >> 6); wv++) incl += s_wave[wv];
+  s_scan[t] = incl;
+  if (t == kPackThreads - 1) {
     const uint32_t base = atomicAdd(a.total, incl);
     s_base = base;
     a.group_base[blockIdx.x] = base;
@@ -112,30 +133,39 @@ __global__ __launch_bounds__(kGroup) void k_export_pack(PackArgs a) {
   }
   __syncthreads();
   if (!live) return;
-  uint32_t w = s_base + incl - (uint32_t)nwords;
-  if (src && w + (uint32_t)nwords <= a.cap_words) {
-    for (int j = 0; j < cnt; j++) {
-      const int v = src[j];
-      if (v == 0) continue;
-      if (v >= -255 && v <= 255) a.stream[w++] = (uint16_t)((v << 7) | j);
+  const uint32_t gbase = s_base;
+  uint32_t w = gbase + incl - (uint32_t)nwords;
+  if (nwords && gbase + s_scan[kPackThreads - 1] <= a.cap_words) {
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+      if (v[e] == 0) continue;
+      const int j = q0 + e - a.off[i];
+      if (v[e] >= -255 && v[e] <= 255) a.stream[w++] = (uint16_t)((v[e] << 7) | j);
       else {
         a.stream[w++] = (uint16_t)((-256 << 7) | j);
-        a.stream[w++] = (uint16_t)(int16_t)v;
+        a.stream[w++] = (uint16_t)(int16_t)v[e];
       }
     }
   }
-  odhip_export_record r;
-  r.qg = (int16_t)qg;
-  r.itheta = (int16_t)itheta;
-  r.max_theta = (int16_t)max_theta;
-  /* with a reference: the K of the chosen candidate as its record has it (also for a skipped band); without:
-     the pulse count (the bands decided inside their search keep no K anywhere else) */
-  if (a.with_ref) k = k_rec;
-  r.k = (uint16_t)(k > 65535 ? 65535 : k < 0 ? 0 : k);
-  r.flags = (uint8_t)flags;
-  r.reserved = 0;
-  r.nwords = (uint16_t)nwords;
-  a.rec[g] = r;
+  if (c == band_first) {
+    const int lane_last = t - c + band_last;
+    const uint32_t band_words = s_scan[lane_last] - (incl - (uint32_t)nwords);
+    const uint16_t fn = (uint16_t)(band_words | (uint32_t)flags << 9);
+    if (a.with_ref) {
+      odhip_export_record8 r;
+      r.qg = (int16_t)qg;
+      r.itheta = (int16_t)itheta;
+      r.max_theta = (int16_t)max_theta;
+      r.fn = fn;
+      static_cast<odhip_export_record8 *>(a.rec)[g] = r;
+    }
+    else {
+      odhip_export_record4 r;
+      r.qg = (int16_t)qg;
+      r.fn = fn;
+      static_cast<odhip_export_record4 *>(a.rec)[g] = r;
+    }
+  }
 }
 
 struct ShipArgs {
@@ -192,13 +222,15 @@ extern "C" int odhip_export_pack(void *d_buf, const odhip_export_layout *lay, in
   a.nb = nb;
   a.len = len;
   a.with_ref = with_ref;
-  a.rec = reinterpret_cast<odhip_export_record *>(base + sec.records_off);
+  if ((int)sec.record_bytes != (with_ref ? 8 : 4)) return ODHIP_EINVAL;
+  a.rec = base + sec.records_off;
   a.group_base = reinterpret_cast<uint32_t *>(base + sec.group_base_off);
   a.stream = reinterpret_cast<uint16_t *>(base + sec.stream_off);
   a.cap_words = sec.cap_words;
   a.total = &h->total_words[section];
   a.overflow = &h->overflow[section];
-  k_export_pack<<<sec.ngroups, kGroup, 0, (hipStream_t)stream>>>(a);
+  a.bpg = (int)sec.blocks_per_group;
+  k_export_pack<<<sec.ngroups, kPackThreads, 0, (hipStream_t)stream>>>(a);
   return odhip_check_launch();
 }
 
@@ -221,8 +253,9 @@ extern "C" int odhip_export_ship(void *host, const void *d_buf, const odhip_expo
 }
 
 /* The layout for `nsections` sections of nblocks[s] blocks at level bs[s]: offsets are multiples of 16. */
-extern "C" int odhip_export_layout_make(odhip_export_layout *lay, int nsections, const long *nblocks, const int *bs) {
-  if (!lay || nsections <= 0 || nsections > ODHIP_EXPORT_MAX_SECTIONS || !nblocks || !bs) return ODHIP_EINVAL;
+extern "C" int odhip_export_layout_make(odhip_export_layout *lay, int nsections, const long *nblocks, const int *bs,
+ const int *with_ref) {
+  if (!lay || nsections <= 0 || nsections > ODHIP_EXPORT_MAX_SECTIONS || !nblocks || !bs || !with_ref) return ODHIP_EINVAL;
   auto up16 = [](size_t v) { return (v + 15) & ~(size_t)15; };
   size_t pos = up16(sizeof(odhip_export_header));
   lay->nsections = nsections;
@@ -233,9 +266,12 @@ extern "C" int odhip_export_layout_make(odhip_export_layout *lay, int nsections,
     odhip_export_section &sec = lay->section[s];
     sec.bs = bs[s];
     sec.nrecords = (uint64_t)nblocks[s]*nb;
-    sec.ngroups = (uint32_t)((sec.nrecords + kGroup - 1)/kGroup);
+    sec.blocks_per_group = (uint32_t)(8*kPackThreads/len);
+    sec.ngroups = (uint32_t)((nblocks[s] + sec.blocks_per_group - 1)/sec.blocks_per_group);
+    sec.record_bytes = with_ref[s] ? 8 : 4;
+    sec.pad = 0;
     sec.records_off = pos;
-    pos = up16(pos + sec.nrecords*sizeof(odhip_export_record));
+    pos = up16(pos + sec.nrecords*sec.record_bytes);
     sec.group_base_off = pos;
     pos = up16(pos + (size_t)sec.ngroups*sizeof(uint32_t));
   }

@@ -103,8 +103,14 @@ struct odhip_pipe {
      every band - leaves for pinned host memory on a third stream, behind the stage that produced it */
   hipStream_t export_stream;
   uint8_t *export_host;
-  uint8_t *export_dev;            /* the packed decisions of the step being exported (export_kernels.hip) */
+  /* the packed decisions (export_kernels.hip) of the step being exported, by step parity: the used part of
+     the streams of step i leaves while step i + 1 is being packed */
+  uint8_t *export_dev[2];
   odhip_export_layout export_lay;
+  odhip_export_header *export_hdr[2];   /* pinned: the totals of that step, read by the host one step late */
+  hipEvent_t ev_exp_hdr[2];
+  hipEvent_t ev_exp_sent[2];      /* the streams of that parity's buffer have left */
+  int export_pending;             /* parity of the step whose streams have not been sent yet, -1 */
   long export_stale;              /* steps re-decided by a late resolve after their export had left */
   bool in_flush;
   hipEvent_t ev_exp_luma[2];      /* the luma outputs of parity [i] have left */
@@ -425,6 +431,7 @@ struct Current {
 int stage_pad_run(odhip_pipe *p, int si, hipStream_t s);
 int export_luma(odhip_pipe *p, int par);
 int export_chroma(odhip_pipe *p, int par);
+int export_finish(odhip_pipe *p);
 
 /* Padding is the only reader of the resident pictures: its completion frees them for the
    next feed. */
@@ -484,8 +491,8 @@ int finish_pending(odhip_pipe *p) {
   p->pending = -1;
   Current cur(p->ctx[1]);
   const bool exporting = p->export_host != nullptr;
-  /* a resolve rewrites choices and pulses of that step: not while the pack kernels read them */
-  if (exporting) ODHIP_TRY(hipStreamWaitEvent(p->stream[1], p->ev_exp_chroma, 0));
+  /* (a resolve rewrites choices and pulses of that step on the side stream: behind the pack kernels that read
+     them, which run on the same stream) */
   const auto t0 = std::chrono::steady_clock::now();
   /* with cfg.price a band re-run with the host's theta is also decided again by the resolve */
   const int n = odhip_pvq_ref_resolve_finish(p->refjobs[par], 4, p->cfg.pvq_norm_lambda, p->stream[1]);
@@ -514,7 +521,14 @@ int finish_pending(odhip_pipe *p) {
        exported again (step, flush, sync, read is exact); inside the NEXT step the host has already been told
        the buffer was complete - counted (odhip_pipe_export_stale) */
     if (p->in_flush) {
+      p->export_pending = -1;        /* (the streams packed before the resolve are not sent) */
+      ODHIP_TRY(hipStreamSynchronize(p->export_stream));
+      ODHIP_TRY(hipStreamSynchronize(p->stream[0]));
+      ODHIP_TRY(hipStreamSynchronize(p->stream[1]));
+      ODHIP_TRY(hipMemset(p->export_dev[par], 0, sizeof(odhip_export_header)));
       STEP_TRY(export_luma(p, par));
+      /* (the chroma packs, on the side stream, wait for the cleared header) */
+      ODHIP_TRY(hipStreamWaitEvent(p->stream[1], p->ev_exp_luma[par], 0));
       STEP_TRY(export_chroma(p, par));
     }
     else p->export_stale++;
@@ -672,40 +686,96 @@ int step_noref(odhip_pipe *p) {
 int export_layout(const odhip_pipe *p, odhip_export_layout *lay) {
   long nblocks[9];
   int bs[9];
+  int with_ref[9];
   for (int i = 0; i < 5; i++) {
     nblocks[i] = p->set[0].nblocks[i];
     bs[i] = i;
+    with_ref[i] = 0;
   }
   for (int i = 0; i < 4; i++) {
     nblocks[5 + i] = p->set[1].nblocks[i];
     bs[5 + i] = i;
+    with_ref[5 + i] = 1;
   }
-  return odhip_export_layout_make(lay, 9, nblocks, bs);
+  return odhip_export_layout_make(lay, 9, nblocks, bs, with_ref);
+}
+
+/* The pack kernels run INSIDE the chains, behind the stage whose outputs they read (luma: main stream, behind the
+   choice; chroma: side stream, behind the band stage): on a stream of their own they waited for the searches of
+   both chains to leave registers free (profiles/r6_overlap.txt) and held back, through their events, the band
+   stages that reuse the buffers they read - 7.2 ms per step instead of 3.6. */
+/* ODHIP_EXPORT_DBG (experiments build): bit 0 no pack kernels, bit 1 no copy of the fixed part, bit 2 no
+   stream copies - which part of the export a step pays for. */
+int export_dbg() {
+  static int v = -1;
+  if (v < 0) {
+    const char *e = ODHIP_EXP_ENV("ODHIP_EXPORT_DBG");
+    v = e ? atoi(e) : 0;
+  }
+  return v;
 }
 
 int export_luma(odhip_pipe *p, int par) {
-  hipStream_t x = p->export_stream;
-  ODHIP_TRY(hipStreamWaitEvent(x, p->ev_refs[par], 0));         /* the luma choices of this step are final */
-  STEP_TRY(odhip_export_begin(p->export_dev, &p->export_lay, x));
-  for (int bs = 0; bs < 5; bs++) {
+  hipStream_t s = p->stream[0];
+  for (int bs = 0; bs < 5 && !(export_dbg() & 1); bs++) {
     const odhip_pvq_job &j = p->jobs[par][bs];
-    STEP_TRY(odhip_export_pack(p->export_dev, &p->export_lay, bs, j.cands.choice, j.cands.y, p->set[0].nblocks[bs], bs,
-     0, x));
+    STEP_TRY(odhip_export_pack(p->export_dev[par], &p->export_lay, bs, j.cands.choice, j.cands.y, p->set[0].nblocks[bs],
+     bs, 0, s));
   }
-  ODHIP_TRY(hipEventRecord(p->ev_exp_luma[par], x));
+  ODHIP_TRY(hipEventRecord(p->ev_exp_luma[par], s));
   return ODHIP_SUCCESS;
 }
 
+/* The chroma sections, then everything whose size the host knows - header, records, group bases - on its way on
+   the export stream (copy engine: no compute unit involved).  The streams follow in export_finish. */
 int export_chroma(odhip_pipe *p, int par) {
+  hipStream_t s = p->stream[1];
   hipStream_t x = p->export_stream;
-  ODHIP_TRY(hipEventRecord(p->ev_chroma_done, p->stream[1]));
-  ODHIP_TRY(hipStreamWaitEvent(x, p->ev_chroma_done, 0));
-  for (int bs = 0; bs < 4; bs++) {
+  for (int bs = 0; bs < 4 && !(export_dbg() & 1); bs++) {
     const odhip_pvq_refjob &j = p->refjobs[par][bs];
-    STEP_TRY(odhip_export_pack(p->export_dev, &p->export_lay, 5 + bs, j.choice, j.y, p->set[1].nblocks[bs], bs, 1, x));
+    STEP_TRY(odhip_export_pack(p->export_dev[par], &p->export_lay, 5 + bs, j.choice, j.y, p->set[1].nblocks[bs], bs, 1,
+     s));
   }
-  ODHIP_TRY(hipEventRecord(p->ev_exp_chroma, x));
-  return odhip_export_ship(p->export_host, p->export_dev, &p->export_lay, x);
+  ODHIP_TRY(hipEventRecord(p->ev_exp_chroma, s));
+  /* the totals travel IN the chain (like the band stages' counts): on the export stream even this 128-byte copy
+     waited for the searches */
+  ODHIP_TRY(hipStreamWaitEvent(s, p->ev_exp_luma[par], 0));
+  if (!(export_dbg() & 8)) {
+    ODHIP_TRY(hipMemcpyAsync(p->export_hdr[par], p->export_dev[par], sizeof(odhip_export_header), hipMemcpyDeviceToHost, s));
+  }
+  ODHIP_TRY(hipEventRecord(p->ev_exp_hdr[par], s));
+  ODHIP_TRY(hipStreamWaitEvent(x, p->ev_exp_hdr[par], 0));
+  if (!(export_dbg() & 2)) {
+    ODHIP_TRY(hipMemcpyAsync(p->export_host, p->export_dev[par], (size_t)p->export_lay.fixed_bytes, hipMemcpyDeviceToHost, x));
+  }
+  p->export_pending = par;
+  return ODHIP_SUCCESS;
+}
+
+/* The used part of every stream of the step packed last, once its totals have reached the host: called one
+   step late (behind finish_pending, when the chroma band stage of that step is known to have ended) and from
+   odhip_pipe_sync. */
+int export_finish(odhip_pipe *p) {
+  if (p->export_pending < 0) return ODHIP_SUCCESS;
+  const int par = p->export_pending;
+  p->export_pending = -1;
+  if (!p->export_host) return ODHIP_SUCCESS;
+  if (!(export_dbg() & 16)) ODHIP_TRY(hipEventSynchronize(p->ev_exp_hdr[par]));
+  const odhip_export_header *h = p->export_hdr[par];
+  for (int s = 0; s < p->export_lay.nsections; s++) {
+    const odhip_export_section &sec = p->export_lay.section[s];
+    uint32_t words = h->total_words[s];
+    if (words > sec.cap_words) words = sec.cap_words;
+    const size_t bytes = ((size_t)words*2 + 15) & ~(size_t)15;
+    if (bytes && !(export_dbg() & 4)) {
+      ODHIP_TRY(hipMemcpyAsync(p->export_host + sec.stream_off, p->export_dev[par] + sec.stream_off, bytes,
+       hipMemcpyDeviceToHost, p->export_stream));
+    }
+  }
+  /* export_dev[par] is packed again two steps later: totals and flags cleared for it */
+  STEP_TRY(odhip_export_begin(p->export_dev[par], &p->export_lay, p->export_stream));
+  ODHIP_TRY(hipEventRecord(p->ev_exp_sent[par], p->export_stream));
+  return ODHIP_SUCCESS;
 }
 
 int step_cfl(odhip_pipe *p) {
@@ -715,10 +785,12 @@ int step_cfl(odhip_pipe *p) {
   const bool exporting = p->export_host != nullptr;
   {
     Current cur(p->ctx[0]);
-    /* exporting: the band stage overwrites the choices and pulses of step i - 2, which must have left */
-    if (exporting) ODHIP_TRY(hipStreamWaitEvent(main, p->ev_exp_luma[par], 0));
     STEP_TRY(luma_front(p, main, par));
     STEP_TRY(luma_choose(p, main, par));
+    /* this parity's export buffer: its last contents (step i - 2) have left and its header has been cleared behind
+       them, on the export stream (export_finish) - not here: even a 128-byte memset in this chain waits for the
+       other chain's searches to leave registers free (profiles/r6_overlap.txt) */
+    if (exporting) ODHIP_TRY(hipStreamWaitEvent(main, p->ev_exp_sent[par], 0));
     /* the luma choices of this step are final: the chroma chain takes its references from
        them (odhip_pvq_refjob.luma) */
     ODHIP_TRY(hipEventRecord(p->ev_refs[par], main));
@@ -726,13 +798,13 @@ int step_cfl(odhip_pipe *p) {
     STEP_TRY(stage_inverse_noref(p, 0, main, par));
   }
   STEP_TRY(finish_pending(p));
+  /* (the chroma band stage of the previous step has ended: its export is packed or about to be) */
+  if (exporting) STEP_TRY(export_finish(p));
   {
     Current cur(p->ctx[1]);
     STEP_TRY(stage_pad(p, 1, side));
     STEP_TRY(stage_pyramid(p, 1, side));
     ODHIP_TRY(hipStreamWaitEvent(side, p->ev_refs[par], 0));
-    /* exporting: the two parities share the chroma outputs - those of step i - 1 must have left */
-    if (exporting) ODHIP_TRY(hipStreamWaitEvent(side, p->ev_exp_chroma, 0));
     STEP_TRY(chroma_bands(p, par, side));
     /* only the preparation kernels of the band stage read the luma choices */
     ODHIP_TRY(hipEventRecord(p->ev_used[par], side));
@@ -771,7 +843,11 @@ extern "C" odhip_pipe *odhip_pipe_create(const odhip_pipe_config *cfg) {
   p->fed = false;
   p->export_stream = nullptr;
   p->export_host = nullptr;
-  p->export_dev = nullptr;
+  p->export_dev[0] = p->export_dev[1] = nullptr;
+  p->export_hdr[0] = p->export_hdr[1] = nullptr;
+  p->ev_exp_hdr[0] = p->ev_exp_hdr[1] = nullptr;
+  p->ev_exp_sent[0] = p->ev_exp_sent[1] = nullptr;
+  p->export_pending = -1;
   p->export_stale = 0;
   p->in_flush = false;
   p->ev_exp_luma[0] = p->ev_exp_luma[1] = p->ev_exp_chroma = p->ev_chroma_done = nullptr;
@@ -798,6 +874,11 @@ extern "C" void odhip_pipe_destroy(odhip_pipe *p) {
   if (p->copy_stream) (void)hipStreamDestroy(p->copy_stream);
   for (hipEvent_t e : {p->ev_exp_luma[0], p->ev_exp_luma[1], p->ev_exp_chroma, p->ev_chroma_done}) {
     if (e) (void)hipEventDestroy(e);
+  }
+  for (int i = 0; i < 2; i++) {
+    if (p->ev_exp_hdr[i]) (void)hipEventDestroy(p->ev_exp_hdr[i]);
+    if (p->ev_exp_sent[i]) (void)hipEventDestroy(p->ev_exp_sent[i]);
+    if (p->export_hdr[i]) (void)hipHostFree(p->export_hdr[i]);
   }
   if (p->export_stream) (void)hipStreamDestroy(p->export_stream);
   if (p->stream[1] && p->stream[1] != p->stream[0]) (void)hipStreamDestroy(p->stream[1]);
@@ -888,10 +969,20 @@ extern "C" int odhip_pipe_set_export(odhip_pipe *p, void *host) {
       if (!*e) ODHIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
     }
   }
-  if (host && !p->export_dev) {
+  if (host && !p->export_dev[0]) {
     STEP_TRY(export_layout(p, &p->export_lay));
-    PIPE_ALLOC(p, p->export_dev, (size_t)p->export_lay.total_bytes, false);
-    ODHIP_TRY(hipMemset(p->export_dev, 0, (size_t)p->export_lay.fixed_bytes));
+    for (int i = 0; i < 2; i++) {
+      PIPE_ALLOC(p, p->export_dev[i], (size_t)p->export_lay.total_bytes, false);
+      ODHIP_TRY(hipMemset(p->export_dev[i], 0, (size_t)p->export_lay.fixed_bytes));
+      ODHIP_TRY(hipHostMalloc((void **)&p->export_hdr[i], sizeof(odhip_export_header), hipHostMallocDefault));
+      ODHIP_TRY(hipEventCreateWithFlags(&p->ev_exp_hdr[i], hipEventDisableTiming));
+      ODHIP_TRY(hipEventCreateWithFlags(&p->ev_exp_sent[i], hipEventDisableTiming));
+    }
+  }
+  p->export_pending = -1;
+  if (host) {
+    /* (the pipe is idle: odhip_pipe_sync above) */
+    for (int i = 0; i < 2; i++) ODHIP_TRY(hipMemset(p->export_dev[i], 0, sizeof(odhip_export_header)));
   }
   p->export_host = static_cast<uint8_t *>(host);
   return ODHIP_SUCCESS;
@@ -948,7 +1039,10 @@ extern "C" int odhip_pipe_sync(odhip_pipe *p) {
   ODHIP_TRY(hipStreamSynchronize(p->stream[0]));
   if (p->stream[1] != p->stream[0]) ODHIP_TRY(hipStreamSynchronize(p->stream[1]));
   ODHIP_TRY(hipStreamSynchronize(p->copy_stream));
-  if (p->export_stream) ODHIP_TRY(hipStreamSynchronize(p->export_stream));
+  if (p->export_stream) {
+    STEP_TRY(export_finish(p));
+    ODHIP_TRY(hipStreamSynchronize(p->export_stream));
+  }
   return ODHIP_SUCCESS;
 }
 

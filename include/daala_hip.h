@@ -1152,29 +1152,34 @@ int odhip_pipe_feed(odhip_pipe *p, const uint8_t *luma, const uint8_t *chroma);
    What od_pvq_encode hands to its entropy coder per band (src/pvq_encoder.c:874-979, the arguments of
    pvq_encode_partition): the coded gain index, theta and its range, K, the skip / no-reference flags and
    the pulse vector - K pulses over n positions, nearly all zero.  One SECTION per (plane set, level):
-     records     odhip_export_record [blocks][bands]
-     stream      uint16 words.  The words of a band are consecutive; the bands of one GROUP (the
-                 ODHIP_EXPORT_GROUP_BANDS consecutive records g*256 ..) follow each other in record order;
-                 group g starts at word group_base[g] of the section's stream (groups are placed in the
-                 order their workgroups finish: placement varies from run to run, content does not).
+     records     odhip_export_record4 / odhip_export_record8 [blocks][bands] (record_bytes of the section)
+     stream      uint16 words.  The words of a band are consecutive; the bands of one GROUP (the records
+                 of blocks_per_group consecutive blocks: 128 / 32 / 8 / 4 / 4 for 4x4 ... 64x64) follow each
+                 other in record order; group g starts at word group_base[g] of the section's stream (groups
+                 are placed in the order their workgroups finish: placement varies from run to run, content
+                 does not).
      word        bits 0-6 the position inside the band, bits 7-15 the signed pulse count (-255 .. 255); a
                  count of -256 is an escape - the next word holds the count as an int16.
-   A band with nwords == 0 holds no pulse (skipped, null gain, or K = 0).  Header first: words written per
+   A band without words holds no pulse (skipped, null gain, or K = 0).  Header first: words written per
    section, and a flag per section that is set when a stream outgrew its capacity (as many words as the
    level has coefficients; never seen - the dense vectors remain readable through odhip_pipe_read). */
-#define ODHIP_EXPORT_GROUP_BANDS 256
 #define ODHIP_EXPORT_MAX_SECTIONS 16
-#define ODHIP_EXPORT_NOREF 1             /* flags bit 0: coded without reference (pvq_theta's noref) */
-                                         /* flags bits 1-2: skip (0, OD_PVQ_SKIP_ZERO 1, OD_PVQ_SKIP_COPY 2) */
+/* `fn` of a record: bits 0-8 the words of this band in the stream (0 .. 256), bit 9 coded without reference
+   (pvq_theta's noref), bits 10-11 skip (0, OD_PVQ_SKIP_ZERO 1, OD_PVQ_SKIP_COPY 2).  K is not exported: for a
+   coded band it is the sum of the magnitudes of its words' counts. */
+#define ODHIP_EXPORT_NWORDS(fn) ((fn) & 0x1ff)
+#define ODHIP_EXPORT_NOREF(fn) ((fn) >> 9 & 1)
+#define ODHIP_EXPORT_SKIP(fn) ((fn) >> 10 & 3)
 typedef struct {
-  int16_t qg;          /* the coded gain index: pvq_theta's return value (:636-637); 0 = null without reference */
-  int16_t itheta;      /* -1 without reference */
+  int16_t qg;          /* the coded gain index; 0 = the null vector */
+  uint16_t fn;
+} odhip_export_record4;   /* sections coded without a reference (keyframe luma): 4 bytes */
+typedef struct {
+  int16_t qg;          /* the coded gain index: pvq_theta's return value (:636-637) */
+  int16_t itheta;
   int16_t max_theta;
-  uint16_t k;          /* K of the chosen candidate = SUM |y_j| of a coded band's pulses (saturates at 65535) */
-  uint8_t flags;
-  uint8_t reserved;
-  uint16_t nwords;     /* words of this band in the stream */
-} odhip_export_record;  /* 12 bytes */
+  uint16_t fn;
+} odhip_export_record8;   /* sections coded against a reference: 8 bytes */
 typedef struct {
   uint32_t total_words[ODHIP_EXPORT_MAX_SECTIONS];
   uint32_t overflow[ODHIP_EXPORT_MAX_SECTIONS];
@@ -1183,6 +1188,8 @@ typedef struct {
   int32_t bs;
   uint32_t ngroups;
   uint32_t cap_words;
+  uint32_t blocks_per_group;
+  uint32_t record_bytes;     /* 4: odhip_export_record4, 8: odhip_export_record8 */
   uint32_t pad;
   uint64_t nrecords;         /* blocks x bands */
   uint64_t records_off;      /* byte offsets from the start of the buffer, multiples of 16 */
@@ -1196,7 +1203,8 @@ typedef struct {
   uint64_t total_bytes;      /* the whole buffer: fixed part + the streams at full capacity */
   odhip_export_section section[ODHIP_EXPORT_MAX_SECTIONS];
 } odhip_export_layout;
-int odhip_export_layout_make(odhip_export_layout *lay, int nsections, const long *nblocks, const int *bs);
+int odhip_export_layout_make(odhip_export_layout *lay, int nsections, const long *nblocks, const int *bs,
+ const int *with_ref);
 int odhip_export_begin(void *d_buf, const odhip_export_layout *lay, odhip_stream stream);
 int odhip_export_pack(void *d_buf, const odhip_export_layout *lay, int section, const int32_t *d_choice,
  const int16_t *d_y, long nblocks, int bs, int with_ref, odhip_stream stream);

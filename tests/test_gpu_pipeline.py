@@ -350,7 +350,7 @@ def test_device_priced_step_across_quantisers(quality, masking, hvs):
 
 def test_exported_decisions_are_the_device_buffers():
     """odhip_pipe_set_export (the output side of the PCIe-inclusive rate): fed steps whose decisions - the
-    record and the pulses of every band, compacted on the device (export_kernels.hip: 12-byte records + 16-bit
+    record and the pulses of every band, compacted on the device (export_kernels.hip: 4- / 8-byte records + 16-bit
     (position, count) words) - leave for pinned host memory on a third stream.  After the sync that follows
     step i the host buffer DECODES (daala_amd.decode_export_sections, the reference-side reader of the format)
     to exactly what the dense device buffers of step i hold (gain index, theta, its range, K, skip and every
@@ -396,7 +396,9 @@ def test_exported_decisions_are_the_device_buffers():
             yw, bw, cw = want[key]
             yg, bg, cg = got[key]
             assert np.array_equal(cg, cw), (step, key, "coded")
-            assert np.array_equal(bg, bw), (step, key, "gain index / theta / max_theta / K")
+            assert np.array_equal(bg[..., :3], bw[..., :3]), (step, key, "gain index / theta / max_theta")
+            # K is not exported: a coded band's K is the sum of its counts' magnitudes
+            assert np.array_equal(bg[..., 3][cw], bw[..., 3][cw]), (step, key, "K of the coded bands")
             assert np.array_equal(yg, yw), (step, key, "pulses")
             dense += yw.size * 2
         shipped = pipe.export_shipped_bytes(host.numpy())
@@ -433,7 +435,7 @@ def test_export_words_escape_and_group_order():
     bs_list = [0, 2, 1]
     with_ref = [0, 0, 1]
     nblocks = [1500, 300, 700]
-    lay_c, lay = D.export_layout_make(nblocks, bs_list)
+    lay_c, lay = D.export_layout_make(nblocks, bs_list, with_ref)
     dev = torch.zeros(lay["total_bytes"], dtype=torch.uint8, device="cuda")
     host = torch.zeros(lay["total_bytes"], dtype=torch.uint8).pin_memory()
     host.fill_(0xAB)
@@ -456,7 +458,7 @@ def test_export_words_escape_and_group_order():
             ch[..., 2] = rng.randint(0, 2, size=(B, nb))                      # noref
             ch[..., 3] = rng.randint(0, 40, size=(B, nb))                     # itheta
             ch[..., 4] = ch[..., 3] + rng.randint(1, 9, size=(B, nb))         # max_theta
-            ch[..., 5] = rng.randint(0, 500, size=(B, nb))                    # k
+            ch[..., 5] = rng.randint(0, 500, size=(B, nb))                    # k (not exported)
             ch[..., 6] = rng.choice([0, 0, 0, 1, 2], size=(B, nb))            # skip
             ch[..., 7] = rng.randint(-3, 300, size=(B, nb))                   # coded gain index
             ch[..., 9] = rng.choice([-1, 0, 1, 2], size=(B, nb))              # yslot
@@ -470,7 +472,8 @@ def test_export_words_escape_and_group_order():
             band[..., 0] = ch[..., 7]
             band[..., 1] = ch[..., 3]
             band[..., 2] = ch[..., 4]
-            band[..., 3] = ch[..., 5]
+            for i in range(nb):
+                band[:, i, 3] = np.abs(yw[:, offs[i]:offs[i + 1]]).sum(axis=1)
             coded = ch[..., 6] == 0
         else:
             ch = np.zeros((B, nb, 4), np.int32)
@@ -480,7 +483,7 @@ def test_export_words_escape_and_group_order():
                 a, b_ = offs[i], offs[i + 1]
                 idx = np.nonzero(ch[:, i, 1] != 0)[0]
                 yw[idx, a:b_] = y[ch[idx, i, 0], idx, a:b_]
-                band[:, i, 3] = np.abs(yw[:, a:b_]).sum(axis=1).clip(max=65535)
+                band[:, i, 3] = np.abs(yw[:, a:b_]).sum(axis=1)
             band[..., 0] = ch[..., 1]
             band[..., 1] = -1
         d_ch = torch.from_numpy(ch).cuda()
