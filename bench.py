@@ -564,7 +564,7 @@ def source_hash():
     return h.hexdigest()[:16]
 
 
-def load_pmc(tag_order=("r5", "r4", "r3")):
+def load_pmc(tag_order=("r6", "r5", "r4", "r3")):
     """(per-kernel counters, source file, stale?) of the committed rocprofv3 --pmc passes."""
     for tag in tag_order:
         path = os.path.join(ROOT, "profiles", "%s_pmc_traffic.json" % tag)

@@ -2651,6 +2651,12 @@ int inverse_launch(const InverseArgs *levels, int nlevels, int nplanes, int dec,
       }
     }
   }
+  /* ODHIP_INV_LDS_PAD=bytes (experiments build): extra dynamic LDS per workgroup of the LUMA walker, i.e. fewer of
+     them per CU and registers left for the other chain's preparation kernels (profiles/r6_overlap.txt, section 7) */
+  static const size_t walk_pad = [] {
+    const char *e = ODHIP_EXP_ENV("ODHIP_INV_LDS_PAD");
+    return e ? (size_t)atoi(e) : (size_t)0;
+  }();
   if (walk) {
     const dim3 glo((ng + seg_lo - 1)/seg_lo, h/tile, nplanes*nlo);
     const dim3 ghi((ng + seg_hi - 1)/seg_hi, h/tile, nplanes*nhi);
@@ -2676,7 +2682,7 @@ int inverse_launch(const InverseArgs *levels, int nlevels, int nplanes, int dec,
       }
       if (nlo) {
         if (src == 2) k_inverse_walk<64, 1, 256, 2, 0, 2><<<glo, 256, 0, s>>>(lo);
-        else if (src == 1) k_inverse_walk<64, 1, 256, 1, 0, 2><<<glo, 256, 0, s>>>(lo);
+        else if (src == 1) k_inverse_walk<64, 1, 256, 1, 0, 2><<<glo, 256, walk_pad, s>>>(lo);
         else k_inverse_walk<64, 1, 256, 0, 0, 2><<<glo, 256, 0, s>>>(lo);
       }
     }
