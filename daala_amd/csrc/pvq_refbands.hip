@@ -2075,7 +2075,14 @@ __device__ __forceinline__ void refb_loops_lean_rows(const RJob &jb, int band, l
       p[5*pre_stride] = (uint32_t)__double2hiint(sin_prod);
     }
   }
-  __syncthreads();
+  /* `pre` is the wavefront's own slice: with several independent wavefronts per workgroup (ODHIP_SEARCH_WAVES > 1,
+     some of which may have left already) only this wavefront's LDS writes have to be ordered */
+  if constexpr (kSearchWaves == 1) __syncthreads();
+  else {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
   if (cl.ntheta > 0) {
     v.load(jb.xr + blk*len + off, true);
     int prev_k = 0;
