@@ -1288,6 +1288,11 @@ class Pipe:
     def theta_reruns(self):
         return int(lib().odhip_pipe_theta_reruns(self._p()))
 
+    def theta_listed(self):
+        """Bands found inside the margin of the device acos so far (theta recomputed by the host's libm)."""
+        lib().odhip_pipe_theta_listed.restype = ctypes.c_long
+        return int(lib().odhip_pipe_theta_listed(self._p()))
+
     def price_reruns(self):
         """Priced choices re-decided with the host libm so far (price=True pipes)."""
         return int(lib().odhip_pipe_price_reruns(self._p()))

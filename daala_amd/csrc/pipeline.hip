@@ -1341,3 +1341,17 @@ extern "C" long odhip_pipe_price_reruns(const odhip_pipe *p) {
 extern "C" long odhip_pipe_theta_reruns(const odhip_pipe *p) {
   return p ? p->reruns : 0;
 }
+
+/* Bands whose theta lay inside the margin of the device acos and were recomputed with the host's libm so far
+   (odhip_pipe_theta_reruns counts the ones whose theta changed). */
+extern "C" long odhip_pipe_theta_listed(odhip_pipe *p) {
+  if (!p) return 0;
+  long n = 0;
+  for (int i = 0; i < 2; i++) {
+    if (i == 0 && !p->cfg.inter) continue;      /* keyframes: only the chroma chain runs the with-reference stage */
+    Current cur(p->ctx[i]);
+    const long v = odhip_pvq_ref_theta_listed();
+    if (v > 0) n += v;
+  }
+  return n;
+}

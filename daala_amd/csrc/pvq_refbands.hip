@@ -1272,6 +1272,8 @@ struct RowVector {
     const int placed = prev_k > 0 && prev_k <= k ? prev_k : 0;
     const int greedy = k - (1 + k/4) - placed;
     pulses += greedy > 0 ? greedy : 0;
+    /* (an upper bound when k > 2 starts from the projection, which places some pulses itself) */
+    rate_pulses += k - placed - (greedy > 0 ? greedy : 0);
     return od_pvq_search_row<E, G>(ax, y, row, l, n_true, k, prev_k, g2, lambda, force, xx, norm_1,
      &cxy, &cyy, &replays);
 #else
@@ -1282,6 +1284,7 @@ struct RowVector {
 #ifdef ODHIP_EXPERIMENTS
   int replays = 0;
   int pulses = 0;
+  int rate_pulses = 0;
 #endif
   __device__ __forceinline__ int moment() const {
     int m = 0;
@@ -1307,8 +1310,9 @@ struct RowVector {
 
 #ifdef ODHIP_EXPERIMENTS
 /* [0] greedy pulses placed by the row searches of the with-reference stage, [1] those that took the
-   double-precision replay (pvq_row.cuh, point 3) - counted once per band */
-__device__ unsigned long long gRowReplayStats[2];
+   double-precision replay (pvq_row.cuh, point 3), [2] pulses placed by the rate-penalised pass (:192-219),
+   [3] bands - counted once per band */
+__device__ unsigned long long gRowReplayStats[4];
 #endif
 
 /* The row search on plain band vectors (odhip_pvq_search_row_batch): one band per group of G lanes,
@@ -2446,9 +2450,11 @@ __global__ __launch_bounds__(kSearchThreads) OD_SEARCH_OCC_ATTR void k_refb_lean
   refb_loops_lean_rows<G*E, G>(jb, band, blk, r, cl, it.lambda, v, dec, s_pre + v.row, C);
   refb_finish_row<E, G>(it, job, jb, band, blk, r, dec, lean_best(dec, cl, jb.is_keyframe), v.l, live);
 #ifdef ODHIP_EXPERIMENTS
-  if (live && v.l == 0 && v.pulses) {
-    atomicAdd(&gRowReplayStats[0], (unsigned long long)v.pulses);
+  if (live && v.l == 0) {
+    if (v.pulses) atomicAdd(&gRowReplayStats[0], (unsigned long long)v.pulses);
     if (v.replays) atomicAdd(&gRowReplayStats[1], (unsigned long long)v.replays);
+    if (v.rate_pulses) atomicAdd(&gRowReplayStats[2], (unsigned long long)v.rate_pulses);
+    atomicAdd(&gRowReplayStats[3], 1ull);
   }
 #endif
 }
@@ -2700,6 +2706,7 @@ constexpr int kProfSlots = 256;
    copies nothing, and the host is not stalled by pageable-memory copies. */
 constexpr int kTableSlots = 8;
 struct RefState {
+  long theta_listed = 0;             /* bands found inside the acos margin so far (recomputed on the host) */
   RJob *d_jobs = nullptr;            /* kTableSlots device job tables of kMaxJobs   */
   unsigned *d_pcount = nullptr;      /* priced choice: bands too close to call ...  */
   PUncR *d_plist = nullptr;          /* ... and their list                          */
@@ -3007,13 +3014,14 @@ extern "C" int odhip_pvq_search_row_batch(const int16_t *d_x, int n, const int32
 
 #ifdef ODHIP_EXPERIMENTS
 /* out[0] = greedy pulses placed by the row searches of the with-reference band stage since the last
-   reset, out[1] = those that took the double-precision replay.  Synchronises the device. */
+   reset, out[1] = those that took the double-precision replay, out[2] = pulses of the rate-penalised pass,
+   out[3] = bands.  Synchronises the device. */
 extern "C" int odhip_exp_row_replay_stats(unsigned long long *out, int reset) {
   if (!out) return ODHIP_EINVAL;
   ODHIP_TRY(hipDeviceSynchronize());
-  ODHIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(gRowReplayStats), 2*sizeof(unsigned long long)));
+  ODHIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(gRowReplayStats), 4*sizeof(unsigned long long)));
   if (reset) {
-    const unsigned long long zero[2] = {0, 0};
+    const unsigned long long zero[4] = {0, 0, 0, 0};
     ODHIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(gRowReplayStats), zero, sizeof(zero)));
   }
   return ODHIP_SUCCESS;
@@ -3225,6 +3233,15 @@ extern "C" int odhip_pvq_ref_resolve_begin(odhip_stream stream) {
 extern "C" int odhip_pvq_ref_resolve(const odhip_pvq_refjob *jobs, int njobs,
  double pvq_norm_lambda, odhip_stream stream);
 
+/* Bands of the current context found inside the margin of the device acos so far: each one had its theta
+   recomputed by the host's libm (odhip_pvq_ref_resolve); the ones whose theta CHANGED are the resolve's return
+   value. */
+extern "C" long odhip_pvq_ref_theta_listed(void) {
+  RefState *st = nullptr;
+  if (ref_state(&st) != ODHIP_SUCCESS) return -1;
+  return st->theta_listed;
+}
+
 extern "C" int odhip_pvq_ref_resolve_finish(const odhip_pvq_refjob *jobs, int njobs,
  double pvq_norm_lambda, odhip_stream stream) {
   REF_STATE_OR_RETURN(st);
@@ -3242,6 +3259,7 @@ extern "C" int odhip_pvq_ref_resolve(const odhip_pvq_refjob *jobs, int njobs,
   unsigned count = 0;
   ODHIP_TRY(hipMemcpy(&count, st.d_unc_count, sizeof(count), hipMemcpyDeviceToHost));
   if (count == 0) return 0;
+  st.theta_listed += count;
   if (count > (unsigned)kUncCap) {
     fprintf(stderr, "libdaalahip: %u bands inside the theta margin exceed the list (%d)\n", count,
      kUncCap);

@@ -1254,6 +1254,9 @@ int odhip_copy_ceiling(size_t bytes, int n, int variant, double *gbs, odhip_stre
    roofline_* entries of bench.py).  parity as for odhip_pipe_stage, -1 = the last step's. */
 int odhip_pipe_time_stage(odhip_pipe *p, int stage, int parity, int n, double *avg_ms);
 long odhip_pipe_theta_reruns(const odhip_pipe *p);
+/* ... and the bands that were listed (inside the acos margin, theta recomputed by the host), changed or not */
+long odhip_pipe_theta_listed(odhip_pipe *p);
+long odhip_pvq_ref_theta_listed(void);
 long odhip_pipe_price_reruns(const odhip_pipe *p);
 double odhip_pipe_host_wait_ms(const odhip_pipe *p);
 /* odhip_ctx_set_test_hooks on both contexts of the pipe. */

@@ -14,8 +14,9 @@ F = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 D.init(0)
 L = D.lib()
 assert hasattr(L, "odhip_exp_row_replay_stats"), "needs the experiments build: ODHIP_LIB=daala_amd/lib/libdaalahip_exp.so"
-out = (ctypes.c_ulonglong * 2)()
-print("content   quality   greedy pulses of the 32-/128-coefficient with-reference bands   replayed in double precision")
+out = (ctypes.c_ulonglong * 4)()
+print("content   quality   bands (32 / 128 coefficients, with reference)   greedy pulses   replayed in double precision   "
+      "rate-pass pulses (upper bound)")
 for content, q in [("checker", 20), ("natural", 20)] + list(B.SWEEP_POINTS):
     B.GENERATOR = B.CONTENT[content]
     luma, chroma = B.synth_pictures(F, 1234)
@@ -30,5 +31,6 @@ for content, q in [("checker", 20), ("natural", 20)] + list(B.SWEEP_POINTS):
     pipe.flush()
     pipe.sync()
     L.odhip_exp_row_replay_stats(out, 1)
-    print("%-9s -v %-3d   %12d   %8d   (%.2e of the pulses)" % (content, q, out[0], out[1], out[1] / max(1, out[0])), flush=True)
+    print("%-9s -v %-3d   %10d bands   %12d greedy   %8d replayed (%.2e)   %12d rate-pass (%.0f %% of the pulses)" % (
+        content, q, out[3], out[0], out[1], out[1] / max(1, out[0]), out[2], 100.0 * out[2] / max(1, out[0] + out[2])), flush=True)
     pipe.destroy()
