@@ -343,6 +343,144 @@ __device__ __forceinline__ int od_lane_greedy_scan(const uint32_t *pk, int lane,
   return pos;
 }
 
+/* ---- greedy pulses by CLASS FRONTS (round 6; pair mode) --------------------------------------------------
+   The greedy argmax (src/pvq_encoder.c:172-183) maximises (xy + |x_j|)^2 / (yy + 2*y_j + 1).  Among the
+   candidates of one CLASS - equal pulse count y_j, hence equal denominator - the quotient is strictly
+   increasing in |x_j|, so the maximum over the band is attained by the FRONT of some class: its member with the
+   largest |x|, lowest position among equals.  In the exact regime (every product of the pulse an exact integer
+   below 2^52, the condition the pair mode checks anyway) the reference's left-to-right scan ends on the lowest
+   position among the candidates of maximal quotient, which is therefore the front that wins the exact comparison
+   of the fronts, ties to the lower position.  A pulse moves its winner from class c to c + 1: only class c needs a
+   new front (one scan of the lane's column: 5 instructions per word against the 15 of an evaluation) and class
+   c + 1 takes the winner if it beats its front.  Fronts are tracked for pulse counts 0 .. kFrontClasses - 1; a
+   band that holds a larger count, or leaves the exact regime, goes on in the literal loop below - so does
+   ODHIP_PVQ_FORCE_SEQ=1, which is how the tests cross-check the two.
+   Key of a member: (|x| + 1) << 16 | (N - 1 - j): larger |x| first, lower position on ties; 0 = empty class. */
+#ifndef ODHIP_GREEDY_FRONTS
+# define ODHIP_GREEDY_FRONTS 1     /* 0: the literal scan for every pulse (the A/B baseline, profiles/r6_fronts.txt) */
+#endif
+#ifndef ODHIP_FRONT_CLASSES
+# define ODHIP_FRONT_CLASSES 8
+#endif
+#ifndef ODHIP_FRONT_MIN
+# define ODHIP_FRONT_MIN 4
+#endif
+constexpr int kFrontClasses = ODHIP_FRONT_CLASSES;
+constexpr int kFrontMinPulses = ODHIP_FRONT_MIN;     /* fewer greedy pulses left in every band of the wavefront: not worth the set-up */
+
+template <int N>
+__device__ __forceinline__ uint32_t od_lane_front_scan(const uint32_t *pk, int lane, uint32_t c2) {
+  static_assert(N % kGrp == 0, "whole groups");
+  constexpr int NG = N/kGrp;
+  uint32_t best = 0;
+  uint32_t w0[kGrp];
+  uint32_t w1[kGrp];
+  od_lane_load_group<N>(w0, pk, lane, 0);
+#pragma unroll
+  for (int g = 0; g < NG; g++) {
+    if (g + 1 < NG) od_lane_load_group<N>(w1, pk, lane, g + 1);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 0; t < kGrp; t++) {
+      const int j = g*kGrp + t;
+      const uint32_t key = (w0[t] & 0xffff0000u) + (0x10000u + (uint32_t)(N - 1 - j));
+      const uint32_t m = (w0[t] & 0xffffu) == c2 ? key : 0u;
+      best = m > best ? m : best;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 0; t < kGrp; t++) w0[t] = w1[t];
+  }
+  return best;
+}
+
+/* Greedy pulses of a lane pair's band until n_greedy pulses are placed or the conditions above end; the caller's
+   literal loop places whatever is left. */
+template <int N>
+__device__ __forceinline__ void od_lane_greedy_fronts(LaneSearch &s, uint32_t *pk, int lane, int half, bool on,
+ int k, int n_greedy) {
+  const int jbase = half*N;
+  unsigned present = 0;
+#pragma unroll 8
+  for (int j = 0; j < N; j++) {
+    const unsigned yc = (pk[j*kPitch + lane] & 0xffffu) >> 1;
+    present |= 1u << (yc < (unsigned)kFrontClasses ? yc : (unsigned)kFrontClasses);
+  }
+  const bool active = on && s.i < n_greedy;
+  const unsigned both = present | od_pair_swap(present);
+  if (__any(active && (both >> kFrontClasses) != 0)) return;
+  uint32_t fr[kFrontClasses];
+#pragma unroll
+  for (int c = 0; c < kFrontClasses; c++) {
+    fr[c] = 0;
+    if (__any(active && (present >> c & 1u))) fr[c] = od_lane_front_scan<N>(pk, lane, 2u*c);
+  }
+  while (__any(on && s.i < n_greedy)) {
+    const bool step = on && s.i < n_greedy;
+    const double tmax = (double)(s.xy + s.xmax);
+    const bool exact = (tmax*tmax)*(double)(s.yy + 2*(unsigned)k + 1) < 4503599627370496.;   /* 2^52, as in the literal loop */
+    if (__any(step && !exact)) return;
+    /* the best front of this lane's half ... */
+    double ba = 0;
+    double bb = 1;
+    int bpos = 0;
+    int bc = 0;
+    bool have = false;
+#pragma unroll
+    for (int c = 0; c < kFrontClasses; c++) {
+      if (__any(step && fr[c] != 0)) {
+        const uint32_t key = fr[c];
+        const bool v = key != 0;
+        const double tt = (double)(s.xy + ((key >> 16) - 1u));
+        const double a = tt*tt;
+        const double b = (double)(s.yy + 1u + 2u*c);
+        const int p = jbase + (N - 1 - (int)(key & 0xffffu));
+        const double l = a*bb;
+        const double r = ba*b;
+        const bool better = v && (!have || l > r || (l == r && p < bpos));
+        ba = better ? a : ba;
+        bb = better ? b : bb;
+        bpos = better ? p : bpos;
+        bc = better ? c : bc;
+        have = have || v;
+      }
+    }
+    /* ... against the other half's */
+    const double oa = od_pair_swap(ba);
+    const double ob = od_pair_swap(bb);
+    const int op = od_pair_swap(bpos);
+    const int oc = od_pair_swap(bc);
+    const bool ohave = od_pair_swap((int)have) != 0;
+    const double l = oa*bb;
+    const double r = ba*ob;
+    const bool other = ohave && (!have || l > r || (l == r && op < bpos));
+    const int pos = other ? op : bpos;
+    const int cw = other ? oc : bc;
+    const bool owner = pos/N == half;
+    const int local = pos - jbase;
+    uint32_t w = 0;
+    if (step && owner) w = pk[local*kPitch + lane];
+    w = od_grp_or<2>(w);
+    const bool mine = step && owner;
+    if (step) {
+      s.xy += w >> 16;
+      s.yy += (w & 0xffffu) + 1;
+      if (owner) pk[local*kPitch + lane] = w + 2;
+      s.i++;
+    }
+    /* the winner's old class needs a new front (the winner now counts one pulse more: the scan passes it
+       over), its new class takes it if it beats that front */
+    const uint32_t nf = od_lane_front_scan<N>(pk, lane, mine ? 2u*(uint32_t)cw : 0xffffffffu);
+    const uint32_t wkey = ((w + 2) & 0xffff0000u) + (0x10000u + (uint32_t)(N - 1 - local));
+#pragma unroll
+    for (int c = 0; c < kFrontClasses; c++) {
+      if (mine && c == cw) fr[c] = nf;
+      if (mine && c == cw + 1) fr[c] = wkey > fr[c] ? wkey : fr[c];
+    }
+    if (__any(mine && cw + 1 >= kFrontClasses)) return;     /* a pulse count without a tracked class */
+  }
+}
+
 /* One candidate: K-pulse search for the lanes with `on` set (k <= kMaxK).
    `fresh` lanes start from the L1 projection (k > 2) or from zero; the others
    continue from the pulses of the previous candidate (prev_k <= k,
@@ -404,6 +542,13 @@ __device__ __forceinline__ double od_lane_search(LaneSearch &s, uint32_t *pk, co
   }
   const int rdo_pulses = 1 + k/4;
   const int n_greedy = k - rdo_pulses;
+#if ODHIP_GREEDY_FRONTS
+  if constexpr (S == 2 && N >= 32 && N % kGrp == 0) {   /* (the 32-coefficient bands, 16 per lane: +26 VGPRs cost their kernel a wavefront per SIMD) */
+    if (!force_seq && __any(on && n_greedy - s.i >= kFrontMinPulses)) {
+      od_lane_greedy_fronts<N>(s, pk, lane, half & 1, on, k, n_greedy);
+    }
+  }
+#endif
   /* Greedy pulses, src/pvq_encoder.c:165-187. */
   while (__any(on && s.i < n_greedy)) {
     const bool step = on && s.i < n_greedy;
