@@ -593,8 +593,10 @@ def step_counters(pmc, src, stale, step_ms):
                                       "dropped" % src}
     if not pmc:
         return None
-    valu = sum(e.get("valu_wave_instructions") or 0 for e in pmc.values())
-    hbm = sum(e.get("hbm_bytes_per_launch") or 0 for e in pmc.values())
+    # kernels of the profiled command that are NOT part of a step: the copy-ceiling measurement, one-time table fills
+    step = {k: e for k, e in pmc.items() if not k.startswith(("k_copy16", "k_export_", "k_rsq_", "k_rate_", "k_nrate_"))}
+    valu = sum(e.get("valu_wave_instructions") or 0 for e in step.values())
+    hbm = sum(e.get("hbm_bytes_per_launch") or 0 for e in step.values())
     return {"valu_wave_instructions_per_step": valu,
             "valu_issue_utilisation": round(valu / (VALU_PEAK_GINSTR * 1e9) / (step_ms * 1e-3), 4),
             "hbm_bytes_per_step": hbm,

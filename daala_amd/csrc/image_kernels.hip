@@ -173,16 +173,19 @@ namespace {
 template <int U>
 __global__ __launch_bounds__(256) void k_copy16(const int4 *__restrict__ src, int4 *__restrict__ dst, size_t nvec) {
   const size_t base = (size_t)blockIdx.x*(256*U) + threadIdx.x;
-  int4 v[U];
+  if (base - threadIdx.x + (size_t)256*U <= nvec) {
+    /* whole block inside the buffer (workgroup-uniform): the U vectors stay in registers */
+    int4 v[U];
 #pragma unroll
-  for (int u = 0; u < U; u++) {
-    const size_t i = base + (size_t)u*256;
-    if (i < nvec) v[u] = src[i];
+    for (int u = 0; u < U; u++) v[u] = src[base + (size_t)u*256];
+#pragma unroll
+    for (int u = 0; u < U; u++) dst[base + (size_t)u*256] = v[u];
   }
-#pragma unroll
-  for (int u = 0; u < U; u++) {
-    const size_t i = base + (size_t)u*256;
-    if (i < nvec) dst[i] = v[u];
+  else {
+    for (int u = 0; u < U; u++) {
+      const size_t i = base + (size_t)u*256;
+      if (i < nvec) dst[i] = src[i];
+    }
   }
 }
 }  // namespace
