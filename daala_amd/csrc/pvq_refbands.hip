@@ -165,6 +165,9 @@ struct RItems {
   double tol_scale;        /* test hook: multiplies the decision margin            */
   int fuse;                /* the per-lane searches also make the priced choice    */
   int reserved1;
+#ifdef ODHIP_EXPERIMENTS
+  int abl;                 /* ODHIP_REFB_ABL: ablation bits (tools/gpu_r6_ablate.sh)  */
+#endif
   int wg_start[kMaxItems + 1];
   unsigned char job[kMaxItems];
   unsigned char band[kMaxItems];
@@ -529,7 +532,12 @@ __global__ __launch_bounds__(kWave) void k_refb_prep_lane(RItems it) {
       qm[i] = qmp[i];
     }
   }
-  if (lref) {
+#ifdef ODHIP_EXPERIMENTS
+  const bool lref_read = lref && !(it.abl & 2);
+#else
+  const bool lref_read = lref;
+#endif
+  if (lref_read) {
     /* coding order is what the luma stage keeps: whole 16-byte pieces */
     if constexpr (N == 15) {
       int lo[8];
@@ -636,9 +644,18 @@ __global__ __launch_bounds__(kWave) void k_refb_prep_lane(RItems it) {
 #pragma unroll
     for (int i = 0; i < N - 1; i++) xr[i] = i < m ? v[i] : v[i + 1];
   }
+#ifdef ODHIP_EXPERIMENTS
+  const bool abl_nostore = (it.abl & 1) != 0;
+  const bool abl_norec = (it.abl & 4) != 0;
+#else
+  constexpr bool abl_nostore = false;
+  constexpr bool abl_norec = false;
+#endif
   /* whole 16-byte vectors: the 15-coefficient band shares its first vector with
      the (unused) DC slot of the block */
-  if (N == 15) {
+  if (abl_nostore) {
+  }
+  else if (N == 15) {
     uint4 *xo = reinterpret_cast<uint4 *>(x16o);
     uint4 *ro = reinterpret_cast<uint4 *>(r16o);
     uint4 *xro4 = reinterpret_cast<uint4 *>(xro);
@@ -663,7 +680,7 @@ __global__ __launch_bounds__(kWave) void k_refb_prep_lane(RItems it) {
     *reinterpret_cast<uint4 *>(xro + off) = make_uint4(pack16(xr[0], xr[1]), pack16(xr[2], xr[3]),
      pack16(xr[4], xr[5]), pack16(xr[6], 0));
   }
-  prep_write(it, rec + band, job, band, blk, xshift, rshift, p, r_null, flip, m, s);
+  if (!abl_norec) prep_write(it, rec + band, job, band, blk, xshift, rshift, p, r_null, flip, m, s);
 }
 
 /* n = G*E coefficients per group of G lanes (G = 16: a DPP row, G = 4: a quad),
@@ -1969,7 +1986,11 @@ __device__ __forceinline__ void refb_loops_lean_gathered(const RJob &jb, int ban
     while (idx < cl.ntheta) {
       const uint32_t w = cl.col[idx*cl.stride];
       const int gi = (int)(w & 3u);
+#ifdef ODHIP_EXPERIMENTS
+      const int k = dec.abl & 8 ? 0 : (int)(w >> 2 & 0xffffu);
+#else
       const int k = (int)(w >> 2 & 0xffffu);
+#endif
       const int i = cl.gb1 + gi;
       const int ts = (int)cl.col[(kSlots + gi)*cl.stride];
       const int j = (int)cl.col[(kSlots + 3 + gi)*cl.stride] + (int)(w >> 18);
@@ -2014,7 +2035,11 @@ __device__ __forceinline__ void refb_loops_lean_gathered(const RJob &jb, int ban
     while (idx < cl.nitems) {
       const uint32_t w = cl.col[idx*cl.stride];
       const int i = cl.gbn + (int)(w & 3u);
+#ifdef ODHIP_EXPERIMENTS
+      const int k = dec.abl & 8 ? 0 : (int)(w >> 2 & 0xffffu);
+#else
       const int k = (int)(w >> 2 & 0xffffu);
+#endif
       const int32_t qcg = odq_shl32(i, ODQ_CGAIN_SHIFT);
       /* :585-595 */
       double dist = (1.4*(qcg - cg))*(qcg - cg);
@@ -2175,6 +2200,9 @@ struct LeanDecide {
   int icgr;
   int is_keyframe;
   int pli;
+#ifdef ODHIP_EXPERIMENTS
+  int abl = 0;
+#endif
   __device__ __forceinline__ void init(const odhip_pvq_refband &r, const RJob &jb, double lam, double tol) {
     best_cost = r.dist0;       /* the initial candidate places no pulse: its rate is 0 */
     chosen = -1;
@@ -2266,6 +2294,9 @@ __global__ __launch_bounds__(kSearchThreads) OD_SEARCH_OCC_ATTR void k_refb_lean
   RegVector<N> v;
   LeanDecide<N> dec;
   dec.init(r, jb, it.lambda, it.tol_scale);
+#ifdef ODHIP_EXPERIMENTS
+  dec.abl = it.abl;
+#endif
   refb_loops_lean_gathered<N>(jb, band, blk, r, cl, it.lambda, v, dec);
   const RefBest best = lean_best(dec, cl, jb.is_keyframe);
   if (best.yslot >= 0) {
@@ -2872,6 +2903,16 @@ void items_begin(RItems &it, const RefState &st, double lambda) {
   it.plist = st.d_plist;
   it.tol_scale = st.tol_scale;
   it.reserved1 = sort_weights();
+#ifdef ODHIP_EXPERIMENTS
+  /* bit 0: the preparation kernels do not store x16 / r16 / xr; 1: they take a zero reference instead of reading the
+     luma choices (lref_piece); 2: they do not write the band record; 3: k_refb_lean_lane places no pulse (K = 0 for
+     every candidate); 4: k_refb_lean_lane does not load its vectors.  Timing only: results are wrong. */
+  static const int abl = [] {
+    const char *e = getenv("ODHIP_REFB_ABL");
+    return e ? atoi(e) : 0;
+  }();
+  it.abl = abl;
+#endif
 }
 
 /* Heaviest items first: the jobs arrive by ascending block size, and the bands of the largest
