@@ -51,7 +51,20 @@ __device__ __forceinline__ int words_of(int v) {
    band (bands start at 1, 16, 24, 32, 64, ... - the chunk at 0 holds the DC slot, which is skipped, and the first
    seven positions of band 0).  One workgroup scan of the lanes' word counts places every band's words in record
    order; the lane that holds a band's first chunk writes its record. */
-__global__ __launch_bounds__(kPackThreads) void k_export_pack(PackArgs a) {
+/* Up to kPackSections sections per launch (a launch inside a chain waits for the other chain's search to leave
+   registers free: fewer launches, fewer waits). */
+constexpr int kPackSections = 5;
+struct PackMulti {
+  int nsec;
+  unsigned group_start[kPackSections + 1];
+  PackArgs sec[kPackSections];
+};
+
+__global__ __launch_bounds__(kPackThreads) void k_export_pack(PackMulti m) {
+  int si = 0;
+  while (si + 1 < m.nsec && blockIdx.x >= m.group_start[si + 1]) si++;
+  const PackArgs &a = m.sec[si];
+  const unsigned group = blockIdx.x - m.group_start[si];
   __shared__ uint32_t s_scan[kPackThreads];
   __shared__ uint32_t s_base;
   __shared__ uint32_t s_wave[kPackThreads/64];
@@ -59,7 +72,7 @@ __global__ __launch_bounds__(kPackThreads) void k_export_pack(PackArgs a) {
   const int cpb = a.len >> 3;                    /* chunks per block */
   const int bl = t/cpb;                          /* block within the group */
   const int c = t - bl*cpb;
-  const long blk = (long)blockIdx.x*a.bpg + bl;
+  const long blk = (long)group*a.bpg + bl;
   const bool live = blk < a.nblocks;
   const int q0 = c << 3;
   int i = 0;
@@ -128,7 +141,7 @@ __global__ __launch_bounds__(kPackThreads) void k_export_pack(PackArgs a) {
   if (t == kPackThreads - 1) {
     const uint32_t base = atomicAdd(a.total, incl);
     s_base = base;
-    a.group_base[blockIdx.x] = base;
+    a.group_base[group] = base;
     if (base + incl > a.cap_words) atomicExch(a.overflow, 1u);
   }
   __syncthreads();
@@ -142,7 +155,7 @@ __global__ __launch_bounds__(kPackThreads) void k_export_pack(PackArgs a) {
       const int j = q0 + e - a.off[i];
       if (v[e] >= -255 && v[e] <= 255) a.stream[w++] = (uint16_t)((v[e] << 7) | j);
       else {
-        a.stream[w++] = (uint16_t)((-256 << 7) | j);
+        a.stream[w++] = (uint16_t)(0x8000u | (uint32_t)j);      /* count -256 << 7: the escape */
         a.stream[w++] = (uint16_t)(int16_t)v[e];
       }
     }
@@ -203,17 +216,16 @@ extern "C" int odhip_export_begin(void *d_buf, const odhip_export_layout *lay, o
   return ODHIP_SUCCESS;
 }
 
-/* Packs one section: the choice records [nblocks][nb][4 or 16] and the pulse vectors [slots][nblocks][len]
-   of level `bs` as a band stage left them. */
-extern "C" int odhip_export_pack(void *d_buf, const odhip_export_layout *lay, int section, const int32_t *d_choice,
- const int16_t *d_y, long nblocks, int bs, int with_ref, odhip_stream stream) {
-  if (!d_buf || !lay || section < 0 || section >= lay->nsections || !d_choice || !d_y || nblocks <= 0) return ODHIP_EINVAL;
+namespace {
+int pack_fill(PackArgs &a, void *d_buf, const odhip_export_layout *lay, int section, const int32_t *d_choice,
+ const int16_t *d_y, long nblocks, int bs, int with_ref) {
+  if (section < 0 || section >= lay->nsections || !d_choice || !d_y || nblocks <= 0) return ODHIP_EINVAL;
   const odhip_export_section &sec = lay->section[section];
-  PackArgs a;
   int nb = 0;
   int len = 0;
   if (odhip_pvq_band_layout(bs, &nb, a.off, &len) != 0) return ODHIP_EINVAL;
   if ((long)sec.nrecords != nblocks*nb) return ODHIP_EINVAL;
+  if ((int)sec.record_bytes != (with_ref ? 8 : 4)) return ODHIP_EINVAL;
   uint8_t *base = static_cast<uint8_t *>(d_buf);
   odhip_export_header *h = reinterpret_cast<odhip_export_header *>(base);
   a.choice = d_choice;
@@ -222,7 +234,6 @@ extern "C" int odhip_export_pack(void *d_buf, const odhip_export_layout *lay, in
   a.nb = nb;
   a.len = len;
   a.with_ref = with_ref;
-  if ((int)sec.record_bytes != (with_ref ? 8 : 4)) return ODHIP_EINVAL;
   a.rec = base + sec.records_off;
   a.group_base = reinterpret_cast<uint32_t *>(base + sec.group_base_off);
   a.stream = reinterpret_cast<uint16_t *>(base + sec.stream_off);
@@ -230,8 +241,36 @@ extern "C" int odhip_export_pack(void *d_buf, const odhip_export_layout *lay, in
   a.total = &h->total_words[section];
   a.overflow = &h->overflow[section];
   a.bpg = (int)sec.blocks_per_group;
-  k_export_pack<<<sec.ngroups, kPackThreads, 0, (hipStream_t)stream>>>(a);
+  return ODHIP_SUCCESS;
+}
+}  // namespace
+
+/* Packs `n` sections (first_section .. first_section + n - 1 of the layout) in launches of up to five: choice
+   records [nblocks][nb][4 or 16] and pulse vectors [slots][nblocks][len] of level bs[i] as a band stage left them. */
+extern "C" int odhip_export_pack_multi(void *d_buf, const odhip_export_layout *lay, int first_section, int n,
+ const int32_t *const *d_choice, const int16_t *const *d_y, const long *nblocks, const int *bs, int with_ref,
+ odhip_stream stream) {
+  if (!d_buf || !lay || n <= 0 || !d_choice || !d_y || !nblocks || !bs) return ODHIP_EINVAL;
+  for (int i0 = 0; i0 < n; i0 += kPackSections) {
+    PackMulti m;
+    m.nsec = n - i0 < kPackSections ? n - i0 : kPackSections;
+    m.group_start[0] = 0;
+    for (int i = 0; i < m.nsec; i++) {
+      const int rc = pack_fill(m.sec[i], d_buf, lay, first_section + i0 + i, d_choice[i0 + i], d_y[i0 + i],
+       nblocks[i0 + i], bs[i0 + i], with_ref);
+      if (rc) return rc;
+      m.group_start[i + 1] = m.group_start[i] + lay->section[first_section + i0 + i].ngroups;
+    }
+    k_export_pack<<<m.group_start[m.nsec], kPackThreads, 0, (hipStream_t)stream>>>(m);
+  }
   return odhip_check_launch();
+}
+
+/* One section. */
+extern "C" int odhip_export_pack(void *d_buf, const odhip_export_layout *lay, int section, const int32_t *d_choice,
+ const int16_t *d_y, long nblocks, int bs, int with_ref, odhip_stream stream) {
+  if (!d_buf || !lay) return ODHIP_EINVAL;
+  return odhip_export_pack_multi(d_buf, lay, section, 1, &d_choice, &d_y, &nblocks, &bs, with_ref, stream);
 }
 
 /* Copies the header, every record and group base and the used part of every stream to `host` (pinned,

@@ -717,10 +717,18 @@ int export_dbg() {
 
 int export_luma(odhip_pipe *p, int par) {
   hipStream_t s = p->stream[0];
-  for (int bs = 0; bs < 5 && !(export_dbg() & 1); bs++) {
-    const odhip_pvq_job &j = p->jobs[par][bs];
-    STEP_TRY(odhip_export_pack(p->export_dev[par], &p->export_lay, bs, j.cands.choice, j.cands.y, p->set[0].nblocks[bs],
-     bs, 0, s));
+  if (!(export_dbg() & 1)) {
+    const int32_t *choice[5];
+    const int16_t *y[5];
+    long nblocks[5];
+    int bss[5];
+    for (int bs = 0; bs < 5; bs++) {
+      choice[bs] = p->jobs[par][bs].cands.choice;
+      y[bs] = p->jobs[par][bs].cands.y;
+      nblocks[bs] = p->set[0].nblocks[bs];
+      bss[bs] = bs;
+    }
+    STEP_TRY(odhip_export_pack_multi(p->export_dev[par], &p->export_lay, 0, 5, choice, y, nblocks, bss, 0, s));
   }
   ODHIP_TRY(hipEventRecord(p->ev_exp_luma[par], s));
   return ODHIP_SUCCESS;
@@ -731,10 +739,18 @@ int export_luma(odhip_pipe *p, int par) {
 int export_chroma(odhip_pipe *p, int par) {
   hipStream_t s = p->stream[1];
   hipStream_t x = p->export_stream;
-  for (int bs = 0; bs < 4 && !(export_dbg() & 1); bs++) {
-    const odhip_pvq_refjob &j = p->refjobs[par][bs];
-    STEP_TRY(odhip_export_pack(p->export_dev[par], &p->export_lay, 5 + bs, j.choice, j.y, p->set[1].nblocks[bs], bs, 1,
-     s));
+  if (!(export_dbg() & 1)) {
+    const int32_t *choice[4];
+    const int16_t *y[4];
+    long nblocks[4];
+    int bss[4];
+    for (int bs = 0; bs < 4; bs++) {
+      choice[bs] = p->refjobs[par][bs].choice;
+      y[bs] = p->refjobs[par][bs].y;
+      nblocks[bs] = p->set[1].nblocks[bs];
+      bss[bs] = bs;
+    }
+    STEP_TRY(odhip_export_pack_multi(p->export_dev[par], &p->export_lay, 5, 4, choice, y, nblocks, bss, 1, s));
   }
   ODHIP_TRY(hipEventRecord(p->ev_exp_chroma, s));
   /* the totals travel IN the chain (like the band stages' counts): on the export stream even this 128-byte copy

@@ -1208,6 +1208,10 @@ int odhip_export_layout_make(odhip_export_layout *lay, int nsections, const long
 int odhip_export_begin(void *d_buf, const odhip_export_layout *lay, odhip_stream stream);
 int odhip_export_pack(void *d_buf, const odhip_export_layout *lay, int section, const int32_t *d_choice,
  const int16_t *d_y, long nblocks, int bs, int with_ref, odhip_stream stream);
+/* sections first_section .. first_section + n - 1 in one launch per five (arrays of n device pointers / sizes) */
+int odhip_export_pack_multi(void *d_buf, const odhip_export_layout *lay, int first_section, int n,
+ const int32_t *const *d_choice, const int16_t *const *d_y, const long *nblocks, const int *bs, int with_ref,
+ odhip_stream stream);
 int odhip_export_ship(void *pinned_host, const void *d_buf, const odhip_export_layout *lay, odhip_stream stream);
 
 /* The OUTPUT side of a streaming host (SURVEY hard part 5: "timed GPU-side incl. transfers"): with a
