@@ -506,3 +506,57 @@ def test_export_words_escape_and_group_order():
         assert 0 < used < sec["cap_words"] * 2
         assert (h[sec["stream_off"] + used:sec["stream_off"] + sec["cap_words"] * 2] == 0xAB).all()
     assert int(h[64:128].view(np.uint32).sum()) == 0          # no overflow flag
+
+
+def test_export_follows_a_late_resolve():
+    """a chroma band that the host-libm resolve re-decides one step late changes choices and pulses
+    AFTER they were packed for the host.  With the margins forced wide (theta margin + a deliberately wrong device
+    theta; price margin scaled up) hundreds of bands are re-decided per step: `step, flush, sync, read` must decode
+    to the FINAL device buffers (the flush re-exports the step), and steps issued back to back count their superseded
+    exports (odhip_pipe_export_stale)."""
+    import torch
+    import daala_amd as D
+    import _pipeline_check as C
+    D.init(0)
+    b = _bench()
+    qt = D.QuantTables.for_quality(40)
+    full = b.natural_like_frame_np(6, 5)
+    pw, ph = 312, 180
+    luma = np.ascontiguousarray(full[0][:ph, :pw])[None]
+    chroma = np.stack([full[1][:ph // 2, :pw // 2], full[2][:ph // 2, :pw // 2]])
+    D.pvq_ref_set_theta_margin(0.25, True)
+    D.set_price_tol_scale(1e7)
+    try:
+        pipe = D.Pipe(qt, 1, pw, ph, chroma_cfl=True, price=True)
+        try:
+            pipe.set_pictures(luma, chroma)
+            host = torch.zeros(pipe.export_bytes(), dtype=torch.uint8).pin_memory()
+            pipe.set_export(host)
+            for step in range(3):
+                before = pipe.theta_reruns() + pipe.price_reruns()
+                pipe.step()
+                pipe.flush()
+                pipe.sync()
+                assert pipe.theta_reruns() + pipe.price_reruns() > before + 50      # the late paths really ran
+                got = pipe.decode_export(host.numpy())
+                want = C.gpu_decisions(D, pipe)
+                for key in sorted(want):
+                    yw, bw, cw = want[key]
+                    yg, bg, cg = got[key]
+                    assert np.array_equal(cg, cw), (step, key)
+                    assert np.array_equal(bg[..., :3], bw[..., :3]), (step, key)
+                    assert np.array_equal(bg[..., 3][cw], bw[..., 3][cw]), (step, key)
+                    assert np.array_equal(yg, yw), (step, key, "pulses after the resolve")
+            assert pipe.export_stale() == 0
+            # back to back: the resolve of step i runs inside step i + 1, after the host could have read the buffer
+            for _ in range(3):
+                pipe.step()
+            pipe.flush()
+            pipe.sync()
+            assert pipe.export_stale() >= 2, pipe.export_stale()
+            pipe.set_export(None)
+        finally:
+            pipe.destroy()
+    finally:
+        D.pvq_ref_set_theta_margin(0, False)
+        D.set_price_tol_scale(1.)
