@@ -344,6 +344,42 @@ double od_pvq_search_rdo_double_hip(const int16_t *xcoeff, int n, int k,
   return *(double *)(host + off_cos);
 }
 
+/* od_pvq_synthesis_partial (src/pvq.c:1037-1115, declared src/pvq.h:164) with the reference's own signature: what
+   pvq_decode_partition's synthesis (src/pvq_decoder.c:77-89, od_pvq_decode :300-376 per band) and pvq_theta's
+   (src/pvq_encoder.c:631) call once per coded band.  One band per call through odhip_pvq_synthesis: a parity surface
+   (the decoder of a whole frame at once is odhip_pvq_decode_bands). */
+void od_pvq_synthesis_partial_hip(od_coeff *xcoeff, const od_coeff *ypulse, const int16_t *r16, int n, int noref,
+ int32_t g, int32_t theta, int m, int s_, const int16_t *qm_inv) {
+  if (n < 2 || n > 128) {
+    fprintf(stderr, "libdaalahip: fatal: pvq synthesis n=%d out of range\n", n);
+    abort();
+  }
+  Scratch &s = g_scratch;
+  /* layout: y[128] int32 | r16[128] int16 | qm_inv[128] int16 | params[5] int32 | pad | out[128] int32 */
+  const size_t off_r = 128*sizeof(od_coeff);
+  const size_t off_q = off_r + 128*sizeof(int16_t);
+  const size_t off_p = off_q + 128*sizeof(int16_t);
+  const size_t off_o = off_p + 32;
+  char host[128*4 + 128*2 + 128*2 + 32 + 128*4];
+  memset(host, 0, sizeof(host));
+  memcpy(host, ypulse, (size_t)(n - !noref)*sizeof(od_coeff));
+  if (!noref) memcpy(host + off_r, r16, n*sizeof(int16_t));
+  memcpy(host + off_q, qm_inv, n*sizeof(int16_t));
+  int32_t *pr = (int32_t *)(host + off_p);
+  pr[0] = noref;
+  pr[1] = g;
+  pr[2] = theta;
+  pr[3] = m;
+  pr[4] = s_;
+  char *d = (char *)s.get(0, sizeof(host));
+  HIP_OR_DIE(hipMemcpyAsync(d, host, off_o, hipMemcpyHostToDevice, s.stream));
+  ok_or_die(odhip_pvq_synthesis((od_coeff *)(d + off_o), (const od_coeff *)d, (const int16_t *)(d + off_r), n, 1,
+   (const int32_t *)(d + off_p), (const int16_t *)(d + off_q), s.stream), "odhip_pvq_synthesis");
+  HIP_OR_DIE(hipMemcpyAsync(host + off_o, d + off_o, n*sizeof(od_coeff), hipMemcpyDeviceToHost, s.stream));
+  HIP_OR_DIE(hipStreamSynchronize(s.stream));
+  memcpy(xcoeff, host + off_o, n*sizeof(od_coeff));
+}
+
 /* Host-pointer form of odhip_inverse_partition for one plane (the decoder-side check
    of tests/interpose: the reference decoder's dtmp plane and bsize map in, pixels
    out): stages through device scratch, synchronous. */

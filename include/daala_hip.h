@@ -123,6 +123,10 @@ void od_apply_postfilter_frame_sbs_hip(od_coeff *c, int stride, int nhsb,
    src/pvq_encoder.c:542,589. */
 double od_pvq_search_rdo_double_hip(const int16_t *xcoeff, int n, int k,
  od_coeff *ypulse, double g2, double pvq_norm_lambda, int prev_k);
+/* od_pvq_synthesis_partial, src/pvq.h:164 (src/pvq.c:1037-1115): the synthesis of one decoded / chosen band -
+   what od_pvq_decode's pvq_decode_partition (src/pvq_decoder.c:77-89) and pvq_theta (src/pvq_encoder.c:631) call. */
+void od_pvq_synthesis_partial_hip(od_coeff *xcoeff, const od_coeff *ypulse, const int16_t *r16, int n, int noref,
+ int32_t g, int32_t theta, int m, int s, const int16_t *qm_inv);
 
 /* ------------------------------------------------------------------------ */
 /* (2) Batched device-pointer API                                            */

@@ -582,6 +582,23 @@ int od_pvq_encode(void *enc, od_coeff *ref, const od_coeff *in, od_coeff *out, i
    speed);
 }
 
+/* od_pvq_synthesis_partial (src/pvq.h:164): called per band by the decoder's pvq_decode_partition
+   (src/pvq_decoder.c:87) and by pvq_theta (src/pvq_encoder.c:631). */
+long odhip_glue_synth_calls;      /* calls bound to the GPU so far */
+void od_pvq_synthesis_partial(od_coeff *xcoeff, const od_coeff *ypulse, const int16_t *r16, int n, int noref,
+ int32_t g, int32_t theta, int m, int s, const int16_t *qm_inv) {
+  typedef void (*fn)(od_coeff *, const od_coeff *, const int16_t *, int, int, int32_t, int32_t, int, int,
+   const int16_t *);
+  static fn next;
+  if (!cfg()->bind_synthesis) {
+    if (!next) next = NEXT(fn, "od_pvq_synthesis_partial");
+    next(xcoeff, ypulse, r16, n, noref, g, theta, m, s, qm_inv);
+    return;
+  }
+  __atomic_add_fetch(&odhip_glue_synth_calls, 1, __ATOMIC_RELAXED);
+  od_pvq_synthesis_partial_hip(xcoeff, ypulse, r16, n, noref, g, theta, m, s, qm_inv);
+}
+
 /* pvq_theta (src/pvq_encoder.c:333-641; file-static in the reference, an ordinary
    symbol of the test build).  This is the glue INTEGRATION.md section 7 puts at the
    top of that function: a keyframe luma band whose reference vector is null takes

@@ -25,6 +25,8 @@ void odhip_glue_startup_config(odhip_glue_config *c) {
   const int pass = env_on("ODHIP_INTERPOSE_PASSTHROUGH");
   c->bind_filters = c->bind_search = c->bind_dering = !pass;
   c->bind_dct_vtbl = env_on("ODHIP_INTERPOSE_VTBL");
+  /* ODHIP_INTERPOSE_SYNTHESIS=1: od_pvq_synthesis_partial per call on the GPU (encoder and decoder) */
+  c->bind_synthesis = env_on("ODHIP_INTERPOSE_SYNTHESIS");
   c->dering_cache = env_on("ODHIP_INTERPOSE_DERING_CACHE");
   c->check_rates = getenv("ODHIP_RATE_CHECK") != NULL;
   c->check_dering = getenv("ODHIP_DERING_CHECK") != NULL;

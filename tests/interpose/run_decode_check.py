@@ -24,10 +24,15 @@ dering = os.environ.get("DERING_CACHE") == "1"
 if dering:
     os.environ["ODHIP_INTERPOSE_DERING_CACHE"] = "1"
     os.environ["ODHIP_DERING_CHECK"] = "1"
+# SYNTHESIS=1: every od_pvq_synthesis_partial call of the encoder and the decoder (od_pvq_decode's
+# pvq_decode_partition, src/pvq_decoder.c:87) on the GPU, one band per call
+synthesis = os.environ.get("SYNTHESIS") == "1"
+if synthesis:
+    os.environ["ODHIP_INTERPOSE_SYNTHESIS"] = "1"
 os.environ["ODHIP_INTERPOSE_PASSTHROUGH"] = "1"
 hip = ctypes.CDLL(os.path.join(ROOT, "daala_amd", "lib", "libdaalahip.so"), mode=ctypes.RTLD_GLOBAL)
 ipo = None
-if check or dering:
+if check or dering or synthesis:
     assert hip.odhip_init(0) == 0
     ipo = ctypes.CDLL(os.path.join(ROOT, "tests", "interpose", "libinterpose.so"), mode=ctypes.RTLD_GLOBAL)
 r = ctypes.CDLL(os.path.join(ROOT, "oracle", "_ref", "libdaalaref.so"))
@@ -59,5 +64,8 @@ if dering:
     ipo.odhip_interpose_dering_stats()
     arr = (ctypes.c_long * 2).in_dll(ipo, "odhip_interposed_dering")
     dstats = [arr[0], arr[1]]
-print(json.dumps({"decoded": hashlib.sha256(decoded.tobytes()).hexdigest(), "check": stats, "dering": dstats,
+nsynth = 0
+if synthesis:
+    nsynth = ctypes.c_long.in_dll(ipo, "odhip_glue_synth_calls").value
+print(json.dumps({"synthesis_calls": nsynth, "decoded": hashlib.sha256(decoded.tobytes()).hexdigest(), "check": stats, "dering": dstats,
                   "mean_abs_error_vs_source": err}))

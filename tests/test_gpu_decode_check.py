@@ -61,3 +61,21 @@ def test_decoder_dering_from_batched_passes():
         assert res["decoded"] == plain["decoded"], (w, h)
         launches, served = res["dering"]
         assert served > 0 and 0 < launches < served, res["dering"]
+
+
+@pytest.mark.skipif(not HAVE_REF, reason="oracle/_ref not present")
+def test_decoder_synthesis_on_the_gpu():
+    """od_pvq_decode's data-parallel half: every od_pvq_synthesis_partial call of the real decoder's
+    pvq_decode_partition (src/pvq_decoder.c:77-89) - and of the encoder's pvq_theta, whose reconstruction
+    the decoder must reproduce (src/pvq_encoder.c:631) - served by od_pvq_synthesis_partial_hip; the bitstream
+    decodes to the same pictures, so every band's synthesis was bit-equal on both sides."""
+    for (w, h, nframes, quality) in ((64, 64, 2, 20), (180, 116, 2, 45)):
+        plain = _run(w, h, nframes, QUALITY=quality, DECODE_CHECK=0)
+        res = _run(w, h, nframes, QUALITY=quality, DECODE_CHECK=0, SYNTHESIS=1)
+        assert res["decoded"] == plain["decoded"], (w, h)
+        assert res["synthesis_calls"] > 100, res
+        # with the GPU reconstruction check on top: decoded coefficients from the GPU synthesis feed
+        # odhip_inverse_partition and the pixels are the decoder's own
+    res = _run(64, 64, 2, QUALITY=20, SYNTHESIS=1)
+    planes, pixels, bad = res["check"]
+    assert planes == 6 and bad == 0 and res["synthesis_calls"] > 100, res
