@@ -48,7 +48,8 @@ class GlueConfig(ctypes.Structure):
     """odhip_glue_config, shim/daala_hip_glue.h."""
     _fields_ = [(n, ctypes.c_int) for n in (
         "device", "bind_filters", "bind_search", "bind_dering", "bind_dct_vtbl", "frame_cache", "band_cache",
-        "dering_cache", "pic_w", "pic_h", "check_rates", "check_dering", "gpu_pass_lock", "dist_cache", "check_dist")]
+        "dering_cache", "pic_w", "pic_h", "check_rates", "check_dering", "gpu_pass_lock", "dist_cache", "check_dist",
+        "bind_synthesis")]
 
 
 class GlueStats(ctypes.Structure):

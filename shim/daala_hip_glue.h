@@ -26,9 +26,6 @@ typedef struct odhip_glue_config {
   int bind_filters;      /* od_prefilter_split, od_postfilter_split, od_apply_{pre,post}filter_frame_sbs */
   int bind_search;       /* pvq_search_rdo_double */
   int bind_dering;       /* od_dering (per call) */
-  int bind_synthesis;    /* od_pvq_synthesis_partial (per call; encoder AND decoder: the data-parallel half of
-                            od_pvq_decode's pvq_decode_partition) - off in the default configuration: one round
-                            trip per coded band */
   int bind_dct_vtbl;     /* od_state_opt_vtbl_init: fdct_2d / idct_2d <- od_bin_{f,i}dctNxN_hip */
   /* Batched bindings. */
   int frame_cache;       /* one batched pyramid per plane behind every fdct_2d call of a frame */
@@ -51,6 +48,10 @@ typedef struct odhip_glue_config {
      (oracle/Makefile DISTGLUE; README.md); without them nothing is served and nothing changes. */
   int dist_cache;
   int check_dist;        /* every served distortion against the C function (abort on a difference) */
+  /* (round 6; appended so that hosts built against the earlier layout keep their field offsets) */
+  int bind_synthesis;    /* per call: od_pvq_synthesis_partial (encoder AND decoder: the data-parallel half of
+                            od_pvq_decode's pvq_decode_partition) - off in the default configuration: one round
+                            trip per coded band */
 } odhip_glue_config;
 
 /* Called by the reference's od_compute_dist (see dist_cache): 1 and *out when the call is one the

@@ -39,3 +39,18 @@ def test_host_cpu_quota_is_positive_and_bounded():
     import bench
     q = bench.host_cpu_quota()
     assert 1 <= q <= (os.cpu_count() or 1)
+
+
+def test_glue_config_mirror_matches_the_header():
+    """encode_job.GlueConfig is filled by field name and read by the shim by offset: its fields must be the
+    header's, in the header's order (a field inserted in the middle of odhip_glue_config once shifted every
+    batched switch of the encode job)."""
+    import re
+    import encode_job as S
+    src = open(os.path.join(ROOT, "shim", "daala_hip_glue.h")).read()
+    body = src[src.index("typedef struct odhip_glue_config {"):src.index("} odhip_glue_config;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    names = []
+    for decl in re.findall(r"\bint\s+([^;]+);", body):
+        names += [n.strip() for n in decl.split(",")]
+    assert names == [n for n, _ in S.GlueConfig._fields_]
