@@ -3,7 +3,8 @@
 reference (oracle/_ref: padding, forward pyramid, pvq_theta with the closed-form rate on every block of every
 level, inverse): random picture sizes (ragged ones included), quantisers, masking / QM switches, content
 generators with random amplitude and offset, keyframes with and without the chroma-from-luma reference, inter
-frames against a random prediction.  Every reconstructed pixel of every level and gain / theta / K / pulses of
+frames against a random prediction, batches of two or three different pictures per step, full-precision
+references (8 / 10 / 12-bit pictures).  Every reconstructed pixel of every level and gain / theta / K / pulses of
 every band must be equal.  TEST INFRASTRUCTURE (it links the oracle), a longer companion of
 tests/test_gpu_pipeline.py.   usage: parity_soak.py [cases=40] [seed0=0] [max_seconds=0]"""
 import os
@@ -70,31 +71,61 @@ for case in range(seed0, seed0 + cases):
         return [np.ascontiguousarray(np.clip((p.astype(np.float64) - 128)*gain + 128 + off, 0, 255).astype(np.uint8))
                 for p in pl]
 
-    pics = picture(int(rng.randint(0, 50)), int(rng.randint(1, 1 << 20)))
+    # one case in four: full-precision references (8 / 10 / 12-bit pictures, 12-bit planes, the xstride-2 conversions)
+    bits = [8, 10, 12][rng.randint(3)] if rng.rand() < 0.25 else 0
+    # one keyframe case in three: a batch of 2 or 3 DIFFERENT pictures per step (frame i must not see frame j)
+    F = int(rng.randint(2, 4)) if (not inter and not bits and rng.rand() < 0.33) else 1
+
+    def deepen(pl):
+        if bits in (0, 8):
+            return pl
+        return [((p.astype(np.int32) << (bits - 8)) + rng.randint(0, 1 << (bits - 8), size=p.shape)).astype(np.int16)
+                for p in pl]
+
+    frames = [deepen(picture(int(rng.randint(0, 50)), int(rng.randint(1, 1 << 20)))) for _ in range(F)]
+    pics = frames[0]
     pred = None
     if inter:
         # a prediction = the picture itself plus noise and a small shift: correlated, as motion compensation is
         pred = []
         for p in pics:
             q = np.roll(p, (int(rng.randint(-1, 2)), int(rng.randint(-2, 3))), axis=(0, 1)).astype(np.int32)
-            q = q + rng.randint(-6, 7, size=q.shape)
-            pred.append(np.clip(q, 0, 255).astype(np.uint8))
+            q = q + rng.randint(-6, 7, size=q.shape)*(1 << max(0, bits - 8))
+            pred.append(np.clip(q, 0, (1 << (bits or 8)) - 1).astype(p.dtype))
     t0 = time.time()
     want = []
     if inter:
         # (the decision dump of the checker covers keyframes; an inter frame is compared by its pixels)
-        cpu, blocks, _ = C.cpu_frame(qt, pics, pw, ph, inter_pred=pred)
+        cpu, blocks, _ = C.cpu_frame(qt, pics, pw, ph, inter_pred=pred, fpr_bits=bits)
         t_cpu = time.time() - t0
-        gpu, reruns = C.gpu_device_priced(D, qt, pics, pw, ph, inter_pred=pred, steps=3)
+        gpu, reruns = C.gpu_device_priced(D, qt, pics, pw, ph, inter_pred=pred, steps=3, fpr_bits=bits)
+        bad = C.compare_frame(gpu, cpu)
+        badd = []
+    elif bits:
+        cpu, blocks, _ = C.cpu_frame(qt, pics, pw, ph, chroma_cfl=cfl, fpr_bits=bits)
+        t_cpu = time.time() - t0
+        gpu, reruns = C.gpu_device_priced(D, qt, pics, pw, ph, chroma_cfl=cfl, fpr_bits=bits)
+        bad = C.compare_frame(gpu, cpu)
         badd = []
     else:
-        cpu, blocks, _ = C.cpu_frame(qt, pics, pw, ph, chroma_cfl=cfl, decisions=want)
-        t_cpu = time.time() - t0
-        gpu, reruns, dec = C.gpu_device_priced(D, qt, pics, pw, ph, chroma_cfl=cfl, decisions=True)
-        badd = C.compare_decisions(dec, want)
-    bad = C.compare_frame(gpu, cpu)
-    tag = "%dx%d q %d/%d masking %d hvs %d cfl %d %s %s" % (pw, ph, quantizer, base, masking, hvs, cfl,
-                                                         "inter" if inter else "key", gen.__name__)
+        stacked = [np.stack([f[p] for f in frames]) for p in range(3)]
+        gpu, reruns, dec = C.gpu_device_priced(D, qt, stacked, pw, ph, chroma_cfl=cfl, frames=F, decisions=True,
+                                               steps=2 + (F > 1))
+        bad, badd, blocks, t_cpu = [], [], 0, 0.
+        for i in range(F):
+            t0 = time.time()
+            w_i = []
+            cpu, b_i, _ = C.cpu_frame(qt, frames[i], pw, ph, chroma_cfl=cfl, decisions=w_i)
+            t_cpu += time.time() - t0
+            blocks += b_i
+            bad += C.compare_frame(gpu, cpu, frame=i, frames=F)
+            badd += C.compare_decisions(dec, w_i, frame=i, frames=F)
+            want += w_i
+            if i:
+                pixels += sum(int(v.size) for pl in cpu for v in pl)
+    tag = "%dx%d q %d/%d masking %d hvs %d cfl %d %s %s%s%s" % (
+        pw, ph, quantizer, base, masking, hvs, cfl, "inter" if inter else "key", gen.__name__,
+        " fpr%d" % bits if bits else "", " x%d frames" % F if F > 1 else "")
     if bad or badd:
         print("case %d %s: MISMATCH %s %s" % (case, tag, bad[:3], badd[:3]), flush=True)
         sys.exit(1)
@@ -102,7 +133,7 @@ for case in range(seed0, seed0 + cases):
     pixels += sum(int(v.size) for pl in cpu for v in pl)
     bands += sum(int(w[1].shape[0]*w[1].shape[1]) for pl in want for w in pl)
     reruns_total += reruns
-    print("case %3d %-62s equal (%d blocks, reference C %.1f s, host-libm re-decisions %d)" % (case, tag, blocks, t_cpu,
+    print("case %3d %-78s equal (%d blocks, reference C %.1f s, host-libm re-decisions %d)" % (case, tag, blocks, t_cpu,
                                                                                                 reruns), flush=True)
 print("parity soak: %d cases equal, %d reconstructed pixels and %d bands compared, %d host-libm re-decisions, %.0f s"
       % (done, pixels, bands, reruns_total, time.time() - t_start))
