@@ -6,7 +6,7 @@ generators with random amplitude and offset, keyframes with and without the chro
 frames against a random prediction, batches of two or three different pictures per step, full-precision
 references (8 / 10 / 12-bit pictures).  Every reconstructed pixel of every level and gain / theta / K / pulses of
 every band must be equal.  TEST INFRASTRUCTURE (it links the oracle), a longer companion of
-tests/test_gpu_pipeline.py.   usage: parity_soak.py [cases=40] [seed0=0] [max_seconds=0]"""
+tests/test_gpu_pipeline.py.   usage: [SOAK_BIG=1] parity_soak.py [cases=40] [seed0=0] [max_seconds=0]"""
 import os
 import sys
 import time
@@ -34,7 +34,10 @@ for case in range(seed0, seed0 + cases):
         break
     rng = np.random.RandomState(77000 + case)
     # sizes: even, from 16 up to 1080p-ish widths; one in three a multiple of 64
-    if case % 3 == 0:
+    if os.environ.get("SOAK_BIG") == "1":
+        # large pictures: around and up to 1920x1080 (the generators' size)
+        pw, ph = 2*rng.randint(500, 961), 2*rng.randint(300, 541)
+    elif case % 3 == 0:
         pw, ph = 64*rng.randint(1, 12), 64*rng.randint(1, 8)
     else:
         pw, ph = 2*rng.randint(16, 500), 2*rng.randint(16, 300)
