@@ -16,7 +16,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 max_seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 600
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 

@@ -1,4 +1,4 @@
-"""Short slices of the randomised soaks (tools/parity_soak.py, tools/decode_soak.py, tools/encode_soak.py; their long runs
+"""Short slices of the randomised soaks (tests/soak/parity_soak.py, tests/soak/decode_soak.py, tests/soak/encode_soak.py; their long runs
 are recorded in profiles/r6_*_soak.txt): a few dozen random cases each, so that every run of the GPU suite also covers
 picture sizes, quantisers and switches nobody wrote down."""
 import os
@@ -15,7 +15,7 @@ HAVE_REF = os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libdaalaref.so")
 def _tool(name, *args, **env):
     e = dict(os.environ)
     e.update({k: str(v) for k, v in env.items()})
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", name)] + [str(a) for a in args],
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "soak", name)] + [str(a) for a in args],
                        capture_output=True, text=True, timeout=1200, env=e)
     assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-2000:])
     return p.stdout.strip().splitlines()[-1]
