@@ -9,7 +9,7 @@ and passes torch device pointers / streams to it.  PyTorch is plumbing here
 There is NO CPU fallback: importing `daala_amd.api` raises if the HIP library
 has not been built, and every call raises if the library reports an error.
 """
-from .api import (DaalaHipError, lib, lib_path, EXPERIMENTS_LIB, init, fdct2d_batch, idct2d_batch,  # noqa: F401
+from .api import (DaalaHipError, PulseRangeError, pvq_k_range_take, lib, lib_path, EXPERIMENTS_LIB, init, fdct2d_batch, idct2d_batch,  # noqa: F401
                   fdct2d_plane, idct2d_plane, filter_batch, dering_planes, forward_pyramid, inverse_level,
                   pvq_search_batch, pvq_search_row_batch, copy_ceiling, decode_export_sections, export_layout_make, pvq_band_layout, alloc_pvq_cands, unpack_cands, BAND_RECORD,
                   pvq_noref_bands,

@@ -51,9 +51,31 @@ def lib():
     return _LIB
 
 
+ERANGE = -24      # ODHIP_ERANGE: a band needs more pulses than ODHIP_PVQ_MAX_K (include/daala_hip.h)
+
+
+class PulseRangeError(DaalaHipError):
+    """A band's reference candidate has more than 32767 pulses (quantiser too fine for the int16 pulse vectors): the
+    results are NOT the reference's."""
+
+
 def _check(rc, what):
+    if rc == ERANGE:
+        raise PulseRangeError("%s: a band needs more pulses than ODHIP_PVQ_MAX_K = 32767; the results since the last "
+                              "sync are not the reference's" % what)
     if rc != 0:
         raise DaalaHipError("%s failed with code %d" % (what, rc))
+
+
+def pvq_k_range_take():
+    """(no-reference bands, with-reference bands) whose candidate exceeded ODHIP_PVQ_MAX_K since the last call; cleared.
+    Synchronise the stream of the band stage first."""
+    a = ctypes.c_uint()
+    b = ctypes.c_uint()
+    rc = lib().odhip_pvq_k_range_take(ctypes.byref(a), ctypes.byref(b))
+    if rc not in (0, ERANGE):
+        _check(rc, "odhip_pvq_k_range_take")
+    return a.value, b.value
 
 
 def init(device=0):
@@ -1223,6 +1245,11 @@ class Pipe:
 
     def sync(self):
         _check(lib().odhip_pipe_sync(self._p()), "odhip_pipe_sync")
+
+    def k_range(self):
+        """Bands above ODHIP_PVQ_MAX_K counted at this pipe's syncs so far."""
+        lib().odhip_pipe_k_range.restype = ctypes.c_long
+        return int(lib().odhip_pipe_k_range(self._p()))
 
     def stage(self, name, parity=0):
         _check(lib().odhip_pipe_stage(self._p(), PIPE_STAGES.index(name), int(parity)),

@@ -91,6 +91,7 @@ struct odhip_pipe {
   long reruns;                    /* bands re-run with the host's theta so far */
   long price_reruns;              /* priced choices re-decided with the host libm so far */
   double wait_ms;                 /* host time spent waiting for the margin count */
+  long k_range;                   /* bands above ODHIP_PVQ_MAX_K seen at syncs */
   bool record;
   /* odhip_pipe_feed: the pictures of the NEXT step arrive in the back buffers on their
      own stream while the current step computes */
@@ -848,6 +849,7 @@ extern "C" odhip_pipe *odhip_pipe_create(const odhip_pipe_config *cfg) {
   p->reruns = 0;
   p->price_reruns = 0;
   p->wait_ms = 0;
+  p->k_range = 0;
   p->record = false;
   memset(p->rate, 0, sizeof(p->rate));
   memset(p->ev_refs, 0, sizeof(p->ev_refs));
@@ -1059,7 +1061,32 @@ extern "C" int odhip_pipe_sync(odhip_pipe *p) {
     STEP_TRY(export_finish(p));
     ODHIP_TRY(hipStreamSynchronize(p->export_stream));
   }
+  /* bands whose reference candidate has more pulses than the pulse vectors hold (include/daala_hip.h,
+     ODHIP_PVQ_MAX_K): their results are not the reference's - say so */
+  unsigned kr[2] = {0, 0};
+  for (int i = 0; i < 2; i++) {
+    /* the counters belong to the contexts of the two chains */
+    if (i == 1 && p->ctx[1] == p->ctx[0]) break;
+    Current cur(p->ctx[i]);
+    unsigned a = 0;
+    unsigned b = 0;
+    const int rc = odhip_pvq_k_range_take(&a, &b);
+    if (rc != ODHIP_SUCCESS && rc != ODHIP_ERANGE) return rc;
+    kr[0] += a;
+    kr[1] += b;
+  }
+  p->k_range += (long)kr[0] + kr[1];
+  if (kr[0] || kr[1]) {
+    fprintf(stderr, "libdaalahip: %u + %u band(s) need more than %d pulses (quantiser too fine for the int16 pulse "
+     "vectors): the steps since the last odhip_pipe_sync are not the reference's\n", kr[0], kr[1], ODHIP_PVQ_MAX_K);
+    return ODHIP_ERANGE;
+  }
   return ODHIP_SUCCESS;
+}
+
+/* Bands counted by odhip_pvq_k_range_take at this pipe's syncs so far. */
+extern "C" long odhip_pipe_k_range(const odhip_pipe *p) {
+  return p ? p->k_range : 0;
 }
 
 /* The stages one at a time, in order on the luma stream (tests, the priced

@@ -39,6 +39,7 @@
 #include "od_ctx.cuh"
 #include "od_pvq_math.cuh"
 #include "od_occupancy.cuh"
+#include "od_krange.cuh"
 #include "gen/od_scan_tables.h"
 #define OD_RSQ_HUGE
 #include "pvq_search.cuh"
@@ -64,6 +65,7 @@ struct DJob {
   int16_t *x16;            /* [B][len]  QM-scaled band vectors, coding order      */
   unsigned short *keys;    /* [nb][B]   sort key (pulse-count class)              */
   unsigned *ids;           /* [nb][B]   block indices sorted by key               */
+  unsigned *krange;        /* od_krange.cuh: the calling context's counter        */
   long nblocks;
   int nplanes;
   int w;
@@ -97,7 +99,8 @@ struct Items {
   const DJob *jobs;        /* the calling context's device job table [kMaxJobs]   */
   unsigned *sort;          /* its counting-sort arrays: histogram, bin starts and
                               cursors, kMaxItems*kKeyBins words each              */
-  unsigned *pcount;        /* priced choice: bands too close to call on the device */
+  unsigned *pcount;        /* priced choice: bands too close to call on the device; pcount[1]: bands with a
+                              candidate above ODHIP_PVQ_MAX_K (od_krange.cuh), cleared only when taken */
   struct PUnc *plist;      /* ... and their list [kPUncCap]                       */
   double tol_scale;        /* test hook: multiplies the decision margin           */
   int fuse;                /* the search kernels also make the priced choice      */
@@ -218,6 +221,7 @@ struct PrepCtx {
   int q2;
   long split_blk;
   int beta;
+  unsigned *krange;        /* od_krange.cuh: the context's counter (Items::pcount + 1) */
 };
 
 /* The band's quantiser step for block blk. */
@@ -227,6 +231,7 @@ __device__ __forceinline__ int prep_q(const PrepCtx &cx, long blk) {
 
 __device__ __forceinline__ PrepCtx prep_ctx(const DJob &jb, int band, int off, int pad) {
   PrepCtx c;
+  c.krange = jb.krange;
   c.qm = jb.qm + off;
   c.x16 = jb.x16 + off - pad;
   c.rec = jb.rec + band;
@@ -285,6 +290,7 @@ __device__ __forceinline__ BandHead od_band_head(int beta, int n, int32_t cg) {
 
 __device__ __forceinline__ void od_band_candidates(const PrepCtx &cx, int n, long blk, int32_t cg) {
   const BandHead bh = od_band_head(cx.beta, n, cg);
+  if (bh.h1.x & 0x0202) atomicAdd(cx.krange, 1u);
   int4 *out = reinterpret_cast<int4 *>(cx.rec + blk*cx.nb_bands);
   out[0] = bh.h0;
   out[1] = bh.h1;
@@ -849,6 +855,9 @@ __device__ __forceinline__ void od_decide_band(const Items &it, int job, const D
   hd.k[1] = bh.h0.w >> 16;
   hd.flags[0] = live ? bh.h1.x & 0xff : 0;
   hd.flags[1] = live ? bh.h1.x >> 8 & 0xff : 0;
+  /* flags == 2: the reference would search this candidate; its K does not fit (od_krange.cuh).  In group mode
+     every lane of the group holds the same head: the first one counts */
+  if (live && half == 0 && (bh.h1.x & 0x0202)) atomicAdd(jb.krange, 1u);
   if constexpr (!MASK) {
 #pragma unroll
     for (int j = 0; j < NL; j++) pk[j*kWave + lane] = (uint32_t)abs(xs[j]) << 16;
@@ -1835,9 +1844,9 @@ int band_state(BandState **out) {
     ODHIP_TRY(hipMalloc((void **)&st->d_jobs, sizeof(DJob)*kMaxJobs*kTableSlots));
     ODHIP_TRY(hipMalloc((void **)&st->d_sort, sizeof(unsigned)*3*kMaxItems*kKeyBins));
     ODHIP_TRY(hipMemset(st->d_sort, 0, sizeof(unsigned)*3*kMaxItems*kKeyBins));
-    ODHIP_TRY(hipMalloc((void **)&st->d_pcount, sizeof(unsigned)));
+    ODHIP_TRY(hipMalloc((void **)&st->d_pcount, 2*sizeof(unsigned)));
     ODHIP_TRY(hipMalloc((void **)&st->d_plist, sizeof(PUnc)*kPUncCap));
-    ODHIP_TRY(hipMemset(st->d_pcount, 0, sizeof(unsigned)));
+    ODHIP_TRY(hipMemset(st->d_pcount, 0, 2*sizeof(unsigned)));
   }
   st->serial = ctx->serial != 0;
   st->tol_scale = ctx->price_tol_scale > 0 ? ctx->price_tol_scale : 1.;   /* test hook of the context */
@@ -1908,7 +1917,8 @@ int fill_jobs(const odhip_pvq_job *jobs, int njobs, int mode, DJob *host) {
   return ODHIP_SUCCESS;
 }
 
-int upload_jobs(BandState &st, const DJob *host, int njobs, hipStream_t s) {
+int upload_jobs(BandState &st, DJob *host, int njobs, hipStream_t s) {
+  for (int i = 0; i < njobs; i++) host[i].krange = st.d_pcount + 1;
   int lru = 0;
   for (int i = 0; i < kTableSlots; i++) {
     if (st.tab_n[i] == njobs && memcmp(st.host_tab[i], host, sizeof(DJob)*njobs) == 0) {
@@ -2522,4 +2532,17 @@ extern "C" int odhip_pvq_select_synth_noref(od_coeff *d_dq, const od_coeff *d_co
   j.d_rate = d_rate;
   j.d_qg = d_qg_out;
   return odhip_pvq_select_synth_noref_multi(&j, 1, pvq_norm_lambda, stream);
+}
+
+/* od_krange.cuh: the current context's count since the last call, then cleared (blocking copies: the stream of the band
+   stage must have been synchronised) */
+int od_k_range_take_noref(unsigned *count) {
+  BandState *st = nullptr;
+  const int rc = band_state(&st);
+  if (rc) return rc;
+  unsigned v = 0;
+  ODHIP_TRY(hipMemcpy(&v, st->d_pcount + 1, sizeof(v), hipMemcpyDeviceToHost));
+  if (v) ODHIP_TRY(hipMemset(st->d_pcount + 1, 0, sizeof(v)));
+  *count = v;
+  return ODHIP_SUCCESS;
 }

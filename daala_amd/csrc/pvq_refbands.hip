@@ -44,6 +44,7 @@
 #include "od_ctx.cuh"
 #include "od_pvq_math.cuh"
 #include "od_occupancy.cuh"
+#include "od_krange.cuh"
 #include "gen/od_scan_tables.h"
 #define OD_RSQ_TABLE_N 512
 #define OD_RSQ_HUGE
@@ -80,6 +81,7 @@ struct RJob {
   /* library scratch of the sorted searches */
   unsigned short *keys;   /* [nb][B] work class of the band (heavy = small)       */
   unsigned *ids;          /* [nb][B] block indices sorted by key                  */
+  unsigned *krange;       /* od_krange.cuh: the calling context's counter          */
   long nblocks;
   int nplanes;
   int w;
@@ -160,7 +162,8 @@ struct RItems {
   Unc *unc;                /* ... and entries [kUncCap]                            */
   unsigned *rhist;         /* counting sort: histogram (zero between calls) ...    */
   unsigned *rcursor;       /* ... and cursors, kMaxItems*kSortBins words each      */
-  unsigned *pcount;        /* priced choice: bands too close to call on the device */
+  unsigned *pcount;        /* priced choice: bands too close to call on the device; pcount[1]: bands with a
+                              candidate above ODHIP_PVQ_MAX_K (od_krange.cuh), cleared only when taken */
   struct PUncR *plist;     /* ... and their list [kPUncCap]                        */
   double tol_scale;        /* test hook: multiplies the decision margin            */
   int fuse;                /* the per-lane searches also make the priced choice    */
@@ -423,6 +426,9 @@ __device__ __forceinline__ void prep_write(const RItems &it, odhip_pvq_refband *
     KeySink ks;
     refb_enumerate(jb, band, o.cg, o.gain_offset, o.theta, flags, o.corr, ks);
     jb.keys[(long)band*jb.nblocks + blk] = (unsigned short)(kSortBins - 1 - od_work_bin(ks.work(it.reserved1)));
+    /* a candidate of this band's list has more pulses than the pulse vectors hold: the searches skip it
+       (conservative: counted even when the reference's own pruning test would have dropped it) */
+    if (ks.kt > ODHIP_PVQ_MAX_K || ks.kn > ODHIP_PVQ_MAX_K) atomicAdd(jb.krange, 1u);
   }
 }
 
@@ -1120,6 +1126,7 @@ __device__ __forceinline__ void refb_loops(const RJob &jb, int band, long blk, b
         /* pulses are stored as int16: reported, never searched or chosen (the
            candidates are sorted by K, so every later one is skipped as well) */
         if (writer) {
+          atomicAdd(jb.krange, 1u);
           ip.tail[idx*ip.stride] = make_int4(qcg, qtheta, ODHIP_REFITEM_WITH_REF | ODHIP_REFITEM_K_RANGE,
            -1);
         }
@@ -1166,6 +1173,7 @@ __device__ __forceinline__ void refb_loops(const RJob &jb, int band, long blk, b
         continue;
       }
       if (k > ODHIP_PVQ_MAX_K) {
+        if (writer) atomicAdd(jb.krange, 1u);
         if (writer) ip.tail[idx*ip.stride] = make_int4(qcg, 0, ODHIP_REFITEM_K_RANGE, -1);
         continue;
       }
@@ -2802,11 +2810,12 @@ int ref_state(RefState **out) {
   RefState *st = odhip_ctx_state<RefState>(ctx, ODHIP_SLOT_REFBANDS);
   if (!st->d_jobs) {
     ODHIP_TRY(hipMalloc((void **)&st->d_jobs, sizeof(RJob)*kMaxJobs*kTableSlots));
-    /* the two counters are adjacent (unc_count, pcount): one clear per band stage */
-    ODHIP_TRY(hipMalloc((void **)&st->d_unc_count, 2*sizeof(unsigned)));
+    /* the two counters are adjacent (unc_count, pcount): one clear per band stage; the third word counts the
+       bands above ODHIP_PVQ_MAX_K and is cleared only by od_k_range_take_ref */
+    ODHIP_TRY(hipMalloc((void **)&st->d_unc_count, 3*sizeof(unsigned)));
     ODHIP_TRY(hipMalloc((void **)&st->d_unc, sizeof(Unc)*kUncCap));
     ODHIP_TRY(hipMalloc((void **)&st->d_sort, sizeof(unsigned)*2*kMaxItems*kSortBins));
-    ODHIP_TRY(hipMemset(st->d_unc_count, 0, 2*sizeof(unsigned)));
+    ODHIP_TRY(hipMemset(st->d_unc_count, 0, 3*sizeof(unsigned)));
     st->d_pcount = st->d_unc_count + 1;
     ODHIP_TRY(hipMalloc((void **)&st->d_plist, sizeof(PUncR)*kPUncCap));
     ODHIP_TRY(hipMemset(st->d_pcount, 0, sizeof(unsigned)));
@@ -2837,6 +2846,7 @@ int stage_jobs(RefState &st, const odhip_pvq_refjob *jobs, int njobs, int mode, 
   for (int i = 0; i < njobs; i++) {
     rc = fill_job(host[i], jobs[i], mode);
     if (rc) return rc;
+    host[i].krange = st.d_pcount + 1;
     pairs += (size_t)host[i].nblocks*host[i].nb_bands;
   }
   if (mode == 0) {
@@ -3558,3 +3568,26 @@ extern "C" int odhip_pvq_ref_choose_priced_resolve(const odhip_pvq_refjob *jobs,
   return rc ? rc : (int)count;
 }
 
+/* od_krange.cuh */
+int od_k_range_take_ref(unsigned *count) {
+  RefState *st = nullptr;
+  const int rc = ref_state(&st);
+  if (rc) return rc;
+  unsigned v = 0;
+  ODHIP_TRY(hipMemcpy(&v, st->d_pcount + 1, sizeof(v), hipMemcpyDeviceToHost));
+  if (v) ODHIP_TRY(hipMemset(st->d_pcount + 1, 0, sizeof(v)));
+  *count = v;
+  return ODHIP_SUCCESS;
+}
+
+extern "C" int odhip_pvq_k_range_take(unsigned *noref_bands, unsigned *ref_bands) {
+  unsigned a = 0;
+  unsigned b = 0;
+  const int rc = od_k_range_take_noref(&a);
+  if (rc) return rc;
+  const int rc2 = od_k_range_take_ref(&b);
+  if (rc2) return rc2;
+  if (noref_bands) *noref_bands = a;
+  if (ref_bands) *ref_bands = b;
+  return a || b ? ODHIP_ERANGE : ODHIP_SUCCESS;
+}

@@ -36,6 +36,7 @@ typedef int32_t od_coeff;
 #define ODHIP_EFAULT (-1)   /* OD_EFAULT: HIP runtime failure / bad pointer */
 #define ODHIP_EINVAL (-10)  /* OD_EINVAL: bad argument */
 #define ODHIP_EIMPL (-23)   /* OD_EIMPL: not implemented */
+#define ODHIP_ERANGE (-24)  /* a band needs more pulses than ODHIP_PVQ_MAX_K: odhip_pvq_k_range_take */
 
 #define ODHIP_NBSIZES 5     /* OD_NBSIZES: 4,8,16,32,64 (src/internal.h:53-59) */
 
@@ -323,6 +324,14 @@ int odhip_pvq_search_row_batch(const int16_t *d_x, int n, const int32_t *d_k, od
    Block index: blk = (plane*(h/N) + by)*(w/N) + bx; B = number of blocks. */
 #define ODHIP_MAX_BANDS 12
 #define ODHIP_PVQ_MAX_K 32767
+/* The reference's pulse count K is an int (od_pvq_compute_k, src/pvq.c:436-470); the pulse vectors here are int16.  A
+   candidate the reference SEARCHES with K above ODHIP_PVQ_MAX_K - seen only below encoder_example's quantiser range, on
+   saturated content in 64x64 blocks - is never searched or chosen by the band stages, so the band would differ from the
+   reference's.  Every such band is counted on the device, per context (with-reference bands conservatively: before the
+   reference's pruning test).  odhip_pvq_k_range_take: the current context's counts since the last call, cleared; returns
+   ODHIP_ERANGE when either is non-zero (blocking copies; call it after the stream of the band stage has been synchronised).
+   odhip_pipe_sync calls it and returns ODHIP_ERANGE: the results of the steps since the last sync are NOT the reference's. */
+int odhip_pvq_k_range_take(unsigned *noref_bands, unsigned *ref_bands);
 /* One record per (block, band), 64 bytes, 64-byte aligned: both halves are
    whole 32-byte HBM sectors and are written by different kernels (the first by
    the preparation pass, the second by the search). */
@@ -1239,7 +1248,9 @@ int odhip_pipe_set_reference_pictures(odhip_pipe *p, const uint8_t *luma, const 
  int on_device);
 int odhip_pipe_step(odhip_pipe *p);
 int odhip_pipe_flush(odhip_pipe *p);
-int odhip_pipe_sync(odhip_pipe *p);
+int odhip_pipe_sync(odhip_pipe *p);       /* ODHIP_ERANGE: see ODHIP_PVQ_MAX_K - the steps since the last sync coded
+                                             a band otherwise than the reference would */
+long odhip_pipe_k_range(const odhip_pipe *p);      /* such bands over this pipe's syncs so far */
 int odhip_pipe_stage(odhip_pipe *p, int stage, int parity);
 /* parity: with chroma from luma the luma pulse vectors / choice records alternate between
    two sets from step to step (the chroma chain of step i reads them while the luma chain of

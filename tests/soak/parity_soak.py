@@ -29,6 +29,7 @@ done = 0
 pixels = 0
 bands = 0
 reruns_total = 0
+refused = 0
 for case in range(seed0, seed0 + cases):
     if max_seconds and time.time() - t_start > max_seconds:
         break
@@ -97,35 +98,42 @@ for case in range(seed0, seed0 + cases):
             pred.append(np.clip(q, 0, (1 << (bits or 8)) - 1).astype(p.dtype))
     t0 = time.time()
     want = []
-    if inter:
-        # (the decision dump of the checker covers keyframes; an inter frame is compared by its pixels)
-        cpu, blocks, _ = C.cpu_frame(qt, pics, pw, ph, inter_pred=pred, fpr_bits=bits)
-        t_cpu = time.time() - t0
-        gpu, reruns = C.gpu_device_priced(D, qt, pics, pw, ph, inter_pred=pred, steps=3, fpr_bits=bits)
-        bad = C.compare_frame(gpu, cpu)
-        badd = []
-    elif bits:
-        cpu, blocks, _ = C.cpu_frame(qt, pics, pw, ph, chroma_cfl=cfl, fpr_bits=bits)
-        t_cpu = time.time() - t0
-        gpu, reruns = C.gpu_device_priced(D, qt, pics, pw, ph, chroma_cfl=cfl, fpr_bits=bits)
-        bad = C.compare_frame(gpu, cpu)
-        badd = []
-    else:
-        stacked = [np.stack([f[p] for f in frames]) for p in range(3)]
-        gpu, reruns, dec = C.gpu_device_priced(D, qt, stacked, pw, ph, chroma_cfl=cfl, frames=F, decisions=True,
-                                               steps=2 + (F > 1))
-        bad, badd, blocks, t_cpu = [], [], 0, 0.
-        for i in range(F):
-            t0 = time.time()
-            w_i = []
-            cpu, b_i, _ = C.cpu_frame(qt, frames[i], pw, ph, chroma_cfl=cfl, decisions=w_i)
-            t_cpu += time.time() - t0
-            blocks += b_i
-            bad += C.compare_frame(gpu, cpu, frame=i, frames=F)
-            badd += C.compare_decisions(dec, w_i, frame=i, frames=F)
-            want += w_i
-            if i:
-                pixels += sum(int(v.size) for pl in cpu for v in pl)
+    try:
+        if inter:
+            # (the decision dump of the checker covers keyframes; an inter frame is compared by its pixels)
+            cpu, blocks, _ = C.cpu_frame(qt, pics, pw, ph, inter_pred=pred, fpr_bits=bits)
+            t_cpu = time.time() - t0
+            gpu, reruns = C.gpu_device_priced(D, qt, pics, pw, ph, inter_pred=pred, steps=3, fpr_bits=bits)
+            bad = C.compare_frame(gpu, cpu)
+            badd = []
+        elif bits:
+            cpu, blocks, _ = C.cpu_frame(qt, pics, pw, ph, chroma_cfl=cfl, fpr_bits=bits)
+            t_cpu = time.time() - t0
+            gpu, reruns = C.gpu_device_priced(D, qt, pics, pw, ph, chroma_cfl=cfl, fpr_bits=bits)
+            bad = C.compare_frame(gpu, cpu)
+            badd = []
+        else:
+            stacked = [np.stack([f[p] for f in frames]) for p in range(3)]
+            gpu, reruns, dec = C.gpu_device_priced(D, qt, stacked, pw, ph, chroma_cfl=cfl, frames=F, decisions=True,
+                                                   steps=2 + (F > 1))
+            bad, badd, blocks, t_cpu = [], [], 0, 0.
+            for i in range(F):
+                t0 = time.time()
+                w_i = []
+                cpu, b_i, _ = C.cpu_frame(qt, frames[i], pw, ph, chroma_cfl=cfl, decisions=w_i)
+                t_cpu += time.time() - t0
+                blocks += b_i
+                bad += C.compare_frame(gpu, cpu, frame=i, frames=F)
+                badd += C.compare_decisions(dec, w_i, frame=i, frames=F)
+                want += w_i
+                if i:
+                    pixels += sum(int(v.size) for pl in cpu for v in pl)
+    except D.PulseRangeError:
+        # a band needs more than 32767 pulses (ODHIP_PVQ_MAX_K): the library refuses loudly instead of differing
+        refused += 1
+        print("case %3d %dx%d q %d/%d: refused - a pulse count above 32767 (reported by odhip_pipe_sync)"
+              % (case, pw, ph, quantizer, base), flush=True)
+        continue
     tag = "%dx%d q %d/%d masking %d hvs %d cfl %d %s %s%s%s" % (
         pw, ph, quantizer, base, masking, hvs, cfl, "inter" if inter else "key", gen.__name__,
         " fpr%d" % bits if bits else "", " x%d frames" % F if F > 1 else "")
@@ -138,5 +146,5 @@ for case in range(seed0, seed0 + cases):
     reruns_total += reruns
     print("case %3d %-78s equal (%d blocks, reference C %.1f s, host-libm re-decisions %d)" % (case, tag, blocks, t_cpu,
                                                                                                 reruns), flush=True)
-print("parity soak: %d cases equal, %d reconstructed pixels and %d bands compared, %d host-libm re-decisions, %.0f s"
-      % (done, pixels, bands, reruns_total, time.time() - t_start))
+print("parity soak: %d cases equal, %d reconstructed pixels and %d bands compared, %d host-libm re-decisions, %d refused "
+      "(pulse count above 32767), %.0f s" % (done, pixels, bands, reruns_total, refused, time.time() - t_start))

@@ -560,3 +560,37 @@ def test_export_follows_a_late_resolve():
     finally:
         D.pvq_ref_set_theta_margin(0, False)
         D.set_price_tol_scale(1.)
+
+
+def test_pulse_count_above_int16_is_reported_not_silently_different():
+    """The reference's pulse count K is an int; the pulse vectors here are int16 (ODHIP_PVQ_MAX_K = 32767).  Found by
+    tests/soak/parity_soak.py: at a coded quantiser of 8 (below encoder_example's range), flat matrices, no masking, a
+    saturated edge inside a 64x64 block asks for K > 35 000 in band 0; such a candidate is not searched here, so the
+    band would differ from the reference's.  It must not differ SILENTLY: the device counts every such band and
+    odhip_pipe_sync returns ODHIP_ERANGE (PulseRangeError)."""
+    import daala_amd as D
+    D.init(0)
+    D.pvq_k_range_take()                                   # (clear whatever an earlier test left)
+    pw, ph = 128, 128
+    luma = np.zeros((1, ph, pw), np.uint8)
+    luma[:, :, 32:64] = 255                                # a saturated step inside every 64x64 block
+    luma[:, :, 96:128] = 255
+    chroma = np.full((2, ph // 2, pw // 2), 128, np.uint8)
+    for (base, quantizer, expect) in ((16, 8, True), (320, 243, False)):
+        qt = D.QuantTables(base, quantizer, 0, 0)
+        pipe = D.Pipe(qt, 1, pw, ph, chroma_cfl=True, price=True)
+        try:
+            pipe.set_pictures(luma, chroma)
+            pipe.step()
+            pipe.flush()
+            if expect:
+                with pytest.raises(D.PulseRangeError):
+                    pipe.sync()
+                assert pipe.k_range() > 0
+                pipe.sync()                                # reported once: the counters were taken
+            else:
+                pipe.sync()
+                assert pipe.k_range() == 0
+        finally:
+            pipe.destroy()
+    assert D.pvq_k_range_take() == (0, 0)
